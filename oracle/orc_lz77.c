@@ -1,0 +1,743 @@
+/* oracle/orc_lz77.c -- CPU restatement of the LZ77 half of rust-brotli's encoder hot path.
+ * TEST INFRASTRUCTURE ONLY (see brotli_oracle.h).
+ *
+ * Follows, function by function:
+ *   src/enc/backward_references/mod.rs  (H9 :598-917, AdvHasher H5/H5q5/H6 :919-1813,
+ *       scoring :1151-1154,1871-1889, static dictionary probe :1891-1988,
+ *       CreateBackwardReferences :2376-2552)
+ *   src/enc/static_dict.rs:125-147      (FindMatchLengthWithLimit[Min4])
+ *   src/enc/command.rs                  (distance code, length codes, Command::init)
+ *   src/enc/encode.rs:834-893,1118-1194 (ChooseHasher, HasherReset, hasher_setup, dictionary prepend)
+ */
+#include "orc_internal.h"
+
+#define BROTLI_TABLE_QUAL
+#include "../tables/brotli_tables.h"
+
+/* ------------------------------------------------------------------ tables */
+const float* orc_logs_16(void) { return (const float*)(const void*)kBrotliLog2Table16_bits; }
+const float* orc_logs_8(void) { return (const float*)(const void*)kBrotliLog2Table8_bits; }
+const uint16_t* orc_static_dictionary_hash(void) { return kBrotliStaticDictionaryHash; }
+const uint8_t* orc_dictionary_data(void) { return kBrotliDictionaryData; }
+const uint32_t* orc_dictionary_offsets_by_length(void) { return kBrotliDictionaryOffsetsByLength; }
+const uint8_t* orc_dictionary_size_bits_by_length(void) { return kBrotliDictionarySizeBitsByLength; }
+const uint32_t* orc_ins_base(void) { return kBrotliInsBase; }
+const uint32_t* orc_ins_extra(void) { return kBrotliInsExtra; }
+const uint32_t* orc_copy_base(void) { return kBrotliCopyBase; }
+const uint32_t* orc_copy_extra(void) { return kBrotliCopyExtra; }
+const uint8_t* orc_utf8_context_lookup(void) { return kBrotliUTF8ContextLookup; }
+const uint8_t* orc_signed3_context_lookup(void) { return kBrotliSigned3BitContextLookup; }
+
+/* ------------------------------------------------------------------ loads */
+static inline uint32_t load32(const uint8_t* p) {
+  uint32_t v;
+  memcpy(&v, p, 4);
+  return v;
+}
+static inline uint64_t load64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v;
+}
+
+static const uint32_t kHashMul32 = 0x1e35a7bdu;
+static const uint64_t kHashMul64Long = 0x1fe35a7bd3579bd3ull;
+
+/* static_dict.rs:125-132 */
+static size_t find_match_length_with_limit(const uint8_t* s1, const uint8_t* s2, size_t limit) {
+  size_t i = 0;
+  while (i + 8 <= limit) {
+    uint64_t a = load64(s1 + i), b = load64(s2 + i);
+    if (a != b) return i + ((size_t)__builtin_ctzll(a ^ b) >> 3);
+    i += 8;
+  }
+  while (i < limit) {
+    if (s1[i] != s2[i]) return i;
+    ++i;
+  }
+  return limit;
+}
+
+/* static_dict.rs:134-147 */
+static size_t find_match_length_with_limit_min4(const uint8_t* s1, const uint8_t* s2, size_t limit) {
+  if (load32(s1) != load32(s2)) return 0;
+  if (limit <= 4 || s1[4] != s2[4]) return ORC_MIN(limit, (size_t)4);
+  return find_match_length_with_limit(s1 + 5, s2 + 5, limit - 5) + 5;
+}
+
+/* mod.rs:42-54 */
+static size_t fix_unbroken_len(size_t unbroken_len, size_t prev_ix, size_t ring_buffer_break) {
+  if (ring_buffer_break != 0) {
+    if (prev_ix < ring_buffer_break && prev_ix + unbroken_len > ring_buffer_break)
+      return ring_buffer_break - prev_ix;
+  }
+  return unbroken_len;
+}
+
+/* ------------------------------------------------------------------ command.rs */
+/* command.rs:48-68 */
+static size_t compute_distance_code(size_t distance, size_t max_distance, const int32_t* dist_cache) {
+  if (distance <= max_distance) {
+    size_t distance_plus_3 = distance + 3;
+    size_t offset0 = distance_plus_3 - (size_t)(int64_t)dist_cache[0];
+    size_t offset1 = distance_plus_3 - (size_t)(int64_t)dist_cache[1];
+    if (distance == (size_t)(int64_t)dist_cache[0]) {
+      return 0;
+    } else if (distance == (size_t)(int64_t)dist_cache[1]) {
+      return 1;
+    } else if (offset0 < 7) {
+      return (size_t)((0x09750468 >> (4 * offset0)) & 0xf);
+    } else if (offset1 < 7) {
+      return (size_t)((0x0fdb1ace >> (4 * offset1)) & 0xf);
+    } else if (distance == (size_t)(int64_t)dist_cache[2]) {
+      return 2;
+    } else if (distance == (size_t)(int64_t)dist_cache[3]) {
+      return 3;
+    }
+  }
+  return distance + 16 - 1;
+}
+
+/* command.rs:71-92 */
+uint16_t orc_get_insert_length_code(size_t insertlen) {
+  if (insertlen < 6) {
+    return (uint16_t)insertlen;
+  } else if (insertlen < 130) {
+    uint32_t nbits = orc_log2_floor_nonzero(insertlen - 2) - 1u;
+    return (uint16_t)((nbits << 1) + ((insertlen - 2) >> nbits) + 2);
+  } else if (insertlen < 2114) {
+    return (uint16_t)(orc_log2_floor_nonzero(insertlen - 66) + 10);
+  } else if (insertlen < 6210) {
+    return 21;
+  } else if (insertlen < 22594) {
+    return 22;
+  } else {
+    return 23;
+  }
+}
+
+/* command.rs:94-108 */
+uint16_t orc_get_copy_length_code(size_t copylen) {
+  if (copylen < 10) {
+    return (uint16_t)(copylen - 2);
+  } else if (copylen < 134) {
+    uint32_t nbits = orc_log2_floor_nonzero(copylen - 6) - 1u;
+    return (uint16_t)((nbits << 1) + ((copylen - 6) >> nbits) + 4);
+  } else if (copylen < 2118) {
+    return (uint16_t)(orc_log2_floor_nonzero(copylen - 70) + 12);
+  } else {
+    return 23;
+  }
+}
+
+/* command.rs:110-125 */
+static uint16_t combine_length_codes(uint16_t inscode, uint16_t copycode, int use_last_distance) {
+  uint16_t bits64 = (uint16_t)((copycode & 0x7u) | ((inscode & 0x7u) << 3));
+  if (use_last_distance && inscode < 8 && copycode < 16) {
+    return (copycode < 8) ? bits64 : (uint16_t)(bits64 | 64);
+  } else {
+    int sub_offset = 2 * ((copycode >> 3) + 3 * (inscode >> 3));
+    int offset = (sub_offset << 5) + 0x40 + ((0x520d40 >> sub_offset) & 0xc0);
+    return (uint16_t)((uint16_t)offset | bits64);
+  }
+}
+
+void orc_get_length_code(size_t insertlen, size_t copylen, int use_last_distance, uint16_t* code) {
+  *code = combine_length_codes(orc_get_insert_length_code(insertlen), orc_get_copy_length_code(copylen),
+                               use_last_distance);
+}
+
+/* command.rs:134-173 */
+static void prefix_encode_copy_distance(size_t distance_code, size_t num_direct_codes, uint64_t postfix_bits,
+                                        uint16_t* code, uint32_t* extra_bits) {
+  if (distance_code < 16 + num_direct_codes) {
+    *code = (uint16_t)distance_code;
+    *extra_bits = 0;
+  } else {
+    uint64_t dist = (1ull << (postfix_bits + 2)) + ((uint64_t)distance_code - 16 - (uint64_t)num_direct_codes);
+    uint64_t bucket = (uint64_t)orc_log2_floor_nonzero(dist) - 1;
+    uint64_t postfix_mask = (1u << postfix_bits) - 1;
+    uint64_t postfix = dist & postfix_mask;
+    uint64_t prefix = (dist >> bucket) & 1;
+    uint64_t offset = (2 + prefix) << bucket;
+    uint64_t nbits = bucket - postfix_bits;
+    *code = (uint16_t)((nbits << 10) |
+                       (16 + (uint64_t)num_direct_codes + ((2 * (nbits - 1) + prefix) << postfix_bits) + postfix));
+    *extra_bits = (uint32_t)((dist - offset) >> postfix_bits);
+  }
+}
+
+/* command.rs:273-297 */
+void orc_command_init(Command* self, const DistanceParams* dist, size_t insertlen, size_t copylen,
+                      size_t copylen_code, size_t distance_code) {
+  self->insert_len_ = (uint32_t)insertlen;
+  int8_t delta = (int8_t)((int32_t)copylen_code - (int32_t)copylen);
+  self->copy_len_ = (uint32_t)copylen | ((uint32_t)(uint8_t)delta << 25);
+  prefix_encode_copy_distance(distance_code, dist->num_direct_distance_codes, dist->distance_postfix_bits,
+                              &self->dist_prefix_, &self->dist_extra_);
+  orc_get_length_code(insertlen, copylen_code, (self->dist_prefix_ & 0x3ff) == 0, &self->cmd_prefix_);
+}
+
+/* command.rs:38-44 */
+void orc_command_init_insert(Command* self, size_t insertlen) {
+  self->insert_len_ = (uint32_t)insertlen;
+  self->copy_len_ = (uint32_t)(4 << 25);
+  self->dist_extra_ = 0;
+  self->dist_prefix_ = (uint16_t)((1u << 10) | 16u);
+  orc_get_length_code(insertlen, 4, 0, &self->cmd_prefix_);
+}
+
+/* command.rs:176-201 */
+uint32_t orc_command_restore_distance_code(const Command* self, const DistanceParams* dist) {
+  if ((int)(self->dist_prefix_ & 0x3ff) < 16 + (int)dist->num_direct_distance_codes) {
+    return (uint32_t)self->dist_prefix_ & 0x3ff;
+  } else {
+    uint32_t dcode = (uint32_t)self->dist_prefix_ & 0x3ff;
+    uint32_t nbits = (uint32_t)(self->dist_prefix_ >> 10);
+    uint32_t extra = self->dist_extra_;
+    uint32_t postfix_mask = (1u << dist->distance_postfix_bits) - 1;
+    uint32_t hcode = (dcode - dist->num_direct_distance_codes - 16u) >> dist->distance_postfix_bits;
+    uint32_t lcode = (dcode - dist->num_direct_distance_codes - 16u) & postfix_mask;
+    uint32_t offset = ((2u + (hcode & 1)) << nbits) - 4u;
+    return ((offset + extra) << dist->distance_postfix_bits) + lcode + dist->num_direct_distance_codes + 16u;
+  }
+}
+
+/* brotli_bit_stream.rs:1923-1929 */
+uint32_t orc_command_copy_len_code(const Command* c) {
+  uint32_t modifier = c->copy_len_ >> 25;
+  int32_t delta = (int32_t)(int8_t)(uint8_t)(modifier | ((modifier & 0x40) << 1));
+  return (uint32_t)((int32_t)(c->copy_len_ & 0x01ffffffu) + delta);
+}
+
+/* ------------------------------------------------------------------ hasher lifecycle */
+void orc_hasher_free(Hasher* h) {
+  free(h->num);
+  free(h->buckets);
+  memset(h, 0, sizeof(*h));
+}
+
+/* encode.rs:834-893 */
+void orc_choose_hasher(EncoderParams* params) {
+  HasherParams* hp = &params->hasher;
+  if (params->quality >= 10 && !params->q9_5) {
+    hp->type_ = 10;
+  } else if (params->quality == 10 || params->quality == 9) {
+    hp->type_ = 9;
+    hp->num_last_distances_to_check = 16;
+    hp->block_bits = 8;
+    hp->bucket_bits = 15;
+    hp->hash_len = 4;
+  } else if (params->quality == 4 && params->size_hint >= (1u << 20)) {
+    hp->type_ = 54;
+  } else if (params->quality < 5) {
+    hp->type_ = params->quality;
+  } else if (params->lgwin <= 16) {
+    hp->type_ = params->quality < 7 ? 40 : (params->quality < 9 ? 41 : 42);
+  } else if (((params->q9_5 && params->size_hint > (1u << 20)) || params->size_hint > (1u << 22)) &&
+             params->lgwin >= 19) {
+    hp->type_ = 6;
+    hp->block_bits = ORC_MIN(params->quality - 1, 9);
+    hp->bucket_bits = 15;
+    hp->hash_len = 5;
+    hp->num_last_distances_to_check = params->quality < 7 ? 4 : (params->quality < 9 ? 10 : 16);
+  } else {
+    hp->type_ = 5;
+    hp->block_bits = ORC_MIN(params->quality - 1, 9);
+    hp->bucket_bits = (params->quality < 7 && params->size_hint <= (1u << 20)) ? 14 : 15;
+    hp->num_last_distances_to_check = params->quality < 7 ? 4 : (params->quality < 9 ? 10 : 16);
+  }
+}
+
+/* encode.rs:968-1117 (InitializeH5/H6/H9, BrotliMakeHasher). Types 40/41/42 are not implemented by
+   the reference and fall back to InitializeH6 with whatever hasher params are current (:1115). */
+static int make_hasher(Hasher* h, const EncoderParams* params) {
+  int t = params->hasher.type_;
+  memset(h, 0, sizeof(*h));
+  h->params = params->hasher;
+  h->literal_byte_score = params->hasher.literal_byte_score ? (uint32_t)params->hasher.literal_byte_score : 540u;
+  if (t == 9) {
+    h->kind = 9;
+    h->bucket_bits = 15;
+    h->block_bits = 8;
+  } else if (t == 5) {
+    h->kind = 5;
+    h->bucket_bits = params->hasher.bucket_bits;
+    h->block_bits = params->hasher.block_bits;
+  } else if (t == 2 || t == 3 || t == 4 || t == 54 || t == 10) {
+    return 0; /* not restated: q<5 / q>=10 hashers are outside the oracle's scope */
+  } else {
+    h->kind = 6;
+    h->bucket_bits = params->hasher.bucket_bits;
+    h->block_bits = params->hasher.block_bits;
+    h->hash_mask = 0xffffffffffffffffull >> (64 - 8 * params->hasher.hash_len);
+  }
+  h->block_size = 1u << h->block_bits;
+  h->block_mask = h->block_size - 1;
+  h->bucket_count = (size_t)1 << h->bucket_bits;
+  h->num = (uint16_t*)calloc(h->bucket_count, sizeof(uint16_t));
+  h->buckets = (uint32_t*)calloc(h->bucket_count << h->block_bits, sizeof(uint32_t));
+  return h->num && h->buckets;
+}
+
+void orc_hasher_reset(Hasher* h) {
+  if (h->kind != 0) h->is_prepared_ = 0;
+}
+
+static inline size_t hash_bytes(const Hasher* h, const uint8_t* data) {
+  if (h->kind == 6) {
+    /* mod.rs:1138-1140, 1521-1525 */
+    uint64_t v = (load64(data) & h->hash_mask) * kHashMul64Long;
+    return (size_t)(uint32_t)(v >> (64 - h->bucket_bits));
+  } else if (h->kind == 5) {
+    /* mod.rs:990-992 */
+    uint64_t v = ((uint64_t)load32(data) * (uint64_t)kHashMul32) & 0xffffffffull;
+    return (size_t)(uint32_t)(v >> (32 - h->bucket_bits));
+  } else {
+    /* H9 mod.rs:720-724 */
+    uint32_t v = load32(data) * kHashMul32;
+    return (size_t)(v >> (32 - 15));
+  }
+}
+
+static inline size_t hash_type_length(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
+static inline size_t store_lookahead(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
+
+/* mod.rs:1644-1656 / 879-887 */
+static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, size_t ix, OrcStats* st) {
+  size_t key = hash_bytes(h, data + (ix & mask));
+  size_t minor_ix = (size_t)(h->num[key] & h->block_mask);
+  h->buckets[minor_ix + (key << h->block_bits)] = (uint32_t)ix;
+  h->num[key] = (uint16_t)(h->num[key] + 1);
+  st->positions_stored++;
+}
+
+/* mod.rs:1491-1510 (AdvHasher::Prepare), :898-906 (H9::Prepare). Returns 1 if newly prepared. */
+static int hasher_prepare(Hasher* h, int one_shot, size_t input_size, const uint8_t* data) {
+  if (h->is_prepared_ != 0) return 0;
+  if (h->kind == 9) {
+    memset(h->num, 0, h->bucket_count * sizeof(uint16_t));
+  } else {
+    size_t partial_prepare_threshold = h->bucket_count >> 6;
+    if (one_shot && input_size <= partial_prepare_threshold) {
+      for (size_t i = 0; i < input_size; ++i) h->num[hash_bytes(h, data + i)] = 0;
+    } else {
+      memset(h->num, 0, h->bucket_count * sizeof(uint16_t));
+    }
+  }
+  h->is_prepared_ = 1;
+  return 1;
+}
+
+/* encode.rs:1125-1161 */
+void orc_hasher_setup(Hasher* h, EncoderParams* params, const uint8_t* data, size_t position,
+                      size_t input_size, int is_last) {
+  int one_shot = (position == 0 && is_last);
+  if (h->kind == 0) {
+    orc_choose_hasher(params);
+    if (!make_hasher(h, params)) abort();
+    h->params = params->hasher;
+    h->is_prepared_ = 1; /* relies on zero-initialised tables (encode.rs:1147) */
+  } else {
+    if (hasher_prepare(h, one_shot, input_size, data)) {
+      if (position == 0) {
+        h->dict_num_lookups = 0;
+        h->dict_num_matches = 0;
+      }
+    }
+  }
+}
+
+/* mod.rs:210-222 */
+void orc_hasher_stitch(Hasher* h, size_t num_bytes, size_t position, const uint8_t* rb, size_t mask,
+                       OrcStats* st) {
+  if (num_bytes >= hash_type_length(h) - 1 && position >= 3) {
+    hasher_store(h, rb, mask, position - 3, st);
+    hasher_store(h, rb, mask, position - 2, st);
+    hasher_store(h, rb, mask, position - 1, st);
+  }
+}
+
+/* encode.rs:1163-1194 + mod.rs:224-229 (StoreLookaheadThenStore, mask = usize::MAX) */
+void orc_hasher_prepend_dictionary(Hasher* h, EncoderParams* params, size_t size, const uint8_t* dict,
+                                   OrcStats* st) {
+  orc_hasher_setup(h, params, dict, 0, size, 0);
+  size_t overlap = store_lookahead(h) - 1;
+  if (size > overlap) {
+    for (size_t i = 0; i < size - overlap; ++i) hasher_store(h, dict, ~(size_t)0, i, st);
+  }
+}
+
+/* ------------------------------------------------------------------ static dictionary (mod.rs:1891-1988) */
+static const uint32_t kCutoffTransformsCount = 10;
+static const uint64_t kCutoffTransforms = 0x071b520ada2d3200ull;
+
+static inline uint64_t backward_reference_score(size_t copy_length, size_t backward, uint32_t lbs) {
+  /* mod.rs:1878-1889 */
+  return (uint64_t)(30 * 8 * 8) + (uint64_t)((size_t)(lbs >> 2) * copy_length) -
+         30ull * (uint64_t)orc_log2_floor_nonzero((uint64_t)backward);
+}
+static inline uint64_t backward_reference_score_using_last_distance(size_t copy_length, uint32_t lbs) {
+  /* mod.rs:1871-1876 */
+  return ((uint64_t)(lbs >> 2)) * (uint64_t)copy_length + (uint64_t)(30 * 8 * 8) + 15;
+}
+static inline uint64_t backward_reference_penalty_using_last_distance(size_t distance_short_code) {
+  /* mod.rs:1151-1154 */
+  return 39ull + ((0x0001ca10ull >> (distance_short_code & 0x0e)) & 0x0e);
+}
+
+static int test_static_dictionary_item(size_t item, const uint8_t* data, size_t max_length, size_t max_backward,
+                                       size_t max_distance, uint32_t lbs, HasherSearchResult* out) {
+  size_t len = item & 0x1f;
+  size_t dist = item >> 5;
+  size_t offset = (size_t)kBrotliDictionaryOffsetsByLength[len] + len * dist;
+  if (len > max_length) return 0;
+  size_t matchlen = find_match_length_with_limit(data, &kBrotliDictionaryData[offset], len);
+  if (matchlen + kCutoffTransformsCount <= len || matchlen == 0) return 0;
+  size_t backward;
+  {
+    uint64_t cut = (uint64_t)(len - matchlen);
+    size_t transform_id = (size_t)((cut << 2) + ((kCutoffTransforms >> (cut * 6)) & 0x3f));
+    backward = max_backward + dist + 1 + (transform_id << kBrotliDictionarySizeBitsByLength[len]);
+  }
+  if (backward > max_distance) return 0;
+  uint64_t score = backward_reference_score(matchlen, backward, lbs);
+  if (score < out->score) return 0;
+  out->len = matchlen;
+  out->len_x_code = len ^ matchlen;
+  out->distance = backward;
+  out->score = score;
+  return 1;
+}
+
+static int search_in_static_dictionary(Hasher* h, const uint8_t* data, size_t max_length, size_t max_backward,
+                                       size_t max_distance, HasherSearchResult* out, int shallow, OrcStats* st) {
+  int is_match_found = 0;
+  if (h->dict_num_matches < (h->dict_num_lookups >> 7)) return 0;
+  size_t key = (size_t)((load32(data) * kHashMul32) >> (32 - 14)) << 1; /* Hash14 << 1 */
+  for (int i = 0; i < (shallow ? 1 : 2); ++i, ++key) {
+    size_t item = kBrotliStaticDictionaryHash[key];
+    h->dict_num_lookups++;
+    st->dict_lookups++;
+    if (item != 0) {
+      if (test_static_dictionary_item(item, data, max_length, max_backward, max_distance,
+                                      h->literal_byte_score, out)) {
+        h->dict_num_matches++;
+        st->dict_matches++;
+        is_match_found = 1;
+      }
+    }
+  }
+  return is_match_found;
+}
+
+/* ------------------------------------------------------------------ AdvHasher::FindLongestMatch (mod.rs:1684-1812) */
+static int adv_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* data, size_t ring_buffer_mask,
+                                  size_t ring_buffer_break, const int32_t* distance_cache, size_t cur_ix,
+                                  size_t max_length, size_t max_backward, size_t gap, size_t max_distance,
+                                  HasherSearchResult* out, OrcStats* st) {
+  const uint32_t lbs = h->literal_byte_score;
+  const size_t cur_ix_masked = cur_ix & ring_buffer_mask;
+  int is_match_found = 0;
+  uint64_t best_score = out->score;
+  size_t best_len = out->len;
+  const uint8_t* cur_data = data + cur_ix_masked;
+  out->len = 0;
+  out->len_x_code = 0;
+  st->positions_searched++;
+  for (size_t i = 0; i < (size_t)h->params.num_last_distances_to_check; ++i) {
+    size_t backward = (size_t)(int64_t)distance_cache[i];
+    size_t prev_ix = cur_ix - backward;
+    if (prev_ix >= cur_ix || backward > max_backward) continue;
+    prev_ix &= ring_buffer_mask;
+    if (cur_ix_masked + best_len > ring_buffer_mask || prev_ix + best_len > ring_buffer_mask ||
+        cur_data[best_len] != data[prev_ix + best_len])
+      continue;
+    size_t unbroken_len = find_match_length_with_limit(data + prev_ix, cur_data, max_length);
+    if (unbroken_len >= 3 || (unbroken_len == 2 && i < 2)) {
+      size_t len = fix_unbroken_len(unbroken_len, prev_ix, ring_buffer_break);
+      uint64_t score = backward_reference_score_using_last_distance(len, lbs);
+      if (best_score < score) {
+        if (i != 0) score -= backward_reference_penalty_using_last_distance(i);
+        if (best_score < score) {
+          best_score = score;
+          best_len = len;
+          out->len = best_len;
+          out->distance = backward;
+          out->score = best_score;
+          is_match_found = 1;
+        }
+      }
+    }
+  }
+  {
+    size_t key = hash_bytes(h, cur_data);
+    uint16_t num_copy = h->num[key];
+    uint32_t* bucket = &h->buckets[key << h->block_bits];
+    if (num_copy != 0) {
+      int32_t dn = (int32_t)num_copy - (int32_t)h->block_size;
+      size_t down = dn > 0 ? (size_t)dn : 0;
+      size_t i = num_copy;
+      while (i > down) {
+        --i;
+        size_t prev_ix = bucket[i & h->block_mask];
+        size_t backward = cur_ix - prev_ix;
+        prev_ix &= ring_buffer_mask;
+        if (cur_ix_masked + best_len > ring_buffer_mask || prev_ix + best_len > ring_buffer_mask ||
+            cur_data[best_len] != data[prev_ix + best_len]) {
+          if (backward > max_backward) break;
+          continue;
+        }
+        if (backward > max_backward) break;
+        size_t unbroken_len = find_match_length_with_limit_min4(data + prev_ix, cur_data, max_length);
+        if (unbroken_len != 0) {
+          size_t len = fix_unbroken_len(unbroken_len, prev_ix, ring_buffer_break);
+          uint64_t score = backward_reference_score(len, backward, lbs);
+          if (best_score < score) {
+            best_score = score;
+            best_len = len;
+            out->len = best_len;
+            out->distance = backward;
+            out->score = best_score;
+            is_match_found = 1;
+          }
+        }
+      }
+    }
+    bucket[num_copy & h->block_mask] = (uint32_t)cur_ix;
+    h->num[key] = (uint16_t)(num_copy + 1);
+    st->positions_stored++;
+  }
+  if (!is_match_found && use_dictionary) {
+    is_match_found = search_in_static_dictionary(h, cur_data, max_length, max_backward + gap, max_distance,
+                                                 out, 0, st);
+  }
+  return is_match_found;
+}
+
+/* ------------------------------------------------------------------ H9::FindLongestMatch (mod.rs:737-877) */
+static const uint8_t kDistanceCacheIndex[16] = {0, 1, 2, 3, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1};
+static const int8_t kDistanceCacheOffset[16] = {0, 0, 0, 0, -1, 1, -2, 2, -3, 3, -1, 1, -2, 2, -3, 3};
+#define H9_SCORE_BASE (120u * 8u * 8u)
+static const uint32_t kDistanceShortCodeCost[16] = {
+    H9_SCORE_BASE + 60,  H9_SCORE_BASE - 95,  H9_SCORE_BASE - 117, H9_SCORE_BASE - 127,
+    H9_SCORE_BASE - 93,  H9_SCORE_BASE - 93,  H9_SCORE_BASE - 96,  H9_SCORE_BASE - 96,
+    H9_SCORE_BASE - 99,  H9_SCORE_BASE - 99,  H9_SCORE_BASE - 105, H9_SCORE_BASE - 105,
+    H9_SCORE_BASE - 115, H9_SCORE_BASE - 115, H9_SCORE_BASE - 125, H9_SCORE_BASE - 125};
+
+static inline uint64_t score_h9(size_t copy_length, size_t backward, uint32_t lbs) {
+  return ((uint64_t)H9_SCORE_BASE + (uint64_t)lbs * (uint64_t)copy_length -
+          120ull * (uint64_t)orc_log2_floor_nonzero((uint64_t)backward)) >> 2;
+}
+static inline uint64_t score_last_h9(size_t copy_length, size_t code, uint32_t lbs) {
+  return ((uint64_t)lbs * (uint64_t)copy_length + (uint64_t)kDistanceShortCodeCost[code]) >> 2;
+}
+
+static int h9_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* data, size_t ring_buffer_mask,
+                                 size_t ring_buffer_break, const int32_t* distance_cache, size_t cur_ix,
+                                 size_t max_length, size_t max_backward, size_t gap, size_t max_distance,
+                                 HasherSearchResult* out, OrcStats* st) {
+  const uint32_t lbs = h->literal_byte_score;
+  const size_t cur_ix_masked = cur_ix & ring_buffer_mask;
+  uint64_t best_score = out->score;
+  size_t best_len = out->len;
+  int is_match_found = 0;
+  out->len_x_code = 0;
+  st->positions_searched++;
+  for (size_t i = 0; i < 16; ++i) {
+    size_t idx = kDistanceCacheIndex[i];
+    size_t backward = (size_t)(int64_t)distance_cache[idx] + (size_t)(int64_t)kDistanceCacheOffset[i];
+    size_t prev_ix = cur_ix - backward;
+    if (prev_ix >= cur_ix) continue;
+    if (backward > max_backward) continue;
+    prev_ix &= ring_buffer_mask;
+    if (cur_ix_masked + best_len > ring_buffer_mask || prev_ix + best_len > ring_buffer_mask ||
+        data[cur_ix_masked + best_len] != data[prev_ix + best_len])
+      continue;
+    size_t unbroken_len = find_match_length_with_limit(data + prev_ix, data + cur_ix_masked, max_length);
+    if (unbroken_len >= 3 || (unbroken_len == 2 && i < 2)) {
+      size_t len = fix_unbroken_len(unbroken_len, prev_ix, ring_buffer_break);
+      uint64_t score = score_last_h9(len, i, lbs);
+      if (best_score < score) {
+        best_score = score;
+        best_len = len;
+        out->len = best_len;
+        out->distance = backward;
+        out->score = best_score;
+        is_match_found = 1;
+      }
+    }
+  }
+  if (max_length >= 4 && cur_ix_masked + best_len <= ring_buffer_mask) {
+    size_t key = hash_bytes(h, data + cur_ix_masked);
+    uint32_t* bucket = &h->buckets[key << 8];
+    uint16_t self_num_key = h->num[key];
+    size_t down = self_num_key > 256 ? (size_t)self_num_key - 256 : 0;
+    size_t i = self_num_key;
+    uint8_t prev_best_val = data[cur_ix_masked + best_len];
+    while (i > down) {
+      --i;
+      size_t prev_ix = bucket[i & 255];
+      size_t backward = cur_ix - prev_ix;
+      if (backward > max_backward) break;
+      prev_ix &= ring_buffer_mask;
+      if (prev_ix + best_len > ring_buffer_mask || prev_best_val != data[prev_ix + best_len]) continue;
+      size_t unbroken_len = find_match_length_with_limit(data + prev_ix, data + cur_ix_masked, max_length);
+      if (unbroken_len >= 4) {
+        size_t len = fix_unbroken_len(unbroken_len, prev_ix, ring_buffer_break);
+        uint64_t score = score_h9(len, backward, lbs);
+        if (best_score < score) {
+          best_score = score;
+          best_len = len;
+          out->len = best_len;
+          out->distance = backward;
+          out->score = best_score;
+          is_match_found = 1;
+          if (cur_ix_masked + best_len > ring_buffer_mask) break;
+          prev_best_val = data[cur_ix_masked + best_len];
+        }
+      }
+    }
+    bucket[self_num_key & 255] = (uint32_t)cur_ix;
+    h->num[key] = (uint16_t)(self_num_key + 1);
+    st->positions_stored++;
+  }
+  if (!is_match_found && use_dictionary) {
+    is_match_found = search_in_static_dictionary(h, data + cur_ix_masked, max_length, max_backward + gap,
+                                                 max_distance, out, 0, st);
+  }
+  return is_match_found;
+}
+
+static inline int find_longest_match(Hasher* h, int use_dictionary, const uint8_t* data, size_t mask,
+                                     size_t rb_break, const int32_t* dc, size_t cur_ix, size_t max_length,
+                                     size_t max_backward, size_t gap, size_t max_distance,
+                                     HasherSearchResult* out, OrcStats* st) {
+  if (h->kind == 9)
+    return h9_find_longest_match(h, use_dictionary, data, mask, rb_break, dc, cur_ix, max_length, max_backward,
+                                 gap, max_distance, out, st);
+  return adv_find_longest_match(h, use_dictionary, data, mask, rb_break, dc, cur_ix, max_length, max_backward,
+                                gap, max_distance, out, st);
+}
+
+/* mod.rs:632-651 */
+static void prepare_distance_cache(const Hasher* h, int32_t* distance_cache) {
+  int num_distances = h->kind == 9 ? 16 : h->params.num_last_distances_to_check;
+  if (num_distances > 4) {
+    int32_t last_distance = distance_cache[0];
+    distance_cache[4] = last_distance - 1;
+    distance_cache[5] = last_distance + 1;
+    distance_cache[6] = last_distance - 2;
+    distance_cache[7] = last_distance + 2;
+    distance_cache[8] = last_distance - 3;
+    distance_cache[9] = last_distance + 3;
+    if (num_distances > 10) {
+      int32_t next_last_distance = distance_cache[1];
+      distance_cache[10] = next_last_distance - 1;
+      distance_cache[11] = next_last_distance + 1;
+      distance_cache[12] = next_last_distance - 2;
+      distance_cache[13] = next_last_distance + 2;
+      distance_cache[14] = next_last_distance - 3;
+      distance_cache[15] = next_last_distance + 3;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ CreateBackwardReferences (mod.rs:2376-2552) */
+void orc_create_backward_references(size_t num_bytes, size_t position, const uint8_t* ringbuffer,
+                                    size_t ringbuffer_mask, size_t ringbuffer_break,
+                                    const EncoderParams* params, Hasher* hasher, int32_t* dist_cache,
+                                    size_t* last_insert_len, Command* commands, size_t* num_commands,
+                                    size_t* num_literals, OrcStats* st) {
+  const int use_dictionary = params->use_dictionary;
+  const size_t gap = 0;
+  const size_t max_backward_limit = ((size_t)1 << params->lgwin) - 16;
+  size_t new_commands_count = 0;
+  size_t insert_length = *last_insert_len;
+  const size_t pos_end = position + num_bytes;
+  const size_t store_end = num_bytes >= store_lookahead(hasher) ? position + num_bytes - store_lookahead(hasher) + 1
+                                                                : position;
+  const size_t random_heuristics_window_size = params->quality < 9 ? 64 : 512;
+  size_t apply_random_heuristics = position + random_heuristics_window_size;
+  const uint64_t kMinScore = 30 * 8 * 8 + 100;
+  const size_t htl = hash_type_length(hasher);
+  prepare_distance_cache(hasher, dist_cache);
+  while (position + htl < pos_end) {
+    size_t max_length = pos_end - position;
+    size_t max_distance = ORC_MIN(position, max_backward_limit);
+    HasherSearchResult sr;
+    sr.len = 0;
+    sr.len_x_code = 0;
+    sr.distance = 0;
+    sr.score = kMinScore;
+    if (find_longest_match(hasher, use_dictionary, ringbuffer, ringbuffer_mask, ringbuffer_break, dist_cache,
+                           position, max_length, max_distance, gap, params->dist.max_distance, &sr, st)) {
+      int delayed_backward_references_in_row = 0;
+      max_length--;
+      for (;;) {
+        const uint64_t cost_diff_lazy = 175;
+        HasherSearchResult sr2;
+        sr2.len = params->quality < 5 ? ORC_MIN(sr.len - 1, max_length) : 0;
+        sr2.len_x_code = 0;
+        sr2.distance = 0;
+        sr2.score = kMinScore;
+        max_distance = ORC_MIN(position + 1, max_backward_limit);
+        int is_match_found =
+            find_longest_match(hasher, use_dictionary, ringbuffer, ringbuffer_mask, ringbuffer_break, dist_cache,
+                               position + 1, max_length, max_distance, gap, params->dist.max_distance, &sr2, st);
+        if (is_match_found && sr2.score >= sr.score + cost_diff_lazy) {
+          position++;
+          insert_length++;
+          sr = sr2;
+          if (++delayed_backward_references_in_row < 4 && position + htl < pos_end) {
+            max_length--;
+            continue;
+          }
+        }
+        break;
+      }
+      apply_random_heuristics = position + 2 * sr.len + random_heuristics_window_size;
+      max_distance = ORC_MIN(position, max_backward_limit);
+      {
+        size_t distance_code = compute_distance_code(sr.distance, max_distance, dist_cache);
+        if (sr.distance <= max_distance && distance_code > 0) {
+          dist_cache[3] = dist_cache[2];
+          dist_cache[2] = dist_cache[1];
+          dist_cache[1] = dist_cache[0];
+          dist_cache[0] = (int32_t)sr.distance;
+          prepare_distance_cache(hasher, dist_cache);
+        }
+        orc_command_init(&commands[new_commands_count++], &params->dist, insert_length, sr.len,
+                         sr.len ^ sr.len_x_code, distance_code);
+      }
+      *num_literals += insert_length;
+      insert_length = 0;
+      {
+        size_t a = position + 2, b = ORC_MIN(position + sr.len, store_end);
+        for (size_t i = a; i < b; ++i) hasher_store(hasher, ringbuffer, ringbuffer_mask, i, st);
+      }
+      position += sr.len;
+    } else {
+      insert_length++;
+      position++;
+      if (position > apply_random_heuristics) {
+        size_t kMargin = ORC_MAX(store_lookahead(hasher) - 1, (size_t)4);
+        if (position + 16 >= pos_end - kMargin) {
+          insert_length += pos_end - position;
+          position = pos_end;
+        } else if (position > apply_random_heuristics + 4 * random_heuristics_window_size) {
+          for (size_t i = 0; i < 4; ++i) hasher_store(hasher, ringbuffer, ringbuffer_mask, position + i * 4, st);
+          insert_length += 16;
+          position += 16;
+        } else {
+          for (size_t i = 0; i < 4; ++i) hasher_store(hasher, ringbuffer, ringbuffer_mask, position + i * 2, st);
+          insert_length += 8;
+          position += 8;
+        }
+      }
+    }
+  }
+  insert_length += pos_end - position;
+  *last_insert_len = insert_length;
+  *num_commands += new_commands_count;
+}

@@ -1,0 +1,120 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so) and of the system brotli decoder.
+Test infrastructure only."""
+import ctypes, os, subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class OrcStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("positions_searched", "positions_stored", "commands", "literals",
+                                               "metablocks", "uncompressed_metablocks", "dict_lookups",
+                                               "dict_matches")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class OrcCommand(ctypes.Structure):
+    _fields_ = [("insert_len_", ctypes.c_uint32), ("copy_len_", ctypes.c_uint32), ("dist_extra_", ctypes.c_uint32),
+                ("cmd_prefix_", ctypes.c_uint16), ("dist_prefix_", ctypes.c_uint16)]
+
+
+TRACE_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_size_t,
+                            ctypes.POINTER(OrcCommand), ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32))
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.orc_max_compressed_size.restype = ctypes.c_size_t
+        L.orc_max_compressed_size.argtypes = [ctypes.c_size_t]
+        L.orc_max_compressed_size_multi.restype = ctypes.c_size_t
+        L.orc_max_compressed_size_multi.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+        L.orc_encoder_compress.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p,
+                                           ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p,
+                                           ctypes.POINTER(OrcStats)]
+        L.orc_writer_compress.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
+                                          ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p,
+                                          ctypes.POINTER(OrcStats), ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_compress_multi.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32),
+                                         ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p,
+                                         ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_size_t]
+        L.orc_log2f_restated.restype = ctypes.c_float
+        L.orc_log2f_restated.argtypes = [ctypes.c_float]
+        L.orc_bits_entropy.restype = ctypes.c_float
+        L.orc_bits_entropy.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
+        _lib = L
+    return _lib
+
+
+def compress(data, quality=5, lgwin=22, mode=0, with_stats=False):
+    """one-shot BrotliEncoderCompress equivalent (size_hint = len)"""
+    L = lib()
+    cap = L.orc_max_compressed_size(len(data)) + 64
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(cap)
+    st = OrcStats()
+    ok = L.orc_encoder_compress(quality, lgwin, mode, len(data), data, ctypes.byref(n), out, ctypes.byref(st))
+    if not ok:
+        raise RuntimeError("oracle compress failed")
+    res = out.raw[:n.value]
+    return (res, st.as_dict()) if with_stats else res
+
+
+def writer_compress(data, quality=5, lgwin=22, chunk=0, with_stats=False, trace=None):
+    """CompressorWriter feeding pattern (size_hint derived from the first write)"""
+    L = lib()
+    cap = L.orc_max_compressed_size(len(data)) + 64
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(cap)
+    st = OrcStats()
+    cb = TRACE_CB(trace) if trace else None
+    ok = L.orc_writer_compress(quality, lgwin, chunk, len(data), data, ctypes.byref(n), out, ctypes.byref(st),
+                               ctypes.cast(cb, ctypes.c_void_p) if cb else None, None)
+    if not ok:
+        raise RuntimeError("oracle writer compress failed")
+    res = out.raw[:n.value]
+    return (res, st.as_dict()) if with_stats else res
+
+
+def compress_multi(data, params, num_threads):
+    L = lib()
+    keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
+    vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
+    cap = L.orc_max_compressed_size_multi(len(data), num_threads) + 64
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(cap)
+    ok = L.orc_compress_multi(keys, vals, len(params), len(data), data, ctypes.byref(n), out, num_threads)
+    if not ok:
+        raise RuntimeError("oracle compress_multi failed")
+    return out.raw[:n.value]
+
+
+# ---- independent decoder (Google libbrotlidec) for round trips
+_dec = None
+
+
+def decompress(comp, expected_size):
+    global _dec
+    if _dec is None:
+        _dec = ctypes.CDLL("libbrotlidec.so.1")
+        _dec.BrotliDecoderDecompress.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t),
+                                                 ctypes.c_char_p]
+    cap = expected_size + 16
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(cap)
+    r = _dec.BrotliDecoderDecompress(len(comp), comp, ctypes.byref(n), out)
+    if r != 1:
+        raise RuntimeError("decoder rejected the stream (result %d)" % r)
+    return out.raw[:n.value]
