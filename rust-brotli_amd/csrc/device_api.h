@@ -1,0 +1,79 @@
+// device_api.h -- the narrow seam between the C++ host driver and the gfx950 kernels.
+//
+// The host driver (encoder_host.cpp) only talks to the device through these functions.  The product
+// library implements them with HIP kernels (lz77_kernels.hip, metablock_kernels.hip).  Tests link the
+// same host driver against a serial CPU emulation of this seam (tests/emu/) so that the speculative
+// parse / resolver logic can be exercised without a GPU; that emulation is never part of the product.
+#ifndef BROTLI_MI355X_DEVICE_API_H_
+#define BROTLI_MI355X_DEVICE_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lz77_types.h"
+
+namespace brotli_mi355x {
+
+// ---- memory ----
+void* dev_alloc(size_t bytes);  // zero-initialised device allocation; throws std::runtime_error
+void dev_free(void* p);
+void dev_memset(void* p, int value, size_t bytes);
+void dev_h2d(void* dst, const void* src, size_t bytes);
+void dev_d2h(void* dst, const void* src, size_t bytes);
+void dev_d2d(void* dst, const void* src, size_t bytes);
+void dev_sync();
+const char* dev_name();  // "hip:gfx950 ..." or "host-emulation"
+
+// Static read-only tables resident on the device (dictionary, dictionary hash, log tables ...).
+struct DeviceTables {
+  const uint16_t* dict_hash;
+  const uint8_t* dict_data;
+  const uint32_t* dict_offsets_by_length;
+  const uint8_t* dict_size_bits_by_length;
+  const float* logs_16;
+  const float* logs_8;
+  const uint8_t* utf8_context_lookup;   // 512
+  const uint8_t* signed_context_lookup; // 256
+};
+const DeviceTables& dev_tables();
+
+// ---- LZ77 stage ----
+struct Lz77Buffers {
+  uint8_t* text;        // total_bytes + 64
+  uint16_t* keys;       // total_bytes
+  uint32_t* by_key;     // positions sorted by (key, position)            [total_bytes]
+  uint16_t* sorted_keys;// keys in that order                              [total_bytes]
+  uint32_t* rank;       // per position                                    [total_bytes]
+  uint32_t* sorted;     // stored positions in (key,pos) order             [total_bytes]
+  uint32_t* key_base;   // per key                                         [65536 + 1]
+  uint8_t* flags[2];    // stored flags, double buffered                   [total_bytes + 64]
+  Command* cmds;        // num_segments * cmd_slab_stride
+  Segment* segments;    // num_segments
+  SegEntry* entries;    // num_segments
+  SegExit* exits;       // num_segments
+  void* sort_tmp;       // scratch for the radix sort / scans
+  size_t sort_tmp_bytes;
+};
+
+size_t lz77_sort_tmp_bytes(uint32_t total_bytes);
+
+// hash key of every position (mod.rs:990-992 H5, :1138-1140 H6)
+void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
+// stable sort of positions by key -> by_key / sorted_keys
+void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
+// rank / sorted / key_base from flags[which]
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which);
+// one round of speculative parsing: segments [first, num_segments) read flags[which] (through
+// rank/sorted) and write flags[which ^ 1], cmds and exits
+void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment);
+// every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
+void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
+// gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]
+void lz77_gather_commands(const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
+                          const uint32_t* counts_dev, Command* out);
+
+// applies extend_last_command / trailing insert-only fix-ups to the gathered commands
+void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n);
+
+}  // namespace brotli_mi355x
+#endif

@@ -1,0 +1,562 @@
+// lz77_chain.h -- one speculative parse chain of the backward-reference search.
+//
+// A chain is the greedy/lazy parse of rust-brotli's CreateBackwardReferences
+// (src/enc/backward_references/mod.rs:2376-2552) restricted to one segment of one input block,
+// executed by ONE 64-lane wavefront: the control flow is wave-uniform, the per-position search
+// (AdvHasher::FindLongestMatch, mod.rs:1684-1812) spreads its <= ndist + block_size candidates
+// over the lanes (one candidate per lane: load, compare, extend), then folds them in the
+// reference's exact order.
+//
+// The reference's bucket ring (num[]/buckets[], mod.rs:932-941) is replaced by a parse-independent
+// surrogate: positions sorted by (key, position), a per-position "stored" flag and the prefix sum of
+// the flags in sorted order (rank).  The candidates the ring would hold when position p is searched
+// are the min(block_size, count mod 65536) stored positions that precede p in its key's list.
+// The flags of positions handled by OTHER chains come from the previous round (Jacobi iteration);
+// the host resolver repeats rounds until entries and flags are a fixed point, which is the
+// sequential parse.
+//
+// The same source is compiled for the host (BROTLI_HOST_EMU) to test the algorithm without a GPU:
+// there a "wave" is one lane and the candidate loops run serially.  The emulation build is test
+// infrastructure; the product library only contains the gfx950 code.
+#ifndef BROTLI_MI355X_LZ77_CHAIN_H_
+#define BROTLI_MI355X_LZ77_CHAIN_H_
+
+#include "lz77_types.h"
+
+#if defined(BROTLI_HOST_EMU)
+#include <string.h>
+#define BR_DEV inline
+#define BR_LANE 0
+#define BR_NLANES 1
+#define BR_SYNC() ((void)0)
+#else
+#include <hip/hip_runtime.h>
+#define BR_DEV __device__ __forceinline__
+#define BR_LANE ((int)threadIdx.x)
+#define BR_NLANES 64
+#define BR_SYNC() __syncthreads()
+#endif
+
+namespace brotli_mi355x {
+
+static constexpr int kMaxCandidates = 16 + 128;  // ndist <= 16, ring depth <= 128 (quality <= 8)
+static constexpr uint32_t kMinScore = 30 * 8 * 8 + 100;  // mod.rs:2408-2410
+
+struct ChainTables {
+  const uint8_t* text;         // dictionary prefix + input (+ >= 16 bytes of zero padding)
+  const uint16_t* keys;        // hash key per position
+  const uint32_t* rank;        // per position: number of stored positions before it in (key,pos) order
+  const uint32_t* key_base;    // per key: rank of the first position of that key
+  const uint32_t* sorted;      // stored positions in (key,pos) order
+  const uint8_t* flags_prev;   // stored flags used to build rank/sorted (previous round)
+  uint8_t* flags_next;         // stored flags produced by this round
+  Command* cmds;
+  const uint16_t* dict_hash;   // kStaticDictionaryHash (src/enc/dictionary_hash.rs)
+  const uint8_t* dict_data;    // RFC 7932 dictionary
+  const uint32_t* dict_offsets_by_length;
+  const uint8_t* dict_size_bits_by_length;
+  uint32_t dist_postfix_bits;
+  uint32_t num_direct_distance_codes;
+};
+
+struct ChainScratch {  // one per wavefront (LDS on the device)
+  uint32_t cand_prev[kMaxCandidates];
+  uint32_t cand_len[kMaxCandidates];
+  uint32_t flag_changes[64];
+};
+
+struct SearchResult {
+  uint32_t len, len_x_code, distance, score;
+  bool found;
+};
+
+BR_DEV uint32_t br_load32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+BR_DEV uint64_t br_load64(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+BR_DEV uint32_t br_log2_floor_nonzero(uint32_t v) { return 31u ^ (uint32_t)__builtin_clz(v); }
+
+// FindMatchLengthWithLimit, src/enc/static_dict.rs:125-132 (8-byte XOR + ctz extension)
+BR_DEV uint32_t br_match_len(const uint8_t* a, const uint8_t* b, uint32_t limit) {
+  uint32_t i = 0;
+  while (i + 8 <= limit) {
+    uint64_t x = br_load64(a + i) ^ br_load64(b + i);
+    if (x != 0) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
+    i += 8;
+  }
+  while (i < limit) {
+    if (a[i] != b[i]) return i;
+    ++i;
+  }
+  return limit;
+}
+
+// ---- command.rs -------------------------------------------------------------------------------
+// ComputeDistanceCode, command.rs:48-68
+BR_DEV uint32_t br_compute_distance_code(uint32_t distance, uint32_t max_distance, const int32_t* dc) {
+  if (distance <= max_distance) {
+    const int64_t d = (int64_t)distance;
+    const uint64_t offset0 = (uint64_t)(d + 3 - (int64_t)dc[0]);
+    const uint64_t offset1 = (uint64_t)(d + 3 - (int64_t)dc[1]);
+    if (d == (int64_t)dc[0]) return 0;
+    if (d == (int64_t)dc[1]) return 1;
+    if (offset0 < 7) return (0x09750468u >> (4 * (uint32_t)offset0)) & 0xf;
+    if (offset1 < 7) return (0x0fdb1aceu >> (4 * (uint32_t)offset1)) & 0xf;
+    if (d == (int64_t)dc[2]) return 2;
+    if (d == (int64_t)dc[3]) return 3;
+  }
+  return distance + 15;
+}
+// GetInsertLengthCode / GetCopyLengthCode, command.rs:71-108
+BR_DEV uint32_t br_insert_length_code(uint32_t insertlen) {
+  if (insertlen < 6) return insertlen;
+  if (insertlen < 130) {
+    uint32_t nbits = br_log2_floor_nonzero(insertlen - 2) - 1u;
+    return (nbits << 1) + ((insertlen - 2) >> nbits) + 2;
+  }
+  if (insertlen < 2114) return br_log2_floor_nonzero(insertlen - 66) + 10;
+  if (insertlen < 6210) return 21;
+  if (insertlen < 22594) return 22;
+  return 23;
+}
+BR_DEV uint32_t br_copy_length_code(uint32_t copylen) {
+  if (copylen < 10) return copylen - 2;
+  if (copylen < 134) {
+    uint32_t nbits = br_log2_floor_nonzero(copylen - 6) - 1u;
+    return (nbits << 1) + ((copylen - 6) >> nbits) + 4;
+  }
+  if (copylen < 2118) return br_log2_floor_nonzero(copylen - 70) + 12;
+  return 23;
+}
+// combine_length_codes, command.rs:110-125
+BR_DEV uint16_t br_combine_length_codes(uint32_t inscode, uint32_t copycode, bool use_last_distance) {
+  uint32_t bits64 = (copycode & 0x7u) | ((inscode & 0x7u) << 3);
+  if (use_last_distance && inscode < 8 && copycode < 16) return (uint16_t)(copycode < 8 ? bits64 : (bits64 | 64));
+  int sub_offset = 2 * (int)((copycode >> 3) + 3 * (inscode >> 3));
+  int offset = (sub_offset << 5) + 0x40 + ((0x520d40 >> sub_offset) & 0xc0);
+  return (uint16_t)((uint32_t)offset | bits64);
+}
+// Command::init, command.rs:273-297 with PrefixEncodeCopyDistance :134-173
+BR_DEV Command br_make_command(const ChainTables& t, uint32_t insertlen, uint32_t copylen, uint32_t copylen_code,
+                               uint32_t distance_code) {
+  Command c;
+  c.insert_len_ = insertlen;
+  int32_t delta = (int32_t)copylen_code - (int32_t)copylen;
+  c.copy_len_ = copylen | ((uint32_t)(uint8_t)(int8_t)delta << 25);
+  const uint32_t ndirect = t.num_direct_distance_codes, npostfix = t.dist_postfix_bits;
+  if (distance_code < 16 + ndirect) {
+    c.dist_prefix_ = (uint16_t)distance_code;
+    c.dist_extra_ = 0;
+  } else {
+    uint64_t dist = (1ull << (npostfix + 2)) + ((uint64_t)distance_code - 16 - ndirect);
+    uint32_t bucket = (63u ^ (uint32_t)__builtin_clzll(dist)) - 1;
+    uint64_t postfix_mask = (1u << npostfix) - 1;
+    uint64_t postfix = dist & postfix_mask;
+    uint64_t prefix = (dist >> bucket) & 1;
+    uint64_t offset = (2 + prefix) << bucket;
+    uint64_t nbits = bucket - npostfix;
+    c.dist_prefix_ = (uint16_t)((nbits << 10) | (16 + ndirect + ((2 * (nbits - 1) + prefix) << npostfix) + postfix));
+    c.dist_extra_ = (uint32_t)((dist - offset) >> npostfix);
+  }
+  c.cmd_prefix_ = br_combine_length_codes(br_insert_length_code(insertlen), br_copy_length_code(copylen_code),
+                                          (c.dist_prefix_ & 0x3ff) == 0);
+  return c;
+}
+
+// fix-ups applied after the parse reached its fixed point
+BR_DEV void br_apply_patch(Command* cmds, const CmdPatch& p) {
+  Command c = cmds[p.index];
+  if (p.kind == 0) {
+    // extend_last_command, encode.rs:385-397: note the 7-bit delta is NOT sign extended there
+    c.copy_len_ += p.value;
+    const uint32_t copy_code = (c.copy_len_ & 0x01ffffffu) + (c.copy_len_ >> 25);
+    c.cmd_prefix_ = br_combine_length_codes(br_insert_length_code(c.insert_len_), br_copy_length_code(copy_code),
+                                            (c.dist_prefix_ & 0x3ff) == 0);
+  } else if (p.kind == 2) {
+    // literals pending at the segment entry belong to its first command
+    c.insert_len_ += p.value;
+    const uint32_t m = c.copy_len_ >> 25;
+    const int32_t delta = (int32_t)(int8_t)(uint8_t)(m | ((m & 0x40) << 1));
+    const uint32_t copy_code = (uint32_t)((int32_t)(c.copy_len_ & 0x01ffffffu) + delta);
+    c.cmd_prefix_ = br_combine_length_codes(br_insert_length_code(c.insert_len_), br_copy_length_code(copy_code),
+                                            (c.dist_prefix_ & 0x3ff) == 0);
+  } else {
+    // Command::init_insert, command.rs:38-44
+    c.insert_len_ = p.value;
+    c.copy_len_ = 4u << 25;
+    c.dist_extra_ = 0;
+    c.dist_prefix_ = (uint16_t)((1u << 10) | 16u);
+    c.cmd_prefix_ = br_combine_length_codes(br_insert_length_code(p.value), br_copy_length_code(4), false);
+  }
+  cmds[p.index] = c;
+}
+
+// ---- ring buffer emulation -----------------------------------------------------------------------
+// The reference reads the input through a ring buffer of ring_mask+1 bytes that is filled one block
+// at a time (encode.rs:709-831).  Everything it reads below pos_end equals the flat text; the byte AT
+// pos_end (reachable by the quick-reject test when best_len == max_length) is not written yet: it is
+// 0 during the first lap (zero-initialised storage + 7 cleared bytes, encode.rs:823-830) and the
+// byte from one lap earlier afterwards.
+BR_DEV uint8_t br_unwritten_byte(const Lz77Params& P, const ChainTables& t, uint32_t pos) {
+  return pos <= P.ring_mask ? (uint8_t)0 : t.text[pos - (P.ring_mask + 1u)];
+}
+
+struct DictState {
+  uint32_t lookups, matches;  // absolute counters (entry hint + local)
+  uint32_t lookups0, matches0;
+  uint32_t mode;              // see SegExit::dict_mode
+  int32_t maxdef;
+};
+
+// SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false)
+BR_DEV bool br_search_static_dictionary(const Lz77Params& P, const ChainTables& t, DictState& ds, const uint8_t* data,
+                                        uint32_t max_length, uint32_t max_backward, SearchResult& out) {
+  const bool dead = ds.matches < (ds.lookups >> 7);
+  const uint32_t seen = dead ? 2u : 1u;
+  ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
+  if (dead) return false;
+  {
+    int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
+    if (def > ds.maxdef) ds.maxdef = def;
+  }
+  bool is_match_found = false;
+  uint32_t key = ((br_load32(data) * 0x1e35a7bdu) >> (32 - 14)) << 1;
+  for (int i = 0; i < 2; ++i, ++key) {
+    const uint32_t item = t.dict_hash[key];
+    ds.lookups++;
+    if (item != 0) {
+      const uint32_t len = item & 0x1f;
+      const uint32_t dist = item >> 5;
+      const uint32_t offset = t.dict_offsets_by_length[len] + len * dist;
+      if (len > max_length) continue;
+      const uint32_t matchlen = br_match_len(data, t.dict_data + offset, len);
+      if (matchlen + 10 <= len || matchlen == 0) continue;
+      const uint32_t cut = len - matchlen;
+      const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
+      const uint32_t backward = max_backward + dist + 1 + (transform_id << t.dict_size_bits_by_length[len]);
+      if (backward > P.dist_max_distance) continue;
+      const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
+      if (score < out.score) continue;
+      out.len = matchlen;
+      out.len_x_code = len ^ matchlen;
+      out.distance = backward;
+      out.score = score;
+      ds.matches++;
+      is_match_found = true;
+    }
+  }
+  return is_match_found;
+}
+
+// AdvHasher::FindLongestMatch, mod.rs:1684-1812.  cache[] holds ndist prepared distances.
+BR_DEV SearchResult br_find_longest_match(const Lz77Params& P, const ChainTables& t, ChainScratch& s, DictState& ds,
+                                          uint32_t cur, const int32_t* cache, uint32_t max_length, uint32_t blk_end) {
+  const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+  const uint8_t* cur_data = t.text + cur;
+  const uint32_t ndist = P.ndist;
+  const uint32_t block_size = 1u << P.block_bits;
+  const uint32_t key = t.keys[cur];
+  const uint32_t g = t.rank[cur];
+  const uint32_t num_copy = (g - t.key_base[key]) & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
+  const uint32_t nbucket = num_copy < block_size ? num_copy : block_size;
+  const uint32_t ncand = ndist + nbucket;
+  // phase 1: one candidate per lane -- locate it and measure the common prefix
+  for (uint32_t c = BR_LANE; c < ncand; c += BR_NLANES) {
+    uint32_t prev = 0xffffffffu, len = 0;
+    if (c < ndist) {
+      const int64_t b = (int64_t)cache[c];
+      if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+    } else {
+      const uint32_t q = t.sorted[g - 1 - (c - ndist)];
+      if (cur - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
+    }
+    if (prev != 0xffffffffu) len = br_match_len(t.text + prev, cur_data, max_length);
+    s.cand_prev[c] = prev;
+    s.cand_len[c] = len;
+  }
+  BR_SYNC();
+  // phase 2: fold in the reference's order
+  SearchResult out;
+  out.len = 0;
+  out.len_x_code = 0;
+  out.distance = 0;
+  out.score = kMinScore;
+  out.found = false;
+  uint32_t best_len = 0;
+  uint32_t best_score = kMinScore;
+  const uint32_t brk = P.prefix_bytes;
+  for (uint32_t c = 0; c < ncand; ++c) {
+    const uint32_t prev = s.cand_prev[c];
+    if (prev == 0xffffffffu) {
+      if (c < ndist) continue;
+      break;  // backward > max_backward: older ring entries are farther still
+    }
+    const uint32_t unbroken = s.cand_len[c];
+    // quick reject (mod.rs:1713-1718 / 1765-1773)
+    if ((cur & P.ring_mask) + best_len > P.ring_mask || (prev & P.ring_mask) + best_len > P.ring_mask) continue;
+    bool same;
+    if (best_len < unbroken) {
+      same = true;
+    } else if (best_len == unbroken && unbroken < max_length) {
+      same = false;
+    } else {
+      const uint8_t cb = (cur + best_len < blk_end) ? t.text[cur + best_len] : br_unwritten_byte(P, t, cur + best_len);
+      same = cb == t.text[prev + best_len];
+    }
+    if (!same) continue;
+    // fix_unbroken_len, mod.rs:42-54
+    uint32_t len = unbroken;
+    if (brk != 0 && prev < brk && prev + unbroken > brk) len = brk - prev;
+    if (c < ndist) {
+      if (unbroken >= 3 || (unbroken == 2 && c < 2)) {
+        uint32_t score = P.score_per_byte * len + 30 * 8 * 8 + 15;  // mod.rs:1871-1876
+        if (best_score < score) {
+          if (c != 0) score -= 39u + ((0x1ca10u >> (c & 0xe)) & 0xe);  // mod.rs:1151-1154
+          if (best_score < score) {
+            best_score = score;
+            best_len = len;
+            out.len = len;
+            out.distance = cur - prev;
+            out.score = score;
+            out.found = true;
+          }
+        }
+      }
+    } else if (unbroken >= 4) {  // FindMatchLengthWithLimitMin4 != 0
+      const uint32_t backward = cur - prev;
+      const uint32_t score = 30 * 8 * 8 + P.score_per_byte * len - 30 * br_log2_floor_nonzero(backward);  // :1878-1889
+      if (best_score < score) {
+        best_score = score;
+        best_len = len;
+        out.len = len;
+        out.distance = backward;
+        out.score = score;
+        out.found = true;
+      }
+    }
+  }
+  BR_SYNC();
+  if (!out.found && P.use_dictionary) {
+    out.found = br_search_static_dictionary(P, t, ds, cur_data, max_length, max_backward, out);
+  }
+  return out;
+}
+
+// adv_prepare_distance_cache, mod.rs:632-651
+BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
+  if (ndist > 4) {
+    const int32_t last = dc[0];
+    dc[4] = last - 1;
+    dc[5] = last + 1;
+    dc[6] = last - 2;
+    dc[7] = last + 2;
+    dc[8] = last - 3;
+    dc[9] = last + 3;
+    if (ndist > 10) {
+      const int32_t next_last = dc[1];
+      dc[10] = next_last - 1;
+      dc[11] = next_last + 1;
+      dc[12] = next_last - 2;
+      dc[13] = next_last + 2;
+      dc[14] = next_last - 3;
+      dc[15] = next_last + 3;
+    }
+  }
+}
+
+struct FlagWriter {
+  const uint8_t* prev;
+  uint8_t* next;
+  uint32_t changes;  // per lane
+  uint32_t tail_lo;  // positions >= tail_lo inside the block get the stitch flag
+  uint8_t tail_value;
+  BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
+    if (BR_LANE == 0) {
+      changes += (prev[q] != v);
+      next[q] = v;
+    }
+  }
+  BR_DEV uint8_t unstored(uint32_t q) const { return q >= tail_lo ? tail_value : (uint8_t)0; }
+  // [a, b) := v for q < split, static "not stored by the main loop" value for q >= split
+  BR_DEV void range(uint32_t a, uint32_t b, uint32_t split) {
+    for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) {
+      const uint8_t v = q < split ? (uint8_t)1 : unstored(q);
+      changes += (prev[q] != v);
+      next[q] = v;
+    }
+  }
+};
+
+// One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
+BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment& seg,
+                             const SegEntry& entry, SegExit& exit_out) {
+  const uint32_t pos_end = seg.blk_end;
+  const uint32_t htl = P.htl;
+  const uint32_t window = P.spree_window;
+  uint32_t position = entry.pos;
+  uint32_t apply = entry.apply;
+  uint32_t insert_length = 0;  // literals carried in are added by the host fix-up (CmdPatch kind 2)
+  int32_t dc[16];
+  for (int i = 0; i < 4; ++i) dc[i] = entry.cache[i];
+  for (int i = 4; i < 16; ++i) dc[i] = 0;
+  DictState ds;
+  ds.lookups = ds.lookups0 = entry.dict_lookups;
+  ds.matches = ds.matches0 = entry.dict_matches;
+  ds.mode = 0;
+  ds.maxdef = -(1 << 30);
+  FlagWriter fw;
+  fw.prev = t.flags_prev;
+  fw.next = t.flags_next;
+  fw.changes = 0;
+  fw.tail_lo = pos_end - 3;
+  fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
+  uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0;
+  uint32_t last_dist_code = 0xffffffffu, last_copy_len = 0;
+  Command* cmds = t.cmds + (size_t)seg.cmd_base;
+
+  if (seg.flags & kSegFirstInBlock) {
+    position = seg.blk_start;
+    if (entry.ext_allowed) {
+      // extend_last_command, encode.rs:360-400: the previous copy continues while bytes keep matching
+      const uint32_t d = (uint32_t)dc[0];
+      uint32_t n = 0;
+      const uint32_t limit = pos_end - position;
+      // lane-parallel byte compare in strides of the wave width
+      for (;;) {
+        uint32_t step = limit - n;
+        if (step == 0) break;
+        const uint32_t m = br_match_len(t.text + position + n, t.text + position + n - d, step < 64 ? step : 64);
+        n += m;
+        if (m < 64) break;
+      }
+      ext_len = n;
+      fw.range(position, position + n, 0);
+      position += n;
+    }
+    apply = position + window;
+  }
+  const uint32_t num_bytes = pos_end - (seg.blk_start + ((seg.flags & kSegFirstInBlock) ? ext_len : 0));
+  (void)num_bytes;
+  // store_end, mod.rs:2397-2404.  For segments after the first one the extension length is unknown,
+  // but whenever (pos_end - start) < lookahead the loop below cannot run anyway.
+  const uint32_t store_end = pos_end >= htl ? pos_end - htl + 1 : 0;
+  br_prepare_distance_cache(dc, P.ndist);
+
+  while (position + htl < pos_end && position < seg.end) {
+    uint32_t max_length = pos_end - position;
+    SearchResult sr = br_find_longest_match(P, t, s, ds, position, dc, max_length, pos_end);
+    n_searches++;
+    if (sr.found) {
+      int delayed = 0;
+      bool next_probed;
+      max_length--;
+      for (;;) {
+        SearchResult sr2 = br_find_longest_match(P, t, s, ds, position + 1, dc, max_length, pos_end);
+        n_searches++;
+        next_probed = true;
+        if (sr2.found && sr2.score >= sr.score + 175) {
+          fw.one(position, 1);
+          position++;
+          insert_length++;
+          sr = sr2;
+          next_probed = false;
+          if (++delayed < 4 && position + htl < pos_end) {
+            max_length--;
+            continue;
+          }
+        }
+        break;
+      }
+      apply = position + 2 * sr.len + window;
+      const uint32_t max_distance = position < P.max_backward_limit ? position : P.max_backward_limit;
+      const uint32_t distance_code = br_compute_distance_code(sr.distance, max_distance, dc);
+      if (sr.distance <= max_distance && distance_code > 0) {
+        dc[3] = dc[2];
+        dc[2] = dc[1];
+        dc[1] = dc[0];
+        dc[0] = (int32_t)sr.distance;
+        if (n_pushes < 4) n_pushes++;
+        br_prepare_distance_cache(dc, P.ndist);
+      }
+      if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride) cmds[n_cmds] = br_make_command(t, insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
+      n_cmds++;
+      n_lits += insert_length;
+      insert_length = 0;
+      last_dist_code = distance_code;
+      last_copy_len = sr.len;
+      // hash-table side effects: position searched, position+1 only if probed, then StoreRange
+      fw.one(position, 1);
+      if (sr.len > 1) fw.one(position + 1, next_probed ? (uint8_t)1 : fw.unstored(position + 1));
+      if (sr.len > 2) fw.range(position + 2, position + sr.len, store_end);
+      position += sr.len;
+    } else {
+      fw.one(position, 1);
+      insert_length++;
+      position++;
+      if (position > apply) {
+        const uint32_t margin = htl - 1 > 4 ? htl - 1 : 4;
+        if (position + 16 >= pos_end - margin) {
+          fw.range(position, pos_end, 0);
+          insert_length += pos_end - position;
+          position = pos_end;
+        } else if (position > apply + 4 * window) {
+          // Store4Vec4: position, +4, +8, +12
+          for (uint32_t q = position + BR_LANE; q < position + 16; q += BR_NLANES) {
+            const uint8_t v = ((q - position) & 3) == 0;
+            fw.changes += (fw.prev[q] != v);
+            fw.next[q] = v;
+          }
+          insert_length += 16;
+          position += 16;
+        } else {
+          // StoreEvenVec4: position, +2, +4, +6
+          for (uint32_t q = position + BR_LANE; q < position + 8; q += BR_NLANES) {
+            const uint8_t v = ((q - position) & 1) == 0;
+            fw.changes += (fw.prev[q] != v);
+            fw.next[q] = v;
+          }
+          insert_length += 8;
+          position += 8;
+        }
+      }
+    }
+  }
+  if (seg.flags & kSegLastInBlock) {
+    if (position < pos_end) fw.range(position, pos_end, 0);
+    insert_length += pos_end - position;
+    position = pos_end;
+  }
+  // reduce the per-lane change counters
+  s.flag_changes[BR_LANE] = fw.changes;
+  BR_SYNC();
+  if (BR_LANE == 0) {
+    uint32_t total = 0;
+    for (int i = 0; i < BR_NLANES; ++i) total += s.flag_changes[i];
+    exit_out.pos = position;
+    exit_out.apply = apply;
+    for (int i = 0; i < 4; ++i) exit_out.cache[i] = dc[i];
+    exit_out.insert_len = insert_length;
+    exit_out.n_cmds = n_cmds;
+    exit_out.n_lits = n_lits;
+    exit_out.ext_len = ext_len;
+    exit_out.dict_lookups = ds.lookups;
+    exit_out.dict_matches = ds.matches;
+    exit_out.last_dist_code = last_dist_code;
+    exit_out.flag_changes = total;
+    exit_out.n_searches = n_searches;
+    exit_out.last_copy_len = last_copy_len;
+    exit_out.dict_mode = ds.mode;
+    exit_out.dict_maxdef = ds.maxdef;
+    exit_out.n_pushes = n_pushes;
+    exit_out.pad1 = 0;
+  }
+}
+
+}  // namespace brotli_mi355x
+#endif

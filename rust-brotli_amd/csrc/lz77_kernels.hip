@@ -1,0 +1,366 @@
+// lz77_kernels.hip -- gfx950 kernels of the backward-reference (LZ77) stage.
+//
+//   k_compute_keys      HashBytes of every position            (mod.rs:990-992, 1138-1140, 1521-1525)
+//   k_radix_*           stable LSD radix sort of positions by key (two 8-bit passes)
+//   k_rank_*            prefix sum of the "stored" flags in (key,pos) order -> rank / sorted / key_base
+//   k_parse_segments    one wavefront per segment: the speculative greedy/lazy parse (lz77_chain.h)
+//
+// All of this is integer/byte work bound by HBM/L2 latency and bandwidth; no MFMA.  Wave width is 64
+// (one wavefront per parse chain), LDS stages the per-search candidate records and the radix digit
+// counters.
+#include <hip/hip_runtime.h>
+#include <stdexcept>
+#include <string>
+
+#include "device_api.h"
+#include "lz77_chain.h"
+
+namespace brotli_mi355x {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define HIP_CHECK(x) hip_check((x), #x)
+
+// ------------------------------------------------------------------------------------------ keys
+__global__ __launch_bounds__(256) void k_compute_keys(const uint8_t* __restrict__ text, uint16_t* __restrict__ keys,
+                                                      uint32_t n, uint32_t valid_n, uint32_t kind, uint32_t bucket_bits,
+                                                      uint64_t hash_mask) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t key = 0xffffu;
+    if (i < valid_n) {
+      if (kind == 6) {
+        const uint64_t v = (br_load64(text + i) & hash_mask) * 0x1fe35a7bd3579bd3ull;
+        key = (uint32_t)(v >> (64 - bucket_bits));
+      } else {
+        const uint32_t v = br_load32(text + i) * 0x1e35a7bdu;
+        key = v >> (32 - bucket_bits);
+      }
+    }
+    keys[i] = (uint16_t)key;
+  }
+}
+
+void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  const uint32_t valid_n = n >= P.htl ? n - P.htl + 1 : 0;
+  const uint64_t hash_mask = P.hasher_kind == 6 ? (0xffffffffffffffffull >> (64 - 8 * P.hash_len)) : 0;
+  if (n == 0) return;
+  uint32_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_compute_keys, dim3(blocks), dim3(256), 0, 0, B.text, B.keys, n, valid_n, P.hasher_kind, P.bucket_bits,
+                     hash_mask);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ scan
+// exclusive prefix sum of a uint32 array (in place), hierarchical: 1024 elements per workgroup
+static constexpr uint32_t kScanTile = 1024;
+
+__global__ __launch_bounds__(256) void k_scan_tiles(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (base + j < n) ? data[base + j] : 0;
+  const uint32_t local = v[0] + v[1] + v[2] + v[3];
+  // inclusive scan across the wavefront (64 lanes) with DPP-free shuffles
+  uint32_t x = local;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_sum[w] = x;
+  __syncthreads();
+  uint32_t wave_off = 0;
+  for (int i = 0; i < w; ++i) wave_off += wave_sum[i];
+  uint32_t excl = wave_off + x - local;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (base + j < n) data[base + j] = excl;
+    excl += v[j];
+  }
+  if (threadIdx.x == 255 && tile_sums) tile_sums[blockIdx.x] = wave_off + x;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ tile_offsets) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  const uint32_t add = tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < n) data[base + j] += add;
+}
+
+// scratch must hold ceil(n/1024) + ceil(n/1024^2) + ... + 2 uint32
+static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* scratch) {
+  if (n == 0) return;
+  const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, 0, data, n, tiles > 1 ? scratch : (uint32_t*)nullptr);
+  if (tiles > 1) {
+    exclusive_scan_u32(scratch, tiles, scratch + tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(256), 0, 0, data, n, scratch);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ radix sort
+static constexpr uint32_t kSortTile = 4096;  // elements per workgroup (16 rounds of 256)
+
+__global__ __launch_bounds__(256) void k_radix_hist(const uint16_t* __restrict__ keys, uint32_t n, uint32_t shift,
+                                                     uint32_t num_tiles, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kSortTile;
+  for (uint32_t r = 0; r < 16; ++r) {
+    const uint32_t i = base + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter: elements keep their input order inside each digit
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                        uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+                                                        uint32_t shift, uint32_t num_tiles, const uint32_t* __restrict__ offsets) {
+  __shared__ uint32_t base[256];
+  __shared__ uint32_t wcount[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  base[tid] = offsets[tid * num_tiles + blockIdx.x];
+  const uint32_t tile_base = blockIdx.x * kSortTile;
+  for (uint32_t r = 0; r < 16; ++r) {
+    const uint32_t i = tile_base + r * 256 + tid;
+    const bool valid = i < n;
+    uint32_t key = 0, val = 0, d = 0;
+    if (valid) {
+      key = keys_in[i];
+      val = vals_in ? vals_in[i] : i;
+      d = (key >> shift) & 255u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wcount[w][lane * 4 + j] = 0;
+    __syncthreads();
+    // lanes of this wavefront that hold the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long b = __ballot(one);
+      peers &= one ? b : ~b;
+    }
+    const uint32_t rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank_in_wave == 0) wcount[w][d] = __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      uint32_t off = base[d] + rank_in_wave;
+      for (int i2 = 0; i2 < w; ++i2) off += wcount[i2][d];
+      keys_out[off] = (uint16_t)key;
+      vals_out[off] = val;
+    }
+    __syncthreads();
+    base[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
+    __syncthreads();
+  }
+}
+
+size_t lz77_sort_tmp_bytes(uint32_t total_bytes) {
+  const size_t n = total_bytes;
+  const size_t tiles = (n + kSortTile - 1) / kSortTile + 1;
+  // ping-pong keys + values, digit histograms, scan scratch
+  return n * 2 + n * 4 + tiles * 256 * 4 + (tiles * 256 / kScanTile + 1024) * 8 + (n / kScanTile + 1024) * 8 + 4096;
+}
+
+void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0) return;
+  const uint32_t tiles = (n + kSortTile - 1) / kSortTile;
+  uint8_t* tmp = (uint8_t*)B.sort_tmp;
+  uint16_t* keys_tmp = (uint16_t*)tmp;
+  tmp += ((size_t)n * 2 + 255) & ~(size_t)255;
+  uint32_t* vals_tmp = (uint32_t*)tmp;
+  tmp += ((size_t)n * 4 + 255) & ~(size_t)255;
+  uint32_t* hist = (uint32_t*)tmp;
+  tmp += (size_t)tiles * 256 * 4;
+  uint32_t* scratch = (uint32_t*)tmp;
+  // pass 1: low 8 bits, keys -> tmp
+  hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, 0, B.keys, n, 0u, tiles, hist);
+  exclusive_scan_u32(hist, tiles * 256, scratch);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, 0, B.keys, (const uint32_t*)nullptr, keys_tmp, vals_tmp, n, 0u, tiles,
+                     hist);
+  // pass 2: high 8 bits, tmp -> by_key / sorted_keys
+  hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, 0, keys_tmp, n, 8u, tiles, hist);
+  exclusive_scan_u32(hist, tiles * 256, scratch);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, 0, keys_tmp, vals_tmp, B.sorted_keys, B.by_key, n, 8u, tiles, hist);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ rank
+// tile sums of flags in (key,pos) order
+__global__ __launch_bounds__(256) void k_rank_tile_sums(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
+                                                         uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t local = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < n) local += flags[by_key[base + j]];
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+__global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__ by_key, const uint16_t* __restrict__ sorted_keys,
+                                                     const uint8_t* __restrict__ flags, uint32_t n, const uint32_t* __restrict__ tile_offsets,
+                                                     uint32_t* __restrict__ rank, uint32_t* __restrict__ sorted, uint32_t* __restrict__ key_base) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t pos[4], f[4];
+  uint32_t local = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    pos[j] = 0;
+    f[j] = 0;
+    if (base + j < n) {
+      pos[j] = by_key[base + j];
+      f[j] = flags[pos[j]];
+    }
+    local += f[j];
+  }
+  uint32_t x = local;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_sum[w] = x;
+  __syncthreads();
+  uint32_t g = tile_offsets[blockIdx.x] + x - local;
+  for (int i = 0; i < w; ++i) g += wave_sum[i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t i = base + j;
+    if (i < n) {
+      rank[pos[j]] = g;
+      if (f[j]) sorted[g] = pos[j];
+      const uint16_t k = sorted_keys[i];
+      if (i == 0 || sorted_keys[i - 1] != k) key_base[k] = g;
+      g += f[j];
+    }
+  }
+}
+
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0) return;
+  const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+  uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
+  uint32_t* scratch = tile_sums + tiles + 64;
+  hipLaunchKernelGGL(k_rank_tile_sums, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, tile_sums);
+  exclusive_scan_u32(tile_sums, tiles, scratch);
+  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.flags[which], n, tile_sums, B.rank, B.sorted,
+                     B.key_base);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ parse
+struct ParseArgs {
+  Lz77Params P;
+  ChainTables T;
+  const Segment* segments;
+  const SegEntry* entries;
+  SegExit* exits;
+  uint32_t first_segment;
+};
+
+__global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
+  __shared__ ChainScratch scratch;
+  const uint32_t k = a.first_segment + blockIdx.x;
+  if (k >= a.P.num_segments) return;
+  const Segment seg = a.segments[k];
+  const SegEntry entry = a.entries[k];
+  br_parse_segment(a.P, a.T, scratch, seg, entry, a.exits[k]);
+}
+
+void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
+  if (first_segment >= P.num_segments) return;
+  const DeviceTables& dt = dev_tables();
+  ParseArgs a;
+  a.P = P;
+  a.T.text = B.text;
+  a.T.keys = B.keys;
+  a.T.rank = B.rank;
+  a.T.key_base = B.key_base;
+  a.T.sorted = B.sorted;
+  a.T.flags_prev = B.flags[which];
+  a.T.flags_next = B.flags[which ^ 1];
+  a.T.cmds = B.cmds;
+  a.T.dict_hash = dt.dict_hash;
+  a.T.dict_data = dt.dict_data;
+  a.T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  a.T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  a.T.dist_postfix_bits = P.dist_postfix_bits;
+  a.T.num_direct_distance_codes = P.num_direct_distance_codes;
+  a.segments = B.segments;
+  a.entries = B.entries;
+  a.exits = B.exits;
+  a.first_segment = first_segment;
+  hipLaunchKernelGGL(k_parse_segments, dim3(P.num_segments - first_segment), dim3(64), 0, 0, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ misc
+__global__ __launch_bounds__(256) void k_sample_histogram(const uint8_t* __restrict__ text, uint32_t start, uint32_t samples,
+                                                           uint32_t* __restrict__ histo) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < samples; i += gridDim.x * blockDim.x)
+    atomicAdd(&h[text[start + i * 13u]], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&histo[threadIdx.x], h[threadIdx.x]);
+}
+
+void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev) {
+  HIP_CHECK(hipMemsetAsync(histo256_dev, 0, 256 * 4, 0));
+  const uint32_t samples = (bytes + 12) / 13;
+  uint32_t blocks = (samples + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(k_sample_histogram, dim3(blocks), dim3(256), 0, 0, text, start, samples, histo256_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_gather_commands(const Command* __restrict__ slabs, uint32_t stride, const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ counts, Command* __restrict__ out) {
+  const uint32_t k = blockIdx.x;
+  const uint32_t n = counts[k];
+  const uint4* src = (const uint4*)(slabs + (size_t)k * stride);
+  uint4* dst = (uint4*)(out + offsets[k]);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+void lz77_gather_commands(const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
+                          const uint32_t* counts_dev, Command* out) {
+  if (num_segments == 0) return;
+  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, 0, B.cmds, stride, offsets_dev, counts_dev, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(64) void k_patch_commands(Command* cmds, const CmdPatch* patches, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) br_apply_patch(cmds, patches[i]);
+}
+
+void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_patch_commands, dim3((n + 63) / 64), dim3(64), 0, 0, cmds, patches_dev, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace brotli_mi355x

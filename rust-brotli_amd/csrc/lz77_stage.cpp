@@ -1,0 +1,538 @@
+// lz77_stage.cpp -- see lz77_stage.h
+#include "lz77_stage.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+#include <string>
+
+#include "host_entropy.h"
+
+namespace brotli_mi355x {
+
+Lz77Stage::~Lz77Stage() { Release(); }
+
+void Lz77Stage::Release() {
+  if (owns_buffers_) {
+    dev_free(B_.keys);
+    dev_free(B_.by_key);
+    dev_free(B_.sorted_keys);
+    dev_free(B_.rank);
+    dev_free(B_.sorted);
+    dev_free(B_.key_base);
+    dev_free(B_.flags[0]);
+    dev_free(B_.flags[1]);
+    dev_free(B_.cmds);
+    dev_free(B_.segments);
+    dev_free(B_.entries);
+    dev_free(B_.exits);
+    dev_free(B_.sort_tmp);
+    dev_free(gathered_cmds_);
+    dev_free(histo_dev_);
+    dev_free(gather_offsets_dev_);
+    dev_free(gather_counts_dev_);
+  }
+  owns_buffers_ = false;
+  gathered_cmds_ = nullptr;
+}
+
+void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t prefix_bytes, uint32_t input_bytes,
+                      uint32_t raw_head_bytes, uint32_t segment_bytes) {
+  Release();
+  params_ = params;
+  input_bytes_ = input_bytes;
+  raw_head_bytes_ = raw_head_bytes;
+  block_bytes_ = 1u << params.lgblock;
+  segment_bytes_ = std::min(std::max(segment_bytes, 256u), block_bytes_);
+  memset(&P_, 0, sizeof(P_));
+  P_.total_bytes = prefix_bytes + input_bytes;
+  P_.prefix_bytes = prefix_bytes;
+  P_.ring_mask = (1u << ComputeRbBits(params)) - 1u;
+  P_.max_backward_limit = (1u << params.lgwin) - 16u;
+  P_.hasher_kind = params.hasher.type == 5 ? 5 : 6;
+  P_.bucket_bits = (uint32_t)params.hasher.bucket_bits;
+  P_.block_bits = (uint32_t)params.hasher.block_bits;
+  P_.hash_len = (uint32_t)params.hasher.hash_len;
+  P_.ndist = (uint32_t)params.hasher.num_last_distances_to_check;
+  P_.htl = P_.hasher_kind == 6 ? 8 : 4;
+  P_.score_per_byte = (uint32_t)(params.hasher.literal_byte_score ? params.hasher.literal_byte_score : 540) >> 2;
+  P_.use_dictionary = params.use_dictionary ? 1 : 0;
+  P_.spree_window = params.quality < 9 ? 64 : 512;
+  P_.dist_max_distance = (uint32_t)params.dist.max_distance;
+  P_.quality = (uint32_t)params.quality;
+  P_.dist_postfix_bits = params.dist.distance_postfix_bits;
+  P_.num_direct_distance_codes = params.dist.num_direct_distance_codes;
+  P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
+  BuildSegments();
+  P_.num_segments = (uint32_t)segments_.size();
+
+  const size_t M = P_.total_bytes;
+  B_ = Lz77Buffers{};
+  B_.text = text_dev;
+  B_.keys = (uint16_t*)dev_alloc(M * 2 + 64);
+  B_.by_key = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.sorted_keys = (uint16_t*)dev_alloc(M * 2 + 64);
+  B_.rank = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.sorted = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
+  B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
+  B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
+  B_.cmds = (Command*)dev_alloc((size_t)segments_.size() * P_.cmd_slab_stride * sizeof(Command) + 64);
+  B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
+  B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
+  B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
+  B_.sort_tmp_bytes = lz77_sort_tmp_bytes(P_.total_bytes);
+  B_.sort_tmp = dev_alloc(B_.sort_tmp_bytes);
+  histo_dev_ = (uint32_t*)dev_alloc(256 * 4);
+  gather_offsets_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+  gather_counts_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+  owns_buffers_ = true;
+  dev_h2d(B_.segments, segments_.data(), segments_.size() * sizeof(Segment));
+}
+
+void Lz77Stage::BuildSegments() {
+  segments_.clear();
+  const uint32_t P0 = P_.prefix_bytes;
+  const uint32_t end = P_.total_bytes;
+  const uint32_t htl = P_.htl;
+  // block geometry: compress_stream hands the encoder at most one full input block at a time
+  // (encode.rs:2940-2964); the catable raw head belongs to the first block but is not searched.
+  std::vector<std::pair<uint32_t, uint32_t>> blocks;
+  for (uint64_t off = 0; off < input_bytes_; off += block_bytes_) {
+    uint32_t bs = P0 + (uint32_t)off;
+    uint32_t be = (uint32_t)std::min<uint64_t>(end, (uint64_t)P0 + off + block_bytes_);
+    if (off == 0) bs = std::min(be, bs + raw_head_bytes_);
+    blocks.emplace_back(bs, be);
+  }
+  uint32_t cmd_base = 0;
+  for (size_t b = 0; b < blocks.size(); ++b) {
+    const uint32_t bs = blocks[b].first, be = blocks[b].second;
+    bool stitched = false;
+    if (b + 1 < blocks.size()) {
+      const uint32_t nbytes = blocks[b + 1].second - blocks[b + 1].first;
+      stitched = nbytes >= htl - 1 && blocks[b + 1].first >= 3;  // StitchToPreviousBlockInternal, mod.rs:210-222
+    }
+    uint32_t s = bs;
+    bool first = true;
+    do {
+      const uint32_t e = std::min(be, s + segment_bytes_);
+      Segment g;
+      g.start = s;
+      g.end = e;
+      g.blk_start = bs;
+      g.blk_end = be;
+      g.flags = (first ? kSegFirstInBlock : 0u) | (e == be ? kSegLastInBlock : 0u) | (stitched ? kSegTailStitched : 0u);
+      g.cmd_base = cmd_base;
+      g.block_index = (uint32_t)b;
+      g.pad = 0;
+      cmd_base += P_.cmd_slab_stride;
+      segments_.push_back(g);
+      first = false;
+      s = e;
+    } while (s < be);
+  }
+}
+
+// First guess of the "stored" flags: every position is in the hash table except the ones the
+// reference never stores (positions at or after store_end that the next block's stitch skips).
+void Lz77Stage::InitFlags() {
+  const uint32_t M = P_.total_bytes, P0 = P_.prefix_bytes, htl = P_.htl;
+  std::vector<uint8_t> f(M + 64, 0);
+  if (P0 > htl - 1) memset(f.data(), 1, P0 - (htl - 1));  // StoreLookaheadThenStore, mod.rs:224-229
+  uint32_t prev_block = 0xffffffffu;
+  for (const Segment& g : segments_) {
+    if (g.block_index == prev_block) continue;
+    prev_block = g.block_index;
+    const uint32_t bs = g.blk_start, be = g.blk_end;
+    if (g.block_index == 0 && be - bs >= htl - 1 && bs >= 3) {
+      f[bs - 3] = f[bs - 2] = f[bs - 1] = 1;  // stitch at the first block (prefix / raw head tail)
+    }
+    if (be > bs) memset(f.data() + bs, 1, be - bs);
+    const uint32_t store_end = (be - bs >= htl) ? be - htl + 1 : bs;
+    for (uint32_t q = store_end; q < be; ++q) f[q] = (q + 3 >= be && (g.flags & kSegTailStitched)) ? 1 : 0;
+  }
+  dev_h2d(B_.flags[0], f.data(), M + 64);
+  dev_h2d(B_.flags[1], f.data(), M + 64);
+  dev_sync();
+}
+
+static bool DictEntryCompatible(const SegEntry& used, const SegExit& x, uint32_t L, uint32_t M) {
+  if (used.dict_lookups == L && used.dict_matches == M) return true;
+  switch (x.dict_mode) {
+    case 0: return true;
+    case 1: return 128ll * (int64_t)M - (int64_t)L + 127 >= (int64_t)x.dict_maxdef;
+    case 2: return M < (L >> 7);
+    default: return false;
+  }
+}
+
+// Chains the exits of the last parse into the entries of the next one, replaying the per-block
+// control flow of encode_data (encode.rs:2214-2543).  Returns true when every entry that the last
+// parse used equals the entry derived here (i.e. the parse is self-consistent).
+bool Lz77Stage::Resolve(bool final_pass) {
+  const uint32_t nseg = (uint32_t)segments_.size();
+  next_entries_.assign(nseg, SegEntry{});
+  metablocks_.clear();
+  patches_.clear();
+  trailing_.clear();
+  carries_.clear();
+  bool consistent = true;
+  first_dirty_ = nseg;
+  auto mark = [&](uint32_t k, bool same) {
+    if (!same) {
+      consistent = false;
+      if (k < first_dirty_) first_dirty_ = k;
+    }
+  };
+
+  int32_t cache[4] = {4, 11, 15, 16};
+  if (params_.catable) {
+    for (int i = 0; i < 4; ++i) cache[i] = 0x7ffffff0;  // encode.rs:693-703
+  }
+  int32_t saved_cache[4];
+  memcpy(saved_cache, cache, sizeof(cache));
+  uint32_t last_insert_len = 0;
+  uint64_t num_commands = 0, num_literals = 0;
+  uint32_t last_flush_pos = P_.prefix_bytes + raw_head_bytes_;
+  uint32_t dictL = 0, dictM = 0;
+  struct LastCmd {
+    bool valid = false;
+    uint32_t seg = 0, idx = 0, dist_code = 0, copy_len = 0;
+  } last_cmd;
+  uint32_t mb_first_seg = 0;
+  uint64_t mb_cmds = 0;
+  const size_t max_mb = MaxMetablockSize(params_);
+  const size_t max_literals = max_mb / 8, max_commands = max_mb / 8;
+  (void)final_pass;
+  std::map<std::pair<uint32_t, uint32_t>, bool>& should_compress_cache = should_compress_cache_;
+
+  uint32_t k = 0;
+  while (k < nseg) {
+    const uint32_t k0 = k;
+    const Segment& g0 = segments_[k0];
+    const uint32_t bs = g0.blk_start, be = g0.blk_end;
+    uint32_t k1 = k0;
+    while (!(segments_[k1].flags & kSegLastInBlock)) ++k1;
+    // ---- entry of the block
+    SegEntry E{};
+    E.pos = bs;
+    E.apply = 0;
+    memcpy(E.cache, cache, sizeof(cache));
+    E.insert_len = last_insert_len;
+    E.ext_allowed = 0;
+    if (num_commands != 0 && last_insert_len == 0 && last_cmd.valid) {
+      const uint64_t cmd_dist = (uint64_t)(int64_t)cache[0];
+      if (last_cmd.dist_code < 16 || (uint64_t)last_cmd.dist_code - 15 == cmd_dist) {
+        const uint64_t lpp = (uint64_t)bs - last_cmd.copy_len;
+        const uint64_t max_distance = std::min<uint64_t>(lpp, P_.max_backward_limit);
+        if (cmd_dist <= max_distance) E.ext_allowed = 1;
+      }
+    }
+    E.dict_lookups = dictL;
+    E.dict_matches = dictM;
+    {
+      const SegEntry& u = entries_[k0];
+      bool same = memcmp(u.cache, E.cache, sizeof(E.cache)) == 0 && u.ext_allowed == E.ext_allowed && DictEntryCompatible(u, exits_[k0], dictL, dictM);
+      mark(k0, same);
+    }
+    next_entries_[k0] = E;
+    // ---- chain through the segments of the block
+    uint32_t curL = dictL, curM = dictM;
+    uint32_t carry = last_insert_len;  // literals pending when the segment is entered
+    int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
+    memcpy(cur_cache, cache, sizeof(cache));
+    for (uint32_t j = k0; j <= k1; ++j) {
+      const SegExit& X = exits_[j];
+      const SegEntry& used = entries_[j];
+      const uint32_t outL = curL + (X.dict_lookups - used.dict_lookups);
+      const uint32_t outM = curM + (X.dict_matches - used.dict_matches);
+      // Exit cache = the segment's own pushes on top of its entry cache.  When the entry cache derived in
+      // this pass differs from the one the chain used, keep the pushes and swap the inherited tail: the
+      // chain is re-run with the new entry anyway, this only lets a change travel through segments that
+      // merely pass the cache along in one round instead of one segment per round.
+      int32_t out_cache[4];
+      for (uint32_t i = 0; i < 4; ++i) out_cache[i] = i < X.n_pushes ? X.cache[i] : cur_cache[i - X.n_pushes];
+      if (j == k0 && X.ext_len > 0 && last_cmd.valid) {
+        if (!patches_.empty() && patches_.back().segment == last_cmd.seg && patches_.back().index == last_cmd.idx) {
+          patches_.back().ext += X.ext_len;
+        } else {
+          patches_.push_back({last_cmd.seg, last_cmd.idx, X.ext_len});
+        }
+        last_cmd.copy_len += X.ext_len;
+      }
+      num_commands += X.n_cmds;
+      mb_cmds += X.n_cmds;
+      num_literals += X.n_lits;
+      if (X.n_cmds > 0) {
+        if (carry != 0) {
+          carries_.push_back({j, carry});
+          num_literals += carry;
+        }
+        carry = X.insert_len;
+      } else {
+        carry += X.insert_len;
+      }
+      if (X.n_cmds > 0) {
+        last_cmd.valid = true;
+        last_cmd.seg = j;
+        last_cmd.idx = X.n_cmds - 1;
+        last_cmd.dist_code = X.last_dist_code;
+        last_cmd.copy_len = X.last_copy_len;
+      }
+      if (j < k1) {
+        SegEntry N{};
+        N.pos = X.pos;
+        N.apply = X.apply;
+        memcpy(N.cache, out_cache, sizeof(N.cache));
+        N.insert_len = carry;
+        N.ext_allowed = 0;
+        N.dict_lookups = outL;
+        N.dict_matches = outM;
+        const SegEntry& u = entries_[j + 1];
+        bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0 &&
+                    DictEntryCompatible(u, exits_[j + 1], outL, outM);
+        if (!same && getenv("BROTLI_MI355X_DEBUG2") && j + 1 < first_dirty_) fprintf(stderr, "  seg %u: pos %u/%u apply %u/%u cache %d/%d dict %u,%u/%u,%u mode %u\n", j + 1, u.pos, N.pos, u.apply, N.apply, u.cache[0], N.cache[0], u.dict_lookups, u.dict_matches, outL, outM, exits_[j + 1].dict_mode);
+        mark(j + 1, same);
+        next_entries_[j + 1] = N;
+      }
+      curL = outL;
+      curM = outM;
+      memcpy(cur_cache, out_cache, sizeof(cur_cache));
+    }
+    memcpy(cache, cur_cache, sizeof(cache));
+    last_insert_len = carry;
+    dictL = curL;
+    dictM = curM;
+    // ---- meta-block flush rule, encode.rs:2454-2483
+    const bool is_last = (k1 + 1 == nseg);
+    const size_t processed_bytes = be - last_flush_pos;
+    const bool next_fits = processed_bytes + block_bytes_ <= max_mb;
+    if (!is_last && next_fits && num_literals < max_literals && num_commands < max_commands) {
+      k = k1 + 1;
+      continue;
+    }
+    MetaBlockPlan mb{};
+    if (last_insert_len > 0) {
+      trailing_.push_back({k1, last_insert_len});
+      num_commands++;
+      mb_cmds++;
+      num_literals += last_insert_len;
+      last_insert_len = 0;
+    }
+    mb.start = last_flush_pos;
+    mb.end = be;
+    mb.n_cmds = (uint32_t)mb_cmds;
+    mb.n_literals = (uint32_t)num_literals;
+    mb.is_last = is_last;
+    mb.cmd_offset = mb_first_seg;  // temporarily: first segment; turned into a command offset by Gather()
+    memcpy(mb.saved_dist_cache, saved_cache, sizeof(saved_cache));
+    // should_compress, encode.rs:1325-1354
+    const uint32_t bytes = mb.end - mb.start;
+    bool compress = true;
+    if (num_commands < (uint64_t)(bytes >> 8) + 2 && (float)num_literals > 0.99f * (float)bytes) {
+      auto key = std::make_pair(mb.start, bytes);
+      auto it = should_compress_cache.find(key);
+      if (it == should_compress_cache.end()) {
+        uint32_t histo[256];
+        lz77_sample_histogram(B_.text, mb.start, bytes, histo_dev_);
+        dev_d2h(histo, histo_dev_, sizeof(histo));
+        const float threshold = (float)bytes * 7.92f / 13.0f;
+        const bool c = !(HostBitsEntropy(histo, 256) > threshold);
+        it = should_compress_cache.emplace(key, c).first;
+      }
+      compress = it->second;
+    }
+    if (std::find(forced_uncompressed_.begin(), forced_uncompressed_.end(), (uint32_t)metablocks_.size()) !=
+        forced_uncompressed_.end())
+      compress = false;
+    mb.uncompressed = !compress;
+    if (!compress) memcpy(cache, saved_cache, sizeof(cache));  // encode.rs:1994, 2142
+    memcpy(mb.dist_cache_after, cache, sizeof(cache));
+    metablocks_.push_back(mb);
+    memcpy(saved_cache, cache, sizeof(cache));
+    num_commands = 0;
+    num_literals = 0;
+    mb_cmds = 0;
+    last_cmd.valid = false;
+    last_flush_pos = be;
+    mb_first_seg = k1 + 1;
+    k = k1 + 1;
+  }
+  return consistent;
+}
+
+void Lz77Stage::Run() {
+  stats_ = Lz77Stats{};
+  should_compress_cache_.clear();
+  const uint32_t nseg = (uint32_t)segments_.size();
+  if (nseg == 0) {
+    metablocks_.clear();
+    total_cmds_ = 0;
+    return;
+  }
+  lz77_compute_keys(P_, B_);
+  lz77_sort_by_key(P_, B_);
+  InitFlags();
+  const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
+  if (selftest) SelfTestSort();
+  // first guess of the entries: every chain starts at its segment start with the default cache
+  entries_.assign(nseg, SegEntry{});
+  for (uint32_t k = 0; k < nseg; ++k) {
+    SegEntry& e = entries_[k];
+    e.pos = segments_[k].start;
+    e.apply = segments_[k].start + P_.spree_window;
+    const int32_t d[4] = {4, 11, 15, 16};
+    for (int i = 0; i < 4; ++i) e.cache[i] = params_.catable ? 0x7ffffff0 : d[i];
+  }
+  exits_.assign(nseg, SegExit{});
+  int which = 0;
+  uint32_t first = 0;
+  const uint32_t max_rounds = nseg + 8;
+  bool done = false;
+  for (uint32_t round = 0; round < max_rounds && !done; ++round) {
+    stats_.rounds++;
+    dev_h2d(B_.entries + first, entries_.data() + first, (size_t)(nseg - first) * sizeof(SegEntry));
+    lz77_rank_flags(P_, B_, which);
+    if (selftest && round == 0) SelfTestRank(which);
+    dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+    lz77_parse_round(P_, B_, which, first);
+    stats_.segments_parsed += nseg - first;
+    dev_d2h(exits_.data() + first, B_.exits + first, (size_t)(nseg - first) * sizeof(SegExit));
+    const bool consistent = Resolve(false);
+    uint32_t first_flag_change = nseg;
+    for (uint32_t k = first; k < nseg; ++k) {
+      if (exits_[k].flag_changes != 0) {
+        first_flag_change = k;
+        break;
+      }
+    }
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u first=%u dirty=%u flagchg=%u consistent=%d\n", round, first, first_dirty_, first_flag_change, (int)consistent);
+    if (consistent && first_flag_change == nseg) {
+      done = true;
+      break;
+    }
+    // everything before the first inconsistency / changed flag is final
+    first = std::min(first_dirty_, first_flag_change);
+    for (uint32_t k = first; k < nseg; ++k) entries_[k] = next_entries_[k];
+    which ^= 1;
+  }
+  if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
+  for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
+  Gather();
+}
+
+// Bring-up checks of the sort / rank kernels against a host recomputation (BROTLI_MI355X_SELFTEST=1).
+void Lz77Stage::SelfTestSort() {
+  const uint32_t n = P_.total_bytes;
+  std::vector<uint16_t> keys(n), skeys(n);
+  std::vector<uint32_t> by_key(n);
+  dev_sync();
+  dev_d2h(keys.data(), B_.keys, (size_t)n * 2);
+  dev_d2h(skeys.data(), B_.sorted_keys, (size_t)n * 2);
+  dev_d2h(by_key.data(), B_.by_key, (size_t)n * 4);
+  std::vector<uint8_t> seen(n, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t p = by_key[i];
+    if (p >= n || seen[p]) throw std::runtime_error("selftest: by_key is not a permutation at slot " + std::to_string(i));
+    seen[p] = 1;
+    if (skeys[i] != keys[p]) throw std::runtime_error("selftest: sorted_keys mismatch at slot " + std::to_string(i));
+    if (i > 0) {
+      if (skeys[i - 1] > skeys[i]) throw std::runtime_error("selftest: keys not ascending at slot " + std::to_string(i));
+      if (skeys[i - 1] == skeys[i] && by_key[i - 1] >= p)
+        throw std::runtime_error("selftest: sort not stable at slot " + std::to_string(i));
+    }
+  }
+}
+
+void Lz77Stage::SelfTestRank(int which) {
+  const uint32_t n = P_.total_bytes;
+  std::vector<uint16_t> skeys(n);
+  std::vector<uint32_t> by_key(n), rank(n), sorted(n), key_base(65537);
+  std::vector<uint8_t> flags(n);
+  dev_sync();
+  dev_d2h(skeys.data(), B_.sorted_keys, (size_t)n * 2);
+  dev_d2h(by_key.data(), B_.by_key, (size_t)n * 4);
+  dev_d2h(rank.data(), B_.rank, (size_t)n * 4);
+  dev_d2h(sorted.data(), B_.sorted, (size_t)n * 4);
+  dev_d2h(key_base.data(), B_.key_base, 65537 * 4);
+  dev_d2h(flags.data(), B_.flags[which], n);
+  uint32_t g = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t p = by_key[i];
+    if (rank[p] != g) throw std::runtime_error("selftest: rank mismatch at slot " + std::to_string(i));
+    if (i == 0 || skeys[i - 1] != skeys[i]) {
+      if (key_base[skeys[i]] != g) throw std::runtime_error("selftest: key_base mismatch for key " + std::to_string(skeys[i]));
+    }
+    if (flags[p]) {
+      if (sorted[g] != p) throw std::runtime_error("selftest: sorted mismatch at rank " + std::to_string(g));
+      g++;
+    }
+  }
+}
+
+void Lz77Stage::Gather() {
+  const uint32_t nseg = (uint32_t)segments_.size();
+  std::vector<uint32_t> offsets(nseg), counts(nseg);
+  std::vector<CmdPatch> fix;
+  size_t t = 0, ti = 0;
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nseg; ++k) {
+    offsets[k] = (uint32_t)total;
+    counts[k] = exits_[k].n_cmds;
+    total += exits_[k].n_cmds;
+    while (ti < trailing_.size() && trailing_[ti].after_segment == k) {
+      CmdPatch p{};
+      p.index = (uint32_t)total;
+      p.kind = 1;
+      p.value = trailing_[ti].insert_len;
+      fix.push_back(p);
+      total++;
+      ti++;
+    }
+  }
+  (void)t;
+  for (const Carry& c : carries_) {
+    CmdPatch p{};
+    p.index = offsets[c.segment];
+    p.kind = 2;
+    p.value = c.literals;
+    fix.push_back(p);
+  }
+  for (const Patch& pt : patches_) {
+    CmdPatch p{};
+    p.index = offsets[pt.segment] + pt.index;
+    p.kind = 0;
+    p.value = pt.ext;
+    fix.push_back(p);
+  }
+  total_cmds_ = total;
+  stats_.total_commands = total;
+  // meta-block command offsets
+  for (MetaBlockPlan& mb : metablocks_) {
+    const uint32_t first_seg = mb.cmd_offset;
+    mb.cmd_offset = first_seg < nseg ? offsets[first_seg] : (uint32_t)total;
+  }
+  if (gathered_capacity_ < total + 16) {
+    dev_free(gathered_cmds_);
+    gathered_capacity_ = total + total / 8 + 1024;
+    gathered_cmds_ = (Command*)dev_alloc(gathered_capacity_ * sizeof(Command));
+  }
+  dev_h2d(gather_offsets_dev_, offsets.data(), nseg * 4);
+  dev_h2d(gather_counts_dev_, counts.data(), nseg * 4);
+  lz77_gather_commands(B_, nseg, P_.cmd_slab_stride, gather_offsets_dev_, gather_counts_dev_, gathered_cmds_);
+  if (!fix.empty()) {
+    CmdPatch* fix_dev = (CmdPatch*)dev_alloc(fix.size() * sizeof(CmdPatch));
+    dev_h2d(fix_dev, fix.data(), fix.size() * sizeof(CmdPatch));
+    lz77_patch_commands(gathered_cmds_, fix_dev, (uint32_t)fix.size());
+    dev_sync();
+    dev_free(fix_dev);
+  }
+  dev_sync();
+}
+
+}  // namespace brotli_mi355x

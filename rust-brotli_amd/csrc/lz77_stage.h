@@ -1,0 +1,116 @@
+// lz77_stage.h -- host orchestration of the backward-reference search on the device.
+//
+// Replaces, for one complete stream, the per-block calls the reference makes from encode_data():
+//   InitOrStitchToPreviousBlock (encode.rs:2417), extend_last_command (:2435),
+//   BrotliCreateBackwardReferences (:2438) and the meta-block flush rule (:2454-2483),
+// and produces exactly the command list the reference would produce, by speculative parallel
+// parsing + a host "resolver" that chains segment exits to entries until a fixed point is reached.
+#ifndef BROTLI_MI355X_LZ77_STAGE_H_
+#define BROTLI_MI355X_LZ77_STAGE_H_
+
+#include <stdint.h>
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "device_api.h"
+#include "encoder_params.h"
+
+namespace brotli_mi355x {
+
+struct MetaBlockPlan {
+  uint32_t start;       // last_flush_pos (position in text)
+  uint32_t end;         // input_pos at the flush
+  uint32_t cmd_offset;  // into the gathered command array
+  uint32_t n_cmds;      // including the trailing insert-only command, if any
+  uint32_t n_literals;
+  bool uncompressed;    // should_compress() == false (encode.rs:1325-1354) or forced by the size fallback
+  bool is_last;
+  int32_t dist_cache_after[4];
+  int32_t saved_dist_cache[4];  // dist cache at the start of the meta-block (for IR-free storing)
+};
+
+struct Lz77Stats {
+  uint32_t rounds = 0;
+  uint64_t segments_parsed = 0;
+  uint64_t searches = 0;
+  uint64_t total_commands = 0;
+};
+
+class Lz77Stage {
+ public:
+  Lz77Stage() = default;
+  ~Lz77Stage();
+  Lz77Stage(const Lz77Stage&) = delete;
+  Lz77Stage& operator=(const Lz77Stage&) = delete;
+
+  // params must be finalized (FinalizeParams + ChooseHasher).  text_dev holds prefix_bytes of
+  // custom dictionary followed by input_bytes of input, plus >= 64 readable zero bytes.
+  // raw_head_bytes: bytes at the start of the input that the caller stores uncompressed before the
+  // first block is searched (catable streams: 2, encode.rs:2283-2333).
+  void Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t prefix_bytes, uint32_t input_bytes,
+             uint32_t raw_head_bytes, uint32_t segment_bytes);
+  // forces meta-block `index` (and only it) to be stored uncompressed in the next Run (size fallback,
+  // encode.rs:2141-2163)
+  void ForceUncompressed(uint32_t index) { forced_uncompressed_.push_back(index); }
+  void Run();
+
+  const std::vector<MetaBlockPlan>& metablocks() const { return metablocks_; }
+  Command* commands_dev() const { return gathered_cmds_; }
+  uint32_t num_commands() const { return (uint32_t)total_cmds_; }
+  const Lz77Stats& stats() const { return stats_; }
+  const Lz77Params& device_params() const { return P_; }
+  const uint8_t* text_dev() const { return B_.text; }
+
+ private:
+  void BuildSegments();
+  void InitFlags();
+  bool Resolve(bool final_pass);
+  void Gather();
+  void SelfTestSort();
+  void SelfTestRank(int which);
+  void Release();
+
+  EncoderParams params_;
+  Lz77Params P_{};
+  Lz77Buffers B_{};
+  uint32_t input_bytes_ = 0;
+  uint32_t raw_head_bytes_ = 0;
+  uint32_t segment_bytes_ = 4096;
+  uint32_t block_bytes_ = 65536;
+  std::vector<Segment> segments_;
+  std::vector<SegEntry> entries_;   // entries used by the most recent parse
+  std::vector<SegEntry> next_entries_;
+  std::vector<SegExit> exits_;
+  std::vector<MetaBlockPlan> metablocks_;
+  std::vector<uint32_t> forced_uncompressed_;
+  struct Patch {
+    uint32_t segment;  // segment holding the command to patch
+    uint32_t index;    // index inside that segment's slab
+    uint32_t ext;      // copy length to add (extend_last_command)
+  };
+  std::vector<Patch> patches_;
+  struct TrailingInsert {
+    uint32_t after_segment;  // inserted after the commands of this segment
+    uint32_t insert_len;
+  };
+  std::vector<TrailingInsert> trailing_;
+  struct Carry {
+    uint32_t segment;   // first command of this segment ...
+    uint32_t literals;  // ... gets this many extra literals in front
+  };
+  std::vector<Carry> carries_;
+  Command* gathered_cmds_ = nullptr;
+  size_t gathered_capacity_ = 0;
+  size_t total_cmds_ = 0;
+  uint32_t* histo_dev_ = nullptr;
+  uint32_t* gather_offsets_dev_ = nullptr;
+  uint32_t* gather_counts_dev_ = nullptr;
+  Lz77Stats stats_;
+  std::map<std::pair<uint32_t, uint32_t>, bool> should_compress_cache_;
+  uint32_t first_dirty_ = 0;
+  bool owns_buffers_ = false;
+};
+
+}  // namespace brotli_mi355x
+#endif

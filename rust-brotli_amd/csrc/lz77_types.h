@@ -1,0 +1,109 @@
+// lz77_types.h -- plain-old-data shared by the host driver and the HIP kernels of the LZ77 stage.
+//
+// Domain vocabulary follows the reference (rust-brotli): "block" = one input block of 1<<lgblock
+// bytes handed to BrotliCreateBackwardReferences (src/enc/encode.rs:2438), "command" = one
+// insert&copy record (src/enc/command.rs:12-21), "dist cache" = the 4 last distances.
+// New here: "segment" = a slice of a block that one wavefront parses speculatively ("chain").
+#ifndef BROTLI_MI355X_LZ77_TYPES_H_
+#define BROTLI_MI355X_LZ77_TYPES_H_
+
+#include <stdint.h>
+
+namespace brotli_mi355x {
+
+// src/enc/command.rs:12-21 (16 bytes)
+struct Command {
+  uint32_t insert_len_;
+  uint32_t copy_len_;   // low 25 bits copy length, high 7 bits (copy_code - copy_len)
+  uint32_t dist_extra_;
+  uint16_t cmd_prefix_;
+  uint16_t dist_prefix_;  // low 10 bits distance code, high 6 bits number of extra bits
+};
+
+// Per-job constants of the backward-reference search (H5 / H5q5 / H6 AdvHasher family,
+// src/enc/backward_references/mod.rs:919-1813, parameters chosen by encode.rs:834-893).
+struct Lz77Params {
+  uint32_t total_bytes;         // M: dictionary prefix + input, positions are offsets into this text
+  uint32_t prefix_bytes;        // custom-dictionary prefix (ring_buffer_break), 0 = none
+  uint32_t ring_mask;           // (1 << (1 + max(lgwin, lgblock))) - 1   (encode.rs:587-601)
+  uint32_t max_backward_limit;  // (1 << lgwin) - 16                      (mod.rs:2393)
+  uint32_t hasher_kind;         // 5 = 32-bit hash of 4 bytes, 6 = 64-bit hash of hash_len bytes
+  uint32_t bucket_bits;
+  uint32_t block_bits;          // ring depth per key = 1 << block_bits
+  uint32_t hash_len;            // H6 only
+  uint32_t ndist;               // num_last_distances_to_check (4, 10 or 16)
+  uint32_t htl;                 // HashTypeLength == StoreLookahead (4 or 8)
+  uint32_t score_per_byte;      // literal_byte_score >> 2 (135)
+  uint32_t use_dictionary;      // static dictionary allowed (params.use_dictionary)
+  uint32_t spree_window;        // LiteralSpreeLengthForSparseSearch: 64 (q<9) or 512
+  uint32_t dist_max_distance;   // params.dist.max_distance
+  uint32_t quality;
+  uint32_t num_segments;
+  uint32_t cmd_slab_stride;     // commands reserved per segment
+  uint32_t dist_postfix_bits;   // params.dist (encode.rs:2169-2190)
+  uint32_t num_direct_distance_codes;
+  uint32_t reserved;
+};
+
+enum SegmentFlags : uint32_t {
+  kSegFirstInBlock = 1u,
+  kSegLastInBlock = 2u,
+  kSegTailStitched = 4u,  // next block's StitchToPreviousBlock will store blk_end-3..blk_end-1
+};
+
+// Static geometry of one segment.
+struct Segment {
+  uint32_t start;      // first position owned (loop-top positions >= start belong here)
+  uint32_t end;        // one past
+  uint32_t blk_start;  // start of the enclosing input block (before extend_last_command)
+  uint32_t blk_end;    // pos_end of the enclosing block
+  uint32_t flags;
+  uint32_t cmd_base;   // index of this segment's command slab
+  uint32_t block_index;
+  uint32_t pad;
+};
+
+// Parse state handed to a chain when it starts (speculated, then confirmed by the host resolver).
+struct SegEntry {
+  uint32_t pos;         // loop-top position where the true parse enters this segment
+  uint32_t apply;       // apply_random_heuristics (mod.rs:2407, 2492)
+  int32_t cache[4];     // dist_cache[0..3]
+  uint32_t insert_len;  // informational: pending literals carried in (not used by the chain)
+  uint32_t ext_allowed; // first-in-block only: extend_last_command may run (encode.rs:2435-2437)
+  uint32_t dict_lookups;  // static-dictionary throttle counters at entry (mod.rs:1957-1960)
+  uint32_t dict_matches;
+  uint32_t ext_max_distance;  // max_distance for extend_last_command
+  uint32_t pad;
+};
+
+struct SegExit {
+  uint32_t pos;
+  uint32_t apply;
+  int32_t cache[4];
+  uint32_t insert_len;
+  uint32_t n_cmds;
+  uint32_t n_lits;          // sum of the LOCAL insert lengths of the emitted commands (carry-in excluded)
+  uint32_t ext_len;         // bytes consumed by extend_last_command (first-in-block)
+  uint32_t dict_lookups;    // counters at exit
+  uint32_t dict_matches;
+  uint32_t last_dist_code;  // restored distance code of the last emitted command (0xffffffff: none)
+  uint32_t flag_changes;    // positions whose stored-flag differs from the previous round
+  uint32_t n_searches;
+  uint32_t last_copy_len;   // copy_len of last emitted command (low 25 bits)
+  uint32_t dict_mode;       // 0 no consult, 1 alive at every consult, 2 dead at every consult, 3 mixed
+  int32_t dict_maxdef;      // mode 1: max over consults of (local lookups - 128 * local matches)
+  uint32_t n_pushes;        // number of dist-cache pushes in this segment, saturated at 4
+  uint32_t pad1;
+};
+
+// Post-parse fix-ups of the gathered command array.
+struct CmdPatch {
+  uint32_t index;  // command index in the gathered array
+  uint32_t kind;   // 0: extend_last_command (copy_len += value, encode.rs:360-400); 1: insert-only command
+                   //    carrying `value` literals (Command::init_insert, command.rs:38-44); 2: insert_len += value
+  uint32_t value;
+  uint32_t pad;
+};
+
+}  // namespace brotli_mi355x
+#endif

@@ -1,0 +1,128 @@
+// tests/emu/device_emu.cpp -- serial CPU stand-in for the device seam (device_api.h).
+//
+// TEST INFRASTRUCTURE ONLY.  It lets the host driver (speculative-parse resolver, meta-block
+// planning) and the chain code (lz77_chain.h compiled with BROTLI_HOST_EMU, one lane per "wave")
+// run in a container without a GPU.  It is never linked into the product library.
+#define BROTLI_HOST_EMU 1
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+#include <vector>
+
+#include "../../rust-brotli_amd/csrc/device_api.h"
+#include "../../rust-brotli_amd/csrc/lz77_chain.h"
+#include "../../tables/brotli_tables.h"
+
+namespace brotli_mi355x {
+
+void* dev_alloc(size_t bytes) {
+  void* p = calloc(bytes ? bytes : 16, 1);
+  if (!p) throw std::runtime_error("emu alloc failed");
+  return p;
+}
+void dev_free(void* p) { free(p); }
+void dev_memset(void* p, int value, size_t bytes) { memset(p, value, bytes); }
+void dev_h2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+void dev_d2h(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+void dev_d2d(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
+void dev_sync() {}
+const char* dev_name() { return "host-emulation"; }
+
+const DeviceTables& dev_tables() {
+  static DeviceTables t;
+  t.dict_hash = kBrotliStaticDictionaryHash;
+  t.dict_data = kBrotliDictionaryData;
+  t.dict_offsets_by_length = kBrotliDictionaryOffsetsByLength;
+  t.dict_size_bits_by_length = kBrotliDictionarySizeBitsByLength;
+  t.logs_16 = (const float*)(const void*)kBrotliLog2Table16_bits;
+  t.logs_8 = (const float*)(const void*)kBrotliLog2Table8_bits;
+  t.utf8_context_lookup = kBrotliUTF8ContextLookup;
+  t.signed_context_lookup = kBrotliSigned3BitContextLookup;
+  return t;
+}
+
+size_t lz77_sort_tmp_bytes(uint32_t) { return 64; }
+
+void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  const uint32_t valid_n = n >= P.htl ? n - P.htl + 1 : 0;
+  const uint64_t hash_mask = P.hasher_kind == 6 ? (0xffffffffffffffffull >> (64 - 8 * P.hash_len)) : 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t key = 0xffffu;
+    if (i < valid_n) {
+      if (P.hasher_kind == 6) {
+        key = (uint32_t)(((br_load64(B.text + i) & hash_mask) * 0x1fe35a7bd3579bd3ull) >> (64 - P.bucket_bits));
+      } else {
+        key = (br_load32(B.text + i) * 0x1e35a7bdu) >> (32 - P.bucket_bits);
+      }
+    }
+    B.keys[i] = (uint16_t)key;
+  }
+}
+
+void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  std::vector<uint32_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0u);
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return B.keys[a] < B.keys[b]; });
+  for (uint32_t i = 0; i < n; ++i) {
+    B.by_key[i] = idx[i];
+    B.sorted_keys[i] = B.keys[idx[i]];
+  }
+}
+
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
+  const uint32_t n = P.total_bytes;
+  uint32_t g = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t pos = B.by_key[i];
+    const uint16_t k = B.sorted_keys[i];
+    B.rank[pos] = g;
+    if (i == 0 || B.sorted_keys[i - 1] != k) B.key_base[k] = g;
+    if (B.flags[which][pos]) B.sorted[g++] = pos;
+  }
+}
+
+void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
+  const DeviceTables& dt = dev_tables();
+  ChainTables T;
+  T.text = B.text;
+  T.keys = B.keys;
+  T.rank = B.rank;
+  T.key_base = B.key_base;
+  T.sorted = B.sorted;
+  T.flags_prev = B.flags[which];
+  T.flags_next = B.flags[which ^ 1];
+  T.cmds = B.cmds;
+  T.dict_hash = dt.dict_hash;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.dist_postfix_bits = P.dist_postfix_bits;
+  T.num_direct_distance_codes = P.num_direct_distance_codes;
+  ChainScratch scratch;
+  for (uint32_t k = first_segment; k < P.num_segments; ++k) {
+    br_parse_segment(P, T, scratch, B.segments[k], B.entries[k], B.exits[k]);
+  }
+}
+
+void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo) {
+  memset(histo, 0, 256 * 4);
+  const uint32_t samples = (bytes + 12) / 13;
+  for (uint32_t i = 0; i < samples; ++i) histo[text[start + i * 13u]]++;
+}
+
+void lz77_gather_commands(const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets,
+                          const uint32_t* counts, Command* out) {
+  for (uint32_t k = 0; k < num_segments; ++k)
+    memcpy(out + offsets[k], B.cmds + (size_t)k * stride, (size_t)counts[k] * sizeof(Command));
+}
+
+void lz77_patch_commands(Command* cmds, const CmdPatch* patches, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) br_apply_patch(cmds, patches[i]);
+}
+
+}  // namespace brotli_mi355x

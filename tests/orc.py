@@ -118,3 +118,49 @@ def decompress(comp, expected_size):
     if r != 1:
         raise RuntimeError("decoder rejected the stream (result %d)" % r)
     return out.raw[:n.value]
+
+
+def stream_compress(data, params, prefix=None, collect_trace=False):
+    """Generic path through the oracle's stream API: set params, optional custom dictionary
+    (multi-thread continuation semantics), one FINISH call.  Returns (bytes, trace) where trace is a
+    list of (kind, start, nbytes, [commands as tuples], dist_cache_after)."""
+    L = lib()
+    L.orc_encoder_create.restype = ctypes.c_void_p
+    L.orc_encoder_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_encoder_set_parameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
+    L.orc_encoder_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_encoder_set_custom_dictionary.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int]
+    L.orc_encoder_compress_stream.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.orc_encoder_is_finished.argtypes = [ctypes.c_void_p]
+    s = L.orc_encoder_create()
+    trace = []
+
+    def cb(opaque, kind, start, nbytes, cmds, n, dc):
+        trace.append((kind, start, nbytes,
+                      [(cmds[i].insert_len_, cmds[i].copy_len_, cmds[i].dist_extra_, cmds[i].cmd_prefix_,
+                        cmds[i].dist_prefix_) for i in range(n)], tuple(dc[i] for i in range(4))))
+
+    cbo = TRACE_CB(cb)
+    for k, v in params:
+        L.orc_encoder_set_parameter(s, k, v)
+    if collect_trace:
+        L.orc_encoder_set_trace(s, ctypes.cast(cbo, ctypes.c_void_p), None)
+    if prefix is not None:
+        L.orc_encoder_set_custom_dictionary(s, len(prefix), prefix, 1)
+    cap = L.orc_max_compressed_size(len(data)) + 64
+    out = ctypes.create_string_buffer(cap)
+    inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)
+    avail_in = ctypes.c_size_t(len(data))
+    next_in = ctypes.c_void_p(ctypes.addressof(inbuf))
+    avail_out = ctypes.c_size_t(cap)
+    next_out = ctypes.c_void_p(ctypes.addressof(out))
+    total = ctypes.c_size_t(0)
+    ok = L.orc_encoder_compress_stream(s, 2, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                       ctypes.byref(next_out), ctypes.byref(total))
+    fin = L.orc_encoder_is_finished(s)
+    L.orc_encoder_destroy(s)
+    if not ok or not fin:
+        raise RuntimeError("oracle stream compress failed")
+    return out.raw[:cap - avail_out.value], trace

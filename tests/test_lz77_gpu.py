@@ -1,0 +1,48 @@
+"""GPU parity of the backward-reference stage: the command list produced by the HIP kernels must be
+identical to the one the oracle (CPU restatement of the reference) produces."""
+import pytest
+
+import synth
+from cmp_lz77 import check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import gpulib
+    return gpulib.lib()
+
+
+def test_alice_q5(L):
+    assert check("alice", synth.alice(), 5, 22, lib=L)
+
+
+@pytest.mark.parametrize("q", [6, 7, 8])
+def test_alice_other_qualities(L, q):
+    assert check("alice", synth.alice(), q, 22, lib=L)
+
+
+def test_markov_h6(L):
+    # > 4 MiB with size_hint => H6 (encode.rs:863-876), several meta-blocks
+    assert check("markov6M", synth.markov_text(6 << 20), 5, 22, lib=L)
+
+
+def test_random_and_zeros(L):
+    assert check("random300k", synth.random_bytes(300000), 5, 22, lib=L)
+    assert check("zeros300k", bytes(300000), 5, 22, lib=L)
+
+
+def test_mixed(L):
+    assert check("mixed2M", synth.mixed(2 << 20), 5, 22, lib=L)
+
+
+def test_catable_shard_with_prefix(L):
+    a = synth.alice()
+    h = len(a) // 2
+    assert check("alice shard1", a[h:], 5, 22, size_hint=0, catable=True, prefix=a[:h], lib=L)
+
+
+@pytest.mark.parametrize("seg", [1024, 65536])
+def test_segment_sizes(L, seg):
+    assert check("alice", synth.alice(), 5, 22, seg=seg, lib=L)
