@@ -55,6 +55,34 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------ flags
+// First guess of the "stored" flags: every position of the input is in the hash table except the ones
+// the reference never stores: positions at or after store_end (mod.rs:2397-2404) unless the next
+// block's StitchToPreviousBlock stores them (mod.rs:210-222).
+__global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restrict__ segments, uint32_t num_segments, uint32_t htl,
+                                                         uint8_t* __restrict__ flags) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_segments) return;
+  const Segment g = segments[k];
+  if (!(g.flags & kSegFirstInBlock)) return;
+  const uint32_t bs = g.blk_start, be = g.blk_end;
+  if (g.block_index == 0 && be - bs >= htl - 1 && bs >= 3) flags[bs - 3] = flags[bs - 2] = flags[bs - 1] = 1;
+  const uint32_t store_end = (be - bs >= htl) ? be - htl + 1 : bs;
+  for (uint32_t q = store_end; q < be; ++q) flags[q] = (q + 3 >= be && (g.flags & kSegTailStitched)) ? 1 : 0;
+}
+
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
+  HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, 0));
+  if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), 0));  // StoreLookaheadThenStore, mod.rs:224-229
+  if (M > P0) HIP_CHECK(hipMemsetAsync(B.flags[0] + P0, 1, M - P0, 0));
+  if (P.num_segments) {
+    hipLaunchKernelGGL(k_init_flag_tails, dim3((P.num_segments + 63) / 64), dim3(64), 0, 0, B.segments, P.num_segments, htl, B.flags[0]);
+  }
+  HIP_CHECK(hipMemcpyAsync(B.flags[1], B.flags[0], (size_t)M + 64, hipMemcpyDeviceToDevice, 0));
+  HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ scan
 // exclusive prefix sum of a uint32 array (in place), hierarchical: 1024 elements per workgroup
 static constexpr uint32_t kScanTile = 1024;

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -138,28 +139,7 @@ void Lz77Stage::BuildSegments() {
   }
 }
 
-// First guess of the "stored" flags: every position is in the hash table except the ones the
-// reference never stores (positions at or after store_end that the next block's stitch skips).
-void Lz77Stage::InitFlags() {
-  const uint32_t M = P_.total_bytes, P0 = P_.prefix_bytes, htl = P_.htl;
-  std::vector<uint8_t> f(M + 64, 0);
-  if (P0 > htl - 1) memset(f.data(), 1, P0 - (htl - 1));  // StoreLookaheadThenStore, mod.rs:224-229
-  uint32_t prev_block = 0xffffffffu;
-  for (const Segment& g : segments_) {
-    if (g.block_index == prev_block) continue;
-    prev_block = g.block_index;
-    const uint32_t bs = g.blk_start, be = g.blk_end;
-    if (g.block_index == 0 && be - bs >= htl - 1 && bs >= 3) {
-      f[bs - 3] = f[bs - 2] = f[bs - 1] = 1;  // stitch at the first block (prefix / raw head tail)
-    }
-    if (be > bs) memset(f.data() + bs, 1, be - bs);
-    const uint32_t store_end = (be - bs >= htl) ? be - htl + 1 : bs;
-    for (uint32_t q = store_end; q < be; ++q) f[q] = (q + 3 >= be && (g.flags & kSegTailStitched)) ? 1 : 0;
-  }
-  dev_h2d(B_.flags[0], f.data(), M + 64);
-  dev_h2d(B_.flags[1], f.data(), M + 64);
-  dev_sync();
-}
+void Lz77Stage::InitFlags() { lz77_init_flags(P_, B_); }
 
 static bool DictEntryCompatible(const SegEntry& used, const SegExit& x, uint32_t L, uint32_t M) {
   if (used.dict_lookups == L && used.dict_matches == M) return true;
@@ -366,8 +346,31 @@ bool Lz77Stage::Resolve(bool final_pass) {
   return consistent;
 }
 
+namespace {
+struct Timer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit Timer(bool enabled) : on(enabled) {
+    if (on) {
+      dev_sync();
+      t0 = std::chrono::steady_clock::now();
+    }
+  }
+  void stop(double* acc) {
+    if (!on) return;
+    dev_sync();
+    auto t1 = std::chrono::steady_clock::now();
+    *acc += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t0 = t1;
+  }
+};
+}  // namespace
+
 void Lz77Stage::Run() {
   stats_ = Lz77Stats{};
+  const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
+  Timer total(true);
+  Timer tm(prof);
   should_compress_cache_.clear();
   const uint32_t nseg = (uint32_t)segments_.size();
   if (nseg == 0) {
@@ -376,8 +379,11 @@ void Lz77Stage::Run() {
     return;
   }
   lz77_compute_keys(P_, B_);
+  tm.stop(&stats_.ms_keys);
   lz77_sort_by_key(P_, B_);
+  tm.stop(&stats_.ms_sort);
   InitFlags();
+  tm.stop(&stats_.ms_init);
   const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
   if (selftest) SelfTestSort();
   // first guess of the entries: every chain starts at its segment start with the default cache
@@ -396,13 +402,16 @@ void Lz77Stage::Run() {
   bool done = false;
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
     stats_.rounds++;
+    tm.stop(&stats_.ms_resolve);
     dev_h2d(B_.entries + first, entries_.data() + first, (size_t)(nseg - first) * sizeof(SegEntry));
     lz77_rank_flags(P_, B_, which);
+    tm.stop(&stats_.ms_rank);
     if (selftest && round == 0) SelfTestRank(which);
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     lz77_parse_round(P_, B_, which, first);
     stats_.segments_parsed += nseg - first;
     dev_d2h(exits_.data() + first, B_.exits + first, (size_t)(nseg - first) * sizeof(SegExit));
+    tm.stop(&stats_.ms_parse);
     const bool consistent = Resolve(false);
     uint32_t first_flag_change = nseg;
     for (uint32_t k = first; k < nseg; ++k) {
@@ -422,8 +431,11 @@ void Lz77Stage::Run() {
     which ^= 1;
   }
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
+  tm.stop(&stats_.ms_resolve);
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
   Gather();
+  tm.stop(&stats_.ms_gather);
+  total.stop(&stats_.ms_total);
 }
 
 // Bring-up checks of the sort / rank kernels against a host recomputation (BROTLI_MI355X_SELFTEST=1).

@@ -35,6 +35,8 @@ struct Lz77Stats {
   uint64_t segments_parsed = 0;
   uint64_t searches = 0;
   uint64_t total_commands = 0;
+  // wall-clock milliseconds per phase (device synchronised), filled when profiling is enabled
+  double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
 
 class Lz77Stage {

@@ -49,7 +49,7 @@ def lz77_trace(L, data, quality=5, lgwin=22, size_hint=None, catable=False, pref
     cmds = (Command * cap)()
     mbs = (MetaBlockInfo * 4096)()
     nmb = ctypes.c_size_t(0)
-    stats = (ctypes.c_uint32 * 4)()
+    stats = (ctypes.c_uint32 * 12)()
     err = ctypes.create_string_buffer(512)
     n = L.brotli_mi355x_lz77_trace(quality, lgwin, size_hint, 1 if catable else 0, prefix, len(prefix), data, len(data),
                                    segment_bytes, cmds, cap, mbs, 4096, ctypes.byref(nmb), stats, err, 512)
@@ -62,4 +62,6 @@ def lz77_trace(L, data, quality=5, lgwin=22, size_hint=None, catable=False, pref
               for j in range(m.cmd_offset, m.cmd_offset + m.n_cmds)]
         out.append(dict(start=m.start, end=m.end, uncompressed=bool(m.uncompressed), is_last=bool(m.is_last), cmds=cl,
                         n_literals=m.n_literals, dist_cache_after=tuple(m.dist_cache_after)))
-    return out, dict(rounds=stats[0], segments_parsed=stats[1], searches=stats[2], total_cmds=stats[3])
+    names = ('keys', 'sort', 'init', 'rank', 'parse', 'resolve', 'gather', 'total')
+    return out, dict(rounds=stats[0], segments_parsed=stats[1], searches=stats[2], total_cmds=stats[3],
+                     ms={n: stats[4 + i] / 1000.0 for i, n in enumerate(names)})

@@ -63,6 +63,23 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   }
 }
 
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
+  uint8_t* f = B.flags[0];
+  memset(f, 0, (size_t)M + 64);
+  if (P0 > htl - 1) memset(f, 1, P0 - (htl - 1));
+  if (M > P0) memset(f + P0, 1, M - P0);
+  for (uint32_t k = 0; k < P.num_segments; ++k) {
+    const Segment& g = B.segments[k];
+    if (!(g.flags & kSegFirstInBlock)) continue;
+    const uint32_t bs = g.blk_start, be = g.blk_end;
+    if (g.block_index == 0 && be - bs >= htl - 1 && bs >= 3) f[bs - 3] = f[bs - 2] = f[bs - 1] = 1;
+    const uint32_t store_end = (be - bs >= htl) ? be - htl + 1 : bs;
+    for (uint32_t q = store_end; q < be; ++q) f[q] = (q + 3 >= be && (g.flags & kSegTailStitched)) ? 1 : 0;
+  }
+  memcpy(B.flags[1], f, (size_t)M + 64);
+}
+
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   const uint32_t n = P.total_bytes;
   std::vector<uint32_t> idx(n);
