@@ -61,7 +61,7 @@ size_t lz77_sort_tmp_bytes(uint32_t total_bytes);
 void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
 // first guess of the stored flags (both buffers): prefix positions, stitch positions and block tails are
 // static, everything else is assumed stored
-void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B);
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start);
 // stable sort of positions by key -> by_key / sorted_keys
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
 // rank / sorted / key_base from flags[which]

@@ -1,0 +1,535 @@
+// encoder.cpp -- see encoder.h
+#include "encoder.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <stdexcept>
+
+#include "device_api.h"
+#include "host_entropy.h"
+#include "lz77_stage.h"
+#include "metablock_api.h"
+#include "metablock_device.h"
+#include "metablock_items.h"
+
+namespace brotli_mi355x {
+
+namespace {
+
+struct DevMem {
+  std::vector<void*> ptrs;
+  ~DevMem() {
+    for (void* p : ptrs) dev_free(p);
+  }
+  template <typename T>
+  T* alloc(size_t count) {
+    void* p = dev_alloc(count * sizeof(T) + 64);
+    ptrs.push_back(p);
+    return (T*)p;
+  }
+};
+
+// host-composed pieces of the stream (window bits, metadata block, uncompressed headers, tail blocks)
+struct BitPiece {
+  uint64_t pos;
+  uint32_t nbits;
+  uint32_t pad;
+  uint64_t bits;
+};
+
+struct HostBits {
+  uint64_t pos = 0;
+  std::vector<BitPiece> pieces;
+  void put(uint32_t nbits, uint64_t bits) {
+    if (nbits == 0) return;
+    pieces.push_back({pos, nbits, 0, bits});
+    pos += nbits;
+  }
+  void jump_to_byte_boundary() { pos = (pos + 7) & ~(uint64_t)7; }
+};
+
+// BrotliWriteMetadataMetaBlock, brotli_bit_stream.rs:2853-2896
+void WriteMetadataMetaBlock(const EncoderParams& p, HostBits* hb) {
+  uint8_t b128[10];
+  size_t count = 0;
+  uint64_t value = p.size_hint;
+  for (size_t index = 0; index < 10; ++index) {
+    b128[index] = (uint8_t)(value & 0x7f);
+    value >>= 7;
+    count = index + 1;
+    if (value != 0) {
+      b128[index] |= 0x80;
+    } else {
+      break;
+    }
+  }
+  hb->put(1, 0);
+  hb->put(2, 3);
+  hb->put(1, 0);
+  hb->put(2, 1);
+  hb->put(8, 3 + count);
+  hb->jump_to_byte_boundary();
+  uint8_t magic[3] = {0xe1, 0x97, 0x80};
+  if (p.catable && !p.use_dictionary) {
+    magic[2] = 0x81;
+  } else if (p.appendable) {
+    magic[2] = 0x82;
+  }
+  for (int i = 0; i < 3; ++i) hb->put(8, magic[i]);
+  hb->put(8, 1);  // VERSION, src/lib.rs:67
+  for (size_t i = 0; i < count; ++i) hb->put(8, b128[i]);
+}
+
+// BrotliStoreUncompressedMetaBlockHeader, brotli_bit_stream.rs:2743-2756
+void WriteUncompressedHeader(uint32_t length, HostBits* hb) {
+  const uint32_t lg = length == 1 ? 1 : (31u ^ (uint32_t)__builtin_clz(length - 1)) + 1;
+  const uint32_t mnibbles = (lg < 16 ? 16 : lg + 3) / 4;
+  hb->put(1, 0);
+  hb->put(2, mnibbles - 4);
+  hb->put(mnibbles * 4, length - 1);
+  hb->put(1, 1);
+  hb->jump_to_byte_boundary();
+}
+
+// WriteEmptyLastBlocksInternal, encode.rs:1928-1940
+void WriteEmptyLastBlocks(const EncoderParams& p, HostBits* hb) {
+  if (p.byte_align && (hb->pos & 7) != 0) {  // BrotliWritePaddingMetaBlock
+    hb->put(6, 6);
+    hb->jump_to_byte_boundary();
+  }
+  if (!p.bare_stream) {  // BrotliWriteEmptyLastMetaBlock
+    hb->put(1, 1);
+    hb->put(1, 1);
+    hb->jump_to_byte_boundary();
+  }
+}
+
+// ChooseContextMap (encode.rs:1717-1780), ShouldUseComplexStaticContextMap (:1802-1871),
+// DecideOverLiteralContextModeling (:1873-1927) evaluated on the device-collected sample histograms.
+void DecideContexts(const uint32_t* s, int quality, size_t size_hint, size_t length, uint32_t* num_contexts,
+                    uint32_t* map_id) {
+  *num_contexts = 1;
+  *map_id = 0;
+  if (quality < 5 || length < 64) return;
+  if (size_hint >= (1u << 20)) {
+    const uint32_t* combined = s + 16;
+    const uint32_t* context = s + 48;
+    const uint32_t total = s[480];
+    float entropy[3];
+    entropy[1] = HostShannonEntropy(combined, 32, nullptr);
+    entropy[2] = 0.0f;
+    for (size_t i = 0; i < 13; ++i) entropy[2] += HostShannonEntropy(context + 32 * i, 32, nullptr);
+    entropy[0] = 1.0f / (float)total;
+    entropy[1] *= entropy[0];
+    entropy[2] *= entropy[0];
+    if (!(entropy[2] > 3.0f || entropy[1] - entropy[2] < 0.2f)) {
+      *num_contexts = 13;
+      *map_id = 3;
+      return;
+    }
+  }
+  uint32_t bigram[9];
+  memcpy(bigram, s, sizeof(bigram));
+  uint32_t monogram[3] = {0, 0, 0};
+  uint32_t two_prefix[6] = {0, 0, 0, 0, 0, 0};
+  float entropy[4] = {0, 0, 0, 0};
+  for (size_t i = 0; i < 9; ++i) {
+    monogram[i % 3] += bigram[i];
+    two_prefix[i % 6] += bigram[i];
+  }
+  entropy[1] = HostShannonEntropy(monogram, 3, nullptr);
+  entropy[2] = HostShannonEntropy(two_prefix, 3, nullptr) + HostShannonEntropy(two_prefix + 3, 3, nullptr);
+  entropy[3] = 0.0f;
+  for (size_t i = 0; i < 3; ++i) entropy[3] += HostShannonEntropy(bigram + 3 * i, 3, nullptr);
+  const size_t total = (size_t)(monogram[0] + monogram[1] + monogram[2]);
+  entropy[0] = 1.0f / (float)total;
+  entropy[1] *= entropy[0];
+  entropy[2] *= entropy[0];
+  entropy[3] *= entropy[0];
+  if (quality < 7) entropy[3] = entropy[1] * 10.0f;
+  if (entropy[1] - entropy[2] < 0.2f && entropy[1] - entropy[3] < 0.2f) {
+    *num_contexts = 1;
+  } else if (entropy[2] - entropy[3] < 0.02f) {
+    *num_contexts = 2;
+    *map_id = 1;
+  } else {
+    *num_contexts = 3;
+    *map_id = 2;
+  }
+}
+
+struct Clock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double lap(bool sync) {
+    if (sync) dev_sync();
+    auto t1 = std::chrono::steady_clock::now();
+    double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t0 = t1;
+    return ms;
+  }
+};
+
+}  // namespace
+
+void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeStats* stats_out) {
+  EncodeStats stats;
+  Clock total_clock;
+  const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
+  EncoderParams p = req.params;
+  const size_t n = req.input_size;
+  if (n >= (1ull << 31) || req.prefix_size >= (1ull << 30)) throw std::runtime_error("brotli_mi355x: streams of 2 GiB or more are not supported");
+  // ---- parameters, in the order the reference fixes them (encode.rs:657-707, 1604-1620, 1125-1161)
+  if (req.prefix_size) p.use_dictionary = false;  // set_custom_dictionary, encode.rs:1213
+  FinalizeParams(&p);
+  if (req.hasher_chosen_before_size_hint) ChooseHasher(&p);  // custom dictionary: hasher_setup runs before any size hint
+  if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
+  if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
+  const char* why = nullptr;
+  if (!IsAccelerated(p, &why)) throw std::runtime_error(std::string("brotli_mi355x: ") + why);
+  bool catable = p.catable;
+  bool appendable = p.appendable;
+  if (req.prefix != nullptr && (req.prefix_size <= 1)) {
+    // set_custom_dictionary with a too-short dictionary: no priming, but catable + appendable (encode.rs:1237-1241)
+    catable = true;
+    appendable = true;
+  }
+  p.catable = catable;
+  p.appendable = appendable;
+  const uint32_t prefix_bytes = req.prefix_size > 1 ? (uint32_t)req.prefix_size : 0;
+
+  HostBits hb;
+  // stream header: window bits (EncodeWindowBits, encode.rs:603-625)
+  if (!(req.params.catable && p.bare_stream)) {
+    const int lgwin = p.lgwin;
+    if (p.large_window) {
+      hb.put(14, (uint64_t)(((lgwin & 0x3F) << 8) | 0x11));
+    } else if (lgwin == 16) {
+      hb.put(1, 0);
+    } else if (lgwin == 17) {
+      hb.put(7, 1);
+    } else if (lgwin > 17) {
+      hb.put(4, (uint64_t)(((lgwin - 17) << 1) | 1));
+    } else {
+      hb.put(7, (uint64_t)(((lgwin - 8) << 4) | 1));
+    }
+  }
+  if (p.magic_number) WriteMetadataMetaBlock(p, &hb);
+  if (n == 0 && p.byte_align && p.appendable && !p.catable && (hb.pos & 7) != 0) {
+    hb.put(6, 6);
+    hb.jump_to_byte_boundary();
+  }
+
+  DevMem mem;
+  const uint32_t M = prefix_bytes + (uint32_t)n;
+  uint8_t* text = mem.alloc<uint8_t>((size_t)M + 64);
+  if (prefix_bytes) dev_h2d(text, req.prefix + (req.prefix_size - prefix_bytes), prefix_bytes);
+  if (n) {
+    if (req.input_on_device) {
+      dev_d2d(text + prefix_bytes, req.input, n);
+    } else {
+      dev_h2d(text + prefix_bytes, req.input, n);
+    }
+  }
+  stats.ms_phase[0] = total_clock.lap(prof);
+
+  struct RawCopy {
+    uint64_t dst_byte;
+    uint32_t src_pos, bytes;
+  };
+  std::vector<RawCopy> raw_copies;
+  uint32_t raw_head = 0;
+  if (p.catable && n != 0) {
+    raw_head = (uint32_t)std::min<size_t>(2, n);
+    WriteUncompressedHeader(raw_head, &hb);
+    raw_copies.push_back({hb.pos >> 3, prefix_bytes, raw_head});
+    hb.pos += (uint64_t)raw_head * 8;
+  }
+  const uint64_t head_bits = hb.pos;
+
+  Lz77Stage lz;
+  std::vector<uint8_t> result;
+  if (n - raw_head == 0) {
+    // nothing left to search: only the trailing blocks (encode.rs:1979-1982)
+    WriteEmptyLastBlocks(p, &hb);
+    const size_t total_bytes = (size_t)((hb.pos + 7) >> 3);
+    result.assign(total_bytes + 8, 0);
+    for (const BitPiece& bp : hb.pieces) {
+      uint64_t v = bp.bits;
+      for (uint32_t b = 0; b < bp.nbits; ++b, v >>= 1)
+        if (v & 1) result[(bp.pos + b) >> 3] |= (uint8_t)(1u << ((bp.pos + b) & 7));
+    }
+    for (const RawCopy& rc : raw_copies) dev_d2h(result.data() + rc.dst_byte, text + rc.src_pos, rc.bytes);
+    result.resize(total_bytes);
+    out->insert(out->end(), result.begin(), result.end());
+    if (stats_out) *stats_out = stats;
+    return;
+  }
+
+  lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, req.segment_bytes);
+  for (;;) {  // repeated only when a compressed meta-block turns out larger than its raw form
+    HostBits bits = hb;  // stream position after the head pieces
+    bits.pos = head_bits;
+    Clock clk;
+    lz.Run();
+    stats.ms_lz77 += clk.lap(prof);
+    stats.lz77_rounds += lz.stats().rounds;
+    stats.searches = lz.stats().searches;
+    const std::vector<MetaBlockPlan>& plans = lz.metablocks();
+    const uint32_t n_mb = (uint32_t)plans.size();
+    const uint32_t K = lz.num_commands();
+    uint64_t L64 = 0;
+    for (const MetaBlockPlan& mp : plans) L64 += mp.n_literals;
+    const uint32_t L = (uint32_t)L64;
+
+    DevMem mm;
+    MbBuffers B{};
+    const DeviceTables& dt = dev_tables();
+    B.text = text;
+    B.cmds = lz.commands_dev();
+    B.n_cmds = K;
+    B.n_lits = L;
+    B.n_mb = n_mb;
+    B.text_base = plans.empty() ? 0 : plans[0].start;
+    B.utf8_lut = dt.utf8_context_lookup;
+    B.signed_lut = dt.signed_context_lookup;
+    B.et.logs_16 = dt.logs_16;
+    B.et.logs_8 = dt.logs_8;
+    B.descs = mm.alloc<MbDesc>(n_mb);
+    B.results = mm.alloc<MbResult>(n_mb);
+    B.cmd_lit_start = mm.alloc<uint32_t>((size_t)K + 1);
+    B.cmd_pos = mm.alloc<uint32_t>((size_t)K + 1);
+    B.cmd_dist_index = mm.alloc<uint32_t>((size_t)K + 1);
+    B.lit_pos = mm.alloc<uint32_t>((size_t)L + 1);
+    B.lit_cmd = mm.alloc<uint32_t>((size_t)L + 1);
+    B.lit_nbits = mm.alloc<uint32_t>((size_t)L + 1);
+    B.cmd_nbits = mm.alloc<uint32_t>((size_t)K + 1);
+    B.cmd_own_bits = mm.alloc<uint32_t>((size_t)K + 1);
+    void* scan_scratch = mm.alloc<uint8_t>(mb_scan_scratch_bytes(std::max<size_t>(K, L) + 2));
+
+    std::vector<MbDesc> descs(n_mb);
+    for (uint32_t m = 0; m < n_mb; ++m) {
+      MbDesc& d = descs[m];
+      memset(&d, 0, sizeof(d));
+      const MetaBlockPlan& mp = plans[m];
+      d.start = mp.start;
+      d.end = mp.end;
+      d.cmd_offset = mp.cmd_offset;
+      d.n_cmds = mp.n_cmds;
+      d.n_lits = mp.n_literals;
+      d.context_mode = 2;  // ChooseContextMode: UTF8 below quality 10 unless forced (encode.rs:1357-1377)
+      switch (p.mode) {
+        case 3: d.context_mode = 0; break;
+        case 4: d.context_mode = 1; break;
+        case 6: d.context_mode = 3; break;
+        default: break;
+      }
+      d.uncompressed = mp.uncompressed ? 1 : 0;
+      const bool actual_last = mp.is_last;
+      d.is_last = (actual_last && !(p.appendable || p.byte_align)) ? 1 : 0;
+      d.num_distance_symbols = p.dist.alphabet_size;
+      d.dist_postfix_bits = p.dist.distance_postfix_bits;
+      d.num_direct_distance_codes = p.dist.num_direct_distance_codes;
+      d.num_contexts = 1;
+    }
+    // prev bytes (encode.rs:2526-2534): bytes preceding the meta-block in the stream, 0 at the very start
+    {
+      std::vector<uint8_t> tails((size_t)n_mb * 2, 0);
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        uint8_t two[2] = {0, 0};
+        const uint32_t s = descs[m].start;
+        const uint32_t lo = (prefix_bytes && !req.prefix_is_file_continuation) ? prefix_bytes : 0;
+        if (s >= lo + 2) {
+          dev_d2h(two, text + s - 2, 2);
+        } else if (s == lo + 1) {
+          dev_d2h(two + 1, text + s - 1, 1);
+        }
+        descs[m].prev_byte = two[1];
+        descs[m].prev_byte2 = two[0];
+      }
+    }
+    {
+      uint32_t lit_base = 0;
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        descs[m].lit_base = lit_base;
+        lit_base += descs[m].n_lits;
+      }
+    }
+    dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+    mb_command_scans(B, scan_scratch);
+    mb_literal_map(B);
+    // distance symbol counts per meta-block
+    {
+      std::vector<uint32_t> di(n_mb + 1);
+      for (uint32_t m = 0; m < n_mb; ++m) dev_d2h(&di[m], B.cmd_dist_index + descs[m].cmd_offset, 4);
+      dev_d2h(&di[n_mb], B.cmd_dist_index + K, 4);
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        descs[m].dist_base = di[m];
+        descs[m].n_dists = di[m + 1] - di[m];
+      }
+      B.n_dists = di[n_mb];
+    }
+    // literal context modelling decision
+    if (p.disable_literal_context_modeling == 0) {
+      uint32_t* stats_dev = mm.alloc<uint32_t>((size_t)n_mb * kContextStatsWords);
+      mb_context_stats(B, stats_dev);
+      std::vector<uint32_t> cs((size_t)n_mb * kContextStatsWords);
+      dev_d2h(cs.data(), stats_dev, cs.size() * 4);
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        if (descs[m].uncompressed) continue;
+        DecideContexts(cs.data() + (size_t)m * kContextStatsWords, p.quality, p.size_hint, descs[m].end - descs[m].start,
+                       &descs[m].num_contexts, &descs[m].context_map_id);
+      }
+    }
+    // pools
+    uint32_t gran_total[3] = {0, 0, 0}, row_total[3] = {0, 0, 0}, block_total[3] = {0, 0, 0}, histo_total[3] = {0, 0, 0};
+    for (uint32_t m = 0; m < n_mb; ++m) {
+      MbDesc& d = descs[m];
+      d.n_symbols[0] = d.n_lits;
+      d.n_symbols[1] = d.n_cmds;
+      d.n_symbols[2] = d.n_dists;
+      for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t gl = kGranuleLen[k];
+        const uint32_t nc = k == 0 ? d.num_contexts : 1;
+        d.granule_base[k] = gran_total[k];
+        d.n_granules[k] = d.uncompressed ? 0 : (d.n_symbols[k] + gl - 1) / gl;
+        d.gran_row_base[k] = row_total[k];
+        d.block_base[k] = block_total[k];
+        d.max_blocks[k] = d.n_symbols[k] / gl + 1;
+        const uint32_t max_types = (k == 0 && nc > 1) ? 256 / nc : 256;
+        d.histo_base[k] = histo_total[k];
+        d.max_histos[k] = std::min(d.max_blocks[k], max_types + 1) * nc;
+        gran_total[k] += d.n_granules[k];
+        row_total[k] += d.n_granules[k] * nc;
+        block_total[k] += d.max_blocks[k] + 1;
+        histo_total[k] += d.max_histos[k];
+      }
+    }
+    std::vector<uint32_t> gran_mb_host[3];
+    for (uint32_t k = 0; k < 3; ++k) {
+      gran_mb_host[k].resize(gran_total[k] + 1);
+      for (uint32_t m = 0; m < n_mb; ++m)
+        for (uint32_t g = 0; g < descs[m].n_granules[k]; ++g) gran_mb_host[k][descs[m].granule_base[k] + g] = m;
+      B.n_granules[k] = gran_total[k];
+      B.gran_mb[k] = mm.alloc<uint32_t>(gran_total[k] + 1);
+      dev_h2d(B.gran_mb[k], gran_mb_host[k].data(), (size_t)gran_total[k] * 4);
+      B.gran_hist[k] = mm.alloc<uint16_t>((size_t)row_total[k] * kRowLen[k] + 8);
+      B.gran_block[k] = mm.alloc<uint16_t>(gran_total[k] + 8);
+      B.histo[k] = mm.alloc<uint32_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+      B.depth[k] = mm.alloc<uint8_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+      B.bits[k] = mm.alloc<uint16_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+      B.tree_bits[k] = mm.alloc<uint64_t>((size_t)histo_total[k] * kTreeBitsWords + 8);
+      B.tree_nbits[k] = mm.alloc<uint32_t>(histo_total[k] + 8);
+      B.block_types[k] = mm.alloc<uint8_t>(block_total[k] + 8);
+      B.block_lengths[k] = mm.alloc<uint32_t>(block_total[k] + 8);
+      B.switch_bits[k] = mm.alloc<uint64_t>(block_total[k] + 8);
+      B.switch_nbits[k] = mm.alloc<uint8_t>(block_total[k] + 8);
+    }
+    B.header_words = mm.alloc<uint64_t>((size_t)n_mb * kHeaderWords);
+    B.ctxmap_scratch = mm.alloc<uint32_t>((size_t)n_mb * 2 * 256 * 64);
+    B.mb_out_bit = mm.alloc<uint64_t>(n_mb + 1);
+    dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+    stats.ms_phase[1] += clk.lap(prof);
+    mb_granule_histograms(B);
+    stats.ms_phase[2] += clk.lap(prof);
+    mb_split_chains(B);
+    std::vector<MbResult> results(n_mb);
+    dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+    stats.ms_phase[3] += clk.lap(prof);
+    // Huffman codes: one job per histogram
+    std::vector<CodeJob> jobs;
+    for (uint32_t m = 0; m < n_mb; ++m) {
+      if (descs[m].uncompressed) continue;
+      for (uint32_t k = 0; k < 3; ++k)
+        for (uint32_t i = 0; i < results[m].num_histos[k]; ++i) jobs.push_back({k, descs[m].histo_base[k] + i, descs[m].num_distance_symbols, 0});
+    }
+    B.huff_scratch = mm.alloc<HuffmanScratch>(std::max<size_t>(jobs.size(), n_mb) + 1);
+    CodeJob* jobs_dev = mm.alloc<CodeJob>(jobs.size() + 1);
+    dev_h2d(jobs_dev, jobs.data(), jobs.size() * sizeof(CodeJob));
+    mb_build_codes(B, jobs_dev, (uint32_t)jobs.size());
+    stats.ms_phase[4] += clk.lap(prof);
+    mb_write_headers(B);
+    stats.ms_phase[5] += clk.lap(prof);
+    mb_symbol_bits(B, scan_scratch);
+    dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+    std::vector<uint32_t> body_off(n_mb + 1);
+    for (uint32_t m = 0; m < n_mb; ++m) dev_d2h(&body_off[m], B.cmd_nbits + descs[m].cmd_offset, 4);
+    dev_d2h(&body_off[n_mb], B.cmd_nbits + K, 4);
+    stats.ms_phase[6] += clk.lap(prof);
+
+    // ---- layout of the stream (WriteMetaBlockInternal, encode.rs:1941-2167)
+    std::vector<uint64_t> mb_out_bit(n_mb + 1, 0);
+    std::vector<RawCopy> copies = raw_copies;
+    int fallback = -1;
+    for (uint32_t m = 0; m < n_mb; ++m) {
+      const MbDesc& d = descs[m];
+      const bool actual_last = plans[m].is_last;
+      const bool is_last = d.is_last != 0;
+      const uint32_t bytes = d.end - d.start;
+      if (d.uncompressed) {
+        WriteUncompressedHeader(bytes, &bits);
+        copies.push_back({bits.pos >> 3, d.start, bytes});
+        bits.pos += (uint64_t)bytes * 8;
+        if (is_last) {
+          bits.put(1, 1);
+          bits.put(1, 1);
+          bits.jump_to_byte_boundary();
+        }
+      } else {
+        const uint64_t start_bit = bits.pos;
+        mb_out_bit[m] = start_bit;
+        const uint64_t body_bits = body_off[m + 1] - body_off[m];
+        bits.pos += results[m].header_bits + body_bits;
+        if (is_last) bits.jump_to_byte_boundary();
+        if ((uint64_t)bytes + 4 + (start_bit >> 3) < (bits.pos >> 3)) {  // encode.rs:2141-2163
+          fallback = (int)m;
+          break;
+        }
+      }
+      if (actual_last != is_last) WriteEmptyLastBlocks(p, &bits);
+    }
+    if (fallback >= 0) {
+      lz.ForceUncompressed((uint32_t)fallback);
+      stats.fallback_retries++;
+      continue;
+    }
+    // ---- emission
+    const size_t total_bytes = (size_t)((bits.pos + 7) >> 3);
+    const size_t out_words = total_bytes / 8 + 4;
+    B.out_words = mm.alloc<uint64_t>(out_words);
+    dev_h2d(B.mb_out_bit, mb_out_bit.data(), (n_mb + 1) * 8);
+    mb_emit(B);
+    for (uint32_t m = 0; m < n_mb; ++m) {
+      if (descs[m].uncompressed) continue;
+      mb_copy_bits(B.out_words, mb_out_bit[m], B.header_words + (size_t)m * kHeaderWords, results[m].header_bits);
+    }
+    for (const RawCopy& rc : copies) dev_d2d((uint8_t*)B.out_words + rc.dst_byte, text + rc.src_pos, rc.bytes);
+    if (!bits.pieces.empty()) {
+      // host composed pieces: uploaded as a tiny word-aligned bit string each
+      for (const BitPiece& bp : bits.pieces) {
+        uint64_t w = bp.bits;
+        uint64_t* tmp = mm.alloc<uint64_t>(2);
+        dev_h2d(tmp, &w, 8);
+        mb_copy_bits(B.out_words, bp.pos, tmp, bp.nbits);
+      }
+    }
+    stats.ms_phase[7] += clk.lap(prof);
+    result.resize(total_bytes);
+    dev_d2h(result.data(), B.out_words, total_bytes);
+    stats.ms_phase[8] += clk.lap(prof);
+    stats.metablocks = n_mb;
+    stats.commands = K;
+    stats.literals = L;
+    for (uint32_t m = 0; m < n_mb; ++m) stats.uncompressed_metablocks += descs[m].uncompressed;
+    break;
+  }
+  out->insert(out->end(), result.begin(), result.end());
+  stats.ms_total = total_clock.lap(false) + stats.ms_phase[0];
+  stats.ms_metablock = 0;
+  for (int i = 1; i < 9; ++i) stats.ms_metablock += stats.ms_phase[i];
+  if (stats_out) *stats_out = stats;
+}
+
+}  // namespace brotli_mi355x

@@ -1,0 +1,46 @@
+// encoder.h -- one-stream encoder: host driver that turns (params, optional LZ77 prefix, input) into a
+// brotli stream using the device stages (lz77_stage + meta-block kernels).
+//
+// It plays the role of the reference's encode_data / WriteMetaBlockInternal loop
+// (src/enc/encode.rs:1941-2167, 2214-2543) for a COMPLETE input: the stream API of the C ABI buffers
+// its input and calls this once at FINISH.
+#ifndef BROTLI_MI355X_ENCODER_H_
+#define BROTLI_MI355X_ENCODER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "encoder_params.h"
+
+namespace brotli_mi355x {
+
+struct EncodeStats {
+  uint32_t lz77_rounds = 0;
+  uint64_t searches = 0, commands = 0, literals = 0;
+  uint32_t metablocks = 0, uncompressed_metablocks = 0;
+  uint32_t fallback_retries = 0;
+  double ms_lz77 = 0, ms_metablock = 0, ms_total = 0;
+  double ms_phase[16] = {0};
+};
+
+struct EncodeRequest {
+  EncoderParams params;         // as set by the user (not yet finalized)
+  const uint8_t* input = nullptr;
+  size_t input_size = 0;
+  bool input_on_device = false;  // input points to device memory (bench path: data resident in HBM)
+  const uint8_t* prefix = nullptr;  // custom LZ77 dictionary (already clipped to the last (1<<lgwin)-16 bytes)
+  size_t prefix_size = 0;
+  bool prefix_is_file_continuation = false;  // compress_multi semantics: prev bytes come from the prefix
+  bool hasher_chosen_before_size_hint = false;  // custom dictionary path picks the hasher early
+  uint32_t segment_bytes = 4096;
+};
+
+// Compresses one stream.  Output is appended to `out`.  Throws std::runtime_error on device errors or
+// unsupported parameters (there is no CPU fallback).
+void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeStats* stats);
+
+}  // namespace brotli_mi355x
+#endif

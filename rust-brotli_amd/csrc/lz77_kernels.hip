@@ -14,13 +14,13 @@
 
 #include "device_api.h"
 #include "lz77_chain.h"
+#include "device_scan.h"
 
 namespace brotli_mi355x {
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
 }
-#define HIP_CHECK(x) hip_check((x), #x)
 
 // ------------------------------------------------------------------------------------------ keys
 __global__ __launch_bounds__(256) void k_compute_keys(const uint8_t* __restrict__ text, uint16_t* __restrict__ keys,
@@ -71,67 +71,17 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
   for (uint32_t q = store_end; q < be; ++q) flags[q] = (q + 3 >= be && (g.flags & kSegTailStitched)) ? 1 : 0;
 }
 
-void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B) {
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start) {
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, 0));
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), 0));  // StoreLookaheadThenStore, mod.rs:224-229
-  if (M > P0) HIP_CHECK(hipMemsetAsync(B.flags[0] + P0, 1, M - P0, 0));
+  // the catable raw head (between the prefix and the first searched block) is only stored by the stitch
+  if (M > first_block_start) HIP_CHECK(hipMemsetAsync(B.flags[0] + first_block_start, 1, M - first_block_start, 0));
   if (P.num_segments) {
     hipLaunchKernelGGL(k_init_flag_tails, dim3((P.num_segments + 63) / 64), dim3(64), 0, 0, B.segments, P.num_segments, htl, B.flags[0]);
   }
   HIP_CHECK(hipMemcpyAsync(B.flags[1], B.flags[0], (size_t)M + 64, hipMemcpyDeviceToDevice, 0));
   HIP_CHECK(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------ scan
-// exclusive prefix sum of a uint32 array (in place), hierarchical: 1024 elements per workgroup
-static constexpr uint32_t kScanTile = 1024;
-
-__global__ __launch_bounds__(256) void k_scan_tiles(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ tile_sums) {
-  __shared__ uint32_t wave_sum[4];
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
-  uint32_t v[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = (base + j < n) ? data[base + j] : 0;
-  const uint32_t local = v[0] + v[1] + v[2] + v[3];
-  // inclusive scan across the wavefront (64 lanes) with DPP-free shuffles
-  uint32_t x = local;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t y = __shfl_up(x, off, 64);
-    if (lane >= off) x += y;
-  }
-  if (lane == 63) wave_sum[w] = x;
-  __syncthreads();
-  uint32_t wave_off = 0;
-  for (int i = 0; i < w; ++i) wave_off += wave_sum[i];
-  uint32_t excl = wave_off + x - local;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (base + j < n) data[base + j] = excl;
-    excl += v[j];
-  }
-  if (threadIdx.x == 255 && tile_sums) tile_sums[blockIdx.x] = wave_off + x;
-}
-
-__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ tile_offsets) {
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
-  const uint32_t add = tile_offsets[blockIdx.x];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (base + j < n) data[base + j] += add;
-}
-
-// scratch must hold ceil(n/1024) + ceil(n/1024^2) + ... + 2 uint32
-static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* scratch) {
-  if (n == 0) return;
-  const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, 0, data, n, tiles > 1 ? scratch : (uint32_t*)nullptr);
-  if (tiles > 1) {
-    exclusive_scan_u32(scratch, tiles, scratch + tiles);
-    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(256), 0, 0, data, n, scratch);
-  }
 }
 
 // ------------------------------------------------------------------------------------------ radix sort

@@ -139,7 +139,7 @@ void Lz77Stage::BuildSegments() {
   }
 }
 
-void Lz77Stage::InitFlags() { lz77_init_flags(P_, B_); }
+void Lz77Stage::InitFlags() { lz77_init_flags(P_, B_, segments_.empty() ? P_.total_bytes : segments_[0].blk_start); }
 
 static bool DictEntryCompatible(const SegEntry& used, const SegExit& x, uint32_t L, uint32_t M) {
   if (used.dict_lookups == L && used.dict_matches == M) return true;

@@ -1,0 +1,39 @@
+// metablock_api.h -- device seam of the meta-block stage (see device_api.h for the conventions).
+#ifndef BROTLI_MI355X_METABLOCK_API_H_
+#define BROTLI_MI355X_METABLOCK_API_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "metablock_types.h"
+
+namespace brotli_mi355x {
+
+struct MbBuffers;  // metablock_items.h
+
+static constexpr uint32_t kContextStatsWords = 512;  // per meta-block: [0..9) bigram prefix histogram
+                                                      // (encode.rs:1885-1918), [16..48) combined 5-bit histogram,
+                                                      // [48..48+13*32) per-context histograms, [480] total (encode.rs:1802-1871)
+
+struct CodeJob {
+  uint32_t kind;
+  uint32_t row_index;
+  uint32_t num_distance_symbols;
+  uint32_t pad;
+};
+
+size_t mb_scan_scratch_bytes(size_t n);
+// per command insert_len / insert+copy / has-distance and their exclusive scans ([K] = totals)
+void mb_command_scans(const MbBuffers& B, void* scan_scratch);
+void mb_literal_map(const MbBuffers& B);
+void mb_context_stats(const MbBuffers& B, uint32_t* stats_dev);
+void mb_granule_histograms(const MbBuffers& B);
+void mb_split_chains(const MbBuffers& B);
+void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs);
+void mb_write_headers(const MbBuffers& B);
+void mb_symbol_bits(const MbBuffers& B, void* scan_scratch);
+void mb_emit(const MbBuffers& B);
+void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits);
+
+}  // namespace brotli_mi355x
+#endif

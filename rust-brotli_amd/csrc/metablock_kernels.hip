@@ -1,0 +1,168 @@
+// metablock_kernels.hip -- gfx950 kernels of the meta-block stage: per-granule histograms, greedy block
+// splitting (one workgroup per splitter, strictly ordered f32 entropy sums), Huffman code construction
+// (one thread per histogram), header serialisation (one thread per meta-block) and the parallel symbol
+// emission (bit length per symbol -> prefix sums -> 64-bit atomic OR scatter).  Integer/byte work, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "device_api.h"
+#include "device_scan.h"
+#include "metablock_api.h"
+#include "metablock_items.h"
+
+namespace brotli_mi355x {
+
+size_t mb_scan_scratch_bytes(size_t n) { return scan_scratch_words(n) * 4 + 256; }
+
+template <typename F>
+__global__ __launch_bounds__(256) void k_for_each(uint32_t n, F f) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f(i);
+}
+template <typename F>
+static void for_each(uint32_t n, F f) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_for_each<F>, dim3((n + 255) / 256), dim3(256), 0, 0, n, f);
+}
+
+void mb_command_scans(const MbBuffers& B, void* scan_scratch) {
+  const MbBuffers b = B;
+  for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_counts(b, c); });
+  // element [K] = 0 so that the exclusive scan leaves the totals there
+  HIP_CHECK(hipMemsetAsync(b.cmd_lit_start + b.n_cmds, 0, 4, 0));
+  HIP_CHECK(hipMemsetAsync(b.cmd_pos + b.n_cmds, 0, 4, 0));
+  HIP_CHECK(hipMemsetAsync(b.cmd_dist_index + b.n_cmds, 0, 4, 0));
+  exclusive_scan_u32(b.cmd_lit_start, b.n_cmds + 1, (uint32_t*)scan_scratch);
+  exclusive_scan_u32(b.cmd_pos, b.n_cmds + 1, (uint32_t*)scan_scratch);
+  exclusive_scan_u32(b.cmd_dist_index, b.n_cmds + 1, (uint32_t*)scan_scratch);
+  HIP_CHECK(hipGetLastError());
+}
+
+void mb_literal_map(const MbBuffers& B) {
+  const MbBuffers b = B;
+  for_each(b.n_lits, [b] __device__(uint32_t i) { mb_item_literal_map(b, i); });
+  HIP_CHECK(hipGetLastError());
+}
+
+// sampled context statistics, one workgroup per meta-block (encode.rs:1802-1927)
+__global__ __launch_bounds__(256) void k_context_stats(MbBuffers B, uint32_t* stats) {
+  __shared__ uint32_t s[kContextStatsWords];
+  const uint32_t m = blockIdx.x;
+  const MbDesc d = B.descs[m];
+  for (uint32_t j = threadIdx.x; j < kContextStatsWords; j += blockDim.x) s[j] = 0;
+  __syncthreads();
+  const uint32_t length = d.end - d.start;
+  const uint32_t n_strides = length >= 64 ? (length - 64) / 4096 + 1 : 0;
+  for (uint32_t t = threadIdx.x; t < n_strides; t += blockDim.x) {
+    const uint32_t start_pos = d.start + t * 4096;
+    const uint8_t* p = B.text + start_pos;
+    // simple bigram-prefix histogram (encode.rs:1885-1918)
+    {
+      const int lut[4] = {0, 0, 1, 2};
+      int prev = lut[p[0] >> 6] * 3;
+      for (uint32_t k = 1; k < 64; ++k) {
+        const uint8_t literal = p[k];
+        atomicAdd(&s[prev + lut[literal >> 6]], 1u);
+        prev = lut[literal >> 6] * 3;
+      }
+    }
+    // complex context statistics (encode.rs:1820-1842)
+    {
+      uint8_t prev2 = p[0], prev1 = p[1];
+      for (uint32_t k = 2; k < 64; ++k) {
+        const uint8_t literal = p[k];
+        const uint32_t context = br_static_context_map(3, br_context(B.utf8_lut, B.signed_lut, prev1, prev2, 2));
+        atomicAdd(&s[480], 1u);
+        atomicAdd(&s[16 + (literal >> 3)], 1u);
+        atomicAdd(&s[48 + context * 32 + (literal >> 3)], 1u);
+        prev2 = prev1;
+        prev1 = literal;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < kContextStatsWords; j += blockDim.x) stats[(size_t)m * kContextStatsWords + j] = s[j];
+}
+
+void mb_context_stats(const MbBuffers& B, uint32_t* stats_dev) {
+  if (B.n_mb == 0) return;
+  hipLaunchKernelGGL(k_context_stats, dim3(B.n_mb), dim3(256), 0, 0, B, stats_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_granule_histograms(MbBuffers B, uint32_t kind) {
+  __shared__ uint32_t lds[kMaxStaticContexts * 256];
+  mb_item_granule_histogram(B, kind, blockIdx.x, lds);
+}
+
+void mb_granule_histograms(const MbBuffers& B) {
+  const MbBuffers b = B;
+  if (b.n_granules[kSplitLiteral]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitLiteral]), dim3(256), 0, 0, b, (uint32_t)kSplitLiteral);
+  if (b.n_granules[kSplitCommand]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitCommand]), dim3(256), 0, 0, b, (uint32_t)kSplitCommand);
+  if (b.n_granules[kSplitDistance]) {
+    HIP_CHECK(hipMemsetAsync(b.gran_hist[kSplitDistance], 0, (size_t)b.n_granules[kSplitDistance] * kNumDistanceHistoSymbols * 2, 0));
+    for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_distance_count(b, c); });
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_split_chains(MbBuffers B) {
+  __shared__ SplitScratch S;
+  mb_item_split_chain(B, blockIdx.x / 3, blockIdx.x % 3, S);
+}
+
+void mb_split_chains(const MbBuffers& B) {
+  if (B.n_mb == 0) return;
+  hipLaunchKernelGGL(k_split_chains, dim3(B.n_mb * 3), dim3(256), 0, 0, B);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(64) void k_build_codes(MbBuffers B, const CodeJob* jobs, uint32_t n_jobs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_jobs) return;
+  const CodeJob j = jobs[i];
+  mb_item_build_code(B, j.kind, j.row_index, j.num_distance_symbols, B.huff_scratch + i);
+}
+
+void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs) {
+  if (n_jobs == 0) return;
+  hipLaunchKernelGGL(k_build_codes, dim3((n_jobs + 63) / 64), dim3(64), 0, 0, B, jobs_dev, n_jobs);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= B.n_mb) return;
+  mb_item_write_header(B, m, B.huff_scratch + m);
+}
+
+void mb_write_headers(const MbBuffers& B) {
+  if (B.n_mb == 0) return;
+  hipLaunchKernelGGL(k_write_headers, dim3((B.n_mb + 63) / 64), dim3(64), 0, 0, B);
+  HIP_CHECK(hipGetLastError());
+}
+
+void mb_symbol_bits(const MbBuffers& B, void* scan_scratch) {
+  const MbBuffers b = B;
+  for_each(b.n_lits, [b] __device__(uint32_t i) { mb_item_literal_nbits(b, i); });
+  HIP_CHECK(hipMemsetAsync(b.lit_nbits + b.n_lits, 0, 4, 0));
+  exclusive_scan_u32(b.lit_nbits, b.n_lits + 1, (uint32_t*)scan_scratch);
+  for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_nbits(b, c); });
+  HIP_CHECK(hipMemsetAsync(b.cmd_nbits + b.n_cmds, 0, 4, 0));
+  exclusive_scan_u32(b.cmd_nbits, b.n_cmds + 1, (uint32_t*)scan_scratch);
+  HIP_CHECK(hipGetLastError());
+}
+
+void mb_emit(const MbBuffers& B) {
+  const MbBuffers b = B;
+  for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_emit_command(b, c); });
+  for_each(b.n_lits, [b] __device__(uint32_t i) { mb_item_emit_literal(b, i); });
+  HIP_CHECK(hipGetLastError());
+}
+
+void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits) {
+  const uint32_t words = (uint32_t)((nbits + 63) / 64);
+  for_each(words, [=] __device__(uint32_t w) { mb_item_copy_bits_word(out, dst_bit, src, nbits, w); });
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace brotli_mi355x

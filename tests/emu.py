@@ -65,3 +65,34 @@ def lz77_trace(L, data, quality=5, lgwin=22, size_hint=None, catable=False, pref
     names = ('keys', 'sort', 'init', 'rank', 'parse', 'resolve', 'gather', 'total')
     return out, dict(rounds=stats[0], segments_parsed=stats[1], searches=stats[2], total_cmds=stats[3],
                      ms={n: stats[4 + i] / 1000.0 for i, n in enumerate(names)})
+
+
+def bind_encode(L):
+    L.brotli_mi355x_encode_stream.restype = ctypes.c_long
+    L.brotli_mi355x_encode_stream.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32),
+                                              ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32,
+                                              ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double),
+                                              ctypes.c_char_p, ctypes.c_size_t]
+    return L
+
+
+def encode_stream(L, data, params, prefix=b"", continuation=True, segment_bytes=4096):
+    """params: list of (BrotliEncoderParameter id, value).  Returns (bytes, stats dict)."""
+    bind_encode(L)
+    keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
+    vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
+    cap = len(data) + len(data) // 4 + 4096
+    out = ctypes.create_string_buffer(cap)
+    st = (ctypes.c_double * 32)()
+    err = ctypes.create_string_buffer(512)
+    buf = ctypes.create_string_buffer(data, len(data) if data else 1)
+    n = L.brotli_mi355x_encode_stream(keys, vals, len(params), prefix, len(prefix), 1 if continuation else 0,
+                                      ctypes.cast(buf, ctypes.c_void_p), len(data), 0, segment_bytes, out, cap, st, err, 512)
+    if n < 0:
+        raise RuntimeError(err.value.decode())
+    names = ["lz77_rounds", "searches", "commands", "literals", "metablocks", "uncompressed_metablocks",
+             "fallback_retries", "ms_lz77", "ms_metablock", "ms_total"]
+    d = {k: st[i] for i, k in enumerate(names)}
+    d["ms_phase"] = [st[10 + i] for i in range(16)]
+    return out.raw[:n], d

@@ -1,0 +1,110 @@
+// tests/emu/metablock_emu.cpp -- serial CPU stand-in for the meta-block device seam (metablock_api.h).
+// TEST INFRASTRUCTURE ONLY (see device_emu.cpp).
+#define BROTLI_HOST_EMU 1
+#include <string.h>
+
+#include <vector>
+
+#include "../../rust-brotli_amd/csrc/metablock_api.h"
+#include "../../rust-brotli_amd/csrc/metablock_items.h"
+
+namespace brotli_mi355x {
+
+size_t mb_scan_scratch_bytes(size_t) { return 64; }
+
+static void exclusive_scan(uint32_t* a, size_t n) {
+  uint32_t run = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t v = a[i];
+    a[i] = run;
+    run += v;
+  }
+}
+
+void mb_command_scans(const MbBuffers& B, void*) {
+  for (uint32_t c = 0; c < B.n_cmds; ++c) mb_item_command_counts(B, c);
+  B.cmd_lit_start[B.n_cmds] = 0;
+  B.cmd_pos[B.n_cmds] = 0;
+  B.cmd_dist_index[B.n_cmds] = 0;
+  exclusive_scan(B.cmd_lit_start, B.n_cmds + 1);
+  exclusive_scan(B.cmd_pos, B.n_cmds + 1);
+  exclusive_scan(B.cmd_dist_index, B.n_cmds + 1);
+}
+
+void mb_literal_map(const MbBuffers& B) {
+  for (uint32_t i = 0; i < B.n_lits; ++i) mb_item_literal_map(B, i);
+}
+
+void mb_context_stats(const MbBuffers& B, uint32_t* stats) {
+  for (uint32_t m = 0; m < B.n_mb; ++m) {
+    uint32_t* s = stats + (size_t)m * kContextStatsWords;
+    memset(s, 0, kContextStatsWords * 4);
+    const MbDesc& d = B.descs[m];
+    const uint32_t length = d.end - d.start;
+    const uint32_t n_strides = length >= 64 ? (length - 64) / 4096 + 1 : 0;
+    for (uint32_t t = 0; t < n_strides; ++t) {
+      const uint8_t* p = B.text + d.start + t * 4096;
+      const int lut[4] = {0, 0, 1, 2};
+      int prev = lut[p[0] >> 6] * 3;
+      for (uint32_t k = 1; k < 64; ++k) {
+        s[prev + lut[p[k] >> 6]]++;
+        prev = lut[p[k] >> 6] * 3;
+      }
+      uint8_t prev2 = p[0], prev1 = p[1];
+      for (uint32_t k = 2; k < 64; ++k) {
+        const uint8_t literal = p[k];
+        const uint32_t context = br_static_context_map(3, br_context(B.utf8_lut, B.signed_lut, prev1, prev2, 2));
+        s[480]++;
+        s[16 + (literal >> 3)]++;
+        s[48 + context * 32 + (literal >> 3)]++;
+        prev2 = prev1;
+        prev1 = literal;
+      }
+    }
+  }
+}
+
+void mb_granule_histograms(const MbBuffers& B) {
+  std::vector<uint32_t> lds(kMaxStaticContexts * 256);
+  for (uint32_t g = 0; g < B.n_granules[kSplitLiteral]; ++g) mb_item_granule_histogram(B, kSplitLiteral, g, lds.data());
+  for (uint32_t g = 0; g < B.n_granules[kSplitCommand]; ++g) mb_item_granule_histogram(B, kSplitCommand, g, lds.data());
+  if (B.n_granules[kSplitDistance]) {
+    memset(B.gran_hist[kSplitDistance], 0, (size_t)B.n_granules[kSplitDistance] * kNumDistanceHistoSymbols * 2);
+    for (uint32_t c = 0; c < B.n_cmds; ++c) mb_item_distance_count(B, c);
+  }
+}
+
+void mb_split_chains(const MbBuffers& B) {
+  static SplitScratch S;
+  for (uint32_t m = 0; m < B.n_mb; ++m)
+    for (uint32_t kind = 0; kind < 3; ++kind) mb_item_split_chain(B, m, kind, S);
+}
+
+void mb_build_codes(const MbBuffers& B, const CodeJob* jobs, uint32_t n_jobs) {
+  for (uint32_t i = 0; i < n_jobs; ++i) mb_item_build_code(B, jobs[i].kind, jobs[i].row_index, jobs[i].num_distance_symbols, B.huff_scratch);
+}
+
+void mb_write_headers(const MbBuffers& B) {
+  for (uint32_t m = 0; m < B.n_mb; ++m) mb_item_write_header(B, m, B.huff_scratch);
+}
+
+void mb_symbol_bits(const MbBuffers& B, void*) {
+  for (uint32_t i = 0; i < B.n_lits; ++i) mb_item_literal_nbits(B, i);
+  B.lit_nbits[B.n_lits] = 0;
+  exclusive_scan(B.lit_nbits, B.n_lits + 1);
+  for (uint32_t c = 0; c < B.n_cmds; ++c) mb_item_command_nbits(B, c);
+  B.cmd_nbits[B.n_cmds] = 0;
+  exclusive_scan(B.cmd_nbits, B.n_cmds + 1);
+}
+
+void mb_emit(const MbBuffers& B) {
+  for (uint32_t c = 0; c < B.n_cmds; ++c) mb_item_emit_command(B, c);
+  for (uint32_t i = 0; i < B.n_lits; ++i) mb_item_emit_literal(B, i);
+}
+
+void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits) {
+  const uint64_t words = (nbits + 63) / 64;
+  for (uint64_t w = 0; w < words; ++w) mb_item_copy_bits_word(out, dst_bit, src, nbits, w);
+}
+
+}  // namespace brotli_mi355x
