@@ -208,6 +208,7 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
         S.last_entropy[i] = e;
         S.last_entropy[nc + i] = e;
       }
+      BR_SYNC();  // the entropy threads must finish reading curr before it is cleared
       for (uint32_t j = BR_TID; j < W; j += BR_NT) {
         H[j] = S.curr[j];
         S.curr[j] = 0;

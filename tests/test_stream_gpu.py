@@ -1,0 +1,57 @@
+"""GPU byte parity of complete streams: HIP encoder output == oracle output."""
+import glob
+import os
+
+import pytest
+
+import synth
+from cmp_stream import check_bytes
+
+pytestmark = pytest.mark.gpu
+Q, W, SH = 1, 2, 5
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import gpulib
+    return gpulib.lib()
+
+
+@pytest.mark.parametrize("q", [5, 6, 7, 8])
+def test_alice(L, q):
+    a = synth.alice()
+    assert check_bytes(L, "alice", a, [(Q, q), (W, 22), (SH, len(a))])
+
+
+def test_alice_variants(L):
+    a = synth.alice()
+    assert check_bytes(L, "alice", a, [(Q, 5), (W, 22)])
+    assert check_bytes(L, "alice", a, [(Q, 5), (W, 18), (SH, len(a))])
+    assert check_bytes(L, "alice", a, [(Q, 5), (W, 22), (168, 1), (169, 1)])
+    assert check_bytes(L, "alice", a, [(Q, 5), (W, 22), (167, 1)])
+    assert check_bytes(L, "alice", a, [(Q, 6), (W, 22), (168, 1), (172, 1)])
+
+
+def test_small_fixtures(L):
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))):
+        d = open(f, "rb").read()
+        assert check_bytes(L, os.path.basename(f), d, [(Q, 5), (W, 22), (SH, len(d))])
+        assert check_bytes(L, os.path.basename(f), d, [(Q, 5), (W, 22), (167, 1)])
+
+
+def test_markov_h6_multi_metablock(L):
+    d = synth.markov_text(6 << 20)
+    assert check_bytes(L, "markov6M", d, [(Q, 5), (W, 22), (SH, len(d))])
+
+
+def test_random_zeros_mixed(L):
+    assert check_bytes(L, "random300k", synth.random_bytes(300000), [(Q, 5), (W, 22)])
+    assert check_bytes(L, "zeros300k", bytes(300000), [(Q, 5), (W, 22)])
+    assert check_bytes(L, "mixed3M", synth.mixed(3 << 20), [(Q, 5), (W, 22)])
+
+
+def test_shard_with_prefix(L):
+    a = synth.alice()
+    h = len(a) // 2
+    assert check_bytes(L, "alice shard1", a[h:], [(Q, 5), (W, 22), (167, 1), (168, 1)], prefix=a[:h])
