@@ -1,0 +1,171 @@
+/* brotli_mi355x.h -- C ABI of the MI355X (gfx950) brotli encoder hot path.
+ *
+ * Drop-in for the encoder half of rust-brotli's C ABI: every entry point below has the same name,
+ * signature and meaning as the one the reference exports from its cdylib (headers c/brotli/encode.h and
+ * c/brotli/multiencode.h, implementation src/ffi/compressor.rs and src/ffi/multicompress/mod.rs).  The
+ * reference location each function replaces is cited next to it.  Plain pointers and sizes only.
+ *
+ * Behavioural contract: for the accelerated configurations (quality 5..8, lgwin 17..24, which select the
+ * H5 / H5q5 / H6 greedy path of the reference) the produced stream is byte-identical to the reference
+ * encoder fed the same way.  Everything runs on the GPU through HIP; there is no CPU fallback: calls with
+ * parameters outside the accelerated set, or on a machine without a usable gfx950 device, fail
+ * (BROTLI_FALSE / 0 / NULL) and print the reason on stderr.
+ *
+ * Streaming: input handed over with BROTLI_OPERATION_PROCESS is buffered (the encoder owns a copy, as the
+ * reference's ring buffer does); the stream is produced at BROTLI_OPERATION_FINISH.
+ * BROTLI_OPERATION_FLUSH and BROTLI_OPERATION_EMIT_METADATA are not implemented yet and return
+ * BROTLI_FALSE.
+ */
+#ifndef BROTLI_MI355X_H_
+#define BROTLI_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BROTLI_BOOL int
+#define BROTLI_TRUE 1
+#define BROTLI_FALSE 0
+
+/* c/brotli/types.h:71,81 */
+typedef void* (*brotli_alloc_func)(void* opaque, size_t size);
+typedef void (*brotli_free_func)(void* opaque, void* address);
+
+/* c/brotli/encode.h:45-61 (+ the reference's extra prior modes, src/ffi/compressor.rs:30-38) */
+typedef enum BrotliEncoderMode {
+  BROTLI_MODE_GENERIC = 0,
+  BROTLI_MODE_TEXT = 1,
+  BROTLI_MODE_FONT = 2,
+  BROTLI_FORCE_LSB_PRIOR = 3,
+  BROTLI_FORCE_MSB_PRIOR = 4,
+  BROTLI_FORCE_UTF8_PRIOR = 5,
+  BROTLI_FORCE_SIGNED_PRIOR = 6
+} BrotliEncoderMode;
+
+/* c/brotli/encode.h:71-135 */
+typedef enum BrotliEncoderOperation {
+  BROTLI_OPERATION_PROCESS = 0,
+  BROTLI_OPERATION_FLUSH = 1,
+  BROTLI_OPERATION_FINISH = 2,
+  BROTLI_OPERATION_EMIT_METADATA = 3
+} BrotliEncoderOperation;
+
+/* c/brotli/encode.h:138-232, src/enc/parameters.rs:3-33 */
+typedef enum BrotliEncoderParameter {
+  BROTLI_PARAM_MODE = 0,
+  BROTLI_PARAM_QUALITY = 1,
+  BROTLI_PARAM_LGWIN = 2,
+  BROTLI_PARAM_LGBLOCK = 3,
+  BROTLI_PARAM_DISABLE_LITERAL_CONTEXT_MODELING = 4,
+  BROTLI_PARAM_SIZE_HINT = 5,
+  BROTLI_PARAM_LARGE_WINDOW = 6,
+  BROTLI_PARAM_NPOSTFIX = 7,
+  BROTLI_PARAM_NDIRECT = 8,
+  BROTLI_PARAM_Q9_5 = 150,
+  BROTLI_METABLOCK_CALLBACK = 151,
+  BROTLI_PARAM_STRIDE_DETECTION_QUALITY = 152,
+  BROTLI_PARAM_HIGH_ENTROPY_DETECTION_QUALITY = 153,
+  BROTLI_PARAM_LITERAL_BYTE_SCORE = 154,
+  BROTLI_PARAM_CDF_ADAPTATION_DETECTION = 155,
+  BROTLI_PARAM_PRIOR_BITMASK_DETECTION = 156,
+  BROTLI_PARAM_SPEED = 157,
+  BROTLI_PARAM_SPEED_MAX = 158,
+  BROTLI_PARAM_CM_SPEED = 159,
+  BROTLI_PARAM_CM_SPEED_MAX = 160,
+  BROTLI_PARAM_SPEED_LOW = 161,
+  BROTLI_PARAM_SPEED_LOW_MAX = 162,
+  BROTLI_PARAM_CM_SPEED_LOW = 164,
+  BROTLI_PARAM_CM_SPEED_LOW_MAX = 165,
+  BROTLI_PARAM_AVOID_DISTANCE_PREFIX_SEARCH = 166,
+  BROTLI_PARAM_CATABLE = 167,
+  BROTLI_PARAM_APPENDABLE = 168,
+  BROTLI_PARAM_MAGIC_NUMBER = 169,
+  BROTLI_PARAM_NO_DICTIONARY = 170,
+  BROTLI_PARAM_FAVOR_EFFICIENCY = 171,
+  BROTLI_PARAM_BYTE_ALIGN = 172,
+  BROTLI_PARAM_BARE_STREAM = 173
+} BrotliEncoderParameter;
+
+typedef struct BrotliEncoderStateStruct BrotliEncoderState;
+typedef struct BrotliEncoderWorkPoolStruct BrotliEncoderWorkPool;
+
+/* ---- single-stream encoder: c/brotli/encode.h:256-457 ---- */
+/* src/ffi/compressor.rs:72 */
+BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, brotli_free_func free_func, void* opaque);
+/* src/ffi/compressor.rs:115 (returns BROTLI_FALSE once the encoder has started, encode.rs:289-295) */
+BROTLI_BOOL BrotliEncoderSetParameter(BrotliEncoderState* state, BrotliEncoderParameter p, uint32_t value);
+/* src/ffi/compressor.rs:128 (NULL is accepted) */
+void BrotliEncoderDestroyInstance(BrotliEncoderState* state);
+/* src/ffi/compressor.rs:190, src/enc/encode.rs:1276-1299 */
+size_t BrotliEncoderMaxCompressedSize(size_t input_size);
+/* src/ffi/compressor.rs:194, src/enc/encode.rs:1436-1538 */
+BROTLI_BOOL BrotliEncoderCompress(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size,
+                                  const uint8_t* input_buffer, size_t* encoded_size, uint8_t* encoded_buffer);
+/* src/ffi/compressor.rs:280, src/enc/encode.rs:2873-2995 */
+BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* state, BrotliEncoderOperation op, size_t* available_in,
+                                        const uint8_t** next_in, size_t* available_out, uint8_t** next_out,
+                                        size_t* total_out);
+/* src/ffi/compressor.rs:260 */
+BROTLI_BOOL BrotliEncoderCompressStreaming(BrotliEncoderState* state, BrotliEncoderOperation op, size_t* available_in,
+                                           const uint8_t* next_in, size_t* available_out, uint8_t* next_out);
+/* src/ffi/compressor.rs:144,153,179 */
+BROTLI_BOOL BrotliEncoderIsFinished(BrotliEncoderState* state);
+BROTLI_BOOL BrotliEncoderHasMoreOutput(BrotliEncoderState* state);
+const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* state, size_t* size);
+/* src/ffi/compressor.rs:162, src/enc/encode.rs:1196-1270 */
+void BrotliEncoderSetCustomDictionary(BrotliEncoderState* state, size_t size, const uint8_t* dict);
+/* src/ffi/compressor.rs:186: 0x01000f01 */
+uint32_t BrotliEncoderVersion(void);
+/* src/ffi/compressor.rs:359-417 */
+uint8_t* BrotliEncoderMallocU8(BrotliEncoderState* state, size_t size);
+void BrotliEncoderFreeU8(BrotliEncoderState* state, uint8_t* data, size_t size);
+size_t* BrotliEncoderMallocUsize(BrotliEncoderState* state, size_t size);
+void BrotliEncoderFreeUsize(BrotliEncoderState* state, size_t* data, size_t size);
+
+/* ---- multi-chunk encoder: c/brotli/multiencode.h:41-127 ---- */
+/* src/ffi/multicompress/mod.rs:49 */
+size_t BrotliEncoderMaxCompressedSizeMulti(size_t input_size, size_t num_threads);
+/* src/ffi/multicompress/mod.rs:93: the input is split into desired_num_threads (<= 16) chunks exactly as the
+   reference's compress_multi does (src/enc/threading/mod.rs:333-411); chunks are compressed on the GPU and
+   stitched with the BroCatli rules (src/concat/mod.rs). */
+int32_t BrotliEncoderCompressMulti(size_t num_params, const BrotliEncoderParameter* param_keys, const uint32_t* param_values,
+                                   size_t input_size, const uint8_t* input_buffer, size_t* encoded_size, uint8_t* encoded,
+                                   size_t desired_num_threads, brotli_alloc_func alloc_func, brotli_free_func free_func,
+                                   void** alloc_opaque_per_thread);
+/* src/ffi/multicompress/mod.rs:240,294,312: the work pool owns no threads here (the GPU is the pool) */
+BrotliEncoderWorkPool* BrotliEncoderCreateWorkPool(size_t num_threads, brotli_alloc_func alloc_func, brotli_free_func free_func,
+                                                   void** alloc_opaque_per_thread);
+void BrotliEncoderDestroyWorkPool(BrotliEncoderWorkPool* work_pool);
+int32_t BrotliEncoderCompressWorkPool(BrotliEncoderWorkPool* work_pool, size_t num_params, const BrotliEncoderParameter* param_keys,
+                                      const uint32_t* param_values, size_t input_size, const uint8_t* input_buffer,
+                                      size_t* encoded_size, uint8_t* encoded, size_t desired_num_threads,
+                                      brotli_alloc_func alloc_func, brotli_free_func free_func, void** alloc_opaque_per_thread);
+
+/* ---- extensions of this implementation (not part of the reference ABI) ---- */
+/* Compresses chunk `thread_index` of `num_threads` of a compress_multi job (what one reference worker thread
+   does in compress_part, src/enc/threading/mod.rs:337-411).  input_on_device != 0: input_buffer is a device
+   pointer (data resident in HBM).  Used to spread the chunks over several GPUs (one process per GPU). */
+int32_t BrotliMi355xCompressChunk(size_t num_params, const BrotliEncoderParameter* param_keys, const uint32_t* param_values,
+                                  size_t input_size, const uint8_t* input_buffer, int input_on_device, size_t thread_index,
+                                  size_t num_threads, size_t* encoded_size, uint8_t* encoded);
+/* Stitches already compressed chunks (in order) into one stream: BroCatli new_brotli_file/stream/finish,
+   src/enc/threading/mod.rs:565-660.  Returns 1 on success. */
+int32_t BrotliMi355xConcatChunks(size_t num_chunks, const uint8_t* const* chunks, const size_t* chunk_sizes,
+                                 size_t* encoded_size, uint8_t* encoded);
+/* One-shot compression of a buffer that is already resident in device memory; per-stage timings (ms) are
+   returned in stats[0..32) (may be NULL).  Same stream as BrotliEncoderCompress on the same bytes. */
+BROTLI_BOOL BrotliMi355xCompressDevice(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size,
+                                       const uint8_t* input_device, size_t* encoded_size, uint8_t* encoded_host,
+                                       double* stats);
+/* Human-readable description of the device backing the library ("hip:gfx950 (...)"). */
+const char* BrotliMi355xDeviceName(void);
+/* Message of the last failure on the calling thread ("" if none). */
+const char* BrotliMi355xLastError(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BROTLI_MI355X_H_ */

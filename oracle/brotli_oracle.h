@@ -108,6 +108,7 @@ int orc_compress_multi(const int* param_keys, const uint32_t* param_values, size
 
 /* glibc-compatible log2f restated (used to check the device implementation) */
 float orc_log2f_restated(float x);
+uint32_t orc_log2f_check_all(void);
 /* f32 BitsEntropy, reference src/enc/bit_cost.rs:13-42 */
 float orc_bits_entropy(const uint32_t* population, size_t size);
 

@@ -82,6 +82,15 @@ float orc_log2f_restated(float x) {
   return (float)y;
 }
 
+/* exhaustive check of the restatement against libm over every integer FastLog2 can be given
+   (256 .. 2^24): returns the number of mismatches */
+uint32_t orc_log2f_check_all(void) {
+  uint32_t bad = 0;
+  for (uint32_t v = 256; v <= (1u << 24); ++v)
+    if (orc_log2f_restated((float)v) != log2f((float)v)) bad++;
+  return bad;
+}
+
 /* histogram.rs:448-463 */
 uint8_t orc_context(uint8_t p1, uint8_t p2, int mode) {
   switch (mode) {

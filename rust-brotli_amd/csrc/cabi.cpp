@@ -1,0 +1,525 @@
+// cabi.cpp -- the C ABI of include/brotli_mi355x.h (drop-in for the encoder half of the reference's cdylib:
+// src/ffi/compressor.rs, src/ffi/multicompress/mod.rs).
+#include "../../include/brotli_mi355x.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "concat.h"
+#include "device_api.h"
+#include "encoder.h"
+#include "encoder_params.h"
+
+using namespace brotli_mi355x;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void SetError(const char* where, const char* what) {
+  g_last_error = std::string(where) + ": " + what;
+  fprintf(stderr, "brotli_mi355x: %s\n", g_last_error.c_str());
+}
+
+enum StreamState { kProcessing = 0, kFlushRequested = 1, kFinished = 2 };
+
+}  // namespace
+
+struct BrotliEncoderStateStruct {
+  brotli_alloc_func alloc_func;
+  brotli_free_func free_func;
+  void* opaque;
+  EncoderParams params;
+  bool initialized;      // set_parameter is refused afterwards (encode.rs:289-295)
+  bool first_encode_seen;
+  bool failed;
+  StreamState stream_state;
+  std::vector<uint8_t> input;
+  std::vector<uint8_t> dictionary;
+  bool has_dictionary;
+  std::vector<uint8_t> output;
+  size_t output_pos;
+  uint64_t total_out;
+  uint64_t total_in;
+};
+
+struct BrotliEncoderWorkPoolStruct {
+  brotli_alloc_func alloc_func;
+  brotli_free_func free_func;
+  void* opaque;
+};
+
+namespace {
+
+void EnsureInitialized(BrotliEncoderState* s) {
+  if (s->initialized) return;
+  s->initialized = true;
+}
+
+size_t BlockSize(const EncoderParams& user) {
+  EncoderParams p = user;
+  FinalizeParams(&p);
+  return (size_t)1 << p.lgblock;
+}
+
+// Runs the device encoder over everything buffered so far (called at FINISH).
+bool EncodeBuffered(BrotliEncoderState* s) {
+  try {
+    EncodeRequest req;
+    req.params = s->params;
+    req.input = s->input.data();
+    req.input_size = s->input.size();
+    if (s->has_dictionary) {
+      // set_custom_dictionary (encode.rs:1196-1270): last (1 << lgwin) - 16 bytes, no static dictionary,
+      // hasher chosen before any size hint, prev bytes stay 0
+      EncoderParams p = s->params;
+      FinalizeParams(&p);
+      const size_t max_dict = ((size_t)1 << p.lgwin) - 16;
+      const size_t n = s->dictionary.size();
+      const size_t use = std::min(n, max_dict);
+      req.prefix = s->dictionary.data() + (n - use);
+      req.prefix_size = use;
+      req.prefix_is_file_continuation = false;
+      req.hasher_chosen_before_size_hint = true;
+      req.params.use_dictionary = false;
+    }
+    std::vector<uint8_t> out;
+    EncodeStream(req, &out, nullptr);
+    s->output.swap(out);
+    s->output_pos = 0;
+    return true;
+  } catch (const std::exception& e) {
+    SetError("BrotliEncoderCompressStream", e.what());
+    s->failed = true;
+    return false;
+  }
+}
+
+size_t AvailableOut(const BrotliEncoderState* s) { return s->output.size() - s->output_pos; }
+
+// One chunk of a compress_multi job: compress_part, src/enc/threading/mod.rs:337-411
+void CompressChunk(const EncoderParams& user_params, const uint8_t* input, size_t input_size, bool input_on_device,
+                   size_t thread_index, size_t num_threads, std::vector<uint8_t>* out, const std::vector<uint8_t>* host_copy) {
+  const size_t start = (thread_index * input_size) / num_threads;
+  const size_t end = ((thread_index + 1) * input_size) / num_threads;
+  EncodeRequest req;
+  req.params = user_params;
+  if (thread_index != 0) {
+    req.params.catable = true;
+    req.params.magic_number = false;
+  }
+  req.params.appendable = true;
+  req.input = input + start;
+  req.input_size = end - start;
+  req.input_on_device = input_on_device;
+  std::vector<uint8_t> prefix_host;
+  if (thread_index != 0) {
+    // set_custom_dictionary_with_optional_precomputed_hasher(range.start, input[..range.start], _, true)
+    req.params.use_dictionary = false;
+    EncoderParams p = req.params;
+    FinalizeParams(&p);
+    const size_t max_dict = ((size_t)1 << p.lgwin) - 16;
+    const size_t use = std::min(start, max_dict);
+    if (input_on_device) {
+      prefix_host.resize(use);
+      dev_d2h(prefix_host.data(), input + (start - use), use);
+      req.prefix = prefix_host.data();
+    } else {
+      req.prefix = input + (start - use);
+    }
+    req.prefix_size = use;
+    if (start <= 1) {
+      // too short to prime: catable + appendable without a dictionary (encode.rs:1237-1241); prefix pointer
+      // stays non-null so that EncodeStream applies that rule
+      static const uint8_t dummy[1] = {0};
+      req.prefix = start == 0 ? dummy : req.prefix;
+      req.prefix_size = start;
+    }
+    req.prefix_is_file_continuation = true;
+    req.hasher_chosen_before_size_hint = start > 1;  // a too-short dictionary returns before hasher_setup
+  }
+  (void)host_copy;
+  EncodeStream(req, out, nullptr);
+}
+
+bool ParamsFromLists(size_t num_params, const BrotliEncoderParameter* keys, const uint32_t* values, EncoderParams* p) {
+  for (size_t i = 0; i < num_params; ++i)
+    if (!SetParameter(p, (int)keys[i], values[i])) return false;
+  return true;
+}
+
+int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys, const uint32_t* values, size_t input_size,
+                          const uint8_t* input, size_t* encoded_size, uint8_t* encoded, size_t desired_num_threads) {
+  if (desired_num_threads == 0) return 0;
+  const size_t num_threads = std::min<size_t>(desired_num_threads, 16);  // MAX_THREADS, multicompress/mod.rs:26
+  try {
+    std::vector<uint8_t> out;
+    if (num_threads == 1) {
+      // help_brotli_encoder_compress_single, multicompress/mod.rs:57-91: invalid parameters are ignored
+      EncodeRequest req;
+      for (size_t i = 0; i < num_params; ++i) SetParameter(&req.params, (int)keys[i], values[i]);
+      req.input = input;
+      req.input_size = input_size;
+      EncodeStream(req, &out, nullptr);
+    } else {
+      EncoderParams params;
+      if (!ParamsFromLists(num_params, keys, values, &params)) return 0;
+      ChunkStitcher stitcher;
+      for (size_t t = 0; t < num_threads; ++t) {
+        std::vector<uint8_t> chunk;
+        CompressChunk(params, input, input_size, false, t, num_threads, &chunk, nullptr);
+        if (!stitcher.Append(chunk.data(), chunk.size(), &out)) throw std::runtime_error("chunk cannot be concatenated");
+      }
+      stitcher.Finish(&out);
+    }
+    if (out.size() > *encoded_size) {
+      SetError("BrotliEncoderCompressMulti", "insufficient output space");
+      return 0;
+    }
+    memcpy(encoded, out.data(), out.size());
+    *encoded_size = out.size();
+    return 1;
+  } catch (const std::exception& e) {
+    SetError("BrotliEncoderCompressMulti", e.what());
+    return 0;
+  }
+}
+
+// MakeUncompressedStream, encode.rs:1388-1433
+size_t MakeUncompressedStream(const uint8_t* input, size_t input_size, uint8_t* output) {
+  size_t size = input_size, result = 0, offset = 0;
+  if (input_size == 0) {
+    output[0] = 6;
+    return 1;
+  }
+  output[result++] = 0x21;
+  output[result++] = 0x03;
+  while (size > 0) {
+    uint32_t nibbles = 0;
+    const uint32_t chunk_size = size > (1u << 24) ? (1u << 24) : (uint32_t)size;
+    if (chunk_size > (1u << 16)) nibbles = chunk_size > (1u << 20) ? 2 : 1;
+    const uint32_t bits = (nibbles << 1) | ((chunk_size - 1) << 3) | (1u << (19 + 4 * nibbles));
+    output[result++] = (uint8_t)bits;
+    output[result++] = (uint8_t)(bits >> 8);
+    output[result++] = (uint8_t)(bits >> 16);
+    if (nibbles == 2) output[result++] = (uint8_t)(bits >> 24);
+    memcpy(&output[result], &input[offset], chunk_size);
+    result += chunk_size;
+    offset += chunk_size;
+    size -= chunk_size;
+  }
+  output[result++] = 3;
+  return result;
+}
+
+}  // namespace
+
+extern "C" {
+
+BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, brotli_free_func free_func, void* opaque) {
+  if ((alloc_func == nullptr) != (free_func == nullptr)) {  // both or neither (compressor.rs:89-98)
+    SetError("BrotliEncoderCreateInstance", "alloc_func and free_func must be given together");
+    return nullptr;
+  }
+  void* mem = alloc_func ? alloc_func(opaque, sizeof(BrotliEncoderStateStruct)) : malloc(sizeof(BrotliEncoderStateStruct));
+  if (!mem) return nullptr;
+  BrotliEncoderState* s = new (mem) BrotliEncoderStateStruct();
+  s->alloc_func = alloc_func;
+  s->free_func = free_func;
+  s->opaque = opaque;
+  s->initialized = false;
+  s->first_encode_seen = false;
+  s->failed = false;
+  s->stream_state = kProcessing;
+  s->has_dictionary = false;
+  s->output_pos = 0;
+  s->total_out = 0;
+  s->total_in = 0;
+  return s;
+}
+
+BROTLI_BOOL BrotliEncoderSetParameter(BrotliEncoderState* state, BrotliEncoderParameter p, uint32_t value) {
+  if (!state || state->initialized) return BROTLI_FALSE;
+  return SetParameter(&state->params, (int)p, value) ? BROTLI_TRUE : BROTLI_FALSE;
+}
+
+void BrotliEncoderDestroyInstance(BrotliEncoderState* state) {
+  if (!state) return;
+  brotli_free_func free_func = state->free_func;
+  void* opaque = state->opaque;
+  state->~BrotliEncoderStateStruct();
+  if (free_func) {
+    free_func(opaque, state);
+  } else {
+    free(state);
+  }
+}
+
+size_t BrotliEncoderMaxCompressedSize(size_t input_size) { return MaxCompressedSize(input_size); }
+size_t BrotliEncoderMaxCompressedSizeMulti(size_t input_size, size_t num_threads) { return MaxCompressedSizeMulti(input_size, num_threads); }
+uint32_t BrotliEncoderVersion(void) { return 0x01000f01u; }
+
+BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOperation op, size_t* available_in,
+                                        const uint8_t** next_in, size_t* available_out, uint8_t** next_out,
+                                        size_t* total_out) {
+  if (!s || s->failed) return BROTLI_FALSE;
+  EnsureInitialized(s);
+  if (op == BROTLI_OPERATION_EMIT_METADATA || op == BROTLI_OPERATION_FLUSH) {
+    SetError("BrotliEncoderCompressStream", "BROTLI_OPERATION_FLUSH / EMIT_METADATA are not implemented on the device path");
+    return BROTLI_FALSE;
+  }
+  if (s->stream_state != kProcessing && *available_in != 0) return BROTLI_FALSE;  // encode.rs:2918-2922
+  if (s->stream_state == kProcessing) {
+    if (*available_in != 0) {
+      s->input.insert(s->input.end(), *next_in, *next_in + *available_in);
+      s->total_in += *available_in;
+      *next_in += *available_in;
+      *available_in = 0;
+    }
+    // size_hint as update_size_hint would see it at the first encode_data (encode.rs:1604-1620, 2970):
+    // everything received up to the end of the call in which the first input block fills up
+    if (!s->first_encode_seen && (s->input.size() >= BlockSize(s->params) || op != BROTLI_OPERATION_PROCESS)) {
+      s->first_encode_seen = true;
+      if (s->params.size_hint == 0) s->params.size_hint = std::min<size_t>(s->input.size(), (size_t)1 << 30);
+    }
+    if (op == BROTLI_OPERATION_FINISH) {
+      if (!EncodeBuffered(s)) return BROTLI_FALSE;
+      s->stream_state = kFinished;
+      std::vector<uint8_t>().swap(s->input);
+    }
+  }
+  // push output (inject_flush_or_push_output, encode.rs:1568-1598)
+  if (AvailableOut(s) != 0 && *available_out != 0) {
+    const size_t n = std::min(AvailableOut(s), *available_out);
+    memcpy(*next_out, s->output.data() + s->output_pos, n);
+    *next_out += n;
+    *available_out -= n;
+    s->output_pos += n;
+    s->total_out += n;
+  }
+  if (total_out) *total_out = (size_t)s->total_out;
+  return BROTLI_TRUE;
+}
+
+BROTLI_BOOL BrotliEncoderCompressStreaming(BrotliEncoderState* state, BrotliEncoderOperation op, size_t* available_in,
+                                           const uint8_t* next_in, size_t* available_out, uint8_t* next_out) {
+  const uint8_t* in = next_in;
+  uint8_t* out = next_out;
+  return BrotliEncoderCompressStream(state, op, available_in, &in, available_out, &out, nullptr);
+}
+
+BROTLI_BOOL BrotliEncoderIsFinished(BrotliEncoderState* s) {
+  return (s && s->stream_state == kFinished && AvailableOut(s) == 0) ? BROTLI_TRUE : BROTLI_FALSE;
+}
+BROTLI_BOOL BrotliEncoderHasMoreOutput(BrotliEncoderState* s) { return (s && AvailableOut(s) != 0) ? BROTLI_TRUE : BROTLI_FALSE; }
+
+const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* s, size_t* size) {
+  // take_output, encode.rs:3004-3030
+  size_t consumed = AvailableOut(s);
+  const uint8_t* result = s->output.data() + s->output_pos;
+  if (*size != 0) consumed = std::min(*size, consumed);
+  if (consumed != 0) {
+    s->output_pos += consumed;
+    s->total_out += consumed;
+    *size = consumed;
+    return result;
+  }
+  *size = 0;
+  return nullptr;
+}
+
+void BrotliEncoderSetCustomDictionary(BrotliEncoderState* s, size_t size, const uint8_t* dict) {
+  if (!s) return;
+  EnsureInitialized(s);
+  s->params.use_dictionary = false;
+  if (size == 0 || size <= 1) {
+    // too short: the reference only turns on catable + appendable (encode.rs:1237-1241)
+    s->params.catable = true;
+    s->params.appendable = true;
+    s->params.use_dictionary = false;
+    return;
+  }
+  s->dictionary.assign(dict, dict + size);
+  s->has_dictionary = true;
+}
+
+uint8_t* BrotliEncoderMallocU8(BrotliEncoderState* s, size_t size) {
+  return (uint8_t*)(s && s->alloc_func ? s->alloc_func(s->opaque, size) : malloc(size));
+}
+void BrotliEncoderFreeU8(BrotliEncoderState* s, uint8_t* data, size_t) {
+  if (s && s->free_func) {
+    s->free_func(s->opaque, data);
+  } else {
+    free(data);
+  }
+}
+size_t* BrotliEncoderMallocUsize(BrotliEncoderState* s, size_t size) {
+  return (size_t*)(s && s->alloc_func ? s->alloc_func(s->opaque, size * sizeof(size_t)) : malloc(size * sizeof(size_t)));
+}
+void BrotliEncoderFreeUsize(BrotliEncoderState* s, size_t* data, size_t) {
+  if (s && s->free_func) {
+    s->free_func(s->opaque, data);
+  } else {
+    free(data);
+  }
+}
+
+static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size, const uint8_t* input,
+                                   bool input_on_device, size_t* encoded_size, uint8_t* encoded, double* stats_out) {
+  // encoder_compress, encode.rs:1436-1538
+  const size_t out_size = *encoded_size;
+  const size_t max_out_size = MaxCompressedSize(input_size);
+  if (out_size == 0) return BROTLI_FALSE;
+  if (input_size == 0) {
+    *encoded_size = 1;
+    encoded[0] = 6;
+    return BROTLI_TRUE;
+  }
+  bool ok = false;
+  std::vector<uint8_t> out;
+  try {
+    EncodeRequest req;
+    SetParameter(&req.params, kParamQuality, (uint32_t)quality);
+    SetParameter(&req.params, kParamLgwin, (uint32_t)lgwin);
+    SetParameter(&req.params, kParamMode, (uint32_t)mode);
+    SetParameter(&req.params, kParamSizeHint, (uint32_t)input_size);
+    if (lgwin > 24) SetParameter(&req.params, kParamLargeWindow, 1);
+    req.input = input;
+    req.input_size = input_size;
+    req.input_on_device = input_on_device;
+    EncodeStats st;
+    EncodeStream(req, &out, &st);
+    if (stats_out) {
+      stats_out[0] = st.lz77_rounds;
+      stats_out[1] = (double)st.searches;
+      stats_out[2] = (double)st.commands;
+      stats_out[3] = (double)st.literals;
+      stats_out[4] = st.metablocks;
+      stats_out[5] = st.uncompressed_metablocks;
+      stats_out[6] = st.fallback_retries;
+      stats_out[7] = st.ms_lz77;
+      stats_out[8] = st.ms_metablock;
+      stats_out[9] = st.ms_total;
+      for (int i = 0; i < 16; ++i) stats_out[10 + i] = st.ms_phase[i];
+    }
+    ok = out.size() <= out_size;
+  } catch (const std::exception& e) {
+    SetError("BrotliEncoderCompress", e.what());
+    *encoded_size = 0;
+    return BROTLI_FALSE;  // no silent fallback for unsupported parameters / missing device
+  }
+  if (ok && !(max_out_size != 0 && out.size() > max_out_size)) {
+    memcpy(encoded, out.data(), out.size());
+    *encoded_size = out.size();
+    return BROTLI_TRUE;
+  }
+  *encoded_size = 0;
+  if (max_out_size == 0) return BROTLI_FALSE;
+  if (out_size >= max_out_size && !input_on_device) {
+    *encoded_size = MakeUncompressedStream(input, input_size, encoded);
+    return BROTLI_TRUE;
+  }
+  return BROTLI_FALSE;
+}
+
+BROTLI_BOOL BrotliEncoderCompress(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size, const uint8_t* input_buffer,
+                                  size_t* encoded_size, uint8_t* encoded_buffer) {
+  return CompressOneShot(quality, lgwin, mode, input_size, input_buffer, false, encoded_size, encoded_buffer, nullptr);
+}
+
+BROTLI_BOOL BrotliMi355xCompressDevice(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size,
+                                       const uint8_t* input_device, size_t* encoded_size, uint8_t* encoded_host, double* stats) {
+  return CompressOneShot(quality, lgwin, mode, input_size, input_device, true, encoded_size, encoded_host, stats);
+}
+
+int32_t BrotliEncoderCompressMulti(size_t num_params, const BrotliEncoderParameter* param_keys, const uint32_t* param_values,
+                                   size_t input_size, const uint8_t* input_buffer, size_t* encoded_size, uint8_t* encoded,
+                                   size_t desired_num_threads, brotli_alloc_func, brotli_free_func, void**) {
+  return CompressMultiImpl(num_params, param_keys, param_values, input_size, input_buffer, encoded_size, encoded, desired_num_threads);
+}
+
+BrotliEncoderWorkPool* BrotliEncoderCreateWorkPool(size_t, brotli_alloc_func alloc_func, brotli_free_func free_func, void** opaque) {
+  if ((alloc_func == nullptr) != (free_func == nullptr)) return nullptr;
+  void* o = opaque ? *opaque : nullptr;
+  void* mem = alloc_func ? alloc_func(o, sizeof(BrotliEncoderWorkPoolStruct)) : malloc(sizeof(BrotliEncoderWorkPoolStruct));
+  if (!mem) return nullptr;
+  BrotliEncoderWorkPool* w = (BrotliEncoderWorkPool*)mem;
+  w->alloc_func = alloc_func;
+  w->free_func = free_func;
+  w->opaque = o;
+  return w;
+}
+void BrotliEncoderDestroyWorkPool(BrotliEncoderWorkPool* w) {
+  if (!w) return;
+  if (w->free_func) {
+    w->free_func(w->opaque, w);
+  } else {
+    free(w);
+  }
+}
+int32_t BrotliEncoderCompressWorkPool(BrotliEncoderWorkPool*, size_t num_params, const BrotliEncoderParameter* param_keys,
+                                      const uint32_t* param_values, size_t input_size, const uint8_t* input_buffer,
+                                      size_t* encoded_size, uint8_t* encoded, size_t desired_num_threads, brotli_alloc_func,
+                                      brotli_free_func, void**) {
+  return CompressMultiImpl(num_params, param_keys, param_values, input_size, input_buffer, encoded_size, encoded, desired_num_threads);
+}
+
+int32_t BrotliMi355xCompressChunk(size_t num_params, const BrotliEncoderParameter* param_keys, const uint32_t* param_values,
+                                  size_t input_size, const uint8_t* input_buffer, int input_on_device, size_t thread_index,
+                                  size_t num_threads, size_t* encoded_size, uint8_t* encoded) {
+  try {
+    EncoderParams params;
+    if (!ParamsFromLists(num_params, param_keys, param_values, &params)) return 0;
+    if (num_threads == 0 || thread_index >= num_threads) return 0;
+    std::vector<uint8_t> out;
+    CompressChunk(params, input_buffer, input_size, input_on_device != 0, thread_index, num_threads, &out, nullptr);
+    if (out.size() > *encoded_size) {
+      SetError("BrotliMi355xCompressChunk", "insufficient output space");
+      return 0;
+    }
+    memcpy(encoded, out.data(), out.size());
+    *encoded_size = out.size();
+    return 1;
+  } catch (const std::exception& e) {
+    SetError("BrotliMi355xCompressChunk", e.what());
+    return 0;
+  }
+}
+
+int32_t BrotliMi355xConcatChunks(size_t num_chunks, const uint8_t* const* chunks, const size_t* chunk_sizes, size_t* encoded_size,
+                                 uint8_t* encoded) {
+  std::vector<uint8_t> out;
+  ChunkStitcher stitcher;
+  for (size_t i = 0; i < num_chunks; ++i) {
+    if (!stitcher.Append(chunks[i], chunk_sizes[i], &out)) {
+      SetError("BrotliMi355xConcatChunks", "chunk cannot be concatenated");
+      return 0;
+    }
+  }
+  stitcher.Finish(&out);
+  if (out.size() > *encoded_size) {
+    SetError("BrotliMi355xConcatChunks", "insufficient output space");
+    return 0;
+  }
+  memcpy(encoded, out.data(), out.size());
+  *encoded_size = out.size();
+  return 1;
+}
+
+const char* BrotliMi355xDeviceName(void) {
+  try {
+    return dev_name();
+  } catch (...) {
+    return "unavailable";
+  }
+}
+const char* BrotliMi355xLastError(void) { return g_last_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""CPU tests of the PRODUCT's host driver and chain / meta-block code, compiled for the host by
+tests/emu (one lane per wave, serial loops instead of kernels), against the oracle.  They prove the
+speculative-parse resolver, meta-block planning, stitching and C-ABI state machine without a GPU; the
+`-m gpu` tests repeat the same comparisons through the HIP kernels."""
+import glob
+import os
+
+import pytest
+
+import emu
+import orc
+import synth
+from cmp_lz77 import check
+from cmp_stream import check_bytes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+Q, W, SH = 1, 2, 5
+
+
+@pytest.fixture(scope="module")
+def L():
+    return emu.lib()
+
+
+@pytest.mark.parametrize("q", [5, 6, 7, 8])
+def test_lz77_commands_alice(L, q):
+    assert check("alice", synth.alice(), q, 22, lib=L)
+
+
+@pytest.mark.parametrize("seg", [512, 1024, 65536])
+def test_lz77_segment_sizes(L, seg):
+    assert check("alice", synth.alice(), 5, 22, seg=seg, lib=L)
+
+
+def test_lz77_h6_and_spree(L):
+    assert check("markov5M", synth.markov_text(5 << 20), 5, 22, lib=L)  # size_hint > 4 MiB: H6
+    assert check("random200k", synth.random_bytes(200000), 5, 22, lib=L)
+    assert check("zeros200k", bytes(200000), 5, 22, lib=L)
+
+
+def test_stream_bytes_fixtures(L):
+    files = sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))) + [os.path.join(GOLDEN, "alice29.txt")]
+    for f in files:
+        d = open(f, "rb").read()
+        b = os.path.basename(f)
+        assert check_bytes(L, b, d, [(Q, 5), (W, 22), (SH, len(d))], verbose=False)
+        assert check_bytes(L, b, d, [(Q, 7), (W, 22)], verbose=False)
+        assert check_bytes(L, b, d, [(Q, 5), (W, 18), (SH, len(d))], verbose=False)
+        assert check_bytes(L, b, d, [(Q, 5), (W, 22), (168, 1), (169, 1)], verbose=False)  # appendable + magic number
+        assert check_bytes(L, b, d, [(Q, 5), (W, 22), (167, 1)], verbose=False)  # catable
+        assert check_bytes(L, b, d, [(Q, 6), (W, 22), (168, 1), (172, 1)], verbose=False)  # appendable + byte_align
+
+
+def test_stream_bytes_synthetic(L):
+    d = synth.markov_text(3 << 20)
+    assert check_bytes(L, "markov3M", d, [(Q, 5), (W, 22), (SH, len(d))], verbose=False)
+    assert check_bytes(L, "mixed2M", synth.mixed(2 << 20), [(Q, 5), (W, 22)], verbose=False)
+    assert check_bytes(L, "random300k", synth.random_bytes(300000), [(Q, 5), (W, 22)], verbose=False)
+
+
+def test_shard_with_prefix(L):
+    a = synth.alice()
+    h = len(a) // 3
+    assert check_bytes(L, "alice shard", a[h:2 * h], [(Q, 5), (W, 22), (167, 1), (168, 1)], prefix=a[:h], verbose=False)

@@ -1,0 +1,80 @@
+"""The oracle (CPU restatement of the reference) against the reference's own pins:
+  * encoder_compress(q9, lgwin16, alice29) == 51737 bytes        (src/enc/encode.rs:3073-3099)
+  * compress_multi size bounds on random_then_unicode             (src/bin/test_threading.rs:91-110)
+  * round trips through an independent decoder (libbrotlidec)
+plus the frozen sha256 of its own outputs (tests/golden/oracle_hashes.json)."""
+import glob
+import hashlib
+import json
+import os
+
+import pytest
+
+import orc
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+Q, W, MAGIC = 1, 2, 169
+
+
+def test_reference_kat_51737():
+    a = synth.alice()
+    assert hashlib.sha256(a).hexdigest().startswith("7467306e")
+    c, st = orc.compress(a, 9, 16, with_stats=True)
+    assert len(c) == 51737
+    assert orc.decompress(c, len(a)) == a
+
+
+def test_compress_multi_bounds():
+    d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
+    assert len(d) == 272666
+    for nt, q, bound in ((3, 5, 144325), (5, 9, 139126)):
+        c = orc.compress_multi(d, [(Q, q), (MAGIC, 1)], nt)
+        assert len(c) <= bound
+        assert orc.decompress(c, len(d)) == d
+
+
+@pytest.mark.parametrize("q,w", [(5, 22), (6, 16), (7, 22), (9, 22), (9, 16), (5, 10), (5, 18)])
+def test_round_trips(q, w):
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))) + [os.path.join(GOLDEN, "alice29.txt")]:
+        d = open(f, "rb").read()
+        assert orc.decompress(orc.compress(d, q, w), len(d)) == d, f
+        assert orc.decompress(orc.writer_compress(d, q, w, chunk=4096), len(d)) == d, f
+
+
+def test_empty_and_tiny_multi():
+    for data in (b"", b"x", b"xy", b"xyz"):
+        for nt in (1, 2, 5):
+            c = orc.compress_multi(data, [(Q, 5), (MAGIC, 1)], nt)
+            assert orc.decompress(c, len(data)) == data
+
+
+def test_frozen_hashes():
+    """sha256 of oracle outputs frozen when the oracle reproduced the reference KAT (regression guard)"""
+    frozen = json.load(open(os.path.join(GOLDEN, "oracle_hashes.json")))
+    a = synth.alice()
+    got = {}
+    for q in (5, 6, 7, 8, 9):
+        got["alice29 q%d w22" % q] = hashlib.sha256(orc.compress(a, q, 22)).hexdigest()
+    got["alice29 q9 w16"] = hashlib.sha256(orc.compress(a, 9, 16)).hexdigest()
+    got["alice29 writer4096 q5 w22"] = hashlib.sha256(orc.writer_compress(a, 5, 22, chunk=4096)).hexdigest()
+    m = synth.markov_text(1 << 20)
+    got["markov1M q5 w22"] = hashlib.sha256(orc.compress(m, 5, 22)).hexdigest()
+    assert got == frozen
+
+
+def test_log2f_restatement_matches_libm():
+    """the device uses a restated glibc log2f; it must equal libm on the values FastLog2 can see"""
+    import ctypes
+    import numpy as np
+    libm = ctypes.CDLL("libm.so.6")
+    libm.log2f.restype = ctypes.c_float
+    libm.log2f.argtypes = [ctypes.c_float]
+    L = orc.lib()
+    rng = np.random.RandomState(1)
+    vals = list(range(256, 70000)) + [int(x) for x in rng.randint(256, 1 << 24, size=60000)] + [1 << 24, (1 << 24) - 1]
+    for v in vals:
+        assert L.orc_log2f_restated(float(v)) == libm.log2f(float(v)), v
+    L.orc_log2f_check_all.restype = ctypes.c_uint32
+    assert L.orc_log2f_check_all() == 0  # every integer in [256, 2^24]
