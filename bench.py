@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- compress throughput of the MI355X brotli encoder hot path (quality 5, lgwin 22).
+
+A "step" is one full compression of one batch of synthetic input: 64 MiB of English-like text
+(word-bigram Markov chain over alice29.txt tokens, SURVEY 8d / BASELINE.json configs[1]) resident in HBM
+when the timed region starts; the compressed stream lands in host memory.  With N > 1 (one process per
+GPU, launched by torch.distributed.run) the job is the reference's compress_multi split: rank r compresses
+chunk r of an N x 64 MiB stream (its chunk plus the preceding <= 4 MiB as LZ77 prefix, exactly what a
+compress_part worker sees, src/enc/threading/mod.rs:337-411); the compressed chunks are gathered to rank 0
+over RCCL and stitched there (BroCatli).  Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0 (see the driver contract): metric/value/unit + `roofline` for the dominant
+kernel (k_parse_segments, HBM bound, timed with HIP events on its stream inside the library) +
+`cpu_baseline` (the oracle = CPU restatement of the reference path, single thread, same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "rust-brotli_amd"))
+
+WORKLOAD_BYTES = 64 << 20
+QUALITY, LGWIN = 5, 22
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s peak
+
+
+def workload(nbytes, seed):
+    import synth
+    cache = "/tmp/brotli_mi355x_markov_%d_%x.bin" % (nbytes, seed)
+    if os.path.exists(cache) and os.path.getsize(cache) == nbytes:
+        return open(cache, "rb").read()
+    data = synth.markov_text(nbytes, seed)
+    try:
+        with open(cache + ".tmp%d" % os.getpid(), "wb") as f:
+            f.write(data)
+        os.replace(cache + ".tmp%d" % os.getpid(), cache)
+    except OSError:
+        pass
+    return data
+
+
+def cpu_baseline(data):
+    """the oracle (port of the reference path), one thread, on the same workload"""
+    import subprocess
+    import orc
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liborc_fast.so"])
+    L = ctypes.CDLL(os.path.join(ROOT, "oracle", "liborc_fast.so"))
+    L.orc_max_compressed_size.restype = ctypes.c_size_t
+    L.orc_max_compressed_size.argtypes = [ctypes.c_size_t]
+    L.orc_encoder_compress.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p,
+                                       ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.c_void_p]
+    cap = L.orc_max_compressed_size(len(data)) + 64
+    out = ctypes.create_string_buffer(cap)
+    best = None
+    reps = 0
+    t_all = time.time()
+    while reps < 2 or (time.time() - t_all < 10.0 and reps < 6):
+        n = ctypes.c_size_t(cap)
+        t = time.time()
+        ok = L.orc_encoder_compress(QUALITY, LGWIN, 0, len(data), data, ctypes.byref(n), out, None)
+        dt = time.time() - t
+        assert ok
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    return {"value": round(len(data) / best / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "the whole %d MiB workload, best of %d runs, oracle built -O3 -march=native" % (len(data) >> 20, reps)}, out.raw[:n.value]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mib", type=int, default=WORKLOAD_BYTES >> 20, help="per-GPU batch size in MiB")
+    ap.add_argument("--segment-bytes", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+
+    import brotli_mi355x as bm
+    lib = bm.default_library()
+    per_gpu = args.mib << 20
+    total = per_gpu * world
+    # every rank needs its chunk and the preceding window of the global stream: generate the part it needs
+    seed = 0x5EED000000000002
+    if world == 1:
+        data = workload(per_gpu, seed)
+        prefix = b""
+        chunk = data
+    else:
+        import synth
+        full = workload(total, seed)  # deterministic; ranks read the cached file after the first run
+        start = (rank * total) // world
+        end = ((rank + 1) * total) // world
+        win = (1 << LGWIN) - 16
+        prefix = full[max(0, start - win):start] if rank else b""
+        chunk = full[start:end]
+        data = full if rank == 0 else None
+    dev = torch.frombuffer(bytearray(chunk), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+
+    # flat entry point: explicit prefix + device resident chunk (tests/emu.py binding)
+    import emu
+    L = emu.bind_encode(lib.lib)
+    params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN)]
+    if world > 1:
+        params.append((bm.BROTLI_PARAM_APPENDABLE, 1))
+        if rank:
+            params.append((bm.BROTLI_PARAM_CATABLE, 1))
+    else:
+        params.append((bm.BROTLI_PARAM_SIZE_HINT, per_gpu))  # BrotliEncoderCompress sets SIZE_HINT = input size
+    keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
+    vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
+    cap = len(chunk) + len(chunk) // 4 + 4096
+    out = ctypes.create_string_buffer(cap)
+    st = (ctypes.c_double * 32)()
+    err = ctypes.create_string_buffer(512)
+
+    def one_step():
+        n = L.brotli_mi355x_encode_stream(keys, vals, len(params), prefix, len(prefix), 1, ctypes.c_void_p(dev.data_ptr()),
+                                          len(chunk), 1, args.segment_bytes, out, cap, st, err, 512)
+        if n < 0:
+            raise RuntimeError(err.value.decode())
+        comp = out.raw[:n]
+        if world > 1:
+            # gather of the variable-length compressed chunks to rank 0 (sizes first, then padded payloads)
+            size_t = torch.tensor([n], dtype=torch.int64, device="cuda")
+            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(sizes, size_t)
+            mx = int(max(int(s.item()) for s in sizes))
+            payload = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+            payload[:n] = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+            bufs = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
+            dist.gather(payload, bufs, dst=0)
+            if rank == 0:
+                chunks = [bytes(bufs[r][:int(sizes[r].item())].cpu().numpy()) for r in range(world)]
+                comp = lib.concat_chunks(chunks)
+        return comp, list(st)
+
+    for _ in range(args.warmup):
+        one_step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    agg = {"parse_ms": 0.0, "launches": 0, "segments": 0.0, "searches": 0.0, "commands": 0.0, "rounds": 0.0}
+    comp = None
+    for _ in range(args.steps):
+        comp, s = one_step()
+        agg["parse_ms"] += s[26]
+        agg["launches"] += int(s[27])
+        agg["segments"] += s[28]
+        agg["searches"] = s[1]
+        agg["commands"] = s[2]
+        agg["rounds"] += s[0]
+        nseg = s[29]
+        phases = s[10:20]
+        lz_ms, mb_ms = s[7], s[8]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.time() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total * args.steps / elapsed / 1e6
+    # algorithmic bytes of one launch of the dominant kernel (DESIGN.md "roofline"): for the bytes a launch
+    # covers: input read once (1 B/B) + stored-flag written (1 B/B) + per searched position the candidate row
+    # (ring depth 16 x 4 B) and its key/rank (6 B) + 16 B per command written.
+    S, K = agg["searches"], agg["commands"]
+    alg_full_pass = per_gpu * 2.0 + S * (16 * 4 + 6) + K * 16
+    frac_per_launch = (agg["segments"] / max(1, agg["launches"])) / max(1.0, nseg)
+    alg_bytes_per_launch = alg_full_pass * frac_per_launch
+    avg_launch_ms = agg["parse_ms"] / max(1, agg["launches"])
+    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_parse.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "compress MB/s at q5 lgwin22", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%d MiB synthetic English-like text per GPU (word-bigram Markov over alice29 tokens), quality=5, lgwin=22, "
+                               "%s" % (args.mib, "one-shot BrotliEncoderCompress semantics (H6 hasher)" if world == 1 else
+                                       "compress_multi chunk per GPU + RCCL gather + BroCatli stitch"),
+                   "input_bytes_total": total, "compressed_bytes": len(comp), "ratio": round(total / max(1, len(comp)), 4),
+                   "segment_bytes": args.segment_bytes, "lz77_rounds_per_step": agg["rounds"] / args.steps,
+                   "stage_ms_last_step": {"lz77": round(lz_ms, 2), "metablock": round(mb_ms, 2)}},
+        "roofline": {"bound": "hbm", "kernel": "k_parse_segments", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": agg["launches"] / args.steps,
+                     "alg_bytes_per_launch": int(alg_bytes_per_launch)},
+    }
+    if not args.no_cpu_baseline:
+        sample = data if world == 1 else data[:per_gpu]
+        base, ref_bytes = cpu_baseline(sample)
+        line["cpu_baseline"] = base
+        if world == 1:
+            line["config"]["identical_to_cpu_oracle"] = (ref_bytes == comp)
+    print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

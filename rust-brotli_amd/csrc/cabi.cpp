@@ -408,6 +408,11 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
       stats_out[8] = st.ms_metablock;
       stats_out[9] = st.ms_total;
       for (int i = 0; i < 16; ++i) stats_out[10 + i] = st.ms_phase[i];
+      stats_out[26] = st.parse_kernel_ms;
+      stats_out[27] = st.parse_launches;
+      stats_out[28] = (double)st.parse_segments;
+      stats_out[29] = st.num_segments;
+      stats_out[30] = st.segment_bytes;
     }
     ok = out.size() <= out_size;
   } catch (const std::exception& e) {

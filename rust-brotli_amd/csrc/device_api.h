@@ -69,6 +69,8 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through
 // rank/sorted) and write flags[which ^ 1], cmds and exits
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment);
+// accumulated device time (HIP events) of the parse kernel launches since the last call
+void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]

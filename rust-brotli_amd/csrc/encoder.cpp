@@ -275,6 +275,17 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     Clock clk;
     lz.Run();
     stats.ms_lz77 += clk.lap(prof);
+    {
+      double ms;
+      uint32_t launches;
+      uint64_t segs;
+      lz77_parse_timing(&ms, &launches, &segs);
+      stats.parse_kernel_ms += ms;
+      stats.parse_launches += launches;
+      stats.parse_segments += segs;
+      stats.num_segments = lz.device_params().num_segments;
+      stats.segment_bytes = req.segment_bytes;
+    }
     stats.lz77_rounds += lz.stats().rounds;
     stats.searches = lz.stats().searches;
     const std::vector<MetaBlockPlan>& plans = lz.metablocks();

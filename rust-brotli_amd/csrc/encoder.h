@@ -24,6 +24,11 @@ struct EncodeStats {
   uint32_t fallback_retries = 0;
   double ms_lz77 = 0, ms_metablock = 0, ms_total = 0;
   double ms_phase[16] = {0};
+  // dominant kernel (k_parse_segments) timed with HIP events on its stream
+  double parse_kernel_ms = 0;
+  uint32_t parse_launches = 0;
+  uint64_t parse_segments = 0;
+  uint32_t num_segments = 0, segment_bytes = 0;
 };
 
 struct EncodeRequest {

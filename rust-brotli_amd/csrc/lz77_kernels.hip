@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "device_api.h"
 #include "lz77_chain.h"
@@ -256,6 +258,15 @@ struct ParseArgs {
   uint32_t first_segment;
 };
 
+struct ParseTiming {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  uint64_t segments = 0;
+};
+static ParseTiming& parse_timing() {
+  static thread_local ParseTiming t;
+  return t;
+}
+
 __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratch scratch;
   const uint32_t k = a.first_segment + blockIdx.x;
@@ -288,8 +299,35 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint
   a.entries = B.entries;
   a.exits = B.exits;
   a.first_segment = first_segment;
+  // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
+  ParseTiming& pt = parse_timing();
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, 0));
   hipLaunchKernelGGL(k_parse_segments, dim3(P.num_segments - first_segment), dim3(64), 0, 0, a);
+  HIP_CHECK(hipEventRecord(e1, 0));
   HIP_CHECK(hipGetLastError());
+  pt.events.push_back(std::make_pair(e0, e1));
+  pt.segments += P.num_segments - first_segment;
+}
+
+void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {
+  ParseTiming& pt = parse_timing();
+  double ms = 0;
+  for (auto& ev : pt.events) {
+    float t = 0;
+    HIP_CHECK(hipEventSynchronize(ev.second));
+    HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
+    ms += t;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  *total_ms = ms;
+  *launches = (uint32_t)pt.events.size();
+  *segments = pt.segments;
+  pt.events.clear();
+  pt.segments = 0;
 }
 
 // ------------------------------------------------------------------------------------------ misc

@@ -126,6 +126,12 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint
   }
 }
 
+void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {
+  *total_ms = 0;
+  *launches = 0;
+  *segments = 0;
+}
+
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo) {
   memset(histo, 0, 256 * 4);
   const uint32_t samples = (bytes + 12) / 13;
