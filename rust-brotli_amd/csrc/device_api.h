@@ -44,6 +44,7 @@ struct Lz77Buffers {
   uint32_t* by_key;     // positions sorted by (key, position)            [total_bytes]
   uint16_t* sorted_keys;// keys in that order                              [total_bytes]
   uint32_t* rank;       // per position                                    [total_bytes]
+  uint32_t* info;       // per position {rank, count of stored same-key positions before it} [2 * total_bytes]
   uint32_t* sorted;     // stored positions in (key,pos) order             [total_bytes]
   uint32_t* key_base;   // per key                                         [65536 + 1]
   uint8_t* flags[2];    // stored flags, double buffered                   [total_bytes + 64]

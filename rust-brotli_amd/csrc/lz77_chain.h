@@ -44,9 +44,8 @@ static constexpr uint32_t kMinScore = 30 * 8 * 8 + 100;  // mod.rs:2408-2410
 
 struct ChainTables {
   const uint8_t* text;         // dictionary prefix + input (+ >= 16 bytes of zero padding)
-  const uint16_t* keys;        // hash key per position
-  const uint32_t* rank;        // per position: number of stored positions before it in (key,pos) order
-  const uint32_t* key_base;    // per key: rank of the first position of that key
+  const uint32_t* info;        // per position: {rank among the stored positions in (key,pos) order,
+                               //                number of stored positions of the same key before it}
   const uint32_t* sorted;      // stored positions in (key,pos) order
   const uint8_t* flags_prev;   // stored flags used to build rank/sorted (previous round)
   uint8_t* flags_next;         // stored flags produced by this round
@@ -60,8 +59,8 @@ struct ChainTables {
 };
 
 struct ChainScratch {  // one per wavefront (LDS on the device)
-  uint32_t cand_prev[kMaxCandidates];
-  uint32_t cand_len[kMaxCandidates];
+  uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
+  uint32_t cand_len[2][kMaxCandidates + 2];
   uint32_t flag_changes[64];
 };
 
@@ -214,74 +213,78 @@ struct DictState {
   int32_t maxdef;
 };
 
-// SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false)
-BR_DEV bool br_search_static_dictionary(const Lz77Params& P, const ChainTables& t, DictState& ds, const uint8_t* data,
-                                        uint32_t max_length, uint32_t max_backward, SearchResult& out) {
-  const bool dead = ds.matches < (ds.lookups >> 7);
-  const uint32_t seen = dead ? 2u : 1u;
-  ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
-  if (dead) return false;
-  {
-    int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
-    if (def > ds.maxdef) ds.maxdef = def;
-  }
-  bool is_match_found = false;
-  uint32_t key = ((br_load32(data) * 0x1e35a7bdu) >> (32 - 14)) << 1;
-  for (int i = 0; i < 2; ++i, ++key) {
-    const uint32_t item = t.dict_hash[key];
-    ds.lookups++;
-    if (item != 0) {
-      const uint32_t len = item & 0x1f;
-      const uint32_t dist = item >> 5;
-      const uint32_t offset = t.dict_offsets_by_length[len] + len * dist;
-      if (len > max_length) continue;
-      const uint32_t matchlen = br_match_len(data, t.dict_data + offset, len);
-      if (matchlen + 10 <= len || matchlen == 0) continue;
-      const uint32_t cut = len - matchlen;
-      const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
-      const uint32_t backward = max_backward + dist + 1 + (transform_id << t.dict_size_bits_by_length[len]);
-      if (backward > P.dist_max_distance) continue;
-      const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
-      if (score < out.score) continue;
-      out.len = matchlen;
-      out.len_x_code = len ^ matchlen;
-      out.distance = backward;
-      out.score = score;
-      ds.matches++;
-      is_match_found = true;
-    }
-  }
-  return is_match_found;
-}
+// ---- speculative probe of two consecutive positions ---------------------------------------------------
+// Phase 1 of AdvHasher::FindLongestMatch (mod.rs:1684-1812) for positions p0 and p0 + 1 at once: every
+// candidate of both positions (dist-cache entries, bucket ring entries, the two static-dictionary probes)
+// gets its own lane, which locates it and measures the common prefix.  All global loads of the two searches
+// are issued together, so the pair costs one dependent-load chain (info -> sorted -> text) instead of two.
+// The greedy parse consumes search(p0) and then, in almost every case, search(p0 + 1) (as the lazy probe
+// after a match, or as the next position after a miss), with an unchanged distance cache.
+struct ProbeMeta {
+  uint32_t pos;       // p0; 0xffffffff = nothing probed
+  uint32_t version;   // dist-cache version the probe was computed with
+  uint32_t g[2], nbucket[2];
+};
 
-// AdvHasher::FindLongestMatch, mod.rs:1684-1812.  cache[] holds ndist prepared distances.
-BR_DEV SearchResult br_find_longest_match(const Lz77Params& P, const ChainTables& t, ChainScratch& s, DictState& ds,
-                                          uint32_t cur, const int32_t* cache, uint32_t max_length, uint32_t blk_end) {
-  const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
-  const uint8_t* cur_data = t.text + cur;
+BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratch& s, ProbeMeta& m, uint32_t p0,
+                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
   const uint32_t ndist = P.ndist;
   const uint32_t block_size = 1u << P.block_bits;
-  const uint32_t key = t.keys[cur];
-  const uint32_t g = t.rank[cur];
-  const uint32_t num_copy = (g - t.key_base[key]) & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
-  const uint32_t nbucket = num_copy < block_size ? num_copy : block_size;
-  const uint32_t ncand = ndist + nbucket;
-  // phase 1: one candidate per lane -- locate it and measure the common prefix
-  for (uint32_t c = BR_LANE; c < ncand; c += BR_NLANES) {
+  const uint32_t ndict = P.use_dictionary ? 2u : 0u;
+  uint32_t n[2];
+  for (int w = 0; w < 2; ++w) {
+    const uint32_t g = t.info[2 * (size_t)(p0 + w)];
+    const uint32_t num_copy = t.info[2 * (size_t)(p0 + w) + 1] & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
+    m.g[w] = g;
+    m.nbucket[w] = num_copy < block_size ? num_copy : block_size;
+    n[w] = ndist + m.nbucket[w] + ndict;
+  }
+  m.pos = p0;
+  m.version = cache_version;
+  const uint32_t total = n[0] + n[1];
+  for (uint32_t slot = BR_LANE; slot < total; slot += BR_NLANES) {
+    const uint32_t w = slot < n[0] ? 0u : 1u;
+    const uint32_t c = slot - (w ? n[0] : 0u);
+    const uint32_t cur = p0 + w;
+    const uint32_t max_length = pos_end - cur;
+    const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+    const uint8_t* cur_data = t.text + cur;
     uint32_t prev = 0xffffffffu, len = 0;
-    if (c < ndist) {
-      const int64_t b = (int64_t)cache[c];
-      if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+    if (c < ndist + m.nbucket[w]) {
+      if (c < ndist) {
+        const int64_t b = (int64_t)cache[c];
+        if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+      } else {
+        const uint32_t q = t.sorted[m.g[w] - 1 - (c - ndist)];
+        if (cur - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
+      }
+      if (prev != 0xffffffffu) len = br_match_len(t.text + prev, cur_data, max_length);
     } else {
-      const uint32_t q = t.sorted[g - 1 - (c - ndist)];
-      if (cur - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
+      // static dictionary probe i (SearchInStaticDictionary, mod.rs:1942-1988): item and matched prefix
+      const uint32_t i = c - ndist - m.nbucket[w];
+      const uint32_t key = (((br_load32(cur_data) * 0x1e35a7bdu) >> (32 - 14)) << 1) + i;
+      const uint32_t item = t.dict_hash[key];
+      prev = item;
+      if (item != 0) {
+        const uint32_t wlen = item & 0x1f;
+        const uint32_t offset = t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
+        len = wlen > max_length ? 0u : br_match_len(cur_data, t.dict_data + offset, wlen);
+      }
     }
-    if (prev != 0xffffffffu) len = br_match_len(t.text + prev, cur_data, max_length);
-    s.cand_prev[c] = prev;
-    s.cand_len[c] = len;
+    s.cand_prev[w][c] = prev;
+    s.cand_len[w][c] = len;
   }
   BR_SYNC();
-  // phase 2: fold in the reference's order
+}
+
+// Phase 2: fold the candidates of probe slot w in the reference's order, then the static dictionary stage.
+BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const ProbeMeta& m, uint32_t w,
+                                  DictState& ds, uint32_t blk_end) {
+  const uint32_t cur = m.pos + w;
+  const uint32_t max_length = blk_end - cur;
+  const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+  const uint32_t ndist = P.ndist;
+  const uint32_t ncand = ndist + m.nbucket[w];
   SearchResult out;
   out.len = 0;
   out.len_x_code = 0;
@@ -292,12 +295,12 @@ BR_DEV SearchResult br_find_longest_match(const Lz77Params& P, const ChainTables
   uint32_t best_score = kMinScore;
   const uint32_t brk = P.prefix_bytes;
   for (uint32_t c = 0; c < ncand; ++c) {
-    const uint32_t prev = s.cand_prev[c];
+    const uint32_t prev = s.cand_prev[w][c];
     if (prev == 0xffffffffu) {
       if (c < ndist) continue;
       break;  // backward > max_backward: older ring entries are farther still
     }
-    const uint32_t unbroken = s.cand_len[c];
+    const uint32_t unbroken = s.cand_len[w][c];
     // quick reject (mod.rs:1713-1718 / 1765-1773)
     if ((cur & P.ring_mask) + best_len > P.ring_mask || (prev & P.ring_mask) + best_len > P.ring_mask) continue;
     bool same;
@@ -341,11 +344,48 @@ BR_DEV SearchResult br_find_longest_match(const Lz77Params& P, const ChainTables
       }
     }
   }
-  BR_SYNC();
   if (!out.found && P.use_dictionary) {
-    out.found = br_search_static_dictionary(P, t, ds, cur_data, max_length, max_backward, out);
+    // SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false), on the probed items
+    const bool dead = ds.matches < (ds.lookups >> 7);
+    const uint32_t seen = dead ? 2u : 1u;
+    ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
+    if (!dead) {
+      const int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
+      if (def > ds.maxdef) ds.maxdef = def;
+      for (uint32_t i = 0; i < 2; ++i) {
+        const uint32_t item = s.cand_prev[w][ncand + i];
+        const uint32_t matchlen = s.cand_len[w][ncand + i];
+        ds.lookups++;
+        if (item == 0) continue;
+        const uint32_t len = item & 0x1f;
+        const uint32_t dist = item >> 5;
+        if (len > max_length) continue;
+        if (matchlen + 10 <= len || matchlen == 0) continue;
+        const uint32_t cut = len - matchlen;
+        const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
+        const uint32_t backward = max_backward + dist + 1 + (transform_id << t.dict_size_bits_by_length[len]);
+        if (backward > P.dist_max_distance) continue;
+        const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
+        if (score < out.score) continue;
+        out.len = matchlen;
+        out.len_x_code = len ^ matchlen;
+        out.distance = backward;
+        out.score = score;
+        ds.matches++;
+        out.found = true;
+      }
+    }
   }
   return out;
+}
+
+// search(x) for the parse loop: reuses the speculative second slot when it is still valid
+BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratch& s, ProbeMeta& m, DictState& ds,
+                              uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end) {
+  if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) return br_fold_probe(P, t, s, m, 1, ds, blk_end);
+  BR_SYNC();  // every lane is done reading the previous probe
+  br_probe_pair(P, t, s, m, x, cache, cache_version, blk_end);
+  return br_fold_probe(P, t, s, m, 0, ds, blk_end);
 }
 
 // adv_prepare_distance_cache, mod.rs:632-651
@@ -418,6 +458,10 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
   uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0;
   uint32_t last_dist_code = 0xffffffffu, last_copy_len = 0;
+  uint32_t cache_version = 0;
+  ProbeMeta probe;
+  probe.pos = 0xffffffffu;
+  probe.version = 0;
   Command* cmds = t.cmds + (size_t)seg.cmd_base;
 
   if (seg.flags & kSegFirstInBlock) {
@@ -449,15 +493,13 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   br_prepare_distance_cache(dc, P.ndist);
 
   while (position + htl < pos_end && position < seg.end) {
-    uint32_t max_length = pos_end - position;
-    SearchResult sr = br_find_longest_match(P, t, s, ds, position, dc, max_length, pos_end);
+    SearchResult sr = br_search(P, t, s, probe, ds, position, dc, cache_version, pos_end);
     n_searches++;
     if (sr.found) {
       int delayed = 0;
       bool next_probed;
-      max_length--;
       for (;;) {
-        SearchResult sr2 = br_find_longest_match(P, t, s, ds, position + 1, dc, max_length, pos_end);
+        SearchResult sr2 = br_search(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end);
         n_searches++;
         next_probed = true;
         if (sr2.found && sr2.score >= sr.score + 175) {
@@ -466,10 +508,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           insert_length++;
           sr = sr2;
           next_probed = false;
-          if (++delayed < 4 && position + htl < pos_end) {
-            max_length--;
-            continue;
-          }
+          if (++delayed < 4 && position + htl < pos_end) continue;
         }
         break;
       }
@@ -482,6 +521,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
         dc[1] = dc[0];
         dc[0] = (int32_t)sr.distance;
         if (n_pushes < 4) n_pushes++;
+        cache_version++;
         br_prepare_distance_cache(dc, P.ndist);
       }
       if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride) cmds[n_cmds] = br_make_command(t, insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);

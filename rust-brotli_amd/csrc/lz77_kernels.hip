@@ -235,6 +235,20 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
   }
 }
 
+// per position: everything a search needs to find its candidates, in one 8-byte record
+__global__ __launch_bounds__(256) void k_make_info(const uint16_t* __restrict__ keys, const uint32_t* __restrict__ rank,
+                                                    const uint32_t* __restrict__ key_base, uint32_t n, uint2* __restrict__ info) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = base + j;
+    if (p < n) {
+      const uint32_t g = rank[p];
+      info[p] = make_uint2(g, g - key_base[keys[p]]);
+    }
+  }
+}
+
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
   const uint32_t n = P.total_bytes;
   if (n == 0) return;
@@ -245,6 +259,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.flags[which], n, tile_sums, B.rank, B.sorted,
                      B.key_base);
+  hipLaunchKernelGGL(k_make_info, dim3(tiles), dim3(256), 0, 0, B.keys, B.rank, B.key_base, n, (uint2*)B.info);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -282,9 +297,7 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint
   ParseArgs a;
   a.P = P;
   a.T.text = B.text;
-  a.T.keys = B.keys;
-  a.T.rank = B.rank;
-  a.T.key_base = B.key_base;
+  a.T.info = B.info;
   a.T.sorted = B.sorted;
   a.T.flags_prev = B.flags[which];
   a.T.flags_next = B.flags[which ^ 1];

@@ -24,6 +24,7 @@ void Lz77Stage::Release() {
     dev_free(B_.by_key);
     dev_free(B_.sorted_keys);
     dev_free(B_.rank);
+    dev_free(B_.info);
     dev_free(B_.sorted);
     dev_free(B_.key_base);
     dev_free(B_.flags[0]);
@@ -79,6 +80,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.by_key = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.sorted_keys = (uint16_t*)dev_alloc(M * 2 + 64);
   B_.rank = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.info = (uint32_t*)dev_alloc(M * 8 + 64);
   B_.sorted = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);

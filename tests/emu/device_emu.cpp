@@ -101,15 +101,17 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
     if (i == 0 || B.sorted_keys[i - 1] != k) B.key_base[k] = g;
     if (B.flags[which][pos]) B.sorted[g++] = pos;
   }
+  for (uint32_t p = 0; p < n; ++p) {
+    B.info[2 * (size_t)p] = B.rank[p];
+    B.info[2 * (size_t)p + 1] = B.rank[p] - B.key_base[B.keys[p]];
+  }
 }
 
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
   const DeviceTables& dt = dev_tables();
   ChainTables T;
   T.text = B.text;
-  T.keys = B.keys;
-  T.rank = B.rank;
-  T.key_base = B.key_base;
+  T.info = B.info;
   T.sorted = B.sorted;
   T.flags_prev = B.flags[which];
   T.flags_next = B.flags[which ^ 1];
