@@ -70,6 +70,9 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through
 // rank/sorted) and write flags[which ^ 1], cmds and exits
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment);
+// same kernel over an explicit list of (segment, entry) pairs (used for the warm-up dry run)
+void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments_dev,
+                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)

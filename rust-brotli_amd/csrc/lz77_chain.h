@@ -413,11 +413,12 @@ BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
 struct FlagWriter {
   const uint8_t* prev;
   uint8_t* next;
+  bool enabled;
   uint32_t changes;  // per lane
   uint32_t tail_lo;  // positions >= tail_lo inside the block get the stitch flag
   uint8_t tail_value;
   BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
-    if (BR_LANE == 0) {
+    if (BR_LANE == 0 && enabled) {
       changes += (prev[q] != v);
       next[q] = v;
     }
@@ -425,6 +426,7 @@ struct FlagWriter {
   BR_DEV uint8_t unstored(uint32_t q) const { return q >= tail_lo ? tail_value : (uint8_t)0; }
   // [a, b) := v for q < split, static "not stored by the main loop" value for q >= split
   BR_DEV void range(uint32_t a, uint32_t b, uint32_t split) {
+    if (!enabled) return;
     for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) {
       const uint8_t v = q < split ? (uint8_t)1 : unstored(q);
       changes += (prev[q] != v);
@@ -454,6 +456,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   fw.prev = t.flags_prev;
   fw.next = t.flags_next;
   fw.changes = 0;
+  fw.enabled = !(seg.flags & kSegWarmup);
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
   uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0;
@@ -524,7 +527,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
         cache_version++;
         br_prepare_distance_cache(dc, P.ndist);
       }
-      if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride) cmds[n_cmds] = br_make_command(t, insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
+      if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride && fw.enabled) cmds[n_cmds] = br_make_command(t, insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
       n_cmds++;
       n_lits += insert_length;
       insert_length = 0;
@@ -547,7 +550,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           position = pos_end;
         } else if (position > apply + 4 * window) {
           // Store4Vec4: position, +4, +8, +12
-          for (uint32_t q = position + BR_LANE; q < position + 16; q += BR_NLANES) {
+          for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 16; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 3) == 0;
             fw.changes += (fw.prev[q] != v);
             fw.next[q] = v;
@@ -556,7 +559,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           position += 16;
         } else {
           // StoreEvenVec4: position, +2, +4, +6
-          for (uint32_t q = position + BR_LANE; q < position + 8; q += BR_NLANES) {
+          for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 8; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 1) == 0;
             fw.changes += (fw.prev[q] != v);
             fw.next[q] = v;

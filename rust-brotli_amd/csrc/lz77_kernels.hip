@@ -291,8 +291,24 @@ __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
   br_parse_segment(a.P, a.T, scratch, seg, entry, a.exits[k]);
 }
 
+static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
+                         SegExit* exits, uint32_t first_segment, uint32_t count);
+
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
   if (first_segment >= P.num_segments) return;
+  launch_parse(P, B, which, B.segments, B.entries, B.exits, first_segment, P.num_segments - first_segment);
+}
+
+void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments_dev,
+                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
+  if (count == 0) return;
+  Lz77Params Q = P;
+  Q.num_segments = count;
+  launch_parse(Q, B, which, segments_dev, entries_dev, exits_dev, 0, count);
+}
+
+static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
+                         SegExit* exits, uint32_t first_segment, uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ParseArgs a;
   a.P = P;
@@ -308,9 +324,9 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint
   a.T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   a.T.dist_postfix_bits = P.dist_postfix_bits;
   a.T.num_direct_distance_codes = P.num_direct_distance_codes;
-  a.segments = B.segments;
-  a.entries = B.entries;
-  a.exits = B.exits;
+  a.segments = segments;
+  a.entries = entries;
+  a.exits = exits;
   a.first_segment = first_segment;
   // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
   ParseTiming& pt = parse_timing();
@@ -318,11 +334,11 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
   HIP_CHECK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_parse_segments, dim3(P.num_segments - first_segment), dim3(64), 0, 0, a);
+  hipLaunchKernelGGL(k_parse_segments, dim3(count), dim3(64), 0, 0, a);
   HIP_CHECK(hipEventRecord(e1, 0));
   HIP_CHECK(hipGetLastError());
   pt.events.push_back(std::make_pair(e0, e1));
-  pt.segments += P.num_segments - first_segment;
+  pt.segments += count;
 }
 
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {

@@ -399,6 +399,47 @@ void Lz77Stage::Run() {
   }
   exits_.assign(nseg, SegExit{});
   int which = 0;
+  // ---- warm-up: a dry run over the tail of every segment gives a good first guess of the state in which the
+  // parse leaves it (greedy parses re-synchronise quickly), so that the first full round already starts
+  // almost every chain from its true entry.
+  if (const char* w = getenv("BROTLI_MI355X_WARMUP")) warmup_bytes_ = (uint32_t)atoi(w);
+  if (nseg > 1 && warmup_bytes_ > 0) {
+    std::vector<Segment> wsegs(nseg);
+    std::vector<SegEntry> wentries(nseg);
+    for (uint32_t k = 0; k < nseg; ++k) {
+      Segment g = segments_[k];
+      const uint32_t len = g.end - g.start;
+      if (len > warmup_bytes_) g.start = g.end - warmup_bytes_;
+      g.flags = (g.flags & kSegTailStitched) | kSegWarmup;
+      wsegs[k] = g;
+      SegEntry e = entries_[k];
+      e.pos = g.start;
+      e.apply = g.start + P_.spree_window;
+      wentries[k] = e;
+    }
+    Segment* wsegs_dev = (Segment*)dev_alloc(nseg * sizeof(Segment));
+    SegEntry* wentries_dev = (SegEntry*)dev_alloc(nseg * sizeof(SegEntry));
+    SegExit* wexits_dev = (SegExit*)dev_alloc(nseg * sizeof(SegExit));
+    dev_h2d(wsegs_dev, wsegs.data(), nseg * sizeof(Segment));
+    dev_h2d(wentries_dev, wentries.data(), nseg * sizeof(SegEntry));
+    lz77_rank_flags(P_, B_, which);
+    lz77_parse_custom(P_, B_, which, wsegs_dev, wentries_dev, wexits_dev, nseg);
+    std::vector<SegExit> wexits(nseg);
+    dev_d2h(wexits.data(), wexits_dev, nseg * sizeof(SegExit));
+    dev_free(wsegs_dev);
+    dev_free(wentries_dev);
+    dev_free(wexits_dev);
+    for (uint32_t k = 0; k + 1 < nseg; ++k) {
+      SegEntry& e = entries_[k + 1];
+      memcpy(e.cache, wexits[k].cache, sizeof(e.cache));
+      if (!(segments_[k + 1].flags & kSegFirstInBlock)) {
+        e.pos = wexits[k].pos;
+        e.apply = wexits[k].apply;
+      }
+    }
+    stats_.segments_parsed += (uint64_t)nseg * warmup_bytes_ / segment_bytes_;
+    tm.stop(&stats_.ms_warmup);
+  }
   uint32_t first = 0;
   const uint32_t max_rounds = nseg + 8;
   bool done = false;

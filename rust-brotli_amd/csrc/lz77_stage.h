@@ -36,7 +36,7 @@ struct Lz77Stats {
   uint64_t searches = 0;
   uint64_t total_commands = 0;
   // wall-clock milliseconds per phase (device synchronised), filled when profiling is enabled
-  double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
+  double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
 
 class Lz77Stage {
@@ -55,6 +55,7 @@ class Lz77Stage {
   // forces meta-block `index` (and only it) to be stored uncompressed in the next Run (size fallback,
   // encode.rs:2141-2163)
   void ForceUncompressed(uint32_t index) { forced_uncompressed_.push_back(index); }
+  void set_warmup_bytes(uint32_t n) { warmup_bytes_ = n; }
   void Run();
 
   const std::vector<MetaBlockPlan>& metablocks() const { return metablocks_; }
@@ -79,6 +80,7 @@ class Lz77Stage {
   uint32_t input_bytes_ = 0;
   uint32_t raw_head_bytes_ = 0;
   uint32_t segment_bytes_ = 4096;
+  uint32_t warmup_bytes_ = 768;
   uint32_t block_bytes_ = 65536;
   std::vector<Segment> segments_;
   std::vector<SegEntry> entries_;   // entries used by the most recent parse

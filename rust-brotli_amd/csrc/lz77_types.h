@@ -49,6 +49,7 @@ enum SegmentFlags : uint32_t {
   kSegFirstInBlock = 1u,
   kSegLastInBlock = 2u,
   kSegTailStitched = 4u,  // next block's StitchToPreviousBlock will store blk_end-3..blk_end-1
+  kSegWarmup = 8u,        // dry run over the tail of a segment: only the exit state matters, nothing is written
 };
 
 // Static geometry of one segment.

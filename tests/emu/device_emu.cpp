@@ -107,7 +107,20 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
   }
 }
 
+static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
+                      SegExit* exits, uint32_t first_segment, uint32_t end_segment);
+
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
+  run_parse(P, B, which, B.segments, B.entries, B.exits, first_segment, P.num_segments);
+}
+
+void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments_dev,
+                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
+  run_parse(P, B, which, segments_dev, entries_dev, exits_dev, 0, count);
+}
+
+static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
+                      SegExit* exits, uint32_t first_segment, uint32_t end_segment) {
   const DeviceTables& dt = dev_tables();
   ChainTables T;
   T.text = B.text;
@@ -123,8 +136,8 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
   ChainScratch scratch;
-  for (uint32_t k = first_segment; k < P.num_segments; ++k) {
-    br_parse_segment(P, T, scratch, B.segments[k], B.entries[k], B.exits[k]);
+  for (uint32_t k = first_segment; k < end_segment; ++k) {
+    br_parse_segment(P, T, scratch, segments[k], entries[k], exits[k]);
   }
 }
 
