@@ -44,8 +44,8 @@ struct Lz77Buffers {
   uint32_t* by_key;     // positions sorted by (key, position)            [total_bytes]
   uint16_t* sorted_keys;// keys in that order                              [total_bytes]
   uint32_t* rank;       // per position                                    [total_bytes]
-  uint32_t* info;       // per position {rank, count of stored same-key positions before it} [2 * total_bytes]
-  uint32_t* sorted;     // stored positions in (key,pos) order             [total_bytes]
+  uint32_t* info[2];    // per position {rank, count of stored same-key positions before it} [2 * total_bytes], double buffered
+  uint32_t* sorted[2];  // stored positions in (key,pos) order             [total_bytes], double buffered
   uint32_t* key_base;   // per key                                         [65536 + 1]
   uint8_t* flags[2];    // stored flags, double buffered                   [total_bytes + 64]
   Command* cmds;        // num_segments * cmd_slab_stride
@@ -65,13 +65,22 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start);
 // stable sort of positions by key -> by_key / sorted_keys
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
-// rank / sorted / key_base from flags[which]
-void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which);
+// rank / sorted[rbuf] / info[rbuf] from flags[which]
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through
 // rank/sorted) and write flags[which ^ 1], cmds and exits
-void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment);
+void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment);
+// the same over an explicit list of segment indices (device array); flags are read from and written to flags[which]
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint32_t count);
+// marks (dirty[k] = 1) the segments that searched a position whose candidate list differs between the rank
+// structures rbuf_old and rbuf_new
+struct SegGeometry {
+  uint32_t prefix_bytes, first_block_start, block_bytes, segment_bytes, segs_per_block, num_segments, block_size /* ring depth */, pad;
+};
+void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
+                   uint8_t* dirty_dev);
 // same kernel over an explicit list of (segment, entry) pairs (used for the warm-up dry run)
-void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments_dev,
+void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
                        const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments);

@@ -40,6 +40,8 @@
 namespace brotli_mi355x {
 
 static constexpr int kMaxCandidates = 16 + 128;  // ndist <= 16, ring depth <= 128 (quality <= 8)
+// per-position flag byte: bit 0 = the position is in the hash table, bit 1 = FindLongestMatch ran on it
+static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 static constexpr uint32_t kMinScore = 30 * 8 * 8 + 100;  // mod.rs:2408-2410
 
 struct ChainTables {
@@ -419,7 +421,7 @@ struct FlagWriter {
   uint8_t tail_value;
   BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
     if (BR_LANE == 0 && enabled) {
-      changes += (prev[q] != v);
+      changes += ((prev[q] ^ v) & 1);
       next[q] = v;
     }
   }
@@ -429,7 +431,7 @@ struct FlagWriter {
     if (!enabled) return;
     for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) {
       const uint8_t v = q < split ? (uint8_t)1 : unstored(q);
-      changes += (prev[q] != v);
+      changes += ((prev[q] ^ v) & 1);
       next[q] = v;
     }
   }
@@ -506,7 +508,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
         n_searches++;
         next_probed = true;
         if (sr2.found && sr2.score >= sr.score + 175) {
-          fw.one(position, 1);
+          fw.one(position, kFlagStored | kFlagSearched);
           position++;
           insert_length++;
           sr = sr2;
@@ -534,12 +536,12 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
       last_dist_code = distance_code;
       last_copy_len = sr.len;
       // hash-table side effects: position searched, position+1 only if probed, then StoreRange
-      fw.one(position, 1);
-      if (sr.len > 1) fw.one(position + 1, next_probed ? (uint8_t)1 : fw.unstored(position + 1));
+      fw.one(position, kFlagStored | kFlagSearched);
+      if (sr.len > 1) fw.one(position + 1, next_probed ? (uint8_t)(kFlagStored | kFlagSearched) : fw.unstored(position + 1));
       if (sr.len > 2) fw.range(position + 2, position + sr.len, store_end);
       position += sr.len;
     } else {
-      fw.one(position, 1);
+      fw.one(position, kFlagStored | kFlagSearched);
       insert_length++;
       position++;
       if (position > apply) {
@@ -552,7 +554,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           // Store4Vec4: position, +4, +8, +12
           for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 16; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 3) == 0;
-            fw.changes += (fw.prev[q] != v);
+            fw.changes += ((fw.prev[q] ^ v) & 1);
             fw.next[q] = v;
           }
           insert_length += 16;
@@ -561,7 +563,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           // StoreEvenVec4: position, +2, +4, +6
           for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 8; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 1) == 0;
-            fw.changes += (fw.prev[q] != v);
+            fw.changes += ((fw.prev[q] ^ v) & 1);
             fw.next[q] = v;
           }
           insert_length += 8;

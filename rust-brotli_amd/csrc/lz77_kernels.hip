@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_rank_tile_sums(const uint32_t* __restri
   uint32_t local = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (base + j < n) local += flags[by_key[base + j]];
+    if (base + j < n) local += flags[by_key[base + j]] & 1u;
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
   if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = local;
   __syncthreads();
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
     f[j] = 0;
     if (base + j < n) {
       pos[j] = by_key[base + j];
-      f[j] = flags[pos[j]];
+      f[j] = flags[pos[j]] & 1u;
     }
     local += f[j];
   }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_make_info(const uint16_t* __restrict__ 
   }
 }
 
-void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf) {
   const uint32_t n = P.total_bytes;
   if (n == 0) return;
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
@@ -257,9 +257,9 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
   uint32_t* scratch = tile_sums + tiles + 64;
   hipLaunchKernelGGL(k_rank_tile_sums, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, tile_sums);
   exclusive_scan_u32(tile_sums, tiles, scratch);
-  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.flags[which], n, tile_sums, B.rank, B.sorted,
+  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.flags[which], n, tile_sums, B.rank, B.sorted[rbuf],
                      B.key_base);
-  hipLaunchKernelGGL(k_make_info, dim3(tiles), dim3(256), 0, 0, B.keys, B.rank, B.key_base, n, (uint2*)B.info);
+  hipLaunchKernelGGL(k_make_info, dim3(tiles), dim3(256), 0, 0, B.keys, B.rank, B.key_base, n, (uint2*)B.info[rbuf]);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -271,6 +271,8 @@ struct ParseArgs {
   const SegEntry* entries;
   SegExit* exits;
   uint32_t first_segment;
+  const uint32_t* list;  // optional explicit segment indices
+  uint32_t count;
 };
 
 struct ParseTiming {
@@ -284,39 +286,23 @@ static ParseTiming& parse_timing() {
 
 __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratch scratch;
-  const uint32_t k = a.first_segment + blockIdx.x;
-  if (k >= a.P.num_segments) return;
+  if (blockIdx.x >= a.count) return;
+  const uint32_t k = a.list ? a.list[blockIdx.x] : a.first_segment + blockIdx.x;
   const Segment seg = a.segments[k];
   const SegEntry entry = a.entries[k];
   br_parse_segment(a.P, a.T, scratch, seg, entry, a.exits[k]);
 }
 
-static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
-                         SegExit* exits, uint32_t first_segment, uint32_t count);
-
-void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
-  if (first_segment >= P.num_segments) return;
-  launch_parse(P, B, which, B.segments, B.entries, B.exits, first_segment, P.num_segments - first_segment);
-}
-
-void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments_dev,
-                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
-  if (count == 0) return;
-  Lz77Params Q = P;
-  Q.num_segments = count;
-  launch_parse(Q, B, which, segments_dev, entries_dev, exits_dev, 0, count);
-}
-
-static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
-                         SegExit* exits, uint32_t first_segment, uint32_t count) {
+static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
+                         const SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ParseArgs a;
   a.P = P;
   a.T.text = B.text;
-  a.T.info = B.info;
-  a.T.sorted = B.sorted;
-  a.T.flags_prev = B.flags[which];
-  a.T.flags_next = B.flags[which ^ 1];
+  a.T.info = B.info[rbuf];
+  a.T.sorted = B.sorted[rbuf];
+  a.T.flags_prev = B.flags[flags_in];
+  a.T.flags_next = B.flags[flags_out];
   a.T.cmds = B.cmds;
   a.T.dict_hash = dt.dict_hash;
   a.T.dict_data = dt.dict_data;
@@ -328,6 +314,8 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int which, c
   a.entries = entries;
   a.exits = exits;
   a.first_segment = first_segment;
+  a.list = list;
+  a.count = count;
   // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
   ParseTiming& pt = parse_timing();
   hipEvent_t e0, e1;
@@ -339,6 +327,58 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int which, c
   HIP_CHECK(hipGetLastError());
   pt.events.push_back(std::make_pair(e0, e1));
   pt.segments += count;
+}
+
+void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment) {
+  if (first_segment >= P.num_segments) return;
+  launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, P.num_segments - first_segment);
+}
+
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint32_t count) {
+  if (count == 0) return;
+  launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, 0, list_dev, count);
+}
+
+void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
+                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
+  if (count == 0) return;
+  launch_parse(P, B, which, which ^ 1, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, count);
+}
+
+// ------------------------------------------------------------------------------------------ validate
+// After some flags changed, the candidate list of a searched position may differ from the one its chain
+// saw.  Comparing the two rank structures entry by entry (no text access) finds those positions exactly.
+__global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ flags, const uint2* __restrict__ info_old,
+                                                   const uint32_t* __restrict__ sorted_old, const uint2* __restrict__ info_new,
+                                                   const uint32_t* __restrict__ sorted_new, uint32_t n, SegGeometry geo,
+                                                   uint8_t* __restrict__ dirty) {
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    if (p < geo.first_block_start || !(flags[p] & kFlagSearched)) continue;
+    const uint2 a = info_old[p], b = info_new[p];
+    const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(b.y & 0xffffu, geo.block_size);
+    bool same = na == nb;
+    for (uint32_t j = 0; same && j < na; ++j) same = sorted_old[a.x - 1 - j] == sorted_new[b.x - 1 - j];
+    if (same) continue;
+    const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
+    const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
+    const uint32_t off = p - bs;
+    uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
+    if (k >= geo.num_segments) k = geo.num_segments - 1;
+    dirty[k] = 1;
+    // a lazy probe just behind a segment boundary belongs to the previous chain
+    if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+  }
+}
+
+void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
+                   uint8_t* dirty_dev) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0) return;
+  uint32_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, 0, B.flags[which], (const uint2*)B.info[rbuf_old], B.sorted[rbuf_old],
+                     (const uint2*)B.info[rbuf_new], B.sorted[rbuf_new], n, geo, dirty_dev);
+  HIP_CHECK(hipGetLastError());
 }
 
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {

@@ -24,8 +24,10 @@ void Lz77Stage::Release() {
     dev_free(B_.by_key);
     dev_free(B_.sorted_keys);
     dev_free(B_.rank);
-    dev_free(B_.info);
-    dev_free(B_.sorted);
+    dev_free(B_.info[0]);
+    dev_free(B_.info[1]);
+    dev_free(B_.sorted[0]);
+    dev_free(B_.sorted[1]);
     dev_free(B_.key_base);
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
@@ -80,8 +82,10 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.by_key = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.sorted_keys = (uint16_t*)dev_alloc(M * 2 + 64);
   B_.rank = (uint32_t*)dev_alloc(M * 4 + 64);
-  B_.info = (uint32_t*)dev_alloc(M * 8 + 64);
-  B_.sorted = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.info[0] = (uint32_t*)dev_alloc(M * 8 + 64);
+  B_.info[1] = (uint32_t*)dev_alloc(M * 8 + 64);
+  B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
   B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
@@ -143,15 +147,56 @@ void Lz77Stage::BuildSegments() {
 
 void Lz77Stage::InitFlags() { lz77_init_flags(P_, B_, segments_.empty() ? P_.total_bytes : segments_[0].blk_start); }
 
-static bool DictEntryCompatible(const SegEntry& used, const SegExit& x, uint32_t L, uint32_t M) {
-  if (used.dict_lookups == L && used.dict_matches == M) return true;
-  switch (x.dict_mode) {
-    case 0: return true;
-    case 1: return 128ll * (int64_t)M - (int64_t)L + 127 >= (int64_t)x.dict_maxdef;
-    case 2: return M < (L >> 7);
-    default: return false;
+// Static-dictionary throttle state (mod.rs:1957-1960) tracked along the segments.  While the dictionary is
+// alive the exact lookup / match counters are known (alive chains report their deltas); once a chain turns it
+// off under the exact counters it stays off for the rest of the stream, and the chains after it only need to
+// know "dead" (they never consult it, so the counter values no longer matter).
+struct DictTracker {
+  enum State { kAlive, kDead, kUnknown };
+  bool use = false;
+  State state = kAlive;
+  uint32_t L = 0, M = 0;     // exact while state == kAlive
+  uint32_t left_alive_at = 0xffffffffu;  // segment at which the state stopped being kAlive
+  uint32_t flips = 0;        // chains behind that point that ran with a live dictionary and must be redone
+  static constexpr uint32_t kDeadL = 0x40000000u, kDeadM = 0;
+  // first guess for chains whose true counters are not known yet: alive with a margin no chain can use up, so
+  // that the chain reports its own deficit (dict_maxdef) instead of tripping over a made-up start of stream
+  static constexpr uint32_t kAliveL = 0, kAliveM = 0x01000000u;
+  void Hint(SegEntry* e) const {
+    e->dict_lookups = state == kAlive ? L : kDeadL;
+    e->dict_matches = state == kAlive ? M : kDeadM;
   }
-}
+  // consumes the exit of segment k, parsed with entry `used`; returns whether that parse is valid here
+  bool Consume(uint32_t k, const SegEntry& used, const SegExit& x) {
+    if (!use) return true;
+    if (state != kAlive) {
+      // certain (kDead) or assumed (kUnknown, until the chain that may have tripped the throttle is redone with
+      // exact counters): the dictionary is off, valid chains are those that never found it alive
+      const bool ok = x.dict_mode == 0 || x.dict_mode == 2;
+      if (!ok) flips++;
+      return ok;
+    }
+    const bool exact = used.dict_lookups == L && used.dict_matches == M;
+    bool ok;
+    switch (x.dict_mode) {
+      case 0: ok = true; break;
+      case 1: ok = exact || (128ll * (int64_t)M - (int64_t)L + 127 >= (int64_t)x.dict_maxdef); break;
+      default: ok = exact; break;  // the chain saw the dictionary switched off: only meaningful with exact counters
+    }
+    if (ok) {
+      L += x.dict_lookups - used.dict_lookups;
+      M += x.dict_matches - used.dict_matches;
+      if (x.dict_mode >= 2) {
+        state = kDead;
+        left_alive_at = k;
+      }
+    } else {
+      state = kUnknown;
+      left_alive_at = k;
+    }
+    return ok;
+  }
+};
 
 // Chains the exits of the last parse into the entries of the next one, replaying the per-block
 // control flow of encode_data (encode.rs:2214-2543).  Returns true when every entry that the last
@@ -165,9 +210,11 @@ bool Lz77Stage::Resolve(bool final_pass) {
   carries_.clear();
   bool consistent = true;
   first_dirty_ = nseg;
+  dirty_entry_.assign(nseg, 0);
   auto mark = [&](uint32_t k, bool same) {
     if (!same) {
       consistent = false;
+      dirty_entry_[k] = 1;
       if (k < first_dirty_) first_dirty_ = k;
     }
   };
@@ -181,7 +228,8 @@ bool Lz77Stage::Resolve(bool final_pass) {
   uint32_t last_insert_len = 0;
   uint64_t num_commands = 0, num_literals = 0;
   uint32_t last_flush_pos = P_.prefix_bytes + raw_head_bytes_;
-  uint32_t dictL = 0, dictM = 0;
+  DictTracker dict;
+  dict.use = P_.use_dictionary != 0;
   struct LastCmd {
     bool valid = false;
     uint32_t seg = 0, idx = 0, dist_code = 0, copy_len = 0;
@@ -215,24 +263,21 @@ bool Lz77Stage::Resolve(bool final_pass) {
         if (cmd_dist <= max_distance) E.ext_allowed = 1;
       }
     }
-    E.dict_lookups = dictL;
-    E.dict_matches = dictM;
+    dict.Hint(&E);
     {
       const SegEntry& u = entries_[k0];
-      bool same = memcmp(u.cache, E.cache, sizeof(E.cache)) == 0 && u.ext_allowed == E.ext_allowed && DictEntryCompatible(u, exits_[k0], dictL, dictM);
+      bool same = memcmp(u.cache, E.cache, sizeof(E.cache)) == 0 && u.ext_allowed == E.ext_allowed;
       mark(k0, same);
     }
     next_entries_[k0] = E;
     // ---- chain through the segments of the block
-    uint32_t curL = dictL, curM = dictM;
     uint32_t carry = last_insert_len;  // literals pending when the segment is entered
     int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
     memcpy(cur_cache, cache, sizeof(cache));
     for (uint32_t j = k0; j <= k1; ++j) {
       const SegExit& X = exits_[j];
       const SegEntry& used = entries_[j];
-      const uint32_t outL = curL + (X.dict_lookups - used.dict_lookups);
-      const uint32_t outM = curM + (X.dict_matches - used.dict_matches);
+      mark(j, dict.Consume(j, used, X));
       // Exit cache = the segment's own pushes on top of its entry cache.  When the entry cache derived in
       // this pass differs from the one the chain used, keep the pushes and swap the inherited tail: the
       // chain is re-run with the new entry anyway, this only lets a change travel through segments that
@@ -273,23 +318,16 @@ bool Lz77Stage::Resolve(bool final_pass) {
         memcpy(N.cache, out_cache, sizeof(N.cache));
         N.insert_len = carry;
         N.ext_allowed = 0;
-        N.dict_lookups = outL;
-        N.dict_matches = outM;
+        dict.Hint(&N);
         const SegEntry& u = entries_[j + 1];
-        bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0 &&
-                    DictEntryCompatible(u, exits_[j + 1], outL, outM);
-        if (!same && getenv("BROTLI_MI355X_DEBUG2") && j + 1 < first_dirty_) fprintf(stderr, "  seg %u: pos %u/%u apply %u/%u cache %d/%d dict %u,%u/%u,%u mode %u\n", j + 1, u.pos, N.pos, u.apply, N.apply, u.cache[0], N.cache[0], u.dict_lookups, u.dict_matches, outL, outM, exits_[j + 1].dict_mode);
+        bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0;
         mark(j + 1, same);
         next_entries_[j + 1] = N;
       }
-      curL = outL;
-      curM = outM;
       memcpy(cur_cache, out_cache, sizeof(cur_cache));
     }
     memcpy(cache, cur_cache, sizeof(cache));
     last_insert_len = carry;
-    dictL = curL;
-    dictM = curM;
     // ---- meta-block flush rule, encode.rs:2454-2483
     const bool is_last = (k1 + 1 == nseg);
     const size_t processed_bytes = be - last_flush_pos;
@@ -345,7 +383,54 @@ bool Lz77Stage::Resolve(bool final_pass) {
     mb_first_seg = k1 + 1;
     k = k1 + 1;
   }
+  dict_death_seg_ = dict.left_alive_at;
+  dict_flips_ = dict.flips;
   return consistent;
+}
+
+// Dry run over the last warmup_bytes_ of segments [first_seg, nseg): fills entries_[k + 1] (position, spree
+// state, distance cache) with the state in which the dry run left segment k.  dict_dead selects the static
+// dictionary regime the dry run assumes.
+void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf) {
+  const uint32_t nseg = (uint32_t)segments_.size();
+  if (first_seg + 1 >= nseg) return;
+  const uint32_t count = nseg - first_seg;
+  std::vector<Segment> wsegs(count);
+  std::vector<SegEntry> wentries(count);
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t k = first_seg + i;
+    Segment g = segments_[k];
+    const uint32_t len = g.end - g.start;
+    if (len > warmup_bytes_) g.start = g.end - warmup_bytes_;
+    g.flags = (g.flags & kSegTailStitched) | kSegWarmup;
+    wsegs[i] = g;
+    SegEntry e = entries_[k];
+    e.pos = g.start;
+    e.apply = g.start + P_.spree_window;
+    e.dict_lookups = dict_dead ? DictTracker::kDeadL : DictTracker::kAliveL;
+    e.dict_matches = dict_dead ? DictTracker::kDeadM : DictTracker::kAliveM;
+    wentries[i] = e;
+  }
+  Segment* wsegs_dev = (Segment*)dev_alloc(count * sizeof(Segment));
+  SegEntry* wentries_dev = (SegEntry*)dev_alloc(count * sizeof(SegEntry));
+  SegExit* wexits_dev = (SegExit*)dev_alloc(count * sizeof(SegExit));
+  dev_h2d(wsegs_dev, wsegs.data(), count * sizeof(Segment));
+  dev_h2d(wentries_dev, wentries.data(), count * sizeof(SegEntry));
+  lz77_parse_custom(P_, B_, which, rbuf, wsegs_dev, wentries_dev, wexits_dev, count);
+  std::vector<SegExit> wexits(count);
+  dev_d2h(wexits.data(), wexits_dev, count * sizeof(SegExit));
+  dev_free(wsegs_dev);
+  dev_free(wentries_dev);
+  dev_free(wexits_dev);
+  for (uint32_t i = 0; i + 1 < count; ++i) {
+    SegEntry& e = entries_[first_seg + i + 1];
+    memcpy(e.cache, wexits[i].cache, sizeof(e.cache));
+    if (!(segments_[first_seg + i + 1].flags & kSegFirstInBlock)) {
+      e.pos = wexits[i].pos;
+      e.apply = wexits[i].apply;
+    }
+  }
+  stats_.segments_parsed += (uint64_t)count * warmup_bytes_ / segment_bytes_;
 }
 
 namespace {
@@ -396,83 +481,113 @@ void Lz77Stage::Run() {
     e.apply = segments_[k].start + P_.spree_window;
     const int32_t d[4] = {4, 11, 15, 16};
     for (int i = 0; i < 4; ++i) e.cache[i] = params_.catable ? 0x7ffffff0 : d[i];
+    if (k != 0) {
+      e.dict_lookups = DictTracker::kAliveL;
+      e.dict_matches = DictTracker::kAliveM;
+    }
   }
   exits_.assign(nseg, SegExit{});
-  int which = 0;
+  int which = 0, rbuf = 0;
+  lz77_rank_flags(P_, B_, which, rbuf);
+  tm.stop(&stats_.ms_rank);
+  if (selftest) SelfTestRank(which, rbuf);
   // ---- warm-up: a dry run over the tail of every segment gives a good first guess of the state in which the
   // parse leaves it (greedy parses re-synchronise quickly), so that the first full round already starts
   // almost every chain from its true entry.
   if (const char* w = getenv("BROTLI_MI355X_WARMUP")) warmup_bytes_ = (uint32_t)atoi(w);
   if (nseg > 1 && warmup_bytes_ > 0) {
-    std::vector<Segment> wsegs(nseg);
-    std::vector<SegEntry> wentries(nseg);
-    for (uint32_t k = 0; k < nseg; ++k) {
-      Segment g = segments_[k];
-      const uint32_t len = g.end - g.start;
-      if (len > warmup_bytes_) g.start = g.end - warmup_bytes_;
-      g.flags = (g.flags & kSegTailStitched) | kSegWarmup;
-      wsegs[k] = g;
-      SegEntry e = entries_[k];
-      e.pos = g.start;
-      e.apply = g.start + P_.spree_window;
-      wentries[k] = e;
-    }
-    Segment* wsegs_dev = (Segment*)dev_alloc(nseg * sizeof(Segment));
-    SegEntry* wentries_dev = (SegEntry*)dev_alloc(nseg * sizeof(SegEntry));
-    SegExit* wexits_dev = (SegExit*)dev_alloc(nseg * sizeof(SegExit));
-    dev_h2d(wsegs_dev, wsegs.data(), nseg * sizeof(Segment));
-    dev_h2d(wentries_dev, wentries.data(), nseg * sizeof(SegEntry));
-    lz77_rank_flags(P_, B_, which);
-    lz77_parse_custom(P_, B_, which, wsegs_dev, wentries_dev, wexits_dev, nseg);
-    std::vector<SegExit> wexits(nseg);
-    dev_d2h(wexits.data(), wexits_dev, nseg * sizeof(SegExit));
-    dev_free(wsegs_dev);
-    dev_free(wentries_dev);
-    dev_free(wexits_dev);
-    for (uint32_t k = 0; k + 1 < nseg; ++k) {
-      SegEntry& e = entries_[k + 1];
-      memcpy(e.cache, wexits[k].cache, sizeof(e.cache));
-      if (!(segments_[k + 1].flags & kSegFirstInBlock)) {
-        e.pos = wexits[k].pos;
-        e.apply = wexits[k].apply;
-      }
-    }
-    stats_.segments_parsed += (uint64_t)nseg * warmup_bytes_ / segment_bytes_;
+    Warmup(0, false, which, rbuf);
     tm.stop(&stats_.ms_warmup);
   }
-  uint32_t first = 0;
+  // ---- rounds.  Round 0 parses every segment; later rounds re-parse only the segments whose entry state
+  // changed or that searched a position whose candidate list changed with the flags (lz77_validate).
+  SegGeometry geo{};
+  geo.prefix_bytes = P_.prefix_bytes;
+  geo.first_block_start = segments_[0].blk_start;
+  geo.block_bytes = block_bytes_;
+  geo.segment_bytes = segment_bytes_;
+  geo.segs_per_block = (block_bytes_ + segment_bytes_ - 1) / segment_bytes_;
+  geo.num_segments = nseg;
+  geo.block_size = 1u << P_.block_bits;
+  uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
+  uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
+  std::vector<uint8_t> dirty(nseg, 0);
+  std::vector<uint32_t> list(nseg);
+  for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
+  uint32_t count = nseg;
   const uint32_t max_rounds = nseg + 8;
   bool done = false;
+  bool full_round = true;
+  uint32_t last_death_seg = 0xffffffffu;
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
     stats_.rounds++;
     tm.stop(&stats_.ms_resolve);
-    dev_h2d(B_.entries + first, entries_.data() + first, (size_t)(nseg - first) * sizeof(SegEntry));
-    lz77_rank_flags(P_, B_, which);
-    tm.stop(&stats_.ms_rank);
-    if (selftest && round == 0) SelfTestRank(which);
+    // upload the entries of the segments to parse, run them, fetch their exits
+    if (full_round) {
+      dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
+    } else {
+      for (uint32_t i = 0; i < count; ++i) dev_h2d(B_.entries + list[i], &entries_[list[i]], sizeof(SegEntry));
+      dev_h2d(list_dev, list.data(), (size_t)count * 4);
+    }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
-    lz77_parse_round(P_, B_, which, first);
-    stats_.segments_parsed += nseg - first;
-    dev_d2h(exits_.data() + first, B_.exits + first, (size_t)(nseg - first) * sizeof(SegExit));
+    if (full_round) {
+      lz77_parse_round(P_, B_, which, rbuf, 0);
+    } else {
+      lz77_parse_list(P_, B_, which, rbuf, list_dev, count);
+    }
+    stats_.segments_parsed += count;
+    dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
     tm.stop(&stats_.ms_parse);
-    const bool consistent = Resolve(false);
-    uint32_t first_flag_change = nseg;
-    for (uint32_t k = first; k < nseg; ++k) {
-      if (exits_[k].flag_changes != 0) {
-        first_flag_change = k;
-        break;
+    uint64_t flag_changes = 0;
+    for (uint32_t i = 0; i < count; ++i) flag_changes += exits_[list[i]].flag_changes;
+    which ^= 1;  // flags[which] now holds the newest flags
+    Resolve(false);
+    for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k];
+    uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
+    for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
+    if (flag_changes != 0) {
+      tm.stop(&stats_.ms_resolve);
+      lz77_rank_flags(P_, B_, which, rbuf ^ 1);
+      dev_memset(dirty_dev, 0, nseg);
+      lz77_validate(P_, B_, which, rbuf, rbuf ^ 1, geo, dirty_dev);
+      std::vector<uint8_t> dv(nseg);
+      dev_d2h(dv.data(), dirty_dev, nseg);
+      for (uint32_t k = 0; k < nseg; ++k) {
+        n_dirty_valid += dv[k];
+        dirty[k] |= dv[k];
+      }
+      rbuf ^= 1;
+      tm.stop(&stats_.ms_rank);
+    }
+    // the static dictionary got switched off at segment dict_death_seg_ and many chains behind it ran in the
+    // wrong regime: they are re-parsed anyway; refresh their entry guesses with a dry run in the new regime
+    const bool regime_flip = dict_death_seg_ != 0xffffffffu && dict_death_seg_ != last_death_seg && dict_flips_ > 64;
+    count = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+      if (dirty[k]) {
+        list[count++] = k;
+        entries_[k] = next_entries_[k];
       }
     }
-    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u first=%u dirty=%u flagchg=%u consistent=%d\n", round, first, first_dirty_, first_flag_change, (int)consistent);
-    if (consistent && first_flag_change == nseg) {
+    if (regime_flip) {
+      last_death_seg = dict_death_seg_;
+      if (warmup_bytes_ > 0 && dict_death_seg_ + 2 < nseg) {
+        // only the dirty segments may take new guesses: the others keep the entries they were parsed with
+        std::vector<SegEntry> keep = entries_;
+        Warmup(dict_death_seg_ + 1, true, which, rbuf);
+        for (uint32_t k = 0; k < nseg; ++k)
+          if (!dirty[k]) entries_[k] = keep[k];
+      }
+    }
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)flag_changes, count, nseg, n_dirty_entry, n_dirty_valid);
+    if (count == 0) {
       done = true;
       break;
     }
-    // everything before the first inconsistency / changed flag is final
-    first = std::min(first_dirty_, first_flag_change);
-    for (uint32_t k = first; k < nseg; ++k) entries_[k] = next_entries_[k];
-    which ^= 1;
+    full_round = false;
   }
+  dev_free(dirty_dev);
+  dev_free(list_dev);
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
   tm.stop(&stats_.ms_resolve);
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
@@ -504,7 +619,7 @@ void Lz77Stage::SelfTestSort() {
   }
 }
 
-void Lz77Stage::SelfTestRank(int which) {
+void Lz77Stage::SelfTestRank(int which, int rbuf) {
   const uint32_t n = P_.total_bytes;
   std::vector<uint16_t> skeys(n);
   std::vector<uint32_t> by_key(n), rank(n), sorted(n), key_base(65537);
@@ -513,7 +628,7 @@ void Lz77Stage::SelfTestRank(int which) {
   dev_d2h(skeys.data(), B_.sorted_keys, (size_t)n * 2);
   dev_d2h(by_key.data(), B_.by_key, (size_t)n * 4);
   dev_d2h(rank.data(), B_.rank, (size_t)n * 4);
-  dev_d2h(sorted.data(), B_.sorted, (size_t)n * 4);
+  dev_d2h(sorted.data(), B_.sorted[rbuf], (size_t)n * 4);
   dev_d2h(key_base.data(), B_.key_base, 65537 * 4);
   dev_d2h(flags.data(), B_.flags[which], n);
   uint32_t g = 0;
@@ -523,7 +638,7 @@ void Lz77Stage::SelfTestRank(int which) {
     if (i == 0 || skeys[i - 1] != skeys[i]) {
       if (key_base[skeys[i]] != g) throw std::runtime_error("selftest: key_base mismatch for key " + std::to_string(skeys[i]));
     }
-    if (flags[p]) {
+    if (flags[p] & 1) {
       if (sorted[g] != p) throw std::runtime_error("selftest: sorted mismatch at rank " + std::to_string(g));
       g++;
     }

@@ -70,8 +70,9 @@ class Lz77Stage {
   void InitFlags();
   bool Resolve(bool final_pass);
   void Gather();
+  void Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf);
   void SelfTestSort();
-  void SelfTestRank(int which);
+  void SelfTestRank(int which, int rbuf);
   void Release();
 
   EncoderParams params_;
@@ -113,6 +114,9 @@ class Lz77Stage {
   Lz77Stats stats_;
   std::map<std::pair<uint32_t, uint32_t>, bool> should_compress_cache_;
   uint32_t first_dirty_ = 0;
+  std::vector<uint8_t> dirty_entry_;
+  uint32_t dict_death_seg_ = 0xffffffffu;
+  uint32_t dict_flips_ = 0;
   bool owns_buffers_ = false;
 };
 

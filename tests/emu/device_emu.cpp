@@ -91,7 +91,7 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   }
 }
 
-void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf) {
   const uint32_t n = P.total_bytes;
   uint32_t g = 0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -99,33 +99,21 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which) {
     const uint16_t k = B.sorted_keys[i];
     B.rank[pos] = g;
     if (i == 0 || B.sorted_keys[i - 1] != k) B.key_base[k] = g;
-    if (B.flags[which][pos]) B.sorted[g++] = pos;
+    if (B.flags[which][pos] & 1) B.sorted[rbuf][g++] = pos;
   }
   for (uint32_t p = 0; p < n; ++p) {
-    B.info[2 * (size_t)p] = B.rank[p];
-    B.info[2 * (size_t)p + 1] = B.rank[p] - B.key_base[B.keys[p]];
+    B.info[rbuf][2 * (size_t)p] = B.rank[p];
+    B.info[rbuf][2 * (size_t)p + 1] = B.rank[p] - B.key_base[B.keys[p]];
   }
 }
 
-static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
-                      SegExit* exits, uint32_t first_segment, uint32_t end_segment);
-
-void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t first_segment) {
-  run_parse(P, B, which, B.segments, B.entries, B.exits, first_segment, P.num_segments);
-}
-
-void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments_dev,
-                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
-  run_parse(P, B, which, segments_dev, entries_dev, exits_dev, 0, count);
-}
-
-static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, const Segment* segments, const SegEntry* entries,
-                      SegExit* exits, uint32_t first_segment, uint32_t end_segment) {
+static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, const SegEntry* entries,
+                      SegExit* exits, uint32_t first_segment, const uint32_t* list, uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ChainTables T;
   T.text = B.text;
-  T.info = B.info;
-  T.sorted = B.sorted;
+  T.info = B.info[rbuf];
+  T.sorted = B.sorted[rbuf];
   T.flags_prev = B.flags[which];
   T.flags_next = B.flags[which ^ 1];
   T.cmds = B.cmds;
@@ -136,8 +124,45 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, cons
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
   ChainScratch scratch;
-  for (uint32_t k = first_segment; k < end_segment; ++k) {
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t k = list ? list[i] : first_segment + i;
     br_parse_segment(P, T, scratch, segments[k], entries[k], exits[k]);
+  }
+}
+
+void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment) {
+  if (first_segment >= P.num_segments) return;
+  run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, P.num_segments - first_segment);
+}
+
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list, uint32_t count) {
+  run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, 0, list, count);
+}
+
+void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
+                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
+  run_parse(P, B, which, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, count);
+}
+
+void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
+                   uint8_t* dirty) {
+  const uint32_t n = P.total_bytes;
+  const uint8_t* flags = B.flags[which];
+  for (uint32_t p = geo.first_block_start; p < n; ++p) {
+    if (!(flags[p] & kFlagSearched)) continue;
+    const uint32_t ga = B.info[rbuf_old][2 * (size_t)p], ca = B.info[rbuf_old][2 * (size_t)p + 1] & 0xffffu;
+    const uint32_t gb = B.info[rbuf_new][2 * (size_t)p], cb = B.info[rbuf_new][2 * (size_t)p + 1] & 0xffffu;
+    const uint32_t na = ca < geo.block_size ? ca : geo.block_size, nb = cb < geo.block_size ? cb : geo.block_size;
+    bool same = na == nb;
+    for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf_old][ga - 1 - j] == B.sorted[rbuf_new][gb - 1 - j];
+    if (same) continue;
+    const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
+    const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
+    const uint32_t off = p - bs;
+    uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
+    if (k >= geo.num_segments) k = geo.num_segments - 1;
+    dirty[k] = 1;
+    if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
   }
 }
 
