@@ -293,6 +293,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   out.distance = 0;
   out.score = kMinScore;
   out.found = false;
+#if defined(BROTLI_HOST_EMU)
   uint32_t best_len = 0;
   uint32_t best_score = kMinScore;
   const uint32_t brk = P.prefix_bytes;
@@ -346,6 +347,67 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
       }
     }
   }
+#else
+  // Wave-parallel form of the same fold.  Every lane scores its own candidate; the reference's sequential rule
+  // ("a later candidate replaces the best one only if it passes the quick-reject test at best_len and scores
+  // strictly higher") is replayed by repeatedly taking the FIRST lane that beats the current best.  A candidate
+  // whose match is not longer than best_len can never score higher than the current best (cache hits carry at
+  // most a 53 point penalty against 135 points per byte, ring entries are ordered by increasing distance), so
+  // "passes the quick reject" reduces to unbroken > best_len, except when the best match already reaches the
+  // block end (best_len == max_length), where the byte behind it decides.
+  uint32_t best_len = 0;
+  uint32_t best_score = kMinScore;
+  const uint32_t brk = P.prefix_bytes;
+  bool walk_broken = false;
+  for (uint32_t base = 0; base < ncand && !walk_broken; base += 64) {
+    const uint32_t c = base + (uint32_t)BR_LANE;
+    const bool in_range = c < ncand;
+    const bool is_cache = c < ndist;
+    const uint32_t prev = in_range ? s.cand_prev[w][c] : 0xffffffffu;
+    const uint32_t unbroken = in_range ? s.cand_len[w][c] : 0u;
+    // the bucket walk stops at the first ring entry that is too far away
+    const unsigned long long stop = __ballot(in_range && !is_cache && prev == 0xffffffffu);
+    bool alive = in_range && prev != 0xffffffffu;
+    if (stop != 0) {
+      const int first_stop = __ffsll((long long)stop) - 1;
+      if (BR_LANE > first_stop) alive = false;
+      walk_broken = true;
+    }
+    uint32_t len = unbroken;
+    if (brk != 0 && alive && prev < brk && prev + unbroken > brk) len = brk - prev;  // fix_unbroken_len
+    const uint32_t backward = cur - prev;
+    bool type_ok;
+    uint32_t score;
+    if (is_cache) {
+      type_ok = unbroken >= 3 || (unbroken == 2 && c < 2);
+      score = P.score_per_byte * len + 30 * 8 * 8 + 15;
+      if (c != 0) score -= 39u + ((0x1ca10u >> (c & 0xe)) & 0xe);
+    } else {
+      type_ok = unbroken >= 4;
+      score = 30 * 8 * 8 + P.score_per_byte * len - 30 * br_log2_floor_nonzero(alive ? backward : 1u);
+    }
+    alive = alive && type_ok;
+    // only needed when a match runs to the end of the block: compare the byte behind it (ring buffer semantics)
+    bool tail_eq = false;
+    if (alive && unbroken == max_length) tail_eq = br_unwritten_byte(P, t, cur + max_length) == t.text[prev + max_length];
+    int start_lane = 0;
+    for (;;) {
+      if ((cur & P.ring_mask) + best_len > P.ring_mask) break;
+      const bool pass = alive && BR_LANE >= start_lane && !((prev & P.ring_mask) + best_len > P.ring_mask) &&
+                        (unbroken > best_len || (unbroken == best_len && best_len == max_length && tail_eq)) && score > best_score;
+      const unsigned long long m = __ballot(pass);
+      if (m == 0) break;
+      const int f = __ffsll((long long)m) - 1;
+      best_len = __shfl(len, f, 64);
+      best_score = __shfl(score, f, 64);
+      out.len = best_len;
+      out.distance = __shfl(backward, f, 64);
+      out.score = best_score;
+      out.found = true;
+      start_lane = f + 1;
+    }
+  }
+#endif
   if (!out.found && P.use_dictionary) {
     // SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false), on the probed items
     const bool dead = ds.matches < (ds.lookups >> 7);

@@ -526,7 +526,7 @@ void Lz77Stage::Run() {
     if (full_round) {
       dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
     } else {
-      for (uint32_t i = 0; i < count; ++i) dev_h2d(B_.entries + list[i], &entries_[list[i]], sizeof(SegEntry));
+      dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
       dev_h2d(list_dev, list.data(), (size_t)count * 4);
     }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
