@@ -140,7 +140,7 @@ def main():
                                           len(chunk), 1, args.segment_bytes, out, cap, st, err, 512)
         if n < 0:
             raise RuntimeError(err.value.decode())
-        comp = out.raw[:n]
+        comp = ctypes.string_at(out, n)
         if world > 1:
             # gather of the variable-length compressed chunks to rank 0 (sizes first, then padded payloads)
             size_t = torch.tensor([n], dtype=torch.int64, device="cuda")
@@ -174,7 +174,7 @@ def main():
         agg["rounds"] += s[0]
         nseg = s[29]
         phases = s[10:20]
-        lz_ms, mb_ms = s[7], s[8]
+        lz_ms, mb_ms, lib_ms = s[7], s[8], s[9]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -215,7 +215,7 @@ def main():
                                        "compress_multi chunk per GPU + RCCL gather + BroCatli stitch"),
                    "input_bytes_total": total, "compressed_bytes": len(comp), "ratio": round(total / max(1, len(comp)), 4),
                    "segment_bytes": args.segment_bytes, "lz77_rounds_per_step": agg["rounds"] / args.steps,
-                   "stage_ms_last_step": {"lz77": round(lz_ms, 2), "metablock": round(mb_ms, 2)}},
+                   "stage_ms_last_step": {"lz77": round(lz_ms, 2), "metablock": round(mb_ms, 2), "phases": [round(x, 2) for x in phases], "library_total": round(lib_ms, 2)}},
         "roofline": {"bound": "hbm", "kernel": "k_parse_segments", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": agg["launches"] / args.steps,

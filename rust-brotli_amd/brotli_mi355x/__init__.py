@@ -159,7 +159,7 @@ class Library(object):
         n = c_size_t(cap)
         if not self.lib.BrotliEncoderCompress(quality, lgwin, mode, len(data), data, byref(n), out):
             raise BrotliCompressorException("BrotliEncoderCompress failed: " + self.last_error())
-        return out.raw[:n.value]
+        return ctypes.string_at(out, n.value)
 
     def compress_device(self, device_ptr, nbytes, quality=5, lgwin=22, mode=0, out_buffer=None):
         """One-shot compression of `nbytes` at device address `device_ptr` (e.g. tensor.data_ptr()).
@@ -170,7 +170,7 @@ class Library(object):
         stats = (c_double * 32)()
         if not self.lib.BrotliMi355xCompressDevice(quality, lgwin, mode, nbytes, c_void_p(device_ptr), byref(n), out, stats):
             raise BrotliCompressorException("BrotliMi355xCompressDevice failed: " + self.last_error())
-        return out.raw[:n.value], list(stats)
+        return ctypes.string_at(out, n.value), list(stats)
 
     # ---- multi-GPU helpers: one chunk per process, stitched on rank 0 ----
     def compress_chunk(self, data_or_ptr, nbytes, thread_index, num_threads, compression_options_map={}, on_device=False):
@@ -189,7 +189,7 @@ class Library(object):
                                                  byref(size), out)
         if ret == 0:
             raise BrotliCompressorException("BrotliMi355xCompressChunk failed: " + self.last_error())
-        return out.raw[:size.value]
+        return ctypes.string_at(out, size.value)
 
     def concat_chunks(self, chunks):
         arr = (c_char_p * len(chunks))(*[bytes(c) for c in chunks])
@@ -199,7 +199,7 @@ class Library(object):
         n = c_size_t(cap)
         if not self.lib.BrotliMi355xConcatChunks(len(chunks), arr, sizes, byref(n), out):
             raise BrotliCompressorException("BrotliMi355xConcatChunks failed: " + self.last_error())
-        return out.raw[:n.value]
+        return ctypes.string_at(out, n.value)
 
     def encoder(self, **params):
         return Encoder(self, **params)

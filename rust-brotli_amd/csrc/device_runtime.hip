@@ -1,6 +1,9 @@
 // device_runtime.hip -- device memory helpers and the read-only tables of the encoder hot path.
 #include <hip/hip_runtime.h>
+#include <map>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 #include <stdexcept>
 #include <string>
 
@@ -12,15 +15,82 @@ namespace brotli_mi355x {
 void hip_check(hipError_t e, const char* what);
 #define HIP_CHECK(x) hip_check((x), #x)
 
+// Device memory pool: a compression call needs a few dozen large scratch buffers whose sizes repeat from call
+// to call.  hipMalloc / hipFree cost milliseconds each (and hipFree synchronises the device), so freed blocks
+// are kept per size class and handed out again.  Blocks are zero-filled on allocation (the encoder relies on
+// it, like the reference relies on zeroed hash tables, encode.rs:1147).
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;  // capacity -> block
+  std::unordered_map<void*, size_t> capacity;  // every live block handed out or pooled
+  size_t pooled_bytes = 0;
+  static constexpr size_t kMaxPooled = (size_t)96 << 30;
+};
+Pool& pool() {
+  static Pool p;
+  return p;
+}
+size_t RoundUp(size_t bytes) {
+  size_t g = 1 << 16;
+  while (g < bytes / 8) g <<= 1;  // granularity ~ 1/8 of the size: at most 12.5 % slack
+  return (bytes + g - 1) / g * g;
+}
+}  // namespace
+
 void* dev_alloc(size_t bytes) {
-  void* p = nullptr;
   if (bytes == 0) bytes = 16;
-  HIP_CHECK(hipMalloc(&p, bytes));
+  const size_t cap = RoundUp(bytes);
+  Pool& P = pool();
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.free_blocks.lower_bound(cap);
+    if (it != P.free_blocks.end() && it->first <= cap + cap / 4) {
+      p = it->second;
+      P.pooled_bytes -= it->first;
+      P.free_blocks.erase(it);
+    }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {
+      // give pooled memory back to the driver and retry once
+      std::vector<void*> drop;
+      {
+        std::lock_guard<std::mutex> lock(P.mu);
+        for (auto& kv : P.free_blocks) {
+          drop.push_back(kv.second);
+          P.capacity.erase(kv.second);
+        }
+        P.free_blocks.clear();
+        P.pooled_bytes = 0;
+      }
+      for (void* d : drop) (void)hipFree(d);
+      HIP_CHECK(hipMalloc(&p, cap));
+    }
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.capacity[p] = cap;
+  }
   HIP_CHECK(hipMemsetAsync(p, 0, bytes, 0));
   return p;
 }
 void dev_free(void* p) {
-  if (p) (void)hipFree(p);
+  if (!p) return;
+  Pool& P = pool();
+  std::lock_guard<std::mutex> lock(P.mu);
+  auto it = P.capacity.find(p);
+  if (it == P.capacity.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  if (P.pooled_bytes + it->second > Pool::kMaxPooled) {
+    P.capacity.erase(it);
+    (void)hipFree(p);
+    return;
+  }
+  P.free_blocks.emplace(it->second, p);
+  P.pooled_bytes += it->second;
 }
 void dev_memset(void* p, int value, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemsetAsync(p, value, bytes, 0));

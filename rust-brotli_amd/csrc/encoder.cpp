@@ -268,7 +268,11 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     return;
   }
 
-  lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, req.segment_bytes);
+  {
+    Clock c;
+    lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, req.segment_bytes);
+    stats.ms_phase[9] = c.lap(prof);
+  }
   for (;;) {  // repeated only when a compressed meta-block turns out larger than its raw form
     HostBits bits = hb;  // stream position after the head pieces
     bits.pos = head_bits;
