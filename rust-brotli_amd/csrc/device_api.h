@@ -71,7 +71,10 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
 // rank/sorted) and write flags[which ^ 1], cmds and exits
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment);
 // the same over an explicit list of segment indices (device array); flags are read from and written to flags[which]
-void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint32_t count);
+// sched_dev[k] = 1 for the segments in the list; a chain continues into following unscheduled segments whose entry
+// it changes (br_parse_chain) and rewrites B.entries for them
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, const uint8_t* sched_dev,
+                     uint32_t count);
 // marks (dirty[k] = 1) the segments that searched a position whose candidate list differs between the rank
 // structures rbuf_old and rbuf_new
 struct SegGeometry {
@@ -81,7 +84,7 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
                    uint8_t* dirty_dev);
 // same kernel over an explicit list of (segment, entry) pairs (used for the warm-up dry run)
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
-                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);
+                       SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)

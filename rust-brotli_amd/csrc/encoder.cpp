@@ -251,6 +251,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
 
   Lz77Stage lz;
   std::vector<uint8_t> result;
+  bool wrote_direct = false;
   if (n - raw_head == 0) {
     // nothing left to search: only the trailing blocks (encode.rs:1979-1982)
     WriteEmptyLastBlocks(p, &hb);
@@ -263,7 +264,13 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     }
     for (const RawCopy& rc : raw_copies) dev_d2h(result.data() + rc.dst_byte, text + rc.src_pos, rc.bytes);
     result.resize(total_bytes);
-    out->insert(out->end(), result.begin(), result.end());
+    if (req.direct_out) {
+      if (result.size() > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
+      memcpy(req.direct_out, result.data(), result.size());
+      *req.direct_size = result.size();
+    } else {
+      out->insert(out->end(), result.begin(), result.end());
+    }
     if (stats_out) *stats_out = stats;
     return;
   }
@@ -531,8 +538,15 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       }
     }
     stats.ms_phase[7] += clk.lap(prof);
-    result.resize(total_bytes);
-    dev_d2h(result.data(), B.out_words, total_bytes);
+    if (req.direct_out) {
+      if (total_bytes > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
+      dev_d2h(req.direct_out, B.out_words, total_bytes);
+      *req.direct_size = total_bytes;
+      wrote_direct = true;
+    } else {
+      result.resize(total_bytes);
+      dev_d2h(result.data(), B.out_words, total_bytes);
+    }
     stats.ms_phase[8] += clk.lap(prof);
     stats.metablocks = n_mb;
     stats.commands = K;
@@ -540,7 +554,15 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     for (uint32_t m = 0; m < n_mb; ++m) stats.uncompressed_metablocks += descs[m].uncompressed;
     break;
   }
-  out->insert(out->end(), result.begin(), result.end());
+  if (!wrote_direct) {
+    if (req.direct_out) {
+      if (result.size() > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
+      memcpy(req.direct_out, result.data(), result.size());
+      *req.direct_size = result.size();
+    } else {
+      out->insert(out->end(), result.begin(), result.end());
+    }
+  }
   stats.ms_total = total_clock.lap(false) + stats.ms_phase[0];
   stats.ms_metablock = 0;
   for (int i = 1; i < 9; ++i) stats.ms_metablock += stats.ms_phase[i];

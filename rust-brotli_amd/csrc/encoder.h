@@ -41,6 +41,11 @@ struct EncodeRequest {
   bool prefix_is_file_continuation = false;  // compress_multi semantics: prev bytes come from the prefix
   bool hasher_chosen_before_size_hint = false;  // custom dictionary path picks the hasher early
   uint32_t segment_bytes = 4096;
+  // optional: the stream is written straight into this buffer instead of `out` (one device-to-host copy, no
+  // intermediate vector); too small a buffer is an error
+  uint8_t* direct_out = nullptr;
+  size_t direct_capacity = 0;
+  size_t* direct_size = nullptr;
 };
 
 // Compresses one stream.  Output is appended to `out`.  Throws std::runtime_error on device errors or

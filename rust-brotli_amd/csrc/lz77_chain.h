@@ -500,8 +500,9 @@ struct FlagWriter {
 };
 
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
+// `next` receives (in every lane) the entry state this parse hands to the following segment.
 BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment& seg,
-                             const SegEntry& entry, SegExit& exit_out) {
+                             const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
   const uint32_t pos_end = seg.blk_end;
   const uint32_t htl = P.htl;
   const uint32_t window = P.spree_window;
@@ -662,6 +663,56 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     exit_out.dict_maxdef = ds.maxdef;
     exit_out.n_pushes = n_pushes;
     exit_out.pad1 = 0;
+  }
+  next.pos = position;
+  next.apply = apply;
+  for (int i = 0; i < 4; ++i) next.cache[i] = dc[i];
+  next.insert_len = 0;
+  next.ext_allowed = 0;
+  next.dict_lookups = ds.lookups;
+  next.dict_matches = ds.matches;
+  next.ext_max_distance = 0;
+  next.dict_exact = entry.dict_exact;
+}
+
+// Parses segment k and -- in list rounds (sched != nullptr) -- keeps going into the following segments of the
+// same input block for as long as the state it arrives with differs from the entry their last parse used and
+// they are not scheduled themselves: a change that would otherwise creep forward one segment per round (each
+// round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
+// written to entries[] so that the host resolver sees what it was parsed with.
+BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment* segments,
+                           SegEntry* entries, SegExit* exits, uint32_t k, const uint8_t* sched) {
+  SegEntry entry = entries[k];
+  for (;;) {
+    const Segment seg = segments[k];
+    SegEntry next;
+    br_parse_segment(P, t, s, seg, entry, exits[k], next);
+    if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
+    if (sched[k + 1]) break;
+    const SegEntry old = entries[k + 1];
+    bool same = old.pos == next.pos && old.apply == next.apply;
+    for (int i = 0; i < 4; ++i) same = same && old.cache[i] == next.cache[i];
+    if (same && P.use_dictionary && next.dict_exact) {
+      // static-dictionary throttle (mod.rs:1957-1960): would the old parse of k + 1 have seen the dictionary in the
+      // same state under the counters this chain arrives with?  (mirrors DictTracker::Consume on the host)
+      const uint32_t mode = exits[k + 1].dict_mode;
+      const int32_t maxdef = exits[k + 1].dict_maxdef;
+      const bool dead = next.dict_matches < (next.dict_lookups >> 7);
+      if (mode != 0) {
+        if (dead) {
+          same = mode == 2;
+        } else if (old.dict_lookups == next.dict_lookups && old.dict_matches == next.dict_matches) {
+          same = true;
+        } else {
+          same = mode == 1 && (128ll * (long long)next.dict_matches - (long long)next.dict_lookups + 127 >= (long long)maxdef);
+        }
+      }
+    }
+    if (same) break;
+    BR_SYNC();
+    ++k;
+    if (BR_LANE == 0) entries[k] = next;
+    entry = next;
   }
 }
 

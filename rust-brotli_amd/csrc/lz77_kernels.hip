@@ -268,10 +268,11 @@ struct ParseArgs {
   Lz77Params P;
   ChainTables T;
   const Segment* segments;
-  const SegEntry* entries;
+  SegEntry* entries;
   SegExit* exits;
   uint32_t first_segment;
   const uint32_t* list;  // optional explicit segment indices
+  const uint8_t* sched;  // list rounds: per segment, 1 if it is in the list (see br_parse_chain)
   uint32_t count;
 };
 
@@ -288,13 +289,12 @@ __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratch scratch;
   if (blockIdx.x >= a.count) return;
   const uint32_t k = a.list ? a.list[blockIdx.x] : a.first_segment + blockIdx.x;
-  const Segment seg = a.segments[k];
-  const SegEntry entry = a.entries[k];
-  br_parse_segment(a.P, a.T, scratch, seg, entry, a.exits[k]);
+  br_parse_chain(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched);
 }
 
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
-                         const SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, uint32_t count) {
+                         SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, const uint8_t* sched,
+                         uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ParseArgs a;
   a.P = P;
@@ -315,6 +315,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.exits = exits;
   a.first_segment = first_segment;
   a.list = list;
+  a.sched = sched;
   a.count = count;
   // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
   ParseTiming& pt = parse_timing();
@@ -331,18 +332,19 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
 
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment) {
   if (first_segment >= P.num_segments) return;
-  launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, P.num_segments - first_segment);
+  launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, nullptr, P.num_segments - first_segment);
 }
 
-void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint32_t count) {
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, const uint8_t* sched_dev,
+                     uint32_t count) {
   if (count == 0) return;
-  launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, 0, list_dev, count);
+  launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, 0, list_dev, sched_dev, count);
 }
 
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
-                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
+                       SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
   if (count == 0) return;
-  launch_parse(P, B, which, which ^ 1, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, count);
+  launch_parse(P, B, which, which ^ 1, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, nullptr, count);
 }
 
 // ------------------------------------------------------------------------------------------ validate

@@ -165,6 +165,7 @@ struct DictTracker {
   void Hint(SegEntry* e) const {
     e->dict_lookups = state == kAlive ? L : kDeadL;
     e->dict_matches = state == kAlive ? M : kDeadM;
+    e->dict_exact = state != kUnknown;
   }
   // consumes the exit of segment k, parsed with entry `used`; returns whether that parse is valid here
   bool Consume(uint32_t k, const SegEntry& used, const SegExit& x) {
@@ -204,6 +205,10 @@ struct DictTracker {
 bool Lz77Stage::Resolve(bool final_pass) {
   const uint32_t nseg = (uint32_t)segments_.size();
   next_entries_.assign(nseg, SegEntry{});
+  if (getenv("BROTLI_MI355X_DEBUG")) {
+    dbg_mismatch_ = dbg_counts_;
+    memset(dbg_counts_, 0, sizeof(dbg_counts_));
+  }
   metablocks_.clear();
   patches_.clear();
   trailing_.clear();
@@ -321,6 +326,12 @@ bool Lz77Stage::Resolve(bool final_pass) {
         dict.Hint(&N);
         const SegEntry& u = entries_[j + 1];
         bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0;
+        if (dbg_mismatch_) {
+          dbg_mismatch_[0] += u.pos != N.pos;
+          dbg_mismatch_[1] += u.pos == N.pos && u.apply != N.apply;
+          dbg_mismatch_[2] += u.pos == N.pos && memcmp(u.cache, N.cache, sizeof(N.cache)) != 0;
+          dbg_mismatch_[3] += u.pos == N.pos && u.apply != N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0;
+        }
         mark(j + 1, same);
         next_entries_[j + 1] = N;
       }
@@ -513,6 +524,7 @@ void Lz77Stage::Run() {
   uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
   std::vector<uint8_t> dirty(nseg, 0);
   std::vector<uint32_t> list(nseg);
+  std::vector<SegEntry> used_entries(nseg);
   for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
   uint32_t count = nseg;
   const uint32_t max_rounds = nseg + 8;
@@ -528,18 +540,33 @@ void Lz77Stage::Run() {
     } else {
       dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
       dev_h2d(list_dev, list.data(), (size_t)count * 4);
+      dev_h2d(dirty_dev, dirty.data(), nseg);
     }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     if (full_round) {
       lz77_parse_round(P_, B_, which, rbuf, 0);
     } else {
-      lz77_parse_list(P_, B_, which, rbuf, list_dev, count);
+      lz77_parse_list(P_, B_, which, rbuf, list_dev, dirty_dev, count);
     }
     stats_.segments_parsed += count;
     dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
-    tm.stop(&stats_.ms_parse);
     uint64_t flag_changes = 0;
     for (uint32_t i = 0; i < count; ++i) flag_changes += exits_[list[i]].flag_changes;
+    if (!full_round) {
+      // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
+      dev_d2h(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
+      for (uint32_t k = 1; k < nseg; ++k) {
+        if (dirty[k]) continue;
+        const SegEntry &a = used_entries[k], &b = entries_[k];
+        if (a.pos != b.pos || a.apply != b.apply || memcmp(a.cache, b.cache, sizeof(a.cache)) != 0 ||
+            a.dict_lookups != b.dict_lookups || a.dict_matches != b.dict_matches) {
+          entries_[k] = a;
+          flag_changes += exits_[k].flag_changes;
+          stats_.segments_parsed++;
+        }
+      }
+    }
+    tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
     Resolve(false);
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k];
@@ -579,6 +606,7 @@ void Lz77Stage::Run() {
           if (!dirty[k]) entries_[k] = keep[k];
       }
     }
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u; dict death seg %u flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dict_death_seg_, dict_flips_);
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)flag_changes, count, nseg, n_dirty_entry, n_dirty_valid);
     if (count == 0) {
       done = true;

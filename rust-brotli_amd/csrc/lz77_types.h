@@ -74,7 +74,7 @@ struct SegEntry {
   uint32_t dict_lookups;  // static-dictionary throttle counters at entry (mod.rs:1957-1960)
   uint32_t dict_matches;
   uint32_t ext_max_distance;  // max_distance for extend_last_command
-  uint32_t pad;
+  uint32_t dict_exact;  // the throttle counters are the true ones (not a guess): br_parse_chain may rely on them
 };
 
 struct SegExit {

@@ -107,8 +107,8 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   }
 }
 
-static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, const SegEntry* entries,
-                      SegExit* exits, uint32_t first_segment, const uint32_t* list, uint32_t count) {
+static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, SegEntry* entries,
+                      SegExit* exits, uint32_t first_segment, const uint32_t* list, const uint8_t* sched, uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ChainTables T;
   T.text = B.text;
@@ -126,22 +126,23 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   ChainScratch scratch;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
-    br_parse_segment(P, T, scratch, segments[k], entries[k], exits[k]);
+    br_parse_chain(P, T, scratch, segments, entries, exits, k, sched);
   }
 }
 
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment) {
   if (first_segment >= P.num_segments) return;
-  run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, P.num_segments - first_segment);
+  run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, nullptr, P.num_segments - first_segment);
 }
 
-void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list, uint32_t count) {
-  run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, 0, list, count);
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list, const uint8_t* sched,
+                     uint32_t count) {
+  run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, 0, list, sched, count);
 }
 
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
-                       const SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
-  run_parse(P, B, which, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, count);
+                       SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
+  run_parse(P, B, which, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, nullptr, count);
 }
 
 void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
