@@ -38,15 +38,21 @@ struct DeviceTables {
 const DeviceTables& dev_tables();
 
 // ---- LZ77 stage ----
+static constexpr uint32_t kChangedCap = 1u << 16;
+
 struct Lz77Buffers {
   uint8_t* text;        // total_bytes + 64
   uint16_t* keys;       // total_bytes
   uint32_t* by_key;     // positions sorted by (key, position)            [total_bytes]
   uint16_t* sorted_keys;// keys in that order                              [total_bytes]
-  uint32_t* rank;       // per position                                    [total_bytes]
+  uint8_t* fbits;       // stored bit of by_key[i], scratch of the full rank pass   [total_bytes + 64]
   uint32_t* info[2];    // per position {rank, count of stored same-key positions before it} [2 * total_bytes], double buffered
   uint32_t* sorted[2];  // stored positions in (key,pos) order             [total_bytes], double buffered
-  uint32_t* key_base;   // per key                                         [65536 + 1]
+  uint32_t* key_base;   // per key: stored positions in front of its first slot (scratch of the full rank pass) [65536 + 1]
+  uint32_t* key_first;  // per key: first / one-past-last slot in (key,pos) order  [65536 + 1] each
+  uint32_t* key_last;
+  uint32_t* changed_keys;  // keys whose stored flags changed in the last parse launch(es) [kChangedCap]
+  uint32_t* changed_count; // [1]
   uint8_t* flags[2];    // stored flags, double buffered                   [total_bytes + 64]
   Command* cmds;        // num_segments * cmd_slab_stride
   Segment* segments;    // num_segments
@@ -65,7 +71,7 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start);
 // stable sort of positions by key -> by_key / sorted_keys
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
-// rank / sorted[rbuf] / info[rbuf] from flags[which]
+// sorted[rbuf] / info[rbuf] from flags[which] (all keys)
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through
 // rank/sorted) and write flags[which ^ 1], cmds and exits
@@ -82,6 +88,18 @@ struct SegGeometry {
 };
 void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
                    uint8_t* dirty_dev);
+// incremental form of rank + validate: re-ranks the listed chunks (all slots of every changed key, cut into pieces of
+// kRerankChunk slots, keys in ascending order) of sorted[rbuf] / info[rbuf] in place from flags[which] and marks the
+// segments that searched a position of those keys whose candidate list changed.  sums_dev: num_chunks words of scratch.
+static constexpr uint32_t kRerankChunk = 4096;
+struct RerankChunk {
+  uint32_t key_lo;     // first slot of the key
+  uint32_t begin, end; // slots of this chunk
+  uint32_t first_sum;  // index (in sums) of the key's first chunk
+  uint32_t my_sum;     // index of this chunk
+};
+void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RerankChunk* chunks_dev, uint32_t num_chunks,
+                      uint32_t* sums_dev, const SegGeometry& geo, uint8_t* dirty_dev);
 // same kernel over an explicit list of (segment, entry) pairs (used for the warm-up dry run)
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
                        SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);

@@ -29,12 +29,14 @@
 #define BR_LANE 0
 #define BR_NLANES 1
 #define BR_SYNC() ((void)0)
+#define BR_ATOMIC_INC(ptr) ((*(ptr))++)
 #else
 #include <hip/hip_runtime.h>
 #define BR_DEV __device__ __forceinline__
 #define BR_LANE ((int)threadIdx.x)
 #define BR_NLANES 64
 #define BR_SYNC() __syncthreads()
+#define BR_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
 #endif
 
 namespace brotli_mi355x {
@@ -58,6 +60,11 @@ struct ChainTables {
   const uint8_t* dict_size_bits_by_length;
   uint32_t dist_postfix_bits;
   uint32_t num_direct_distance_codes;
+  // log of the keys whose stored flags changed in this round (for the incremental re-rank)
+  const uint16_t* keys;
+  uint32_t* changed_keys;   // [changed_cap]
+  uint32_t* changed_count;  // may run past changed_cap: the host then falls back to a full re-rank
+  uint32_t changed_cap;
 };
 
 struct ChainScratch {  // one per wavefront (LDS on the device)
@@ -477,15 +484,21 @@ BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
 struct FlagWriter {
   const uint8_t* prev;
   uint8_t* next;
+  const ChainTables* t;
   bool enabled;
   uint32_t changes;  // per lane
   uint32_t tail_lo;  // positions >= tail_lo inside the block get the stitch flag
   uint8_t tail_value;
-  BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
-    if (BR_LANE == 0 && enabled) {
-      changes += ((prev[q] ^ v) & 1);
-      next[q] = v;
+  BR_DEV void put(uint32_t q, uint8_t v) {
+    if ((prev[q] ^ v) & 1) {
+      changes++;
+      const uint32_t idx = BR_ATOMIC_INC(t->changed_count);
+      if (idx < t->changed_cap) t->changed_keys[idx] = t->keys[q];
     }
+    next[q] = v;
+  }
+  BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
+    if (BR_LANE == 0 && enabled) put(q, v);
   }
   BR_DEV uint8_t unstored(uint32_t q) const { return q >= tail_lo ? tail_value : (uint8_t)0; }
   // [a, b) := v for q < split, static "not stored by the main loop" value for q >= split
@@ -493,8 +506,7 @@ struct FlagWriter {
     if (!enabled) return;
     for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) {
       const uint8_t v = q < split ? (uint8_t)1 : unstored(q);
-      changes += ((prev[q] ^ v) & 1);
-      next[q] = v;
+      put(q, v);
     }
   }
 };
@@ -520,6 +532,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   FlagWriter fw;
   fw.prev = t.flags_prev;
   fw.next = t.flags_next;
+  fw.t = &t;
   fw.changes = 0;
   fw.enabled = !(seg.flags & kSegWarmup);
   fw.tail_lo = pos_end - 3;
@@ -617,8 +630,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           // Store4Vec4: position, +4, +8, +12
           for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 16; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 3) == 0;
-            fw.changes += ((fw.prev[q] ^ v) & 1);
-            fw.next[q] = v;
+            fw.put(q, v);
           }
           insert_length += 16;
           position += 16;
@@ -626,8 +638,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           // StoreEvenVec4: position, +2, +4, +6
           for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 8; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 1) == 0;
-            fw.changes += ((fw.prev[q] ^ v) & 1);
-            fw.next[q] = v;
+            fw.put(q, v);
           }
           insert_length += 8;
           position += 8;

@@ -151,8 +151,11 @@ size_t lz77_sort_tmp_bytes(uint32_t total_bytes) {
   const size_t n = total_bytes;
   const size_t tiles = (n + kSortTile - 1) / kSortTile + 1;
   // ping-pong keys + values, digit histograms, scan scratch
-  return n * 2 + n * 4 + tiles * 256 * 4 + (tiles * 256 / kScanTile + 1024) * 8 + (n / kScanTile + 1024) * 8 + 4096;
+  // (the incremental re-rank uses the same scratch for two u32 arrays in (key,pos) index space)
+  return n * 8 + 1024 + tiles * 256 * 4 + (tiles * 256 / kScanTile + 1024) * 8 + (n / kScanTile + 1024) * 8 + 4096;
 }
+
+void lz77_key_ranges(const Lz77Params& P, const Lz77Buffers& B);
 
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   const uint32_t n = P.total_bytes;
@@ -176,38 +179,80 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   exclusive_scan_u32(hist, tiles * 256, scratch);
   hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, 0, keys_tmp, vals_tmp, B.sorted_keys, B.by_key, n, 8u, tiles, hist);
   HIP_CHECK(hipGetLastError());
+  lz77_key_ranges(P, B);
 }
 
 // ------------------------------------------------------------------------------------------ rank
-// tile sums of flags in (key,pos) order
-__global__ __launch_bounds__(256) void k_rank_tile_sums(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
-                                                         uint32_t* __restrict__ tile_sums) {
+// The "hash table" of the reference as a function of the stored flags.  Index space = (key, position) order
+// (by_key): key k owns the slots [key_first[k], key_last[k]); the stored positions of that key are compacted
+// to the front of its slots in `sorted`, and info[p] = {slot one past ... i.e. key_first + local rank, local rank}
+// where local rank = number of stored same-key positions before p.  Because a key's slots do not depend on any
+// other key, a handful of flag changes can be applied key by key (k_rerank_keys) without touching the rest.
+__global__ __launch_bounds__(256) void k_key_ranges(const uint16_t* __restrict__ sorted_keys, uint32_t n, uint32_t* __restrict__ key_first,
+                                                     uint32_t* __restrict__ key_last) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint16_t k = sorted_keys[i];
+  if (i == 0 || sorted_keys[i - 1] != k) key_first[k] = i;
+  if (i + 1 == n || sorted_keys[i + 1] != k) key_last[k] = i + 1;
+}
+
+// pass A: gather the stored bits into (key,pos) order (one byte each) and sum them per tile
+__global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
+                                                      uint8_t* __restrict__ fbits, uint32_t* __restrict__ tile_sums) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
-  uint32_t local = 0;
+  uint32_t local = 0, packed = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (base + j < n) local += flags[by_key[base + j]] & 1u;
+    if (base + j < n) {
+      const uint32_t f = flags[by_key[base + j]] & 1u;
+      packed |= f << (8 * j);
+      local += f;
+    }
+  if (base < n) *(uint32_t*)(fbits + base) = packed;
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
   if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = local;
   __syncthreads();
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
+// pass K: global count of stored positions in front of every key's first slot
+__global__ __launch_bounds__(256) void k_key_bases(const uint8_t* __restrict__ fbits, const uint32_t* __restrict__ tile_offsets,
+                                                    const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
+                                                    uint32_t* __restrict__ key_base) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 65536) return;
+  const uint32_t i0 = key_first[k];
+  if (key_last[k] <= i0) return;
+  const uint32_t tile = i0 / kScanTile;
+  uint32_t g = tile_offsets[tile];
+  uint32_t i = tile * kScanTile;
+  for (; i + 4 <= i0; i += 4) g += (*(const uint32_t*)(fbits + i) * 0x01010101u) >> 24;
+  for (; i < i0; ++i) g += fbits[i];
+  key_base[k] = g;
+}
+
+// pass B: local ranks -> sorted / info
 __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__ by_key, const uint16_t* __restrict__ sorted_keys,
-                                                     const uint8_t* __restrict__ flags, uint32_t n, const uint32_t* __restrict__ tile_offsets,
-                                                     uint32_t* __restrict__ rank, uint32_t* __restrict__ sorted, uint32_t* __restrict__ key_base) {
+                                                     const uint8_t* __restrict__ fbits, uint32_t n, const uint32_t* __restrict__ tile_offsets,
+                                                     const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_base,
+                                                     uint32_t* __restrict__ sorted, uint2* __restrict__ info) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
-  uint32_t pos[4], f[4];
+  uint32_t pos[4], f[4], key[4];
   uint32_t local = 0;
+  const uint32_t packed = base < n ? *(const uint32_t*)(fbits + base) : 0u;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     pos[j] = 0;
-    f[j] = 0;
+    key[j] = 0;
+    f[j] = (packed >> (8 * j)) & 1u;
     if (base + j < n) {
       pos[j] = by_key[base + j];
-      f[j] = flags[pos[j]] & 1u;
+      key[j] = sorted_keys[base + j];
+    } else {
+      f[j] = 0;
     }
     local += f[j];
   }
@@ -224,29 +269,23 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
   for (int i = 0; i < w; ++i) g += wave_sum[i];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t i = base + j;
-    if (i < n) {
-      rank[pos[j]] = g;
-      if (f[j]) sorted[g] = pos[j];
-      const uint16_t k = sorted_keys[i];
-      if (i == 0 || sorted_keys[i - 1] != k) key_base[k] = g;
+    if (base + j < n) {
+      const uint32_t lr = g - key_base[key[j]];
+      const uint32_t slot = key_first[key[j]] + lr;
+      info[pos[j]] = make_uint2(slot, lr);
+      if (f[j]) sorted[slot] = pos[j];
       g += f[j];
     }
   }
 }
 
-// per position: everything a search needs to find its candidates, in one 8-byte record
-__global__ __launch_bounds__(256) void k_make_info(const uint16_t* __restrict__ keys, const uint32_t* __restrict__ rank,
-                                                    const uint32_t* __restrict__ key_base, uint32_t n, uint2* __restrict__ info) {
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t p = base + j;
-    if (p < n) {
-      const uint32_t g = rank[p];
-      info[p] = make_uint2(g, g - key_base[keys[p]]);
-    }
-  }
+void lz77_key_ranges(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  HIP_CHECK(hipMemsetAsync(B.key_first, 0, 65537 * 4, 0));
+  HIP_CHECK(hipMemsetAsync(B.key_last, 0, 65537 * 4, 0));
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_key_ranges, dim3((n + 255) / 256), dim3(256), 0, 0, B.sorted_keys, n, B.key_first, B.key_last);
+  HIP_CHECK(hipGetLastError());
 }
 
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf) {
@@ -255,11 +294,138 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
-  hipLaunchKernelGGL(k_rank_tile_sums, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, tile_sums);
+  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, B.fbits, tile_sums);
   exclusive_scan_u32(tile_sums, tiles, scratch);
-  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.flags[which], n, tile_sums, B.rank, B.sorted[rbuf],
-                     B.key_base);
-  hipLaunchKernelGGL(k_make_info, dim3(tiles), dim3(256), 0, 0, B.keys, B.rank, B.key_base, n, (uint2*)B.info[rbuf]);
+  hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, 0, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
+  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
+                     B.sorted[rbuf], (uint2*)B.info[rbuf]);
+  HIP_CHECK(hipGetLastError());
+}
+
+// marks the chain(s) that searched position p
+__device__ __forceinline__ void mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* __restrict__ dirty) {
+  const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
+  const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
+  const uint32_t off = p - bs;
+  uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
+  if (k >= geo.num_segments) k = geo.num_segments - 1;
+  dirty[k] = 1;
+  // a lazy probe just behind a segment boundary belongs to the previous chain
+  if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+}
+
+// Incremental update after a few flag changes: the slots of every changed key are cut into chunks of
+// kRerankChunk; one workgroup per chunk (1) counts the stored bits, (2) recomputes the local ranks into scratch,
+// (3) marks the chains that searched a position of that key whose candidate list is no longer what they saw and
+// (4) commits the new ranks in place.  Keys that did not change are not touched.
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* wave_sum) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+__global__ __launch_bounds__(256) void k_rerank_count(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ by_key,
+                                                       const uint8_t* __restrict__ flags, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t wave_sum[4];
+  const RerankChunk c = chunks[blockIdx.x];
+  uint32_t local = 0;
+  for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) local += flags[by_key[i]] & 1u;
+  const uint32_t total = block_sum_256(local, wave_sum);
+  if (threadIdx.x == 0) sums[c.my_sum] = total;
+}
+
+__global__ __launch_bounds__(256) void k_rerank_apply(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ sums,
+                                                       const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags,
+                                                       uint32_t* __restrict__ rank_tmp, uint32_t* __restrict__ sorted_tmp) {
+  __shared__ uint32_t wave_sum[4];
+  __shared__ uint32_t running;
+  const RerankChunk c = chunks[blockIdx.x];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t before = 0;
+  for (uint32_t j = c.first_sum + threadIdx.x; j < c.my_sum; j += 256) before += sums[j];
+  before = block_sum_256(before, wave_sum);
+  if (threadIdx.x == 0) running = before;
+  __syncthreads();
+  for (uint32_t tile = c.begin; tile < c.end; tile += kScanTile) {
+    const uint32_t base = tile + threadIdx.x * 4;
+    uint32_t pos[4], f[4], local = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pos[j] = 0;
+      f[j] = 0;
+      if (base + j < c.end) {
+        pos[j] = by_key[base + j];
+        f[j] = flags[pos[j]] & 1u;
+      }
+      local += f[j];
+    }
+    uint32_t x = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sum[w] = x;
+    __syncthreads();
+    uint32_t g = running + x - local;
+    for (int i = 0; i < w; ++i) g += wave_sum[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (base + j < c.end) {
+        rank_tmp[base + j] = g;
+        if (f[j]) sorted_tmp[c.key_lo + g] = pos[j];
+        g += f[j];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) running += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rerank_check(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ by_key,
+                                                       const uint8_t* __restrict__ flags, const uint32_t* __restrict__ sorted,
+                                                       const uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
+                                                       const uint32_t* __restrict__ sorted_tmp, SegGeometry geo,
+                                                       uint8_t* __restrict__ dirty) {
+  const RerankChunk c = chunks[blockIdx.x];
+  for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
+    const uint32_t p = by_key[i];
+    if (p < geo.first_block_start || !(flags[p] & kFlagSearched)) continue;
+    const uint2 a = info[p];
+    const uint32_t rb = rank_tmp[i];
+    const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(rb & 0xffffu, geo.block_size);
+    bool same = na == nb;
+    for (uint32_t j = 0; same && j < na; ++j) same = sorted[a.x - 1 - j] == sorted_tmp[c.key_lo + rb - 1 - j];
+    if (!same) mark_dirty(p, geo, dirty);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rerank_commit(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ by_key,
+                                                        const uint8_t* __restrict__ flags, uint32_t* __restrict__ sorted,
+                                                        uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp) {
+  const RerankChunk c = chunks[blockIdx.x];
+  for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
+    const uint32_t p = by_key[i];
+    const uint32_t rb = rank_tmp[i];
+    info[p] = make_uint2(c.key_lo + rb, rb);
+    if (flags[p] & 1u) sorted[c.key_lo + rb] = p;
+  }
+}
+
+void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RerankChunk* chunks_dev, uint32_t num_chunks,
+                      uint32_t* sums_dev, const SegGeometry& geo, uint8_t* dirty_dev) {
+  if (num_chunks == 0 || P.total_bytes == 0) return;
+  uint32_t* rank_tmp = (uint32_t*)B.sort_tmp;
+  uint32_t* sorted_tmp = rank_tmp + (((size_t)P.total_bytes + 63) & ~(size_t)63);
+  hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], sums_dev);
+  hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
+  hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
+                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev);
+  hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
+                     (uint2*)B.info[rbuf], rank_tmp);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -310,6 +476,10 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   a.T.dist_postfix_bits = P.dist_postfix_bits;
   a.T.num_direct_distance_codes = P.num_direct_distance_codes;
+  a.T.keys = B.keys;
+  a.T.changed_keys = B.changed_keys;
+  a.T.changed_count = B.changed_count;
+  a.T.changed_cap = kChangedCap;
   a.segments = segments;
   a.entries = entries;
   a.exits = exits;
@@ -361,14 +531,7 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ fl
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted_old[a.x - 1 - j] == sorted_new[b.x - 1 - j];
     if (same) continue;
-    const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
-    const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
-    const uint32_t off = p - bs;
-    uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
-    if (k >= geo.num_segments) k = geo.num_segments - 1;
-    dirty[k] = 1;
-    // a lazy probe just behind a segment boundary belongs to the previous chain
-    if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+    mark_dirty(p, geo, dirty);
   }
 }
 

@@ -23,7 +23,11 @@ void Lz77Stage::Release() {
     dev_free(B_.keys);
     dev_free(B_.by_key);
     dev_free(B_.sorted_keys);
-    dev_free(B_.rank);
+    dev_free(B_.fbits);
+    dev_free(B_.key_first);
+    dev_free(B_.key_last);
+    dev_free(B_.changed_keys);
+    dev_free(B_.changed_count);
     dev_free(B_.info[0]);
     dev_free(B_.info[1]);
     dev_free(B_.sorted[0]);
@@ -81,7 +85,11 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.keys = (uint16_t*)dev_alloc(M * 2 + 64);
   B_.by_key = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.sorted_keys = (uint16_t*)dev_alloc(M * 2 + 64);
-  B_.rank = (uint32_t*)dev_alloc(M * 4 + 64);
+  B_.fbits = (uint8_t*)dev_alloc(M + 64);
+  B_.key_first = (uint32_t*)dev_alloc((65536 + 1) * 4);
+  B_.key_last = (uint32_t*)dev_alloc((65536 + 1) * 4);
+  B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
+  B_.changed_count = (uint32_t*)dev_alloc(64);
   B_.info[0] = (uint32_t*)dev_alloc(M * 8 + 64);
   B_.info[1] = (uint32_t*)dev_alloc(M * 8 + 64);
   B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
@@ -479,6 +487,10 @@ void Lz77Stage::Run() {
   lz77_compute_keys(P_, B_);
   tm.stop(&stats_.ms_keys);
   lz77_sort_by_key(P_, B_);
+  key_first_.resize(65537);
+  key_last_.resize(65537);
+  dev_d2h(key_first_.data(), B_.key_first, 65537 * 4);
+  dev_d2h(key_last_.data(), B_.key_last, 65537 * 4);
   tm.stop(&stats_.ms_sort);
   InitFlags();
   tm.stop(&stats_.ms_init);
@@ -543,6 +555,7 @@ void Lz77Stage::Run() {
       dev_h2d(dirty_dev, dirty.data(), nseg);
     }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+    dev_memset(B_.changed_count, 0, 4);
     if (full_round) {
       lz77_parse_round(P_, B_, which, rbuf, 0);
     } else {
@@ -550,8 +563,6 @@ void Lz77Stage::Run() {
     }
     stats_.segments_parsed += count;
     dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
-    uint64_t flag_changes = 0;
-    for (uint32_t i = 0; i < count; ++i) flag_changes += exits_[list[i]].flag_changes;
     if (!full_round) {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
       dev_d2h(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
@@ -561,7 +572,6 @@ void Lz77Stage::Run() {
         if (a.pos != b.pos || a.apply != b.apply || memcmp(a.cache, b.cache, sizeof(a.cache)) != 0 ||
             a.dict_lookups != b.dict_lookups || a.dict_matches != b.dict_matches) {
           entries_[k] = a;
-          flag_changes += exits_[k].flag_changes;
           stats_.segments_parsed++;
         }
       }
@@ -572,18 +582,57 @@ void Lz77Stage::Run() {
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k];
     uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
     for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
-    if (flag_changes != 0) {
+    uint32_t n_changed = 0;
+    dev_d2h(&n_changed, B_.changed_count, 4);
+    if (n_changed != 0) {
       tm.stop(&stats_.ms_resolve);
-      lz77_rank_flags(P_, B_, which, rbuf ^ 1);
+      // few changes: re-rank only the keys concerned, in place; otherwise rebuild everything into the other buffer
+      // and diff the two
+      std::vector<uint32_t> changed;
+      bool incremental = false;
+      if (n_changed <= kChangedCap) {
+        changed.resize(n_changed);
+        dev_d2h(changed.data(), B_.changed_keys, (size_t)n_changed * 4);
+        std::sort(changed.begin(), changed.end());
+        changed.erase(std::unique(changed.begin(), changed.end()), changed.end());
+        uint64_t affected = 0;
+        uint32_t widest = 0;
+        for (uint32_t key : changed) {
+          const uint32_t width = key_last_[key] - key_first_[key];
+          affected += width;
+          widest = std::max(widest, width);
+        }
+        (void)widest;
+        incremental = affected <= (uint64_t)P_.total_bytes / 4;
+      }
       dev_memset(dirty_dev, 0, nseg);
-      lz77_validate(P_, B_, which, rbuf, rbuf ^ 1, geo, dirty_dev);
+      if (incremental) {
+        std::vector<RerankChunk> chunks;
+        for (uint32_t key : changed) {
+          const uint32_t lo = key_first_[key], hi = key_last_[key];
+          const uint32_t first_sum = (uint32_t)chunks.size();
+          for (uint32_t b = lo; b < hi; b += kRerankChunk)
+            chunks.push_back({lo, b, std::min(hi, b + kRerankChunk), first_sum, (uint32_t)chunks.size()});
+        }
+        RerankChunk* chunks_dev = (RerankChunk*)dev_alloc(chunks.size() * sizeof(RerankChunk) + 64);
+        uint32_t* sums_dev = (uint32_t*)dev_alloc(chunks.size() * 4 + 64);
+        dev_h2d(chunks_dev, chunks.data(), chunks.size() * sizeof(RerankChunk));
+        lz77_rerank_keys(P_, B_, which, rbuf, chunks_dev, (uint32_t)chunks.size(), sums_dev, geo, dirty_dev);
+        dev_free(chunks_dev);
+        dev_free(sums_dev);
+        stats_.incremental_ranks++;
+      } else {
+        lz77_rank_flags(P_, B_, which, rbuf ^ 1);
+        lz77_validate(P_, B_, which, rbuf, rbuf ^ 1, geo, dirty_dev);
+        rbuf ^= 1;
+        stats_.full_ranks++;
+      }
       std::vector<uint8_t> dv(nseg);
       dev_d2h(dv.data(), dirty_dev, nseg);
       for (uint32_t k = 0; k < nseg; ++k) {
         n_dirty_valid += dv[k];
         dirty[k] |= dv[k];
       }
-      rbuf ^= 1;
       tm.stop(&stats_.ms_rank);
     }
     // the static dictionary got switched off at segment dict_death_seg_ and many chains behind it ran in the
@@ -607,7 +656,7 @@ void Lz77Stage::Run() {
       }
     }
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u; dict death seg %u flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dict_death_seg_, dict_flips_);
-    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)flag_changes, count, nseg, n_dirty_entry, n_dirty_valid);
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid);
     if (count == 0) {
       done = true;
       break;
@@ -650,25 +699,30 @@ void Lz77Stage::SelfTestSort() {
 void Lz77Stage::SelfTestRank(int which, int rbuf) {
   const uint32_t n = P_.total_bytes;
   std::vector<uint16_t> skeys(n);
-  std::vector<uint32_t> by_key(n), rank(n), sorted(n), key_base(65537);
+  std::vector<uint32_t> by_key(n), sorted(n), info((size_t)n * 2);
   std::vector<uint8_t> flags(n);
   dev_sync();
   dev_d2h(skeys.data(), B_.sorted_keys, (size_t)n * 2);
   dev_d2h(by_key.data(), B_.by_key, (size_t)n * 4);
-  dev_d2h(rank.data(), B_.rank, (size_t)n * 4);
   dev_d2h(sorted.data(), B_.sorted[rbuf], (size_t)n * 4);
-  dev_d2h(key_base.data(), B_.key_base, 65537 * 4);
+  dev_d2h(info.data(), B_.info[rbuf], (size_t)n * 8);
   dev_d2h(flags.data(), B_.flags[which], n);
-  uint32_t g = 0;
+  uint32_t first = 0, local = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t p = by_key[i];
-    if (rank[p] != g) throw std::runtime_error("selftest: rank mismatch at slot " + std::to_string(i));
     if (i == 0 || skeys[i - 1] != skeys[i]) {
-      if (key_base[skeys[i]] != g) throw std::runtime_error("selftest: key_base mismatch for key " + std::to_string(skeys[i]));
+      first = i;
+      local = 0;
+      if (key_first_[skeys[i]] != i) throw std::runtime_error("selftest: key_first mismatch for key " + std::to_string(skeys[i]));
     }
+    if (i + 1 == n || skeys[i + 1] != skeys[i]) {
+      if (key_last_[skeys[i]] != i + 1) throw std::runtime_error("selftest: key_last mismatch for key " + std::to_string(skeys[i]));
+    }
+    if (info[2 * (size_t)p] != first + local || info[2 * (size_t)p + 1] != local)
+      throw std::runtime_error("selftest: info mismatch at slot " + std::to_string(i));
     if (flags[p] & 1) {
-      if (sorted[g] != p) throw std::runtime_error("selftest: sorted mismatch at rank " + std::to_string(g));
-      g++;
+      if (sorted[first + local] != p) throw std::runtime_error("selftest: sorted mismatch at slot " + std::to_string(i));
+      local++;
     }
   }
 }

@@ -35,6 +35,7 @@ struct Lz77Stats {
   uint64_t segments_parsed = 0;
   uint64_t searches = 0;
   uint64_t total_commands = 0;
+  uint32_t incremental_ranks = 0, full_ranks = 0;
   // wall-clock milliseconds per phase (device synchronised), filled when profiling is enabled
   double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
@@ -84,6 +85,7 @@ class Lz77Stage {
   uint32_t warmup_bytes_ = 768;
   uint32_t block_bytes_ = 65536;
   std::vector<Segment> segments_;
+  std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
   std::vector<SegEntry> entries_;   // entries used by the most recent parse
   std::vector<SegEntry> next_entries_;
   std::vector<SegExit> exits_;

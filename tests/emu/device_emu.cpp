@@ -89,21 +89,71 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
     B.by_key[i] = idx[i];
     B.sorted_keys[i] = B.keys[idx[i]];
   }
+  memset(B.key_first, 0, 65537 * 4);
+  memset(B.key_last, 0, 65537 * 4);
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint16_t k = B.sorted_keys[i];
+    if (i == 0 || B.sorted_keys[i - 1] != k) B.key_first[k] = i;
+    if (i + 1 == n || B.sorted_keys[i + 1] != k) B.key_last[k] = i + 1;
+  }
 }
 
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf) {
   const uint32_t n = P.total_bytes;
-  uint32_t g = 0;
+  uint32_t first = 0, local = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t pos = B.by_key[i];
-    const uint16_t k = B.sorted_keys[i];
-    B.rank[pos] = g;
-    if (i == 0 || B.sorted_keys[i - 1] != k) B.key_base[k] = g;
-    if (B.flags[which][pos] & 1) B.sorted[rbuf][g++] = pos;
+    if (i == 0 || B.sorted_keys[i - 1] != B.sorted_keys[i]) {
+      first = i;
+      local = 0;
+    }
+    B.info[rbuf][2 * (size_t)pos] = first + local;
+    B.info[rbuf][2 * (size_t)pos + 1] = local;
+    if (B.flags[which][pos] & 1) B.sorted[rbuf][first + local++] = pos;
   }
-  for (uint32_t p = 0; p < n; ++p) {
-    B.info[rbuf][2 * (size_t)p] = B.rank[p];
-    B.info[rbuf][2 * (size_t)p + 1] = B.rank[p] - B.key_base[B.keys[p]];
+}
+
+static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
+  const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
+  const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
+  const uint32_t off = p - bs;
+  uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
+  if (k >= geo.num_segments) k = geo.num_segments - 1;
+  dirty[k] = 1;
+  if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+}
+
+void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RerankChunk* chunks, uint32_t num_chunks,
+                      uint32_t* sums, const SegGeometry& geo, uint8_t* dirty) {
+  (void)P;
+  (void)sums;
+  const uint8_t* flags = B.flags[which];
+  for (uint32_t e = 0; e < num_chunks; ++e) {
+    if (chunks[e].first_sum != chunks[e].my_sum) continue;  // one pass per key, at its first chunk
+    const uint32_t lo = chunks[e].key_lo;
+    uint32_t hi = chunks[e].end;
+    for (uint32_t f = e + 1; f < num_chunks && chunks[f].first_sum == chunks[e].first_sum; ++f) hi = chunks[f].end;
+    std::vector<uint32_t> new_sorted, new_rank(hi - lo);
+    for (uint32_t i = lo; i < hi; ++i) {
+      new_rank[i - lo] = (uint32_t)new_sorted.size();
+      if (flags[B.by_key[i]] & 1) new_sorted.push_back(B.by_key[i]);
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t p = B.by_key[i];
+      if (p < geo.first_block_start || !(flags[p] & kFlagSearched)) continue;
+      const uint32_t ax = B.info[rbuf][2 * (size_t)p], ay = B.info[rbuf][2 * (size_t)p + 1];
+      const uint32_t rb = new_rank[i - lo];
+      const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(rb & 0xffffu, geo.block_size);
+      bool same = na == nb;
+      for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf][ax - 1 - j] == new_sorted[rb - 1 - j];
+      if (!same) emu_mark_dirty(p, geo, dirty);
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t p = B.by_key[i];
+      B.info[rbuf][2 * (size_t)p] = lo + new_rank[i - lo];
+      B.info[rbuf][2 * (size_t)p + 1] = new_rank[i - lo];
+    }
+    for (size_t j = 0; j < new_sorted.size(); ++j) B.sorted[rbuf][lo + j] = new_sorted[j];
   }
 }
 
@@ -123,6 +173,10 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
+  T.keys = B.keys;
+  T.changed_keys = B.changed_keys;
+  T.changed_count = B.changed_count;
+  T.changed_cap = kChangedCap;
   ChainScratch scratch;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
