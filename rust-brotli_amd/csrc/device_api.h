@@ -81,6 +81,9 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int 
 // it changes (br_parse_chain) and rewrites B.entries for them
 void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, const uint8_t* sched_dev,
                      uint32_t count);
+// lists the keys of the positions whose stored flag differs between flags[prev] and flags[next] in B.changed_keys /
+// B.changed_count (the count may exceed kChangedCap; only the first kChangedCap entries are kept)
+void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next);
 // marks (dirty[k] = 1) the segments that searched a position whose candidate list differs between the rank
 // structures rbuf_old and rbuf_new
 struct SegGeometry {
@@ -108,7 +111,7 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments)
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]
-void lz77_gather_commands(const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
+void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out);
 
 // applies extend_last_command / trailing insert-only fix-ups to the gathered commands

@@ -137,7 +137,8 @@ const DeviceTables& dev_tables() {
   if (h.device == dev) return h.t;
   auto upload = [](const void* src, size_t bytes) -> void* {
     void* p = nullptr;
-    HIP_CHECK(hipMalloc(&p, bytes));
+    HIP_CHECK(hipMalloc(&p, bytes + 64));  // padded: the match-length code reads 32 bytes at a time
+    HIP_CHECK(hipMemset(p, 0, bytes + 64));
     HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     return p;
   };

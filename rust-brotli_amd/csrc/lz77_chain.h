@@ -30,6 +30,8 @@
 #define BR_NLANES 1
 #define BR_SYNC() ((void)0)
 #define BR_ATOMIC_INC(ptr) ((*(ptr))++)
+#define BR_UNIFORM(x) (x)
+#define BR_READLANE(x, lane) (x)
 #else
 #include <hip/hip_runtime.h>
 #define BR_DEV __device__ __forceinline__
@@ -37,6 +39,11 @@
 #define BR_NLANES 64
 #define BR_SYNC() __syncthreads()
 #define BR_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
+// The control flow of a chain is wave-uniform by construction, but values that come back from vector loads or
+// cross-lane operations live in VGPRs and would make the compiler predicate every branch with exec masks.
+// BR_UNIFORM moves such a value into an SGPR (all lanes hold the same value); BR_READLANE picks one lane's value.
+#define BR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define BR_READLANE(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))
 #endif
 
 namespace brotli_mi355x {
@@ -51,7 +58,6 @@ struct ChainTables {
   const uint32_t* info;        // per position: {rank among the stored positions in (key,pos) order,
                                //                number of stored positions of the same key before it}
   const uint32_t* sorted;      // stored positions in (key,pos) order
-  const uint8_t* flags_prev;   // stored flags used to build rank/sorted (previous round)
   uint8_t* flags_next;         // stored flags produced by this round
   Command* cmds;
   const uint16_t* dict_hash;   // kStaticDictionaryHash (src/enc/dictionary_hash.rs)
@@ -60,17 +66,15 @@ struct ChainTables {
   const uint8_t* dict_size_bits_by_length;
   uint32_t dist_postfix_bits;
   uint32_t num_direct_distance_codes;
-  // log of the keys whose stored flags changed in this round (for the incremental re-rank)
-  const uint16_t* keys;
-  uint32_t* changed_keys;   // [changed_cap]
-  uint32_t* changed_count;  // may run past changed_cap: the host then falls back to a full re-rank
-  uint32_t changed_cap;
 };
 
+static constexpr uint32_t kInfoWindow = 64;
+
 struct ChainScratch {  // one per wavefront (LDS on the device)
+  uint32_t win[kInfoWindow][2];  // rank records (info) of positions [win_base, win_base + kInfoWindow)
+  int32_t dc[16];                // distance cache incl. the derived entries (mod.rs:632-651); lanes index it by candidate
   uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
   uint32_t cand_len[2][kMaxCandidates + 2];
-  uint32_t flag_changes[64];
 };
 
 struct SearchResult {
@@ -151,13 +155,12 @@ BR_DEV uint16_t br_combine_length_codes(uint32_t inscode, uint32_t copycode, boo
   return (uint16_t)((uint32_t)offset | bits64);
 }
 // Command::init, command.rs:273-297 with PrefixEncodeCopyDistance :134-173
-BR_DEV Command br_make_command(const ChainTables& t, uint32_t insertlen, uint32_t copylen, uint32_t copylen_code,
+BR_DEV Command br_make_command(uint32_t ndirect, uint32_t npostfix, uint32_t insertlen, uint32_t copylen, uint32_t copylen_code,
                                uint32_t distance_code) {
   Command c;
   c.insert_len_ = insertlen;
   int32_t delta = (int32_t)copylen_code - (int32_t)copylen;
   c.copy_len_ = copylen | ((uint32_t)(uint8_t)(int8_t)delta << 25);
-  const uint32_t ndirect = t.num_direct_distance_codes, npostfix = t.dist_postfix_bits;
   if (distance_code < 16 + ndirect) {
     c.dist_prefix_ = (uint16_t)distance_code;
     c.dist_extra_ = 0;
@@ -175,6 +178,25 @@ BR_DEV Command br_make_command(const ChainTables& t, uint32_t insertlen, uint32_
   c.cmd_prefix_ = br_combine_length_codes(br_insert_length_code(insertlen), br_copy_length_code(copylen_code),
                                           (c.dist_prefix_ & 0x3ff) == 0);
   return c;
+}
+
+// The chains only record what a command is made of; the prefix codes are computed when the per-segment slabs are
+// gathered (one thread per command instead of one lane of a whole wavefront).
+BR_DEV Command br_raw_command(uint32_t insertlen, uint32_t copylen, uint32_t copylen_code, uint32_t distance_code) {
+  Command c;
+  c.insert_len_ = insertlen;
+  const int32_t delta = (int32_t)copylen_code - (int32_t)copylen;
+  c.copy_len_ = copylen | ((uint32_t)(uint8_t)(int8_t)delta << 25);
+  c.dist_extra_ = distance_code;
+  c.cmd_prefix_ = 0;
+  c.dist_prefix_ = 0;
+  return c;
+}
+BR_DEV Command br_finish_command(const Command& raw, uint32_t ndirect, uint32_t npostfix) {
+  const uint32_t copylen = raw.copy_len_ & 0x01ffffffu;
+  const uint32_t m = raw.copy_len_ >> 25;
+  const int32_t delta = (int32_t)(int8_t)(uint8_t)(m | ((m & 0x40) << 1));
+  return br_make_command(ndirect, npostfix, raw.insert_len_, copylen, (uint32_t)((int32_t)copylen + delta), raw.dist_extra_);
 }
 
 // fix-ups applied after the parse reached its fixed point
@@ -233,17 +255,59 @@ struct ProbeMeta {
   uint32_t pos;       // p0; 0xffffffff = nothing probed
   uint32_t version;   // dist-cache version the probe was computed with
   uint32_t g[2], nbucket[2];
+  uint32_t win_base;  // first position of the rank-record window held in ChainScratch::win
+#if defined(BR_CHAIN_PROFILE)
+  unsigned long long t_probe, t_fold, n_probe, n_fold;
+#endif
 };
+#if defined(BR_CHAIN_PROFILE)
+#define BR_TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
+extern __device__ unsigned long long g_chain_prof[8];
+#endif
+
+#if defined(BROTLI_HOST_EMU)
+BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit) { return br_match_len(a, b, limit); }
+#else
+// Common prefix of a and b, at most `limit`: the first 32 bytes of both sides are fetched in one go (four independent
+// 16-byte loads, one memory round trip; both buffers are padded so reading past `limit` is harmless), only longer
+// matches fall back to the 8-byte loop.
+BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2), aligned(1)));
+  const u64x2 a0 = *(const u64x2*)a, a1 = *(const u64x2*)(a + 16);
+  const u64x2 b0 = *(const u64x2*)b, b1 = *(const u64x2*)(b + 16);
+  const unsigned long long x0 = a0.x ^ b0.x, x1 = a0.y ^ b0.y, x2 = a1.x ^ b1.x, x3 = a1.y ^ b1.y;
+  uint32_t n;
+  if (x0 != 0) n = (uint32_t)(__builtin_ctzll(x0) >> 3);
+  else if (x1 != 0) n = 8 + (uint32_t)(__builtin_ctzll(x1) >> 3);
+  else if (x2 != 0) n = 16 + (uint32_t)(__builtin_ctzll(x2) >> 3);
+  else if (x3 != 0) n = 24 + (uint32_t)(__builtin_ctzll(x3) >> 3);
+  else n = 32;
+  if (n >= 32 && limit > 32) n = 32 + br_match_len(a + 32, b + 32, limit - 32);
+  return n < limit ? n : limit;
+}
+#endif
 
 BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratch& s, ProbeMeta& m, uint32_t p0,
                           const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
   const uint32_t ndist = P.ndist;
   const uint32_t block_size = 1u << P.block_bits;
   const uint32_t ndict = P.use_dictionary ? 2u : 0u;
+  // rank records of the positions around p0: one coalesced load serves the next ~60 positions
+  if (p0 < m.win_base || p0 + 1 >= m.win_base + kInfoWindow) {
+    BR_SYNC();
+    for (uint32_t i = BR_LANE; i < kInfoWindow; i += BR_NLANES) {
+      const uint32_t q = p0 + i;
+      const bool ok = q < P.total_bytes;
+      s.win[i][0] = ok ? t.info[2 * (size_t)q] : 0u;
+      s.win[i][1] = ok ? t.info[2 * (size_t)q + 1] : 0u;
+    }
+    m.win_base = p0;
+    BR_SYNC();
+  }
   uint32_t n[2];
   for (int w = 0; w < 2; ++w) {
-    const uint32_t g = t.info[2 * (size_t)(p0 + w)];
-    const uint32_t num_copy = t.info[2 * (size_t)(p0 + w) + 1] & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
+    const uint32_t g = s.win[p0 + w - m.win_base][0];
+    const uint32_t num_copy = s.win[p0 + w - m.win_base][1] & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
     m.g[w] = g;
     m.nbucket[w] = num_copy < block_size ? num_copy : block_size;
     n[w] = ndist + m.nbucket[w] + ndict;
@@ -258,28 +322,37 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     const uint32_t max_length = pos_end - cur;
     const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
     const uint8_t* cur_data = t.text + cur;
-    uint32_t prev = 0xffffffffu, len = 0;
-    if (c < ndist + m.nbucket[w]) {
-      if (c < ndist) {
-        const int64_t b = (int64_t)cache[c];
-        if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
-      } else {
-        const uint32_t q = t.sorted[m.g[w] - 1 - (c - ndist)];
-        if (cur - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
-      }
-      if (prev != 0xffffffffu) len = br_match_len(t.text + prev, cur_data, max_length);
+    const bool is_cache = c < ndist;
+    const bool is_bucket = !is_cache && c < ndist + m.nbucket[w];
+    const bool is_dict = !is_cache && !is_bucket;
+    // step 1 (one memory round trip for every kind of candidate): where does the candidate live?
+    uint32_t q = 0, item = 0;
+    if (is_bucket) q = t.sorted[m.g[w] - 1 - (c - ndist)];
+    if (is_dict) {
+      // static dictionary probe i (SearchInStaticDictionary, mod.rs:1942-1988)
+      const uint32_t key = (((br_load32(cur_data) * 0x1e35a7bdu) >> (32 - 14)) << 1) + (c - ndist - m.nbucket[w]);
+      item = t.dict_hash[key];
+    }
+    uint32_t prev = 0xffffffffu, limit = max_length;
+    const uint8_t* src = nullptr;
+    if (is_cache) {
+      const int64_t b = (int64_t)cache[c];
+      if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+    } else if (is_bucket) {
+      if (cur - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
     } else {
-      // static dictionary probe i (SearchInStaticDictionary, mod.rs:1942-1988): item and matched prefix
-      const uint32_t i = c - ndist - m.nbucket[w];
-      const uint32_t key = (((br_load32(cur_data) * 0x1e35a7bdu) >> (32 - 14)) << 1) + i;
-      const uint32_t item = t.dict_hash[key];
       prev = item;
       if (item != 0) {
         const uint32_t wlen = item & 0x1f;
-        const uint32_t offset = t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
-        len = wlen > max_length ? 0u : br_match_len(cur_data, t.dict_data + offset, wlen);
+        if (wlen <= max_length) {
+          src = t.dict_data + t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
+          limit = wlen;
+        }
       }
     }
+    if (!is_dict && prev != 0xffffffffu) src = t.text + prev;
+    // step 2 (second round trip): measure the common prefix
+    const uint32_t len = src ? br_match_len_wide(src, cur_data, limit) : 0u;
     s.cand_prev[w][c] = prev;
     s.cand_len[w][c] = len;
   }
@@ -405,10 +478,10 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
       const unsigned long long m = __ballot(pass);
       if (m == 0) break;
       const int f = __ffsll((long long)m) - 1;
-      best_len = __shfl(len, f, 64);
-      best_score = __shfl(score, f, 64);
+      best_len = BR_READLANE(len, f);
+      best_score = BR_READLANE(score, f);
       out.len = best_len;
-      out.distance = __shfl(backward, f, 64);
+      out.distance = BR_READLANE(backward, f);
       out.score = best_score;
       out.found = true;
       start_lane = f + 1;
@@ -424,8 +497,8 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
       const int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
       if (def > ds.maxdef) ds.maxdef = def;
       for (uint32_t i = 0; i < 2; ++i) {
-        const uint32_t item = s.cand_prev[w][ncand + i];
-        const uint32_t matchlen = s.cand_len[w][ncand + i];
+        const uint32_t item = BR_UNIFORM(s.cand_prev[w][ncand + i]);
+        const uint32_t matchlen = BR_UNIFORM(s.cand_len[w][ncand + i]);
         ds.lookups++;
         if (item == 0) continue;
         const uint32_t len = item & 0x1f;
@@ -434,7 +507,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
         if (matchlen + 10 <= len || matchlen == 0) continue;
         const uint32_t cut = len - matchlen;
         const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
-        const uint32_t backward = max_backward + dist + 1 + (transform_id << t.dict_size_bits_by_length[len]);
+        const uint32_t backward = max_backward + dist + 1 + (transform_id << BR_UNIFORM(t.dict_size_bits_by_length[len]));
         if (backward > P.dist_max_distance) continue;
         const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
         if (score < out.score) continue;
@@ -453,10 +526,32 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
 // search(x) for the parse loop: reuses the speculative second slot when it is still valid
 BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratch& s, ProbeMeta& m, DictState& ds,
                               uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end) {
-  if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) return br_fold_probe(P, t, s, m, 1, ds, blk_end);
-  BR_SYNC();  // every lane is done reading the previous probe
+#if defined(BR_CHAIN_PROFILE)
+  unsigned long long t0 = BR_TICK();
+  if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) {
+    SearchResult r = br_fold_probe(P, t, s, m, 1, ds, blk_end);
+    m.t_fold += BR_TICK() - t0;
+    m.n_fold++;
+    return r;
+  }
+  BR_SYNC();
   br_probe_pair(P, t, s, m, x, cache, cache_version, blk_end);
-  return br_fold_probe(P, t, s, m, 0, ds, blk_end);
+  unsigned long long t1 = BR_TICK();
+  m.t_probe += t1 - t0;
+  m.n_probe++;
+  SearchResult r = br_fold_probe(P, t, s, m, 0, ds, blk_end);
+  m.t_fold += BR_TICK() - t1;
+  m.n_fold++;
+  return r;
+#else
+  uint32_t w = 1;
+  if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
+    BR_SYNC();  // every lane is done reading the previous probe
+    br_probe_pair(P, t, s, m, x, cache, cache_version, blk_end);
+    w = 0;
+  }
+  return br_fold_probe(P, t, s, m, w, ds, blk_end);
+#endif
 }
 
 // adv_prepare_distance_cache, mod.rs:632-651
@@ -482,21 +577,11 @@ BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
 }
 
 struct FlagWriter {
-  const uint8_t* prev;
   uint8_t* next;
-  const ChainTables* t;
   bool enabled;
-  uint32_t changes;  // per lane
   uint32_t tail_lo;  // positions >= tail_lo inside the block get the stitch flag
   uint8_t tail_value;
-  BR_DEV void put(uint32_t q, uint8_t v) {
-    if ((prev[q] ^ v) & 1) {
-      changes++;
-      const uint32_t idx = BR_ATOMIC_INC(t->changed_count);
-      if (idx < t->changed_cap) t->changed_keys[idx] = t->keys[q];
-    }
-    next[q] = v;
-  }
+  BR_DEV void put(uint32_t q, uint8_t v) { next[q] = v; }
   BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
     if (BR_LANE == 0 && enabled) put(q, v);
   }
@@ -504,36 +589,39 @@ struct FlagWriter {
   // [a, b) := v for q < split, static "not stored by the main loop" value for q >= split
   BR_DEV void range(uint32_t a, uint32_t b, uint32_t split) {
     if (!enabled) return;
-    for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) {
-      const uint8_t v = q < split ? (uint8_t)1 : unstored(q);
-      put(q, v);
-    }
+    for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) put(q, q < split ? (uint8_t)1 : unstored(q));
   }
 };
 
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
-BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment& seg,
+BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment& seg_in,
                              const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
-  const uint32_t pos_end = seg.blk_end;
+  const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
+  Segment seg;
+  seg.start = BR_UNIFORM(seg_in.start);
+  seg.end = BR_UNIFORM(seg_in.end);
+  seg.blk_start = BR_UNIFORM(seg_in.blk_start);
+  seg.blk_end = pos_end;
+  seg.flags = BR_UNIFORM(seg_in.flags);
+  seg.cmd_base = BR_UNIFORM(seg_in.cmd_base);
+  seg.block_index = 0;
+  seg.pad = 0;
   const uint32_t htl = P.htl;
   const uint32_t window = P.spree_window;
-  uint32_t position = entry.pos;
-  uint32_t apply = entry.apply;
+  uint32_t position = BR_UNIFORM(entry.pos);
+  uint32_t apply = BR_UNIFORM(entry.apply);
   uint32_t insert_length = 0;  // literals carried in are added by the host fix-up (CmdPatch kind 2)
-  int32_t dc[16];
-  for (int i = 0; i < 4; ++i) dc[i] = entry.cache[i];
+  int32_t* dc = s.dc;
+  for (int i = 0; i < 4; ++i) dc[i] = (int32_t)BR_UNIFORM(entry.cache[i]);
   for (int i = 4; i < 16; ++i) dc[i] = 0;
   DictState ds;
-  ds.lookups = ds.lookups0 = entry.dict_lookups;
-  ds.matches = ds.matches0 = entry.dict_matches;
+  ds.lookups = ds.lookups0 = BR_UNIFORM(entry.dict_lookups);
+  ds.matches = ds.matches0 = BR_UNIFORM(entry.dict_matches);
   ds.mode = 0;
   ds.maxdef = -(1 << 30);
   FlagWriter fw;
-  fw.prev = t.flags_prev;
   fw.next = t.flags_next;
-  fw.t = &t;
-  fw.changes = 0;
   fw.enabled = !(seg.flags & kSegWarmup);
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
@@ -543,6 +631,11 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   ProbeMeta probe;
   probe.pos = 0xffffffffu;
   probe.version = 0;
+  probe.win_base = 0xffffff00u;
+#if defined(BR_CHAIN_PROFILE)
+  probe.t_probe = probe.t_fold = probe.n_probe = probe.n_fold = 0;
+  const unsigned long long t_begin = BR_TICK();
+#endif
   Command* cmds = t.cmds + (size_t)seg.cmd_base;
 
   if (seg.flags & kSegFirstInBlock) {
@@ -605,7 +698,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
         cache_version++;
         br_prepare_distance_cache(dc, P.ndist);
       }
-      if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride && fw.enabled) cmds[n_cmds] = br_make_command(t, insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
+      if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride && fw.enabled) cmds[n_cmds] = br_raw_command(insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
       n_cmds++;
       n_lits += insert_length;
       insert_length = 0;
@@ -651,12 +744,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     insert_length += pos_end - position;
     position = pos_end;
   }
-  // reduce the per-lane change counters
-  s.flag_changes[BR_LANE] = fw.changes;
-  BR_SYNC();
   if (BR_LANE == 0) {
-    uint32_t total = 0;
-    for (int i = 0; i < BR_NLANES; ++i) total += s.flag_changes[i];
     exit_out.pos = position;
     exit_out.apply = apply;
     for (int i = 0; i < 4; ++i) exit_out.cache[i] = dc[i];
@@ -667,7 +755,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     exit_out.dict_lookups = ds.lookups;
     exit_out.dict_matches = ds.matches;
     exit_out.last_dist_code = last_dist_code;
-    exit_out.flag_changes = total;
+    exit_out.flag_changes = 0;
     exit_out.n_searches = n_searches;
     exit_out.last_copy_len = last_copy_len;
     exit_out.dict_mode = ds.mode;
@@ -675,6 +763,17 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     exit_out.n_pushes = n_pushes;
     exit_out.pad1 = 0;
   }
+#if defined(BR_CHAIN_PROFILE)
+  if (BR_LANE == 0) {
+    atomicAdd(&g_chain_prof[0], BR_TICK() - t_begin);
+    atomicAdd(&g_chain_prof[1], probe.t_probe);
+    atomicAdd(&g_chain_prof[2], probe.t_fold);
+    atomicAdd(&g_chain_prof[3], probe.n_probe);
+    atomicAdd(&g_chain_prof[4], probe.n_fold);
+    atomicAdd(&g_chain_prof[5], 1ull);
+    atomicAdd(&g_chain_prof[6], (unsigned long long)n_cmds);
+  }
+#endif
   next.pos = position;
   next.apply = apply;
   for (int i = 0; i < 4; ++i) next.cache[i] = dc[i];

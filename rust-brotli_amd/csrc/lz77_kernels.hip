@@ -440,6 +440,7 @@ struct ParseArgs {
   const uint32_t* list;  // optional explicit segment indices
   const uint8_t* sched;  // list rounds: per segment, 1 if it is in the list (see br_parse_chain)
   uint32_t count;
+  uint32_t per_xcd;      // 0: identity mapping
 };
 
 struct ParseTiming {
@@ -453,8 +454,12 @@ static ParseTiming& parse_timing() {
 
 __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratch scratch;
-  if (blockIdx.x >= a.count) return;
-  const uint32_t k = a.list ? a.list[blockIdx.x] : a.first_segment + blockIdx.x;
+  // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
+  // window and the rank rows its chains touch stay in that XCD's L2
+  uint32_t item = blockIdx.x;
+  if (a.per_xcd) item = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+  if (item >= a.count) return;
+  const uint32_t k = a.list ? a.list[item] : a.first_segment + item;
   br_parse_chain(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched);
 }
 
@@ -467,7 +472,6 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.text = B.text;
   a.T.info = B.info[rbuf];
   a.T.sorted = B.sorted[rbuf];
-  a.T.flags_prev = B.flags[flags_in];
   a.T.flags_next = B.flags[flags_out];
   a.T.cmds = B.cmds;
   a.T.dict_hash = dt.dict_hash;
@@ -476,10 +480,6 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   a.T.dist_postfix_bits = P.dist_postfix_bits;
   a.T.num_direct_distance_codes = P.num_direct_distance_codes;
-  a.T.keys = B.keys;
-  a.T.changed_keys = B.changed_keys;
-  a.T.changed_count = B.changed_count;
-  a.T.changed_cap = kChangedCap;
   a.segments = segments;
   a.entries = entries;
   a.exits = exits;
@@ -493,7 +493,10 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
   HIP_CHECK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_parse_segments, dim3(count), dim3(64), 0, 0, a);
+  static const bool xcd_aware = getenv("BROTLI_MI355X_NO_XCD_MAP") == nullptr;
+  a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
+  const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
+  hipLaunchKernelGGL(k_parse_segments, dim3(grid), dim3(64), 0, 0, a);
   HIP_CHECK(hipEventRecord(e1, 0));
   HIP_CHECK(hipGetLastError());
   pt.events.push_back(std::make_pair(e0, e1));
@@ -515,6 +518,38 @@ void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int
                        SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
   if (count == 0) return;
   launch_parse(P, B, which, which ^ 1, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, nullptr, count);
+}
+
+// ------------------------------------------------------------------------------------------ flag diff
+// After a parse launch: which keys had a stored flag change?  (The chains only write flags; comparing the two
+// flag arrays in one streaming pass is far cheaper than having every chain read the old flag of each position.)
+__global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next, uint32_t n,
+                                                     const uint16_t* __restrict__ keys, uint32_t* __restrict__ changed_keys,
+                                                     uint32_t* __restrict__ changed_count, uint32_t cap) {
+  const uint32_t words = (n + 15) / 16;  // both arrays are padded by 64 bytes
+  for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < words; wi += gridDim.x * blockDim.x) {
+    const uint4 a = ((const uint4*)prev)[wi], b = ((const uint4*)next)[wi];
+    const uint32_t d[4] = {(a.x ^ b.x) & 0x01010101u, (a.y ^ b.y) & 0x01010101u, (a.z ^ b.z) & 0x01010101u, (a.w ^ b.w) & 0x01010101u};
+    if ((d[0] | d[1] | d[2] | d[3]) == 0) continue;
+    for (uint32_t j = 0; j < 16; ++j) {
+      const uint32_t q = wi * 16 + j;
+      if (q < n && ((d[j >> 2] >> (8 * (j & 3))) & 1u)) {
+        const uint32_t idx = atomicAdd(changed_count, 1u);
+        if (idx < cap) changed_keys[idx] = keys[q];
+      }
+    }
+  }
+}
+
+void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
+  const uint32_t n = P.total_bytes;
+  HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, 0));
+  if (n == 0) return;
+  uint32_t blocks = ((n + 15) / 16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_diff_flags, dim3(blocks), dim3(256), 0, 0, B.flags[prev], B.flags[next], n, B.keys, B.changed_keys, B.changed_count,
+                     kChangedCap);
+  HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------ validate
@@ -546,7 +581,21 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
   HIP_CHECK(hipGetLastError());
 }
 
+#if defined(BR_CHAIN_PROFILE)
+__device__ unsigned long long g_chain_prof[8];
+#endif
+
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {
+#if defined(BR_CHAIN_PROFILE)
+  {
+    unsigned long long h[8];
+    HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_prof), sizeof(h)));
+    fprintf(stderr, "chain profile: segments %llu total ticks %llu probe %llu (%llu calls) fold %llu (%llu calls) cmds %llu\n", h[5], h[0], h[1], h[3],
+            h[2], h[4], h[6]);
+    unsigned long long z[8] = {0};
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_prof), z, sizeof(z)));
+  }
+#endif
   ParseTiming& pt = parse_timing();
   double ms = 0;
   for (auto& ev : pt.events) {
@@ -586,19 +635,22 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
   HIP_CHECK(hipGetLastError());
 }
 
+// compacts the per-segment slabs and turns the raw records of the chains into Commands (Command::init, command.rs:273-297)
 __global__ __launch_bounds__(256) void k_gather_commands(const Command* __restrict__ slabs, uint32_t stride, const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ counts, Command* __restrict__ out) {
+                                                          const uint32_t* __restrict__ counts, Command* __restrict__ out, uint32_t ndirect,
+                                                          uint32_t npostfix) {
   const uint32_t k = blockIdx.x;
   const uint32_t n = counts[k];
-  const uint4* src = (const uint4*)(slabs + (size_t)k * stride);
-  uint4* dst = (uint4*)(out + offsets[k]);
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+  const Command* src = slabs + (size_t)k * stride;
+  Command* dst = out + offsets[k];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = br_finish_command(src[i], ndirect, npostfix);
 }
 
-void lz77_gather_commands(const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
+void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out) {
   if (num_segments == 0) return;
-  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, 0, B.cmds, stride, offsets_dev, counts_dev, out);
+  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, 0, B.cmds, stride, offsets_dev, counts_dev, out,
+                     P.num_direct_distance_codes, P.dist_postfix_bits);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -555,13 +555,13 @@ void Lz77Stage::Run() {
       dev_h2d(dirty_dev, dirty.data(), nseg);
     }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
-    dev_memset(B_.changed_count, 0, 4);
     if (full_round) {
       lz77_parse_round(P_, B_, which, rbuf, 0);
     } else {
       lz77_parse_list(P_, B_, which, rbuf, list_dev, dirty_dev, count);
     }
     stats_.segments_parsed += count;
+    lz77_diff_flags(P_, B_, which, which ^ 1);
     dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
     if (!full_round) {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
@@ -776,7 +776,7 @@ void Lz77Stage::Gather() {
   }
   dev_h2d(gather_offsets_dev_, offsets.data(), nseg * 4);
   dev_h2d(gather_counts_dev_, counts.data(), nseg * 4);
-  lz77_gather_commands(B_, nseg, P_.cmd_slab_stride, gather_offsets_dev_, gather_counts_dev_, gathered_cmds_);
+  lz77_gather_commands(P_, B_, nseg, P_.cmd_slab_stride, gather_offsets_dev_, gather_counts_dev_, gathered_cmds_);
   if (!fix.empty()) {
     CmdPatch* fix_dev = (CmdPatch*)dev_alloc(fix.size() * sizeof(CmdPatch));
     dev_h2d(fix_dev, fix.data(), fix.size() * sizeof(CmdPatch));

@@ -164,7 +164,6 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.text = B.text;
   T.info = B.info[rbuf];
   T.sorted = B.sorted[rbuf];
-  T.flags_prev = B.flags[which];
   T.flags_next = B.flags[which ^ 1];
   T.cmds = B.cmds;
   T.dict_hash = dt.dict_hash;
@@ -173,10 +172,6 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
-  T.keys = B.keys;
-  T.changed_keys = B.changed_keys;
-  T.changed_count = B.changed_count;
-  T.changed_cap = kChangedCap;
   ChainScratch scratch;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
@@ -233,10 +228,22 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
   for (uint32_t i = 0; i < samples; ++i) histo[text[start + i * 13u]]++;
 }
 
-void lz77_gather_commands(const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets,
+void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets,
                           const uint32_t* counts, Command* out) {
   for (uint32_t k = 0; k < num_segments; ++k)
-    memcpy(out + offsets[k], B.cmds + (size_t)k * stride, (size_t)counts[k] * sizeof(Command));
+    for (uint32_t i = 0; i < counts[k]; ++i)
+      out[offsets[k] + i] = br_finish_command(B.cmds[(size_t)k * stride + i], P.num_direct_distance_codes, P.dist_postfix_bits);
+}
+
+void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
+  uint32_t count = 0;
+  for (uint32_t q = 0; q < P.total_bytes; ++q) {
+    if ((B.flags[prev][q] ^ B.flags[next][q]) & 1) {
+      if (count < kChangedCap) B.changed_keys[count] = B.keys[q];
+      count++;
+    }
+  }
+  *B.changed_count = count;
 }
 
 void lz77_patch_commands(Command* cmds, const CmdPatch* patches, uint32_t n) {
