@@ -810,7 +810,8 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
       const bool dead = next.dict_matches < (next.dict_lookups >> 7);
       if (mode != 0) {
         if (dead) {
-          same = mode == 2;
+          // (a chain that looked things up but never got a dictionary match parses the same with the dictionary off)
+          same = mode == 2 || (mode == 1 && exits[k + 1].dict_matches == old.dict_matches);
         } else if (old.dict_lookups == next.dict_lookups && old.dict_matches == next.dict_matches) {
           same = true;
         } else {

@@ -181,7 +181,8 @@ struct DictTracker {
     if (state != kAlive) {
       // certain (kDead) or assumed (kUnknown, until the chain that may have tripped the throttle is redone with
       // exact counters): the dictionary is off, valid chains are those that never found it alive
-      const bool ok = x.dict_mode == 0 || x.dict_mode == 2;
+      // ... or that consulted it without ever getting a match out of it: failed lookups do not change the parse
+      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || (x.dict_mode == 1 && x.dict_matches == used.dict_matches);
       if (!ok) flips++;
       return ok;
     }
@@ -410,14 +411,20 @@ bool Lz77Stage::Resolve(bool final_pass) {
 // Dry run over the last warmup_bytes_ of segments [first_seg, nseg): fills entries_[k + 1] (position, spree
 // state, distance cache) with the state in which the dry run left segment k.  dict_dead selects the static
 // dictionary regime the dry run assumes.
-void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf) {
+void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, const std::vector<uint8_t>* only_after_dirty) {
   const uint32_t nseg = (uint32_t)segments_.size();
   if (first_seg + 1 >= nseg) return;
-  const uint32_t count = nseg - first_seg;
+  // dry-run segment k to get a guess for the entry of k + 1; with only_after_dirty, just where both k and k + 1 are
+  // about to be re-parsed (otherwise the resolver already chained the exact entry from a valid parse of k)
+  std::vector<uint32_t> ks;
+  for (uint32_t k = first_seg; k + 1 < nseg; ++k)
+    if (!only_after_dirty || ((*only_after_dirty)[k] && (*only_after_dirty)[k + 1])) ks.push_back(k);
+  const uint32_t count = (uint32_t)ks.size();
+  if (count == 0) return;
   std::vector<Segment> wsegs(count);
   std::vector<SegEntry> wentries(count);
   for (uint32_t i = 0; i < count; ++i) {
-    const uint32_t k = first_seg + i;
+    const uint32_t k = ks[i];
     Segment g = segments_[k];
     const uint32_t len = g.end - g.start;
     if (len > warmup_bytes_) g.start = g.end - warmup_bytes_;
@@ -441,10 +448,10 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf) 
   dev_free(wsegs_dev);
   dev_free(wentries_dev);
   dev_free(wexits_dev);
-  for (uint32_t i = 0; i + 1 < count; ++i) {
-    SegEntry& e = entries_[first_seg + i + 1];
+  for (uint32_t i = 0; i < count; ++i) {
+    SegEntry& e = entries_[ks[i] + 1];
     memcpy(e.cache, wexits[i].cache, sizeof(e.cache));
-    if (!(segments_[first_seg + i + 1].flags & kSegFirstInBlock)) {
+    if (!(segments_[ks[i] + 1].flags & kSegFirstInBlock)) {
       e.pos = wexits[i].pos;
       e.apply = wexits[i].apply;
     }
@@ -519,7 +526,7 @@ void Lz77Stage::Run() {
   // almost every chain from its true entry.
   if (const char* w = getenv("BROTLI_MI355X_WARMUP")) warmup_bytes_ = (uint32_t)atoi(w);
   if (nseg > 1 && warmup_bytes_ > 0) {
-    Warmup(0, false, which, rbuf);
+    Warmup(0, false, which, rbuf, nullptr);
     tm.stop(&stats_.ms_warmup);
   }
   // ---- rounds.  Round 0 parses every segment; later rounds re-parse only the segments whose entry state
@@ -648,11 +655,7 @@ void Lz77Stage::Run() {
     if (regime_flip) {
       last_death_seg = dict_death_seg_;
       if (warmup_bytes_ > 0 && dict_death_seg_ + 2 < nseg) {
-        // only the dirty segments may take new guesses: the others keep the entries they were parsed with
-        std::vector<SegEntry> keep = entries_;
-        Warmup(dict_death_seg_ + 1, true, which, rbuf);
-        for (uint32_t k = 0; k < nseg; ++k)
-          if (!dirty[k]) entries_[k] = keep[k];
+        Warmup(dict_death_seg_ + 1, true, which, rbuf, &dirty);
       }
     }
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u; dict death seg %u flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dict_death_seg_, dict_flips_);

@@ -71,7 +71,7 @@ class Lz77Stage {
   void InitFlags();
   bool Resolve(bool final_pass);
   void Gather();
-  void Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf);
+  void Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, const std::vector<uint8_t>* only_after_dirty);
   void SelfTestSort();
   void SelfTestRank(int which, int rbuf);
   void Release();

@@ -116,28 +116,31 @@ void mb_split_chains(const MbBuffers& B) {
   HIP_CHECK(hipGetLastError());
 }
 
+// The Huffman construction is sequential, data-dependent control flow: 64 different histograms in the lanes of one
+// wavefront would serialise on every divergent branch.  One histogram per wavefront (lane 0 works) puts the jobs
+// on different SIMDs instead, where they really run concurrently.
 __global__ __launch_bounds__(64) void k_build_codes(MbBuffers B, const CodeJob* jobs, uint32_t n_jobs) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_jobs) return;
+  const uint32_t i = blockIdx.x;
+  if (i >= n_jobs || threadIdx.x != 0) return;
   const CodeJob j = jobs[i];
   mb_item_build_code(B, j.kind, j.row_index, j.num_distance_symbols, B.huff_scratch + i);
 }
 
 void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs) {
   if (n_jobs == 0) return;
-  hipLaunchKernelGGL(k_build_codes, dim3((n_jobs + 63) / 64), dim3(64), 0, 0, B, jobs_dev, n_jobs);
+  hipLaunchKernelGGL(k_build_codes, dim3(n_jobs), dim3(64), 0, 0, B, jobs_dev, n_jobs);
   HIP_CHECK(hipGetLastError());
 }
 
 __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
-  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= B.n_mb) return;
+  const uint32_t m = blockIdx.x;
+  if (m >= B.n_mb || threadIdx.x != 0) return;
   mb_item_write_header(B, m, B.huff_scratch + m);
 }
 
 void mb_write_headers(const MbBuffers& B) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_write_headers, dim3((B.n_mb + 63) / 64), dim3(64), 0, 0, B);
+  hipLaunchKernelGGL(k_write_headers, dim3(B.n_mb), dim3(64), 0, 0, B);
   HIP_CHECK(hipGetLastError());
 }
 
