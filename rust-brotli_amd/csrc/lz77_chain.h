@@ -439,7 +439,50 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   uint32_t best_score = kMinScore;
   const uint32_t brk = P.prefix_bytes;
   bool walk_broken = false;
-  for (uint32_t base = 0; base < ncand && !walk_broken; base += 64) {
+  bool folded = false;
+  if (ncand <= 64) {
+    // Fast path (all candidates in one pass of the wave, nothing near a ring-buffer wrap, the block end or the
+    // custom-dictionary boundary): straight-line scoring, then a loop whose body is two compares, a mask AND,
+    // a find-first-set and two lane reads.
+    const uint32_t c = (uint32_t)BR_LANE;
+    const bool in_range = c < ncand;
+    const bool is_cache = c < ndist;
+    const uint32_t prev = in_range ? s.cand_prev[w][c] : 0xffffffffu;
+    const uint32_t unbroken = in_range ? s.cand_len[w][c] : 0u;
+    const bool has = prev != 0xffffffffu;
+    const unsigned long long stop = __ballot(in_range && !is_cache && !has);
+    const unsigned long long below_stop = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;  // lanes in front of the first stop
+    const bool special_lane = has && (((prev & P.ring_mask) + unbroken > P.ring_mask) || unbroken == max_length ||
+                                      (prev < brk && prev + unbroken > brk));
+    const bool cur_near_wrap = (cur & P.ring_mask) + max_length > P.ring_mask;
+    if (!cur_near_wrap && __ballot(special_lane) == 0) {
+      folded = true;
+      const uint32_t backward = cur - prev;
+      const uint32_t pen = c != 0 ? 39u + ((0x1ca10u >> (c & 0xe)) & 0xe) : 0u;
+      const uint32_t score_cache = P.score_per_byte * unbroken + (30 * 8 * 8 + 15) - pen;
+      const uint32_t score_ring = 30 * 8 * 8 + P.score_per_byte * unbroken - 30 * br_log2_floor_nonzero(has ? backward : 1u);
+      const uint32_t score = is_cache ? score_cache : score_ring;
+      const bool type_ok = is_cache ? (unbroken >= 3 || (unbroken == 2 && c < 2)) : unbroken >= 4;
+      unsigned long long live = __ballot(has && type_ok) & below_stop;
+      uint32_t best_lane = 64;
+      while (live != 0) {
+        const unsigned long long m = live & __ballot(unbroken > best_len && score > best_score);
+        if (m == 0) break;
+        const uint32_t f = (uint32_t)__ffsll((long long)m) - 1u;
+        best_len = BR_READLANE(unbroken, f);
+        best_score = BR_READLANE(score, f);
+        best_lane = f;
+        live = f >= 63 ? 0ull : (m >> (f + 1)) << (f + 1);
+      }
+      if (best_lane != 64) {
+        out.len = best_len;
+        out.distance = BR_READLANE(backward, best_lane);
+        out.score = best_score;
+        out.found = true;
+      }
+    }
+  }
+  for (uint32_t base = 0; !folded && base < ncand && !walk_broken; base += 64) {
     const uint32_t c = base + (uint32_t)BR_LANE;
     const bool in_range = c < ncand;
     const bool is_cache = c < ndist;

@@ -342,12 +342,11 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
 }
 
 // ---- K5: one histogram -> optimised counts, code lengths, codes and its serialised tree
-BR_DEV void mb_item_build_code(const MbBuffers& B, uint32_t kind, uint32_t row_index, uint32_t num_distance_symbols,
-                               HuffmanScratch* sc) {
+// core of the job on explicit buffers (the device kernel stages them in LDS): h[row] in/out, depth[row], bits[row],
+// words[kTreeBitsWords] out; returns the number of header bits
+BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols, uint32_t* h, uint8_t* depth, uint16_t* bits,
+                                   uint64_t* words, HuffmanScratch* sc) {
   const uint32_t row = kRowLen[kind];
-  uint32_t* h = B.histo[kind] + (size_t)row_index * row;
-  uint8_t* depth = B.depth[kind] + (size_t)row_index * row;
-  uint16_t* bits = B.bits[kind] + (size_t)row_index * row;
   // BrotliOptimizeHistograms (metablock.rs:1076-1108): literal 256, command 704, distance min(alphabet, 544)
   uint32_t opt_len = row;
   if (kind == kSplitDistance) opt_len = num_distance_symbols < kNumDistanceHistoSymbols ? num_distance_symbols : kNumDistanceHistoSymbols;
@@ -363,13 +362,20 @@ BR_DEV void mb_item_build_code(const MbBuffers& B, uint32_t kind, uint32_t row_i
     depth[i] = 0;
     bits[i] = 0;
   }
-  uint64_t* words = B.tree_bits[kind] + (size_t)row_index * kTreeBitsWords;
   for (uint32_t i = 0; i < kTreeBitsWords; ++i) words[i] = 0;
   BitSink sink;
   sink.words = words;
   sink.pos = 0;
   br_build_and_store_huffman_tree(h, hist_len, alphabet, sc, depth, bits, sink);
-  B.tree_nbits[kind][row_index] = (uint32_t)sink.pos;
+  return (uint32_t)sink.pos;
+}
+
+BR_DEV void mb_item_build_code(const MbBuffers& B, uint32_t kind, uint32_t row_index, uint32_t num_distance_symbols,
+                               HuffmanScratch* sc) {
+  const uint32_t row = kRowLen[kind];
+  B.tree_nbits[kind][row_index] =
+      mb_build_code_core(kind, num_distance_symbols, B.histo[kind] + (size_t)row_index * row, B.depth[kind] + (size_t)row_index * row,
+                         B.bits[kind] + (size_t)row_index * row, B.tree_bits[kind] + (size_t)row_index * kTreeBitsWords, sc);
 }
 
 BR_DEV void mb_append_bits(BitSink& out, const uint64_t* words, uint32_t nbits) {

@@ -120,10 +120,33 @@ void mb_split_chains(const MbBuffers& B) {
 // wavefront would serialise on every divergent branch.  One histogram per wavefront (lane 0 works) puts the jobs
 // on different SIMDs instead, where they really run concurrently.
 __global__ __launch_bounds__(64) void k_build_codes(MbBuffers B, const CodeJob* jobs, uint32_t n_jobs) {
+  // everything the sequential builder touches is staged in LDS (its loads/stores are dependent, so their latency is
+  // what the job costs); the 64 lanes only help with the copies
+  __shared__ HuffmanScratch sc;
+  __shared__ uint32_t h[704];
+  __shared__ uint16_t bits[704];
+  __shared__ uint8_t depth[704];
+  __shared__ uint64_t words[kTreeBitsWords];
+  __shared__ uint32_t nbits;
   const uint32_t i = blockIdx.x;
-  if (i >= n_jobs || threadIdx.x != 0) return;
+  if (i >= n_jobs) return;
   const CodeJob j = jobs[i];
-  mb_item_build_code(B, j.kind, j.row_index, j.num_distance_symbols, B.huff_scratch + i);
+  const uint32_t row = kRowLen[j.kind];
+  uint32_t* gh = B.histo[j.kind] + (size_t)j.row_index * row;
+  for (uint32_t k = threadIdx.x; k < row; k += 64) h[k] = gh[k];
+  __syncthreads();
+  if (threadIdx.x == 0) nbits = mb_build_code_core(j.kind, j.num_distance_symbols, h, depth, bits, words, &sc);
+  __syncthreads();
+  uint8_t* gd = B.depth[j.kind] + (size_t)j.row_index * row;
+  uint16_t* gb = B.bits[j.kind] + (size_t)j.row_index * row;
+  uint64_t* gw = B.tree_bits[j.kind] + (size_t)j.row_index * kTreeBitsWords;
+  for (uint32_t k = threadIdx.x; k < row; k += 64) {
+    gh[k] = h[k];
+    gd[k] = depth[k];
+    gb[k] = bits[k];
+  }
+  for (uint32_t k = threadIdx.x; k < kTreeBitsWords; k += 64) gw[k] = words[k];
+  if (threadIdx.x == 0) B.tree_nbits[j.kind][j.row_index] = nbits;
 }
 
 void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs) {
