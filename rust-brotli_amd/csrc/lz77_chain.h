@@ -242,6 +242,11 @@ struct DictState {
   uint32_t lookups0, matches0;
   uint32_t mode;              // see SegExit::dict_mode
   int32_t maxdef;
+  // bookkeeping of a chain that finds the dictionary switched off: what it WOULD have looked up, and whether any of
+  // those lookups would have produced a match.  While none does, its parse is also the parse of a live dictionary,
+  // which lets the host accept it in either regime (and keep exact counters).
+  uint32_t vlookups, vwould;
+  int32_t vmaxdef;
 };
 
 // ---- speculative probe of two consecutive positions ---------------------------------------------------
@@ -536,31 +541,40 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     const bool dead = ds.matches < (ds.lookups >> 7);
     const uint32_t seen = dead ? 2u : 1u;
     ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
-    if (!dead) {
+    if (dead && ds.vwould) return out;
+    if (dead) {
+      if ((int32_t)ds.vlookups > ds.vmaxdef) ds.vmaxdef = (int32_t)ds.vlookups;
+    } else {
       const int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
       if (def > ds.maxdef) ds.maxdef = def;
-      for (uint32_t i = 0; i < 2; ++i) {
-        const uint32_t item = BR_UNIFORM(s.cand_prev[w][ncand + i]);
-        const uint32_t matchlen = BR_UNIFORM(s.cand_len[w][ncand + i]);
-        ds.lookups++;
-        if (item == 0) continue;
-        const uint32_t len = item & 0x1f;
-        const uint32_t dist = item >> 5;
-        if (len > max_length) continue;
-        if (matchlen + 10 <= len || matchlen == 0) continue;
-        const uint32_t cut = len - matchlen;
-        const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
-        const uint32_t backward = max_backward + dist + 1 + (transform_id << BR_UNIFORM(t.dict_size_bits_by_length[len]));
-        if (backward > P.dist_max_distance) continue;
-        const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
-        if (score < out.score) continue;
-        out.len = matchlen;
-        out.len_x_code = len ^ matchlen;
-        out.distance = backward;
-        out.score = score;
-        ds.matches++;
-        out.found = true;
+    }
+    uint32_t threshold = out.score;
+    for (uint32_t i = 0; i < 2; ++i) {
+      const uint32_t item = BR_UNIFORM(s.cand_prev[w][ncand + i]);
+      const uint32_t matchlen = BR_UNIFORM(s.cand_len[w][ncand + i]);
+      if (dead) ds.vlookups++; else ds.lookups++;
+      if (item == 0) continue;
+      const uint32_t len = item & 0x1f;
+      const uint32_t dist = item >> 5;
+      if (len > max_length) continue;
+      if (matchlen + 10 <= len || matchlen == 0) continue;
+      const uint32_t cut = len - matchlen;
+      const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
+      const uint32_t backward = max_backward + dist + 1 + (transform_id << BR_UNIFORM(t.dict_size_bits_by_length[len]));
+      if (backward > P.dist_max_distance) continue;
+      const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
+      if (score < threshold) continue;
+      threshold = score;
+      if (dead) {
+        ds.vwould = 1;
+        continue;
       }
+      out.len = matchlen;
+      out.len_x_code = len ^ matchlen;
+      out.distance = backward;
+      out.score = score;
+      ds.matches++;
+      out.found = true;
     }
   }
   return out;
@@ -663,6 +677,9 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   ds.matches = ds.matches0 = BR_UNIFORM(entry.dict_matches);
   ds.mode = 0;
   ds.maxdef = -(1 << 30);
+  ds.vlookups = 0;
+  ds.vwould = 0;
+  ds.vmaxdef = -(1 << 30);
   FlagWriter fw;
   fw.next = t.flags_next;
   fw.enabled = !(seg.flags & kSegWarmup);
@@ -795,14 +812,15 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     exit_out.n_cmds = n_cmds;
     exit_out.n_lits = n_lits;
     exit_out.ext_len = ext_len;
-    exit_out.dict_lookups = ds.lookups;
-    exit_out.dict_matches = ds.matches;
+    // (a chain that only ever saw the dictionary off reports its virtual bookkeeping instead, see DictState)
+    exit_out.dict_lookups = ds.mode == 2 ? ds.lookups + ds.vlookups : ds.lookups;
+    exit_out.dict_matches = ds.mode == 2 ? ds.matches + ds.vwould : ds.matches;
     exit_out.last_dist_code = last_dist_code;
     exit_out.flag_changes = 0;
     exit_out.n_searches = n_searches;
     exit_out.last_copy_len = last_copy_len;
     exit_out.dict_mode = ds.mode;
-    exit_out.dict_maxdef = ds.maxdef;
+    exit_out.dict_maxdef = ds.mode == 2 ? ds.vmaxdef : ds.maxdef;
     exit_out.n_pushes = n_pushes;
     exit_out.pad1 = 0;
   }
@@ -851,14 +869,17 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
       const uint32_t mode = exits[k + 1].dict_mode;
       const int32_t maxdef = exits[k + 1].dict_maxdef;
       const bool dead = next.dict_matches < (next.dict_lookups >> 7);
+      const bool no_match = exits[k + 1].dict_matches == old.dict_matches;  // none used (mode 1) / none possible (mode 2)
+      const bool stays_alive = 128ll * (long long)next.dict_matches - (long long)next.dict_lookups + 127 >= (long long)maxdef;
       if (mode != 0) {
         if (dead) {
-          // (a chain that looked things up but never got a dictionary match parses the same with the dictionary off)
-          same = mode == 2 || (mode == 1 && exits[k + 1].dict_matches == old.dict_matches);
+          same = mode == 2 || (mode == 1 && no_match);
         } else if (old.dict_lookups == next.dict_lookups && old.dict_matches == next.dict_matches) {
           same = true;
+        } else if (mode == 1) {
+          same = stays_alive || no_match;
         } else {
-          same = mode == 1 && (128ll * (long long)next.dict_matches - (long long)next.dict_lookups + 127 >= (long long)maxdef);
+          same = mode == 2 && no_match;
         }
       }
     }

@@ -14,6 +14,8 @@
 
 #include "host_entropy.h"
 
+#include <cmath>
+
 namespace brotli_mi355x {
 
 Lz77Stage::~Lz77Stage() { Release(); }
@@ -160,49 +162,102 @@ void Lz77Stage::InitFlags() { lz77_init_flags(P_, B_, segments_.empty() ? P_.tot
 // off under the exact counters it stays off for the rest of the stream, and the chains after it only need to
 // know "dead" (they never consult it, so the counter values no longer matter).
 struct DictTracker {
-  enum State { kAlive, kDead, kUnknown };
+  // kAlive: on, exact counters.  kFuzzy: on as far as known, but a chain in front could not be accounted for exactly
+  // (it has to be redone): counters are approximate, `slack` bounds the error.  kDead: off for good (exact).
+  // kUnknown: probably off -- the chain that seems to trip the throttle has to be redone with exact counters first.
+  enum State { kAlive, kFuzzy, kDead, kUnknown };
   bool use = false;
   State state = kAlive;
-  uint32_t L = 0, M = 0;     // exact while state == kAlive
-  uint32_t left_alive_at = 0xffffffffu;  // segment at which the state stopped being kAlive
+  uint32_t L = 0, M = 0;
+  int64_t slack = 0;
+  uint32_t left_alive_at = 0xffffffffu;  // segment at which the dictionary (probably) went off
   uint32_t flips = 0;        // chains behind that point that ran with a live dictionary and must be redone
   static constexpr uint32_t kDeadL = 0x40000000u, kDeadM = 0;
   // first guess for chains whose true counters are not known yet: alive with a margin no chain can use up, so
   // that the chain reports its own deficit (dict_maxdef) instead of tripping over a made-up start of stream
   static constexpr uint32_t kAliveL = 0, kAliveM = 0x01000000u;
+  static constexpr int64_t kSlackPerChain = 256;
   void Hint(SegEntry* e) const {
-    e->dict_lookups = state == kAlive ? L : kDeadL;
-    e->dict_matches = state == kAlive ? M : kDeadM;
-    e->dict_exact = state != kUnknown;
+    switch (state) {
+      case kAlive:
+        e->dict_lookups = L;
+        e->dict_matches = M;
+        e->dict_exact = 1;
+        break;
+      case kFuzzy:
+        e->dict_lookups = kAliveL;
+        e->dict_matches = kAliveM;
+        e->dict_exact = 0;
+        break;
+      default:
+        e->dict_lookups = kDeadL;
+        e->dict_matches = kDeadM;
+        e->dict_exact = state == kDead;
+        break;
+    }
   }
-  // consumes the exit of segment k, parsed with entry `used`; returns whether that parse is valid here
+  // consumes the exit of segment k, parsed with entry `used`; returns whether that parse is valid here.
+  // A chain that never got (mode 1) or never could have got (mode 2, see DictState in lz77_chain.h) a dictionary
+  // match parses the same whether the dictionary is on or off, which makes most chains valid in either regime.
   bool Consume(uint32_t k, const SegEntry& used, const SegExit& x) {
     if (!use) return true;
-    if (state != kAlive) {
-      // certain (kDead) or assumed (kUnknown, until the chain that may have tripped the throttle is redone with
-      // exact counters): the dictionary is off, valid chains are those that never found it alive
-      // ... or that consulted it without ever getting a match out of it: failed lookups do not change the parse
-      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || (x.dict_mode == 1 && x.dict_matches == used.dict_matches);
+    const bool no_match = x.dict_matches == used.dict_matches;
+    if (state == kDead || state == kUnknown) {
+      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || (x.dict_mode == 1 && no_match);
       if (!ok) flips++;
       return ok;
     }
-    const bool exact = used.dict_lookups == L && used.dict_matches == M;
-    bool ok;
+    const bool exact = state == kAlive && used.dict_lookups == L && used.dict_matches == M;
+    const bool stays_alive = 128ll * (int64_t)M - (int64_t)L + 127 - slack >= (int64_t)x.dict_maxdef;
+    bool ok = true;
+    State next = state;
     switch (x.dict_mode) {
-      case 0: ok = true; break;
-      case 1: ok = exact || (128ll * (int64_t)M - (int64_t)L + 127 >= (int64_t)x.dict_maxdef); break;
-      default: ok = exact; break;  // the chain saw the dictionary switched off: only meaningful with exact counters
+      case 0:
+        break;
+      case 1:  // found the dictionary on at every consult under the counters it was given
+        if (exact || stays_alive) {
+          L += x.dict_lookups - used.dict_lookups;
+          M += x.dict_matches - used.dict_matches;
+        } else if (no_match) {
+          // under the true counters it (probably, if they are approximate) dies inside this chain, whose parse does
+          // not depend on it
+          next = state == kAlive ? kDead : kUnknown;
+        } else {
+          ok = false;
+          next = kUnknown;
+        }
+        break;
+      case 2:  // ran with the dictionary off (a guess); the exit carries the virtual bookkeeping
+        if (no_match) {
+          if (stays_alive) {
+            L += x.dict_lookups - used.dict_lookups;
+          } else {
+            next = state == kAlive ? kDead : kUnknown;
+          }
+        } else {
+          // the dictionary is on here and this chain would have used it: redo it; the chains behind it are judged
+          // with approximate counters meanwhile
+          ok = false;
+          next = kFuzzy;
+          slack += kSlackPerChain;
+        }
+        break;
+      default:  // switched off inside the chain under its own counters: only meaningful when those were exact
+        if (exact) {
+          next = kDead;
+        } else {
+          ok = false;
+          next = kUnknown;
+        }
+        break;
     }
-    if (ok) {
-      L += x.dict_lookups - used.dict_lookups;
-      M += x.dict_matches - used.dict_matches;
-      if (x.dict_mode >= 2) {
-        state = kDead;
-        left_alive_at = k;
-      }
-    } else {
-      state = kUnknown;
-      left_alive_at = k;
+    if (getenv("BROTLI_MI355X_DEBUG_DICT") && (!ok || next != state))
+      fprintf(stderr, "  dict seg %u: state %d->%d L %u M %u slack %lld used (%u,%u,%u) exit (%u,%u) mode %u maxdef %d ok %d\n", k, (int)state,
+              (int)next, L, M, (long long)slack, used.dict_lookups, used.dict_matches, used.dict_exact, x.dict_lookups, x.dict_matches,
+              x.dict_mode, x.dict_maxdef, (int)ok);
+    if (next != state) {
+      if (next == kDead || next == kUnknown) left_alive_at = k;
+      state = next;
     }
     return ok;
   }
@@ -448,12 +503,34 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
   dev_free(wsegs_dev);
   dev_free(wentries_dev);
   dev_free(wexits_dev);
+  if (!dict_dead && !only_after_dirty) {
+    // lookups / matches the dry runs saw, scaled to the whole segment: a forecast of where the throttle trips
+    warm_lookups_.assign(nseg, 0.0);
+    warm_matches_.assign(nseg, 0.0);
+    for (uint32_t i = 0; i < count; ++i) {
+      const double scale = (double)(segments_[ks[i]].end - segments_[ks[i]].start) / (double)(wsegs[i].end - wsegs[i].start);
+      warm_lookups_[ks[i]] = scale * (double)(wexits[i].dict_lookups - wentries[i].dict_lookups);
+      warm_matches_[ks[i]] = scale * (double)(wexits[i].dict_matches - wentries[i].dict_matches);
+    }
+  }
   for (uint32_t i = 0; i < count; ++i) {
     SegEntry& e = entries_[ks[i] + 1];
     memcpy(e.cache, wexits[i].cache, sizeof(e.cache));
     if (!(segments_[ks[i] + 1].flags & kSegFirstInBlock)) {
       e.pos = wexits[i].pos;
       e.apply = wexits[i].apply;
+    } else {
+      // will extend_last_command run at the start of the next block (encode.rs:2435-2437, 360-400)?  Same test as in
+      // Resolve(), on the dry run's last command.  A wrong guess is caught there.
+      const SegExit& x = wexits[i];
+      e.ext_allowed = 0;
+      if (x.n_cmds > 0 && x.insert_len == 0) {
+        const uint64_t cmd_dist = (uint64_t)(int64_t)x.cache[0];
+        if (x.last_dist_code < 16 || (uint64_t)x.last_dist_code - 15 == cmd_dist) {
+          const uint64_t lpp = (uint64_t)segments_[ks[i] + 1].blk_start - x.last_copy_len;
+          if (cmd_dist <= std::min<uint64_t>(lpp, P_.max_backward_limit)) e.ext_allowed = 1;
+        }
+      }
     }
   }
   stats_.segments_parsed += (uint64_t)count * warmup_bytes_ / segment_bytes_;
@@ -527,6 +604,32 @@ void Lz77Stage::Run() {
   if (const char* w = getenv("BROTLI_MI355X_WARMUP")) warmup_bytes_ = (uint32_t)atoi(w);
   if (nseg > 1 && warmup_bytes_ > 0) {
     Warmup(0, false, which, rbuf, nullptr);
+    if (P_.use_dictionary && warm_lookups_.size() == nseg) {
+      // forecast of the segment in which the static dictionary gets switched off (matches < lookups >> 7,
+      // mod.rs:1957-1960); chains behind it start with the "off" guess.  A wrong forecast only costs re-parses of
+      // the chains that actually used / could have used a dictionary match (DictTracker::Consume).
+      // Guessing "off" too early is the expensive mistake (a chain that ran without the dictionary cannot tell what
+      // it would have counted, so the exact counters can only advance one redone chain per round), guessing "on" too
+      // long only costs the re-parse of the chains that really used a dictionary match.  Hence a forecast three
+      // standard deviations of the sampled match count on the late side.
+      const double sample = (double)warmup_bytes_ / (double)segment_bytes_;
+      double Lc = 0, Mc = 0;
+      uint32_t death = nseg;
+      for (uint32_t k = 0; k < nseg; ++k) {
+        Lc += warm_lookups_[k];
+        Mc += warm_matches_[k];
+        const double sigma = std::sqrt(std::max(1.0, Mc * sample)) / sample;
+        if (Lc >= 256.0 && Mc + 3.0 * sigma < Lc / 128.0) {
+          death = k;
+          break;
+        }
+      }
+      for (uint32_t k = death + 1; k < nseg; ++k) {
+        entries_[k].dict_lookups = DictTracker::kDeadL;
+        entries_[k].dict_matches = DictTracker::kDeadM;
+      }
+      predicted_death_ = death;
+    }
     tm.stop(&stats_.ms_warmup);
   }
   // ---- rounds.  Round 0 parses every segment; later rounds re-parse only the segments whose entry state
@@ -569,6 +672,17 @@ void Lz77Stage::Run() {
     }
     stats_.segments_parsed += count;
     lz77_diff_flags(P_, B_, which, which ^ 1);
+    if (getenv("BROTLI_MI355X_DEBUG_FLAGS")) {
+      std::vector<uint8_t> fa(P_.total_bytes), fb(P_.total_bytes);
+      dev_d2h(fa.data(), B_.flags[which], P_.total_bytes);
+      dev_d2h(fb.data(), B_.flags[which ^ 1], P_.total_bytes);
+      uint32_t shown = 0;
+      for (uint32_t q = 0; q < P_.total_bytes && shown < 40; ++q)
+        if ((fa[q] ^ fb[q]) & 1) {
+          fprintf(stderr, "  flag change at %u (seg %u, off %u): %u -> %u\n", q, q / segment_bytes_, q % segment_bytes_, fa[q], fb[q]);
+          shown++;
+        }
+    }
     dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
     if (!full_round) {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
@@ -658,7 +772,7 @@ void Lz77Stage::Run() {
         Warmup(dict_death_seg_ + 1, true, which, rbuf, &dirty);
       }
     }
-    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u; dict death seg %u flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dict_death_seg_, dict_flips_);
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dict_death_seg_, predicted_death_, dict_flips_);
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid);
     if (count == 0) {
       done = true;

@@ -85,6 +85,8 @@ class Lz77Stage {
   uint32_t warmup_bytes_ = 768;
   uint32_t block_bytes_ = 65536;
   std::vector<Segment> segments_;
+  std::vector<double> warm_lookups_, warm_matches_;  // per segment, forecast from the warm-up dry run
+  uint32_t predicted_death_ = 0xffffffffu;
   std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
   std::vector<SegEntry> entries_;   // entries used by the most recent parse
   std::vector<SegEntry> next_entries_;
