@@ -107,53 +107,30 @@ def main():
         prefix = b""
         chunk = data
     else:
-        import synth
-        full = workload(total, seed)  # deterministic; ranks read the cached file after the first run
-        start = (rank * total) // world
-        end = ((rank + 1) * total) // world
-        win = (1 << LGWIN) - 16
-        prefix = full[max(0, start - win):start] if rank else b""
-        chunk = full[start:end]
-        data = full if rank == 0 else None
+        # the N x 64 MiB stream is the concatenation of N independently seeded texts, so that a rank only has to
+        # generate its own shard and the one in front of it (for the LZ77 prefix)
+        from brotli_mi355x import multi as _m
+        lo, start, end = _m.shard_window(total, rank, world, LGWIN)
+        assert start == rank * per_gpu and end == start + per_gpu
+        chunk = workload(per_gpu, seed + rank)
+        prefix = workload(per_gpu, seed + rank - 1)[lo - (start - per_gpu):] if rank else b""
+        data = chunk if rank == 0 else None
     dev = torch.frombuffer(bytearray(chunk), dtype=torch.uint8).cuda()
     torch.cuda.synchronize()
 
-    # flat entry point: explicit prefix + device resident chunk (tests/emu.py binding)
-    import emu
-    L = emu.bind_encode(lib.lib)
+    # shard encoder: explicit prefix + device resident chunk through the library's flat entry point
+    from brotli_mi355x import multi
+    enc = multi.ShardEncoder(lib.lib, args.segment_bytes)
     params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN)]
-    if world > 1:
-        params.append((bm.BROTLI_PARAM_APPENDABLE, 1))
-        if rank:
-            params.append((bm.BROTLI_PARAM_CATABLE, 1))
-    else:
+    if world == 1:
         params.append((bm.BROTLI_PARAM_SIZE_HINT, per_gpu))  # BrotliEncoderCompress sets SIZE_HINT = input size
-    keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
-    vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
-    cap = len(chunk) + len(chunk) // 4 + 4096
-    out = ctypes.create_string_buffer(cap)
-    st = (ctypes.c_double * 32)()
-    err = ctypes.create_string_buffer(512)
+    st = enc.stats
 
     def one_step():
-        n = L.brotli_mi355x_encode_stream(keys, vals, len(params), prefix, len(prefix), 1, ctypes.c_void_p(dev.data_ptr()),
-                                          len(chunk), 1, args.segment_bytes, out, cap, st, err, 512)
-        if n < 0:
-            raise RuntimeError(err.value.decode())
-        comp = ctypes.string_at(out, n)
-        if world > 1:
-            # gather of the variable-length compressed chunks to rank 0 (sizes first, then padded payloads)
-            size_t = torch.tensor([n], dtype=torch.int64, device="cuda")
-            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(sizes, size_t)
-            mx = int(max(int(s.item()) for s in sizes))
-            payload = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-            payload[:n] = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
-            bufs = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
-            dist.gather(payload, bufs, dst=0)
-            if rank == 0:
-                chunks = [bytes(bufs[r][:int(sizes[r].item())].cpu().numpy()) for r in range(world)]
-                comp = lib.concat_chunks(chunks)
+        if world == 1:
+            comp = enc.encode(params, b"", dev.data_ptr(), len(chunk), True)
+        else:
+            comp = multi.compress_sharded(dist, lib, enc, params, LGWIN, prefix, dev.data_ptr(), len(chunk), True, rank, world, "cuda")
         return comp, list(st)
 
     for _ in range(args.warmup):
@@ -221,8 +198,8 @@ def main():
                      "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": agg["launches"] / args.steps,
                      "alg_bytes_per_launch": int(alg_bytes_per_launch)},
     }
-    if not args.no_cpu_baseline:
-        sample = data if world == 1 else data[:per_gpu]
+    if not args.no_cpu_baseline and world == 1:  # (the CPU leg is reported at N = 1 only)
+        sample = data
         base, ref_bytes = cpu_baseline(sample)
         line["cpu_baseline"] = base
         if world == 1:

@@ -1,0 +1,96 @@
+"""One shard per process (one process per GPU): the reference's compress_multi split carried over ranks.
+
+Mirrors src/enc/threading/mod.rs:333-411: shard i of T is bytes [i*N/T, (i+1)*N/T) of the input; shard 0 is encoded
+`appendable`, every later shard `catable` + `appendable` with the preceding (1 << lgwin) - 16 bytes of the stream as
+LZ77 prefix; rank 0 stitches the shards with the BroCatli rules (src/concat/mod.rs:274-608, csrc/concat.cpp).  The only
+collective is the gather of the compressed shards -- RCCL (`nccl` backend) between GPUs, `gloo` in the CPU tests.
+"""
+import ctypes
+
+BROTLI_PARAM_LGWIN = 2
+BROTLI_PARAM_CATABLE = 167
+BROTLI_PARAM_APPENDABLE = 168
+
+
+def shard_range(total, rank, world):
+    """get_range, src/enc/threading/mod.rs:333-335"""
+    return (rank * total) // world, ((rank + 1) * total) // world
+
+
+def shard_window(total, rank, world, lgwin):
+    """(first byte of the LZ77 prefix, shard start, shard end) for `rank`"""
+    start, end = shard_range(total, rank, world)
+    win = (1 << lgwin) - 16  # encode.rs:1231, 1243-1246
+    return (max(0, start - win) if rank else start), start, end
+
+
+def shard_params(params, rank):
+    """parameter list of one shard (threading/mod.rs:354-358)"""
+    out = list(params) + [(BROTLI_PARAM_APPENDABLE, 1)]
+    if rank:
+        out.append((BROTLI_PARAM_CATABLE, 1))
+    return out
+
+
+class ShardEncoder(object):
+    """Binds the flat entry point brotli_mi355x_encode_stream of a loaded library (product or emulation)."""
+
+    def __init__(self, cdll, segment_bytes=4096):
+        self.L = cdll
+        self.segment_bytes = segment_bytes
+        f = self.L.brotli_mi355x_encode_stream
+        f.restype = ctypes.c_long
+        f.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_char_p,
+                      ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32,
+                      ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_size_t]
+        self.stats = (ctypes.c_double * 32)()
+        self._err = ctypes.create_string_buffer(512)
+        self._out = None
+
+    def encode(self, params, prefix, chunk, nbytes, on_device):
+        """chunk: device address (on_device) or bytes.  Returns the compressed shard as bytes."""
+        keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
+        vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
+        cap = nbytes + nbytes // 4 + 4096
+        if self._out is None or len(self._out) < cap:
+            self._out = ctypes.create_string_buffer(cap)
+        if on_device:
+            src = ctypes.c_void_p(chunk)
+            keep = None
+        else:
+            keep = ctypes.create_string_buffer(bytes(chunk), max(1, nbytes))
+            src = ctypes.cast(keep, ctypes.c_void_p)
+        n = self.L.brotli_mi355x_encode_stream(keys, vals, len(params), prefix, len(prefix), 1, src, nbytes, 1 if on_device else 0,
+                                               self.segment_bytes, self._out, cap, self.stats, self._err, 512)
+        if n < 0:
+            raise RuntimeError(self._err.value.decode())
+        return ctypes.string_at(self._out, n)
+
+
+def gather_shards(dist, comp, rank, world, device):
+    """Variable-length gather of the compressed shards to rank 0 (sizes first, then padded payloads).
+    Returns the list of shards on rank 0, None elsewhere."""
+    import torch
+    size_t = torch.tensor([len(comp)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, size_t)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    payload = torch.zeros(mx, dtype=torch.uint8, device=device)
+    payload[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(device)
+    bufs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(payload, bufs, dst=0)
+    if rank != 0:
+        return None
+    return [bytes(bufs[r][:sizes[r]].cpu().numpy()) for r in range(world)]
+
+
+def compress_sharded(dist, library, encoder, params, lgwin, prefix, chunk, nbytes, on_device, rank, world, device):
+    """One step of the multi-process job: encode this rank's shard, gather, stitch on rank 0 (returns the stream there)."""
+    comp = encoder.encode(shard_params(params, rank), prefix, chunk, nbytes, on_device)
+    if world == 1:
+        return comp
+    shards = gather_shards(dist, comp, rank, world, device)
+    if rank != 0:
+        return None
+    return library.concat_chunks(shards)
