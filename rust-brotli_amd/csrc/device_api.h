@@ -71,8 +71,12 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start);
 // stable sort of positions by key -> by_key / sorted_keys
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
-// sorted[rbuf] / info[rbuf] from flags[which] (all keys)
-void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf);
+// sorted[rbuf] / info[rbuf] from flags[which] (all keys).  `initial` (optional): flags[which] is still exactly what
+// lz77_init_flags wrote, which lets the kernel skip most of the random flag reads.
+struct RankInitialHint {
+  uint32_t first_block_start, block_bytes;
+};
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint* initial = nullptr);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through
 // rank/sorted) and write flags[which ^ 1], cmds and exits
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment);

@@ -197,16 +197,33 @@ __global__ __launch_bounds__(256) void k_key_ranges(const uint16_t* __restrict__
   if (i + 1 == n || sorted_keys[i + 1] != k) key_last[k] = i + 1;
 }
 
-// pass A: gather the stored bits into (key,pos) order (one byte each) and sum them per tile
+// pass A: gather the stored bits into (key,pos) order (one byte each) and sum them per tile.
+// `initial`: the flags are still the first guess of lz77_init_flags, which is 1 everywhere except next to the block
+// ends and in front of the first block -- only positions there are fetched (a random 1-byte gather costs a 64-byte line).
+struct InitialFlagGeometry {
+  uint32_t enabled, first_block_start, prefix_bytes, block_bytes, total_bytes, prefix_stored_end;
+};
+
 __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
-                                                      uint8_t* __restrict__ fbits, uint32_t* __restrict__ tile_sums) {
+                                                      uint8_t* __restrict__ fbits, uint32_t* __restrict__ tile_sums,
+                                                      InitialFlagGeometry ig) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
   uint32_t local = 0, packed = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (base + j < n) {
-      const uint32_t f = flags[by_key[base + j]] & 1u;
+      const uint32_t p = by_key[base + j];
+      uint32_t f;
+      bool known = false;
+      if (ig.enabled) {
+        if (p >= ig.first_block_start) {
+          known = ((p - ig.prefix_bytes) % ig.block_bytes) + 16 < ig.block_bytes && p + 16 < ig.total_bytes;
+        } else {
+          known = p + 16 < ig.prefix_stored_end;
+        }
+      }
+      f = known ? 1u : (flags[p] & 1u);
       packed |= f << (8 * j);
       local += f;
     }
@@ -288,13 +305,22 @@ void lz77_key_ranges(const Lz77Params& P, const Lz77Buffers& B) {
   HIP_CHECK(hipGetLastError());
 }
 
-void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf) {
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint* initial) {
   const uint32_t n = P.total_bytes;
   if (n == 0) return;
+  InitialFlagGeometry ig{};
+  if (initial) {
+    ig.enabled = 1;
+    ig.first_block_start = initial->first_block_start;
+    ig.prefix_bytes = P.prefix_bytes;
+    ig.block_bytes = initial->block_bytes;
+    ig.total_bytes = n;
+    ig.prefix_stored_end = P.prefix_bytes > P.htl - 1 ? P.prefix_bytes - (P.htl - 1) : 0;  // StoreLookaheadThenStore, mod.rs:224-229
+  }
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
-  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, B.fbits, tile_sums);
+  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, 0, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,

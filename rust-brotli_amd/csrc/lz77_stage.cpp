@@ -595,7 +595,10 @@ void Lz77Stage::Run() {
   }
   exits_.assign(nseg, SegExit{});
   int which = 0, rbuf = 0;
-  lz77_rank_flags(P_, B_, which, rbuf);
+  {
+    RankInitialHint hint{segments_[0].blk_start, block_bytes_};
+    lz77_rank_flags(P_, B_, which, rbuf, &hint);
+  }
   tm.stop(&stats_.ms_rank);
   if (selftest) SelfTestRank(which, rbuf);
   // ---- warm-up: a dry run over the tail of every segment gives a good first guess of the state in which the

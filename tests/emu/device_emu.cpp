@@ -98,7 +98,7 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   }
 }
 
-void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf) {
+void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint*) {
   const uint32_t n = P.total_bytes;
   uint32_t first = 0, local = 0;
   for (uint32_t i = 0; i < n; ++i) {
