@@ -82,7 +82,7 @@ class Lz77Stage {
   uint32_t input_bytes_ = 0;
   uint32_t raw_head_bytes_ = 0;
   uint32_t segment_bytes_ = 4096;
-  uint32_t warmup_bytes_ = 768;
+  uint32_t warmup_bytes_ = 384;
   uint32_t block_bytes_ = 65536;
   std::vector<Segment> segments_;
   std::vector<double> warm_lookups_, warm_matches_;  // per segment, forecast from the warm-up dry run

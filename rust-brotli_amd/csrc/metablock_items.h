@@ -151,14 +151,63 @@ BR_DEV void mb_item_distance_count(const MbBuffers& B, uint32_t c) {
 
 // ---- K4: greedy block splitter chain for one (meta-block, kind).
 // BlockSplitter / ContextBlockSplitter FinishBlock, metablock.rs:551-792, driven granule by granule.
+static constexpr uint32_t kSplitRowMax = kMaxStaticContexts * 256 > 704 ? kMaxStaticContexts * 256 : 704;
+
 struct SplitScratch {
   // workgroup shared memory
-  uint32_t curr[kMaxStaticContexts * 256 > 704 ? kMaxStaticContexts * 256 : 704];
-  uint32_t comb[2][kMaxStaticContexts * 256 > 704 ? kMaxStaticContexts * 256 : 704];
+  uint32_t curr[kSplitRowMax];
+  uint32_t comb[2][kSplitRowMax];
+  uint32_t last[2][kSplitRowMax];  // the histograms of the last and the second last block type (copies of the rows in H)
+  float terms[3][kSplitRowMax];    // non-zero entropy terms of curr / comb[0] / comb[1], compacted per context row
   float entropy[3 * kMaxStaticContexts];  // [0..nc) current, [nc..2nc) combined with last, [2nc..3nc) with second last
   float last_entropy[2 * kMaxStaticContexts];
   uint32_t ctl[16];
 };
+
+// BitsEntropy (bit_cost.rs:13-42) of the 3 * nc rows {curr, comb[0], comb[1]} x contexts, cooperatively.
+// The reference accumulates `retval -= p * log2(p)` strictly left to right in f32; bins with p == 0 contribute an
+// exact 0.0, so leaving them out does not change any intermediate value.  Each wavefront takes a row: the lanes compute
+// the terms and compact the non-zero ones (ballot + popcount), then one lane adds them up in order -- the sequential
+// part shrinks from `alphabet` dependent adds to the number of symbols that actually occur.
+BR_DEV void mb_rows_entropy(const EntropyTables& et, SplitScratch& S, uint32_t nc, uint32_t row, uint32_t alphabet) {
+#if defined(BROTLI_HOST_EMU)
+  const uint32_t lane = 0, lanes = 1, wave = 0, waves = 1;
+#else
+  const uint32_t lane = threadIdx.x & 63u, lanes = 64, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+#endif
+  for (uint32_t r = wave; r < 3 * nc; r += waves) {
+    const uint32_t w = r / nc, i = r % nc;
+    const uint32_t* src = (w == 0 ? S.curr : S.comb[w - 1]) + i * row;
+    float* out = S.terms[w] + i * row;
+    uint32_t cnt = 0, total = 0;
+    for (uint32_t base = 0; base < alphabet; base += lanes) {
+      const uint32_t j = base + lane;
+      const uint32_t p = j < alphabet ? src[j] : 0u;
+      total += p;
+      const bool nz = p != 0;
+#if defined(BROTLI_HOST_EMU)
+      if (nz) out[cnt] = (float)p * et.logs_16[p & 0xffffu];
+      cnt += nz ? 1u : 0u;
+#else
+      const unsigned long long mask = __ballot(nz);
+      const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (nz) out[cnt + before] = (float)p * et.logs_16[p & 0xffffu];
+      cnt += (uint32_t)__popcll(mask);
+#endif
+    }
+#if !defined(BROTLI_HOST_EMU)
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    __threadfence_block();
+#endif
+    if (lane == 0) {
+      float retval = 0.0f;
+      for (uint32_t n = 0; n < cnt; ++n) retval = retval - out[n];
+      if (total != 0) retval = retval + (float)total * br_fast_log2(et, total);
+      const float fsum = (float)total;
+      S.entropy[r] = retval < fsum ? fsum : retval;
+    }
+  }
+}
 
 BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, SplitScratch& S) {
   const MbDesc d = B.descs[m];
@@ -183,7 +232,11 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
   uint32_t num_blocks = 0, num_types = 0, block_size = 0, target = min_block, curr_ix = 0, merge_count = 0;
   uint32_t last_ix[2] = {0, 0};
   uint32_t block_first_granule = 0;
-  for (uint32_t j = BR_TID; j < W; j += BR_NT) S.curr[j] = 0;
+  for (uint32_t j = BR_TID; j < W; j += BR_NT) {
+    S.curr[j] = 0;
+    S.last[0][j] = 0;
+    S.last[1][j] = 0;
+  }
   BR_SYNC();
   uint32_t g = 0;
   for (;;) {
@@ -210,7 +263,10 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
       }
       BR_SYNC();  // the entropy threads must finish reading curr before it is cleared
       for (uint32_t j = BR_TID; j < W; j += BR_NT) {
-        H[j] = S.curr[j];
+        const uint32_t c = S.curr[j];
+        H[j] = c;
+        S.last[0][j] = c;  // last_histogram_ix = {0, 0}: both slots refer to block type 0
+        S.last[1][j] = c;
         S.curr[j] = 0;
       }
       if (BR_TID == 0) {
@@ -225,20 +281,13 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
       block_size = 0;
       BR_SYNC();
     } else if (block_size > 0) {
-      const uint32_t* L0 = H + (size_t)last_ix[0] * row;
-      const uint32_t* L1 = H + (size_t)last_ix[1] * row;
       for (uint32_t j = BR_TID; j < W; j += BR_NT) {
         const uint32_t c = S.curr[j];
-        S.comb[0][j] = c + L0[j];
-        S.comb[1][j] = c + L1[j];
+        S.comb[0][j] = c + S.last[0][j];
+        S.comb[1][j] = c + S.last[1][j];
       }
       BR_SYNC();
-      // 3 * nc independent, strictly sequential f32 sums
-      for (uint32_t t = BR_TID; t < 3 * nc; t += BR_NT) {
-        const uint32_t w = t / nc, i = t % nc;
-        const uint32_t* src = w == 0 ? S.curr + i * row : S.comb[w - 1] + i * row;
-        S.entropy[t] = br_bits_entropy(B.et, src, entropy_alphabet);
-      }
+      mb_rows_entropy(B.et, S, nc, row, entropy_alphabet);
       BR_SYNC();
       if (BR_TID == 0) {
         float diff[2] = {0.0f, 0.0f};
@@ -269,7 +318,10 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
         uint32_t* Hn = H + (size_t)curr_ix * row;
         const bool room = curr_ix + nc <= max_histos;
         for (uint32_t j = BR_TID; j < W; j += BR_NT) {
-          if (room) Hn[j] = S.curr[j];
+          const uint32_t c = S.curr[j];
+          if (room) Hn[j] = c;
+          S.last[1][j] = S.last[0][j];
+          S.last[0][j] = c;
           S.curr[j] = 0;
         }
         if (BR_TID == 0) {
@@ -295,7 +347,10 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
         last_ix[1] = t;
         uint32_t* Hl = H + (size_t)last_ix[0] * row;
         for (uint32_t j = BR_TID; j < W; j += BR_NT) {
-          Hl[j] = S.comb[1][j];
+          const uint32_t merged = S.comb[1][j];
+          Hl[j] = merged;
+          S.last[1][j] = S.last[0][j];
+          S.last[0][j] = merged;
           S.curr[j] = 0;
         }
         if (BR_TID == 0) {
@@ -313,8 +368,12 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
         target = min_block;
       } else {  // merge into the last block
         uint32_t* Hl = H + (size_t)last_ix[0] * row;
+        const bool single_type = num_types == 1;
         for (uint32_t j = BR_TID; j < W; j += BR_NT) {
-          Hl[j] = S.comb[0][j];
+          const uint32_t merged = S.comb[0][j];
+          Hl[j] = merged;
+          S.last[0][j] = merged;
+          if (single_type) S.last[1][j] = merged;  // both slots still name the only block type
           S.curr[j] = 0;
         }
         if (BR_TID == 0) {
