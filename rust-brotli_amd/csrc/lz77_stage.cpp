@@ -787,6 +787,10 @@ void Lz77Stage::Run() {
   dev_free(list_dev);
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
   tm.stop(&stats_.ms_resolve);
+  if (getenv("BROTLI_MI355X_DEBUG_EXITS"))
+    for (uint32_t k = 0; k < nseg && k < 40; ++k)
+      fprintf(stderr, "  seg %u [%u,%u) entry pos %u | exit pos %u insert %u cmds %u lits %u searches %u\n", k, segments_[k].start, segments_[k].end,
+              entries_[k].pos, exits_[k].pos, exits_[k].insert_len, exits_[k].n_cmds, exits_[k].n_lits, exits_[k].n_searches);
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
   Gather();
   tm.stop(&stats_.ms_gather);
@@ -850,7 +854,9 @@ void Lz77Stage::SelfTestRank(int which, int rbuf) {
 void Lz77Stage::Gather() {
   const uint32_t nseg = (uint32_t)segments_.size();
   std::vector<uint32_t> offsets(nseg), counts(nseg);
-  std::vector<CmdPatch> fix;
+  // Two batches: a command can receive both a carried-in insert length (kind 2) and an extension of its copy (kind 0);
+  // the patches of one batch touch distinct commands, so each batch is applied with one thread per patch.
+  std::vector<CmdPatch> fix, fix_ext;
   size_t t = 0, ti = 0;
   uint64_t total = 0;
   for (uint32_t k = 0; k < nseg; ++k) {
@@ -880,7 +886,7 @@ void Lz77Stage::Gather() {
     p.index = offsets[pt.segment] + pt.index;
     p.kind = 0;
     p.value = pt.ext;
-    fix.push_back(p);
+    fix_ext.push_back(p);
   }
   total_cmds_ = total;
   stats_.total_commands = total;
@@ -897,10 +903,11 @@ void Lz77Stage::Gather() {
   dev_h2d(gather_offsets_dev_, offsets.data(), nseg * 4);
   dev_h2d(gather_counts_dev_, counts.data(), nseg * 4);
   lz77_gather_commands(P_, B_, nseg, P_.cmd_slab_stride, gather_offsets_dev_, gather_counts_dev_, gathered_cmds_);
-  if (!fix.empty()) {
-    CmdPatch* fix_dev = (CmdPatch*)dev_alloc(fix.size() * sizeof(CmdPatch));
-    dev_h2d(fix_dev, fix.data(), fix.size() * sizeof(CmdPatch));
-    lz77_patch_commands(gathered_cmds_, fix_dev, (uint32_t)fix.size());
+  for (const std::vector<CmdPatch>* batch : {&fix, &fix_ext}) {
+    if (batch->empty()) continue;
+    CmdPatch* fix_dev = (CmdPatch*)dev_alloc(batch->size() * sizeof(CmdPatch));
+    dev_h2d(fix_dev, batch->data(), batch->size() * sizeof(CmdPatch));
+    lz77_patch_commands(gathered_cmds_, fix_dev, (uint32_t)batch->size());
     dev_sync();
     dev_free(fix_dev);
   }
