@@ -115,4 +115,7 @@ float orc_bits_entropy(const uint32_t* population, size_t size);
 #ifdef __cplusplus
 }
 #endif
+/* test hook (orc_lz77.c): map[ix] |= 1 for every position inserted into the hash table, |= 2 for every searched one */
+void orc_set_debug_store_map(uint8_t* map, size_t size);
+
 #endif

@@ -303,6 +303,15 @@ static inline size_t hash_bytes(const Hasher* h, const uint8_t* data) {
 static inline size_t hash_type_length(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
 static inline size_t store_lookahead(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
 
+/* test hook: when set, map[ix] |= 1 for every position inserted into the hash table and |= 2 for every position
+   FindLongestMatch runs on (lets tests compare the device's stored / searched flags with the truth) */
+uint8_t* orc_debug_store_map = 0;
+size_t orc_debug_store_map_size = 0;
+void orc_set_debug_store_map(uint8_t* map, size_t size) {
+  orc_debug_store_map = map;
+  orc_debug_store_map_size = size;
+}
+
 /* mod.rs:1644-1656 / 879-887 */
 static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, size_t ix, OrcStats* st) {
   size_t key = hash_bytes(h, data + (ix & mask));
@@ -310,6 +319,7 @@ static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, siz
   h->buckets[minor_ix + (key << h->block_bits)] = (uint32_t)ix;
   h->num[key] = (uint16_t)(h->num[key] + 1);
   st->positions_stored++;
+  if (orc_debug_store_map && ix < orc_debug_store_map_size) orc_debug_store_map[ix] |= 1;
 }
 
 /* mod.rs:1491-1510 (AdvHasher::Prepare), :898-906 (H9::Prepare). Returns 1 if newly prepared. */
@@ -507,6 +517,7 @@ static int adv_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* 
     bucket[num_copy & h->block_mask] = (uint32_t)cur_ix;
     h->num[key] = (uint16_t)(num_copy + 1);
     st->positions_stored++;
+    if (orc_debug_store_map && cur_ix < orc_debug_store_map_size) orc_debug_store_map[cur_ix] |= 3;
   }
   if (!is_match_found && use_dictionary) {
     is_match_found = search_in_static_dictionary(h, cur_data, max_length, max_backward + gap, max_distance,

@@ -636,9 +636,12 @@ BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
 struct FlagWriter {
   uint8_t* next;
   bool enabled;
+  uint32_t hi;       // writes are clipped to positions < hi (the end of the chain's own segment)
   uint32_t tail_lo;  // positions >= tail_lo inside the block get the stitch flag
   uint8_t tail_value;
-  BR_DEV void put(uint32_t q, uint8_t v) { next[q] = v; }
+  BR_DEV void put(uint32_t q, uint8_t v) {
+    if (q < hi) next[q] = v;
+  }
   BR_DEV void one(uint32_t q, uint8_t v) {  // uniform call: lane 0 writes
     if (BR_LANE == 0 && enabled) put(q, v);
   }
@@ -646,7 +649,29 @@ struct FlagWriter {
   // [a, b) := v for q < split, static "not stored by the main loop" value for q >= split
   BR_DEV void range(uint32_t a, uint32_t b, uint32_t split) {
     if (!enabled) return;
+    if (b > hi) b = hi;
     for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) put(q, q < split ? (uint8_t)1 : unstored(q));
+  }
+  // the part [a, b) of the step described by (kind, base, p1) -- see HeadKind
+  BR_DEV void head(uint32_t kind, uint32_t base, uint32_t p1, uint32_t a, uint32_t b, uint32_t store_end) {
+    if (!enabled || kind == kHeadNone) return;
+    if (b > hi) b = hi;
+    for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) {
+      uint8_t v;
+      if (kind == kHeadCopy) {
+        // q <= base: lazily delayed literals and the position the match starts at (all searched and stored)
+        if (q <= base) v = kFlagStored | kFlagSearched;
+        else if (q == base + 1) v = p1 ? (uint8_t)(kFlagStored | kFlagSearched) : unstored(q);
+        else v = q < store_end ? (uint8_t)1 : unstored(q);
+      } else if (kind == kHeadUnstored) {
+        v = unstored(q);
+      } else if (kind == kHeadVec4) {
+        v = ((q - base) & 3) == 0;
+      } else {
+        v = ((q - base) & 1) == 0;
+      }
+      put(q, v);
+    }
   }
 };
 
@@ -683,6 +708,8 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   FlagWriter fw;
   fw.next = t.flags_next;
   fw.enabled = !(seg.flags & kSegWarmup);
+  fw.hi = seg.end;
+  uint32_t tail_kind = kHeadNone, tail_base = 0, tail_p1 = 0;
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
   uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0;
@@ -715,6 +742,8 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
       }
       ext_len = n;
       fw.range(position, position + n, 0);
+      tail_kind = kHeadUnstored;
+      tail_base = position;
       position += n;
     }
     apply = position + window;
@@ -725,6 +754,13 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   // but whenever (pos_end - start) < lookahead the loop below cannot run anyway.
   const uint32_t store_end = pos_end >= htl ? pos_end - htl + 1 : 0;
   br_prepare_distance_cache(dc, P.ndist);
+  if (!(seg.flags & kSegFirstInBlock)) {
+    // the part of the previous chain's last step that lies in this segment
+    tail_kind = BR_UNIFORM(entry.head_kind);
+    tail_base = BR_UNIFORM(entry.head_base);
+    tail_p1 = BR_UNIFORM(entry.head_p1);
+    if (position > seg.start) fw.head(tail_kind, tail_base, tail_p1, seg.start, position, store_end);
+  }
 
   while (position + htl < pos_end && position < seg.end) {
     SearchResult sr = br_search(P, t, s, probe, ds, position, dc, cache_version, pos_end);
@@ -765,6 +801,9 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
       last_dist_code = distance_code;
       last_copy_len = sr.len;
       // hash-table side effects: position searched, position+1 only if probed, then StoreRange
+      tail_kind = kHeadCopy;
+      tail_base = position;
+      tail_p1 = next_probed ? 1u : 0u;
       fw.one(position, kFlagStored | kFlagSearched);
       if (sr.len > 1) fw.one(position + 1, next_probed ? (uint8_t)(kFlagStored | kFlagSearched) : fw.unstored(position + 1));
       if (sr.len > 2) fw.range(position + 2, position + sr.len, store_end);
@@ -776,11 +815,15 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
       if (position > apply) {
         const uint32_t margin = htl - 1 > 4 ? htl - 1 : 4;
         if (position + 16 >= pos_end - margin) {
+          tail_kind = kHeadUnstored;
+          tail_base = position;
           fw.range(position, pos_end, 0);
           insert_length += pos_end - position;
           position = pos_end;
         } else if (position > apply + 4 * window) {
           // Store4Vec4: position, +4, +8, +12
+          tail_kind = kHeadVec4;
+          tail_base = position;
           for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 16; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 3) == 0;
             fw.put(q, v);
@@ -789,6 +832,8 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
           position += 16;
         } else {
           // StoreEvenVec4: position, +2, +4, +6
+          tail_kind = kHeadEven4;
+          tail_base = position;
           for (uint32_t q = position + BR_LANE; fw.enabled && q < position + 8; q += BR_NLANES) {
             const uint8_t v = ((q - position) & 1) == 0;
             fw.put(q, v);
@@ -822,7 +867,9 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     exit_out.dict_mode = ds.mode;
     exit_out.dict_maxdef = ds.mode == 2 ? ds.vmaxdef : ds.maxdef;
     exit_out.n_pushes = n_pushes;
-    exit_out.pad1 = 0;
+    exit_out.tail_kind = position > seg.end ? tail_kind : (uint32_t)kHeadNone;
+    exit_out.tail_base = position > seg.end ? tail_base : 0u;
+    exit_out.tail_p1 = position > seg.end ? tail_p1 : 0u;
   }
 #if defined(BR_CHAIN_PROFILE)
   if (BR_LANE == 0) {
@@ -844,6 +891,10 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   next.dict_matches = ds.matches;
   next.ext_max_distance = 0;
   next.dict_exact = entry.dict_exact;
+  next.head_kind = position > seg.end ? tail_kind : (uint32_t)kHeadNone;
+  next.head_base = position > seg.end ? tail_base : 0u;
+  next.head_p1 = position > seg.end ? tail_p1 : 0u;
+  next.pad = 0;
 }
 
 // Parses segment k and -- in list rounds (sched != nullptr) -- keeps going into the following segments of the
@@ -861,7 +912,8 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
     if (sched[k + 1]) break;
     const SegEntry old = entries[k + 1];
-    bool same = old.pos == next.pos && old.apply == next.apply;
+    bool same = old.pos == next.pos && old.apply == next.apply && old.head_kind == next.head_kind && old.head_base == next.head_base &&
+                old.head_p1 == next.head_p1;
     for (int i = 0; i < 4; ++i) same = same && old.cache[i] == next.cache[i];
     if (same && P.use_dictionary && next.dict_exact) {
       // static-dictionary throttle (mod.rs:1957-1960): would the old parse of k + 1 have seen the dictionary in the

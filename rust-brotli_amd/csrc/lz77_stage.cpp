@@ -387,9 +387,13 @@ bool Lz77Stage::Resolve(bool final_pass) {
         memcpy(N.cache, out_cache, sizeof(N.cache));
         N.insert_len = carry;
         N.ext_allowed = 0;
+        N.head_kind = X.tail_kind;
+        N.head_base = X.tail_base;
+        N.head_p1 = X.tail_p1;
         dict.Hint(&N);
         const SegEntry& u = entries_[j + 1];
-        bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0;
+        bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0 &&
+                    u.head_kind == N.head_kind && u.head_base == N.head_base && u.head_p1 == N.head_p1;
         if (dbg_mismatch_) {
           dbg_mismatch_[0] += u.pos != N.pos;
           dbg_mismatch_[1] += u.pos == N.pos && u.apply != N.apply;
@@ -519,6 +523,9 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
     if (!(segments_[ks[i] + 1].flags & kSegFirstInBlock)) {
       e.pos = wexits[i].pos;
       e.apply = wexits[i].apply;
+      e.head_kind = wexits[i].tail_kind;
+      e.head_base = wexits[i].tail_base;
+      e.head_p1 = wexits[i].tail_p1;
     } else {
       // will extend_last_command run at the start of the next block (encode.rs:2435-2437, 360-400)?  Same test as in
       // Resolve(), on the dry run's last command.  A wrong guess is caught there.
@@ -694,7 +701,8 @@ void Lz77Stage::Run() {
         if (dirty[k]) continue;
         const SegEntry &a = used_entries[k], &b = entries_[k];
         if (a.pos != b.pos || a.apply != b.apply || memcmp(a.cache, b.cache, sizeof(a.cache)) != 0 ||
-            a.dict_lookups != b.dict_lookups || a.dict_matches != b.dict_matches) {
+            a.dict_lookups != b.dict_lookups || a.dict_matches != b.dict_matches || a.head_kind != b.head_kind ||
+            a.head_base != b.head_base || a.head_p1 != b.head_p1) {
           entries_[k] = a;
           stats_.segments_parsed++;
         }
@@ -786,6 +794,11 @@ void Lz77Stage::Run() {
   dev_free(dirty_dev);
   dev_free(list_dev);
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
+  final_flags_ = which;
+  if (selftest) {
+    // the incrementally maintained rank structures must equal a rebuild from the final flags
+    SelfTestRank(which, rbuf);
+  }
   tm.stop(&stats_.ms_resolve);
   if (getenv("BROTLI_MI355X_DEBUG_EXITS"))
     for (uint32_t k = 0; k < nseg && k < 40; ++k)
@@ -795,6 +808,11 @@ void Lz77Stage::Run() {
   Gather();
   tm.stop(&stats_.ms_gather);
   total.stop(&stats_.ms_total);
+}
+
+void Lz77Stage::DumpFlags(uint8_t* out, size_t size) const {
+  dev_sync();
+  dev_d2h(out, B_.flags[final_flags_], std::min<size_t>(size, P_.total_bytes));
 }
 
 // Bring-up checks of the sort / rank kernels against a host recomputation (BROTLI_MI355X_SELFTEST=1).

@@ -58,6 +58,7 @@ class Lz77Stage {
   void ForceUncompressed(uint32_t index) { forced_uncompressed_.push_back(index); }
   void set_warmup_bytes(uint32_t n) { warmup_bytes_ = n; }
   void Run();
+  void DumpFlags(uint8_t* out, size_t size) const;  // test hook: final per-position flags
 
   const std::vector<MetaBlockPlan>& metablocks() const { return metablocks_; }
   Command* commands_dev() const { return gathered_cmds_; }
@@ -87,6 +88,7 @@ class Lz77Stage {
   std::vector<Segment> segments_;
   std::vector<double> warm_lookups_, warm_matches_;  // per segment, forecast from the warm-up dry run
   uint32_t predicted_death_ = 0xffffffffu;
+  int final_flags_ = 0;
   std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
   std::vector<SegEntry> entries_;   // entries used by the most recent parse
   std::vector<SegEntry> next_entries_;

@@ -64,6 +64,16 @@ struct Segment {
   uint32_t pad;
 };
 
+// What covers the positions between a segment's start and the position where its chain takes over.
+enum HeadKind : uint32_t {
+  kHeadNone = 0,
+  kHeadCopy = 1,      // copy that started at head_base: base + 1 is 3 if it was probed (head_p1) else "not stored",
+                      // the rest is stored up to store_end (StoreRange, mod.rs:2519-2527)
+  kHeadUnstored = 2,  // extend_last_command / end-of-block flush: nothing is stored
+  kHeadVec4 = 3,      // Store4Vec4 from head_base: every 4th position (mod.rs:2538-2541)
+  kHeadEven4 = 4,     // StoreEvenVec4 from head_base: every 2nd position (mod.rs:2542-2545)
+};
+
 // Parse state handed to a chain when it starts (speculated, then confirmed by the host resolver).
 struct SegEntry {
   uint32_t pos;         // loop-top position where the true parse enters this segment
@@ -75,6 +85,11 @@ struct SegEntry {
   uint32_t dict_matches;
   uint32_t ext_max_distance;  // max_distance for extend_last_command
   uint32_t dict_exact;  // the throttle counters are the true ones (not a guess): br_parse_chain may rely on them
+  // How to flag the positions [start, pos) of this segment, which the LAST step of the previous chain covers (a copy,
+  // an extension, a sparse-store jump ...).  Every position's flag is written by the chain of the segment it lies in,
+  // so that no two chains ever write the same byte.  See HeadKind.
+  uint32_t head_kind, head_base, head_p1;
+  uint32_t pad;
 };
 
 struct SegExit {
@@ -94,7 +109,7 @@ struct SegExit {
   uint32_t dict_mode;       // 0 no consult, 1 alive at every consult, 2 dead at every consult, 3 mixed
   int32_t dict_maxdef;      // mode 1: max over consults of (local lookups - 128 * local matches)
   uint32_t n_pushes;        // number of dist-cache pushes in this segment, saturated at 4
-  uint32_t pad1;
+  uint32_t tail_kind, tail_base, tail_p1;  // the step that carried the parse past the segment end (-> next entry's head_*)
 };
 
 // Post-parse fix-ups of the gathered command array.

@@ -81,3 +81,17 @@ def mixed(nbytes, seed=0x5EED000000000004):
         else:
             out += random_bytes(seglen, rng.next())
     return bytes(out[:nbytes])
+
+
+def repeated_excerpts(nbytes, seed=1, source_bytes=1 << 20):
+    """Random-offset excerpts (4..68 KiB) of one 1 MiB text, concatenated: long exact repeats whose copies run across
+    segment and block boundaries and get continued by extend_last_command, with more than a ring's worth of earlier
+    occurrences of most hash keys."""
+    text = markov_text(source_bytes, 0x1234)
+    rng = XorShift(seed)
+    out = bytearray()
+    while len(out) < nbytes:
+        seglen = 4096 + rng.next() % 65536
+        off = rng.next() % (len(text) - seglen)
+        out += text[off:off + seglen]
+    return bytes(out[:nbytes])

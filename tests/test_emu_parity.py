@@ -63,3 +63,11 @@ def test_shard_with_prefix(L):
     a = synth.alice()
     h = len(a) // 3
     assert check_bytes(L, "alice shard", a[h:2 * h], [(Q, 5), (W, 22), (167, 1), (168, 1)], prefix=a[:h], verbose=False)
+
+
+def test_stored_flags_equal_reference_table(L):
+    import cmp_flags
+    for name, d in cmp_flags.tricky_inputs():
+        assert cmp_flags.stored_flags_match(L, d), name
+        assert check(name, d, 5, 22, lib=L)
+        assert check_bytes(L, name, d, [(Q, 5), (W, 22), (SH, len(d))], verbose=False)

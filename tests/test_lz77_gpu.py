@@ -46,3 +46,15 @@ def test_catable_shard_with_prefix(L):
 @pytest.mark.parametrize("seg", [1024, 65536])
 def test_segment_sizes(L, seg):
     assert check("alice", synth.alice(), 5, 22, seg=seg, lib=L)
+
+
+def test_stored_flags_equal_reference_table(L):
+    import cmp_flags
+    for name, d in cmp_flags.tricky_inputs():
+        assert cmp_flags.stored_flags_match(L, d), name
+        assert check(name, d, 5, 22, lib=L)
+
+
+def test_mixed_16M(L):
+    # mixed content across several meta-blocks (zero runs, binary records, text, random)
+    assert check("mixed16M", synth.mixed(16 << 20), 5, 22, lib=L)
