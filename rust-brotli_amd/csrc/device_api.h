@@ -81,9 +81,10 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
 // rank/sorted) and write flags[which ^ 1], cmds and exits
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment);
 // the same over an explicit list of segment indices (device array); flags are read from and written to flags[which]
-// sched_dev[k] = 1 for the segments in the list; a chain continues into following unscheduled segments whose entry
-// it changes (br_parse_chain) and rewrites B.entries for them
-void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, const uint8_t* sched_dev,
+// sched_dev[k] = 1 for the segments in the list, 2 for segments left to the chain of their predecessor that must be
+// redone in any case, 0 otherwise; a chain continues into following segments marked 2, or marked 0 whose entry it
+// changes (br_parse_chain), rewrites B.entries for them and marks them 3
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint8_t* sched_dev,
                      uint32_t count);
 // lists the keys of the positions whose stored flag differs between flags[prev] and flags[next] in B.changed_keys /
 // B.changed_count (the count may exceed kChangedCap; only the first kChangedCap entries are kept)

@@ -69,6 +69,7 @@ struct ChainTables {
 };
 
 static constexpr uint32_t kInfoWindow = 64;
+static constexpr uint32_t kMaxContinuation = 4;
 
 struct ChainScratch {  // one per wavefront (LDS on the device)
   uint32_t win[kInfoWindow][2];  // rank records (info) of positions [win_base, win_base + kInfoWindow)
@@ -107,6 +108,35 @@ BR_DEV uint32_t br_match_len(const uint8_t* a, const uint8_t* b, uint32_t limit)
     ++i;
   }
   return limit;
+}
+
+// Does replacing the candidate list `a` of position p by `b` (both newest first: a_last[0], a_last[-1], ...) possibly
+// change what FindLongestMatch finds there?  A ring entry takes part in the search only through
+// FindMatchLengthWithLimitMin4 (static_dict.rs:134-147), which ignores it unless its first four bytes equal those at p;
+// entries that fail this test can come and go without any effect (they do not even end the bucket walk, which stops
+// on distance alone).  So only the entries in the symmetric difference of the two lists need a look.
+BR_DEV bool br_row_change_matters(const uint8_t* text, uint32_t p, const uint32_t* a_last, uint32_t na, const uint32_t* b_last,
+                                  uint32_t nb) {
+  const uint32_t head = br_load32(text + p);
+  uint32_t i = 0, j = 0;
+  while (i < na || j < nb) {
+    const uint32_t qa = i < na ? *(a_last - i) : 0u, qb = j < nb ? *(b_last - j) : 0u;
+    if (i < na && j < nb && qa == qb) {
+      ++i;
+      ++j;
+      continue;
+    }
+    uint32_t q;
+    if (j >= nb || (i < na && qa > qb)) {
+      q = qa;
+      ++i;
+    } else {
+      q = qb;
+      ++j;
+    }
+    if (br_load32(text + q) == head) return true;
+  }
+  return false;
 }
 
 // ---- command.rs -------------------------------------------------------------------------------
@@ -903,14 +933,21 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
 // round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
 // written to entries[] so that the host resolver sees what it was parsed with.
 BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment* segments,
-                           SegEntry* entries, SegExit* exits, uint32_t k, const uint8_t* sched) {
+                           SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched) {
   SegEntry entry = entries[k];
+  // a chain takes at most kMaxContinuation further segments: what it leaves behind is picked up in the next round by
+  // a chain of its own, so that one launch never lasts much longer than a handful of segment parses
+  uint32_t continued = 0;
   for (;;) {
     const Segment seg = segments[k];
     SegEntry next;
     br_parse_segment(P, t, s, seg, entry, exits[k], next);
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
-    if (sched[k + 1]) break;
+    const uint32_t mark = sched[k + 1];
+    if (mark == 1 || mark == 3) break;  // has its own chain in this launch
+    if (continued >= kMaxContinuation) break;
+    ++continued;
+    const bool forced = mark == 2;     // left to this chain, must be redone whatever state we arrive with
     const SegEntry old = entries[k + 1];
     bool same = old.pos == next.pos && old.apply == next.apply && old.head_kind == next.head_kind && old.head_base == next.head_base &&
                 old.head_p1 == next.head_p1;
@@ -935,10 +972,13 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
         }
       }
     }
-    if (same) break;
+    if (same && !forced) break;
     BR_SYNC();
     ++k;
-    if (BR_LANE == 0) entries[k] = next;
+    if (BR_LANE == 0) {
+      entries[k] = next;
+      sched[k] = 3;
+    }
     entry = next;
   }
 }

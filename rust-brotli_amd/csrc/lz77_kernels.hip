@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256) void k_rerank_apply(const RerankChunk* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void k_rerank_check(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ by_key,
+__global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict__ text, const RerankChunk* __restrict__ chunks,
+                                                       const uint32_t* __restrict__ by_key,
                                                        const uint8_t* __restrict__ flags, const uint32_t* __restrict__ sorted,
                                                        const uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
                                                        const uint32_t* __restrict__ sorted_tmp, SegGeometry geo,
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) void k_rerank_check(const RerankChunk* __restr
     const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(rb & 0xffffu, geo.block_size);
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted[a.x - 1 - j] == sorted_tmp[c.key_lo + rb - 1 - j];
-    if (!same) mark_dirty(p, geo, dirty);
+    if (!same && br_row_change_matters(text, p, sorted + a.x - 1, na, sorted_tmp + c.key_lo + rb - 1, nb)) mark_dirty(p, geo, dirty);
   }
 }
 
@@ -448,7 +449,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   uint32_t* sorted_tmp = rank_tmp + (((size_t)P.total_bytes + 63) & ~(size_t)63);
   hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], sums_dev);
   hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
-  hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
+  hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, 0, B.text, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
                      (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev);
   hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
                      (uint2*)B.info[rbuf], rank_tmp);
@@ -464,7 +465,7 @@ struct ParseArgs {
   SegExit* exits;
   uint32_t first_segment;
   const uint32_t* list;  // optional explicit segment indices
-  const uint8_t* sched;  // list rounds: per segment, 1 if it is in the list (see br_parse_chain)
+  uint8_t* sched;  // list rounds: per segment, 1 if it is in the list (see br_parse_chain)
   uint32_t count;
   uint32_t per_xcd;      // 0: identity mapping
 };
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
 }
 
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
-                         SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, const uint8_t* sched,
+                         SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, uint8_t* sched,
                          uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ParseArgs a;
@@ -534,7 +535,7 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, nullptr, P.num_segments - first_segment);
 }
 
-void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, const uint8_t* sched_dev,
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint8_t* sched_dev,
                      uint32_t count) {
   if (count == 0) return;
   launch_parse(P, B, which, which ^ 1, rbuf, B.segments, B.entries, B.exits, 0, list_dev, sched_dev, count);
@@ -581,7 +582,7 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
 // ------------------------------------------------------------------------------------------ validate
 // After some flags changed, the candidate list of a searched position may differ from the one its chain
 // saw.  Comparing the two rank structures entry by entry (no text access) finds those positions exactly.
-__global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ flags, const uint2* __restrict__ info_old,
+__global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ text, const uint8_t* __restrict__ flags, const uint2* __restrict__ info_old,
                                                    const uint32_t* __restrict__ sorted_old, const uint2* __restrict__ info_new,
                                                    const uint32_t* __restrict__ sorted_new, uint32_t n, SegGeometry geo,
                                                    uint8_t* __restrict__ dirty) {
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ fl
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted_old[a.x - 1 - j] == sorted_new[b.x - 1 - j];
     if (same) continue;
-    mark_dirty(p, geo, dirty);
+    if (br_row_change_matters(text, p, sorted_old + a.x - 1, na, sorted_new + b.x - 1, nb)) mark_dirty(p, geo, dirty);
   }
 }
 
@@ -602,7 +603,7 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
   if (n == 0) return;
   uint32_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, 0, B.flags[which], (const uint2*)B.info[rbuf_old], B.sorted[rbuf_old],
+  hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, 0, B.text, B.flags[which], (const uint2*)B.info[rbuf_old], B.sorted[rbuf_old],
                      (const uint2*)B.info[rbuf_new], B.sorted[rbuf_new], n, geo, dirty_dev);
   HIP_CHECK(hipGetLastError());
 }

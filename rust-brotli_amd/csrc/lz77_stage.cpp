@@ -272,6 +272,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
   if (getenv("BROTLI_MI355X_DEBUG")) {
     dbg_mismatch_ = dbg_counts_;
     memset(dbg_counts_, 0, sizeof(dbg_counts_));
+    memset(dbg_first_, 0, sizeof(dbg_first_));
   }
   metablocks_.clear();
   patches_.clear();
@@ -336,6 +337,10 @@ bool Lz77Stage::Resolve(bool final_pass) {
     {
       const SegEntry& u = entries_[k0];
       bool same = memcmp(u.cache, E.cache, sizeof(E.cache)) == 0 && u.ext_allowed == E.ext_allowed;
+      if (dbg_mismatch_) {
+        dbg_first_[0] += memcmp(u.cache, E.cache, sizeof(E.cache)) != 0;
+        dbg_first_[1] += u.ext_allowed != E.ext_allowed;
+      }
       mark(k0, same);
     }
     next_entries_[k0] = E;
@@ -395,6 +400,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
         bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0 &&
                     u.head_kind == N.head_kind && u.head_base == N.head_base && u.head_p1 == N.head_p1;
         if (dbg_mismatch_) {
+          dbg_first_[2] += u.head_kind != N.head_kind || u.head_base != N.head_base || u.head_p1 != N.head_p1;
           dbg_mismatch_[0] += u.pos != N.pos;
           dbg_mismatch_[1] += u.pos == N.pos && u.apply != N.apply;
           dbg_mismatch_[2] += u.pos == N.pos && memcmp(u.cache, N.cache, sizeof(N.cache)) != 0;
@@ -657,6 +663,7 @@ void Lz77Stage::Run() {
   std::vector<uint8_t> dirty(nseg, 0);
   std::vector<uint32_t> list(nseg);
   std::vector<SegEntry> used_entries(nseg);
+  std::vector<uint8_t> entry_streak(nseg, 0), was_dirty, cand_dirty, pending(nseg, 0), sched(nseg, 0);
   for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
   uint32_t count = nseg;
   const uint32_t max_rounds = nseg + 8;
@@ -672,7 +679,7 @@ void Lz77Stage::Run() {
     } else {
       dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
       dev_h2d(list_dev, list.data(), (size_t)count * 4);
-      dev_h2d(dirty_dev, dirty.data(), nseg);
+      dev_h2d(dirty_dev, sched.data(), nseg);
     }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     if (full_round) {
@@ -697,25 +704,23 @@ void Lz77Stage::Run() {
     if (!full_round) {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
       dev_d2h(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
-      for (uint32_t k = 1; k < nseg; ++k) {
-        if (dirty[k]) continue;
-        const SegEntry &a = used_entries[k], &b = entries_[k];
-        if (a.pos != b.pos || a.apply != b.apply || memcmp(a.cache, b.cache, sizeof(a.cache)) != 0 ||
-            a.dict_lookups != b.dict_lookups || a.dict_matches != b.dict_matches || a.head_kind != b.head_kind ||
-            a.head_base != b.head_base || a.head_p1 != b.head_p1) {
-          entries_[k] = a;
-          stats_.segments_parsed++;
-        }
+      dev_d2h(sched.data(), dirty_dev, nseg);
+      for (uint32_t k = 0; k < nseg; ++k) {
+        if (sched[k] != 3) continue;
+        pending[k] = 0;
+        entries_[k] = used_entries[k];
+        stats_.segments_parsed++;
       }
     }
     tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
     Resolve(false);
-    for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k];
+    for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
     uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
     for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
     uint32_t n_changed = 0;
     dev_d2h(&n_changed, B_.changed_count, 4);
+    cand_dirty.clear();
     if (n_changed != 0) {
       tm.stop(&stats_.ms_resolve);
       // few changes: re-rank only the keys concerned, in place; otherwise rebuild everything into the other buffer
@@ -759,23 +764,44 @@ void Lz77Stage::Run() {
         rbuf ^= 1;
         stats_.full_ranks++;
       }
-      std::vector<uint8_t> dv(nseg);
-      dev_d2h(dv.data(), dirty_dev, nseg);
+      cand_dirty.resize(nseg);
+      dev_d2h(cand_dirty.data(), dirty_dev, nseg);
       for (uint32_t k = 0; k < nseg; ++k) {
-        n_dirty_valid += dv[k];
-        dirty[k] |= dv[k];
+        n_dirty_valid += cand_dirty[k];
+        dirty[k] |= cand_dirty[k];
       }
       tm.stop(&stats_.ms_rank);
     }
     // the static dictionary got switched off at segment dict_death_seg_ and many chains behind it ran in the
     // wrong regime: they are re-parsed anyway; refresh their entry guesses with a dry run in the new regime
     const bool regime_flip = dict_death_seg_ != 0xffffffffu && dict_death_seg_ != last_death_seg && dict_flips_ > 64;
+    // Which dirty segments get their own chain?  Normally all of them, each started from the entry chained out of its
+    // predecessor's last exit (a guess while that predecessor is itself being redone -- fine when parses re-synchronise
+    // quickly).  Where they do not (long literal stretches with sparse hashing keep the phase of the previous chain
+    // for ever), the guess fails round after round and the fix would creep forward one segment per round.  So a
+    // segment whose entry was wrong twice in a row, and whose predecessor is being redone as well, is left to that
+    // predecessor's chain, which continues into it with its real exit state (br_parse_chain).
+    for (uint32_t k = 0; k < nseg; ++k) entry_streak[k] = dirty_entry_[k] ? (uint8_t)std::min<uint32_t>(entry_streak[k] + 1u, 255u) : (uint8_t)0;
+    was_dirty = dirty;
+    // speculation is failing broadly (or we are in the tail of the iteration): do not guess at all behind a segment
+    // that is being redone
+    const bool aggressive = (uint64_t)n_dirty_entry * 8 > nseg || round >= 2;
     count = 0;
     for (uint32_t k = 0; k < nseg; ++k) {
-      if (dirty[k]) {
-        list[count++] = k;
-        entries_[k] = next_entries_[k];
+      sched[k] = 0;
+      if (!dirty[k]) continue;
+      const bool must_redo = pending[k] || (!cand_dirty.empty() && cand_dirty[k]);  // its candidates changed
+      const bool defer = (aggressive || entry_streak[k] >= 2) && !(segments_[k].flags & kSegFirstInBlock) && k > 0 && was_dirty[k - 1];
+      if (defer) {
+        sched[k] = must_redo ? 2 : 0;
+        pending[k] = must_redo;  // stays owed until some chain really gets here
+        dirty[k] = 0;
+        continue;
       }
+      pending[k] = 0;
+      sched[k] = 1;
+      list[count++] = k;
+      entries_[k] = next_entries_[k];
     }
     if (regime_flip) {
       last_death_seg = dict_death_seg_;
@@ -783,7 +809,7 @@ void Lz77Stage::Run() {
         Warmup(dict_death_seg_ + 1, true, which, rbuf, &dirty);
       }
     }
-    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dict_death_seg_, predicted_death_, dict_flips_);
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u | block-first: cache %u ext %u | head %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dbg_first_[0], dbg_first_[1], dbg_first_[2], dict_death_seg_, predicted_death_, dict_flips_);
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid);
     if (count == 0) {
       done = true;

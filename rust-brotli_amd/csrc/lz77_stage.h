@@ -119,6 +119,7 @@ class Lz77Stage {
   uint32_t* gather_counts_dev_ = nullptr;
   Lz77Stats stats_;
   uint32_t dbg_counts_[4] = {0, 0, 0, 0};
+  uint32_t dbg_first_[4] = {0, 0, 0, 0};
   uint32_t* dbg_mismatch_ = nullptr;  // set to dbg_counts_ under BROTLI_MI355X_DEBUG
   std::map<std::pair<uint32_t, uint32_t>, bool> should_compress_cache_;
   uint32_t first_dirty_ = 0;

@@ -146,7 +146,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
       const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(rb & 0xffffu, geo.block_size);
       bool same = na == nb;
       for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf][ax - 1 - j] == new_sorted[rb - 1 - j];
-      if (!same) emu_mark_dirty(p, geo, dirty);
+      if (!same && br_row_change_matters(B.text, p, B.sorted[rbuf] + ax - 1, na, new_sorted.data() + rb - 1, nb)) emu_mark_dirty(p, geo, dirty);
     }
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t p = B.by_key[i];
@@ -158,7 +158,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
 }
 
 static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, SegEntry* entries,
-                      SegExit* exits, uint32_t first_segment, const uint32_t* list, const uint8_t* sched, uint32_t count) {
+                      SegExit* exits, uint32_t first_segment, const uint32_t* list, uint8_t* sched, uint32_t count) {
   const DeviceTables& dt = dev_tables();
   ChainTables T;
   T.text = B.text;
@@ -184,7 +184,7 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, first_segment, nullptr, nullptr, P.num_segments - first_segment);
 }
 
-void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list, const uint8_t* sched,
+void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list, uint8_t* sched,
                      uint32_t count) {
   run_parse(P, B, which, rbuf, B.segments, B.entries, B.exits, 0, list, sched, count);
 }
@@ -206,6 +206,7 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf_old][ga - 1 - j] == B.sorted[rbuf_new][gb - 1 - j];
     if (same) continue;
+    if (!br_row_change_matters(B.text, p, B.sorted[rbuf_old] + ga - 1, na, B.sorted[rbuf_new] + gb - 1, nb)) continue;
     const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
     const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
     const uint32_t off = p - bs;
