@@ -222,6 +222,10 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     hb.jump_to_byte_boundary();
   }
 
+  // positions are 32-bit on the device (like the reference's u32 ring positions, which wrap instead); longer streams
+  // go through BrotliEncoderCompressMulti / the chunk entry points
+  if ((uint64_t)prefix_bytes + (uint64_t)n > 0xE0000000ull)
+    throw std::runtime_error("brotli_mi355x: more than 3.5 GiB in one stream is not supported, split it into chunks");
   DevMem mem;
   const uint32_t M = prefix_bytes + (uint32_t)n;
   uint8_t* text = mem.alloc<uint8_t>((size_t)M + 64);

@@ -705,6 +705,13 @@ void Lz77Stage::Run() {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
       dev_d2h(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
       dev_d2h(sched.data(), dirty_dev, nseg);
+      uint32_t n_cont = 0, n_def0 = 0, n_def2 = 0;
+      for (uint32_t k = 0; k < nseg; ++k) {
+        n_cont += sched[k] == 3;
+        n_def2 += sched[k] == 2;
+      }
+      (void)n_def0;
+      if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "  continued into %u segments, %u forced ones not reached\n", n_cont, n_def2);
       for (uint32_t k = 0; k < nseg; ++k) {
         if (sched[k] != 3) continue;
         pending[k] = 0;
@@ -782,6 +789,15 @@ void Lz77Stage::Run() {
     // segment whose entry was wrong twice in a row, and whose predecessor is being redone as well, is left to that
     // predecessor's chain, which continues into it with its real exit state (br_parse_chain).
     for (uint32_t k = 0; k < nseg; ++k) entry_streak[k] = dirty_entry_[k] ? (uint8_t)std::min<uint32_t>(entry_streak[k] + 1u, 255u) : (uint8_t)0;
+    if (getenv("BROTLI_MI355X_DEBUG_MAP")) {
+      std::string m;
+      for (uint32_t k = 16; k < 48 && k < nseg; ++k) m += dirty_entry_[k] ? (pending[k] ? 'P' : 'E') : (dirty[k] ? 'c' : '.');
+      fprintf(stderr, "  map[16..48) %s\n", m.c_str());
+      for (uint32_t k = 16; k < 24 && k < nseg; ++k)
+        fprintf(stderr, "    seg %u used pos %u apply %u head %u/%u | chained pos %u apply %u head %u/%u | exit pos %u\n", k, entries_[k].pos, entries_[k].apply,
+                entries_[k].head_kind, entries_[k].head_base, next_entries_[k].pos, next_entries_[k].apply, next_entries_[k].head_kind,
+                next_entries_[k].head_base, exits_[k].pos);
+    }
     was_dirty = dirty;
     // speculation is failing broadly (or we are in the tail of the iteration): do not guess at all behind a segment
     // that is being redone

@@ -1,0 +1,53 @@
+"""Full-size checks on the GPU (BASELINE.json sizes) through properties that do not need the oracle to run for
+minutes: the stream must decode (system libbrotlidec) to exactly the input, incompressible input must come out as
+stored meta-blocks, and compressing the same input twice must give the same bytes (the parse is a fixed point, not a
+race)."""
+import ctypes
+import hashlib
+
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+Q, W, SH = 1, 2, 5
+
+
+@pytest.fixture(scope="module")
+def L():
+    import gpulib
+    return gpulib.lib()
+
+
+def _encode(L, data):
+    import emu
+    return emu.encode_stream(L, data, [(Q, 5), (W, 22), (SH, min(len(data), 1 << 30))])
+
+
+def test_text_256MiB_round_trip(L):
+    block = synth.markov_text(64 << 20)
+    data = block * 4  # repeats lie beyond the 4 MiB window: every copy has to be found inside its own 64 MiB
+    out, st = _encode(L, data)
+    assert len(out) < len(data) // 3
+    assert hashlib.sha256(orc.decompress(out, len(data))).digest() == hashlib.sha256(data).digest()
+    out2, _ = _encode(L, data)
+    assert out2 == out
+
+
+def test_random_1GiB_is_stored(L):
+    data = synth.random_bytes(64 << 20) * 16
+    out, st = _encode(L, data)
+    # every meta-block stored raw (should_compress, encode.rs:1325-1354): 8 MiB blocks, a few header bytes each
+    overhead = len(out) - len(data)
+    print("overhead", overhead, "metablocks", st["metablocks"], st["uncompressed_metablocks"])
+    assert 0 < overhead < 16 * st["metablocks"] + 64
+    assert st["uncompressed_metablocks"] == st["metablocks"]
+    assert hashlib.sha256(orc.decompress(out, len(data))).digest() == hashlib.sha256(data).digest()
+
+
+def test_zero_fill_512MiB(L):
+    data = bytes(512 << 20)
+    out, st = _encode(L, data)
+    assert len(out) < 4096
+    assert orc.decompress(out, len(data)) == data
