@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mib", type=int, default=WORKLOAD_BYTES >> 20, help="per-GPU batch size in MiB")
-    ap.add_argument("--segment-bytes", type=int, default=4096)
+    ap.add_argument("--segment-bytes", type=int, default=0, help="bytes per parse chain (0 = the library's choice for the input size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -150,6 +150,7 @@ def main():
         agg["commands"] = s[2]
         agg["rounds"] += s[0]
         nseg = s[29]
+        seg_bytes = s[30]
         phases = s[10:20]
         lz_ms, mb_ms, lib_ms = s[7], s[8], s[9]
     torch.cuda.synchronize()
@@ -191,7 +192,7 @@ def main():
                                "%s" % (args.mib, "one-shot BrotliEncoderCompress semantics (H6 hasher)" if world == 1 else
                                        "compress_multi chunk per GPU + RCCL gather + BroCatli stitch"),
                    "input_bytes_total": total, "compressed_bytes": len(comp), "ratio": round(total / max(1, len(comp)), 4),
-                   "segment_bytes": args.segment_bytes, "lz77_rounds_per_step": agg["rounds"] / args.steps,
+                   "segment_bytes": int(seg_bytes), "lz77_rounds_per_step": agg["rounds"] / args.steps,
                    "stage_ms_last_step": {"lz77": round(lz_ms, 2), "metablock": round(mb_ms, 2), "phases": [round(x, 2) for x in phases], "library_total": round(lib_ms, 2)}},
         "roofline": {"bound": "hbm", "kernel": "k_parse_segments", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -35,7 +35,7 @@ def shard_params(params, rank):
 class ShardEncoder(object):
     """Binds the flat entry point brotli_mi355x_encode_stream of a loaded library (product or emulation)."""
 
-    def __init__(self, cdll, segment_bytes=4096):
+    def __init__(self, cdll, segment_bytes=0):
         self.L = cdll
         self.segment_bytes = segment_bytes
         f = self.L.brotli_mi355x_encode_stream

@@ -174,6 +174,13 @@ struct Clock {
 
 }  // namespace
 
+uint32_t ChooseSegmentBytes(size_t input_bytes) {
+  if (input_bytes <= ((size_t)4 << 20)) return 512;
+  if (input_bytes <= ((size_t)16 << 20)) return 1024;
+  if (input_bytes <= ((size_t)128 << 20)) return 2048;
+  return 4096;
+}
+
 void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeStats* stats_out) {
   EncodeStats stats;
   Clock total_clock;
@@ -279,9 +286,10 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     return;
   }
 
+  const uint32_t segment_bytes = req.segment_bytes ? req.segment_bytes : ChooseSegmentBytes(n);
   {
     Clock c;
-    lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, req.segment_bytes);
+    lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, segment_bytes);
     stats.ms_phase[9] = c.lap(prof);
   }
   for (;;) {  // repeated only when a compressed meta-block turns out larger than its raw form
@@ -299,7 +307,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       stats.parse_launches += launches;
       stats.parse_segments += segs;
       stats.num_segments = lz.device_params().num_segments;
-      stats.segment_bytes = req.segment_bytes;
+      stats.segment_bytes = segment_bytes;
     }
     stats.lz77_rounds += lz.stats().rounds;
     stats.searches = lz.stats().searches;

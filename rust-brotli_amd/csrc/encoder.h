@@ -40,7 +40,7 @@ struct EncodeRequest {
   size_t prefix_size = 0;
   bool prefix_is_file_continuation = false;  // compress_multi semantics: prev bytes come from the prefix
   bool hasher_chosen_before_size_hint = false;  // custom dictionary path picks the hasher early
-  uint32_t segment_bytes = 4096;
+  uint32_t segment_bytes = 0;  // bytes per parse chain; 0 = chosen from the input size (ChooseSegmentBytes)
   // optional: the stream is written straight into this buffer instead of `out` (one device-to-host copy, no
   // intermediate vector); too small a buffer is an error
   uint8_t* direct_out = nullptr;
@@ -50,6 +50,10 @@ struct EncodeRequest {
 
 // Compresses one stream.  Output is appended to `out`.  Throws std::runtime_error on device errors or
 // unsupported parameters (there is no CPU fallback).
+// Segment size of the speculative parse: short segments give low latency (few, short chains finish quickly), long ones
+// less per-segment overhead (warm-up, resolver work) on big inputs.
+uint32_t ChooseSegmentBytes(size_t input_bytes);
+
 void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeStats* stats);
 
 }  // namespace brotli_mi355x

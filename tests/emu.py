@@ -77,7 +77,7 @@ def bind_encode(L):
     return L
 
 
-def encode_stream(L, data, params, prefix=b"", continuation=True, segment_bytes=4096):
+def encode_stream(L, data, params, prefix=b"", continuation=True, segment_bytes=0):
     """params: list of (BrotliEncoderParameter id, value).  Returns (bytes, stats dict)."""
     bind_encode(L)
     keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
