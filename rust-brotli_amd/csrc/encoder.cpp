@@ -21,12 +21,27 @@ namespace {
 
 struct DevMem {
   std::vector<void*> ptrs;
+  // small buffers are carved out of zero-filled arenas (one fill per arena instead of one tiny fill kernel each)
+  static constexpr size_t kArenaBytes = (size_t)4 << 20, kSmall = (size_t)256 << 10;
+  uint8_t* arena = nullptr;
+  size_t arena_used = kArenaBytes;
   ~DevMem() {
     for (void* p : ptrs) dev_free(p);
   }
   template <typename T>
   T* alloc(size_t count) {
-    void* p = dev_alloc(count * sizeof(T) + 64);
+    const size_t bytes = (count * sizeof(T) + 64 + 255) & ~(size_t)255;
+    if (bytes <= kSmall) {
+      if (arena_used + bytes > kArenaBytes) {
+        arena = (uint8_t*)dev_alloc(kArenaBytes);
+        ptrs.push_back(arena);
+        arena_used = 0;
+      }
+      T* p = (T*)(arena + arena_used);
+      arena_used += bytes;
+      return p;
+    }
+    void* p = dev_alloc(bytes);
     ptrs.push_back(p);
     return (T*)p;
   }
@@ -392,13 +407,14 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       }
     }
     dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+    uint32_t* boundary_words = mm.alloc<uint32_t>(n_mb + 1);
     mb_command_scans(B, scan_scratch);
     mb_literal_map(B);
     // distance symbol counts per meta-block
     {
       std::vector<uint32_t> di(n_mb + 1);
-      for (uint32_t m = 0; m < n_mb; ++m) dev_d2h(&di[m], B.cmd_dist_index + descs[m].cmd_offset, 4);
-      dev_d2h(&di[n_mb], B.cmd_dist_index + K, 4);
+      mb_gather_at_metablock_starts(B, B.cmd_dist_index, boundary_words);
+      dev_d2h(di.data(), boundary_words, (n_mb + 1) * 4);
       for (uint32_t m = 0; m < n_mb; ++m) {
         descs[m].dist_base = di[m];
         descs[m].n_dists = di[m + 1] - di[m];
@@ -489,8 +505,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     mb_symbol_bits(B, scan_scratch);
     dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
     std::vector<uint32_t> body_off(n_mb + 1);
-    for (uint32_t m = 0; m < n_mb; ++m) dev_d2h(&body_off[m], B.cmd_nbits + descs[m].cmd_offset, 4);
-    dev_d2h(&body_off[n_mb], B.cmd_nbits + K, 4);
+    mb_gather_at_metablock_starts(B, B.cmd_nbits, boundary_words);
+    dev_d2h(body_off.data(), boundary_words, (n_mb + 1) * 4);
     stats.ms_phase[6] += clk.lap(prof);
 
     // ---- layout of the stream (WriteMetaBlockInternal, encode.rs:1941-2167)

@@ -25,6 +25,8 @@ struct CodeJob {
 size_t mb_scan_scratch_bytes(size_t n);
 // per command insert_len / insert+copy / has-distance and their exclusive scans ([K] = totals)
 void mb_command_scans(const MbBuffers& B, void* scan_scratch);
+// out_dev[m] = src[first command of meta-block m], out_dev[n_mb] = src[n_cmds]  (descs must be on the device)
+void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint32_t* out_dev);
 void mb_literal_map(const MbBuffers& B);
 void mb_context_stats(const MbBuffers& B, uint32_t* stats_dev);
 void mb_granule_histograms(const MbBuffers& B);

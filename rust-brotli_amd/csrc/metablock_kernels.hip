@@ -24,6 +24,14 @@ static void for_each(uint32_t n, F f) {
   hipLaunchKernelGGL(k_for_each<F>, dim3((n + 255) / 256), dim3(256), 0, 0, n, f);
 }
 
+// out[m] = src[descs[m].cmd_offset] for every meta-block, out[n_mb] = src[n_cmds]: the per-meta-block boundaries of an
+// exclusive scan over the commands, fetched with one copy instead of one per meta-block
+void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint32_t* out_dev) {
+  const MbBuffers b = B;
+  for_each(b.n_mb + 1, [b, src, out_dev] __device__(uint32_t m) { out_dev[m] = src[m < b.n_mb ? b.descs[m].cmd_offset : b.n_cmds]; });
+  HIP_CHECK(hipGetLastError());
+}
+
 void mb_command_scans(const MbBuffers& B, void* scan_scratch) {
   const MbBuffers b = B;
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_counts(b, c); });

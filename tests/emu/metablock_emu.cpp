@@ -21,6 +21,10 @@ static void exclusive_scan(uint32_t* a, size_t n) {
   }
 }
 
+void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint32_t* out) {
+  for (uint32_t m = 0; m <= B.n_mb; ++m) out[m] = src[m < B.n_mb ? B.descs[m].cmd_offset : B.n_cmds];
+}
+
 void mb_command_scans(const MbBuffers& B, void*) {
   for (uint32_t c = 0; c < B.n_cmds; ++c) mb_item_command_counts(B, c);
   B.cmd_lit_start[B.n_cmds] = 0;
