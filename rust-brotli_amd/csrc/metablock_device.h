@@ -125,7 +125,28 @@ BR_DEV bool br_sort_cmp(const HuffmanTree& v0, const HuffmanTree& v1) {  // entr
 }
 
 // SortHuffmanTreeItems, entropy_encode.rs:71-116 (insertion sort below 13 items, else shell sort)
-BR_DEV void br_sort_huffman_tree_items(HuffmanTree* items, uint32_t n) {
+// coop_tmp != nullptr (device only): all 64 lanes of the wavefront are executing this call with identical state; the order
+// is a strict total order (count, then symbol), so any sorting method gives the reference's result -- here a rank sort:
+// every lane counts, for its items, how many items precede them.
+BR_DEV void br_sort_huffman_tree_items(HuffmanTree* items, uint32_t n, HuffmanTree* coop_tmp) {
+#if !defined(BROTLI_HOST_EMU)
+  if (coop_tmp != nullptr && n >= 13) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t e = lane; e < n; e += 64) coop_tmp[e] = items[e];
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t e = lane; e < n; e += 64) {
+      const HuffmanTree mine = coop_tmp[e];
+      uint32_t rank = 0;
+      for (uint32_t f = 0; f < n; ++f) rank += br_sort_cmp(coop_tmp[f], mine) ? 1u : 0u;
+      items[rank] = mine;
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
+#endif
+  (void)coop_tmp;
   const uint32_t gaps[6] = {132, 57, 23, 10, 4, 1};
   if (n < 13) {
     for (uint32_t i = 1; i < n; ++i) {
@@ -153,7 +174,8 @@ BR_DEV void br_sort_huffman_tree_items(HuffmanTree* items, uint32_t n) {
 }
 
 // BrotliCreateHuffmanTree, entropy_encode.rs:133-210.  tree must hold 2*length+1 nodes.
-BR_DEV void br_create_huffman_tree(const uint32_t* data, uint32_t length, int tree_limit, HuffmanTree* tree, uint8_t* depth) {
+BR_DEV void br_create_huffman_tree(const uint32_t* data, uint32_t length, int tree_limit, HuffmanTree* tree, uint8_t* depth,
+                                   HuffmanTree* coop_tmp = nullptr) {
   HuffmanTree sentinel;
   sentinel.total_count_ = 0xffffffffu;
   sentinel.index_left_ = -1;
@@ -173,7 +195,7 @@ BR_DEV void br_create_huffman_tree(const uint32_t* data, uint32_t length, int tr
       depth[tree[0].index_right_or_value_] = 1;
       break;
     }
-    br_sort_huffman_tree_items(tree, n);
+    br_sort_huffman_tree_items(tree, n, coop_tmp);
     tree[n] = sentinel;
     tree[n + 1] = sentinel;
     uint32_t i = 0, j = n + 1;
@@ -426,6 +448,7 @@ struct HuffmanScratch {
   uint8_t rle_extra[704];
   uint8_t good_for_rle[704];
   uint8_t pad[8];
+  HuffmanTree sort_tmp[704];  // cooperative sort only
 };
 
 // BrotliStoreHuffmanTree (+ ...OfHuffmanTreeToBitMask, ...ToBitMask), brotli_bit_stream.rs:764-911
@@ -490,7 +513,7 @@ BR_DEV void br_store_huffman_tree(const uint8_t* depths, uint32_t num, HuffmanSc
 
 // BuildAndStoreHuffmanTree, brotli_bit_stream.rs:1445-1498 (+ StoreSimpleHuffmanTree :1401-1443)
 BR_DEV void br_build_and_store_huffman_tree(const uint32_t* histogram, uint32_t histogram_length, uint32_t alphabet_size,
-                                            HuffmanScratch* sc, uint8_t* depth, uint16_t* bits, BitSink& out) {
+                                            HuffmanScratch* sc, uint8_t* depth, uint16_t* bits, BitSink& out, bool coop = false) {
   uint32_t count = 0;
   uint32_t s4[4] = {0, 0, 0, 0};
   uint32_t max_bits = 0;
@@ -513,7 +536,7 @@ BR_DEV void br_build_and_store_huffman_tree(const uint32_t* histogram, uint32_t 
     return;
   }
   for (uint32_t i = 0; i < histogram_length; ++i) depth[i] = 0;
-  br_create_huffman_tree(histogram, histogram_length, 15, sc->tree, depth);
+  br_create_huffman_tree(histogram, histogram_length, 15, sc->tree, depth, coop ? sc->sort_tmp : nullptr);
   br_convert_bit_depths_to_symbols(depth, histogram_length, bits);
   if (count <= 4) {
     out.put(2, 1);

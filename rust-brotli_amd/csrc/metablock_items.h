@@ -403,8 +403,11 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
 // ---- K5: one histogram -> optimised counts, code lengths, codes and its serialised tree
 // core of the job on explicit buffers (the device kernel stages them in LDS): h[row] in/out, depth[row], bits[row],
 // words[kTreeBitsWords] out; returns the number of header bits
+// coop: the call is made by all 64 lanes of a wavefront in lock step on the same (LDS) buffers -- every lane redoes the
+// same scalar work (stores of identical values, ORs of identical bits), which costs nothing extra on SIMT hardware and
+// lets the O(n^2 / 64) sort inside use all lanes.
 BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols, uint32_t* h, uint8_t* depth, uint16_t* bits,
-                                   uint64_t* words, HuffmanScratch* sc) {
+                                   uint64_t* words, HuffmanScratch* sc, bool coop = false) {
   const uint32_t row = kRowLen[kind];
   // BrotliOptimizeHistograms (metablock.rs:1076-1108): literal 256, command 704, distance min(alphabet, 544)
   uint32_t opt_len = row;
@@ -425,7 +428,7 @@ BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols,
   BitSink sink;
   sink.words = words;
   sink.pos = 0;
-  br_build_and_store_huffman_tree(h, hist_len, alphabet, sc, depth, bits, sink);
+  br_build_and_store_huffman_tree(h, hist_len, alphabet, sc, depth, bits, sink, coop);
   return (uint32_t)sink.pos;
 }
 

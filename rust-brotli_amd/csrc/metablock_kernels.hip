@@ -143,7 +143,10 @@ __global__ __launch_bounds__(64) void k_build_codes(MbBuffers B, const CodeJob* 
   uint32_t* gh = B.histo[j.kind] + (size_t)j.row_index * row;
   for (uint32_t k = threadIdx.x; k < row; k += 64) h[k] = gh[k];
   __syncthreads();
-  if (threadIdx.x == 0) nbits = mb_build_code_core(j.kind, j.num_distance_symbols, h, depth, bits, words, &sc);
+  {
+    const uint32_t nb = mb_build_code_core(j.kind, j.num_distance_symbols, h, depth, bits, words, &sc, true);
+    if (threadIdx.x == 0) nbits = nb;
+  }
   __syncthreads();
   uint8_t* gd = B.depth[j.kind] + (size_t)j.row_index * row;
   uint16_t* gb = B.bits[j.kind] + (size_t)j.row_index * row;
