@@ -933,10 +933,11 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
 // round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
 // written to entries[] so that the host resolver sees what it was parsed with.
 BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment* segments,
-                           SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched) {
+                           SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
   SegEntry entry = entries[k];
-  // a chain takes at most kMaxContinuation further segments: what it leaves behind is picked up in the next round by
-  // a chain of its own, so that one launch never lasts much longer than a handful of segment parses
+  // a chain takes at most max_continuation further segments: what it leaves behind is picked up in the next round by
+  // a chain of its own, so that a launch with many chains never lasts much longer than a handful of segment parses
+  // (launches with only a few chains are latency bound anyway and let them run to the end of the block)
   uint32_t continued = 0;
   for (;;) {
     const Segment seg = segments[k];
@@ -945,7 +946,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
     const uint32_t mark = sched[k + 1];
     if (mark == 1 || mark == 3) break;  // has its own chain in this launch
-    if (continued >= kMaxContinuation) break;
+    if (continued >= max_continuation) break;
     ++continued;
     const bool forced = mark == 2;     // left to this chain, must be redone whatever state we arrive with
     const SegEntry old = entries[k + 1];

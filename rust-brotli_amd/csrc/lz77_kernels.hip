@@ -468,6 +468,7 @@ struct ParseArgs {
   uint8_t* sched;  // list rounds: per segment, 1 if it is in the list (see br_parse_chain)
   uint32_t count;
   uint32_t per_xcd;      // 0: identity mapping
+  uint32_t max_continuation;
 };
 
 struct ParseTiming {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
   if (a.per_xcd) item = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
   if (item >= a.count) return;
   const uint32_t k = a.list ? a.list[item] : a.first_segment + item;
-  br_parse_chain(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched);
+  br_parse_chain(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
 }
 
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
@@ -513,6 +514,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.first_segment = first_segment;
   a.list = list;
   a.sched = sched;
+  a.max_continuation = count <= 256 ? 1024u : kMaxContinuation;
   a.count = count;
   // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
   ParseTiming& pt = parse_timing();

@@ -99,7 +99,8 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
   B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
-  B_.cmds = (Command*)dev_alloc((size_t)segments_.size() * P_.cmd_slab_stride * sizeof(Command) + 64);
+  cmds_bytes_ = (size_t)segments_.size() * P_.cmd_slab_stride * sizeof(Command) + 64;
+  B_.cmds = (Command*)dev_alloc(cmds_bytes_);
   B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
   B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
   B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
@@ -269,11 +270,9 @@ struct DictTracker {
 bool Lz77Stage::Resolve(bool final_pass) {
   const uint32_t nseg = (uint32_t)segments_.size();
   next_entries_.assign(nseg, SegEntry{});
-  if (getenv("BROTLI_MI355X_DEBUG")) {
-    dbg_mismatch_ = dbg_counts_;
-    memset(dbg_counts_, 0, sizeof(dbg_counts_));
-    memset(dbg_first_, 0, sizeof(dbg_first_));
-  }
+  dbg_mismatch_ = dbg_counts_;
+  memset(dbg_counts_, 0, sizeof(dbg_counts_));
+  memset(dbg_first_, 0, sizeof(dbg_first_));
   metablocks_.clear();
   patches_.clear();
   trailing_.clear();
@@ -344,6 +343,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
       mark(k0, same);
     }
     next_entries_[k0] = E;
+    block_entry_guess_[bs] = E;
     // ---- chain through the segments of the block
     uint32_t carry = last_insert_len;  // literals pending when the segment is entered
     int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
@@ -525,7 +525,12 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
   }
   for (uint32_t i = 0; i < count; ++i) {
     SegEntry& e = entries_[ks[i] + 1];
-    memcpy(e.cache, wexits[i].cache, sizeof(e.cache));
+    // distance cache guess: the pushes the dry run made, on top of the guess for the segment it ran in (a dry run that
+    // pushed fewer than 4 distances still carries its cold start values behind them)
+    const uint32_t np = std::min<uint32_t>(wexits[i].n_pushes, 4);
+    int32_t guess[4];
+    for (uint32_t c = 0; c < 4; ++c) guess[c] = c < np ? wexits[i].cache[c] : entries_[ks[i]].cache[c - np];
+    memcpy(e.cache, guess, sizeof(e.cache));
     if (!(segments_[ks[i] + 1].flags & kSegFirstInBlock)) {
       e.pos = wexits[i].pos;
       e.apply = wexits[i].apply;
@@ -589,6 +594,33 @@ void Lz77Stage::Run() {
   dev_d2h(key_first_.data(), B_.key_first, 65537 * 4);
   dev_d2h(key_last_.data(), B_.key_last, 65537 * 4);
   tm.stop(&stats_.ms_sort);
+  tm.stop(&stats_.ms_sort);
+  RunRounds(true);
+  tm.stop(&stats_.ms_resolve);
+  Gather();
+  tm.stop(&stats_.ms_gather);
+  total.stop(&stats_.ms_total);
+}
+
+// Re-cut the input into segments of a different size (the sort by key stays valid).
+void Lz77Stage::Resegment(uint32_t segment_bytes) {
+  segment_bytes_ = std::min(std::max(segment_bytes, 256u), block_bytes_);
+  P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
+  BuildSegments();
+  P_.num_segments = (uint32_t)segments_.size();
+  const size_t need = (size_t)segments_.size() * P_.cmd_slab_stride * sizeof(Command) + 64;
+  if (need > cmds_bytes_) {
+    dev_free(B_.cmds);
+    B_.cmds = (Command*)dev_alloc(need);
+    cmds_bytes_ = need;
+  }
+  dev_h2d(B_.segments, segments_.data(), segments_.size() * sizeof(Segment));
+}
+
+void Lz77Stage::RunRounds(bool allow_restart) {
+  const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
+  Timer tm(prof);
+  const uint32_t nseg = (uint32_t)segments_.size();
   InitFlags();
   tm.stop(&stats_.ms_init);
   const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
@@ -648,6 +680,17 @@ void Lz77Stage::Run() {
     }
     tm.stop(&stats_.ms_warmup);
   }
+  if (!allow_restart && !saved_block_guess_.empty()) {
+    // second pass after a coarse restart: the first pass chained the distance cache through every segment of the
+    // input, which beats the dry run's view of the last few hundred bytes of each block
+    for (uint32_t k = 0; k < nseg; ++k) {
+      if (!(segments_[k].flags & kSegFirstInBlock)) continue;
+      auto it = saved_block_guess_.find(segments_[k].blk_start);
+      if (it == saved_block_guess_.end()) continue;
+      memcpy(entries_[k].cache, it->second.cache, sizeof(entries_[k].cache));
+      entries_[k].ext_allowed = it->second.ext_allowed;
+    }
+  }
   // ---- rounds.  Round 0 parses every segment; later rounds re-parse only the segments whose entry state
   // changed or that searched a position whose candidate list changed with the flags (lz77_validate).
   SegGeometry geo{};
@@ -668,6 +711,7 @@ void Lz77Stage::Run() {
   uint32_t count = nseg;
   const uint32_t max_rounds = nseg + 8;
   bool done = false;
+  bool restart = false;
   bool full_round = true;
   uint32_t last_death_seg = 0xffffffffu;
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
@@ -725,6 +769,12 @@ void Lz77Stage::Run() {
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
     uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
     for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
+    // (dbg_counts_[0]: chains that were started at the wrong position -- the signature of sparse hashing / long runs,
+    // where the phase of the previous chain never washes out)
+    if (round == 0 && allow_restart && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)dbg_counts_[0] * 2 > nseg) {
+      restart = true;
+      break;
+    }
     uint32_t n_changed = 0;
     dev_d2h(&n_changed, B_.changed_count, 4);
     cand_dirty.clear();
@@ -799,9 +849,7 @@ void Lz77Stage::Run() {
                 next_entries_[k].head_base, exits_[k].pos);
     }
     was_dirty = dirty;
-    // speculation is failing broadly (or we are in the tail of the iteration): do not guess at all behind a segment
-    // that is being redone
-    const bool aggressive = (uint64_t)n_dirty_entry * 8 > nseg || round >= 2;
+    const bool aggressive = false;
     count = 0;
     for (uint32_t k = 0; k < nseg; ++k) {
       sched[k] = 0;
@@ -835,6 +883,15 @@ void Lz77Stage::Run() {
   }
   dev_free(dirty_dev);
   dev_free(list_dev);
+  if (restart) {
+    saved_block_guess_ = block_entry_guess_;  // what the pass so far says about the state at every block start
+    // Hardly any guess held: this input does not re-synchronise (incompressible stretches, data whose parse hangs on
+    // the distance cache).  Parse it one chain per input block instead -- nothing is guessed inside a block then.
+    Resegment(block_bytes_);
+    stats_.coarse_restarts++;
+    RunRounds(false);
+    return;
+  }
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
   final_flags_ = which;
   if (selftest) {
@@ -847,10 +904,8 @@ void Lz77Stage::Run() {
       fprintf(stderr, "  seg %u [%u,%u) entry pos %u | exit pos %u insert %u cmds %u lits %u searches %u\n", k, segments_[k].start, segments_[k].end,
               entries_[k].pos, exits_[k].pos, exits_[k].insert_len, exits_[k].n_cmds, exits_[k].n_lits, exits_[k].n_searches);
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
-  Gather();
-  tm.stop(&stats_.ms_gather);
-  total.stop(&stats_.ms_total);
 }
+
 
 void Lz77Stage::DumpFlags(uint8_t* out, size_t size) const {
   dev_sync();

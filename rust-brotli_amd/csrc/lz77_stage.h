@@ -35,7 +35,7 @@ struct Lz77Stats {
   uint64_t segments_parsed = 0;
   uint64_t searches = 0;
   uint64_t total_commands = 0;
-  uint32_t incremental_ranks = 0, full_ranks = 0;
+  uint32_t incremental_ranks = 0, full_ranks = 0, coarse_restarts = 0;
   // wall-clock milliseconds per phase (device synchronised), filled when profiling is enabled
   double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
@@ -69,6 +69,8 @@ class Lz77Stage {
 
  private:
   void BuildSegments();
+  void Resegment(uint32_t segment_bytes);
+  void RunRounds(bool allow_restart);
   void InitFlags();
   bool Resolve(bool final_pass);
   void Gather();
@@ -89,6 +91,8 @@ class Lz77Stage {
   std::vector<double> warm_lookups_, warm_matches_;  // per segment, forecast from the warm-up dry run
   uint32_t predicted_death_ = 0xffffffffu;
   int final_flags_ = 0;
+  std::map<uint32_t, SegEntry> block_entry_guess_, saved_block_guess_;  // by block start
+  size_t cmds_bytes_ = 0;
   std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
   std::vector<SegEntry> entries_;   // entries used by the most recent parse
   std::vector<SegEntry> next_entries_;

@@ -175,7 +175,7 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   ChainScratch scratch;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
-    br_parse_chain(P, T, scratch, segments, entries, exits, k, sched);
+    br_parse_chain(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
   }
 }
 
