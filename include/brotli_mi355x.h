@@ -12,9 +12,11 @@
  * (BROTLI_FALSE / 0 / NULL) and print the reason on stderr.
  *
  * Streaming: input handed over with BROTLI_OPERATION_PROCESS is buffered (the encoder owns a copy, as the
- * reference's ring buffer does); the stream is produced at BROTLI_OPERATION_FINISH.
- * BROTLI_OPERATION_FLUSH and BROTLI_OPERATION_EMIT_METADATA are not implemented yet and return
- * BROTLI_FALSE.
+ * reference's ring buffer does); output is produced at BROTLI_OPERATION_FLUSH (everything handed over so far,
+ * byte-identical to what the reference emits for the same flush points, encode.rs:2940-2975 + 1541-1566) and at
+ * BROTLI_OPERATION_FINISH.  A flushed stream keeps its whole input on the host and re-indexes it at every flush
+ * (cost proportional to the stream so far; at most 1 GiB), and cannot be combined with a custom dictionary or the
+ * catable / appendable modes.  BROTLI_OPERATION_EMIT_METADATA is not implemented and returns BROTLI_FALSE.
  */
 #ifndef BROTLI_MI355X_H_
 #define BROTLI_MI355X_H_

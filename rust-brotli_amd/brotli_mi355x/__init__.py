@@ -242,13 +242,22 @@ class Encoder(object):
     def write(self, data):
         self._stream(BROTLI_OPERATION_PROCESS, data)
 
+    def flush(self, data=b""):
+        """BROTLI_OPERATION_FLUSH (CompressorWriter::flush, src/enc/writer.rs): everything written so far becomes
+        decodable; returns the bytes produced since the last flush / start"""
+        self._stream(BROTLI_OPERATION_FLUSH, data)
+        piece = bytes(self._out)
+        self._flushed = getattr(self, "_flushed", b"") + piece
+        self._out = bytearray()
+        return piece
+
     def set_parameter(self, key, value):
         return bool(self._l.lib.BrotliEncoderSetParameter(self._s, int(key), int(value)))
 
     def finish(self):
         self._stream(BROTLI_OPERATION_FINISH, b"")
         assert self._l.lib.BrotliEncoderIsFinished(self._s)
-        return bytes(self._out)
+        return bytes(self._out)  # (after flush() calls: the remainder of the stream)
 
     def close(self):
         if self._s:

@@ -48,6 +48,9 @@ struct BrotliEncoderStateStruct {
   size_t output_pos;
   uint64_t total_out;
   uint64_t total_in;
+  // BROTLI_OPERATION_FLUSH: `input` keeps the whole stream, [0, encoded_upto) of it is already in the output
+  size_t encoded_upto;
+  StreamCarry carry;
 };
 
 struct BrotliEncoderWorkPoolStruct {
@@ -69,13 +72,24 @@ size_t BlockSize(const EncoderParams& user) {
   return (size_t)1 << p.lgblock;
 }
 
-// Runs the device encoder over everything buffered so far (called at FINISH).
-bool EncodeBuffered(BrotliEncoderState* s) {
+// Runs the device encoder over everything buffered since the last flush (FLUSH: finish = false, FINISH: true).
+bool EncodeBuffered(BrotliEncoderState* s, bool finish) {
   try {
     EncodeRequest req;
     req.params = s->params;
-    req.input = s->input.data();
-    req.input_size = s->input.size();
+    req.input = s->input.data() + s->encoded_upto;
+    req.input_size = s->input.size() - s->encoded_upto;
+    req.finish = finish;
+    const bool flushed_stream = !finish || s->carry.valid;
+    if (flushed_stream) {
+      if (s->has_dictionary || s->params.catable || s->params.appendable)
+        throw std::runtime_error("BROTLI_OPERATION_FLUSH is not supported together with a custom dictionary or catable / appendable streams");
+      req.prefix = s->encoded_upto ? s->input.data() : nullptr;
+      req.prefix_size = s->encoded_upto;
+      req.prefix_is_file_continuation = true;
+      req.carry_in = &s->carry;
+      req.carry_out = &s->carry;
+    }
     if (s->has_dictionary) {
       // set_custom_dictionary (encode.rs:1196-1270): last (1 << lgwin) - 16 bytes, no static dictionary,
       // hasher chosen before any size hint, prev bytes stay 0
@@ -90,10 +104,13 @@ bool EncodeBuffered(BrotliEncoderState* s) {
       req.hasher_chosen_before_size_hint = true;
       req.params.use_dictionary = false;
     }
-    std::vector<uint8_t> out;
-    EncodeStream(req, &out, nullptr);
-    s->output.swap(out);
-    s->output_pos = 0;
+    // output not yet taken by the caller stays in front
+    if (s->output_pos != 0) {
+      s->output.erase(s->output.begin(), s->output.begin() + (ptrdiff_t)s->output_pos);
+      s->output_pos = 0;
+    }
+    EncodeStream(req, &s->output, nullptr);
+    s->encoded_upto = s->input.size();
     return true;
   } catch (const std::exception& e) {
     SetError("BrotliEncoderCompressStream", e.what());
@@ -242,6 +259,7 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, br
   s->output_pos = 0;
   s->total_out = 0;
   s->total_in = 0;
+  s->encoded_upto = 0;
   return s;
 }
 
@@ -271,8 +289,8 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
                                         size_t* total_out) {
   if (!s || s->failed) return BROTLI_FALSE;
   EnsureInitialized(s);
-  if (op == BROTLI_OPERATION_EMIT_METADATA || op == BROTLI_OPERATION_FLUSH) {
-    SetError("BrotliEncoderCompressStream", "BROTLI_OPERATION_FLUSH / EMIT_METADATA are not implemented on the device path");
+  if (op == BROTLI_OPERATION_EMIT_METADATA) {
+    SetError("BrotliEncoderCompressStream", "BROTLI_OPERATION_EMIT_METADATA is not implemented on the device path");
     return BROTLI_FALSE;
   }
   if (s->stream_state != kProcessing && *available_in != 0) return BROTLI_FALSE;  // encode.rs:2918-2922
@@ -290,9 +308,14 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
       if (s->params.size_hint == 0) s->params.size_hint = std::min<size_t>(s->input.size(), (size_t)1 << 30);
     }
     if (op == BROTLI_OPERATION_FINISH) {
-      if (!EncodeBuffered(s)) return BROTLI_FALSE;
+      if (!EncodeBuffered(s, true)) return BROTLI_FALSE;
       s->stream_state = kFinished;
       std::vector<uint8_t>().swap(s->input);
+    } else if (op == BROTLI_OPERATION_FLUSH) {
+      // everything handed over so far becomes decodable output (encode.rs:2940-2975 with force_flush, then the
+      // injected byte-alignment block :1541-1566); the encoder keeps the stream so far as the window of what follows
+      // (repeated FLUSH calls that only drain output must not encode again)
+      if (!(s->carry.valid && s->encoded_upto == s->input.size()) && !EncodeBuffered(s, false)) return BROTLI_FALSE;
     }
   }
   // push output (inject_flush_or_push_output, encode.rs:1568-1598)

@@ -68,13 +68,17 @@ size_t lz77_sort_tmp_bytes(uint32_t total_bytes);
 void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
 // first guess of the stored flags (both buffers): prefix positions, stitch positions and block tails are
 // static, everything else is assumed stored
-void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start);
+// (prefix_flags_host: optional stored flags of the first prefix_flags_bytes positions, for the continuation of a
+// stream after a flush; otherwise the prefix is a custom dictionary that was stored position by position)
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host = nullptr,
+                     uint32_t prefix_flags_bytes = 0);
 // stable sort of positions by key -> by_key / sorted_keys
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
 // sorted[rbuf] / info[rbuf] from flags[which] (all keys).  `initial` (optional): flags[which] is still exactly what
 // lz77_init_flags wrote, which lets the kernel skip most of the random flag reads.
 struct RankInitialHint {
   uint32_t first_block_start, block_bytes;
+  uint32_t prefix_is_dictionary;  // the prefix flags follow the custom-dictionary rule (all stored but the last htl - 1)
 };
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint* initial = nullptr);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through

@@ -204,27 +204,33 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   const size_t n = req.input_size;
   if (n >= (1ull << 31) || req.prefix_size >= (1ull << 30)) throw std::runtime_error("brotli_mi355x: streams of 2 GiB or more are not supported");
   // ---- parameters, in the order the reference fixes them (encode.rs:657-707, 1604-1620, 1125-1161)
-  if (req.prefix_size) p.use_dictionary = false;  // set_custom_dictionary, encode.rs:1213
+  const bool continuing = req.carry_in != nullptr && req.carry_in->valid;  // a later piece of a flushed stream
+  if (req.prefix_size && !continuing) p.use_dictionary = false;  // set_custom_dictionary, encode.rs:1213
   FinalizeParams(&p);
-  if (req.hasher_chosen_before_size_hint) ChooseHasher(&p);  // custom dictionary: hasher_setup runs before any size hint
-  if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
-  if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
+  if (continuing) {
+    p.size_hint = req.carry_in->size_hint;  // both were fixed by the first encode_data of the stream
+    p.hasher = req.carry_in->hasher;
+  } else {
+    if (req.hasher_chosen_before_size_hint) ChooseHasher(&p);  // custom dictionary: hasher_setup runs before any size hint
+    if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
+    if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
+  }
   const char* why = nullptr;
   if (!IsAccelerated(p, &why)) throw std::runtime_error(std::string("brotli_mi355x: ") + why);
   bool catable = p.catable;
   bool appendable = p.appendable;
-  if (req.prefix != nullptr && (req.prefix_size <= 1)) {
+  if (!continuing && req.carry_in == nullptr && req.prefix != nullptr && (req.prefix_size <= 1)) {
     // set_custom_dictionary with a too-short dictionary: no priming, but catable + appendable (encode.rs:1237-1241)
     catable = true;
     appendable = true;
   }
   p.catable = catable;
   p.appendable = appendable;
-  const uint32_t prefix_bytes = req.prefix_size > 1 ? (uint32_t)req.prefix_size : 0;
+  const uint32_t prefix_bytes = (continuing || req.prefix_size > 1) ? (uint32_t)req.prefix_size : 0;
 
   HostBits hb;
   // stream header: window bits (EncodeWindowBits, encode.rs:603-625)
-  if (!(req.params.catable && p.bare_stream)) {
+  if (!continuing && !(req.params.catable && p.bare_stream)) {
     const int lgwin = p.lgwin;
     if (p.large_window) {
       hb.put(14, (uint64_t)(((lgwin & 0x3F) << 8) | 0x11));
@@ -238,8 +244,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       hb.put(7, (uint64_t)(((lgwin - 8) << 4) | 1));
     }
   }
-  if (p.magic_number) WriteMetadataMetaBlock(p, &hb);
-  if (n == 0 && p.byte_align && p.appendable && !p.catable && (hb.pos & 7) != 0) {
+  if (p.magic_number && !continuing) WriteMetadataMetaBlock(p, &hb);
+  if (!continuing && req.finish && n == 0 && p.byte_align && p.appendable && !p.catable && (hb.pos & 7) != 0) {
     hb.put(6, 6);
     hb.jump_to_byte_boundary();
   }
@@ -280,7 +286,23 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   bool wrote_direct = false;
   if (n - raw_head == 0) {
     // nothing left to search: only the trailing blocks (encode.rs:1979-1982)
-    WriteEmptyLastBlocks(p, &hb);
+    if (req.finish) {
+      WriteEmptyLastBlocks(p, &hb);
+    } else if ((hb.pos & 7) != 0) {  // injected flush: an empty metadata block pads to the byte boundary (encode.rs:1541-1566)
+      hb.put(6, 6);
+      hb.jump_to_byte_boundary();
+    }
+    if (req.carry_out) {
+      StreamCarry& co = *req.carry_out;
+      if (continuing) co = *req.carry_in;
+      if (!co.valid) {
+        co.valid = true;
+        co.hasher = p.hasher;
+        co.size_hint = p.size_hint;
+        const int32_t d0[4] = {4, 11, 15, 16};
+        memcpy(co.dist_cache, d0, sizeof(d0));
+      }
+    }
     const size_t total_bytes = (size_t)((hb.pos + 7) >> 3);
     result.assign(total_bytes + 8, 0);
     for (const BitPiece& bp : hb.pieces) {
@@ -304,6 +326,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   const uint32_t segment_bytes = req.segment_bytes ? req.segment_bytes : ChooseSegmentBytes(n);
   {
     Clock c;
+    lz.SetStreamState(continuing ? req.carry_in : nullptr, req.finish);
     lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, segment_bytes);
     stats.ms_phase[9] = c.lap(prof);
   }
@@ -545,6 +568,10 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       stats.fallback_retries++;
       continue;
     }
+    if (!req.finish && (bits.pos & 7) != 0) {  // injected flush (encode.rs:1541-1566)
+      bits.put(6, 6);
+      bits.jump_to_byte_boundary();
+    }
     // ---- emission
     const size_t total_bytes = (size_t)((bits.pos + 7) >> 3);
     const size_t out_words = total_bytes / 8 + 4;
@@ -576,6 +603,19 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       dev_d2h(result.data(), B.out_words, total_bytes);
     }
     stats.ms_phase[8] += clk.lap(prof);
+    if (req.carry_out) {
+      // state for the next piece of the stream: distance cache, dictionary counters, what is in the hash table
+      StreamCarry co;
+      co.valid = true;
+      co.hasher = p.hasher;
+      co.size_hint = p.size_hint;
+      memcpy(co.dist_cache, plans.back().dist_cache_after, sizeof(co.dist_cache));
+      lz.FinalDictState(&co.dict_lookups, &co.dict_matches, &co.dict_dead);
+      co.stored.resize(M);
+      lz.DumpFlags(co.stored.data(), M);
+      for (uint8_t& f : co.stored) f &= 1;
+      *req.carry_out = std::move(co);
+    }
     stats.metablocks = n_mb;
     stats.commands = K;
     stats.literals = L;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "encoder_params.h"
+#include "lz77_stage.h"
 
 namespace brotli_mi355x {
 
@@ -46,6 +47,12 @@ struct EncodeRequest {
   uint8_t* direct_out = nullptr;
   size_t direct_capacity = 0;
   size_t* direct_size = nullptr;
+  // BROTLI_OPERATION_FLUSH support: `prefix` is the stream encoded so far, *carry_in its state (may be !valid for the
+  // first piece); finish = false leaves the stream open (no ISLAST, padded to a byte boundary like the reference's
+  // injected flush, encode.rs:1541-1566); the state for the next piece is written to *carry_out
+  const StreamCarry* carry_in = nullptr;
+  StreamCarry* carry_out = nullptr;
+  bool finish = true;
 };
 
 // Compresses one stream.  Output is appended to `out`.  Throws std::runtime_error on device errors or

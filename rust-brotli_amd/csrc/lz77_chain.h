@@ -411,7 +411,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
 #if defined(BROTLI_HOST_EMU)
   uint32_t best_len = 0;
   uint32_t best_score = kMinScore;
-  const uint32_t brk = P.prefix_bytes;
+  const uint32_t brk = P.dict_break;
   for (uint32_t c = 0; c < ncand; ++c) {
     const uint32_t prev = s.cand_prev[w][c];
     if (prev == 0xffffffffu) {
@@ -472,7 +472,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   // block end (best_len == max_length), where the byte behind it decides.
   uint32_t best_len = 0;
   uint32_t best_score = kMinScore;
-  const uint32_t brk = P.prefix_bytes;
+  const uint32_t brk = P.dict_break;
   bool walk_broken = false;
   bool folded = false;
   if (ncand <= 64) {

@@ -73,11 +73,16 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
   for (uint32_t q = store_end; q < be; ++q) flags[q] = (q + 3 >= be && (g.flags & kSegTailStitched)) ? 1 : 0;
 }
 
-void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start) {
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
+                     uint32_t prefix_flags_bytes) {
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, 0));
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), 0));  // StoreLookaheadThenStore, mod.rs:224-229
   // the catable raw head (between the prefix and the first searched block) is only stored by the stitch
+  if (prefix_flags_host && prefix_flags_bytes) {
+    // continuation of a stream: the earlier positions are in the table exactly as the earlier parse left them
+    HIP_CHECK(hipMemcpyAsync(B.flags[0], prefix_flags_host, prefix_flags_bytes, hipMemcpyHostToDevice, 0));
+  }
   if (M > first_block_start) HIP_CHECK(hipMemsetAsync(B.flags[0] + first_block_start, 1, M - first_block_start, 0));
   if (P.num_segments) {
     hipLaunchKernelGGL(k_init_flag_tails, dim3((P.num_segments + 63) / 64), dim3(64), 0, 0, B.segments, P.num_segments, htl, B.flags[0]);
@@ -315,7 +320,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
     ig.prefix_bytes = P.prefix_bytes;
     ig.block_bytes = initial->block_bytes;
     ig.total_bytes = n;
-    ig.prefix_stored_end = P.prefix_bytes > P.htl - 1 ? P.prefix_bytes - (P.htl - 1) : 0;  // StoreLookaheadThenStore, mod.rs:224-229
+    ig.prefix_stored_end = (initial->prefix_is_dictionary && P.prefix_bytes > P.htl - 1) ? P.prefix_bytes - (P.htl - 1) : 0;  // StoreLookaheadThenStore, mod.rs:224-229
   }
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;

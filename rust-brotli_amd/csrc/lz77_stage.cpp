@@ -62,6 +62,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   memset(&P_, 0, sizeof(P_));
   P_.total_bytes = prefix_bytes + input_bytes;
   P_.prefix_bytes = prefix_bytes;
+  P_.dict_break = (carry_ && carry_->valid) ? 0u : prefix_bytes;
   P_.ring_mask = (1u << ComputeRbBits(params)) - 1u;
   P_.max_backward_limit = (1u << params.lgwin) - 16u;
   P_.hasher_kind = params.hasher.type == 5 ? 5 : 6;
@@ -156,7 +157,11 @@ void Lz77Stage::BuildSegments() {
   }
 }
 
-void Lz77Stage::InitFlags() { lz77_init_flags(P_, B_, segments_.empty() ? P_.total_bytes : segments_[0].blk_start); }
+void Lz77Stage::InitFlags() {
+  const bool cont = carry_ && carry_->valid;
+  lz77_init_flags(P_, B_, segments_.empty() ? P_.total_bytes : segments_[0].blk_start, cont ? carry_->stored.data() : nullptr,
+                  cont ? (uint32_t)std::min<size_t>(carry_->stored.size(), P_.prefix_bytes) : 0u);
+}
 
 // Static-dictionary throttle state (mod.rs:1957-1960) tracked along the segments.  While the dictionary is
 // alive the exact lookup / match counters are known (alive chains report their deltas); once a chain turns it
@@ -292,6 +297,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
   if (params_.catable) {
     for (int i = 0; i < 4; ++i) cache[i] = 0x7ffffff0;  // encode.rs:693-703
   }
+  if (carry_ && carry_->valid) memcpy(cache, carry_->dist_cache, sizeof(cache));
   int32_t saved_cache[4];
   memcpy(saved_cache, cache, sizeof(cache));
   uint32_t last_insert_len = 0;
@@ -299,6 +305,11 @@ bool Lz77Stage::Resolve(bool final_pass) {
   uint32_t last_flush_pos = P_.prefix_bytes + raw_head_bytes_;
   DictTracker dict;
   dict.use = P_.use_dictionary != 0;
+  if (carry_ && carry_->valid) {
+    dict.L = carry_->dict_lookups;
+    dict.M = carry_->dict_matches;
+    if (carry_->dict_dead) dict.state = DictTracker::kDead;
+  }
   struct LastCmd {
     bool valid = false;
     uint32_t seg = 0, idx = 0, dist_code = 0, copy_len = 0;
@@ -433,7 +444,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
     mb.end = be;
     mb.n_cmds = (uint32_t)mb_cmds;
     mb.n_literals = (uint32_t)num_literals;
-    mb.is_last = is_last;
+    mb.is_last = is_last && stream_is_last_;
     mb.cmd_offset = mb_first_seg;  // temporarily: first segment; turned into a command offset by Gather()
     memcpy(mb.saved_dist_cache, saved_cache, sizeof(saved_cache));
     // should_compress, encode.rs:1325-1354
@@ -470,6 +481,9 @@ bool Lz77Stage::Resolve(bool final_pass) {
   }
   dict_death_seg_ = dict.left_alive_at;
   dict_flips_ = dict.flips;
+  final_dict_lookups_ = dict.L;
+  final_dict_matches_ = dict.M;
+  final_dict_dead_ = dict.state == DictTracker::kDead || dict.state == DictTracker::kUnknown;
   return consistent;
 }
 
@@ -632,7 +646,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     e.pos = segments_[k].start;
     e.apply = segments_[k].start + P_.spree_window;
     const int32_t d[4] = {4, 11, 15, 16};
-    for (int i = 0; i < 4; ++i) e.cache[i] = params_.catable ? 0x7ffffff0 : d[i];
+    for (int i = 0; i < 4; ++i) e.cache[i] = (carry_ && carry_->valid) ? carry_->dist_cache[i] : (params_.catable ? 0x7ffffff0 : d[i]);
     if (k != 0) {
       e.dict_lookups = DictTracker::kAliveL;
       e.dict_matches = DictTracker::kAliveM;
@@ -641,7 +655,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   exits_.assign(nseg, SegExit{});
   int which = 0, rbuf = 0;
   {
-    RankInitialHint hint{segments_[0].blk_start, block_bytes_};
+    RankInitialHint hint{segments_[0].blk_start, block_bytes_, (carry_ && carry_->valid) ? 0u : 1u};
     lz77_rank_flags(P_, B_, which, rbuf, &hint);
   }
   tm.stop(&stats_.ms_rank);

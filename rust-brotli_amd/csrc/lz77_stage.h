@@ -40,6 +40,19 @@ struct Lz77Stats {
   double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
 
+// What an encoder keeps between two encode_data calls of one stream (BROTLI_OPERATION_FLUSH): the reference's hasher
+// contents, distance cache and dictionary-throttle counters.  The hasher is represented by which positions of the
+// stream so far are stored in it.
+struct StreamCarry {
+  bool valid = false;
+  int32_t dist_cache[4] = {4, 11, 15, 16};
+  uint32_t dict_lookups = 0, dict_matches = 0;
+  bool dict_dead = false;
+  std::vector<uint8_t> stored;  // per byte of the stream so far: bit 0 = the position is in the hash table
+  HasherParams hasher;          // fixed by the first encode_data (encode.rs:1125-1161)
+  size_t size_hint = 0;
+};
+
 class Lz77Stage {
  public:
   Lz77Stage() = default;
@@ -56,6 +69,19 @@ class Lz77Stage {
   // forces meta-block `index` (and only it) to be stored uncompressed in the next Run (size fallback,
   // encode.rs:2141-2163)
   void ForceUncompressed(uint32_t index) { forced_uncompressed_.push_back(index); }
+  // continuation of a stream after a flush: the prefix is the stream so far, `carry` its state; stream_is_last = false
+  // keeps the ISLAST bit off the final meta-block (more input may follow)
+  void SetStreamState(const StreamCarry* carry, bool stream_is_last) {
+    carry_ = carry;
+    stream_is_last_ = stream_is_last;
+  }
+  // state after Run() for the next continuation (dist cache comes from metablocks().back())
+  void FinalDictState(uint32_t* lookups, uint32_t* matches, bool* dead) const {
+    *lookups = final_dict_lookups_;
+    *matches = final_dict_matches_;
+    *dead = final_dict_dead_;
+  }
+  uint32_t total_bytes() const { return P_.total_bytes; }
   void set_warmup_bytes(uint32_t n) { warmup_bytes_ = n; }
   void Run();
   void DumpFlags(uint8_t* out, size_t size) const;  // test hook: final per-position flags
@@ -91,6 +117,10 @@ class Lz77Stage {
   std::vector<double> warm_lookups_, warm_matches_;  // per segment, forecast from the warm-up dry run
   uint32_t predicted_death_ = 0xffffffffu;
   int final_flags_ = 0;
+  const StreamCarry* carry_ = nullptr;
+  bool stream_is_last_ = true;
+  uint32_t final_dict_lookups_ = 0, final_dict_matches_ = 0;
+  bool final_dict_dead_ = false;
   std::map<uint32_t, SegEntry> block_entry_guess_, saved_block_guess_;  // by block start
   size_t cmds_bytes_ = 0;
   std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key

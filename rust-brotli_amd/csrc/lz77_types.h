@@ -24,7 +24,10 @@ struct Command {
 // src/enc/backward_references/mod.rs:919-1813, parameters chosen by encode.rs:834-893).
 struct Lz77Params {
   uint32_t total_bytes;         // M: dictionary prefix + input, positions are offsets into this text
-  uint32_t prefix_bytes;        // custom-dictionary prefix (ring_buffer_break), 0 = none
+  uint32_t prefix_bytes;        // bytes in front of the input: custom dictionary, or the part of the stream already
+                                // encoded before a BROTLI_OPERATION_FLUSH
+  uint32_t dict_break;          // ring_buffer_break: matches may not straddle the end of a custom dictionary
+                                // (mod.rs:42-54); 0 when the prefix is earlier stream data
   uint32_t ring_mask;           // (1 << (1 + max(lgwin, lgblock))) - 1   (encode.rs:587-601)
   uint32_t max_backward_limit;  // (1 << lgwin) - 16                      (mod.rs:2393)
   uint32_t hasher_kind;         // 5 = 32-bit hash of 4 bytes, 6 = 64-bit hash of hash_len bytes

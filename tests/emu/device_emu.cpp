@@ -63,11 +63,13 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   }
 }
 
-void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start) {
+void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
+                     uint32_t prefix_flags_bytes) {
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   uint8_t* f = B.flags[0];
   memset(f, 0, (size_t)M + 64);
   if (P0 > htl - 1) memset(f, 1, P0 - (htl - 1));
+  if (prefix_flags_host && prefix_flags_bytes) memcpy(f, prefix_flags_host, prefix_flags_bytes);
   if (M > first_block_start) memset(f + first_block_start, 1, M - first_block_start);
   for (uint32_t k = 0; k < P.num_segments; ++k) {
     const Segment& g = B.segments[k];

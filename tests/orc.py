@@ -164,3 +164,59 @@ def stream_compress(data, params, prefix=None, collect_trace=False):
     if not ok or not fin:
         raise RuntimeError("oracle stream compress failed")
     return out.raw[:cap - avail_out.value], trace
+
+
+def stream_with_flushes(data, params, cuts, write_size=0):
+    """Oracle stream API with BROTLI_OPERATION_FLUSH after the bytes up to each offset in `cuts` (ascending) and FINISH
+    at the end; between flushes the input is handed over with PROCESS in pieces of `write_size` bytes (0: all at once).
+    Returns the list of output pieces (one per flush + the final one)."""
+    L = lib()
+    L.orc_encoder_create.restype = ctypes.c_void_p
+    L.orc_encoder_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_encoder_set_parameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
+    L.orc_encoder_compress_stream.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t),
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.orc_encoder_is_finished.argtypes = [ctypes.c_void_p]
+    L.orc_encoder_has_more_output.argtypes = [ctypes.c_void_p]
+    s = L.orc_encoder_create()
+    for k, v in params:
+        L.orc_encoder_set_parameter(s, k, v)
+    cap = L.orc_max_compressed_size(len(data)) + 1024 + 16 * len(cuts)
+    out = ctypes.create_string_buffer(cap)
+    inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)
+    base = ctypes.addressof(inbuf)
+    avail_out = ctypes.c_size_t(cap)
+    next_out = ctypes.c_void_p(ctypes.addressof(out))
+    total = ctypes.c_size_t(0)
+    pieces = []
+    pos = 0
+    done_out = 0
+
+    def call(op, lo, hi):
+        avail_in = ctypes.c_size_t(hi - lo)
+        next_in = ctypes.c_void_p(base + lo)
+        while True:
+            ok = L.orc_encoder_compress_stream(s, op, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                               ctypes.byref(next_out), ctypes.byref(total))
+            if not ok:
+                raise RuntimeError("oracle compress_stream failed (op %d)" % op)
+            if avail_in.value == 0 and not L.orc_encoder_has_more_output(s):
+                break
+
+    for cut in list(cuts) + [len(data)]:
+        final = cut == len(data) and cut == (list(cuts) + [len(data)])[-1] and len(pieces) == len(cuts)
+        if write_size:
+            while cut - pos > write_size:
+                call(0, pos, pos + write_size)
+                pos += write_size
+        call(2 if final else 1, pos, cut)
+        pos = cut
+        produced = cap - avail_out.value
+        pieces.append(out.raw[done_out:produced])
+        done_out = produced
+    fin = L.orc_encoder_is_finished(s)
+    L.orc_encoder_destroy(s)
+    if not fin:
+        raise RuntimeError("oracle stream did not finish")
+    return pieces

@@ -68,6 +68,31 @@ def _suite(lib):
     pool = lib.BrotliEncoderCreateWorkPool(4)
     assert bytes(lib.BrotliEncoderCompressWorkPool(pool, a, {Q: 5, W: 22}, 4)) == orc.compress_multi(a, [(Q, 5), (W, 22)], 4)
     lib.BrotliEncoderDestroyWorkPool(pool)
+    # BROTLI_OPERATION_FLUSH (CompressorWriter::flush): every piece byte-identical to the reference's, and the
+    # concatenation a valid stream
+    def flushed(data, cuts, params):
+        e = lib.encoder(params=list(params))
+        pieces, pos = [], 0
+        for c in cuts:
+            pieces.append(e.flush(data[pos:c]))
+            pos = c
+        e.write(data[pos:])
+        pieces.append(e.finish())
+        e.close()
+        return pieces
+    for params in ([(Q, 5), (W, 22)], [(Q, 7), (W, 20)]):
+        for cuts in ([50000, 100000], [0, 70000, 70000], [1], [65536], [65535, 65537], [3, 10, 100], [len(a)]):
+            got = flushed(a, cuts, params)
+            assert got == orc.stream_with_flushes(a, params, cuts), (params, cuts)
+            assert orc.decompress(b"".join(got), len(a)) == a
+    mix = synth.mixed(700000)
+    cuts = [100000, 300000, 300001, 650000]
+    assert flushed(mix, cuts, [(Q, 5), (W, 22)]) == orc.stream_with_flushes(mix, [(Q, 5), (W, 22)], cuts)
+    # not supported: flushing a stream with a custom dictionary
+    e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
+    with pytest.raises(Exception):
+        e.flush(a[1000:2000])
+    e.close()
     # unsupported parameters fail loudly instead of silently doing something else
     import brotli_mi355x as _m  # noqa: F401
     with pytest.raises(Exception):
