@@ -5,8 +5,8 @@
  * c/brotli/multiencode.h, implementation src/ffi/compressor.rs and src/ffi/multicompress/mod.rs).  The
  * reference location each function replaces is cited next to it.  Plain pointers and sizes only.
  *
- * Behavioural contract: for the accelerated configurations (quality 5..8, lgwin 17..24, which select the
- * H5 / H5q5 / H6 greedy path of the reference) the produced stream is byte-identical to the reference
+ * Behavioural contract: for the accelerated configurations (quality 5..9, lgwin 17..24, which select the
+ * H5 / H5q5 / H6 / H9 greedy path of the reference) the produced stream is byte-identical to the reference
  * encoder fed the same way.  Everything runs on the GPU through HIP; there is no CPU fallback: calls with
  * parameters outside the accelerated set, or on a machine without a usable gfx950 device, fail
  * (BROTLI_FALSE / 0 / NULL) and print the reason on stderr.

@@ -612,6 +612,7 @@ static int h9_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* d
     bucket[self_num_key & 255] = (uint32_t)cur_ix;
     h->num[key] = (uint16_t)(self_num_key + 1);
     st->positions_stored++;
+    if (orc_debug_store_map && cur_ix < orc_debug_store_map_size) orc_debug_store_map[cur_ix] |= 3;
   }
   if (!is_match_found && use_dictionary) {
     is_match_found = search_in_static_dictionary(h, data + cur_ix_masked, max_length, max_backward + gap,

@@ -155,12 +155,12 @@ void ChooseHasher(EncoderParams* params) {
 
 bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
-  if (p.quality < 5 || p.quality > 8) {
-    why = "only qualities 5..8 (H5/H5q5/H6 greedy path) are implemented on the device in this build";
-  } else if (p.hasher.type != 5 && p.hasher.type != 6) {
+  if (p.quality < 5 || p.quality > 9) {
+    why = "only qualities 5..9 (H5/H5q5/H6/H9 greedy path) are implemented on the device in this build";
+  } else if (p.hasher.type != 5 && p.hasher.type != 6 && p.hasher.type != 9) {
     why = "hasher type not implemented on the device (lgwin <= 16 at quality 5..8 selects the reference's H6 fallback with 256-deep rings)";
-  } else if (p.hasher.block_bits > 7) {
-    why = "ring depth above 128 not implemented on the device";
+  } else if (p.hasher.block_bits > 8) {
+    why = "ring depth above 256 not implemented on the device";
   } else if (p.large_window) {
     why = "large_window not implemented on the device";
   }

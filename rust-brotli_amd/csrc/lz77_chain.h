@@ -48,7 +48,8 @@
 
 namespace brotli_mi355x {
 
-static constexpr int kMaxCandidates = 16 + 128;  // ndist <= 16, ring depth <= 128 (quality <= 8)
+static constexpr int kMaxCandidatesH9 = 16 + 256;  // ndist <= 16, ring depth <= 256 (H9, quality 9)
+static constexpr int kMaxCandidatesAdv = 16 + 128;  // ring depth <= 128 (quality <= 8)
 // per-position flag byte: bit 0 = the position is in the hash table, bit 1 = FindLongestMatch ran on it
 static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 static constexpr uint32_t kMinScore = 30 * 8 * 8 + 100;  // mod.rs:2408-2410
@@ -71,7 +72,9 @@ struct ChainTables {
 static constexpr uint32_t kInfoWindow = 64;
 static constexpr uint32_t kMaxContinuation = 4;
 
-struct ChainScratch {  // one per wavefront (LDS on the device)
+template <bool kH9>
+struct ChainScratchT {  // one per wavefront (LDS on the device)
+  static constexpr int kMaxCandidates = kH9 ? kMaxCandidatesH9 : kMaxCandidatesAdv;
   uint32_t win[kInfoWindow][2];  // rank records (info) of positions [win_base, win_base + kInfoWindow)
   int32_t dc[16];                // distance cache incl. the derived entries (mod.rs:632-651); lanes index it by candidate
   uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
@@ -81,6 +84,8 @@ struct ChainScratch {  // one per wavefront (LDS on the device)
 struct SearchResult {
   uint32_t len, len_x_code, distance, score;
   bool found;
+  bool stored;  // false only for H9 when a cache match reaches the ring-buffer end: the bucket stage, and with it the
+                // insertion of the position, is skipped (mod.rs:789-791, 868-870)
 };
 
 BR_DEV uint32_t br_load32(const uint8_t* p) {
@@ -108,6 +113,30 @@ BR_DEV uint32_t br_match_len(const uint8_t* a, const uint8_t* b, uint32_t limit)
     ++i;
   }
   return limit;
+}
+
+// Scores of a distance-cache candidate (short code c) and of a ring candidate.
+// AdvHasher (H5/H6): BackwardReferenceScoreUsingLastDistance minus BackwardReferencePenaltyUsingLastDistance /
+// BackwardReferenceScore, mod.rs:1871-1889, 1151-1154.  H9: mod.rs:685-708 with kDistanceShortCodeCost.
+template <bool kH9>
+BR_DEV uint32_t br_score_cache(const Lz77Params& P, uint32_t len, uint32_t c) {
+  if (kH9) {
+    // kDistanceShortCodeCost[c] - (120 * 8 * 8 - 127), one byte per entry
+    const uint64_t tab_lo = ((uint64_t)187) | ((uint64_t)32 << 8) | ((uint64_t)10 << 16) | ((uint64_t)0 << 24) | ((uint64_t)34 << 32) |
+                            ((uint64_t)34 << 40) | ((uint64_t)31 << 48) | ((uint64_t)31 << 56);
+    const uint64_t tab_hi = ((uint64_t)28) | ((uint64_t)28 << 8) | ((uint64_t)22 << 16) | ((uint64_t)22 << 24) | ((uint64_t)12 << 32) |
+                            ((uint64_t)12 << 40) | ((uint64_t)2 << 48) | ((uint64_t)2 << 56);
+    const uint32_t cost = (120u * 8u * 8u - 127u) + (uint32_t)(((c < 8 ? tab_lo : tab_hi) >> (8 * (c & 7))) & 0xff);
+    return (P.literal_byte_score * len + cost) >> 2;
+  }
+  uint32_t score = P.score_per_byte * len + 30 * 8 * 8 + 15;
+  if (c != 0) score -= 39u + ((0x1ca10u >> (c & 0xe)) & 0xe);
+  return score;
+}
+template <bool kH9>
+BR_DEV uint32_t br_score_ring(const Lz77Params& P, uint32_t len, uint32_t backward) {
+  if (kH9) return (120u * 8u * 8u + P.literal_byte_score * len - 120u * br_log2_floor_nonzero(backward)) >> 2;
+  return 30 * 8 * 8 + P.score_per_byte * len - 30 * br_log2_floor_nonzero(backward);
 }
 
 // Does replacing the candidate list `a` of position p by `b` (both newest first: a_last[0], a_last[-1], ...) possibly
@@ -322,7 +351,8 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
 }
 #endif
 
-BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratch& s, ProbeMeta& m, uint32_t p0,
+template <bool kH9>
+BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, ProbeMeta& m, uint32_t p0,
                           const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
   const uint32_t ndist = P.ndist;
   const uint32_t block_size = 1u << P.block_bits;
@@ -395,7 +425,8 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
 }
 
 // Phase 2: fold the candidates of probe slot w in the reference's order, then the static dictionary stage.
-BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const ProbeMeta& m, uint32_t w,
+template <bool kH9>
+BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const ProbeMeta& m, uint32_t w,
                                   DictState& ds, uint32_t blk_end) {
   const uint32_t cur = m.pos + w;
   const uint32_t max_length = blk_end - cur;
@@ -408,11 +439,17 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   out.distance = 0;
   out.score = kMinScore;
   out.found = false;
+  out.stored = true;
 #if defined(BROTLI_HOST_EMU)
   uint32_t best_len = 0;
   uint32_t best_score = kMinScore;
   const uint32_t brk = P.dict_break;
-  for (uint32_t c = 0; c < ncand; ++c) {
+  for (uint32_t c = 0; c <= ncand; ++c) {
+    if (kH9 && c == ndist && (cur & P.ring_mask) + best_len > P.ring_mask) {
+      out.stored = false;  // H9: no bucket stage, no insertion
+      break;
+    }
+    if (c == ncand) break;
     const uint32_t prev = s.cand_prev[w][c];
     if (prev == 0xffffffffu) {
       if (c < ndist) continue;
@@ -436,22 +473,19 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     if (brk != 0 && prev < brk && prev + unbroken > brk) len = brk - prev;
     if (c < ndist) {
       if (unbroken >= 3 || (unbroken == 2 && c < 2)) {
-        uint32_t score = P.score_per_byte * len + 30 * 8 * 8 + 15;  // mod.rs:1871-1876
+        const uint32_t score = br_score_cache<kH9>(P, len, c);
         if (best_score < score) {
-          if (c != 0) score -= 39u + ((0x1ca10u >> (c & 0xe)) & 0xe);  // mod.rs:1151-1154
-          if (best_score < score) {
-            best_score = score;
-            best_len = len;
-            out.len = len;
-            out.distance = cur - prev;
-            out.score = score;
-            out.found = true;
-          }
+          best_score = score;
+          best_len = len;
+          out.len = len;
+          out.distance = cur - prev;
+          out.score = score;
+          out.found = true;
         }
       }
     } else if (unbroken >= 4) {  // FindMatchLengthWithLimitMin4 != 0
       const uint32_t backward = cur - prev;
-      const uint32_t score = 30 * 8 * 8 + P.score_per_byte * len - 30 * br_log2_floor_nonzero(backward);  // :1878-1889
+      const uint32_t score = br_score_ring<kH9>(P, len, backward);
       if (best_score < score) {
         best_score = score;
         best_len = len;
@@ -493,10 +527,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     if (!cur_near_wrap && __ballot(special_lane) == 0) {
       folded = true;
       const uint32_t backward = cur - prev;
-      const uint32_t pen = c != 0 ? 39u + ((0x1ca10u >> (c & 0xe)) & 0xe) : 0u;
-      const uint32_t score_cache = P.score_per_byte * unbroken + (30 * 8 * 8 + 15) - pen;
-      const uint32_t score_ring = 30 * 8 * 8 + P.score_per_byte * unbroken - 30 * br_log2_floor_nonzero(has ? backward : 1u);
-      const uint32_t score = is_cache ? score_cache : score_ring;
+      const uint32_t score = is_cache ? br_score_cache<kH9>(P, unbroken, c & 15u) : br_score_ring<kH9>(P, unbroken, has ? backward : 1u);
       const bool type_ok = is_cache ? (unbroken >= 3 || (unbroken == 2 && c < 2)) : unbroken >= 4;
       unsigned long long live = __ballot(has && type_ok) & below_stop;
       uint32_t best_lane = 64;
@@ -538,11 +569,10 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     uint32_t score;
     if (is_cache) {
       type_ok = unbroken >= 3 || (unbroken == 2 && c < 2);
-      score = P.score_per_byte * len + 30 * 8 * 8 + 15;
-      if (c != 0) score -= 39u + ((0x1ca10u >> (c & 0xe)) & 0xe);
+      score = br_score_cache<kH9>(P, len, c & 15u);
     } else {
       type_ok = unbroken >= 4;
-      score = 30 * 8 * 8 + P.score_per_byte * len - 30 * br_log2_floor_nonzero(alive ? backward : 1u);
+      score = br_score_ring<kH9>(P, len, alive ? backward : 1u);
     }
     alive = alive && type_ok;
     // only needed when a match runs to the end of the block: compare the byte behind it (ring buffer semantics)
@@ -550,7 +580,11 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     if (alive && unbroken == max_length) tail_eq = br_unwritten_byte(P, t, cur + max_length) == t.text[prev + max_length];
     int start_lane = 0;
     for (;;) {
-      if ((cur & P.ring_mask) + best_len > P.ring_mask) break;
+      if ((cur & P.ring_mask) + best_len > P.ring_mask) {
+        // H9: if this happened before any ring entry was looked at, the position is not inserted either
+        if (kH9 && base == 0 && (start_lane == 0 || (uint32_t)(start_lane - 1) < ndist)) out.stored = false;
+        break;
+      }
       const bool pass = alive && BR_LANE >= start_lane && !((prev & P.ring_mask) + best_len > P.ring_mask) &&
                         (unbroken > best_len || (unbroken == best_len && best_len == max_length && tail_eq)) && score > best_score;
       const unsigned long long m = __ballot(pass);
@@ -611,22 +645,23 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
 }
 
 // search(x) for the parse loop: reuses the speculative second slot when it is still valid
-BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratch& s, ProbeMeta& m, DictState& ds,
+template <bool kH9>
+BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, ProbeMeta& m, DictState& ds,
                               uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end) {
 #if defined(BR_CHAIN_PROFILE)
   unsigned long long t0 = BR_TICK();
   if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) {
-    SearchResult r = br_fold_probe(P, t, s, m, 1, ds, blk_end);
+    SearchResult r = br_fold_probe<kH9>(P, t, s, m, 1, ds, blk_end);
     m.t_fold += BR_TICK() - t0;
     m.n_fold++;
     return r;
   }
   BR_SYNC();
-  br_probe_pair(P, t, s, m, x, cache, cache_version, blk_end);
+  br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end);
   unsigned long long t1 = BR_TICK();
   m.t_probe += t1 - t0;
   m.n_probe++;
-  SearchResult r = br_fold_probe(P, t, s, m, 0, ds, blk_end);
+  SearchResult r = br_fold_probe<kH9>(P, t, s, m, 0, ds, blk_end);
   m.t_fold += BR_TICK() - t1;
   m.n_fold++;
   return r;
@@ -634,10 +669,10 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
     BR_SYNC();  // every lane is done reading the previous probe
-    br_probe_pair(P, t, s, m, x, cache, cache_version, blk_end);
+    br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end);
     w = 0;
   }
-  return br_fold_probe(P, t, s, m, w, ds, blk_end);
+  return br_fold_probe<kH9>(P, t, s, m, w, ds, blk_end);
 #endif
 }
 
@@ -683,6 +718,7 @@ struct FlagWriter {
     for (uint32_t q = a + BR_LANE; q < b; q += BR_NLANES) put(q, q < split ? (uint8_t)1 : unstored(q));
   }
   // the part [a, b) of the step described by (kind, base, p1) -- see HeadKind
+  template <bool kH9>
   BR_DEV void head(uint32_t kind, uint32_t base, uint32_t p1, uint32_t a, uint32_t b, uint32_t store_end) {
     if (!enabled || kind == kHeadNone) return;
     if (b > hi) b = hi;
@@ -690,8 +726,10 @@ struct FlagWriter {
       uint8_t v;
       if (kind == kHeadCopy) {
         // q <= base: lazily delayed literals and the position the match starts at (all searched and stored)
-        if (q <= base) v = kFlagStored | kFlagSearched;
-        else if (q == base + 1) v = p1 ? (uint8_t)(kFlagStored | kFlagSearched) : unstored(q);
+        // p1 bit 0: base + 1 was probed; bit 2: ... but not inserted; bits 8 + j: base - j was searched but not inserted
+        // (the H9 ring-end case, see SearchResult::stored)
+        if (q <= base) v = (kH9 && base - q < 8 && ((p1 >> (8 + base - q)) & 1u)) ? kFlagSearched : (uint8_t)(kFlagStored | kFlagSearched);
+        else if (q == base + 1) v = (p1 & 1u) ? ((kH9 && (p1 & 4u)) ? kFlagSearched : (uint8_t)(kFlagStored | kFlagSearched)) : unstored(q);
         else v = q < store_end ? (uint8_t)1 : unstored(q);
       } else if (kind == kHeadUnstored) {
         v = unstored(q);
@@ -707,7 +745,8 @@ struct FlagWriter {
 
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
-BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment& seg_in,
+template <bool kH9>
+BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment& seg_in,
                              const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
   Segment seg;
@@ -789,21 +828,24 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
     tail_kind = BR_UNIFORM(entry.head_kind);
     tail_base = BR_UNIFORM(entry.head_base);
     tail_p1 = BR_UNIFORM(entry.head_p1);
-    if (position > seg.start) fw.head(tail_kind, tail_base, tail_p1, seg.start, position, store_end);
+    if (position > seg.start) fw.template head<kH9>(tail_kind, tail_base, tail_p1, seg.start, position, store_end);
   }
 
   while (position + htl < pos_end && position < seg.end) {
-    SearchResult sr = br_search(P, t, s, probe, ds, position, dc, cache_version, pos_end);
+    SearchResult sr = br_search<kH9>(P, t, s, probe, ds, position, dc, cache_version, pos_end);
     n_searches++;
     if (sr.found) {
       int delayed = 0;
-      bool next_probed;
+      bool next_probed, next_stored = true;
+      uint32_t special = 0;  // bit j: the search j positions before the match start was not inserted (H9 ring end)
       for (;;) {
-        SearchResult sr2 = br_search(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end);
+        SearchResult sr2 = br_search<kH9>(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end);
         n_searches++;
         next_probed = true;
+        if (kH9) next_stored = sr2.stored;
         if (sr2.found && sr2.score >= sr.score + 175) {
-          fw.one(position, kFlagStored | kFlagSearched);
+          fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);
+          if (kH9) special = (special << 1) | (sr.stored ? 0u : 2u);
           position++;
           insert_length++;
           sr = sr2;
@@ -812,6 +854,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
         }
         break;
       }
+      if (kH9) special |= sr.stored ? 0u : 1u;
       apply = position + 2 * sr.len + window;
       const uint32_t max_distance = position < P.max_backward_limit ? position : P.max_backward_limit;
       const uint32_t distance_code = br_compute_distance_code(sr.distance, max_distance, dc);
@@ -834,12 +877,14 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
       tail_kind = kHeadCopy;
       tail_base = position;
       tail_p1 = next_probed ? 1u : 0u;
-      fw.one(position, kFlagStored | kFlagSearched);
-      if (sr.len > 1) fw.one(position + 1, next_probed ? (uint8_t)(kFlagStored | kFlagSearched) : fw.unstored(position + 1));
+      if (kH9) tail_p1 |= ((next_probed && !next_stored) ? 4u : 0u) | ((special & 0xffu) << 8);
+      fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);
+      if (sr.len > 1)
+        fw.one(position + 1, next_probed ? ((!kH9 || next_stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched) : fw.unstored(position + 1));
       if (sr.len > 2) fw.range(position + 2, position + sr.len, store_end);
       position += sr.len;
     } else {
-      fw.one(position, kFlagStored | kFlagSearched);
+      fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);
       insert_length++;
       position++;
       if (position > apply) {
@@ -932,7 +977,8 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
 // they are not scheduled themselves: a change that would otherwise creep forward one segment per round (each
 // round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
 // written to entries[] so that the host resolver sees what it was parsed with.
-BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratch& s, const Segment* segments,
+template <bool kH9>
+BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment* segments,
                            SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
   SegEntry entry = entries[k];
   // a chain takes at most max_continuation further segments: what it leaves behind is picked up in the next round by
@@ -942,7 +988,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
   for (;;) {
     const Segment seg = segments[k];
     SegEntry next;
-    br_parse_segment(P, t, s, seg, entry, exits[k], next);
+    br_parse_segment<kH9>(P, t, s, seg, entry, exits[k], next);
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
     const uint32_t mark = sched[k + 1];
     if (mark == 1 || mark == 3) break;  // has its own chain in this launch

@@ -485,15 +485,16 @@ static ParseTiming& parse_timing() {
   return t;
 }
 
+template <bool kH9>
 __global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
-  __shared__ ChainScratch scratch;
+  __shared__ ChainScratchT<kH9> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
   // window and the rank rows its chains touch stay in that XCD's L2
   uint32_t item = blockIdx.x;
   if (a.per_xcd) item = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
   if (item >= a.count) return;
   const uint32_t k = a.list ? a.list[item] : a.first_segment + item;
-  br_parse_chain(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+  br_parse_chain<kH9>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
 }
 
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
@@ -530,7 +531,11 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   static const bool xcd_aware = getenv("BROTLI_MI355X_NO_XCD_MAP") == nullptr;
   a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
   const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
-  hipLaunchKernelGGL(k_parse_segments, dim3(grid), dim3(64), 0, 0, a);
+  if (P.hasher_kind == 9) {
+    hipLaunchKernelGGL(k_parse_segments<true>, dim3(grid), dim3(64), 0, 0, a);
+  } else {
+    hipLaunchKernelGGL(k_parse_segments<false>, dim3(grid), dim3(64), 0, 0, a);
+  }
   HIP_CHECK(hipEventRecord(e1, 0));
   HIP_CHECK(hipGetLastError());
   pt.events.push_back(std::make_pair(e0, e1));

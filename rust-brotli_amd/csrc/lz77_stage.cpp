@@ -65,13 +65,14 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   P_.dict_break = (carry_ && carry_->valid) ? 0u : prefix_bytes;
   P_.ring_mask = (1u << ComputeRbBits(params)) - 1u;
   P_.max_backward_limit = (1u << params.lgwin) - 16u;
-  P_.hasher_kind = params.hasher.type == 5 ? 5 : 6;
+  P_.hasher_kind = params.hasher.type == 5 ? 5 : (params.hasher.type == 9 ? 9 : 6);
   P_.bucket_bits = (uint32_t)params.hasher.bucket_bits;
   P_.block_bits = (uint32_t)params.hasher.block_bits;
   P_.hash_len = (uint32_t)params.hasher.hash_len;
   P_.ndist = (uint32_t)params.hasher.num_last_distances_to_check;
   P_.htl = P_.hasher_kind == 6 ? 8 : 4;
-  P_.score_per_byte = (uint32_t)(params.hasher.literal_byte_score ? params.hasher.literal_byte_score : 540) >> 2;
+  P_.literal_byte_score = (uint32_t)(params.hasher.literal_byte_score ? params.hasher.literal_byte_score : 540);
+  P_.score_per_byte = P_.literal_byte_score >> 2;
   P_.use_dictionary = params.use_dictionary ? 1 : 0;
   P_.spree_window = params.quality < 9 ? 64 : 512;
   P_.dist_max_distance = (uint32_t)params.dist.max_distance;

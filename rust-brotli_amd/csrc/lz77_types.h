@@ -36,6 +36,7 @@ struct Lz77Params {
   uint32_t hash_len;            // H6 only
   uint32_t ndist;               // num_last_distances_to_check (4, 10 or 16)
   uint32_t htl;                 // HashTypeLength == StoreLookahead (4 or 8)
+  uint32_t literal_byte_score;   // H9 scores with the full value and shifts the sum (mod.rs:685-708)
   uint32_t score_per_byte;      // literal_byte_score >> 2 (135)
   uint32_t use_dictionary;      // static dictionary allowed (params.use_dictionary)
   uint32_t spree_window;        // LiteralSpreeLengthForSparseSearch: 64 (q<9) or 512

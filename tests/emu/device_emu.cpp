@@ -174,10 +174,15 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
-  ChainScratch scratch;
+  ChainScratchT<false> scratch;
+  ChainScratchT<true> scratch9;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
-    br_parse_chain(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+    if (P.hasher_kind == 9) {
+      br_parse_chain<true>(P, T, scratch9, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+    } else {
+      br_parse_chain<false>(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+    }
   }
 }
 

@@ -71,3 +71,18 @@ def test_stored_flags_equal_reference_table(L):
         assert cmp_flags.stored_flags_match(L, d), name
         assert check(name, d, 5, 22, lib=L)
         assert check_bytes(L, name, d, [(Q, 5), (W, 22), (SH, len(d))], verbose=False)
+
+
+def test_quality9_h9(L):
+    """quality 9 = the H9 hasher (256-deep rings, 16 cache candidates, its own scoring): the reference's own size KAT
+    (alice29 at q9 / lgwin 16 -> 51 737 bytes, src/enc/encode.rs:3091) through the product's host + chain code"""
+    a = synth.alice()
+    out, _ = emu.encode_stream(L, a, [(Q, 9), (W, 16), (SH, len(a))])
+    assert len(out) == 51737
+    assert out == orc.compress(a, 9, 16)
+    assert check("alice q9", a, 9, 22, lib=L)
+    d = synth.markov_text(2 << 20)
+    assert check("markov2M q9 w18", d, 9, 18, lib=L)  # ring buffer of 512 KiB: positions wrap four times
+    import cmp_flags
+    assert cmp_flags.stored_flags_match(L, bytes(2 << 20), 9, 18)
+    assert check_bytes(L, "mixed1M q9", synth.mixed(1 << 20), [(Q, 9), (W, 22)], verbose=False)

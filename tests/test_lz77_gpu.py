@@ -58,3 +58,13 @@ def test_stored_flags_equal_reference_table(L):
 def test_mixed_16M(L):
     # mixed content across several meta-blocks (zero runs, binary records, text, random)
     assert check("mixed16M", synth.mixed(16 << 20), 5, 22, lib=L)
+
+
+def test_quality9_h9(L):
+    a = synth.alice()
+    assert check("alice q9", a, 9, 22, lib=L)
+    assert check("alice q9 w16", a, 9, 16, lib=L)
+    assert check("markov4M q9 w18", synth.markov_text(4 << 20), 9, 18, lib=L)
+    assert check("mixed2M q9", synth.mixed(2 << 20), 9, 22, lib=L)
+    import cmp_flags
+    assert cmp_flags.stored_flags_match(L, bytes(2 << 20), 9, 18)

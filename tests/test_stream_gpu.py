@@ -55,3 +55,15 @@ def test_shard_with_prefix(L):
     a = synth.alice()
     h = len(a) // 2
     assert check_bytes(L, "alice shard1", a[h:], [(Q, 5), (W, 22), (167, 1), (168, 1)], prefix=a[:h])
+
+
+def test_quality9_kat_51737(L):
+    """the reference's own known answer (src/enc/encode.rs:3091): alice29 at quality 9, lgwin 16, one shot -> 51 737 B"""
+    import emu
+    a = synth.alice()
+    out, _ = emu.encode_stream(L, a, [(Q, 9), (W, 16), (SH, len(a))])
+    assert len(out) == 51737
+    assert check_bytes(L, "alice q9 w16", a, [(Q, 9), (W, 16), (SH, len(a))])
+    assert check_bytes(L, "alice q9", a, [(Q, 9), (W, 22), (SH, len(a))])
+    d = synth.markov_text(5 << 20)
+    assert check_bytes(L, "markov5M q9", d, [(Q, 9), (W, 22), (SH, len(d))])
