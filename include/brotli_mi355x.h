@@ -16,7 +16,8 @@
  * byte-identical to what the reference emits for the same flush points, encode.rs:2940-2975 + 1541-1566) and at
  * BROTLI_OPERATION_FINISH.  A flushed stream keeps its whole input on the host and re-indexes it at every flush
  * (cost proportional to the stream so far; at most 1 GiB), and cannot be combined with a custom dictionary or the
- * catable / appendable modes.  BROTLI_OPERATION_EMIT_METADATA is not implemented and returns BROTLI_FALSE.
+ * catable / appendable modes.  BROTLI_OPERATION_EMIT_METADATA (encode.rs:2579-2685) flushes pending input the same
+ * way and writes the payload (<= 16 MiB) as a metadata block.
  */
 #ifndef BROTLI_MI355X_H_
 #define BROTLI_MI355X_H_

@@ -839,12 +839,98 @@ static void check_flush_complete(OrcEncoder* s) {
   }
 }
 
-/* encode.rs:2873-2995 (EMIT_METADATA is not restated: outside the hot path) */
+/* encode.rs:2545-2575 */
+static size_t write_metadata_header(OrcEncoder* s) {
+  size_t block_size = s->remaining_metadata_bytes_;
+  uint8_t* header = s->tiny_buf_;
+  size_t storage_ix = s->last_bytes_bits_;
+  memset(header, 0, sizeof(s->tiny_buf_));
+  header[0] = (uint8_t)s->last_bytes_;
+  header[1] = (uint8_t)(s->last_bytes_ >> 8);
+  s->last_bytes_ = 0;
+  s->last_bytes_bits_ = 0;
+  orc_write_bits(1, 0, &storage_ix, header);
+  orc_write_bits(2, 3, &storage_ix, header);
+  orc_write_bits(1, 0, &storage_ix, header);
+  if (block_size == 0) {
+    orc_write_bits(2, 0, &storage_ix, header);
+  } else {
+    uint32_t nbits = block_size == 1 ? 0 : orc_log2_floor_nonzero((uint32_t)block_size - 1) + 1;
+    uint32_t nbytes = (nbits + 7) / 8;
+    orc_write_bits(2, nbytes, &storage_ix, header);
+    orc_write_bits(8 * nbytes, block_size - 1, &storage_ix, header);
+  }
+  return (storage_ix + 7) >> 3;
+}
+
+/* encode.rs:2579-2685 */
+static int process_metadata(OrcEncoder* s, size_t* available_in, const uint8_t** next_in, size_t* available_out,
+                            uint8_t** next_out, size_t* total_out) {
+  if (*available_in > (1u << 24)) return 0;
+  if (s->stream_state_ == STREAM_PROCESSING) {
+    s->remaining_metadata_bytes_ = (uint32_t)*available_in;
+    s->stream_state_ = STREAM_METADATA_HEAD;
+  }
+  if (s->stream_state_ != STREAM_METADATA_HEAD && s->stream_state_ != STREAM_METADATA_BODY) return 0;
+  for (;;) {
+    if (inject_flush_or_push_output(s, available_out, next_out, total_out)) continue;
+    if (s->available_out_ != 0) break;
+    if (s->input_pos_ != s->last_flush_pos_) {
+      size_t avail_out = s->available_out_;
+      int result = encode_data(s, 0, 1, &avail_out);
+      s->available_out_ = avail_out;
+      if (!result) return 0;
+      continue;
+    }
+    if (s->stream_state_ == STREAM_METADATA_HEAD) {
+      s->next_out_kind = NEXT_OUT_TINY;
+      s->next_out_off = 0;
+      s->available_out_ = write_metadata_header(s);
+      s->stream_state_ = STREAM_METADATA_BODY;
+      continue;
+    } else {
+      if (s->remaining_metadata_bytes_ == 0) {
+        s->remaining_metadata_bytes_ = 0xffffffffu;
+        s->stream_state_ = STREAM_PROCESSING;
+        break;
+      }
+      if (*available_out != 0) {
+        uint32_t copy = (uint32_t)ORC_MIN((size_t)s->remaining_metadata_bytes_, *available_out);
+        memcpy(*next_out, *next_in, copy);
+        *next_in += copy;
+        *available_in -= copy;
+        s->remaining_metadata_bytes_ -= copy;
+        *next_out += copy;
+        *available_out -= copy;
+      } else {
+        uint32_t copy = ORC_MIN(s->remaining_metadata_bytes_, 16u);
+        s->next_out_kind = NEXT_OUT_TINY;
+        s->next_out_off = 0;
+        memcpy(s->tiny_buf_, *next_in, copy);
+        *next_in += copy;
+        *available_in -= copy;
+        s->remaining_metadata_bytes_ -= copy;
+        s->available_out_ = copy;
+      }
+      continue;
+    }
+  }
+  return 1;
+}
+
+/* encode.rs:2873-2995 */
 int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, const uint8_t** next_in,
                                 size_t* available_out, uint8_t** next_out, size_t* total_out) {
   if (!ensure_initialized(s)) return 0;
-  if (s->remaining_metadata_bytes_ != 0xffffffffu) return 0;
-  if (op == ORC_OP_EMIT_METADATA) return 0;
+  if (s->params.quality < 4 || s->params.quality > 9) return 0; /* only q4..q9 are restated */
+  if (s->remaining_metadata_bytes_ != 0xffffffffu) {
+    if (*available_in != (size_t)s->remaining_metadata_bytes_) return 0;
+    if (op != ORC_OP_EMIT_METADATA) return 0;
+  }
+  if (op == ORC_OP_EMIT_METADATA) {
+    update_size_hint(s, 0);
+    return process_metadata(s, available_in, next_in, available_out, next_out, total_out);
+  }
   if (s->stream_state_ == STREAM_METADATA_HEAD || s->stream_state_ == STREAM_METADATA_BODY) return 0;
   if (s->stream_state_ != STREAM_PROCESSING && *available_in != 0) return 0;
   if (s->params.quality < 4 || s->params.quality > 9) return 0; /* only q4..q9 are restated */

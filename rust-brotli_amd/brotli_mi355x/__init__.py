@@ -251,6 +251,14 @@ class Encoder(object):
         self._out = bytearray()
         return piece
 
+    def emit_metadata(self, payload):
+        """BROTLI_OPERATION_EMIT_METADATA: pending input is flushed, then `payload` (at most 16 MiB) goes out as a
+        metadata block, which decoders skip; returns the bytes produced"""
+        self._stream(BROTLI_OPERATION_EMIT_METADATA, payload)
+        piece = bytes(self._out)
+        self._out = bytearray()
+        return piece
+
     def set_parameter(self, key, value):
         return bool(self._l.lib.BrotliEncoderSetParameter(self._s, int(key), int(value)))
 

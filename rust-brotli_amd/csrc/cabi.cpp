@@ -51,6 +51,7 @@ struct BrotliEncoderStateStruct {
   // BROTLI_OPERATION_FLUSH: `input` keeps the whole stream, [0, encoded_upto) of it is already in the output
   size_t encoded_upto;
   StreamCarry carry;
+  bool metadata_draining;  // an EMIT_METADATA operation whose output has not been fully taken yet
 };
 
 struct BrotliEncoderWorkPoolStruct {
@@ -73,13 +74,15 @@ size_t BlockSize(const EncoderParams& user) {
 }
 
 // Runs the device encoder over everything buffered since the last flush (FLUSH: finish = false, FINISH: true).
-bool EncodeBuffered(BrotliEncoderState* s, bool finish) {
+bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = false, size_t metadata_size = 0) {
   try {
     EncodeRequest req;
     req.params = s->params;
     req.input = s->input.data() + s->encoded_upto;
     req.input_size = s->input.size() - s->encoded_upto;
     req.finish = finish;
+    req.emit_metadata = emit_metadata;
+    req.metadata_size = metadata_size;
     const bool flushed_stream = !finish || s->carry.valid;
     if (flushed_stream) {
       if (s->has_dictionary || s->params.catable || s->params.appendable)
@@ -260,6 +263,7 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, br
   s->total_out = 0;
   s->total_in = 0;
   s->encoded_upto = 0;
+  s->metadata_draining = false;
   return s;
 }
 
@@ -290,11 +294,26 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
   if (!s || s->failed) return BROTLI_FALSE;
   EnsureInitialized(s);
   if (op == BROTLI_OPERATION_EMIT_METADATA) {
-    SetError("BrotliEncoderCompressStream", "BROTLI_OPERATION_EMIT_METADATA is not implemented on the device path");
-    return BROTLI_FALSE;
+    // process_metadata, encode.rs:2579-2685: the bytes handed over are not input but the payload of a metadata block;
+    // pending input is flushed in front of it (without the byte-alignment block: the metadata header follows directly)
+    if (s->stream_state != kProcessing || *available_in > ((size_t)1 << 24)) return BROTLI_FALSE;
+    if (s->metadata_draining) {
+      if (*available_in != 0) return BROTLI_FALSE;  // (the reference insists on the rest of the same payload)
+    } else {
+    if (!s->first_encode_seen) {
+      s->first_encode_seen = true;
+      if (s->params.size_hint == 0) s->params.size_hint = std::min<size_t>(s->input.size(), (size_t)1 << 30);
+    }
+    const size_t n_meta = *available_in;
+    if (!EncodeBuffered(s, false, true, n_meta)) return BROTLI_FALSE;
+    s->output.insert(s->output.end(), *next_in, *next_in + n_meta);
+    *next_in += n_meta;
+    *available_in = 0;
+    s->metadata_draining = true;
+    }
   }
   if (s->stream_state != kProcessing && *available_in != 0) return BROTLI_FALSE;  // encode.rs:2918-2922
-  if (s->stream_state == kProcessing) {
+  if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA) {
     if (*available_in != 0) {
       s->input.insert(s->input.end(), *next_in, *next_in + *available_in);
       s->total_in += *available_in;
@@ -327,6 +346,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     s->output_pos += n;
     s->total_out += n;
   }
+  if (AvailableOut(s) == 0) s->metadata_draining = false;
   if (total_out) *total_out = (size_t)s->total_out;
   return BROTLI_TRUE;
 }

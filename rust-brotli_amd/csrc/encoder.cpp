@@ -189,6 +189,36 @@ struct Clock {
 
 }  // namespace
 
+// tail of a piece that leaves the stream open: the injected flush (an empty metadata block, only when the stream is
+// not byte aligned, encode.rs:1541-1566) or the header of a real metadata block (write_metadata_header, :2545-2575)
+template <typename Bits>
+void WriteOpenTail(const EncodeRequest& req, Bits* bits) {
+  if (req.emit_metadata) {
+    bits->put(1, 0);
+    bits->put(2, 3);
+    bits->put(1, 0);
+    if (req.metadata_size == 0) {
+      bits->put(2, 0);
+    } else {
+      uint32_t nbits = 0;
+      if (req.metadata_size > 1) {
+        uint32_t v = (uint32_t)req.metadata_size - 1;
+        while (v) {
+          nbits++;
+          v >>= 1;
+        }
+      }
+      const uint32_t nbytes = (nbits + 7) / 8;
+      bits->put(2, nbytes);
+      if (nbytes) bits->put(8 * nbytes, (uint64_t)req.metadata_size - 1);
+    }
+    bits->jump_to_byte_boundary();
+  } else if ((bits->pos & 7) != 0) {
+    bits->put(6, 6);
+    bits->jump_to_byte_boundary();
+  }
+}
+
 uint32_t ChooseSegmentBytes(size_t input_bytes) {
   if (input_bytes <= ((size_t)4 << 20)) return 512;
   if (input_bytes <= ((size_t)16 << 20)) return 1024;
@@ -288,9 +318,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     // nothing left to search: only the trailing blocks (encode.rs:1979-1982)
     if (req.finish) {
       WriteEmptyLastBlocks(p, &hb);
-    } else if ((hb.pos & 7) != 0) {  // injected flush: an empty metadata block pads to the byte boundary (encode.rs:1541-1566)
-      hb.put(6, 6);
-      hb.jump_to_byte_boundary();
+    } else {
+      WriteOpenTail(req, &hb);
     }
     if (req.carry_out) {
       StreamCarry& co = *req.carry_out;
@@ -568,10 +597,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       stats.fallback_retries++;
       continue;
     }
-    if (!req.finish && (bits.pos & 7) != 0) {  // injected flush (encode.rs:1541-1566)
-      bits.put(6, 6);
-      bits.jump_to_byte_boundary();
-    }
+    if (!req.finish) WriteOpenTail(req, &bits);
     // ---- emission
     const size_t total_bytes = (size_t)((bits.pos + 7) >> 3);
     const size_t out_words = total_bytes / 8 + 4;

@@ -53,6 +53,10 @@ struct EncodeRequest {
   const StreamCarry* carry_in = nullptr;
   StreamCarry* carry_out = nullptr;
   bool finish = true;
+  // BROTLI_OPERATION_EMIT_METADATA (with finish = false): instead of the flush padding, the header of a metadata block
+  // of metadata_size bytes is written (encode.rs:2545-2575); the caller appends the bytes themselves
+  bool emit_metadata = false;
+  size_t metadata_size = 0;
 };
 
 // Compresses one stream.  Output is appended to `out`.  Throws std::runtime_error on device errors or

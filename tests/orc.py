@@ -204,13 +204,33 @@ def stream_with_flushes(data, params, cuts, write_size=0):
             if avail_in.value == 0 and not L.orc_encoder_has_more_output(s):
                 break
 
-    for cut in list(cuts) + [len(data)]:
-        final = cut == len(data) and cut == (list(cuts) + [len(data)])[-1] and len(pieces) == len(cuts)
+    for item in list(cuts) + [len(data)]:
+        # an entry of `cuts` is an offset (flush there) or (offset, metadata bytes): BROTLI_OPERATION_EMIT_METADATA after
+        # the input up to the offset has been handed over with PROCESS
+        meta = None
+        cut = item
+        if isinstance(item, tuple):
+            cut, meta = item
+        final = meta is None and cut == len(data) and len(pieces) == len(cuts)
         if write_size:
             while cut - pos > write_size:
                 call(0, pos, pos + write_size)
                 pos += write_size
-        call(2 if final else 1, pos, cut)
+        if meta is None:
+            call(2 if final else 1, pos, cut)
+        else:
+            if cut > pos:
+                call(0, pos, cut)
+            mbuf = ctypes.create_string_buffer(bytes(meta), max(1, len(meta)))
+            avail_in = ctypes.c_size_t(len(meta))
+            next_in = ctypes.c_void_p(ctypes.addressof(mbuf))
+            while True:
+                ok = L.orc_encoder_compress_stream(s, 3, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                                   ctypes.byref(next_out), ctypes.byref(total))
+                if not ok:
+                    raise RuntimeError("oracle EMIT_METADATA failed")
+                if avail_in.value == 0 and not L.orc_encoder_has_more_output(s):
+                    break
         pos = cut
         produced = cap - avail_out.value
         pieces.append(out.raw[done_out:produced])

@@ -88,6 +88,30 @@ def _suite(lib):
     mix = synth.mixed(700000)
     cuts = [100000, 300000, 300001, 650000]
     assert flushed(mix, cuts, [(Q, 5), (W, 22)]) == orc.stream_with_flushes(mix, [(Q, 5), (W, 22)], cuts)
+    # BROTLI_OPERATION_EMIT_METADATA: pending input flushed, then the payload as a metadata block (decoders skip it)
+    def with_ops(data, ops, params):
+        e = lib.encoder(params=list(params))
+        pieces, pos = [], 0
+        for item in ops:
+            if isinstance(item, tuple):
+                c, meta = item
+                if c > pos:
+                    e.write(data[pos:c])
+                pieces.append(e.emit_metadata(meta))
+            else:
+                c = item
+                pieces.append(e.flush(data[pos:c]))
+            pos = c
+        e.write(data[pos:])
+        pieces.append(e.finish())
+        e.close()
+        return pieces
+    big = bytes(range(256)) * 300
+    for ops in ([(50000, b"hello metadata")], [(0, b"x" * 300)], [(70000, b""), 100000], [(65536, big), (65536, b"second")],
+                [10000, (20000, b"mm"), 30000, (30000, b"")], [(len(a), b"tail")]):
+        got = with_ops(a, ops, [(Q, 5), (W, 22)])
+        assert got == orc.stream_with_flushes(a, [(Q, 5), (W, 22)], ops), ops
+        assert orc.decompress(b"".join(got), len(a)) == a
     # not supported: flushing a stream with a custom dictionary
     e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
     with pytest.raises(Exception):

@@ -51,3 +51,16 @@ def test_zero_fill_512MiB(L):
     out, st = _encode(L, data)
     assert len(out) < 4096
     assert orc.decompress(out, len(data)) == data
+
+
+def test_quality9_256MiB_round_trip(L):
+    """BASELINE.json configs[2]: 256 MiB enwik-style corpus at quality 9 (H9)"""
+    import emu
+    block = synth.markov_text(32 << 20)
+    parts = []
+    for i in range(8):  # page-like records with varying headers so that the eight copies are not byte-identical
+        parts.append(b"<page><title>%d</title><id>%d</id><text>" % (i * 7919, i) + block[i:] + b"</text></page>\n")
+    data = b"".join(parts)[:256 << 20]
+    out, st = emu.encode_stream(L, data, [(Q, 9), (W, 22), (SH, len(data))])
+    assert len(out) < len(data) // 3
+    assert hashlib.sha256(orc.decompress(out, len(data))).digest() == hashlib.sha256(data).digest()
