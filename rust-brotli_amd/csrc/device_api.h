@@ -96,7 +96,11 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
 // marks (dirty[k] = 1) the segments that searched a position whose candidate list differs between the rank
 // structures rbuf_old and rbuf_new
 struct SegGeometry {
-  uint32_t prefix_bytes, first_block_start, block_bytes, segment_bytes, segs_per_block, num_segments, block_size /* ring depth */, pad;
+  uint32_t prefix_bytes, first_block_start, block_bytes, num_blocks, num_segments, block_size /* ring depth */;
+  // per input block (segments may be cut differently in every block): index of its first segment [num_blocks + 1]
+  // and the bytes per segment [num_blocks]
+  const uint32_t* block_first_segment;
+  const uint32_t* block_segment_bytes;
 };
 void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
                    uint8_t* dirty_dev);
@@ -120,7 +124,7 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments)
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]
-void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
+void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out);
 
 // applies extend_last_command / trailing insert-only fix-ups to the gathered commands

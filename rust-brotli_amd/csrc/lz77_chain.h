@@ -757,7 +757,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   seg.flags = BR_UNIFORM(seg_in.flags);
   seg.cmd_base = BR_UNIFORM(seg_in.cmd_base);
   seg.block_index = 0;
-  seg.pad = 0;
+  seg.cmd_cap = BR_UNIFORM(seg_in.cmd_cap);
   const uint32_t htl = P.htl;
   const uint32_t window = P.spree_window;
   uint32_t position = BR_UNIFORM(entry.pos);
@@ -867,7 +867,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
         cache_version++;
         br_prepare_distance_cache(dc, P.ndist);
       }
-      if (BR_LANE == 0 && n_cmds < P.cmd_slab_stride && fw.enabled) cmds[n_cmds] = br_raw_command(insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
+      if (BR_LANE == 0 && n_cmds < seg.cmd_cap && fw.enabled) cmds[n_cmds] = br_raw_command(insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
       n_cmds++;
       n_lits += insert_length;
       insert_length = 0;

@@ -338,11 +338,12 @@ __device__ __forceinline__ void mark_dirty(uint32_t p, const SegGeometry& geo, u
   const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
   const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
   const uint32_t off = p - bs;
-  uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
-  if (k >= geo.num_segments) k = geo.num_segments - 1;
+  const uint32_t seg_bytes = geo.block_segment_bytes[blk];
+  uint32_t k = geo.block_first_segment[blk] + off / seg_bytes;
+  if (k >= geo.block_first_segment[blk + 1]) k = geo.block_first_segment[blk + 1] - 1;
   dirty[k] = 1;
   // a lazy probe just behind a segment boundary belongs to the previous chain
-  if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+  if (k > 0 && (off % seg_bytes) < 8) dirty[k - 1] = 1;
 }
 
 // Incremental update after a few flag changes: the slots of every changed key are cut into chunks of
@@ -675,20 +676,20 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
 }
 
 // compacts the per-segment slabs and turns the raw records of the chains into Commands (Command::init, command.rs:273-297)
-__global__ __launch_bounds__(256) void k_gather_commands(const Command* __restrict__ slabs, uint32_t stride, const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ counts, Command* __restrict__ out, uint32_t ndirect,
-                                                          uint32_t npostfix) {
+__global__ __launch_bounds__(256) void k_gather_commands(const Command* __restrict__ slabs, const Segment* __restrict__ segments,
+                                                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                          Command* __restrict__ out, uint32_t ndirect, uint32_t npostfix) {
   const uint32_t k = blockIdx.x;
   const uint32_t n = counts[k];
-  const Command* src = slabs + (size_t)k * stride;
+  const Command* src = slabs + (size_t)segments[k].cmd_base;
   Command* dst = out + offsets[k];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = br_finish_command(src[i], ndirect, npostfix);
 }
 
-void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets_dev,
+void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out) {
   if (num_segments == 0) return;
-  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, 0, B.cmds, stride, offsets_dev, counts_dev, out,
+  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, 0, B.cmds, B.segments, offsets_dev, counts_dev, out,
                      P.num_direct_distance_codes, P.dist_postfix_bits);
   HIP_CHECK(hipGetLastError());
 }

@@ -54,6 +54,7 @@ void Lz77Stage::Release() {
 void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t prefix_bytes, uint32_t input_bytes,
                       uint32_t raw_head_bytes, uint32_t segment_bytes) {
   Release();
+  coarse_blocks_.clear();
   params_ = params;
   input_bytes_ = input_bytes;
   raw_head_bytes_ = raw_head_bytes;
@@ -101,7 +102,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
   B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
-  cmds_bytes_ = (size_t)segments_.size() * P_.cmd_slab_stride * sizeof(Command) + 64;
+  cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
   B_.cmds = (Command*)dev_alloc(cmds_bytes_);
   B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
   B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
@@ -130,6 +131,8 @@ void Lz77Stage::BuildSegments() {
     blocks.emplace_back(bs, be);
   }
   uint32_t cmd_base = 0;
+  block_first_segment_.clear();
+  block_segment_bytes_.clear();
   for (size_t b = 0; b < blocks.size(); ++b) {
     const uint32_t bs = blocks[b].first, be = blocks[b].second;
     bool stitched = false;
@@ -137,10 +140,14 @@ void Lz77Stage::BuildSegments() {
       const uint32_t nbytes = blocks[b + 1].second - blocks[b + 1].first;
       stitched = nbytes >= htl - 1 && blocks[b + 1].first >= 3;  // StitchToPreviousBlockInternal, mod.rs:210-222
     }
+    // a block can be marked for a single chain (coarse_blocks_, see RunRounds)
+    const uint32_t seg_bytes = (b < coarse_blocks_.size() && coarse_blocks_[b]) ? block_bytes_ : segment_bytes_;
+    block_first_segment_.push_back((uint32_t)segments_.size());
+    block_segment_bytes_.push_back(seg_bytes);
     uint32_t s = bs;
     bool first = true;
     do {
-      const uint32_t e = std::min(be, s + segment_bytes_);
+      const uint32_t e = std::min(be, s + seg_bytes);
       Segment g;
       g.start = s;
       g.end = e;
@@ -149,13 +156,15 @@ void Lz77Stage::BuildSegments() {
       g.flags = (first ? kSegFirstInBlock : 0u) | (e == be ? kSegLastInBlock : 0u) | (stitched ? kSegTailStitched : 0u);
       g.cmd_base = cmd_base;
       g.block_index = (uint32_t)b;
-      g.pad = 0;
-      cmd_base += P_.cmd_slab_stride;
+      g.cmd_cap = (e - s) / 2 + 8;
+      cmd_base += g.cmd_cap;
       segments_.push_back(g);
       first = false;
       s = e;
     } while (s < be);
   }
+  block_first_segment_.push_back((uint32_t)segments_.size());
+  total_cmd_slots_ = cmd_base;
 }
 
 void Lz77Stage::InitFlags() {
@@ -623,7 +632,7 @@ void Lz77Stage::Resegment(uint32_t segment_bytes) {
   P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
   BuildSegments();
   P_.num_segments = (uint32_t)segments_.size();
-  const size_t need = (size_t)segments_.size() * P_.cmd_slab_stride * sizeof(Command) + 64;
+  const size_t need = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
   if (need > cmds_bytes_) {
     dev_free(B_.cmds);
     B_.cmds = (Command*)dev_alloc(need);
@@ -712,8 +721,12 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   geo.prefix_bytes = P_.prefix_bytes;
   geo.first_block_start = segments_[0].blk_start;
   geo.block_bytes = block_bytes_;
-  geo.segment_bytes = segment_bytes_;
-  geo.segs_per_block = (block_bytes_ + segment_bytes_ - 1) / segment_bytes_;
+  geo.num_blocks = (uint32_t)block_segment_bytes_.size();
+  uint32_t* geo_tables = (uint32_t*)dev_alloc((block_first_segment_.size() + block_segment_bytes_.size()) * 4 + 64);
+  dev_h2d(geo_tables, block_first_segment_.data(), block_first_segment_.size() * 4);
+  dev_h2d(geo_tables + block_first_segment_.size(), block_segment_bytes_.data(), block_segment_bytes_.size() * 4);
+  geo.block_first_segment = geo_tables;
+  geo.block_segment_bytes = geo_tables + block_first_segment_.size();
   geo.num_segments = nseg;
   geo.block_size = 1u << P_.block_bits;
   uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
@@ -784,9 +797,13 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
     uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
     for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
-    // (dbg_counts_[0]: chains that were started at the wrong position -- the signature of sparse hashing / long runs,
-    // where the phase of the previous chain never washes out)
+    // When most chains were started at the wrong position the input does not re-synchronise (sparse hashing in
+    // incompressible data, long runs: the phase of the previous chain never washes out).  It is re-cut into one chain
+    // per input block -- nothing is guessed inside a block then -- and the iteration starts over.  (Doing this for the
+    // offending blocks only was tried and is worse on mixed content: a single-chain block that is merely re-validated
+    // costs a 64 KiB serial parse per round.)
     if (round == 0 && allow_restart && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)dbg_counts_[0] * 2 > nseg) {
+      coarse_blocks_.assign(block_segment_bytes_.size(), 1);
       restart = true;
       break;
     }
@@ -898,11 +915,12 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   }
   dev_free(dirty_dev);
   dev_free(list_dev);
+  dev_free(geo_tables);
   if (restart) {
     saved_block_guess_ = block_entry_guess_;  // what the pass so far says about the state at every block start
     // Hardly any guess held: this input does not re-synchronise (incompressible stretches, data whose parse hangs on
     // the distance cache).  Parse it one chain per input block instead -- nothing is guessed inside a block then.
-    Resegment(block_bytes_);
+    Resegment(segment_bytes_);
     stats_.coarse_restarts++;
     RunRounds(false);
     return;
@@ -1032,7 +1050,7 @@ void Lz77Stage::Gather() {
   }
   dev_h2d(gather_offsets_dev_, offsets.data(), nseg * 4);
   dev_h2d(gather_counts_dev_, counts.data(), nseg * 4);
-  lz77_gather_commands(P_, B_, nseg, P_.cmd_slab_stride, gather_offsets_dev_, gather_counts_dev_, gathered_cmds_);
+  lz77_gather_commands(P_, B_, nseg, gather_offsets_dev_, gather_counts_dev_, gathered_cmds_);
   for (const std::vector<CmdPatch>* batch : {&fix, &fix_ext}) {
     if (batch->empty()) continue;
     CmdPatch* fix_dev = (CmdPatch*)dev_alloc(batch->size() * sizeof(CmdPatch));

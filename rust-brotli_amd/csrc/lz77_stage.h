@@ -114,6 +114,9 @@ class Lz77Stage {
   uint32_t warmup_bytes_ = 384;
   uint32_t block_bytes_ = 65536;
   std::vector<Segment> segments_;
+  std::vector<uint32_t> block_first_segment_, block_segment_bytes_;  // per input block (+ one-past-the-end entry)
+  std::vector<uint8_t> coarse_blocks_;  // blocks that are parsed by a single chain
+  uint32_t total_cmd_slots_ = 0;
   std::vector<double> warm_lookups_, warm_matches_;  // per segment, forecast from the warm-up dry run
   uint32_t predicted_death_ = 0xffffffffu;
   int final_flags_ = 0;

@@ -65,7 +65,7 @@ struct Segment {
   uint32_t flags;
   uint32_t cmd_base;   // index of this segment's command slab
   uint32_t block_index;
-  uint32_t pad;
+  uint32_t cmd_cap;    // commands its slab can hold
 };
 
 // What covers the positions between a segment's start and the position where its chain takes over.

@@ -119,10 +119,11 @@ static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
   const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
   const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
   const uint32_t off = p - bs;
-  uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
-  if (k >= geo.num_segments) k = geo.num_segments - 1;
+  const uint32_t seg_bytes = geo.block_segment_bytes[blk];
+  uint32_t k = geo.block_first_segment[blk] + off / seg_bytes;
+  if (k >= geo.block_first_segment[blk + 1]) k = geo.block_first_segment[blk + 1] - 1;
   dirty[k] = 1;
-  if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+  if (k > 0 && (off % seg_bytes) < 8) dirty[k - 1] = 1;
 }
 
 void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RerankChunk* chunks, uint32_t num_chunks,
@@ -214,13 +215,7 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
     for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf_old][ga - 1 - j] == B.sorted[rbuf_new][gb - 1 - j];
     if (same) continue;
     if (!br_row_change_matters(B.text, p, B.sorted[rbuf_old] + ga - 1, na, B.sorted[rbuf_new] + gb - 1, nb)) continue;
-    const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
-    const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
-    const uint32_t off = p - bs;
-    uint32_t k = blk * geo.segs_per_block + off / geo.segment_bytes;
-    if (k >= geo.num_segments) k = geo.num_segments - 1;
-    dirty[k] = 1;
-    if (k > 0 && (off % geo.segment_bytes) < 8) dirty[k - 1] = 1;
+    emu_mark_dirty(p, geo, dirty);
   }
 }
 
@@ -236,11 +231,11 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
   for (uint32_t i = 0; i < samples; ++i) histo[text[start + i * 13u]]++;
 }
 
-void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, uint32_t stride, const uint32_t* offsets,
+void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets,
                           const uint32_t* counts, Command* out) {
   for (uint32_t k = 0; k < num_segments; ++k)
     for (uint32_t i = 0; i < counts[k]; ++i)
-      out[offsets[k] + i] = br_finish_command(B.cmds[(size_t)k * stride + i], P.num_direct_distance_codes, P.dist_postfix_bits);
+      out[offsets[k] + i] = br_finish_command(B.cmds[(size_t)B.segments[k].cmd_base + i], P.num_direct_distance_codes, P.dist_postfix_bits);
 }
 
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
