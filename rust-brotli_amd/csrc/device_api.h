@@ -12,6 +12,10 @@
 
 #include "lz77_types.h"
 
+// Every thread of the host program works on its own HIP stream (hipStreamPerThread): independent encoder calls from
+// different threads overlap on the GPU, nothing ever runs on the synchronising null stream.
+#define BR_STREAM hipStreamPerThread
+
 namespace brotli_mi355x {
 
 // ---- memory ----

@@ -26,9 +26,13 @@ struct Pool {
   std::unordered_map<void*, size_t> capacity;  // every live block handed out or pooled
   size_t pooled_bytes = 0;
   static constexpr size_t kMaxPooled = (size_t)96 << 30;
+  ~Pool() {
+    for (auto& kv : free_blocks) (void)hipFree(kv.second);  // (errors at process exit are of no consequence)
+  }
 };
+// one pool per host thread = per stream: a block is only ever reused by work queued behind its previous use
 Pool& pool() {
-  static Pool p;
+  static thread_local Pool p;
   return p;
 }
 size_t RoundUp(size_t bytes) {
@@ -72,7 +76,7 @@ void* dev_alloc(size_t bytes) {
     std::lock_guard<std::mutex> lock(P.mu);
     P.capacity[p] = cap;
   }
-  HIP_CHECK(hipMemsetAsync(p, 0, bytes, 0));
+  HIP_CHECK(hipMemsetAsync(p, 0, bytes, BR_STREAM));
   return p;
 }
 void dev_free(void* p) {
@@ -93,18 +97,21 @@ void dev_free(void* p) {
   P.pooled_bytes += it->second;
 }
 void dev_memset(void* p, int value, size_t bytes) {
-  if (bytes) HIP_CHECK(hipMemsetAsync(p, value, bytes, 0));
+  if (bytes) HIP_CHECK(hipMemsetAsync(p, value, bytes, BR_STREAM));
 }
 void dev_h2d(void* dst, const void* src, size_t bytes) {
-  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, 0));
+  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, BR_STREAM));
 }
 void dev_d2h(void* dst, const void* src, size_t bytes) {
-  if (bytes) HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  if (bytes) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, BR_STREAM));
+    HIP_CHECK(hipStreamSynchronize(BR_STREAM));
+  }
 }
 void dev_d2d(void* dst, const void* src, size_t bytes) {
-  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0));
+  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, BR_STREAM));
 }
-void dev_sync() { HIP_CHECK(hipStreamSynchronize(0)); }
+void dev_sync() { HIP_CHECK(hipStreamSynchronize(BR_STREAM)); }
 
 const char* dev_name() {
   static std::string name;

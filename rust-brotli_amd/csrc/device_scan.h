@@ -55,10 +55,10 @@ static __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ 
 static void exclusive_scan_u32(uint32_t* data, uint32_t n, uint32_t* scratch) {
   if (n == 0) return;
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, 0, data, n, tiles > 1 ? scratch : (uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(256), 0, BR_STREAM, data, n, tiles > 1 ? scratch : (uint32_t*)nullptr);
   if (tiles > 1) {
     exclusive_scan_u32(scratch, tiles, scratch + tiles);
-    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(256), 0, 0, data, n, scratch);
+    hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(256), 0, BR_STREAM, data, n, scratch);
   }
 }
 

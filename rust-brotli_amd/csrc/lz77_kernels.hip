@@ -52,7 +52,7 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   if (n == 0) return;
   uint32_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_compute_keys, dim3(blocks), dim3(256), 0, 0, B.text, B.keys, n, valid_n, P.hasher_kind, P.bucket_bits,
+  hipLaunchKernelGGL(k_compute_keys, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, B.keys, n, valid_n, P.hasher_kind, P.bucket_bits,
                      hash_mask);
   HIP_CHECK(hipGetLastError());
 }
@@ -76,18 +76,18 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
                      uint32_t prefix_flags_bytes) {
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
-  HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, 0));
-  if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), 0));  // StoreLookaheadThenStore, mod.rs:224-229
+  HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, BR_STREAM));
+  if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), BR_STREAM));  // StoreLookaheadThenStore, mod.rs:224-229
   // the catable raw head (between the prefix and the first searched block) is only stored by the stitch
   if (prefix_flags_host && prefix_flags_bytes) {
     // continuation of a stream: the earlier positions are in the table exactly as the earlier parse left them
-    HIP_CHECK(hipMemcpyAsync(B.flags[0], prefix_flags_host, prefix_flags_bytes, hipMemcpyHostToDevice, 0));
+    HIP_CHECK(hipMemcpyAsync(B.flags[0], prefix_flags_host, prefix_flags_bytes, hipMemcpyHostToDevice, BR_STREAM));
   }
-  if (M > first_block_start) HIP_CHECK(hipMemsetAsync(B.flags[0] + first_block_start, 1, M - first_block_start, 0));
+  if (M > first_block_start) HIP_CHECK(hipMemsetAsync(B.flags[0] + first_block_start, 1, M - first_block_start, BR_STREAM));
   if (P.num_segments) {
-    hipLaunchKernelGGL(k_init_flag_tails, dim3((P.num_segments + 63) / 64), dim3(64), 0, 0, B.segments, P.num_segments, htl, B.flags[0]);
+    hipLaunchKernelGGL(k_init_flag_tails, dim3((P.num_segments + 63) / 64), dim3(64), 0, BR_STREAM, B.segments, P.num_segments, htl, B.flags[0]);
   }
-  HIP_CHECK(hipMemcpyAsync(B.flags[1], B.flags[0], (size_t)M + 64, hipMemcpyDeviceToDevice, 0));
+  HIP_CHECK(hipMemcpyAsync(B.flags[1], B.flags[0], (size_t)M + 64, hipMemcpyDeviceToDevice, BR_STREAM));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -175,14 +175,14 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   tmp += (size_t)tiles * 256 * 4;
   uint32_t* scratch = (uint32_t*)tmp;
   // pass 1: low 8 bits, keys -> tmp
-  hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, 0, B.keys, n, 0u, tiles, hist);
+  hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, BR_STREAM, B.keys, n, 0u, tiles, hist);
   exclusive_scan_u32(hist, tiles * 256, scratch);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, 0, B.keys, (const uint32_t*)nullptr, keys_tmp, vals_tmp, n, 0u, tiles,
+  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, BR_STREAM, B.keys, (const uint32_t*)nullptr, keys_tmp, vals_tmp, n, 0u, tiles,
                      hist);
   // pass 2: high 8 bits, tmp -> by_key / sorted_keys
-  hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, 0, keys_tmp, n, 8u, tiles, hist);
+  hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, BR_STREAM, keys_tmp, n, 8u, tiles, hist);
   exclusive_scan_u32(hist, tiles * 256, scratch);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, 0, keys_tmp, vals_tmp, B.sorted_keys, B.by_key, n, 8u, tiles, hist);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, BR_STREAM, keys_tmp, vals_tmp, B.sorted_keys, B.by_key, n, 8u, tiles, hist);
   HIP_CHECK(hipGetLastError());
   lz77_key_ranges(P, B);
 }
@@ -303,10 +303,10 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
 
 void lz77_key_ranges(const Lz77Params& P, const Lz77Buffers& B) {
   const uint32_t n = P.total_bytes;
-  HIP_CHECK(hipMemsetAsync(B.key_first, 0, 65537 * 4, 0));
-  HIP_CHECK(hipMemsetAsync(B.key_last, 0, 65537 * 4, 0));
+  HIP_CHECK(hipMemsetAsync(B.key_first, 0, 65537 * 4, BR_STREAM));
+  HIP_CHECK(hipMemsetAsync(B.key_last, 0, 65537 * 4, BR_STREAM));
   if (n == 0) return;
-  hipLaunchKernelGGL(k_key_ranges, dim3((n + 255) / 256), dim3(256), 0, 0, B.sorted_keys, n, B.key_first, B.key_last);
+  hipLaunchKernelGGL(k_key_ranges, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.sorted_keys, n, B.key_first, B.key_last);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -325,10 +325,10 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
-  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, 0, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
+  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
   exclusive_scan_u32(tile_sums, tiles, scratch);
-  hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, 0, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
-  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, 0, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
+  hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
+  hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
                      B.sorted[rbuf], (uint2*)B.info[rbuf]);
   HIP_CHECK(hipGetLastError());
 }
@@ -453,11 +453,11 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   if (num_chunks == 0 || P.total_bytes == 0) return;
   uint32_t* rank_tmp = (uint32_t*)B.sort_tmp;
   uint32_t* sorted_tmp = rank_tmp + (((size_t)P.total_bytes + 63) & ~(size_t)63);
-  hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], sums_dev);
-  hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
-  hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, 0, B.text, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
+  hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], sums_dev);
+  hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
+  hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, BR_STREAM, B.text, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
                      (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev);
-  hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, 0, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
+  hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
                      (uint2*)B.info[rbuf], rank_tmp);
   HIP_CHECK(hipGetLastError());
 }
@@ -528,16 +528,16 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   hipEvent_t e0, e1;
   HIP_CHECK(hipEventCreate(&e0));
   HIP_CHECK(hipEventCreate(&e1));
-  HIP_CHECK(hipEventRecord(e0, 0));
+  HIP_CHECK(hipEventRecord(e0, BR_STREAM));
   static const bool xcd_aware = getenv("BROTLI_MI355X_NO_XCD_MAP") == nullptr;
   a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
   const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
   if (P.hasher_kind == 9) {
-    hipLaunchKernelGGL(k_parse_segments<true>, dim3(grid), dim3(64), 0, 0, a);
+    hipLaunchKernelGGL(k_parse_segments<true>, dim3(grid), dim3(64), 0, BR_STREAM, a);
   } else {
-    hipLaunchKernelGGL(k_parse_segments<false>, dim3(grid), dim3(64), 0, 0, a);
+    hipLaunchKernelGGL(k_parse_segments<false>, dim3(grid), dim3(64), 0, BR_STREAM, a);
   }
-  HIP_CHECK(hipEventRecord(e1, 0));
+  HIP_CHECK(hipEventRecord(e1, BR_STREAM));
   HIP_CHECK(hipGetLastError());
   pt.events.push_back(std::make_pair(e0, e1));
   pt.segments += count;
@@ -583,11 +583,11 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
 
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
   const uint32_t n = P.total_bytes;
-  HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, 0));
+  HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, BR_STREAM));
   if (n == 0) return;
   uint32_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_diff_flags, dim3(blocks), dim3(256), 0, 0, B.flags[prev], B.flags[next], n, B.keys, B.changed_keys, B.changed_count,
+  hipLaunchKernelGGL(k_diff_flags, dim3(blocks), dim3(256), 0, BR_STREAM, B.flags[prev], B.flags[next], n, B.keys, B.changed_keys, B.changed_count,
                      kChangedCap);
   HIP_CHECK(hipGetLastError());
 }
@@ -616,7 +616,7 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
   if (n == 0) return;
   uint32_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, 0, B.text, B.flags[which], (const uint2*)B.info[rbuf_old], B.sorted[rbuf_old],
+  hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, B.flags[which], (const uint2*)B.info[rbuf_old], B.sorted[rbuf_old],
                      (const uint2*)B.info[rbuf_new], B.sorted[rbuf_new], n, geo, dirty_dev);
   HIP_CHECK(hipGetLastError());
 }
@@ -666,12 +666,12 @@ __global__ __launch_bounds__(256) void k_sample_histogram(const uint8_t* __restr
 }
 
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev) {
-  HIP_CHECK(hipMemsetAsync(histo256_dev, 0, 256 * 4, 0));
+  HIP_CHECK(hipMemsetAsync(histo256_dev, 0, 256 * 4, BR_STREAM));
   const uint32_t samples = (bytes + 12) / 13;
   uint32_t blocks = (samples + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks == 0) return;
-  hipLaunchKernelGGL(k_sample_histogram, dim3(blocks), dim3(256), 0, 0, text, start, samples, histo256_dev);
+  hipLaunchKernelGGL(k_sample_histogram, dim3(blocks), dim3(256), 0, BR_STREAM, text, start, samples, histo256_dev);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_gather_commands(const Command* __restri
 void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out) {
   if (num_segments == 0) return;
-  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, 0, B.cmds, B.segments, offsets_dev, counts_dev, out,
+  hipLaunchKernelGGL(k_gather_commands, dim3(num_segments), dim3(256), 0, BR_STREAM, B.cmds, B.segments, offsets_dev, counts_dev, out,
                      P.num_direct_distance_codes, P.dist_postfix_bits);
   HIP_CHECK(hipGetLastError());
 }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64) void k_patch_commands(Command* cmds, const CmdP
 
 void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_patch_commands, dim3((n + 63) / 64), dim3(64), 0, 0, cmds, patches_dev, n);
+  hipLaunchKernelGGL(k_patch_commands, dim3((n + 63) / 64), dim3(64), 0, BR_STREAM, cmds, patches_dev, n);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_for_each(uint32_t n, F f) {
 template <typename F>
 static void for_each(uint32_t n, F f) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_for_each<F>, dim3((n + 255) / 256), dim3(256), 0, 0, n, f);
+  hipLaunchKernelGGL(k_for_each<F>, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, n, f);
 }
 
 // out[m] = src[descs[m].cmd_offset] for every meta-block, out[n_mb] = src[n_cmds]: the per-meta-block boundaries of an
@@ -36,9 +36,9 @@ void mb_command_scans(const MbBuffers& B, void* scan_scratch) {
   const MbBuffers b = B;
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_counts(b, c); });
   // element [K] = 0 so that the exclusive scan leaves the totals there
-  HIP_CHECK(hipMemsetAsync(b.cmd_lit_start + b.n_cmds, 0, 4, 0));
-  HIP_CHECK(hipMemsetAsync(b.cmd_pos + b.n_cmds, 0, 4, 0));
-  HIP_CHECK(hipMemsetAsync(b.cmd_dist_index + b.n_cmds, 0, 4, 0));
+  HIP_CHECK(hipMemsetAsync(b.cmd_lit_start + b.n_cmds, 0, 4, BR_STREAM));
+  HIP_CHECK(hipMemsetAsync(b.cmd_pos + b.n_cmds, 0, 4, BR_STREAM));
+  HIP_CHECK(hipMemsetAsync(b.cmd_dist_index + b.n_cmds, 0, 4, BR_STREAM));
   exclusive_scan_u32(b.cmd_lit_start, b.n_cmds + 1, (uint32_t*)scan_scratch);
   exclusive_scan_u32(b.cmd_pos, b.n_cmds + 1, (uint32_t*)scan_scratch);
   exclusive_scan_u32(b.cmd_dist_index, b.n_cmds + 1, (uint32_t*)scan_scratch);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_context_stats(MbBuffers B, uint32_t* st
 
 void mb_context_stats(const MbBuffers& B, uint32_t* stats_dev) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_context_stats, dim3(B.n_mb), dim3(256), 0, 0, B, stats_dev);
+  hipLaunchKernelGGL(k_context_stats, dim3(B.n_mb), dim3(256), 0, BR_STREAM, B, stats_dev);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void k_granule_histograms(MbBuffers B, uint32_
 
 void mb_granule_histograms(const MbBuffers& B) {
   const MbBuffers b = B;
-  if (b.n_granules[kSplitLiteral]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitLiteral]), dim3(256), 0, 0, b, (uint32_t)kSplitLiteral);
-  if (b.n_granules[kSplitCommand]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitCommand]), dim3(256), 0, 0, b, (uint32_t)kSplitCommand);
+  if (b.n_granules[kSplitLiteral]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitLiteral]), dim3(256), 0, BR_STREAM, b, (uint32_t)kSplitLiteral);
+  if (b.n_granules[kSplitCommand]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitCommand]), dim3(256), 0, BR_STREAM, b, (uint32_t)kSplitCommand);
   if (b.n_granules[kSplitDistance]) {
-    HIP_CHECK(hipMemsetAsync(b.gran_hist[kSplitDistance], 0, (size_t)b.n_granules[kSplitDistance] * kNumDistanceHistoSymbols * 2, 0));
+    HIP_CHECK(hipMemsetAsync(b.gran_hist[kSplitDistance], 0, (size_t)b.n_granules[kSplitDistance] * kNumDistanceHistoSymbols * 2, BR_STREAM));
     for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_distance_count(b, c); });
   }
   HIP_CHECK(hipGetLastError());
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_split_chains(MbBuffers B) {
 
 void mb_split_chains(const MbBuffers& B) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_split_chains, dim3(B.n_mb * 3), dim3(256), 0, 0, B);
+  hipLaunchKernelGGL(k_split_chains, dim3(B.n_mb * 3), dim3(256), 0, BR_STREAM, B);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void k_build_codes(MbBuffers B, const CodeJob* 
 
 void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs) {
   if (n_jobs == 0) return;
-  hipLaunchKernelGGL(k_build_codes, dim3(n_jobs), dim3(64), 0, 0, B, jobs_dev, n_jobs);
+  hipLaunchKernelGGL(k_build_codes, dim3(n_jobs), dim3(64), 0, BR_STREAM, B, jobs_dev, n_jobs);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -174,17 +174,17 @@ __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
 
 void mb_write_headers(const MbBuffers& B) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_write_headers, dim3(B.n_mb), dim3(64), 0, 0, B);
+  hipLaunchKernelGGL(k_write_headers, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B);
   HIP_CHECK(hipGetLastError());
 }
 
 void mb_symbol_bits(const MbBuffers& B, void* scan_scratch) {
   const MbBuffers b = B;
   for_each(b.n_lits, [b] __device__(uint32_t i) { mb_item_literal_nbits(b, i); });
-  HIP_CHECK(hipMemsetAsync(b.lit_nbits + b.n_lits, 0, 4, 0));
+  HIP_CHECK(hipMemsetAsync(b.lit_nbits + b.n_lits, 0, 4, BR_STREAM));
   exclusive_scan_u32(b.lit_nbits, b.n_lits + 1, (uint32_t*)scan_scratch);
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_nbits(b, c); });
-  HIP_CHECK(hipMemsetAsync(b.cmd_nbits + b.n_cmds, 0, 4, 0));
+  HIP_CHECK(hipMemsetAsync(b.cmd_nbits + b.n_cmds, 0, 4, BR_STREAM));
   exclusive_scan_u32(b.cmd_nbits, b.n_cmds + 1, (uint32_t*)scan_scratch);
   HIP_CHECK(hipGetLastError());
 }

@@ -153,3 +153,31 @@ def test_library_exports_every_declared_symbol():
     lib.BrotliEncoderMaxCompressedSizeMulti.restype = ctypes.c_size_t
     lib.BrotliEncoderMaxCompressedSizeMulti.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
     assert lib.BrotliEncoderMaxCompressedSizeMulti(0, 1) == 25  # src/ffi/multicompress/test.rs:258
+
+
+@pytest.mark.gpu
+def test_concurrent_calls_from_threads():
+    """independent BrotliEncoderCompress calls from several host threads (one HIP stream per thread) must not disturb
+    each other"""
+    import threading
+    lib = _load("gpu")
+    inputs = [synth.alice(), synth.markov_text(1 << 20, 7), synth.mixed(600000, 3), synth.random_bytes(300000, 11),
+              synth.markov_text(3 << 20, 9), bytes(500000)]
+    expected = [orc.compress(d, 5, 22) for d in inputs]
+    results = [None] * len(inputs)
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                results[i] = lib.compress(inputs[i], 5, 22)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert results == expected
