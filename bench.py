@@ -91,10 +91,18 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (test aid: BROTLI_MI355X_BENCH_SHARD_JOB=1 runs the multi-GPU code path -- process group, device-resident shard,
+    # gather, stitch -- with a single rank)
+    shard_job = world > 1 or os.environ.get("BROTLI_MI355X_BENCH_SHARD_JOB") == "1"
+    if shard_job:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend="nccl")  # RCCL on ROCm
 
     import brotli_mi355x as bm
     lib = bm.default_library()
@@ -102,7 +110,7 @@ def main():
     total = per_gpu * world
     # every rank needs its chunk and the preceding window of the global stream: generate the part it needs
     seed = 0x5EED000000000002
-    if world == 1:
+    if not shard_job:
         data = workload(per_gpu, seed)
         prefix = b""
         chunk = data
@@ -122,15 +130,16 @@ def main():
     from brotli_mi355x import multi
     enc = multi.ShardEncoder(lib.lib, args.segment_bytes)
     params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN)]
-    if world == 1:
+    if not shard_job:
         params.append((bm.BROTLI_PARAM_SIZE_HINT, per_gpu))  # BrotliEncoderCompress sets SIZE_HINT = input size
     st = enc.stats
+    job = multi.DeviceShardJob(dist, lib, enc, rank, world, per_gpu) if shard_job else None
 
     def one_step():
-        if world == 1:
+        if not shard_job:
             comp = enc.encode(params, b"", dev.data_ptr(), len(chunk), True)
         else:
-            comp = multi.compress_sharded(dist, lib, enc, params, LGWIN, prefix, dev.data_ptr(), len(chunk), True, rank, world, "cuda")
+            comp = job.step(params, prefix, dev.data_ptr(), len(chunk))  # compressed shards gathered GPU to GPU, stitched on rank 0
         return comp, list(st)
 
     for _ in range(args.warmup):
@@ -189,7 +198,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%d MiB synthetic English-like text per GPU (word-bigram Markov over alice29 tokens), quality=5, lgwin=22, "
-                               "%s" % (args.mib, "one-shot BrotliEncoderCompress semantics (H6 hasher)" if world == 1 else
+                               "%s" % (args.mib, "one-shot BrotliEncoderCompress semantics (H6 hasher)" if not shard_job else
                                        "compress_multi chunk per GPU + RCCL gather + BroCatli stitch"),
                    "input_bytes_total": total, "compressed_bytes": len(comp), "ratio": round(total / max(1, len(comp)), 4),
                    "segment_bytes": int(seg_bytes), "lz77_rounds_per_step": agg["rounds"] / args.steps,
@@ -199,12 +208,11 @@ def main():
                      "avg_launch_ms": round(avg_launch_ms, 3), "launches_per_step": agg["launches"] / args.steps,
                      "alg_bytes_per_launch": int(alg_bytes_per_launch)},
     }
-    if not args.no_cpu_baseline and world == 1:  # (the CPU leg is reported at N = 1 only)
+    if not args.no_cpu_baseline and not shard_job:  # (the CPU leg is reported at N = 1 only)
         sample = data
         base, ref_bytes = cpu_baseline(sample)
         line["cpu_baseline"] = base
-        if world == 1:
-            line["config"]["identical_to_cpu_oracle"] = (ref_bytes == comp)
+        line["config"]["identical_to_cpu_oracle"] = (ref_bytes == comp)
     print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

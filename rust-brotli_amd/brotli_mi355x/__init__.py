@@ -201,6 +201,20 @@ class Library(object):
             raise BrotliCompressorException("BrotliMi355xConcatChunks failed: " + self.last_error())
         return ctypes.string_at(out, n.value)
 
+    def concat_chunk_views(self, views):
+        """like concat_chunks, but on (address, size) pairs of host memory and without copying the result: returns a
+        memoryview of a buffer owned by the Library (valid until the next call)"""
+        n_chunks = len(views)
+        arr = (c_void_p * n_chunks)(*[c_void_p(a) for a, _ in views])
+        sizes = (c_size_t * n_chunks)(*[s for _, s in views])
+        cap = sum(s for _, s in views) + 64
+        if getattr(self, "_concat_buf", None) is None or len(self._concat_buf) < cap:
+            self._concat_buf = ctypes.create_string_buffer(cap)
+        n = c_size_t(len(self._concat_buf))
+        if not self.lib.BrotliMi355xConcatChunks(n_chunks, ctypes.cast(arr, ctypes.POINTER(c_char_p)), sizes, byref(n), self._concat_buf):
+            raise BrotliCompressorException("BrotliMi355xConcatChunks failed: " + self.last_error())
+        return memoryview(self._concat_buf)[:n.value]
+
     def encoder(self, **params):
         return Encoder(self, **params)
 

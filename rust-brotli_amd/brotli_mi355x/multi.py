@@ -66,6 +66,17 @@ class ShardEncoder(object):
             raise RuntimeError(self._err.value.decode())
         return ctypes.string_at(self._out, n)
 
+    def encode_to_device(self, params, prefix, chunk_ptr, nbytes, out_ptr, out_capacity):
+        """input and output both in device memory; returns the compressed size"""
+        keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
+        vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
+        n = self.L.brotli_mi355x_encode_stream(keys, vals, len(params), prefix, len(prefix), 1, ctypes.c_void_p(chunk_ptr), nbytes, 3,
+                                               self.segment_bytes, ctypes.cast(ctypes.c_void_p(out_ptr), ctypes.c_char_p), out_capacity,
+                                               self.stats, self._err, 512)
+        if n < 0:
+            raise RuntimeError(self._err.value.decode())
+        return n
+
 
 def gather_shards(dist, comp, rank, world, device):
     """Variable-length gather of the compressed shards to rank 0 (sizes first, then padded payloads).
@@ -94,3 +105,34 @@ def compress_sharded(dist, library, encoder, params, lgwin, prefix, chunk, nbyte
     if rank != 0:
         return None
     return library.concat_chunks(shards)
+
+
+class DeviceShardJob(object):
+    """The same job with the compressed shards kept in HBM until rank 0 has all of them: each rank encodes straight into
+    a device buffer, the gather runs GPU to GPU (RCCL over xGMI), rank 0 copies the gathered shards to pinned host memory
+    once and stitches them there.  Buffers are allocated once and reused by every step."""
+
+    def __init__(self, dist, library, encoder, rank, world, shard_bytes):
+        import torch
+        self.dist, self.library, self.encoder, self.rank, self.world = dist, library, encoder, rank, world
+        self.cap = shard_bytes + shard_bytes // 4 + 4096
+        self.out = torch.zeros(self.cap, dtype=torch.uint8, device="cuda")
+        self.size = torch.zeros(1, dtype=torch.int64, device="cuda")
+        self.sizes = torch.zeros(world, dtype=torch.int64, device="cuda")
+        self.rows = torch.zeros((world, self.cap), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        self.rows_host = torch.zeros((world, self.cap), dtype=torch.uint8).pin_memory() if rank == 0 else None
+
+    def step(self, params, prefix, chunk_ptr, nbytes):
+        import torch
+        n = self.encoder.encode_to_device(shard_params(params, self.rank), prefix, chunk_ptr, nbytes, self.out.data_ptr(), self.cap)
+        self.size[0] = n
+        self.dist.all_gather_into_tensor(self.sizes, self.size)
+        sizes = [int(v) for v in self.sizes.tolist()]
+        mx = max(sizes)
+        gather_list = [self.rows[r, :mx] for r in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(self.out[:mx], gather_list, dst=0)
+        if self.rank != 0:
+            return None
+        self.rows_host[:, :mx].copy_(self.rows[:, :mx], non_blocking=False)
+        base = self.rows_host.data_ptr()
+        return self.library.concat_chunk_views([(base + r * self.cap, sizes[r]) for r in range(self.world)])

@@ -543,7 +543,8 @@ int32_t BrotliMi355xCompressChunk(size_t num_params, const BrotliEncoderParamete
 
 int32_t BrotliMi355xConcatChunks(size_t num_chunks, const uint8_t* const* chunks, const size_t* chunk_sizes, size_t* encoded_size,
                                  uint8_t* encoded) {
-  std::vector<uint8_t> out;
+  // stitched straight into the caller's buffer: every chunk byte is copied once
+  ByteSink out(encoded, *encoded_size);
   ChunkStitcher stitcher;
   for (size_t i = 0; i < num_chunks; ++i) {
     if (!stitcher.Append(chunks[i], chunk_sizes[i], &out)) {
@@ -552,11 +553,10 @@ int32_t BrotliMi355xConcatChunks(size_t num_chunks, const uint8_t* const* chunks
     }
   }
   stitcher.Finish(&out);
-  if (out.size() > *encoded_size) {
+  if (out.overflow()) {
     SetError("BrotliMi355xConcatChunks", "insufficient output space");
     return 0;
   }
-  memcpy(encoded, out.data(), out.size());
   *encoded_size = out.size();
   return 1;
 }

@@ -82,7 +82,21 @@ bool DetectVarlenOffset(const uint8_t* b, size_t n, size_t* out) {
 }  // namespace
 
 // flush_previous_stream, concat/mod.rs:277-330: drops the ISLAST/ISLASTEMPTY bits that end the previous chunk
-bool ChunkStitcher::FlushPreviousStream(std::vector<uint8_t>* out) {
+void ByteSink::append(const uint8_t* first, const uint8_t* last) {
+  if (vec_) {
+    vec_->insert(vec_->end(), first, last);
+    return;
+  }
+  const size_t n = (size_t)(last - first);
+  if (n > cap_ - size_) {
+    overflow_ = true;
+    return;
+  }
+  memcpy(buf_ + size_, first, n);
+  size_ += n;
+}
+
+bool ChunkStitcher::FlushPreviousStream(ByteSink* out) {
   if (last_byte_sanitized_) return true;
   if (last_bytes_len_ == 0) {
     last_byte_sanitized_ = true;
@@ -113,7 +127,7 @@ bool ChunkStitcher::FlushPreviousStream(std::vector<uint8_t>* out) {
   return true;
 }
 
-bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, std::vector<uint8_t>* out) {
+bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, ByteSink* out) {
   // new_brotli_file() + stream(), concat/mod.rs:274-276, 450-566
   if (!FlushPreviousStream(out)) return false;
   uint8_t header[5] = {0, 0, 0, 0, 0};
@@ -155,7 +169,7 @@ bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, std::vector<uint8_t
     pending_len = whole_byte_destination + num_whole_bytes_to_copy;
     memcpy(pending, realigned, pending_len);
   }
-  out->insert(out->end(), pending, pending + pending_len);
+  out->append(pending, pending + pending_len);
   any_bytes_emitted_ = true;
   // the last byte may still change (next chunk / end of stream): take it back
   last_byte_sanitized_ = false;
@@ -179,14 +193,14 @@ bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, std::vector<uint8_t
   }
   out->push_back(last_bytes_[0]);
   out->push_back(last_bytes_[1]);
-  out->insert(out->end(), in + in_offset, in + in_offset + to_copy - 2);
+  out->append(in + in_offset, in + in_offset + to_copy - 2);
   last_bytes_[0] = in[in_offset + to_copy - 2];
   last_bytes_[1] = in[in_offset + to_copy - 1];
   return true;
 }
 
 // finish, concat/mod.rs:567-608
-bool ChunkStitcher::Finish(std::vector<uint8_t>* out) {
+bool ChunkStitcher::Finish(ByteSink* out) {
   if (last_byte_sanitized_ && last_bytes_len_ != 0) {
     uint16_t last_bytes = (uint16_t)(last_bytes_[0] | (last_bytes_[1] << 8));
     const uint8_t bit_end = (uint8_t)((last_bytes_len_ - 1) * 8 + last_byte_bit_offset_);

@@ -9,14 +9,49 @@
 
 namespace brotli_mi355x {
 
+// Where the stitched stream goes: a growing vector or a caller-owned buffer (the bytes of a chunk are then copied
+// exactly once; `overflow` is set and further bytes are dropped when the buffer is too small).
+class ByteSink {
+ public:
+  explicit ByteSink(std::vector<uint8_t>* v) : vec_(v) {}
+  ByteSink(uint8_t* buffer, size_t capacity) : buf_(buffer), cap_(capacity) {}
+  void push_back(uint8_t b) {
+    if (vec_) vec_->push_back(b);
+    else if (size_ < cap_) buf_[size_++] = b;
+    else overflow_ = true;
+  }
+  void append(const uint8_t* first, const uint8_t* last);
+  uint8_t back() const { return vec_ ? vec_->back() : buf_[size_ - 1]; }
+  void pop_back() {
+    if (vec_) vec_->pop_back();
+    else --size_;
+  }
+  size_t size() const { return vec_ ? vec_->size() : size_; }
+  bool overflow() const { return overflow_; }
+
+ private:
+  std::vector<uint8_t>* vec_ = nullptr;
+  uint8_t* buf_ = nullptr;
+  size_t cap_ = 0, size_ = 0;
+  bool overflow_ = false;
+};
+
 class ChunkStitcher {
  public:
   // returns false when the chunk cannot be concatenated (not appendable / not catable / window too large)
-  bool Append(const uint8_t* chunk, size_t size, std::vector<uint8_t>* out);
-  bool Finish(std::vector<uint8_t>* out);
+  bool Append(const uint8_t* chunk, size_t size, ByteSink* out);
+  bool Finish(ByteSink* out);
+  bool Append(const uint8_t* chunk, size_t size, std::vector<uint8_t>* out) {
+    ByteSink sink(out);
+    return Append(chunk, size, &sink);
+  }
+  bool Finish(std::vector<uint8_t>* out) {
+    ByteSink sink(out);
+    return Finish(&sink);
+  }
 
  private:
-  bool FlushPreviousStream(std::vector<uint8_t>* out);
+  bool FlushPreviousStream(ByteSink* out);
   uint8_t last_bytes_[2] = {0, 0};
   uint8_t last_bytes_len_ = 0;
   bool last_byte_sanitized_ = false;

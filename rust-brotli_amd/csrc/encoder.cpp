@@ -343,7 +343,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     result.resize(total_bytes);
     if (req.direct_out) {
       if (result.size() > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
-      memcpy(req.direct_out, result.data(), result.size());
+      if (req.direct_out_on_device) {
+        dev_h2d(req.direct_out, result.data(), result.size());
+        dev_sync();
+      } else {
+        memcpy(req.direct_out, result.data(), result.size());
+      }
       *req.direct_size = result.size();
     } else {
       out->insert(out->end(), result.begin(), result.end());
@@ -621,7 +626,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     stats.ms_phase[7] += clk.lap(prof);
     if (req.direct_out) {
       if (total_bytes > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
-      dev_d2h(req.direct_out, B.out_words, total_bytes);
+      if (req.direct_out_on_device) {
+        dev_d2d(req.direct_out, B.out_words, total_bytes);
+        dev_sync();
+      } else {
+        dev_d2h(req.direct_out, B.out_words, total_bytes);
+      }
       *req.direct_size = total_bytes;
       wrote_direct = true;
     } else {
@@ -651,7 +661,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   if (!wrote_direct) {
     if (req.direct_out) {
       if (result.size() > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
-      memcpy(req.direct_out, result.data(), result.size());
+      if (req.direct_out_on_device) {
+        dev_h2d(req.direct_out, result.data(), result.size());
+        dev_sync();
+      } else {
+        memcpy(req.direct_out, result.data(), result.size());
+      }
       *req.direct_size = result.size();
     } else {
       out->insert(out->end(), result.begin(), result.end());

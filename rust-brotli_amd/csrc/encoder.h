@@ -47,6 +47,7 @@ struct EncodeRequest {
   uint8_t* direct_out = nullptr;
   size_t direct_capacity = 0;
   size_t* direct_size = nullptr;
+  bool direct_out_on_device = false;  // direct_out is device memory: the stream stays in HBM (multi-GPU gather)
   // BROTLI_OPERATION_FLUSH support: `prefix` is the stream encoded so far, *carry_in its state (may be !valid for the
   // first piece); finish = false leaves the stream open (no ISLAST, padded to a byte boundary like the reference's
   // injected flush, encode.rs:1541-1566); the state for the next piece is written to *carry_out

@@ -1,0 +1,47 @@
+"""The multi-GPU job's plumbing (device-resident shard output, RCCL collectives, pinned staging, zero-copy stitch) on ONE
+GPU: a process group of size 1 on the nccl backend runs the same code path as bench.py --gpus N."""
+import os
+import socket
+import sys
+
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+Q, W = 1, 2
+
+
+def test_device_shard_job_world1():
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "rust-brotli_amd"))
+    import brotli_mi355x as bm
+    from brotli_mi355x import multi
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        lib = bm.default_library()
+        enc = multi.ShardEncoder(lib.lib)
+        data = synth.markov_text(3 << 20, 5)
+        dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        job = multi.DeviceShardJob(dist, lib, enc, 0, 1, len(data))
+        params = [(Q, 5), (W, 22)]
+        for _ in range(2):  # buffers are reused from step to step
+            got = bytes(job.step(params, b"", dev.data_ptr(), len(data)))
+        host = lib.concat_chunks([enc.encode(multi.shard_params(params, 0), b"", dev.data_ptr(), len(data), True)])
+        assert got == host
+        assert got == lib.concat_chunks([orc.stream_compress(data, multi.shard_params(params, 0))[0]])
+        assert orc.decompress(got, len(data)) == data
+    finally:
+        dist.destroy_process_group()
