@@ -158,6 +158,13 @@ int32_t BrotliMi355xCompressChunk(size_t num_params, const BrotliEncoderParamete
    src/enc/threading/mod.rs:565-660.  Returns 1 on success. */
 int32_t BrotliMi355xConcatChunks(size_t num_chunks, const uint8_t* const* chunks, const size_t* chunk_sizes,
                                  size_t* encoded_size, uint8_t* encoded);
+/* The same for chunks whose bodies live elsewhere (device memory): only the first and last min(8, size) bytes of every
+   chunk are given (heads[8 * i ..], tails[8 * i ..]).  The junction bytes are written into `encoded`; for chunk i the
+   caller then copies body_copies[3 * i + 2] bytes from offset body_copies[3 * i + 1] of the chunk to offset
+   body_copies[3 * i] of `encoded`. */
+int32_t BrotliMi355xConcatChunkEnds(size_t num_chunks, const uint8_t* heads, const uint8_t* tails,
+                                    const size_t* chunk_sizes, size_t* encoded_size, uint8_t* encoded,
+                                    size_t* body_copies);
 /* One-shot compression of a buffer that is already resident in device memory; per-stage timings (ms) are
    returned in stats[0..32) (may be NULL).  Same stream as BrotliEncoderCompress on the same bytes. */
 BROTLI_BOOL BrotliMi355xCompressDevice(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size,

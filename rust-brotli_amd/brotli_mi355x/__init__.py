@@ -79,6 +79,8 @@ def _bind(lib):
                                               c_size_t, c_size_t, POINTER(c_size_t), c_char_p]
     lib.BrotliMi355xConcatChunks.restype = c_int32
     lib.BrotliMi355xConcatChunks.argtypes = [c_size_t, POINTER(c_char_p), POINTER(c_size_t), POINTER(c_size_t), c_char_p]
+    lib.BrotliMi355xConcatChunkEnds.restype = c_int32
+    lib.BrotliMi355xConcatChunkEnds.argtypes = [c_size_t, c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_size_t), c_void_p, POINTER(c_size_t)]
     lib.BrotliMi355xCompressDevice.restype = c_int
     lib.BrotliMi355xCompressDevice.argtypes = [c_int, c_int, c_int, c_size_t, c_void_p, POINTER(c_size_t), c_char_p,
                                                POINTER(c_double)]
@@ -214,6 +216,18 @@ class Library(object):
         if not self.lib.BrotliMi355xConcatChunks(n_chunks, ctypes.cast(arr, ctypes.POINTER(c_char_p)), sizes, byref(n), self._concat_buf):
             raise BrotliCompressorException("BrotliMi355xConcatChunks failed: " + self.last_error())
         return memoryview(self._concat_buf)[:n.value]
+
+    def concat_chunk_ends(self, heads, tails, sizes, out_address, out_capacity):
+        """BrotliMi355xConcatChunkEnds: heads / tails are (n, 8) uint8 host tensors (or anything with data_ptr()) holding the
+        first / last bytes of every chunk; junction bytes go to out_address.  Returns (total size, [(dst, src, count)])"""
+        n_chunks = len(sizes)
+        csizes = (c_size_t * n_chunks)(*sizes)
+        bodies = (c_size_t * (3 * n_chunks))()
+        n = c_size_t(out_capacity)
+        if not self.lib.BrotliMi355xConcatChunkEnds(n_chunks, c_void_p(heads.data_ptr()), c_void_p(tails.data_ptr()), csizes, byref(n),
+                                                    c_void_p(out_address), bodies):
+            raise BrotliCompressorException("BrotliMi355xConcatChunkEnds failed: " + self.last_error())
+        return n.value, [(bodies[3 * i], bodies[3 * i + 1], bodies[3 * i + 2]) for i in range(n_chunks)]
 
     def encoder(self, **params):
         return Encoder(self, **params)

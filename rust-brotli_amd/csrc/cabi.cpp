@@ -561,6 +561,34 @@ int32_t BrotliMi355xConcatChunks(size_t num_chunks, const uint8_t* const* chunks
   return 1;
 }
 
+int32_t BrotliMi355xConcatChunkEnds(size_t num_chunks, const uint8_t* heads, const uint8_t* tails, const size_t* chunk_sizes,
+                                    size_t* encoded_size, uint8_t* encoded, size_t* body_copies) {
+  ByteSink out(encoded, *encoded_size);
+  ChunkStitcher stitcher;
+  for (size_t i = 0; i < num_chunks; ++i) {
+    ChunkView view;
+    view.size = chunk_sizes[i];
+    view.head = heads + 8 * i;
+    view.tail = tails + 8 * i;
+    view.head_len = view.tail_len = view.size < 8 ? view.size : 8;
+    BodyCopy body;
+    if (!stitcher.Append(view, &out, &body)) {
+      SetError("BrotliMi355xConcatChunkEnds", "chunk cannot be concatenated");
+      return 0;
+    }
+    body_copies[3 * i] = body.dst_offset;
+    body_copies[3 * i + 1] = body.src_offset;
+    body_copies[3 * i + 2] = body.size;
+  }
+  stitcher.Finish(&out);
+  if (out.overflow()) {
+    SetError("BrotliMi355xConcatChunkEnds", "insufficient output space");
+    return 0;
+  }
+  *encoded_size = out.size();
+  return 1;
+}
+
 const char* BrotliMi355xDeviceName(void) {
   try {
     return dev_name();

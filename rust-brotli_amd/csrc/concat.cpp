@@ -128,11 +128,20 @@ bool ChunkStitcher::FlushPreviousStream(ByteSink* out) {
 }
 
 bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, ByteSink* out) {
+  ChunkView view;
+  view.full = in;
+  view.size = in_len;
+  return Append(view, out, nullptr);
+}
+
+bool ChunkStitcher::Append(const ChunkView& in, ByteSink* out, BodyCopy* body) {
+  const size_t in_len = in.size;
+  if (body) *body = BodyCopy{0, 0, 0};
   // new_brotli_file() + stream(), concat/mod.rs:274-276, 450-566
   if (!FlushPreviousStream(out)) return false;
   uint8_t header[5] = {0, 0, 0, 0, 0};
   size_t num_read = in_len < 5 ? in_len : 5;
-  memcpy(header, in, num_read);
+  for (size_t i = 0; i < num_read; ++i) header[i] = in.at(i);
   size_t in_offset = num_read;
   const bool sufficient = (num_read == 4 && (127 & header[0]) != 17) || num_read == 5;
   if (!sufficient) return true;  // the reference waits for more input that never comes: the chunk is dropped
@@ -181,21 +190,25 @@ bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, ByteSink* out) {
   // body: keep the last two bytes back
   while (last_bytes_len_ != 2) {
     if (in_offset == in_len) return true;
-    last_bytes_[last_bytes_len_++] = in[in_offset++];
+    last_bytes_[last_bytes_len_++] = in.at(in_offset++);
   }
   const size_t to_copy = in_len - in_offset;
   if (to_copy == 0) return true;
   if (to_copy == 1) {
     out->push_back(last_bytes_[0]);
     last_bytes_[0] = last_bytes_[1];
-    last_bytes_[1] = in[in_offset];
+    last_bytes_[1] = in.at(in_offset);
     return true;
   }
   out->push_back(last_bytes_[0]);
   out->push_back(last_bytes_[1]);
-  out->append(in + in_offset, in + in_offset + to_copy - 2);
-  last_bytes_[0] = in[in_offset + to_copy - 2];
-  last_bytes_[1] = in[in_offset + to_copy - 1];
+  if (body) {
+    *body = BodyCopy{out->skip(to_copy - 2), in_offset, to_copy - 2};
+  } else {
+    out->append(in.full + in_offset, in.full + in_offset + to_copy - 2);
+  }
+  last_bytes_[0] = in.at(in_offset + to_copy - 2);
+  last_bytes_[1] = in.at(in_offset + to_copy - 1);
   return true;
 }
 

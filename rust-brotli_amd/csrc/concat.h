@@ -21,6 +21,13 @@ class ByteSink {
     else overflow_ = true;
   }
   void append(const uint8_t* first, const uint8_t* last);
+  // leaves n bytes of a caller-owned buffer unwritten (the caller fills them); returns their offset
+  size_t skip(size_t n) {
+    const size_t at = size_;
+    if (n > cap_ - size_) overflow_ = true;
+    else size_ += n;
+    return at;
+  }
   uint8_t back() const { return vec_ ? vec_->back() : buf_[size_ - 1]; }
   void pop_back() {
     if (vec_) vec_->pop_back();
@@ -36,8 +43,24 @@ class ByteSink {
   bool overflow_ = false;
 };
 
+// A compressed chunk as the stitcher sees it: either all of its bytes, or only its first and last few (the body then
+// stays where it is -- e.g. in device memory -- and the stitcher reports where it belongs in the output).
+struct ChunkView {
+  const uint8_t* full = nullptr;
+  const uint8_t* head = nullptr;  // first min(size, head_len) bytes
+  const uint8_t* tail = nullptr;  // last min(size, tail_len) bytes
+  size_t head_len = 0, tail_len = 0;
+  size_t size = 0;
+  uint8_t at(size_t i) const { return full ? full[i] : (i < head_len ? head[i] : tail[i - (size - tail_len)]); }
+};
+struct BodyCopy {
+  size_t dst_offset, src_offset, size;
+};
+
 class ChunkStitcher {
  public:
+  // body != nullptr: the bytes of the chunk body are not copied; *body says which range of the chunk belongs where
+  bool Append(const ChunkView& chunk, ByteSink* out, BodyCopy* body);
   // returns false when the chunk cannot be concatenated (not appendable / not catable / window too large)
   bool Append(const uint8_t* chunk, size_t size, ByteSink* out);
   bool Finish(ByteSink* out);
