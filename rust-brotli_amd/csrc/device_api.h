@@ -123,6 +123,15 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
 // same kernel over an explicit list of (segment, entry) pairs (used for the warm-up dry run)
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
                        SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);
+// Would a literal-only parse of these segments (no match found at any searched position, flags[which] says which were
+// searched) stay literal-only with another distance cache at its entry?  ok_dev[i] = 1 when none of the four distances
+// yields even a two-byte match at any searched position (FindLongestMatch accepts cache candidates from length 2,
+// mod.rs:1707-1741) -- conservative: 0 only means "parse it again".  H5 / H6 hashers (4 cache candidates) only.
+struct CacheCheck {
+  uint32_t segment;
+  int32_t cache[4];
+};
+void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items_dev, uint32_t count, uint8_t* ok_dev);
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)

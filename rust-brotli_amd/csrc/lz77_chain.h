@@ -746,8 +746,8 @@ struct FlagWriter {
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
 template <bool kH9>
-BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment& seg_in,
-                             const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
+BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment& seg_in,
+                                 const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
   Segment seg;
   seg.start = BR_UNIFORM(seg_in.start);
@@ -970,6 +970,7 @@ BR_DEV void br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScr
   next.head_base = position > seg.end ? tail_base : 0u;
   next.head_p1 = position > seg.end ? tail_p1 : 0u;
   next.pad = 0;
+  return n_searches;  // what the segment cost
 }
 
 // Parses segment k and -- in list rounds (sched != nullptr) -- keeps going into the following segments of the
@@ -981,24 +982,39 @@ template <bool kH9>
 BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment* segments,
                            SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
   SegEntry entry = entries[k];
-  // a chain takes at most max_continuation further segments: what it leaves behind is picked up in the next round by
-  // a chain of its own, so that a launch with many chains never lasts much longer than a handful of segment parses
-  // (launches with only a few chains are latency bound anyway and let them run to the end of the block)
-  uint32_t continued = 0;
+  // a chain takes on at most max_continuation further segments' worth of searches (one search every other byte is
+  // the going rate): what it leaves behind is picked up in the next round by a chain of its own, so that a launch with
+  // many chains never lasts much longer than a handful of segment parses (launches with only a few chains are latency
+  // bound anyway and let them run to the end of the block).  Counting searches rather than segments lets a chain run
+  // through a long stretch of incompressible data -- one search every 9 or 17 bytes (literal spree, mod.rs:2529-2546),
+  // and a state that no dry run can guess because it depends on where the stretch began -- in one launch.
+  uint32_t budget = 0;
+  bool first = true;
   for (;;) {
     const Segment seg = segments[k];
     SegEntry next;
-    br_parse_segment<kH9>(P, t, s, seg, entry, exits[k], next);
+    const uint32_t cost = br_parse_segment<kH9>(P, t, s, seg, entry, exits[k], next);
+    if (first) {
+      const uint32_t per_segment = (seg.end - seg.start) / 2;
+      budget = max_continuation > 0xffffffffu / (per_segment + 1) ? 0xffffffffu : max_continuation * per_segment;
+      first = false;
+    } else {
+      budget = budget > cost ? budget - cost : 0;
+    }
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
     const uint32_t mark = sched[k + 1];
     if (mark == 1 || mark == 3) break;  // has its own chain in this launch
-    if (continued >= max_continuation) break;
-    ++continued;
+    if (budget == 0) break;
     const bool forced = mark == 2;     // left to this chain, must be redone whatever state we arrive with
     const SegEntry old = entries[k + 1];
     bool same = old.pos == next.pos && old.apply == next.apply && old.head_kind == next.head_kind && old.head_base == next.head_base &&
                 old.head_p1 == next.head_p1;
     for (int i = 0; i < 4; ++i) same = same && old.cache[i] == next.cache[i];
+    // The old parse of k + 1 found nothing to copy: the host does better than walking through it.  A changed position
+    // it carries through a whole literal spree by arithmetic, giving every segment behind a chain of its own in the
+    // next round (PredictLiteralRun); a changed distance cache it checks against all searched positions in parallel
+    // (lz77_check_cache).
+    if (!kH9 && !same && !forced && exits[k + 1].n_cmds == 0 && exits[k + 1].n_searches != 0 && exits[k + 1].ext_len == 0) break;
     if (same && P.use_dictionary && next.dict_exact) {
       // static-dictionary throttle (mod.rs:1957-1960): would the old parse of k + 1 have seen the dictionary in the
       // same state under the counters this chain arrives with?  (mirrors DictTracker::Consume on the host)

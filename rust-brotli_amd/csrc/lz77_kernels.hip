@@ -479,6 +479,7 @@ struct ParseArgs {
 
 struct ParseTiming {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<uint32_t> counts;  // chains per launch
   uint64_t segments = 0;
 };
 static ParseTiming& parse_timing() {
@@ -540,6 +541,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   HIP_CHECK(hipEventRecord(e1, BR_STREAM));
   HIP_CHECK(hipGetLastError());
   pt.events.push_back(std::make_pair(e0, e1));
+  pt.counts.push_back(count);
   pt.segments += count;
 }
 
@@ -567,15 +569,38 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
                                                      const uint16_t* __restrict__ keys, uint32_t* __restrict__ changed_keys,
                                                      uint32_t* __restrict__ changed_count, uint32_t cap) {
   const uint32_t words = (n + 15) / 16;  // both arrays are padded by 64 bytes
-  for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < words; wi += gridDim.x * blockDim.x) {
-    const uint4 a = ((const uint4*)prev)[wi], b = ((const uint4*)next)[wi];
-    const uint32_t d[4] = {(a.x ^ b.x) & 0x01010101u, (a.y ^ b.y) & 0x01010101u, (a.z ^ b.z) & 0x01010101u, (a.w ^ b.w) & 0x01010101u};
-    if ((d[0] | d[1] | d[2] | d[3]) == 0) continue;
+  const uint32_t lane = threadIdx.x & 63u;
+  // (the loop bound is wave-uniform: all lanes of a wave take part in the scan below)
+  for (uint32_t w0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; w0 < words; w0 += gridDim.x * blockDim.x) {
+    const uint32_t wi = w0 + lane;
+    uint32_t d[4] = {0, 0, 0, 0};
+    if (wi < words) {
+      const uint4 a = ((const uint4*)prev)[wi], b = ((const uint4*)next)[wi];
+      d[0] = (a.x ^ b.x) & 0x01010101u;
+      d[1] = (a.y ^ b.y) & 0x01010101u;
+      d[2] = (a.z ^ b.z) & 0x01010101u;
+      d[3] = (a.w ^ b.w) & 0x01010101u;
+      // bytes past n are padding
+      for (uint32_t j = 0; j < 16; ++j)
+        if (wi * 16 + j >= n) d[j >> 2] &= ~(1u << (8 * (j & 3)));
+    }
+    const uint32_t mine = (uint32_t)(__popc(d[0]) + __popc(d[1]) + __popc(d[2]) + __popc(d[3]));
+    if (__ballot(mine != 0) == 0) continue;
+    // one atomic per wave: exclusive scan of the per-lane counts, the last lane reserves the range
+    uint32_t incl = mine;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(changed_count, incl);
+    base = (uint32_t)__shfl((int)base, 63, 64);
+    uint32_t idx = base + incl - mine;
+    if (mine == 0 || idx >= cap) continue;
     for (uint32_t j = 0; j < 16; ++j) {
-      const uint32_t q = wi * 16 + j;
-      if (q < n && ((d[j >> 2] >> (8 * (j & 3))) & 1u)) {
-        const uint32_t idx = atomicAdd(changed_count, 1u);
-        if (idx < cap) changed_keys[idx] = keys[q];
+      if ((d[j >> 2] >> (8 * (j & 3))) & 1u) {
+        if (idx < cap) changed_keys[idx] = keys[wi * 16 + j];
+        ++idx;
       }
     }
   }
@@ -638,22 +663,56 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments)
 #endif
   ParseTiming& pt = parse_timing();
   double ms = 0;
+  static const bool show = getenv("BROTLI_MI355X_DEBUG_LAUNCH") != nullptr;
+  size_t idx = 0;
   for (auto& ev : pt.events) {
     float t = 0;
     HIP_CHECK(hipEventSynchronize(ev.second));
     HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
+    if (show) fprintf(stderr, "  parse launch %zu: %u chains, %.3f ms\n", idx, pt.counts[idx], t);
+    ++idx;
     ms += t;
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
   *total_ms = ms;
   *launches = (uint32_t)pt.events.size();
+  pt.counts.clear();
   *segments = pt.segments;
   pt.events.clear();
   pt.segments = 0;
 }
 
 // ------------------------------------------------------------------------------------------ misc
+// see lz77_check_cache: one wave per segment, one lane per position
+__global__ __launch_bounds__(64) void k_check_cache(const uint8_t* __restrict__ text, const uint8_t* __restrict__ flags,
+                                                     const Segment* __restrict__ segments, const CacheCheck* __restrict__ items,
+                                                     uint32_t max_backward_limit, uint8_t* __restrict__ ok) {
+  const CacheCheck it = items[blockIdx.x];
+  const Segment seg = segments[it.segment];
+  bool hit = false;
+  for (uint32_t p = seg.start + threadIdx.x; p < seg.end; p += 64) {
+    if (!(flags[p] & kFlagSearched)) continue;
+    const uint32_t max_backward = p < max_backward_limit ? p : max_backward_limit;
+    const uint32_t cur = (uint32_t)text[p] | ((uint32_t)text[p + 1] << 8);
+    for (int i = 0; i < 4; ++i) {
+      const int64_t d = (int64_t)it.cache[i];
+      if (d <= 0 || d > (int64_t)max_backward) continue;
+      const uint32_t q = p - (uint32_t)d;
+      hit |= cur == ((uint32_t)text[q] | ((uint32_t)text[q + 1] << 8));
+    }
+  }
+  const bool any = __any(hit);
+  if (threadIdx.x == 0) ok[blockIdx.x] = any ? 0 : 1;
+}
+
+void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items_dev, uint32_t count, uint8_t* ok_dev) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_check_cache, dim3(count), dim3(64), 0, BR_STREAM, B.text, B.flags[which], B.segments, items_dev, P.max_backward_limit,
+                     ok_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void k_sample_histogram(const uint8_t* __restrict__ text, uint32_t start, uint32_t samples,
                                                            uint32_t* __restrict__ histo) {
   __shared__ uint32_t h[256];

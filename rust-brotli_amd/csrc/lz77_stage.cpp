@@ -282,6 +282,44 @@ struct DictTracker {
 // Chains the exits of the last parse into the entries of the next one, replaying the per-block
 // control flow of encode_data (encode.rs:2214-2543).  Returns true when every entry that the last
 // parse used equals the entry derived here (i.e. the parse is self-consistent).
+// Where a chain that finds no match at all leaves segment `seg` when it enters it in state `e`: the stepping of the
+// parse loop (br_parse_segment) through a literal spree -- every position, then every 9th, then every 17th
+// (mod.rs:2529-2546) -- is plain arithmetic on (position, apply).  Used by the resolver to carry a corrected phase
+// through a whole stretch of incompressible data in one pass; like every entry guess it is verified by the re-parse.
+static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const SegEntry& e, SegExit* x) {
+  const uint32_t pos_end = seg.blk_end, htl = P.htl, window = P.spree_window;
+  const uint32_t margin = htl - 1 > 4 ? htl - 1 : 4;
+  uint32_t position = e.pos;
+  const uint32_t apply = e.apply;
+  uint32_t tail_kind = e.head_kind, tail_base = e.head_base;
+  const uint32_t tail_p1 = e.head_p1;
+  while (position + htl < pos_end && position < seg.end) {
+    position++;
+    if (position > apply) {
+      if (position + 16 >= pos_end - margin) {
+        tail_kind = kHeadUnstored;
+        tail_base = position;
+        position = pos_end;
+      } else if (position > apply + 4 * window) {
+        tail_kind = kHeadVec4;
+        tail_base = position;
+        position += 16;
+      } else {
+        tail_kind = kHeadEven4;
+        tail_base = position;
+        position += 8;
+      }
+    }
+  }
+  if (seg.flags & kSegLastInBlock) position = pos_end;
+  x->pos = position;
+  x->apply = apply;
+  x->insert_len = position - e.pos;
+  x->tail_kind = position > seg.end ? tail_kind : (uint32_t)kHeadNone;
+  x->tail_base = position > seg.end ? tail_base : 0u;
+  x->tail_p1 = position > seg.end ? tail_p1 : 0u;
+}
+
 bool Lz77Stage::Resolve(bool final_pass) {
   const uint32_t nseg = (uint32_t)segments_.size();
   next_entries_.assign(nseg, SegEntry{});
@@ -293,12 +331,17 @@ bool Lz77Stage::Resolve(bool final_pass) {
   trailing_.clear();
   carries_.clear();
   bool consistent = true;
+  predicted_runs_ = 0;
   first_dirty_ = nseg;
   dirty_entry_.assign(nseg, 0);
-  auto mark = [&](uint32_t k, bool same) {
+  entry_reason_.assign(nseg, 0);
+  predicted_entry_.assign(nseg, 0);
+  // reason: bit 1 = the distance cache at the entry differs, bit 0 = anything else
+  auto mark = [&](uint32_t k, bool same, uint8_t reason = 1) {
     if (!same) {
       consistent = false;
       dirty_entry_[k] = 1;
+      entry_reason_[k] |= reason;
       if (k < first_dirty_) first_dirty_ = k;
     }
   };
@@ -356,12 +399,13 @@ bool Lz77Stage::Resolve(bool final_pass) {
     dict.Hint(&E);
     {
       const SegEntry& u = entries_[k0];
-      bool same = memcmp(u.cache, E.cache, sizeof(E.cache)) == 0 && u.ext_allowed == E.ext_allowed;
+      const bool cache_same = memcmp(u.cache, E.cache, sizeof(E.cache)) == 0;
+      const bool ext_same = u.ext_allowed == E.ext_allowed && !E.ext_allowed;  // (an extension runs at distance cache[0])
       if (dbg_mismatch_) {
-        dbg_first_[0] += memcmp(u.cache, E.cache, sizeof(E.cache)) != 0;
+        dbg_first_[0] += !cache_same;
         dbg_first_[1] += u.ext_allowed != E.ext_allowed;
       }
-      mark(k0, same);
+      mark(k0, cache_same && u.ext_allowed == E.ext_allowed, (uint8_t)((ext_same ? 0 : 1) | (cache_same ? 0 : 2)));
     }
     next_entries_[k0] = E;
     block_entry_guess_[bs] = E;
@@ -370,9 +414,28 @@ bool Lz77Stage::Resolve(bool final_pass) {
     int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
     memcpy(cur_cache, cache, sizeof(cache));
     for (uint32_t j = k0; j <= k1; ++j) {
-      const SegExit& X = exits_[j];
       const SegEntry& used = entries_[j];
-      mark(j, dict.Consume(j, used, X));
+      mark(j, dict.Consume(j, used, exits_[j]));
+      // A segment that was parsed from the wrong position and found nothing to copy sits in a literal spree: where
+      // the chain leaves it from the right position is arithmetic.  Chain that prediction on instead of the stale exit.
+      SegExit predicted;
+      const SegExit* chained = &exits_[j];
+      if (j > k0 && exits_[j].n_cmds == 0) {
+        const SegEntry& d = next_entries_[j];
+        // (a segment that a copy of the previous chain covered entirely searched nothing; if the new entry covers it as
+        // well, the state just passes through, otherwise the old exit is all there is to go by)
+        const bool moved = used.pos != d.pos || used.apply != d.apply || used.head_kind != d.head_kind || used.head_base != d.head_base;
+        if (moved && (exits_[j].n_searches != 0 || d.pos >= segments_[j].end)) {
+          predicted = exits_[j];
+          PredictLiteralRun(P_, segments_[j], d, &predicted);
+          chained = &predicted;
+          if (exits_[j].n_searches != 0) {
+            predicted_runs_++;
+            if (j < k1) predicted_entry_[j + 1] = 1;
+          }
+        }
+      }
+      const SegExit& X = *chained;
       // Exit cache = the segment's own pushes on top of its entry cache.  When the entry cache derived in
       // this pass differs from the one the chain used, keep the pushes and swap the inherited tail: the
       // chain is re-run with the new entry anyway, this only lets a change travel through segments that
@@ -418,8 +481,8 @@ bool Lz77Stage::Resolve(bool final_pass) {
         N.head_p1 = X.tail_p1;
         dict.Hint(&N);
         const SegEntry& u = entries_[j + 1];
-        bool same = u.pos == N.pos && u.apply == N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0 &&
-                    u.head_kind == N.head_kind && u.head_base == N.head_base && u.head_p1 == N.head_p1;
+        const bool cache_same = memcmp(u.cache, N.cache, sizeof(N.cache)) == 0;
+        const bool rest_same = u.pos == N.pos && u.apply == N.apply && u.head_kind == N.head_kind && u.head_base == N.head_base && u.head_p1 == N.head_p1;
         if (dbg_mismatch_) {
           dbg_first_[2] += u.head_kind != N.head_kind || u.head_base != N.head_base || u.head_p1 != N.head_p1;
           dbg_mismatch_[0] += u.pos != N.pos;
@@ -427,7 +490,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
           dbg_mismatch_[2] += u.pos == N.pos && memcmp(u.cache, N.cache, sizeof(N.cache)) != 0;
           dbg_mismatch_[3] += u.pos == N.pos && u.apply != N.apply && memcmp(u.cache, N.cache, sizeof(N.cache)) == 0;
         }
-        mark(j + 1, same);
+        mark(j + 1, cache_same && rest_same, (uint8_t)((rest_same ? 0 : 1) | (cache_same ? 0 : 2)));
         next_entries_[j + 1] = N;
       }
       memcpy(cur_cache, out_cache, sizeof(cur_cache));
@@ -576,6 +639,43 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
     }
   }
   stats_.segments_parsed += (uint64_t)count * warmup_bytes_ / segment_bytes_;
+}
+
+// Segments whose entry changed in the distance cache only and whose parse found nothing to copy: instead of parsing
+// them again, ask the device whether any of the new cache distances would match at a searched position.  If not, the
+// old parse holds for the new entry as it stands (no command to re-code, the cache passes through).
+uint32_t Lz77Stage::RecheckCacheOnly(int which) {
+  if (P_.hasher_kind == 9) return 0;
+  const uint32_t nseg = (uint32_t)segments_.size();
+  std::vector<CacheCheck> items;
+  for (uint32_t k = 0; k < nseg; ++k) {
+    if (!dirty_entry_[k] || entry_reason_[k] != 2) continue;
+    const SegExit& x = exits_[k];
+    if (x.n_cmds != 0 || x.ext_len != 0 || x.n_pushes != 0) continue;
+    CacheCheck c;
+    c.segment = k;
+    memcpy(c.cache, next_entries_[k].cache, sizeof(c.cache));
+    items.push_back(c);
+  }
+  if (items.empty()) return 0;
+  const uint32_t count = (uint32_t)items.size();
+  CacheCheck* items_dev = (CacheCheck*)dev_alloc(count * sizeof(CacheCheck) + 64);
+  uint8_t* ok_dev = (uint8_t*)dev_alloc(count + 64);
+  dev_h2d(items_dev, items.data(), count * sizeof(CacheCheck));
+  lz77_check_cache(P_, B_, which, items_dev, count, ok_dev);
+  std::vector<uint8_t> ok(count);
+  dev_d2h(ok.data(), ok_dev, count);
+  dev_free(items_dev);
+  dev_free(ok_dev);
+  uint32_t cleared = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (!ok[i]) continue;
+    const uint32_t k = items[i].segment;
+    memcpy(entries_[k].cache, items[i].cache, sizeof(items[i].cache));
+    dirty_entry_[k] = 0;
+    ++cleared;
+  }
+  return cleared;
 }
 
 namespace {
@@ -794,6 +894,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
     Resolve(false);
+    const uint32_t rechecked = RecheckCacheOnly(which);
+    stats_.cache_rechecks += rechecked;
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
     uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
     for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
@@ -802,7 +904,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     // per input block -- nothing is guessed inside a block then -- and the iteration starts over.  (Doing this for the
     // offending blocks only was tried and is worse on mixed content: a single-chain block that is merely re-validated
     // costs a 64 KiB serial parse per round.)
-    if (round == 0 && allow_restart && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)dbg_counts_[0] * 2 > nseg) {
+    if (round == 0 && allow_restart && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)(dbg_counts_[0] - std::min(dbg_counts_[0], predicted_runs_)) * 2 > nseg) {
       coarse_blocks_.assign(block_segment_bytes_.size(), 1);
       restart = true;
       break;
@@ -887,7 +989,9 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       sched[k] = 0;
       if (!dirty[k]) continue;
       const bool must_redo = pending[k] || (!cand_dirty.empty() && cand_dirty[k]);  // its candidates changed
-      const bool defer = (aggressive || entry_streak[k] >= 2) && !(segments_[k].flags & kSegFirstInBlock) && k > 0 && was_dirty[k - 1];
+      // (an entry predicted through a literal spree is as good as it gets: such a segment always gets its own chain)
+      const bool defer = (aggressive || entry_streak[k] >= 2) && !(segments_[k].flags & kSegFirstInBlock) && k > 0 && was_dirty[k - 1] &&
+                         !predicted_entry_[k];
       if (defer) {
         sched[k] = must_redo ? 2 : 0;
         pending[k] = must_redo;  // stays owed until some chain really gets here
@@ -906,7 +1010,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       }
     }
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u | block-first: cache %u ext %u | head %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dbg_first_[0], dbg_first_[1], dbg_first_[2], dict_death_seg_, predicted_death_, dict_flips_);
-    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u)\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid);
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u), predicted literal runs %u, cache rechecks passed %u\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid, predicted_runs_, rechecked);
     if (count == 0) {
       done = true;
       break;

@@ -37,6 +37,7 @@ struct Lz77Stats {
   uint64_t total_commands = 0;
   uint32_t incremental_ranks = 0, full_ranks = 0, coarse_restarts = 0;
   // wall-clock milliseconds per phase (device synchronised), filled when profiling is enabled
+  uint64_t cache_rechecks = 0;
   double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
 
@@ -160,6 +161,10 @@ class Lz77Stage {
   uint32_t* dbg_mismatch_ = nullptr;  // set to dbg_counts_ under BROTLI_MI355X_DEBUG
   std::map<std::pair<uint32_t, uint32_t>, bool> should_compress_cache_;
   uint32_t first_dirty_ = 0;
+  std::vector<uint8_t> predicted_entry_;  // the entry chained for segment k comes out of a predicted literal run
+  std::vector<uint8_t> entry_reason_;  // why dirty_entry_[k] is set, see Resolve()
+  uint32_t RecheckCacheOnly(int which);
+  uint32_t predicted_runs_ = 0;  // segments whose exit the last Resolve() predicted (literal spree arithmetic)
   std::vector<uint8_t> dirty_entry_;
   uint32_t dict_death_seg_ = 0xffffffffu;
   uint32_t dict_flips_ = 0;

@@ -231,6 +231,24 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
   for (uint32_t i = 0; i < samples; ++i) histo[text[start + i * 13u]]++;
 }
 
+void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items, uint32_t count, uint8_t* ok) {
+  for (uint32_t n = 0; n < count; ++n) {
+    const Segment& seg = B.segments[items[n].segment];
+    bool hit = false;
+    for (uint32_t p = seg.start; p < seg.end && !hit; ++p) {
+      if (!(B.flags[which][p] & kFlagSearched)) continue;
+      const uint32_t max_backward = p < P.max_backward_limit ? p : P.max_backward_limit;
+      for (int i = 0; i < 4; ++i) {
+        const int64_t d = (int64_t)items[n].cache[i];
+        if (d <= 0 || d > (int64_t)max_backward) continue;
+        const uint32_t q = p - (uint32_t)d;
+        hit |= B.text[p] == B.text[q] && B.text[p + 1] == B.text[q + 1];
+      }
+    }
+    ok[n] = hit ? 0 : 1;
+  }
+}
+
 void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets,
                           const uint32_t* counts, Command* out) {
   for (uint32_t k = 0; k < num_segments; ++k)

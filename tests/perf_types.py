@@ -19,6 +19,11 @@ cases = {
     "period100k": lambda: periodic(n, 100003),
     "lowentropy": lambda: rng.integers(0, 4, n, dtype=np.uint8).tobytes(),
     "text_x4": lambda: (synth.markov_text(n // 4) * 4)[:n],
+    "enwik": lambda: synth.enwik_like(n),
+    "silesia": lambda: synth.silesia_like(n),
+    "binary": lambda: synth.silesia_like(n, only=60),
+    "hex": lambda: synth.silesia_like(n, only=85),
+    "silesia_fine": lambda: synth.silesia_like(n, min_segment=64 << 10, max_segment=2 << 20),
 }
 sel = sys.argv[3].split(",") if len(sys.argv) > 3 else list(cases)
 for name in sel:

@@ -95,3 +95,65 @@ def repeated_excerpts(nbytes, seed=1, source_bytes=1 << 20):
         off = rng.next() % (len(text) - seglen)
         out += text[off:off + seglen]
     return bytes(out[:nbytes])
+
+
+def enwik_like(nbytes, seed=0x5EED000000000003):
+    """the Markov text wrapped in <page> records of 2..40 KiB with [[links]]"""
+    rng = XorShift(seed)
+    pool = markov_text(min(nbytes, 8 << 20) + (64 << 10), seed ^ 0x3333)
+    out = bytearray()
+    page = 0
+    at = 0
+    while len(out) < nbytes:
+        page += 1
+        want = 2048 + rng.next() % (38 << 10)
+        if at + want > len(pool):
+            pool = markov_text(len(pool), rng.next())
+            at = 0
+        body = bytearray(pool[at:at + want])
+        at += want
+        # turn some words into [[links]]
+        words = body.split(b" ")
+        step = 23 + rng.next() % 17
+        for i in range(step, len(words), step):
+            if words[i] and b"\n" not in words[i]:
+                words[i] = b"[[" + words[i] + b"]]"
+        title = b" ".join(words[:3]).replace(b"\n", b" ")
+        out += b"<page><title>" + title + b"</title><id>" + str(page).encode() + b"</id><text>" + b" ".join(words) + b"</text></page>\n"
+    return bytes(out[:nbytes])
+
+
+def silesia_like(nbytes, seed=0x5EED000000000004, min_segment=1 << 20, max_segment=32 << 20, only=None):
+    """segments of min_segment..max_segment bytes; 40 % fresh Markov text, 20 % enwik-style XML, 15 % binary
+    records (LE u32 counters + floats with 12 bits of entropy), 10 % zero fill, 10 % hex / source-like, 5 % random"""
+    import numpy as np
+    rng = XorShift(seed)
+    out = bytearray()
+    while len(out) < nbytes:
+        kind = rng.next() % 100
+        if only is not None:
+            kind = only
+        seglen = min(min_segment + rng.next() % (max_segment - min_segment + 1), nbytes - len(out))
+        sub = rng.next()
+        g = np.random.Generator(np.random.PCG64(sub))
+        if kind < 40:
+            out += markov_text(seglen, sub)
+        elif kind < 60:
+            out += enwik_like(seglen, sub)
+        elif kind < 75:
+            n = seglen // 8 + 1
+            rec = np.empty((n, 2), dtype="<u4")
+            rec[:, 0] = np.arange(n, dtype=np.uint32) * 3 + (sub & 0xffff)
+            rec[:, 1] = (np.float32(1.0) + g.integers(0, 4096, n).astype(np.float32) / np.float32(4096.0)).view(np.uint32)
+            out += rec.tobytes()[:seglen]
+        elif kind < 85:
+            out += bytes(seglen)
+        elif kind < 95:
+            raw = g.integers(0, 256, seglen // 2 + 1, dtype=np.uint8).tobytes().hex().encode()
+            lines = bytearray()
+            for i in range(0, len(raw), 64):
+                lines += b"  0x" + raw[i:i + 64] + b",\n"
+            out += lines[:seglen]
+        else:
+            out += g.integers(0, 256, seglen, dtype=np.uint8).tobytes()
+    return bytes(out[:nbytes])
