@@ -346,7 +346,17 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
   else if (x2 != 0) n = 16 + (uint32_t)(__builtin_ctzll(x2) >> 3);
   else if (x3 != 0) n = 24 + (uint32_t)(__builtin_ctzll(x3) >> 3);
   else n = 32;
-  if (n >= 32 && limit > 32) n = 32 + br_match_len(a + 32, b + 32, limit - 32);
+  if (n >= 32 && limit > 32) {
+    // long matches (runs, repeats): 32 bytes per trip while they last, then the 8-byte loop for the remainder
+    uint32_t i = 32;
+    while (i + 32 <= limit) {
+      const u64x2 c0 = *(const u64x2*)(a + i), c1 = *(const u64x2*)(a + i + 16);
+      const u64x2 d0 = *(const u64x2*)(b + i), d1 = *(const u64x2*)(b + i + 16);
+      if (((c0.x ^ d0.x) | (c0.y ^ d0.y) | (c1.x ^ d1.x) | (c1.y ^ d1.y)) != 0) break;
+      i += 32;
+    }
+    n = i + br_match_len(a + i, b + i, limit - i);
+  }
   return n < limit ? n : limit;
 }
 #endif
