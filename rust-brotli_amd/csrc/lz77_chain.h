@@ -79,6 +79,7 @@ struct ChainScratchT {  // one per wavefront (LDS on the device)
   int32_t dc[16];                // distance cache incl. the derived entries (mod.rs:632-651); lanes index it by candidate
   uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
   uint32_t cand_len[2][kMaxCandidates + 2];
+  uint32_t keep[12];  // br_parse_chain: what the previous parse of the segment being redone left behind
 };
 
 struct SearchResult {
@@ -980,7 +981,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   next.head_base = position > seg.end ? tail_base : 0u;
   next.head_p1 = position > seg.end ? tail_p1 : 0u;
   next.pad = 0;
-  return n_searches;  // what the segment cost
+  return (n_searches < 0x0fffffffu ? n_searches : 0x0fffffffu) | (n_pushes << 28);  // what the segment cost | distances pushed
 }
 
 // Parses segment k and -- in list rounds (sched != nullptr) -- keeps going into the following segments of the
@@ -1000,16 +1001,28 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
   // and a state that no dry run can guess because it depends on where the stretch began -- in one launch.
   uint32_t budget = 0;
   bool first = true;
+  // A segment entered because only the distance cache differed, whose parse then comes out as before (same pushes on
+  // top of another inherited tail), merely passes the cache along.  The host resolver composes that through any number
+  // of segments at once and has them verified side by side in the next round: the chain stops walking.  It keeps
+  // walking where its arrival really changes parses (data whose parse hangs on the cache contents).
+  bool watch = false, passes_along = false;
   for (;;) {
     const Segment seg = segments[k];
     SegEntry next;
-    const uint32_t cost = br_parse_segment<kH9>(P, t, s, seg, entry, exits[k], next);
+    const uint32_t ret = br_parse_segment<kH9>(P, t, s, seg, entry, exits[k], next);
+    const uint32_t cost = ret & 0x0fffffffu, np = ret >> 28;
     if (first) {
       const uint32_t per_segment = (seg.end - seg.start) / 2;
       budget = max_continuation > 0xffffffffu / (per_segment + 1) ? 0xffffffffu : max_continuation * per_segment;
       first = false;
     } else {
       budget = budget > cost ? budget - cost : 0;
+    }
+    if (watch) {
+      bool unchanged = np < 4 && np == s.keep[2] && next.pos == s.keep[0] && next.apply == s.keep[1] && next.head_kind == s.keep[3] &&
+                       next.head_base == s.keep[4] && next.head_p1 == s.keep[5];
+      for (uint32_t i = 0; i < 4; ++i) unchanged = unchanged && (i >= np || (uint32_t)next.cache[i] == s.keep[6 + i]);
+      passes_along = BR_UNIFORM(unchanged ? 1u : 0u) != 0;
     }
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
     const uint32_t mark = sched[k + 1];
@@ -1019,6 +1032,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
     const SegEntry old = entries[k + 1];
     bool same = old.pos == next.pos && old.apply == next.apply && old.head_kind == next.head_kind && old.head_base == next.head_base &&
                 old.head_p1 == next.head_p1;
+    const bool rest_same = same;
     for (int i = 0; i < 4; ++i) same = same && old.cache[i] == next.cache[i];
     // The old parse of k + 1 found nothing to copy: the host does better than walking through it.  A changed position
     // it carries through a whole literal spree by arithmetic, giving every segment behind a chain of its own in the
@@ -1046,7 +1060,19 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
       }
     }
     if (same && !forced) break;
+    if (passes_along && !forced) break;
+    watch = rest_same && !forced;
     BR_SYNC();
+    if (watch && BR_LANE == 0) {
+      const SegExit& ox = exits[k + 1];
+      s.keep[0] = ox.pos;
+      s.keep[1] = ox.apply;
+      s.keep[2] = ox.n_pushes;
+      s.keep[3] = ox.tail_kind;
+      s.keep[4] = ox.tail_base;
+      s.keep[5] = ox.tail_p1;
+      for (int i = 0; i < 4; ++i) s.keep[6 + i] = (uint32_t)ox.cache[i];
+    }
     ++k;
     if (BR_LANE == 0) {
       entries[k] = next;
