@@ -20,6 +20,7 @@ namespace brotli_mi355x {
 
 // ---- memory ----
 void* dev_alloc(size_t bytes);  // zero-initialised device allocation; throws std::runtime_error
+void* dev_alloc_uninit(size_t bytes);  // contents undefined: only for arrays that are written before they are read
 void dev_free(void* p);
 void dev_memset(void* p, int value, size_t bytes);
 void dev_h2d(void* dst, const void* src, size_t bytes);

@@ -1,5 +1,6 @@
 // device_runtime.hip -- device memory helpers and the read-only tables of the encoder hot path.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -42,8 +43,23 @@ size_t RoundUp(size_t bytes) {
 }
 }  // namespace
 
+static void* AllocBlock(size_t bytes);
 void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 16;
+  void* p = AllocBlock(bytes);
+  HIP_CHECK(hipMemsetAsync(p, 0, bytes, BR_STREAM));
+  return p;
+}
+// for the big work arrays that are written in full before anything reads them (zero-filling them costs a pass over
+// gigabytes per call); BROTLI_MI355X_POISON=1 fills them with a pattern instead, to flush out hidden dependencies
+void* dev_alloc_uninit(size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  void* p = AllocBlock(bytes);
+  static const bool poison = getenv("BROTLI_MI355X_POISON") != nullptr;
+  if (poison) HIP_CHECK(hipMemsetAsync(p, 0xA5, bytes, BR_STREAM));
+  return p;
+}
+static void* AllocBlock(size_t bytes) {
   const size_t cap = RoundUp(bytes);
   Pool& P = pool();
   void* p = nullptr;
@@ -76,7 +92,6 @@ void* dev_alloc(size_t bytes) {
     std::lock_guard<std::mutex> lock(P.mu);
     P.capacity[p] = cap;
   }
-  HIP_CHECK(hipMemsetAsync(p, 0, bytes, BR_STREAM));
   return p;
 }
 void dev_free(void* p) {

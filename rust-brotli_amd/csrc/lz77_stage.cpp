@@ -87,23 +87,23 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   const size_t M = P_.total_bytes;
   B_ = Lz77Buffers{};
   B_.text = text_dev;
-  B_.keys = (uint16_t*)dev_alloc(M * 2 + 64);
-  B_.by_key = (uint32_t*)dev_alloc(M * 4 + 64);
-  B_.sorted_keys = (uint16_t*)dev_alloc(M * 2 + 64);
-  B_.fbits = (uint8_t*)dev_alloc(M + 64);
+  B_.keys = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
+  B_.by_key = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
+  B_.sorted_keys = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
+  B_.fbits = (uint8_t*)dev_alloc_uninit(M + 64);
   B_.key_first = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.key_last = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
   B_.changed_count = (uint32_t*)dev_alloc(64);
-  B_.info[0] = (uint32_t*)dev_alloc(M * 8 + 64);
-  B_.info[1] = (uint32_t*)dev_alloc(M * 8 + 64);
+  B_.info[0] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
+  B_.info[1] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
   B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
   B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
   cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
-  B_.cmds = (Command*)dev_alloc(cmds_bytes_);
+  B_.cmds = (Command*)dev_alloc_uninit(cmds_bytes_);
   B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
   B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
   B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
@@ -724,6 +724,10 @@ void Lz77Stage::Run() {
   Gather();
   tm.stop(&stats_.ms_gather);
   total.stop(&stats_.ms_total);
+  if (prof)
+    fprintf(stderr, "lz77 stage: keys %.2f sort %.2f init %.2f warmup %.2f rank %.2f parse %.2f resolve %.2f gather %.2f | total %.2f ms, rounds %u\n",
+            stats_.ms_keys, stats_.ms_sort, stats_.ms_init, stats_.ms_warmup, stats_.ms_rank, stats_.ms_parse, stats_.ms_resolve, stats_.ms_gather,
+            stats_.ms_total, (unsigned)stats_.rounds);
 }
 
 // Re-cut the input into segments of a different size (the sort by key stays valid).
@@ -735,7 +739,7 @@ void Lz77Stage::Resegment(uint32_t segment_bytes) {
   const size_t need = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
   if (need > cmds_bytes_) {
     dev_free(B_.cmds);
-    B_.cmds = (Command*)dev_alloc(need);
+    B_.cmds = (Command*)dev_alloc_uninit(need);
     cmds_bytes_ = need;
   }
   dev_h2d(B_.segments, segments_.data(), segments_.size() * sizeof(Segment));
@@ -893,27 +897,10 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
-    Resolve(false);
-    const uint32_t rechecked = RecheckCacheOnly(which);
-    stats_.cache_rechecks += rechecked;
-    for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
-    uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
-    for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
-    // When most chains were started at the wrong position the input does not re-synchronise (sparse hashing in
-    // incompressible data, long runs: the phase of the previous chain never washes out).  It is re-cut into one chain
-    // per input block -- nothing is guessed inside a block then -- and the iteration starts over.  (Doing this for the
-    // offending blocks only was tried and is worse on mixed content: a single-chain block that is merely re-validated
-    // costs a 64 KiB serial parse per round.)
-    if (round == 0 && allow_restart && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)(dbg_counts_[0] - std::min(dbg_counts_[0], predicted_runs_)) * 2 > nseg) {
-      coarse_blocks_.assign(block_segment_bytes_.size(), 1);
-      restart = true;
-      break;
-    }
+    // the rank structures are brought up to date on the device while the host chains the exits together
     uint32_t n_changed = 0;
     dev_d2h(&n_changed, B_.changed_count, 4);
-    cand_dirty.clear();
     if (n_changed != 0) {
-      tm.stop(&stats_.ms_resolve);
       // few changes: re-rank only the keys concerned, in place; otherwise rebuild everything into the other buffer
       // and diff the two
       std::vector<uint32_t> changed;
@@ -955,6 +942,26 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         rbuf ^= 1;
         stats_.full_ranks++;
       }
+    }
+    tm.stop(&stats_.ms_rank);
+    Resolve(false);
+    const uint32_t rechecked = RecheckCacheOnly(which);
+    stats_.cache_rechecks += rechecked;
+    for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
+    uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
+    for (uint32_t k = 0; k < nseg; ++k) n_dirty_entry += dirty[k];
+    // When most chains were started at the wrong position the input does not re-synchronise (sparse hashing in
+    // incompressible data, long runs: the phase of the previous chain never washes out).  It is re-cut into one chain
+    // per input block -- nothing is guessed inside a block then -- and the iteration starts over.  (Doing this for the
+    // offending blocks only was tried and is worse on mixed content: a single-chain block that is merely re-validated
+    // costs a 64 KiB serial parse per round.)
+    if (round == 0 && allow_restart && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)(dbg_counts_[0] - std::min(dbg_counts_[0], predicted_runs_)) * 2 > nseg) {
+      coarse_blocks_.assign(block_segment_bytes_.size(), 1);
+      restart = true;
+      break;
+    }
+    cand_dirty.clear();
+    if (n_changed != 0) {
       cand_dirty.resize(nseg);
       dev_d2h(cand_dirty.data(), dirty_dev, nseg);
       for (uint32_t k = 0; k < nseg; ++k) {

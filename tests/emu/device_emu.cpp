@@ -23,6 +23,13 @@ void* dev_alloc(size_t bytes) {
   if (!p) throw std::runtime_error("emu alloc failed");
   return p;
 }
+void* dev_alloc_uninit(size_t bytes) {
+  // poisoned, so that the CPU tests notice a read of something the device build leaves undefined
+  void* p = malloc(bytes ? bytes : 16);
+  if (!p) throw std::runtime_error("emu alloc failed");
+  memset(p, 0xA5, bytes ? bytes : 16);
+  return p;
+}
 void dev_free(void* p) { free(p); }
 void dev_memset(void* p, int value, size_t bytes) { memset(p, value, bytes); }
 void dev_h2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }

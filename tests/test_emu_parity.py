@@ -39,6 +39,15 @@ def test_lz77_h6_and_spree(L):
     assert check("zeros200k", bytes(200000), 5, 22, lib=L)
 
 
+def test_lz77_silesia_like(L):
+    # literal sprees inside mixed content (the resolver predicts their phase), binary records (distance caches that
+    # pass through whole segments), random data with its rare cache matches (checked, not re-parsed)
+    assert check("silesia2M", synth.silesia_like(2 << 20, min_segment=16 << 10, max_segment=256 << 10), 5, 22, lib=L)
+    assert check("binary1M", synth.silesia_like(1 << 20, only=60), 5, 22, lib=L)
+    assert check("random2M", synth.random_bytes(2 << 20), 5, 22, lib=L)
+    assert check("enwik1M", synth.enwik_like(1 << 20), 5, 22, lib=L)
+
+
 def test_stream_bytes_fixtures(L):
     files = sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))) + [os.path.join(GOLDEN, "alice29.txt")]
     for f in files:

@@ -68,3 +68,13 @@ def test_quality9_h9(L):
     assert check("mixed2M q9", synth.mixed(2 << 20), 9, 22, lib=L)
     import cmp_flags
     assert cmp_flags.stored_flags_match(L, bytes(2 << 20), 9, 18)
+
+
+def test_silesia_like_and_enwik_like(L):
+    # SURVEY 8d C3 / C4 content: XML-wrapped text; a mix of text, XML, binary records, zero fill, hex and random
+    # stretches (literal sprees whose phase the resolver predicts, distance caches that pass through whole segments)
+    assert check("enwik8M", synth.enwik_like(8 << 20), 5, 22, lib=L)
+    assert check("silesia16M", synth.silesia_like(16 << 20, min_segment=64 << 10, max_segment=1 << 20), 5, 22, lib=L)
+    assert check("binary4M", synth.silesia_like(4 << 20, only=60), 5, 22, lib=L)
+    assert check("hex4M", synth.silesia_like(4 << 20, only=85), 5, 22, lib=L)
+    assert check("silesia4M q9", synth.silesia_like(4 << 20, min_segment=64 << 10, max_segment=512 << 10), 9, 22, lib=L)
