@@ -108,15 +108,42 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint16_t* __restrict__
   hist[threadIdx.x * num_tiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// stable scatter: elements keep their input order inside each digit
+// stable scatter: elements keep their input order inside each digit.  The tile is first reordered by digit in LDS, then
+// written out run by run, so that the lanes of a wave write neighbouring addresses (a direct scatter writes one isolated
+// 2- and 4-byte element per digit and round).
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                         uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                         uint32_t shift, uint32_t num_tiles, const uint32_t* __restrict__ offsets) {
-  __shared__ uint32_t base[256];
+  __shared__ uint32_t gbase[256];   // where digit d of this tile goes in the output
+  __shared__ uint32_t lstart[256];  // where digit d starts inside the reordered tile
+  __shared__ uint32_t run[256];     // next free local slot of digit d
   __shared__ uint32_t wcount[4][256];
+  __shared__ uint32_t wave_total[4];
+  __shared__ uint16_t skey[kSortTile];
+  __shared__ uint32_t sval[kSortTile];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  base[tid] = offsets[tid * num_tiles + blockIdx.x];
   const uint32_t tile_base = blockIdx.x * kSortTile;
+  const uint32_t tile_n = n - tile_base < kSortTile ? n - tile_base : kSortTile;
+  {
+    // digit counts of this tile out of the scanned histogram ([digit][tile] order), then their exclusive scan
+    const uint32_t idx = (uint32_t)tid * num_tiles + blockIdx.x;
+    const uint32_t here = offsets[idx];
+    const uint32_t next = idx + 1 < 256u * num_tiles ? offsets[idx + 1] : n;
+    const uint32_t count = next - here;
+    gbase[tid] = here;
+    uint32_t incl = count;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if ((uint32_t)lane >= off) incl += up;
+    }
+    if (lane == 63) wave_total[w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int i = 0; i < w; ++i) before += wave_total[i];
+    lstart[tid] = before + incl - count;
+    run[tid] = before + incl - count;
+  }
+  __syncthreads();
   for (uint32_t r = 0; r < 16; ++r) {
     const uint32_t i = tile_base + r * 256 + tid;
     const bool valid = i < n;
@@ -141,14 +168,21 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restric
     if (valid && rank_in_wave == 0) wcount[w][d] = __popcll(peers);
     __syncthreads();
     if (valid) {
-      uint32_t off = base[d] + rank_in_wave;
-      for (int i2 = 0; i2 < w; ++i2) off += wcount[i2][d];
-      keys_out[off] = (uint16_t)key;
-      vals_out[off] = val;
+      uint32_t at = run[d] + rank_in_wave;
+      for (int i2 = 0; i2 < w; ++i2) at += wcount[i2][d];
+      skey[at] = (uint16_t)key;
+      sval[at] = val;
     }
     __syncthreads();
-    base[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
+    run[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
     __syncthreads();
+  }
+  for (uint32_t at = tid; at < tile_n; at += 256) {
+    const uint32_t key = skey[at];
+    const uint32_t d = (key >> shift) & 255u;
+    const uint32_t dst = gbase[d] + (at - lstart[d]);
+    keys_out[dst] = (uint16_t)key;
+    vals_out[dst] = sval[at];
   }
 }
 

@@ -728,6 +728,8 @@ void Lz77Stage::Run() {
     fprintf(stderr, "lz77 stage: keys %.2f sort %.2f init %.2f warmup %.2f rank %.2f parse %.2f resolve %.2f gather %.2f | total %.2f ms, rounds %u\n",
             stats_.ms_keys, stats_.ms_sort, stats_.ms_init, stats_.ms_warmup, stats_.ms_rank, stats_.ms_parse, stats_.ms_resolve, stats_.ms_gather,
             stats_.ms_total, (unsigned)stats_.rounds);
+  if (prof) fprintf(stderr, "  host: Resolve() %.2f ms, recheck + scheduling %.2f ms\n", host_resolve_ms_, host_schedule_ms_);
+  host_resolve_ms_ = host_schedule_ms_ = 0;
 }
 
 // Re-cut the input into segments of a different size (the sort by key stays valid).
@@ -944,7 +946,10 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       }
     }
     tm.stop(&stats_.ms_rank);
+    const auto host_t0 = std::chrono::steady_clock::now();
     Resolve(false);
+    const auto host_t1 = std::chrono::steady_clock::now();
+    host_resolve_ms_ += std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();
     const uint32_t rechecked = RecheckCacheOnly(which);
     stats_.cache_rechecks += rechecked;
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
@@ -1018,6 +1023,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u | block-first: cache %u ext %u | head %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dbg_first_[0], dbg_first_[1], dbg_first_[2], dict_death_seg_, predicted_death_, dict_flips_);
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u), predicted literal runs %u, cache rechecks passed %u\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid, predicted_runs_, rechecked);
+    host_schedule_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
     if (count == 0) {
       done = true;
       break;

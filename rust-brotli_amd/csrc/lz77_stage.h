@@ -164,6 +164,7 @@ class Lz77Stage {
   std::vector<uint8_t> predicted_entry_;  // the entry chained for segment k comes out of a predicted literal run
   std::vector<uint8_t> entry_reason_;  // why dirty_entry_[k] is set, see Resolve()
   uint32_t RecheckCacheOnly(int which);
+  double host_resolve_ms_ = 0, host_schedule_ms_ = 0;  // BROTLI_MI355X_PROFILE
   uint32_t predicted_runs_ = 0;  // segments whose exit the last Resolve() predicted (literal spree arithmetic)
   std::vector<uint8_t> dirty_entry_;
   uint32_t dict_death_seg_ = 0xffffffffu;
