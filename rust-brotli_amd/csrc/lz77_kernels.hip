@@ -556,7 +556,8 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.first_segment = first_segment;
   a.list = list;
   a.sched = sched;
-  a.max_continuation = count <= 256 ? 1024u : kMaxContinuation;
+  static const uint32_t tuned = getenv("BROTLI_MI355X_CONT") ? (uint32_t)atoi(getenv("BROTLI_MI355X_CONT")) : kMaxContinuation;
+  a.max_continuation = count <= 256 ? 1024u : tuned;
   a.count = count;
   // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
   ParseTiming& pt = parse_timing();

@@ -37,4 +37,4 @@ for name in sel:
     ok = ""
     if check:
         ok = " identical=%s" % (orc.compress(d, 5, 22) == out)
-    print("%-11s %4d MiB  %7.1f MB/s  rounds %2d  out %9d  lz77 %.1f ms  mb %.1f ms%s" % (name, mb, len(d) / best / 1e6, st["lz77_rounds"], len(out), st["ms_lz77"], st["ms_metablock"], ok), flush=True)
+    print("%-12s %4d MiB  %7.1f ms  %7.1f MB/s  rounds %2d  out %9d  lz77 %.1f ms  mb %.1f ms%s" % (name, mb, best * 1e3, len(d) / best / 1e6, st["lz77_rounds"], len(out), st["ms_lz77"], st["ms_metablock"], ok), flush=True)
