@@ -242,12 +242,26 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
   for (;;) {
     bool is_final = false;
     if (g < n_gran) {
-      uint32_t in_g = n_symbols - g * min_block;
-      if (in_g > min_block) in_g = min_block;
+      // all the granules up to the next decision point in one go (the target grows with every merge, so homogeneous
+      // data asks for hundreds at a time): independent loads, instead of one memory round trip per granule
+      uint32_t m = (target - block_size) / min_block;
+      if (m == 0) m = 1;
+      if (m > n_gran - g) m = n_gran - g;
       const uint16_t* gr = G + (size_t)g * W;
-      for (uint32_t j = BR_TID; j < W; j += BR_NT) S.curr[j] += gr[j];
-      block_size += in_g;
-      g++;
+      for (uint32_t j = BR_TID; j < W; j += BR_NT) {
+        uint32_t acc = 0;
+        uint32_t q = 0;
+        for (; q + 4 <= m; q += 4) {
+          const uint32_t a0 = gr[(size_t)q * W + j], a1 = gr[(size_t)(q + 1) * W + j], a2 = gr[(size_t)(q + 2) * W + j],
+                         a3 = gr[(size_t)(q + 3) * W + j];
+          acc += a0 + a1 + a2 + a3;
+        }
+        for (; q < m; ++q) acc += gr[(size_t)q * W + j];
+        S.curr[j] += acc;
+      }
+      const uint64_t upto = (uint64_t)(g + m) * min_block;
+      block_size += (uint32_t)((upto < n_symbols ? upto : n_symbols) - (uint64_t)g * min_block);
+      g += m;
       BR_SYNC();
       if (block_size != target) continue;
     } else {
