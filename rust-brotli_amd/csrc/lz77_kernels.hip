@@ -664,7 +664,17 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ te
     const uint2 a = info_old[p], b = info_new[p];
     const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(b.y & 0xffffu, geo.block_size);
     bool same = na == nb;
-    for (uint32_t j = 0; same && j < na; ++j) same = sorted_old[a.x - 1 - j] == sorted_new[b.x - 1 - j];
+    // four entries per trip, all eight loads in flight (a row is one or two cache lines)
+    for (uint32_t j = 0; same && j < na; j += 4) {
+      uint32_t x[4], y[4];
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        const bool in = j + i < na;
+        x[i] = in ? sorted_old[a.x - 1 - j - i] : 0u;
+        y[i] = in ? sorted_new[b.x - 1 - j - i] : 0u;
+      }
+      same = x[0] == y[0] && x[1] == y[1] && x[2] == y[2] && x[3] == y[3];
+    }
     if (same) continue;
     if (br_row_change_matters(text, p, sorted_old + a.x - 1, na, sorted_new + b.x - 1, nb)) mark_dirty(p, geo, dirty);
   }
