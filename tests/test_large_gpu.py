@@ -64,3 +64,17 @@ def test_quality9_256MiB_round_trip(L):
     out, st = emu.encode_stream(L, data, [(Q, 9), (W, 22), (SH, len(data))])
     assert len(out) < len(data) // 3
     assert hashlib.sha256(orc.decompress(out, len(data))).digest() == hashlib.sha256(data).digest()
+
+
+def test_silesia_like_multi_8_shards(L):
+    """BASELINE config 4 at 1/64 of its size on one GPU: BrotliEncoderCompressMulti with 8 shards over a Silesia-like mix
+    (SURVEY 8d C4), byte-identical to the oracle's compress_multi (src/enc/threading/mod.rs:333-453) and round-tripping."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-brotli_amd"))
+    import brotli_mi355x
+    data = synth.silesia_like(64 << 20, min_segment=256 << 10, max_segment=8 << 20)
+    params = {1: 5, 2: 22}
+    got = bytes(brotli_mi355x.default_library().BrotliCompress(data, params, 8))
+    assert got == orc.compress_multi(data, [(1, 5), (2, 22)], 8)
+    assert orc.decompress(got, len(data)) == data
