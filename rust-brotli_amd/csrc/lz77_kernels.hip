@@ -522,7 +522,7 @@ static ParseTiming& parse_timing() {
 }
 
 template <bool kH9>
-__global__ __launch_bounds__(64) void k_parse_segments(ParseArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratchT<kH9> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
   // window and the rank rows its chains touch stay in that XCD's L2
@@ -568,10 +568,11 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   static const bool xcd_aware = getenv("BROTLI_MI355X_NO_XCD_MAP") == nullptr;
   a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
   const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
+  static const uint32_t lds_pad = getenv("BROTLI_MI355X_LDS_PAD") ? (uint32_t)atoi(getenv("BROTLI_MI355X_LDS_PAD")) : 0u;  // occupancy experiments
   if (P.hasher_kind == 9) {
-    hipLaunchKernelGGL(k_parse_segments<true>, dim3(grid), dim3(64), 0, BR_STREAM, a);
+    hipLaunchKernelGGL(k_parse_segments<true>, dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else {
-    hipLaunchKernelGGL(k_parse_segments<false>, dim3(grid), dim3(64), 0, BR_STREAM, a);
+    hipLaunchKernelGGL(k_parse_segments<false>, dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   }
   HIP_CHECK(hipEventRecord(e1, BR_STREAM));
   HIP_CHECK(hipGetLastError());
