@@ -925,7 +925,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
           widest = std::max(widest, width);
         }
         (void)widest;
-        incremental = affected <= (uint64_t)P_.total_bytes / 4;
+        static const uint32_t inc_pct = getenv("BROTLI_MI355X_INC_PCT") ? (uint32_t)atoi(getenv("BROTLI_MI355X_INC_PCT")) : 100u;
+        incremental = affected <= (uint64_t)P_.total_bytes * inc_pct / 100;
       }
       dev_memset(dirty_dev, 0, nseg);
       if (incremental) {
