@@ -144,6 +144,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if job:
+        job.finish()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -162,6 +164,8 @@ def main():
         seg_bytes = s[30]
         phases = s[10:20]
         lz_ms, mb_ms, lib_ms = s[7], s[8], s[9]
+    if job:
+        comp = job.finish()  # the pipeline hands out step i while step i + 1 is encoded: drain it inside the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -109,41 +109,71 @@ def compress_sharded(dist, library, encoder, params, lgwin, prefix, chunk, nbyte
 
 class DeviceShardJob(object):
     """The same job with the compressed shards kept in HBM until rank 0 has all of them: each rank encodes straight into
-    a device buffer, the gather runs GPU to GPU (RCCL over xGMI), rank 0 copies the gathered shards to pinned host memory
-    once and stitches them there.  Buffers are allocated once and reused by every step."""
+    a device buffer, the gather runs GPU to GPU (RCCL over xGMI), rank 0 copies the shard bodies to their place in a
+    pinned result and stitches the junctions there.  Buffers are allocated once and reused.
+
+    The job is a two-stage pipeline: gather + copy-out + stitch of step i run on a side stream while the ranks already
+    encode step i + 1 (double-buffered shard outputs), so step() hands back the stream of the PREVIOUS step (None the
+    first time) and finish() the last one."""
 
     def __init__(self, dist, library, encoder, rank, world, shard_bytes):
         import torch
         self.dist, self.library, self.encoder, self.rank, self.world = dist, library, encoder, rank, world
         self.cap = shard_bytes + shard_bytes // 4 + 4096
-        self.out = torch.zeros(self.cap, dtype=torch.uint8, device="cuda")
-        self.size = torch.zeros(1, dtype=torch.int64, device="cuda")
-        self.sizes = torch.zeros(world, dtype=torch.int64, device="cuda")
-        self.rows = torch.zeros((world, self.cap), dtype=torch.uint8, device="cuda") if rank == 0 else None
-        self.stitched = torch.zeros(world * self.cap + 64, dtype=torch.uint8).pin_memory() if rank == 0 else None
-        self.ends_host = torch.zeros((world, 16), dtype=torch.uint8).pin_memory() if rank == 0 else None
-        self.lane = torch.arange(8, dtype=torch.int64, device="cuda") if rank == 0 else None
+        self.side = torch.cuda.Stream()
+        self.out = [torch.zeros(self.cap, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.size = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+        self.sizes = [torch.zeros(world, dtype=torch.int64, device="cuda") for _ in range(2)]
+        root = rank == 0
+        self.rows = [torch.zeros((world, self.cap), dtype=torch.uint8, device="cuda") for _ in range(2)] if root else None
+        self.stitched = [torch.zeros(world * self.cap + 64, dtype=torch.uint8).pin_memory() for _ in range(2)] if root else None
+        self.ends_host = torch.zeros((world, 16), dtype=torch.uint8).pin_memory() if root else None
+        self.lane = torch.arange(8, dtype=torch.int64, device="cuda") if root else None
+        self.parity = 0
+        self.pending = None  # (event, buffer index, total size) of the step whose result has not been handed out yet
+
+    def _collect(self):
+        """waits for the copy-out of the pending step and returns its stream (rank 0) / None"""
+        if self.pending is None:
+            return None
+        event, b, total = self.pending
+        self.pending = None
+        event.synchronize()
+        if self.rank != 0:
+            return None
+        return memoryview(self.stitched[b].numpy())[:total]
 
     def step(self, params, prefix, chunk_ptr, nbytes):
         import torch
-        n = self.encoder.encode_to_device(shard_params(params, self.rank), prefix, chunk_ptr, nbytes, self.out.data_ptr(), self.cap)
-        self.size[0] = n
-        self.dist.all_gather_into_tensor(self.sizes, self.size)
-        sizes = [int(v) for v in self.sizes.tolist()]
-        mx = max(sizes)
-        gather_list = [self.rows[r, :mx] for r in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(self.out[:mx], gather_list, dst=0)
-        if self.rank != 0:
-            return None
-        # the stitcher only looks at the first and last bytes of every shard: fetch those, let it write the junction
-        # bytes into the pinned result, then copy every shard body from HBM to its place in the result (one D2H each)
-        tail_at = torch.clamp(self.sizes - 8, min=0)[:, None] + self.lane[None, :]
-        ends = torch.cat([self.rows[:, :8], torch.gather(self.rows, 1, tail_at)], dim=1)
-        self.ends_host.copy_(ends)
-        total, bodies = self.library.concat_chunk_ends(self.ends_host[:, :8].contiguous(), self.ends_host[:, 8:].contiguous(), sizes,
-                                                       self.stitched.data_ptr(), self.stitched.numel())
-        for r, (dst, src, count) in enumerate(bodies):
-            if count:
-                self.stitched[dst:dst + count].copy_(self.rows[r, src:src + count], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        return memoryview(self.stitched.numpy())[:total]
+        b = self.parity
+        self.parity ^= 1
+        # (the library call returns when the shard is complete in out[b]; the previous step's gather reads out[b ^ 1])
+        n = self.encoder.encode_to_device(shard_params(params, self.rank), prefix, chunk_ptr, nbytes, self.out[b].data_ptr(), self.cap)
+        previous = self._collect()
+        with torch.cuda.stream(self.side):
+            self.size[b][0] = n
+            self.dist.all_gather_into_tensor(self.sizes[b], self.size[b])
+            sizes = [int(v) for v in self.sizes[b].tolist()]
+            mx = max(sizes)
+            gather_list = [self.rows[b][r, :mx] for r in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(self.out[b][:mx], gather_list, dst=0)
+            total = 0
+            if self.rank == 0:
+                # the stitcher only looks at the first and last bytes of every shard: fetch those, let it write the
+                # junction bytes into the pinned result, then copy every shard body from HBM to its place in the result
+                rows = self.rows[b]
+                tail_at = torch.clamp(self.sizes[b] - 8, min=0)[:, None] + self.lane[None, :]
+                ends = torch.cat([rows[:, :8], torch.gather(rows, 1, tail_at)], dim=1)
+                self.ends_host.copy_(ends)
+                total, bodies = self.library.concat_chunk_ends(self.ends_host[:, :8].contiguous(), self.ends_host[:, 8:].contiguous(), sizes,
+                                                               self.stitched[b].data_ptr(), self.stitched[b].numel())
+                for r, (dst, src, count) in enumerate(bodies):
+                    if count:
+                        self.stitched[b][dst:dst + count].copy_(rows[r, src:src + count], non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(self.side)
+        self.pending = (event, b, total)
+        return previous
+
+    def finish(self):
+        return self._collect()

@@ -37,9 +37,13 @@ def test_device_shard_job_world1():
         torch.cuda.synchronize()
         job = multi.DeviceShardJob(dist, lib, enc, 0, 1, len(data))
         params = [(Q, 5), (W, 22)]
-        for _ in range(2):  # buffers are reused from step to step
-            got = bytes(job.step(params, b"", dev.data_ptr(), len(data)))
         host = lib.concat_chunks([enc.encode(multi.shard_params(params, 0), b"", dev.data_ptr(), len(data), True)])
+        # two-stage pipeline: a step hands out the stream of the step before it; buffers alternate from step to step
+        assert job.step(params, b"", dev.data_ptr(), len(data)) is None
+        for _ in range(3):
+            assert bytes(job.step(params, b"", dev.data_ptr(), len(data))) == host
+        got = bytes(job.finish())
+        assert job.finish() is None
         assert got == host
         assert got == lib.concat_chunks([orc.stream_compress(data, multi.shard_params(params, 0))[0]])
         assert orc.decompress(got, len(data)) == data
