@@ -30,7 +30,7 @@ void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint
 void mb_literal_map(const MbBuffers& B);
 void mb_context_stats(const MbBuffers& B, uint32_t* stats_dev);
 void mb_granule_histograms(const MbBuffers& B);
-void mb_split_chains(const MbBuffers& B);
+void mb_split_chains(const MbBuffers& B, bool wide = false);
 void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs);
 void mb_write_headers(const MbBuffers& B);
 void mb_symbol_bits(const MbBuffers& B, void* scan_scratch);

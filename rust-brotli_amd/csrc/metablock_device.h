@@ -697,7 +697,11 @@ BR_DEV void br_encode_context_map(const uint32_t* context_map, uint32_t context_
   if (num_clusters == 1) return;
   // MoveToFrontTransform
   {
+#if defined(BROTLI_HOST_EMU)
     uint8_t mtf[256];
+#else
+    __shared__ uint8_t mtf[256];  // (one lane works here; a private array would live in scratch memory)
+#endif
     uint32_t max_value = context_map[0];
     for (uint32_t i = 1; i < context_map_size; ++i)
       if (context_map[i] > max_value) max_value = context_map[i];
@@ -752,9 +756,15 @@ BR_DEV void br_encode_context_map(const uint32_t* context_map, uint32_t context_
     }
     num_rle_symbols = o;
   }
+#if defined(BROTLI_HOST_EMU)
   uint32_t histogram[272];
   uint8_t depths[272];
   uint16_t bits[272];
+#else
+  __shared__ uint32_t histogram[272];
+  __shared__ uint8_t depths[272];
+  __shared__ uint16_t bits[272];
+#endif
   for (int i = 0; i < 272; ++i) {
     histogram[i] = 0;
     depths[i] = 0;

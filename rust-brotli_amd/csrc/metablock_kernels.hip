@@ -113,14 +113,16 @@ void mb_granule_histograms(const MbBuffers& B) {
   HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void k_split_chains(MbBuffers B) {
+__global__ __launch_bounds__(1024) void k_split_chains(MbBuffers B) {
   __shared__ SplitScratch S;
   mb_item_split_chain(B, blockIdx.x / 3, blockIdx.x % 3, S);
 }
 
-void mb_split_chains(const MbBuffers& B) {
+// `wide`: some meta-block models its literals with the 13-context map (39 histogram rows per decision instead of 3-9):
+// 16 waves per chain take them side by side; otherwise 4 waves are enough and synchronise faster.
+void mb_split_chains(const MbBuffers& B, bool wide) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_split_chains, dim3(B.n_mb * 3), dim3(256), 0, BR_STREAM, B);
+  hipLaunchKernelGGL(k_split_chains, dim3(B.n_mb * 3), dim3(wide ? 1024 : 256), 0, BR_STREAM, B);
   HIP_CHECK(hipGetLastError());
 }
 
