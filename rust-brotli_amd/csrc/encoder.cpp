@@ -442,18 +442,22 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     }
     // prev bytes (encode.rs:2526-2534): bytes preceding the meta-block in the stream, 0 at the very start
     {
-      std::vector<uint8_t> tails((size_t)n_mb * 2, 0);
+      std::vector<uint32_t> where((size_t)n_mb * 2, 0xffffffffu);
       for (uint32_t m = 0; m < n_mb; ++m) {
-        uint8_t two[2] = {0, 0};
         const uint32_t s = descs[m].start;
         const uint32_t lo = (prefix_bytes && !req.prefix_is_file_continuation) ? prefix_bytes : 0;
-        if (s >= lo + 2) {
-          dev_d2h(two, text + s - 2, 2);
-        } else if (s == lo + 1) {
-          dev_d2h(two + 1, text + s - 1, 1);
-        }
-        descs[m].prev_byte = two[1];
-        descs[m].prev_byte2 = two[0];
+        if (s >= lo + 2) where[2 * m] = s - 2;
+        if (s >= lo + 1) where[2 * m + 1] = s - 1;
+      }
+      uint32_t* where_dev = mm.alloc<uint32_t>((size_t)n_mb * 2);
+      uint8_t* tails_dev = mm.alloc<uint8_t>((size_t)n_mb * 2);
+      std::vector<uint8_t> tails((size_t)n_mb * 2, 0);
+      dev_h2d(where_dev, where.data(), where.size() * 4);
+      mb_gather_bytes(text, where_dev, n_mb * 2, tails_dev);
+      dev_d2h(tails.data(), tails_dev, tails.size());
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        descs[m].prev_byte = tails[2 * m + 1];
+        descs[m].prev_byte2 = tails[2 * m];
       }
     }
     {

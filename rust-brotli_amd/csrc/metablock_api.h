@@ -27,6 +27,8 @@ size_t mb_scan_scratch_bytes(size_t n);
 void mb_command_scans(const MbBuffers& B, void* scan_scratch);
 // out_dev[m] = src[first command of meta-block m], out_dev[n_mb] = src[n_cmds]  (descs must be on the device)
 void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint32_t* out_dev);
+// out[i] = text[positions[i]] (0 for position 0xffffffff): a handful of scattered bytes in one round trip
+void mb_gather_bytes(const uint8_t* text, const uint32_t* positions_dev, uint32_t n, uint8_t* out_dev);
 void mb_literal_map(const MbBuffers& B);
 void mb_context_stats(const MbBuffers& B, uint32_t* stats_dev);
 void mb_granule_histograms(const MbBuffers& B);

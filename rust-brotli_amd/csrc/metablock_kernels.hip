@@ -32,6 +32,14 @@ void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint
   HIP_CHECK(hipGetLastError());
 }
 
+void mb_gather_bytes(const uint8_t* text, const uint32_t* positions_dev, uint32_t n, uint8_t* out_dev) {
+  for_each(n, [text, positions_dev, out_dev] __device__(uint32_t i) {
+    const uint32_t p = positions_dev[i];
+    out_dev[i] = p == 0xffffffffu ? (uint8_t)0 : text[p];
+  });
+  HIP_CHECK(hipGetLastError());
+}
+
 void mb_command_scans(const MbBuffers& B, void* scan_scratch) {
   const MbBuffers b = B;
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_counts(b, c); });

@@ -25,6 +25,10 @@ void mb_gather_at_metablock_starts(const MbBuffers& B, const uint32_t* src, uint
   for (uint32_t m = 0; m <= B.n_mb; ++m) out[m] = src[m < B.n_mb ? B.descs[m].cmd_offset : B.n_cmds];
 }
 
+void mb_gather_bytes(const uint8_t* text, const uint32_t* positions, uint32_t n, uint8_t* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = positions[i] == 0xffffffffu ? (uint8_t)0 : text[positions[i]];
+}
+
 void mb_command_scans(const MbBuffers& B, void*) {
   for (uint32_t c = 0; c < B.n_cmds; ++c) mb_item_command_counts(B, c);
   B.cmd_lit_start[B.n_cmds] = 0;
