@@ -24,7 +24,8 @@ void* dev_alloc_uninit(size_t bytes);  // contents undefined: only for arrays th
 void dev_free(void* p);
 void dev_memset(void* p, int value, size_t bytes);
 void dev_h2d(void* dst, const void* src, size_t bytes);
-void dev_d2h(void* dst, const void* src, size_t bytes);
+void dev_d2h(void* dst, const void* src, size_t bytes);        // copy + wait
+void dev_d2h_async(void* dst, const void* src, size_t bytes);  // several copies, then one dev_sync()
 void dev_d2d(void* dst, const void* src, size_t bytes);
 void dev_sync();
 const char* dev_name();  // "hip:gfx950 ..." or "host-emulation"

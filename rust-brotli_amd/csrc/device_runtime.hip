@@ -117,6 +117,9 @@ void dev_memset(void* p, int value, size_t bytes) {
 void dev_h2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, BR_STREAM));
 }
+void dev_d2h_async(void* dst, const void* src, size_t bytes) {
+  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, BR_STREAM));
+}
 void dev_d2h(void* dst, const void* src, size_t bytes) {
   if (bytes) {
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, BR_STREAM));

@@ -566,16 +566,17 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     mb_write_headers(B);
     stats.ms_phase[5] += clk.lap(prof);
     mb_symbol_bits(B, scan_scratch);
-    dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+    std::vector<uint32_t> body_off(n_mb + 1);
+    mb_gather_at_metablock_starts(B, B.cmd_nbits, boundary_words);
+    dev_d2h_async(results.data(), B.results, n_mb * sizeof(MbResult));
+    dev_d2h_async(body_off.data(), boundary_words, (n_mb + 1) * 4);
+    dev_sync();
     if (getenv("BROTLI_MI355X_DEBUG_MB"))
       for (uint32_t m = 0; m < n_mb; ++m)
         fprintf(stderr, "  meta-block %u [%u,%u) cmds %u lits %u contexts %u | literal blocks %u types %u | command blocks %u types %u | distance blocks %u types %u | header %u bits\n",
                 m, descs[m].start, descs[m].end, descs[m].n_symbols[1], descs[m].n_symbols[0], descs[m].num_contexts, results[m].num_blocks[0],
                 results[m].num_types[0], results[m].num_blocks[1], results[m].num_types[1], results[m].num_blocks[2], results[m].num_types[2],
                 results[m].header_bits);
-    std::vector<uint32_t> body_off(n_mb + 1);
-    mb_gather_at_metablock_starts(B, B.cmd_nbits, boundary_words);
-    dev_d2h(body_off.data(), boundary_words, (n_mb + 1) * 4);
     stats.ms_phase[6] += clk.lap(prof);
 
     // ---- layout of the stream (WriteMetaBlockInternal, encode.rs:1941-2167)

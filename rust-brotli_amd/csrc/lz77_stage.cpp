@@ -720,8 +720,9 @@ void Lz77Stage::Run() {
   lz77_sort_by_key(P_, B_);
   key_first_.resize(65537);
   key_last_.resize(65537);
-  dev_d2h(key_first_.data(), B_.key_first, 65537 * 4);
-  dev_d2h(key_last_.data(), B_.key_last, 65537 * 4);
+  dev_d2h_async(key_first_.data(), B_.key_first, 65537 * 4);
+  dev_d2h_async(key_last_.data(), B_.key_last, 65537 * 4);
+  dev_sync();
   tm.stop(&stats_.ms_sort);
   tm.stop(&stats_.ms_sort);
   RunRounds(true);
@@ -845,6 +846,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   std::vector<uint8_t> dirty(nseg, 0);
   std::vector<uint32_t> list(nseg);
   std::vector<SegEntry> used_entries(nseg);
+  std::vector<uint32_t> changed_all(kChangedCap);
   std::vector<uint8_t> entry_streak(nseg, 0), was_dirty, cand_dirty, pending(nseg, 0), sched(nseg, 0);
   for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
   uint32_t count = nseg;
@@ -883,11 +885,19 @@ void Lz77Stage::RunRounds(bool allow_restart) {
           shown++;
         }
     }
-    dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
+    // everything the host needs from this launch in one round trip: exit records, the change list, and -- in list
+    // rounds -- the entries and marks of the segments that chains continued into
+    uint32_t n_changed = 0;
+    dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
+    dev_d2h_async(&n_changed, B_.changed_count, 4);
+    dev_d2h_async(changed_all.data(), B_.changed_keys, (size_t)kChangedCap * 4);
+    if (!full_round) {
+      dev_d2h_async(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
+      dev_d2h_async(sched.data(), dirty_dev, nseg);
+    }
+    dev_sync();
     if (!full_round) {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
-      dev_d2h(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
-      dev_d2h(sched.data(), dirty_dev, nseg);
       uint32_t n_cont = 0, n_def0 = 0, n_def2 = 0;
       for (uint32_t k = 0; k < nseg; ++k) {
         n_cont += sched[k] == 3;
@@ -905,16 +915,13 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
     // the rank structures are brought up to date on the device while the host chains the exits together
-    uint32_t n_changed = 0;
-    dev_d2h(&n_changed, B_.changed_count, 4);
     if (n_changed != 0) {
       // few changes: re-rank only the keys concerned, in place; otherwise rebuild everything into the other buffer
       // and diff the two
       std::vector<uint32_t> changed;
       bool incremental = false;
       if (n_changed <= kChangedCap) {
-        changed.resize(n_changed);
-        dev_d2h(changed.data(), B_.changed_keys, (size_t)n_changed * 4);
+        changed.assign(changed_all.begin(), changed_all.begin() + n_changed);
         std::sort(changed.begin(), changed.end());
         changed.erase(std::unique(changed.begin(), changed.end()), changed.end());
         uint64_t affected = 0;

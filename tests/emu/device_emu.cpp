@@ -34,6 +34,7 @@ void dev_free(void* p) { free(p); }
 void dev_memset(void* p, int value, size_t bytes) { memset(p, value, bytes); }
 void dev_h2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 void dev_d2h(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+void dev_d2h_async(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 void dev_d2d(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
 void dev_sync() {}
 const char* dev_name() { return "host-emulation"; }
