@@ -126,9 +126,10 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
                        SegEntry* entries_dev, SegExit* exits_dev, uint32_t count);
 // Would a literal-only parse of these segments (no match found at any searched position, flags[which] says which were
-// searched) stay literal-only with another distance cache at its entry?  ok_dev[i] = 1 when none of the four distances
-// yields even a two-byte match at any searched position (FindLongestMatch accepts cache candidates from length 2,
-// mod.rs:1707-1741) -- conservative: 0 only means "parse it again".  H5 / H6 hashers (4 cache candidates) only.
+// searched) stay literal-only with another distance cache at its entry?  ok_dev[i] = 1 when none of the P.ndist
+// candidate distances derived from it (4 at qualities 5-6, 10 at 7-8) yields even a two-byte match at any searched
+// position (FindLongestMatch accepts cache candidates from length 2, mod.rs:1707-1741) -- conservative: 0 only means
+// "parse it again".  H5 / H6 hashers only.
 struct CacheCheck {
   uint32_t segment;
   int32_t cache[4];

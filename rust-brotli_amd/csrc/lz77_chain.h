@@ -307,9 +307,6 @@ struct DictState {
   // which lets the host accept it in either regime (and keep exact counters).
   uint32_t vlookups, vwould;
   int32_t vmaxdef;
-  // the entry state says -- exactly, not as a guess -- that the throttle has switched the dictionary off for good
-  // (mod.rs:1957-1960: no lookups are counted any more, so it never comes back): no probes, no bookkeeping (mode 4)
-  uint32_t off;
 };
 
 // ---- speculative probe of two consecutive positions ---------------------------------------------------
@@ -367,9 +364,10 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
 
 template <bool kH9>
 BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, ProbeMeta& m, uint32_t p0,
-                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end, uint32_t ndict) {
+                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
   const uint32_t ndist = P.ndist;
   const uint32_t block_size = 1u << P.block_bits;
+  const uint32_t ndict = P.use_dictionary ? 2u : 0u;
   // rank records of the positions around p0: one coalesced load serves the next ~60 positions
   if (p0 < m.win_base || p0 + 1 >= m.win_base + kInfoWindow) {
     BR_SYNC();
@@ -613,9 +611,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     }
   }
 #endif
-  if (!out.found && P.use_dictionary && ds.off) {
-    ds.mode = 4;
-  } else if (!out.found && P.use_dictionary) {
+  if (!out.found && P.use_dictionary) {
     // SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false), on the probed items
     const bool dead = ds.matches < (ds.lookups >> 7);
     const uint32_t seen = dead ? 2u : 1u;
@@ -672,7 +668,7 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
     return r;
   }
   BR_SYNC();
-  br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end, (P.use_dictionary && !ds.off) ? 2u : 0u);
+  br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end);
   unsigned long long t1 = BR_TICK();
   m.t_probe += t1 - t0;
   m.n_probe++;
@@ -684,7 +680,7 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
     BR_SYNC();  // every lane is done reading the previous probe
-    br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end, (P.use_dictionary && !ds.off) ? 2u : 0u);
+    br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end);
     w = 0;
   }
   return br_fold_probe<kH9>(P, t, s, m, w, ds, blk_end);
@@ -789,7 +785,6 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   ds.vlookups = 0;
   ds.vwould = 0;
   ds.vmaxdef = -(1 << 30);
-  ds.off = (BR_UNIFORM(entry.dict_exact) != 0 && ds.matches < (ds.lookups >> 7)) ? 1u : 0u;
   FlagWriter fw;
   fw.next = t.flags_next;
   fw.enabled = !(seg.flags & kSegWarmup);
@@ -1054,7 +1049,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
       const bool stays_alive = 128ll * (long long)next.dict_matches - (long long)next.dict_lookups + 127 >= (long long)maxdef;
       if (mode != 0) {
         if (dead) {
-          same = mode == 2 || mode == 4 || (mode == 1 && no_match);
+          same = mode == 2 || (mode == 1 && no_match);
         } else if (old.dict_lookups == next.dict_lookups && old.dict_matches == next.dict_matches) {
           same = true;
         } else if (mode == 1) {

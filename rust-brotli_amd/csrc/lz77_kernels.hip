@@ -733,16 +733,22 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments)
 // see lz77_check_cache: one wave per segment, one lane per position
 __global__ __launch_bounds__(64) void k_check_cache(const uint8_t* __restrict__ text, const uint8_t* __restrict__ flags,
                                                      const Segment* __restrict__ segments, const CacheCheck* __restrict__ items,
-                                                     uint32_t max_backward_limit, uint8_t* __restrict__ ok) {
+                                                     uint32_t max_backward_limit, uint32_t ndist, uint8_t* __restrict__ ok) {
   const CacheCheck it = items[blockIdx.x];
   const Segment seg = segments[it.segment];
+  // the candidate distances FindLongestMatch derives from the cache (adv_prepare_distance_cache, mod.rs:632-651):
+  // 4 at qualities 5-6, 10 (last distance +-1..3) at 7-8
+  int32_t dc[16];
+  for (int i = 0; i < 4; ++i) dc[i] = it.cache[i];
+  for (int i = 4; i < 16; ++i) dc[i] = 0;
+  br_prepare_distance_cache(dc, ndist);
   bool hit = false;
   for (uint32_t p = seg.start + threadIdx.x; p < seg.end; p += 64) {
     if (!(flags[p] & kFlagSearched)) continue;
     const uint32_t max_backward = p < max_backward_limit ? p : max_backward_limit;
     const uint32_t cur = (uint32_t)text[p] | ((uint32_t)text[p + 1] << 8);
-    for (int i = 0; i < 4; ++i) {
-      const int64_t d = (int64_t)it.cache[i];
+    for (uint32_t i = 0; i < ndist; ++i) {
+      const int64_t d = (int64_t)dc[i];
       if (d <= 0 || d > (int64_t)max_backward) continue;
       const uint32_t q = p - (uint32_t)d;
       hit |= cur == ((uint32_t)text[q] | ((uint32_t)text[q + 1] << 8));
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(64) void k_check_cache(const uint8_t* __restrict__ 
 void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items_dev, uint32_t count, uint8_t* ok_dev) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_check_cache, dim3(count), dim3(64), 0, BR_STREAM, B.text, B.flags[which], B.segments, items_dev, P.max_backward_limit,
-                     ok_dev);
+                     P.ndist, ok_dev);
   HIP_CHECK(hipGetLastError());
 }
 

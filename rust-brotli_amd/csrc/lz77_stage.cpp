@@ -219,7 +219,7 @@ struct DictTracker {
     if (!use) return true;
     const bool no_match = x.dict_matches == used.dict_matches;
     if (state == kDead || state == kUnknown) {
-      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || x.dict_mode == 4 || (x.dict_mode == 1 && no_match);
+      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || (x.dict_mode == 1 && no_match);
       if (!ok) flips++;
       return ok;
     }
@@ -257,11 +257,6 @@ struct DictTracker {
           next = kFuzzy;
           slack += kSlackPerChain;
         }
-        break;
-      case 4:  // was told the dictionary is off for good and kept no books: has to be redone with it on
-        ok = false;
-        next = kFuzzy;
-        slack += kSlackPerChain;
         break;
       default:  // switched off inside the chain under its own counters: only meaningful when those were exact
         if (exact) {

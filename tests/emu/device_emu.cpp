@@ -242,12 +242,15 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
 void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items, uint32_t count, uint8_t* ok) {
   for (uint32_t n = 0; n < count; ++n) {
     const Segment& seg = B.segments[items[n].segment];
+    int32_t dc[16] = {0};
+    for (int i = 0; i < 4; ++i) dc[i] = items[n].cache[i];
+    br_prepare_distance_cache(dc, P.ndist);
     bool hit = false;
     for (uint32_t p = seg.start; p < seg.end && !hit; ++p) {
       if (!(B.flags[which][p] & kFlagSearched)) continue;
       const uint32_t max_backward = p < P.max_backward_limit ? p : P.max_backward_limit;
-      for (int i = 0; i < 4; ++i) {
-        const int64_t d = (int64_t)items[n].cache[i];
+      for (uint32_t i = 0; i < P.ndist; ++i) {
+        const int64_t d = (int64_t)dc[i];
         if (d <= 0 || d > (int64_t)max_backward) continue;
         const uint32_t q = p - (uint32_t)d;
         hit |= B.text[p] == B.text[q] && B.text[p + 1] == B.text[q + 1];

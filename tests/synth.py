@@ -157,3 +157,25 @@ def silesia_like(nbytes, seed=0x5EED000000000004, min_segment=1 << 20, max_segme
         else:
             out += g.integers(0, 256, seglen, dtype=np.uint8).tobytes()
     return bytes(out[:nbytes])
+
+
+def stretches(nbytes, seed=1):
+    """Stretches of random bytes, zero fill, text, binary records and hex of random lengths (1 B .. 200 KB): literal
+    sprees next to compressible data, rare distance-cache hits inside the sprees (found by the fuzz sweep: at
+    qualities 7-8 the cache contributes 10 candidate distances, not 4)."""
+    rng = XorShift(seed)
+    text = markov_text(1 << 20, seed ^ 0x77)
+    rand = random_bytes(1 << 20, seed ^ 0x78)
+    binary = silesia_like(1 << 20, seed ^ 0x79, only=60)
+    hexa = silesia_like(1 << 20, seed ^ 0x7a, only=85)
+    out = bytearray()
+    while len(out) < nbytes:
+        k = rng.next() % 5
+        m = 1 + rng.next() % (200000 if k else 20000)
+        src = [rand, None, text, binary, hexa][k]
+        if src is None:
+            out += bytes(m)
+        else:
+            o = rng.next() % max(1, len(src) - m)
+            out += src[o:o + m]
+    return bytes(out[:nbytes])

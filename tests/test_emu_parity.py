@@ -95,3 +95,8 @@ def test_quality9_h9(L):
     import cmp_flags
     assert cmp_flags.stored_flags_match(L, bytes(2 << 20), 9, 18)
     assert check_bytes(L, "mixed1M q9", synth.mixed(1 << 20), [(Q, 9), (W, 22)], verbose=False)
+
+
+def test_distance_cache_check(L):
+    import check_cache_cases
+    check_cache_cases.run(L)

@@ -78,3 +78,8 @@ def test_silesia_like_and_enwik_like(L):
     assert check("binary4M", synth.silesia_like(4 << 20, only=60), 5, 22, lib=L)
     assert check("hex4M", synth.silesia_like(4 << 20, only=85), 5, 22, lib=L)
     assert check("silesia4M q9", synth.silesia_like(4 << 20, min_segment=64 << 10, max_segment=512 << 10), 9, 22, lib=L)
+
+
+def test_distance_cache_check(L):
+    import check_cache_cases
+    check_cache_cases.run(L)
