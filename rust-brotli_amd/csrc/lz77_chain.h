@@ -481,7 +481,8 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     if (!same) continue;
     // fix_unbroken_len, mod.rs:42-54
     uint32_t len = unbroken;
-    if (brk != 0 && prev < brk && prev + unbroken > brk) len = brk - prev;
+    // (on the ring-buffer index of the candidate, like the reference: the rule comes back with every revolution of the ring)
+    if (brk != 0 && (prev & P.ring_mask) < brk && (prev & P.ring_mask) + unbroken > brk) len = brk - (prev & P.ring_mask);
     if (c < ndist) {
       if (unbroken >= 3 || (unbroken == 2 && c < 2)) {
         const uint32_t score = br_score_cache<kH9>(P, len, c);
@@ -533,7 +534,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     const unsigned long long stop = __ballot(in_range && !is_cache && !has);
     const unsigned long long below_stop = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;  // lanes in front of the first stop
     const bool special_lane = has && (((prev & P.ring_mask) + unbroken > P.ring_mask) || unbroken == max_length ||
-                                      (prev < brk && prev + unbroken > brk));
+                                      ((prev & P.ring_mask) < brk && (prev & P.ring_mask) + unbroken > brk));
     const bool cur_near_wrap = (cur & P.ring_mask) + max_length > P.ring_mask;
     if (!cur_near_wrap && __ballot(special_lane) == 0) {
       folded = true;
@@ -574,7 +575,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
       walk_broken = true;
     }
     uint32_t len = unbroken;
-    if (brk != 0 && alive && prev < brk && prev + unbroken > brk) len = brk - prev;  // fix_unbroken_len
+    if (brk != 0 && alive && (prev & P.ring_mask) < brk && (prev & P.ring_mask) + unbroken > brk) len = brk - (prev & P.ring_mask);  // fix_unbroken_len
     const uint32_t backward = cur - prev;
     bool type_ok;
     uint32_t score;

@@ -1,0 +1,66 @@
+"""Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
+[emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
+oracle."""
+import sys, time
+import synth, orc
+import test_cabi
+kind = "emu" if len(sys.argv) > 3 and sys.argv[3] == "emu" else "gpu"
+lib = test_cabi._load(kind)
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = synth.XorShift(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+Q, W, MAGIC = 1, 2, 169
+pools = [synth.markov_text(3 << 20, 31), synth.mixed(3 << 20, 32), synth.silesia_like(3 << 20, 33, min_segment=8 << 10, max_segment=200 << 10),
+         synth.stretches(3 << 20, 34), synth.repeated_excerpts(3 << 20, 35)]
+bad = 0
+t0 = time.time()
+for c in range(cases):
+    pool = pools[rng.next() % len(pools)]
+    n = 1 + rng.next() % (1200000 if rng.next() % 3 else 5000)
+    o = rng.next() % (len(pool) - n)
+    d = pool[o:o + n]
+    q = 5 + rng.next() % 5
+    w = [17, 18, 20, 22, 24][rng.next() % 5]
+    mode = rng.next() % 3
+    try:
+        if mode == 0:
+            nt = 1 + rng.next() % 9
+            got = bytes(lib.BrotliCompress(d, {Q: q, W: w}, nt))
+            want = orc.compress_multi(d, [(Q, q), (W, w)], nt) if nt > 1 else orc.stream_compress(d, [(Q, q), (W, w)])[0]
+            ok = got == want and orc.decompress(got, len(d)) == d
+            what = "multi nt=%d" % nt
+        else:
+            ncut = 1 + rng.next() % 4
+            cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))
+            ops = []
+            for cut in cuts:
+                if mode == 2 and rng.next() % 2:
+                    ops.append((cut, bytes([65 + (rng.next() % 26)]) * (2 + rng.next() % 300)))
+                else:
+                    ops.append(cut)
+            e = lib.encoder(params=[(Q, q), (W, w)])
+            pieces, pos = [], 0
+            for item in ops:
+                if isinstance(item, tuple):
+                    cpos, meta = item
+                    if cpos > pos:
+                        e.write(d[pos:cpos])
+                    pieces.append(e.emit_metadata(meta))
+                else:
+                    cpos = item
+                    pieces.append(e.flush(d[pos:cpos]))
+                pos = cpos
+            e.write(d[pos:])
+            pieces.append(e.finish())
+            e.close()
+            want = orc.stream_with_flushes(d, [(Q, q), (W, w)], ops)
+            ok = pieces == want and orc.decompress(b"".join(pieces), len(d)) == d
+            what = "ops %r" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops],)
+    except Exception as ex:
+        ok = False
+        what = "EXCEPTION %r" % (ex,)
+    if not ok:
+        bad += 1
+        print("FAIL case %d n %d q %d w %d %s" % (c, n, q, w, what), flush=True)
+        open("/tmp/fuzzapi_fail_%d.bin" % c, "wb").write(d)
+print("%d cases, %d failures, %.1f s" % (cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)

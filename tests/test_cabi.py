@@ -61,6 +61,12 @@ def _suite(lib):
     for data in (b"", b"x", b"xy", b"xyz", d[:17]):
         for nt in (2, 5):
             assert bytes(lib.BrotliCompress(data, {Q: 5, MAGIC: 1}, nt)) == orc.compress_multi(data, [(Q, 5), (MAGIC, 1)], nt)
+    # a shard long enough for its ring buffer to wrap (lgwin 17: 256 KiB ring, 128 KiB of prefix): the reference applies the
+    # "no match across the end of the custom dictionary" rule to ring indices, i.e. again in every revolution
+    # (backward_references/mod.rs:42-54, 1712-1724); found by the fuzz sweep
+    for seed in (2, 6):
+        t = synth.markov_text(700000, seed)
+        assert bytes(lib.BrotliCompress(t, {Q: 5, W: 17}, 2)) == orc.compress_multi(t, [(Q, 5), (W, 17)], 2)
     # chunk + concat path used for multi-GPU == in-process multi
     chunks = [lib.compress_chunk(d, len(d), t, 4, {Q: 5, W: 22}) for t in range(4)]
     assert lib.concat_chunks(chunks) == orc.compress_multi(d, [(Q, 5), (W, 22)], 4)
