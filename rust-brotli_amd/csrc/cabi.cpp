@@ -44,6 +44,7 @@ struct BrotliEncoderStateStruct {
   std::vector<uint8_t> input;
   std::vector<uint8_t> dictionary;
   bool has_dictionary;
+  size_t size_hint_at_dictionary;  // params.size_hint when BrotliEncoderSetCustomDictionary ran
   std::vector<uint8_t> output;
   size_t output_pos;
   uint64_t total_out;
@@ -105,6 +106,8 @@ bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = fal
       req.prefix_size = use;
       req.prefix_is_file_continuation = false;
       req.hasher_chosen_before_size_hint = true;
+      req.has_hasher_size_hint = true;
+      req.hasher_size_hint = s->size_hint_at_dictionary;
       req.params.use_dictionary = false;
     }
     // output not yet taken by the caller stays in front
@@ -259,6 +262,7 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, br
   s->failed = false;
   s->stream_state = kProcessing;
   s->has_dictionary = false;
+  s->size_hint_at_dictionary = 0;
   s->output_pos = 0;
   s->total_out = 0;
   s->total_in = 0;
@@ -391,6 +395,7 @@ void BrotliEncoderSetCustomDictionary(BrotliEncoderState* s, size_t size, const 
   }
   s->dictionary.assign(dict, dict + size);
   s->has_dictionary = true;
+  s->size_hint_at_dictionary = s->params.size_hint;  // ensure_initialized() fixes the hasher parameters here
 }
 
 uint8_t* BrotliEncoderMallocU8(BrotliEncoderState* s, size_t size) {

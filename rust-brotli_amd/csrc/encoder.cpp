@@ -241,7 +241,14 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     p.size_hint = req.carry_in->size_hint;  // both were fixed by the first encode_data of the stream
     p.hasher = req.carry_in->hasher;
   } else {
-    if (req.hasher_chosen_before_size_hint) ChooseHasher(&p);  // custom dictionary: hasher_setup runs before any size hint
+    if (req.hasher_chosen_before_size_hint) {
+      // custom dictionary: hasher_setup ran inside set_custom_dictionary (encode.rs:1234, 1125-1161), with the size hint
+      // the caller had set by then -- what update_size_hint fills in later does not reach the hasher parameters
+      EncoderParams early = p;
+      if (req.has_hasher_size_hint) early.size_hint = req.hasher_size_hint;
+      ChooseHasher(&early);
+      p.hasher = early.hasher;
+    }
     if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
     if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
   }

@@ -40,7 +40,9 @@ struct EncodeRequest {
   const uint8_t* prefix = nullptr;  // custom LZ77 dictionary (already clipped to the last (1<<lgwin)-16 bytes)
   size_t prefix_size = 0;
   bool prefix_is_file_continuation = false;  // compress_multi semantics: prev bytes come from the prefix
-  bool hasher_chosen_before_size_hint = false;  // custom dictionary path picks the hasher early
+  bool hasher_chosen_before_size_hint = false;  // custom dictionary path picks the hasher early ...
+  bool has_hasher_size_hint = false;            // ... with the size hint as it stood at that moment (else: params.size_hint)
+  size_t hasher_size_hint = 0;
   uint32_t segment_bytes = 0;  // bytes per parse chain; 0 = chosen from the input size (ChooseSegmentBytes)
   // optional: the stream is written straight into this buffer instead of `out` (one device-to-host copy, no
   // intermediate vector); too small a buffer is an error

@@ -20,7 +20,7 @@ for c in range(cases):
     d = pool[o:o + n]
     q = 5 + rng.next() % 5
     w = [17, 18, 20, 22, 24][rng.next() % 5]
-    mode = rng.next() % 3
+    mode = rng.next() % 4
     try:
         if mode == 0:
             nt = 1 + rng.next() % 9
@@ -28,6 +28,18 @@ for c in range(cases):
             want = orc.compress_multi(d, [(Q, q), (W, w)], nt) if nt > 1 else orc.stream_compress(d, [(Q, q), (W, w)])[0]
             ok = got == want and orc.decompress(got, len(d)) == d
             what = "multi nt=%d" % nt
+        elif mode == 3:
+            # custom LZ77 dictionary (BrotliEncoderSetCustomDictionary), written in two pieces
+            m = 1 + rng.next() % 400000
+            o2 = rng.next() % (len(pool) - m)
+            dic = pool[o2:o2 + m]
+            e = lib.encoder(params=[(Q, q), (W, w)], dictionary=dic)
+            e.write(d)
+            got = e.finish()
+            e.close()
+            want = orc.stream_compress(d, [(Q, q), (W, w)], prefix=dic, continuation=False)[0]
+            ok = got == want
+            what = "dictionary %d B" % m
         else:
             ncut = 1 + rng.next() % 4
             cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))

@@ -120,7 +120,7 @@ def decompress(comp, expected_size):
     return out.raw[:n.value]
 
 
-def stream_compress(data, params, prefix=None, collect_trace=False):
+def stream_compress(data, params, prefix=None, collect_trace=False, continuation=True):
     """Generic path through the oracle's stream API: set params, optional custom dictionary
     (multi-thread continuation semantics), one FINISH call.  Returns (bytes, trace) where trace is a
     list of (kind, start, nbytes, [commands as tuples], dist_cache_after)."""
@@ -148,7 +148,7 @@ def stream_compress(data, params, prefix=None, collect_trace=False):
     if collect_trace:
         L.orc_encoder_set_trace(s, ctypes.cast(cbo, ctypes.c_void_p), None)
     if prefix is not None:
-        L.orc_encoder_set_custom_dictionary(s, len(prefix), prefix, 1)
+        L.orc_encoder_set_custom_dictionary(s, len(prefix), prefix, 1 if continuation else 0)
     cap = L.orc_max_compressed_size(len(data)) + 64
     out = ctypes.create_string_buffer(cap)
     inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)

@@ -118,6 +118,16 @@ def _suite(lib):
         got = with_ops(a, ops, [(Q, 5), (W, 22)])
         assert got == orc.stream_with_flushes(a, [(Q, 5), (W, 22)], ops), ops
         assert orc.decompress(b"".join(got), len(a)) == a
+    # BrotliEncoderSetCustomDictionary fixes the hasher parameters on the spot (ensure_initialized inside set_custom_dictionary,
+    # encode.rs:1234): with no size hint set, an input of more than 1 MiB still gets the 14-bit bucket table; found by
+    # the fuzz sweep
+    big = synth.markov_text(1200000, 9)
+    for params in ([(Q, 5), (W, 22)], [(Q, 5), (W, 22), (SH, 1200000)]):
+        e = lib.encoder(params=list(params), dictionary=a[:50000])
+        e.write(big)
+        got = e.finish()
+        e.close()
+        assert got == orc.stream_compress(big, params, prefix=a[:50000], continuation=False)[0], params
     # not supported: flushing a stream with a custom dictionary
     e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
     with pytest.raises(Exception):
