@@ -116,8 +116,17 @@ uint16_t orc_get_insert_length_code(size_t insertlen) {
   }
 }
 
+/* Set when the restated code reaches a state in which the Rust reference panics (bounds-checked table index); the
+   entry points report failure then, as the reference's FFI does after catching the panic (ffi/compressor.rs:419-434). */
+int orc_reference_would_panic = 0;
+
 /* command.rs:94-108 */
 uint16_t orc_get_copy_length_code(size_t copylen) {
+  /* copylen 1 (a match cut by fix_unbroken_len) wraps to code 65535; kCopyBase[65535] panics in StoreCommandExtra */
+  if (copylen < 2) {
+    orc_reference_would_panic = 1;
+    return 0; /* (keeps the rest of this run inside its tables; the result is discarded) */
+  }
   if (copylen < 10) {
     return (uint16_t)(copylen - 2);
   } else if (copylen < 134) {

@@ -793,7 +793,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   uint32_t tail_kind = kHeadNone, tail_base = 0, tail_p1 = 0;
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
-  uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0;
+  uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0, n_bad = 0;
   uint32_t last_dist_code = 0xffffffffu, last_copy_len = 0;
   uint32_t cache_version = 0;
   ProbeMeta probe;
@@ -881,6 +881,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
       }
       if (BR_LANE == 0 && n_cmds < seg.cmd_cap && fw.enabled) cmds[n_cmds] = br_raw_command(insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
       n_cmds++;
+      if (sr.len < 2) n_bad++;
       n_lits += insert_length;
       insert_length = 0;
       last_dist_code = distance_code;
@@ -948,7 +949,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     exit_out.dict_lookups = ds.mode == 2 ? ds.lookups + ds.vlookups : ds.lookups;
     exit_out.dict_matches = ds.mode == 2 ? ds.matches + ds.vwould : ds.matches;
     exit_out.last_dist_code = last_dist_code;
-    exit_out.flag_changes = 0;
+    exit_out.bad_commands = n_bad;
     exit_out.n_searches = n_searches;
     exit_out.last_copy_len = last_copy_len;
     exit_out.dict_mode = ds.mode;

@@ -1126,6 +1126,11 @@ void Lz77Stage::SelfTestRank(int which, int rbuf) {
 
 void Lz77Stage::Gather() {
   const uint32_t nseg = (uint32_t)segments_.size();
+  for (uint32_t k = 0; k < nseg; ++k)
+    if (exits_[k].bad_commands != 0)
+      throw std::runtime_error(
+          "brotli_mi355x: the reference encoder fails on this input: a match cut to one byte at the end of the custom dictionary "
+          "gives a copy it cannot encode (fix_unbroken_len, backward_references/mod.rs:42-54; GetCopyLengthCode, command.rs:91-93)");
   std::vector<uint32_t> offsets(nseg), counts(nseg);
   // Two batches: a command can receive both a carried-in insert length (kind 2) and an extension of its copy (kind 0);
   // the patches of one batch touch distinct commands, so each batch is applied with one thread per patch.

@@ -107,7 +107,8 @@ struct SegExit {
   uint32_t dict_lookups;    // counters at exit
   uint32_t dict_matches;
   uint32_t last_dist_code;  // restored distance code of the last emitted command (0xffffffff: none)
-  uint32_t flag_changes;    // positions whose stored-flag differs from the previous round
+  uint32_t bad_commands;    // copies shorter than 2 bytes (a match cut to 1 byte at the end of a custom dictionary): the
+                            // reference cannot encode them (GetCopyLengthCode, command.rs:91-93) and fails
   uint32_t n_searches;
   uint32_t last_copy_len;   // copy_len of last emitted command (low 25 bits)
   uint32_t dict_mode;       // 0 no consult, 1 alive at every consult, 2 dead at every consult, 3 mixed

@@ -1,7 +1,7 @@
 """Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
 oracle."""
-import sys, time
+import os, sys, time
 import synth, orc
 import test_cabi
 kind = "emu" if len(sys.argv) > 3 and sys.argv[3] == "emu" else "gpu"
@@ -12,6 +12,7 @@ Q, W, MAGIC = 1, 2, 169
 pools = [synth.markov_text(3 << 20, 31), synth.mixed(3 << 20, 32), synth.silesia_like(3 << 20, 33, min_segment=8 << 10, max_segment=200 << 10),
          synth.stretches(3 << 20, 34), synth.repeated_excerpts(3 << 20, 35)]
 bad = 0
+panics = 0
 t0 = time.time()
 for c in range(cases):
     pool = pools[rng.next() % len(pools)]
@@ -21,58 +22,82 @@ for c in range(cases):
     q = 5 + rng.next() % 5
     w = [17, 18, 20, 22, 24][rng.next() % 5]
     mode = rng.next() % 4
-    try:
-        if mode == 0:
-            nt = 1 + rng.next() % 9
-            got = bytes(lib.BrotliCompress(d, {Q: q, W: w}, nt))
-            want = orc.compress_multi(d, [(Q, q), (W, w)], nt) if nt > 1 else orc.stream_compress(d, [(Q, q), (W, w)])[0]
-            ok = got == want and orc.decompress(got, len(d)) == d
-            what = "multi nt=%d" % nt
-        elif mode == 3:
-            # custom LZ77 dictionary (BrotliEncoderSetCustomDictionary), written in two pieces
-            m = 1 + rng.next() % 400000
-            o2 = rng.next() % (len(pool) - m)
-            dic = pool[o2:o2 + m]
+    if os.environ.get("FUZZ_TRACE"):
+        print("case %d n %d q %d w %d mode %d" % (c, n, q, w, mode), flush=True)
+        open(os.environ["FUZZ_TRACE"], "wb").write(d)
+    def flushed(ops):
+        e = lib.encoder(params=[(Q, q), (W, w)])
+        pieces, pos = [], 0
+        for item in ops:
+            if isinstance(item, tuple):
+                cpos, meta = item
+                if cpos > pos:
+                    e.write(d[pos:cpos])
+                pieces.append(e.emit_metadata(meta))
+            else:
+                cpos = item
+                pieces.append(e.flush(d[pos:cpos]))
+            pos = cpos
+        e.write(d[pos:])
+        pieces.append(e.finish())
+        e.close()
+        return pieces
+
+    if mode == 0:
+        nt = 1 + rng.next() % 9
+        what = "multi nt=%d" % nt
+        product = lambda: bytes(lib.BrotliCompress(d, {Q: q, W: w}, nt))
+        oracle = lambda: orc.compress_multi(d, [(Q, q), (W, w)], nt) if nt > 1 else orc.stream_compress(d, [(Q, q), (W, w)])[0]
+    elif mode == 3:
+        # custom LZ77 dictionary (BrotliEncoderSetCustomDictionary)
+        m = 1 + rng.next() % 400000
+        o2 = rng.next() % (len(pool) - m)
+        dic = pool[o2:o2 + m]
+        what = "dictionary %d B" % m
+
+        def product():
             e = lib.encoder(params=[(Q, q), (W, w)], dictionary=dic)
             e.write(d)
             got = e.finish()
             e.close()
-            want = orc.stream_compress(d, [(Q, q), (W, w)], prefix=dic, continuation=False)[0]
-            ok = got == want
-            what = "dictionary %d B" % m
-        else:
-            ncut = 1 + rng.next() % 4
-            cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))
-            ops = []
-            for cut in cuts:
-                if mode == 2 and rng.next() % 2:
-                    ops.append((cut, bytes([65 + (rng.next() % 26)]) * (2 + rng.next() % 300)))
-                else:
-                    ops.append(cut)
-            e = lib.encoder(params=[(Q, q), (W, w)])
-            pieces, pos = [], 0
-            for item in ops:
-                if isinstance(item, tuple):
-                    cpos, meta = item
-                    if cpos > pos:
-                        e.write(d[pos:cpos])
-                    pieces.append(e.emit_metadata(meta))
-                else:
-                    cpos = item
-                    pieces.append(e.flush(d[pos:cpos]))
-                pos = cpos
-            e.write(d[pos:])
-            pieces.append(e.finish())
-            e.close()
-            want = orc.stream_with_flushes(d, [(Q, q), (W, w)], ops)
-            ok = pieces == want and orc.decompress(b"".join(pieces), len(d)) == d
-            what = "ops %r" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops],)
+            return got
+        oracle = lambda: orc.stream_compress(d, [(Q, q), (W, w)], prefix=dic, continuation=False)[0]
+    else:
+        ncut = 1 + rng.next() % 4
+        cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))
+        ops = []
+        for cut in cuts:
+            if mode == 2 and rng.next() % 2:
+                ops.append((cut, bytes([65 + (rng.next() % 26)]) * (2 + rng.next() % 300)))
+            else:
+                ops.append(cut)
+        what = "ops %r" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops],)
+        product = lambda: flushed(ops)
+        oracle = lambda: orc.stream_with_flushes(d, [(Q, q), (W, w)], ops)
+    # an input on which the reference itself fails (it panics on a copy of length 1, see orc.ReferencePanics) must make
+    # the product fail too, with the message that says so
+    try:
+        want = oracle()
+    except orc.ReferencePanics:
+        want = "reference fails"
+    try:
+        got = product()
     except Exception as ex:
-        ok = False
-        what = "EXCEPTION %r" % (ex,)
+        got = "reference fails" if "reference encoder fails" in str(ex) else "EXCEPTION %r" % (ex,)
+    ok = got == want
+    if want == "reference fails":
+        panics += 1
+    elif ok and mode != 3:  # (a stream that refers to a custom dictionary needs that dictionary to decode)
+        try:
+            ok = orc.decompress(got if isinstance(got, bytes) else b"".join(got), len(d)) == d
+        except RuntimeError as ex:
+            ok = False
+            what += " -> identical to the oracle, but: %s" % ex
+    if not ok and isinstance(got, str):
+        what += " -> " + got[:200]
     if not ok:
         bad += 1
         print("FAIL case %d n %d q %d w %d %s" % (c, n, q, w, what), flush=True)
         open("/tmp/fuzzapi_fail_%d.bin" % c, "wb").write(d)
-print("%d cases, %d failures, %.1f s" % (cases, bad, time.time() - t0))
+print("%d cases, %d failures, %d on which the reference fails (and so does the product), %.1f s" % (cases, bad, panics, time.time() - t0))
 sys.exit(1 if bad else 0)

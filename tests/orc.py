@@ -58,6 +58,17 @@ def lib():
     return _lib
 
 
+class ReferencePanics(Exception):
+    """the restated code reached a state in which the Rust reference panics (and its FFI reports failure)"""
+
+
+def _check_panic():
+    flag = ctypes.c_int.in_dll(lib(), "orc_reference_would_panic")
+    if flag.value:
+        flag.value = 0
+        raise ReferencePanics("the reference encoder fails on this input")
+
+
 def compress(data, quality=5, lgwin=22, mode=0, with_stats=False):
     """one-shot BrotliEncoderCompress equivalent (size_hint = len)"""
     L = lib()
@@ -69,6 +80,7 @@ def compress(data, quality=5, lgwin=22, mode=0, with_stats=False):
     if not ok:
         raise RuntimeError("oracle compress failed")
     res = out.raw[:n.value]
+    _check_panic()
     return (res, st.as_dict()) if with_stats else res
 
 
@@ -85,6 +97,7 @@ def writer_compress(data, quality=5, lgwin=22, chunk=0, with_stats=False, trace=
     if not ok:
         raise RuntimeError("oracle writer compress failed")
     res = out.raw[:n.value]
+    _check_panic()
     return (res, st.as_dict()) if with_stats else res
 
 
@@ -96,6 +109,7 @@ def compress_multi(data, params, num_threads):
     out = ctypes.create_string_buffer(cap)
     n = ctypes.c_size_t(cap)
     ok = L.orc_compress_multi(keys, vals, len(params), len(data), data, ctypes.byref(n), out, num_threads)
+    _check_panic()
     if not ok:
         raise RuntimeError("oracle compress_multi failed")
     return out.raw[:n.value]
@@ -163,6 +177,7 @@ def stream_compress(data, params, prefix=None, collect_trace=False, continuation
     L.orc_encoder_destroy(s)
     if not ok or not fin:
         raise RuntimeError("oracle stream compress failed")
+    _check_panic()
     return out.raw[:cap - avail_out.value], trace
 
 
@@ -239,4 +254,5 @@ def stream_with_flushes(data, params, cuts, write_size=0):
     L.orc_encoder_destroy(s)
     if not fin:
         raise RuntimeError("oracle stream did not finish")
+    _check_panic()
     return pieces

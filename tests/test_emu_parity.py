@@ -100,3 +100,18 @@ def test_quality9_h9(L):
 def test_distance_cache_check(L):
     import check_cache_cases
     check_cache_cases.run(L)
+
+
+def test_input_on_which_the_reference_fails(L):
+    """A shard whose parse cuts a match to ONE byte at the end of the custom dictionary (fix_unbroken_len,
+    backward_references/mod.rs:42-54, accepted through the last-distance candidate at score 2070 > 2020): the reference
+    then indexes kCopyBase with GetCopyLengthCode(1) = 65535 (command.rs:91-93) and panics, its FFI reports failure.  The
+    oracle flags that state and the product refuses the input with a message instead of emitting something (found by
+    the fuzz sweep as a GPU memory fault)."""
+    x = open(os.path.join(GOLDEN, "copy_of_length_one.bin"), "rb").read()
+    with pytest.raises(orc.ReferencePanics):
+        orc.stream_compress(x[64:], [(Q, 6), (W, 20)], prefix=x[:64])
+    with pytest.raises(RuntimeError, match="reference encoder fails"):
+        emu.encode_stream(L, x[64:], [(Q, 6), (W, 20)], prefix=x[:64])
+    # the same bytes without the dictionary boundary are fine
+    assert check_bytes(L, "no boundary", x, [(Q, 6), (W, 20)], verbose=False)

@@ -67,3 +67,13 @@ def test_quality9_kat_51737(L):
     assert check_bytes(L, "alice q9", a, [(Q, 9), (W, 22), (SH, len(a))])
     d = synth.markov_text(5 << 20)
     assert check_bytes(L, "markov5M q9", d, [(Q, 9), (W, 22), (SH, len(d))])
+
+
+def test_input_on_which_the_reference_fails(L):
+    """see tests/test_emu_parity.py: a match cut to one byte at the end of the custom dictionary makes the reference panic;
+    the HIP path must refuse the input with a message (it used to fault on the copy-length table)"""
+    import emu
+    x = open(os.path.join(GOLDEN, "copy_of_length_one.bin"), "rb").read()
+    with pytest.raises(RuntimeError, match="reference encoder fails"):
+        emu.encode_stream(L, x[64:], [(Q, 6), (W, 20)], prefix=x[:64])
+    assert check_bytes(L, "no boundary", x, [(Q, 6), (W, 20)], verbose=False)
