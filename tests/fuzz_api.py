@@ -21,7 +21,13 @@ for c in range(cases):
     d = pool[o:o + n]
     q = 5 + rng.next() % 5
     w = [17, 18, 20, 22, 24][rng.next() % 5]
-    mode = rng.next() % 4
+    mode = rng.next() % 5
+    extra = []
+    for pid in (167, 168, 169, 172):  # catable, appendable, magic number, byte align
+        if rng.next() % 4 == 0:
+            extra.append((pid, 1))
+    if rng.next() % 3 == 0:
+        extra.append((5, [1, 1000, 1 << 20, (1 << 20) + 1, 5 << 20][rng.next() % 5]))  # size hint
     if os.environ.get("FUZZ_TRACE"):
         print("case %d n %d q %d w %d mode %d" % (c, n, q, w, mode), flush=True)
         open(os.environ["FUZZ_TRACE"], "wb").write(d)
@@ -62,6 +68,17 @@ for c in range(cases):
             e.close()
             return got
         oracle = lambda: orc.stream_compress(d, [(Q, q), (W, w)], prefix=dic, continuation=False)[0]
+    elif mode == 4:
+        # one FINISH with extra stream parameters (everything offered in one call, as the oracle helper does)
+        what = "params %r" % (extra,)
+
+        def product():
+            e = lib.encoder(params=[(Q, q), (W, w)] + extra)
+            e.write(d)
+            got = e.finish()
+            e.close()
+            return got
+        oracle = lambda: orc.stream_compress(d, [(Q, q), (W, w)] + extra)[0]
     else:
         ncut = 1 + rng.next() % 4
         cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))
