@@ -12,13 +12,14 @@ else:
     L = gpulib.lib()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = synth.XorShift(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-pool_text = synth.markov_text(6 << 20, 77)
-pool_mixed = synth.mixed(6 << 20, 78)
-pool_fine = synth.silesia_like(6 << 20, 79, min_segment=8 << 10, max_segment=256 << 10)
+big = max(6 << 20, 2 * max_bytes)
+pool_text = synth.markov_text(big, 77)
+pool_mixed = synth.mixed(big, 78)
+pool_fine = synth.silesia_like(big, 79, min_segment=8 << 10, max_segment=256 << 10)
 pool_bin = synth.silesia_like(3 << 20, 80, only=60)
 pool_hex = synth.silesia_like(3 << 20, 81, only=85)
 pool_rand = synth.random_bytes(3 << 20, 82)
-pool_rep = synth.repeated_excerpts(4 << 20, 3)
+pool_rep = synth.repeated_excerpts(max(4 << 20, max_bytes + (1 << 20)), 3)
 
 
 def make(kind, n):
