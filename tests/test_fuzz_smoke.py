@@ -1,0 +1,39 @@
+"""A short run of the randomised sweeps (tests/fuzz_gpu.py, tests/fuzz_api.py) inside the suites: on the host emulation
+build for `-m "not gpu"`, on the device for `-m gpu`.  The long sweeps are run by hand (README)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(HERE, script)] + [str(a) for a in args], cwd=HERE, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=1500)
+    tail = r.stdout.decode(errors="replace")[-2000:]
+    assert r.returncode == 0, tail
+    return tail
+
+
+def test_one_shot_sweep_emulation():
+    import emu
+    emu.build()
+    assert "0 mismatches" in _run("fuzz_gpu.py", 60, 5, "emu", 0.3)
+
+
+def test_api_sweep_emulation():
+    import emu
+    emu.build()
+    assert " 0 failures" in _run("fuzz_api.py", 60, 5, "emu")
+
+
+@pytest.mark.gpu
+def test_one_shot_sweep_device():
+    assert "0 mismatches" in _run("fuzz_gpu.py", 200, 6)
+
+
+@pytest.mark.gpu
+def test_api_sweep_device():
+    assert " 0 failures" in _run("fuzz_api.py", 300, 6)
