@@ -21,7 +21,7 @@ for c in range(cases):
     d = pool[o:o + n]
     q = 5 + rng.next() % 5
     w = [17, 18, 20, 22, 24][rng.next() % 5]
-    mode = rng.next() % 5
+    mode = rng.next() % 6
     extra = []
     for pid in (167, 168, 169, 172):  # catable, appendable, magic number, byte align
         if rng.next() % 4 == 0:
@@ -68,6 +68,19 @@ for c in range(cases):
             e.close()
             return got
         oracle = lambda: orc.stream_compress(d, [(Q, q), (W, w)], prefix=dic, continuation=False)[0]
+    elif mode == 5:
+        # CompressorWriter feeding pattern (src/enc/writer.rs:183-313): PROCESS calls of one buffer each, then FINISH
+        chunk = [1000, 4096, 65536, 100000, 1 << 20][rng.next() % 5]
+        what = "writer chunk %d" % chunk
+
+        def product():
+            e = lib.encoder(params=[(Q, q), (W, w)])
+            for i in range(0, len(d), chunk):
+                e.write(d[i:i + chunk])
+            got = e.finish()
+            e.close()
+            return got
+        oracle = lambda: orc.writer_compress(d, q, w, chunk=chunk)
     elif mode == 4:
         # one FINISH with extra stream parameters (everything offered in one call, as the oracle helper does)
         what = "params %r" % (extra,)
