@@ -217,6 +217,12 @@ struct DictTracker {
   // match parses the same whether the dictionary is on or off, which makes most chains valid in either regime.
   bool Consume(uint32_t k, const SegEntry& used, const SegExit& x) {
     if (!use) return true;
+    // the exact counters may already say "off" when the last lookup of the chain in front tipped the balance and
+    // nothing was consulted after it: from here on the dictionary is off for good (mod.rs:1957-1960)
+    if (state == kAlive && M < (L >> 7)) {
+      state = kDead;
+      left_alive_at = k;
+    }
     const bool no_match = x.dict_matches == used.dict_matches;
     if (state == kDead || state == kUnknown) {
       const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || (x.dict_mode == 1 && no_match);

@@ -104,6 +104,8 @@ for c in range(cases):
         what = "ops %r" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops],)
         product = lambda: flushed(ops)
         oracle = lambda: orc.stream_with_flushes(d, [(Q, q), (W, w)], ops)
+    if os.environ.get("FUZZ_ONLY") and c != int(os.environ["FUZZ_ONLY"]):
+        continue
     # an input on which the reference itself fails (it panics on a copy of length 1, see orc.ReferencePanics) must make
     # the product fail too, with the message that says so
     try:

@@ -128,6 +128,15 @@ def _suite(lib):
         got = e.finish()
         e.close()
         assert got == orc.stream_compress(big, params, prefix=a[:50000], continuation=False)[0], params
+    # the static-dictionary throttle (matches < lookups >> 7, mod.rs:1957-1960) tips over with the LAST lookup of a chain:
+    # the exact counters say "off" at the next segment's entry although no chain has seen it off yet (the resolver used
+    # to go round in circles here; found by the fuzz sweep)
+    x = open(os.path.join(HERE, "golden", "dictionary_off_at_segment_boundary.bin"), "rb").read()
+    e = lib.encoder(params=[(Q, 8), (W, 17)])
+    e.write(x)
+    got = e.finish()
+    e.close()
+    assert got == orc.writer_compress(x, 8, 17, chunk=100000)
     # not supported: flushing a stream with a custom dictionary
     e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
     with pytest.raises(Exception):
