@@ -17,6 +17,8 @@ t0 = time.time()
 for c in range(cases):
     pool = pools[rng.next() % len(pools)]
     n = 1 + rng.next() % (1200000 if rng.next() % 3 else 5000)
+    if os.environ.get("FUZZ_TINY"):
+        n = rng.next() % 300
     o = rng.next() % (len(pool) - n)
     d = pool[o:o + n]
     q = 5 + rng.next() % 5
