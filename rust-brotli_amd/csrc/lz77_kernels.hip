@@ -380,6 +380,22 @@ __device__ __forceinline__ void mark_dirty(uint32_t p, const SegGeometry& geo, u
   if (k > 0 && (off % seg_bytes) < 8) dirty[k - 1] = 1;
 }
 
+// A chain evaluates the lazy alternative one position ahead, up to four times in a row (mod.rs:2455-2480), so its last
+// probes can fall on the first positions of the NEXT segment.  Their "searched" flags are written by that segment's
+// chain (flag ownership) -- possibly a round later -- so for validation the first 8 positions of a segment count as
+// searched by the chain in front whatever their flag says.  Returns that chain's index, or 0xffffffff.
+__device__ __forceinline__ uint32_t chain_in_front_if_near_boundary(uint32_t p, const SegGeometry& geo) {
+  const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
+  const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
+  const uint32_t off = p - bs;
+  const uint32_t seg_bytes = geo.block_segment_bytes[blk];
+  const uint32_t first = geo.block_first_segment[blk];
+  uint32_t k = first + off / seg_bytes;
+  if (k >= geo.block_first_segment[blk + 1]) return 0xffffffffu;  // (the tail of the block belongs to its last segment)
+  if (k == first || (off % seg_bytes) >= 8) return 0xffffffffu;
+  return k - 1;
+}
+
 // Incremental update after a few flag changes: the slots of every changed key are cut into chunks of
 // kRerankChunk; one workgroup per chunk (1) counts the stored bits, (2) recomputes the local ranks into scratch,
 // (3) marks the chains that searched a position of that key whose candidate list is no longer what they saw and
@@ -460,13 +476,19 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
-    if (p < geo.first_block_start || !(flags[p] & kFlagSearched)) continue;
+    if (p < geo.first_block_start) continue;
+    const bool searched = (flags[p] & kFlagSearched) != 0;
+    const uint32_t in_front = searched ? 0xffffffffu : chain_in_front_if_near_boundary(p, geo);
+    if (!searched && in_front == 0xffffffffu) continue;
     const uint2 a = info[p];
     const uint32_t rb = rank_tmp[i];
     const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(rb & 0xffffu, geo.block_size);
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted[a.x - 1 - j] == sorted_tmp[c.key_lo + rb - 1 - j];
-    if (!same && br_row_change_matters(text, p, sorted + a.x - 1, na, sorted_tmp + c.key_lo + rb - 1, nb)) mark_dirty(p, geo, dirty);
+    if (!same && br_row_change_matters(text, p, sorted + a.x - 1, na, sorted_tmp + c.key_lo + rb - 1, nb)) {
+      if (searched) mark_dirty(p, geo, dirty);
+      else dirty[in_front] = 1;
+    }
   }
 }
 
@@ -661,7 +683,10 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ te
                                                    const uint32_t* __restrict__ sorted_new, uint32_t n, SegGeometry geo,
                                                    uint8_t* __restrict__ dirty) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-    if (p < geo.first_block_start || !(flags[p] & kFlagSearched)) continue;
+    if (p < geo.first_block_start) continue;
+    const bool searched = (flags[p] & kFlagSearched) != 0;
+    const uint32_t in_front = searched ? 0xffffffffu : chain_in_front_if_near_boundary(p, geo);
+    if (!searched && in_front == 0xffffffffu) continue;
     const uint2 a = info_old[p], b = info_new[p];
     const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(b.y & 0xffffu, geo.block_size);
     bool same = na == nb;
@@ -677,7 +702,10 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ te
       same = x[0] == y[0] && x[1] == y[1] && x[2] == y[2] && x[3] == y[3];
     }
     if (same) continue;
-    if (br_row_change_matters(text, p, sorted_old + a.x - 1, na, sorted_new + b.x - 1, nb)) mark_dirty(p, geo, dirty);
+    if (br_row_change_matters(text, p, sorted_old + a.x - 1, na, sorted_new + b.x - 1, nb)) {
+      if (searched) mark_dirty(p, geo, dirty);
+      else dirty[in_front] = 1;
+    }
   }
 }
 

@@ -123,6 +123,19 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   }
 }
 
+// see chain_in_front_if_near_boundary in lz77_kernels.hip
+static uint32_t emu_chain_in_front(uint32_t p, const SegGeometry& geo) {
+  const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
+  const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
+  const uint32_t off = p - bs;
+  const uint32_t seg_bytes = geo.block_segment_bytes[blk];
+  const uint32_t first = geo.block_first_segment[blk];
+  const uint32_t k = first + off / seg_bytes;
+  if (k >= geo.block_first_segment[blk + 1]) return 0xffffffffu;
+  if (k == first || (off % seg_bytes) >= 8) return 0xffffffffu;
+  return k - 1;
+}
+
 static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
   const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
   const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
@@ -151,13 +164,19 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
     }
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t p = B.by_key[i];
-      if (p < geo.first_block_start || !(flags[p] & kFlagSearched)) continue;
+      if (p < geo.first_block_start) continue;
+      const bool searched = (flags[p] & kFlagSearched) != 0;
+      const uint32_t in_front = searched ? 0xffffffffu : emu_chain_in_front(p, geo);
+      if (!searched && in_front == 0xffffffffu) continue;
       const uint32_t ax = B.info[rbuf][2 * (size_t)p], ay = B.info[rbuf][2 * (size_t)p + 1];
       const uint32_t rb = new_rank[i - lo];
       const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(rb & 0xffffu, geo.block_size);
       bool same = na == nb;
       for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf][ax - 1 - j] == new_sorted[rb - 1 - j];
-      if (!same && br_row_change_matters(B.text, p, B.sorted[rbuf] + ax - 1, na, new_sorted.data() + rb - 1, nb)) emu_mark_dirty(p, geo, dirty);
+      if (!same && br_row_change_matters(B.text, p, B.sorted[rbuf] + ax - 1, na, new_sorted.data() + rb - 1, nb)) {
+        if (searched) emu_mark_dirty(p, geo, dirty);
+        else dirty[in_front] = 1;
+      }
     }
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t p = B.by_key[i];
@@ -215,7 +234,9 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
   const uint32_t n = P.total_bytes;
   const uint8_t* flags = B.flags[which];
   for (uint32_t p = geo.first_block_start; p < n; ++p) {
-    if (!(flags[p] & kFlagSearched)) continue;
+    const bool searched = (flags[p] & kFlagSearched) != 0;
+    const uint32_t in_front = searched ? 0xffffffffu : emu_chain_in_front(p, geo);
+    if (!searched && in_front == 0xffffffffu) continue;
     const uint32_t ga = B.info[rbuf_old][2 * (size_t)p], ca = B.info[rbuf_old][2 * (size_t)p + 1] & 0xffffu;
     const uint32_t gb = B.info[rbuf_new][2 * (size_t)p], cb = B.info[rbuf_new][2 * (size_t)p + 1] & 0xffffu;
     const uint32_t na = ca < geo.block_size ? ca : geo.block_size, nb = cb < geo.block_size ? cb : geo.block_size;
@@ -223,7 +244,8 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
     for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf_old][ga - 1 - j] == B.sorted[rbuf_new][gb - 1 - j];
     if (same) continue;
     if (!br_row_change_matters(B.text, p, B.sorted[rbuf_old] + ga - 1, na, B.sorted[rbuf_new] + gb - 1, nb)) continue;
-    emu_mark_dirty(p, geo, dirty);
+    if (searched) emu_mark_dirty(p, geo, dirty);
+    else dirty[in_front] = 1;
   }
 }
 

@@ -115,3 +115,13 @@ def test_input_on_which_the_reference_fails(L):
         emu.encode_stream(L, x[64:], [(Q, 6), (W, 20)], prefix=x[:64])
     # the same bytes without the dictionary boundary are fine
     assert check_bytes(L, "no boundary", x, [(Q, 6), (W, 20)], verbose=False)
+
+
+def test_lazy_probe_across_a_segment_boundary(L):
+    """The lazy evaluation of a chain probes up to four positions ahead, i.e. into the next segment, whose chain records
+    the "searched" flags of those positions -- possibly a round later.  Validation has to treat the first positions of
+    a segment as searched by the chain in front regardless (found by the fuzz sweep with 256-byte segments: a stale
+    candidate row went unnoticed and the fixed point was not the sequential parse)."""
+    d = open(os.path.join(GOLDEN, "lazy_probe_across_segments.bin"), "rb").read()
+    assert check("lazy probe", d, 5, 22, seg=256, lib=L)
+    assert check("lazy probe", d, 5, 22, seg=512, lib=L)

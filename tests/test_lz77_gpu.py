@@ -83,3 +83,9 @@ def test_silesia_like_and_enwik_like(L):
 def test_distance_cache_check(L):
     import check_cache_cases
     check_cache_cases.run(L)
+
+
+def test_lazy_probe_across_a_segment_boundary(L):
+    import os
+    d = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lazy_probe_across_segments.bin"), "rb").read()
+    assert check("lazy probe", d, 5, 22, seg=256, lib=L)
