@@ -59,6 +59,8 @@ for c in range(cases):
     q = 5 + rng.next() % 5
     w = [17, 18, 20, 22, 24][rng.next() % 5]
     seg = [0, 0, 256, 512, 1024, 4096][rng.next() % 6]
+    if os.environ.get("FUZZ_SEG"):
+        seg = int(os.environ["FUZZ_SEG"])
     d = make(kind, n)
     try:
         out, st = emu.encode_stream(L, d, [(1, q), (2, w), (5, len(d))], segment_bytes=seg)
