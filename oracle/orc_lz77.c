@@ -120,6 +120,18 @@ uint16_t orc_get_insert_length_code(size_t insertlen) {
    entry points report failure then, as the reference's FFI does after catching the panic (ffi/compressor.rs:419-434). */
 int orc_reference_would_panic = 0;
 
+/* TEST SWITCH (tests/test_oracle_vs_libbrotlienc.py only; 0 = the rust-brotli behaviour this oracle restates).
+   Google's C encoder 1.0.9 differs from rust-brotli in the hash-table update after a copy: "Avoid hash poisoning with RLE
+   data" (c/enc/backward_references_inc.h) starts StoreRange no earlier than position + len - 4 * distance when
+   distance < len / 4; rust-brotli stores from position + 2 (backward_references/mod.rs:2516-2521).  With this switch on,
+   the oracle follows the C rule, which makes its streams comparable byte for byte with libbrotlienc.so.1 and thereby pins
+   every OTHER part of the restated path against an independent implementation. */
+int orc_test_c109_rle_store_rule = 0;
+/* Second difference in the same loop: inside a literal spree rust-brotli gives up the rest of a block as soon as a sparse
+   jump would come within kMargin of its end (mod.rs:2529-2533); C 1.0.9 clamps the jump (pos_jump = min(position + 16,
+   pos_end - kMargin)) and keeps storing every 4th / 2nd position up to there. */
+int orc_test_c109_spree_tail = 0;
+
 /* command.rs:94-108 */
 uint16_t orc_get_copy_length_code(size_t copylen) {
   /* copylen 1 (a match cut by fix_unbroken_len) wraps to code 65535; kCopyBase[65535] panics in StoreCommandExtra */
@@ -227,8 +239,22 @@ void orc_hasher_free(Hasher* h) {
 }
 
 /* encode.rs:834-893 */
+/* TEST SWITCH, see orc_test_c109_rle_store_rule: C 1.0.9 (c/enc/quality.h ChooseHasher) takes H6 from size_hint >= 1 MiB
+   (rust-brotli: > 4 MiB, encode.rs:863-865) and gives H5 14 bucket bits at every size below quality 7 (rust-brotli: only
+   up to 1 MiB, encode.rs:880). */
+int orc_test_c109_hasher_choice = 0;
+
 void orc_choose_hasher(EncoderParams* params) {
   HasherParams* hp = &params->hasher;
+  if (orc_test_c109_hasher_choice && params->quality >= 5 && params->quality <= 8 && params->lgwin > 16) {
+    const int h6 = params->size_hint >= (1u << 20) && params->lgwin >= 19;
+    hp->type_ = h6 ? 6 : 5;
+    hp->block_bits = params->quality - 1;
+    hp->bucket_bits = h6 ? 15 : (params->quality < 7 ? 14 : 15);
+    if (h6) hp->hash_len = 5;
+    hp->num_last_distances_to_check = params->quality < 7 ? 4 : 10;
+    return;
+  }
   if (params->quality >= 10 && !params->q9_5) {
     hp->type_ = 10;
   } else if (params->quality == 10 || params->quality == 9) {
@@ -735,6 +761,8 @@ void orc_create_backward_references(size_t num_bytes, size_t position, const uin
       insert_length = 0;
       {
         size_t a = position + 2, b = ORC_MIN(position + sr.len, store_end);
+        if (orc_test_c109_rle_store_rule && sr.distance < (sr.len >> 2))
+          a = ORC_MIN(b, ORC_MAX(a, position + sr.len - (sr.distance << 2)));
         for (size_t i = a; i < b; ++i) hasher_store(hasher, ringbuffer, ringbuffer_mask, i, st);
       }
       position += sr.len;
@@ -743,7 +771,22 @@ void orc_create_backward_references(size_t num_bytes, size_t position, const uin
       position++;
       if (position > apply_random_heuristics) {
         size_t kMargin = ORC_MAX(store_lookahead(hasher) - 1, (size_t)4);
-        if (position + 16 >= pos_end - kMargin) {
+        if (orc_test_c109_spree_tail) {
+          if (position > apply_random_heuristics + 4 * random_heuristics_window_size) {
+            size_t pos_jump = ORC_MIN(position + 16, pos_end - kMargin);
+            for (; position < pos_jump; position += 4) {
+              hasher_store(hasher, ringbuffer, ringbuffer_mask, position, st);
+              insert_length += 4;
+            }
+          } else {
+            size_t margin3 = ORC_MAX(store_lookahead(hasher) - 1, (size_t)3);
+            size_t pos_jump = ORC_MIN(position + 8, pos_end - margin3);
+            for (; position < pos_jump; position += 2) {
+              hasher_store(hasher, ringbuffer, ringbuffer_mask, position, st);
+              insert_length += 2;
+            }
+          }
+        } else if (position + 16 >= pos_end - kMargin) {
           insert_length += pos_end - position;
           position = pos_end;
         } else if (position > apply_random_heuristics + 4 * random_heuristics_window_size) {

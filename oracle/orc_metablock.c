@@ -21,11 +21,29 @@ float orc_fast_log2(uint64_t v) {
   return log2f((float)v);
 }
 
+/* TEST SWITCH (tests/test_oracle_vs_libbrotlienc.py only; 0 = the rust-brotli behaviour this oracle restates).
+   rust-brotli indexes its 65 536-entry log table with `p as u16` (bit_cost.rs:22,27): a histogram count >= 65 536 is
+   TRUNCATED before the lookup, and everything is summed in f32.  Google's C encoder 1.0.9 (c/enc/bit_cost.h) sums
+   p * log2(p) in double with the true logarithm.  With this switch on the oracle follows the C arithmetic, so that the
+   two can be compared on inputs whose meta-blocks hold symbols more frequent than 65 535. */
+int orc_test_c109_entropy = 0;
+
 /* bit_cost.rs:13-33 */
 float orc_shannon_entropy(const uint32_t* population, size_t size, size_t* total) {
   const float* l16 = orc_logs_16();
   size_t sum = 0;
   float retval = 0.0f;
+  if (orc_test_c109_entropy) {
+    double r = 0.0;
+    for (size_t i = 0; i < size; ++i) {
+      size_t p = population[i];
+      sum += p;
+      r -= (double)p * (p < 256 ? (double)orc_logs_8()[p] : log2((double)p));
+    }
+    if (sum != 0) r += (double)sum * (sum < 256 ? (double)orc_logs_8()[sum] : log2((double)sum));
+    *total = sum;
+    return (float)r;
+  }
   for (size_t i = 0; i < size; ++i) {
     size_t p = population[i];
     sum += p;

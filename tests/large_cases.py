@@ -1,0 +1,33 @@
+"""The BASELINE.json configurations at their stated sizes: seeded inputs + encoder settings.
+tools/freeze_large_hashes.py runs the CPU oracle over them once; tests/test_large_gpu.py compares the HIP path with the
+frozen hashes."""
+import synth
+
+CASES = {
+    # configs[1]: 64 MiB English-like text, q5 / lgwin 22 (H6)
+    "c2_text_64MiB_q5": dict(make=lambda: synth.markov_text(64 << 20), quality=5, lgwin=22),
+    # the same generator at 256 MiB: 4 KiB-segment regime of the speculative parse
+    "text_256MiB_q5": dict(make=lambda: synth.markov_text(256 << 20), quality=5, lgwin=22),
+    # configs[2]: 256 MiB enwik-style corpus, q9 / lgwin 22 (H9 greedy)
+    "c3_enwik_256MiB_q9": dict(make=lambda: synth.enwik_like(256 << 20), quality=9, lgwin=22),
+    # configs[4]: 1 GiB xorshift64* (incompressible), q5
+    "c5_xorshift_1GiB_q5": dict(make=lambda: synth.random_bytes(1 << 30, 0x5EED000000000005), quality=5, lgwin=22),
+    # zero fill, 1 GiB (north_star's fifth distribution)
+    "zero_1GiB_q5": dict(make=lambda: bytes(1 << 30), quality=5, lgwin=22),
+    # configs[3] at a quarter of its size: Silesia-like mix, BrotliEncoderCompressMulti with 8 shards of 128 MiB.
+    # `seeds`: the reference encoder FAILS on some shardings of this kind of data (a match cut to one byte at the end of the
+    # custom dictionary; the oracle raises ReferencePanics): the first seed it accepts is frozen.
+    "c4_silesia_1GiB_multi8": dict(make=lambda seed: synth.silesia_like(1 << 30, seed), quality=5, lgwin=22, shards=8,
+                                   seeds=[0x5EED000000000004 + i for i in range(16)]),
+    # configs[3] itself: 4 GiB, 8 shards of 512 MiB (bench.py --gpus N distributes the 8 shards over N GPUs)
+    "c4_silesia_4GiB_multi8": dict(make=lambda seed: synth.silesia_like(4 << 30, seed), quality=5, lgwin=22, shards=8,
+                                   seeds=[0x5EED000000000004 + i for i in range(16)], bench_only=True),
+}
+
+
+def make_input(name, frozen=None):
+    """the input of case `name`; multi-shard cases use the seed recorded in tests/golden/large_hashes.json"""
+    case = CASES[name]
+    if "seeds" in case:
+        return case["make"](int(frozen[name]["seed"], 16))
+    return case["make"]()

@@ -33,9 +33,14 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(ORACLE_DIR, "liborc.so")
+        # ORC_FAST=1: the -O3 -march=native build of the same sources (bench baseline / hash freezing)
+        fast = os.environ.get("ORC_FAST")
+        path = os.path.join(ORACLE_DIR, "liborc_fast.so" if fast else "liborc.so")
         if not os.path.exists(path):
-            build()
+            if fast:
+                subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liborc_fast.so"])
+            else:
+                build()
         L = ctypes.CDLL(path)
         L.orc_max_compressed_size.restype = ctypes.c_size_t
         L.orc_max_compressed_size.argtypes = [ctypes.c_size_t]

@@ -26,7 +26,51 @@ def alice():
     raise FileNotFoundError("alice29.txt fixture")
 
 
+_clib = None
+_markov_handle = None
+
+
+def _c():
+    """tools/libsynth.so (tools/synth_gen.c): the same generators at several hundred MB/s; None if it is not built"""
+    global _clib
+    if _clib is None:
+        import ctypes
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "libsynth.so")
+        if not os.environ.get("SYNTH_PURE_PYTHON") and not os.path.exists(path):
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-s", "-C", os.path.dirname(path)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except Exception:
+                pass
+        if os.environ.get("SYNTH_PURE_PYTHON") or not os.path.exists(path):
+            _clib = False
+        else:
+            L = ctypes.CDLL(path)
+            L.synth_xorshift.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_char_p]
+            L.synth_xorshift.restype = None
+            L.synth_markov_new.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+            L.synth_markov_new.restype = ctypes.c_void_p
+            L.synth_markov_text.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_char_p]
+            L.synth_markov_text.restype = None
+            _clib = L
+    return _clib or None
+
+
 def markov_text(nbytes, seed=0x5EED000000000002):
+    L = _c()
+    if L is not None:
+        import ctypes
+        global _markov_handle
+        if _markov_handle is None:
+            a = alice()
+            _markov_handle = L.synth_markov_new(a, len(a))
+        buf = ctypes.create_string_buffer(max(1, nbytes))
+        L.synth_markov_text(_markov_handle, seed & MASK, nbytes, buf)
+        return buf.raw[:nbytes]
+    return markov_text_py(nbytes, seed)
+
+
+def markov_text_py(nbytes, seed=0x5EED000000000002):
     toks = alice().split()
     nxt = {}
     for a, b in zip(toks, toks[1:]):
@@ -53,6 +97,16 @@ def markov_text(nbytes, seed=0x5EED000000000002):
 
 
 def random_bytes(nbytes, seed=0x5EED000000000005):
+    L = _c()
+    if L is not None:
+        import ctypes
+        buf = ctypes.create_string_buffer(max(1, nbytes))
+        L.synth_xorshift(seed & MASK, nbytes, buf)
+        return buf.raw[:nbytes]
+    return random_bytes_py(nbytes, seed)
+
+
+def random_bytes_py(nbytes, seed=0x5EED000000000005):
     rng = XorShift(seed)
     out = bytearray()
     while len(out) < nbytes:
@@ -123,40 +177,70 @@ def enwik_like(nbytes, seed=0x5EED000000000003):
     return bytes(out[:nbytes])
 
 
-def silesia_like(nbytes, seed=0x5EED000000000004, min_segment=1 << 20, max_segment=32 << 20, only=None):
-    """SURVEY 8d C4: segments of min_segment..max_segment bytes; 40 % fresh Markov text, 20 % enwik-style XML, 15 % binary
-    records (LE u32 counters + floats with 12 bits of entropy), 10 % zero fill, 10 % hex / source-like, 5 % random"""
-    import numpy as np
+def silesia_plan(nbytes, seed=0x5EED000000000004, min_segment=1 << 20, max_segment=32 << 20, only=None):
+    """the pieces of silesia_like(): list of (kind, offset, length, sub-seed); no content is generated"""
     rng = XorShift(seed)
-    out = bytearray()
-    while len(out) < nbytes:
+    plan = []
+    at = 0
+    while at < nbytes:
         kind = rng.next() % 100
         if only is not None:
             kind = only
-        seglen = min(min_segment + rng.next() % (max_segment - min_segment + 1), nbytes - len(out))
+        seglen = min(min_segment + rng.next() % (max_segment - min_segment + 1), nbytes - at)
         sub = rng.next()
-        g = np.random.Generator(np.random.PCG64(sub))
-        if kind < 40:
-            out += markov_text(seglen, sub)
-        elif kind < 60:
-            out += enwik_like(seglen, sub)
-        elif kind < 75:
-            n = seglen // 8 + 1
-            rec = np.empty((n, 2), dtype="<u4")
-            rec[:, 0] = np.arange(n, dtype=np.uint32) * 3 + (sub & 0xffff)
-            rec[:, 1] = (np.float32(1.0) + g.integers(0, 4096, n).astype(np.float32) / np.float32(4096.0)).view(np.uint32)
-            out += rec.tobytes()[:seglen]
-        elif kind < 85:
-            out += bytes(seglen)
-        elif kind < 95:
-            raw = g.integers(0, 256, seglen // 2 + 1, dtype=np.uint8).tobytes().hex().encode()
-            lines = bytearray()
-            for i in range(0, len(raw), 64):
-                lines += b"  0x" + raw[i:i + 64] + b",\n"
-            out += lines[:seglen]
-        else:
-            out += g.integers(0, 256, seglen, dtype=np.uint8).tobytes()
-    return bytes(out[:nbytes])
+        plan.append((kind, at, seglen, sub))
+        at += seglen
+    return plan
+
+
+def _silesia_piece(kind, seglen, sub):
+    import numpy as np
+    g = np.random.Generator(np.random.PCG64(sub))
+    if kind < 40:
+        return markov_text(seglen, sub)
+    if kind < 60:
+        return enwik_like(seglen, sub)
+    if kind < 75:
+        n = seglen // 8 + 1
+        rec = np.empty((n, 2), dtype="<u4")
+        rec[:, 0] = np.arange(n, dtype=np.uint32) * 3 + (sub & 0xffff)
+        rec[:, 1] = (np.float32(1.0) + g.integers(0, 4096, n).astype(np.float32) / np.float32(4096.0)).view(np.uint32)
+        return rec.tobytes()[:seglen]
+    if kind < 85:
+        return bytes(seglen)
+    if kind < 95:
+        raw = np.frombuffer(g.integers(0, 256, seglen // 2 + 1, dtype=np.uint8).tobytes().hex().encode(), dtype=np.uint8)
+        # lines of 64 hex digits: "  0x" + digits + ",\n"
+        nlines = (len(raw) + 63) // 64
+        padded = np.zeros(nlines * 64, dtype=np.uint8)
+        padded[:len(raw)] = raw
+        lines = np.empty((nlines, 70), dtype=np.uint8)
+        lines[:, 0:4] = np.frombuffer(b"  0x", dtype=np.uint8)
+        lines[:, 4:68] = padded.reshape(nlines, 64)
+        lines[:, 68:70] = np.frombuffer(b",\n", dtype=np.uint8)
+        out = lines.tobytes()
+        short = nlines * 64 - len(raw)
+        if short:  # the last line holds fewer digits
+            out = out[:len(out) - 2 - short] + b",\n"
+        return out[:seglen]
+    return g.integers(0, 256, seglen, dtype=np.uint8).tobytes()
+
+
+def silesia_range(plan, lo, hi):
+    """bytes [lo, hi) of the input described by `plan` (only the pieces that overlap the range are generated)"""
+    out = bytearray()
+    for kind, at, seglen, sub in plan:
+        if at + seglen <= lo or at >= hi:
+            continue
+        piece = _silesia_piece(kind, seglen, sub)
+        out += piece[max(lo, at) - at:min(hi, at + seglen) - at]
+    return bytes(out)
+
+
+def silesia_like(nbytes, seed=0x5EED000000000004, min_segment=1 << 20, max_segment=32 << 20, only=None):
+    """SURVEY 8d C4: segments of min_segment..max_segment bytes; 40 % fresh Markov text, 20 % enwik-style XML, 15 % binary
+    records (LE u32 counters + floats with 12 bits of entropy), 10 % zero fill, 10 % hex / source-like, 5 % random"""
+    return silesia_range(silesia_plan(nbytes, seed, min_segment, max_segment, only), 0, nbytes)
 
 
 def stretches(nbytes, seed=1):
