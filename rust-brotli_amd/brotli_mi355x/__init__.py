@@ -14,7 +14,7 @@ import os
 from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbrotli_mi355x.so")
+LIB_PATH = os.environ.get("BROTLI_MI355X_LIB") or os.path.join(os.path.dirname(_HERE), "libbrotli_mi355x.so")  # (the override is for profiling builds)
 
 # BrotliEncoderParameter ids (c/brotli/encode.h:138-232)
 BROTLI_PARAM_MODE = 0

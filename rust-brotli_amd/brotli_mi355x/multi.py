@@ -10,6 +10,7 @@ import ctypes
 BROTLI_PARAM_LGWIN = 2
 BROTLI_PARAM_CATABLE = 167
 BROTLI_PARAM_APPENDABLE = 168
+BROTLI_PARAM_MAGIC_NUMBER = 169
 
 
 def shard_range(total, rank, world):
@@ -28,7 +29,9 @@ def shard_params(params, rank):
     """parameter list of one shard (threading/mod.rs:354-358)"""
     out = list(params) + [(BROTLI_PARAM_APPENDABLE, 1)]
     if rank:
+        # compress_part: catable = true, magic_number = false for every shard but the first (threading/mod.rs:354-357)
         out.append((BROTLI_PARAM_CATABLE, 1))
+        out.append((BROTLI_PARAM_MAGIC_NUMBER, 0))
     return out
 
 
@@ -86,9 +89,10 @@ def gather_shards(dist, comp, rank, world, device):
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(sizes, size_t)
     sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
+    mx = max(1, max(sizes))
     payload = torch.zeros(mx, dtype=torch.uint8, device=device)
-    payload[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(device)
+    if len(comp):  # (a rank without a shard in this round contributes an empty payload)
+        payload[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8).to(device)
     bufs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
     dist.gather(payload, bufs, dst=0)
     if rank != 0:
@@ -105,6 +109,31 @@ def compress_sharded(dist, library, encoder, params, lgwin, prefix, chunk, nbyte
     if rank != 0:
         return None
     return library.concat_chunks(shards)
+
+
+def compress_multi_over_ranks(dist, library, encoder, params, total, nshards, rank, world, device, shard_input):
+    """BrotliEncoderCompressMulti(total bytes, nshards threads) with the shards dealt round-robin to the ranks (shard s ->
+    rank s % world): every rank encodes its shards one after the other, each round of `world` shards is gathered to rank 0,
+    which stitches all of them at the end.  The stream does not depend on `world`.
+    shard_input(s) -> (prefix bytes, chunk (bytes or device address), nbytes, on_device).  Returns the stream on rank 0."""
+    collected = {}
+    for base in range(0, nshards, world):
+        s = base + rank
+        comp = b""
+        if s < nshards:
+            prefix, chunk, nbytes, on_device = shard_input(s)
+            comp = encoder.encode(shard_params(params, s), prefix, chunk, nbytes, on_device)
+        if world == 1:
+            collected[s] = comp
+        else:
+            got = gather_shards(dist, comp, rank, world, device)
+            if rank == 0:
+                for r in range(world):
+                    if base + r < nshards:
+                        collected[base + r] = got[r]
+    if rank != 0:
+        return None
+    return library.concat_chunks([collected[s] for s in range(nshards)])
 
 
 class DeviceShardJob(object):

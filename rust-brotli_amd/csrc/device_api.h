@@ -28,6 +28,9 @@ void dev_d2h(void* dst, const void* src, size_t bytes);        // copy + wait
 void dev_d2h_async(void* dst, const void* src, size_t bytes);  // several copies, then one dev_sync()
 void dev_d2d(void* dst, const void* src, size_t bytes);
 void dev_sync();
+void dev_mark();       // records a point in the calling thread's stream ...
+void dev_wait_mark();  // ... and waits until everything queued before the last mark has finished (later work keeps running)
+size_t dev_trim_pool();  // returns the pooled, currently unused device memory of the calling thread to the driver; bytes freed
 const char* dev_name();  // "hip:gfx950 ..." or "host-emulation"
 
 // Static read-only tables resident on the device (dictionary, dictionary hash, log tables ...).
@@ -45,6 +48,11 @@ const DeviceTables& dev_tables();
 
 // ---- LZ77 stage ----
 static constexpr uint32_t kChangedCap = 1u << 16;
+struct RankInitialHint {
+  uint32_t first_block_start, block_bytes;
+  uint32_t prefix_is_dictionary;  // the prefix flags follow the custom-dictionary rule (all stored but the last htl - 1)
+};
+struct SegGeometry;
 
 struct Lz77Buffers {
   uint8_t* text;        // total_bytes + 64
@@ -59,6 +67,15 @@ struct Lz77Buffers {
   uint32_t* key_last;
   uint32_t* changed_keys;  // keys whose stored flags changed in the last parse launch(es) [kChangedCap]
   uint32_t* changed_count; // [1]
+  // candidate rows (ring depth <= 16, i.e. quality 5; null otherwise -- then info / sorted are used instead)
+  uint16_t* stag;       // br_tag16 of by_key[i]                           [total_bytes]
+  uint32_t* rows;       // per position kRowEntries candidates             [16 * total_bytes]
+  uint32_t* changed_slot;  // slot of every changed position                [changed_cap]
+  uint32_t* row_ctl;    // device-side control words of lz77_rows_update    [4]
+  unsigned long long* smask;  // stored bits of the slots, one word per 64 slots      [total_bytes / 64 + 2]
+  uint32_t* gprev;      // per 64 slots: 1 + last stored slot in front of them           [total_bytes / 64 + 2]
+  uint8_t* big_tile;    // per 1024 slots: holds slots of a key with >= 65 536 slots  [total_bytes / 1024 + 64]
+  uint32_t changed_cap; // entries in changed_keys / changed_slot
   uint8_t* flags[2];    // stored flags, double buffered                   [total_bytes + 64]
   Command* cmds;        // num_segments * cmd_slab_stride
   Segment* segments;    // num_segments
@@ -82,11 +99,15 @@ void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_b
 void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B);
 // sorted[rbuf] / info[rbuf] from flags[which] (all keys).  `initial` (optional): flags[which] is still exactly what
 // lz77_init_flags wrote, which lets the kernel skip most of the random flag reads.
-struct RankInitialHint {
-  uint32_t first_block_start, block_bytes;
-  uint32_t prefix_is_dictionary;  // the prefix flags follow the custom-dictionary rule (all stored but the last htl - 1)
-};
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint* initial = nullptr);
+// Candidate rows (see kRowEntries in lz77_chain.h).  lz77_rows_init: fbits + every row from flags[which] (no validation).
+// lz77_rows_update: after a parse launch and lz77_diff_flags(prev, next) -- brings fbits and the rows up to date with
+// flags[next] and marks (dirty[k] = 1) the chains that searched a position whose row changed.  Everything is decided on
+// the device (few changes: only the rows behind the changed slots; list overflow or a change in a key with >= 65 536
+// slots: all rows), nothing is read back.  has_big_keys: some key owns >= 65 536 slots (exact ring counters needed).
+void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const RankInitialHint* initial, bool has_big_keys);
+void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int next, const SegGeometry& geo, uint8_t* dirty_dev,
+                      bool has_big_keys);
 // one round of speculative parsing: segments [first, num_segments) read flags[which] (through
 // rank/sorted) and write flags[which ^ 1], cmds and exits
 void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, uint32_t first_segment);
@@ -136,7 +157,8 @@ struct CacheCheck {
 };
 void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items_dev, uint32_t count, uint8_t* ok_dev);
 // accumulated device time (HIP events) of the parse kernel launches since the last call
-void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments);
+// work[3] (optional): what those launches did -- positions walked, searches, commands written (all chains, re-parses included)
+void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments, uint64_t* work = nullptr);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]

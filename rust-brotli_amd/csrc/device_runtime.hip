@@ -131,6 +131,48 @@ void dev_d2d(void* dst, const void* src, size_t bytes) {
 }
 void dev_sync() { HIP_CHECK(hipStreamSynchronize(BR_STREAM)); }
 
+namespace {
+struct Mark {
+  hipEvent_t ev = nullptr;
+  ~Mark() {
+    if (ev) (void)hipEventDestroy(ev);
+  }
+};
+Mark& mark() {
+  static thread_local Mark m;
+  return m;
+}
+}  // namespace
+void dev_mark() {
+  Mark& m = mark();
+  if (!m.ev) HIP_CHECK(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(m.ev, BR_STREAM));
+}
+void dev_wait_mark() {
+  Mark& m = mark();
+  if (m.ev) HIP_CHECK(hipEventSynchronize(m.ev));
+}
+
+// gives the pooled (currently unused) device memory of the calling thread back to the driver
+size_t dev_trim_pool() {
+  Pool& P = pool();
+  std::vector<void*> drop;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (auto& kv : P.free_blocks) {
+      drop.push_back(kv.second);
+      P.capacity.erase(kv.second);
+      bytes += kv.first;
+    }
+    P.free_blocks.clear();
+    P.pooled_bytes = 0;
+  }
+  if (!drop.empty()) HIP_CHECK(hipStreamSynchronize(BR_STREAM));
+  for (void* q : drop) (void)hipFree(q);
+  return bytes;
+}
+
 const char* dev_name() {
   static std::string name;
   static std::once_flag once;

@@ -381,7 +381,11 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       double ms;
       uint32_t launches;
       uint64_t segs;
-      lz77_parse_timing(&ms, &launches, &segs);
+      uint64_t work[3] = {0, 0, 0};
+      lz77_parse_timing(&ms, &launches, &segs, work);
+      stats.parse_walked += work[0];
+      stats.parse_searches += work[1];
+      stats.parse_commands += work[2];
       stats.parse_kernel_ms += ms;
       stats.parse_launches += launches;
       stats.parse_segments += segs;

@@ -30,6 +30,8 @@ struct EncodeStats {
   uint32_t parse_launches = 0;
   uint64_t parse_segments = 0;
   uint32_t num_segments = 0, segment_bytes = 0;
+  // what those launches did, all chains and re-parses included: positions walked, searches, commands written
+  uint64_t parse_walked = 0, parse_searches = 0, parse_commands = 0;
 };
 
 struct EncodeRequest {

@@ -59,6 +59,7 @@ struct ChainTables {
   const uint32_t* info;        // per position: {rank among the stored positions in (key,pos) order,
                                //                number of stored positions of the same key before it}
   const uint32_t* sorted;      // stored positions in (key,pos) order
+  const uint32_t* rows;        // kRows chains: per position kRowEntries candidate positions, newest first, 0xffffffff-terminated
   uint8_t* flags_next;         // stored flags produced by this round
   Command* cmds;
   const uint16_t* dict_hash;   // kStaticDictionaryHash (src/enc/dictionary_hash.rs)
@@ -67,15 +68,34 @@ struct ChainTables {
   const uint8_t* dict_size_bits_by_length;
   uint32_t dist_postfix_bits;
   uint32_t num_direct_distance_codes;
+  // measurement (bench.py roofline): per launch-set totals of what the chains actually did -- [0] positions walked,
+  // [1] searches, [2] commands written.  Null in the host emulation.
+  unsigned long long* work;
 };
 
 static constexpr uint32_t kInfoWindow = 64;
 static constexpr uint32_t kMaxContinuation = 4;
 
-template <bool kH9>
+// ---- candidate rows (the hash table of the reference, indexed by POSITION) -------------------------------------------
+// For ring depth 16 (quality 5) the candidates of every position are materialised once per flag state: rows[p] holds the
+// positions FindLongestMatch would find in bucket key(p) when it searches p -- the (up to) 16 most recent stored
+// same-key positions in front of p, nearest first, cut at the first one farther away than max_backward (the bucket walk
+// breaks there, mod.rs:1769-1776) -- minus those whose first four bytes certainly differ from the four bytes at p: a ring
+// entry takes part in the search only through FindMatchLengthWithLimitMin4 (static_dict.rs:134-147), which returns 0
+// for them, so they can be dropped without any effect.  "Certainly differ" = a 16-bit hash of the four bytes (br_tag16)
+// differs.  The rows of a segment are contiguous in memory: the chain streams them through an LDS window instead of
+// chasing rank -> bucket row through two dependent random loads, and a flag change touches the rows of the next <= 16
+// stored positions of its key only (lz77_update_rows).
+static constexpr uint32_t kRowWindow = 32;  // positions held in LDS
+BR_DEV uint32_t br_tag16(uint32_t first_four_bytes) { return (first_four_bytes * 0x9E3779B1u) >> 16; }
+
+template <bool kH9, bool kRows = false>
 struct ChainScratchT {  // one per wavefront (LDS on the device)
-  static constexpr int kMaxCandidates = kH9 ? kMaxCandidatesH9 : kMaxCandidatesAdv;
-  uint32_t win[kInfoWindow][2];  // rank records (info) of positions [win_base, win_base + kInfoWindow)
+  static constexpr int kMaxCandidates = kRows ? 16 + (int)kRowEntries : (kH9 ? kMaxCandidatesH9 : kMaxCandidatesAdv);
+  // !kRows: rank records (info) of positions [win_base, win_base + kInfoWindow), two words each
+  //  kRows: candidate rows of positions [win_base, win_base + kRowWindow)
+  alignas(16) uint32_t win[kRows ? kRowWindow * kRowEntries : kInfoWindow * 2];
+  uint16_t dictwin[kRows ? kRowWindow * 2 : 2];  // kRows: the two static-dictionary hash items of every window position
   int32_t dc[16];                // distance cache incl. the derived entries (mod.rs:632-651); lanes index it by candidate
   uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
   uint32_t cand_len[2][kMaxCandidates + 2];
@@ -321,13 +341,16 @@ struct ProbeMeta {
   uint32_t version;   // dist-cache version the probe was computed with
   uint32_t g[2], nbucket[2];
   uint32_t win_base;  // first position of the rank-record window held in ChainScratch::win
+  // kRows on the device: the candidate of THIS lane (lanes 0..31 serve p0, lanes 32..63 p0 + 1; see br_probe_pair_rows)
+  uint32_t r_prev, r_len;
+  uint32_t no_dict;   // the static dictionary is known to be switched off for good: no probes, no bookkeeping
 #if defined(BR_CHAIN_PROFILE)
-  unsigned long long t_probe, t_fold, n_probe, n_fold;
+  unsigned long long t_probe, t_fold, n_probe, n_fold, t_setup, t_refill, n_refill;
 #endif
 };
 #if defined(BR_CHAIN_PROFILE)
 #define BR_TICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
-extern __device__ unsigned long long g_chain_prof[8];
+extern __device__ unsigned long long g_chain_prof[16];
 #endif
 
 #if defined(BROTLI_HOST_EMU)
@@ -362,32 +385,160 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
 }
 #endif
 
+#if !defined(BROTLI_HOST_EMU)
+// kRows, device: fixed lane layout, results stay in registers.  Half w = lane >> 5 probes position p0 + w; inside a half
+// lane c = lane & 31 holds: c < ndist the distance-cache candidate c, ndist <= c < ndist + 16 ring entry c - ndist of the
+// row, c = ndist + 16 / + 17 the two static-dictionary probes.  One memory round trip per probe: the rows and the
+// dictionary hash items of the next kRowWindow positions sit in LDS (refilled with one coalesced load per window).
+static constexpr uint32_t kRowDictLane = 16;  // offset of the dictionary lanes behind the cache lanes
 template <bool kH9>
-BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, ProbeMeta& m, uint32_t p0,
-                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
+BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, true>& s, ProbeMeta& m, uint32_t p0,
+                               const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
   const uint32_t ndist = P.ndist;
-  const uint32_t block_size = 1u << P.block_bits;
-  const uint32_t ndict = P.use_dictionary ? 2u : 0u;
-  // rank records of the positions around p0: one coalesced load serves the next ~60 positions
-  if (p0 < m.win_base || p0 + 1 >= m.win_base + kInfoWindow) {
+  const bool use_dict = P.use_dictionary && !m.no_dict;
+#if defined(BR_CHAIN_PROFILE)
+  const unsigned long long tp0 = BR_TICK();
+#endif
+  if (p0 < m.win_base || p0 + 1 >= m.win_base + kRowWindow) {
     BR_SYNC();
-    for (uint32_t i = BR_LANE; i < kInfoWindow; i += BR_NLANES) {
-      const uint32_t q = p0 + i;
-      const bool ok = q < P.total_bytes;
-      s.win[i][0] = ok ? t.info[2 * (size_t)q] : 0u;
-      s.win[i][1] = ok ? t.info[2 * (size_t)q + 1] : 0u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // dictionary hash items of the window positions (SearchInStaticDictionary, mod.rs:1942-1988): lane = 2 * position + probe
+    uint32_t first4 = 0;
+    if (use_dict) first4 = br_load32(t.text + p0 + (BR_LANE >> 1));
+    u32x4 v[kRowWindow * (kRowEntries / 4) / 64];
+#pragma unroll
+    for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) {
+      const uint32_t i = j * 64 + BR_LANE;
+      const uint32_t q = p0 + i / (kRowEntries / 4);
+      const u32x4 none = {kRowEnd, kRowEnd, kRowEnd, kRowEnd};
+      v[j] = none;
+      if (q < P.total_bytes) v[j] = __builtin_nontemporal_load((const u32x4*)t.rows + (size_t)q * (kRowEntries / 4) + (i % (kRowEntries / 4)));
     }
+    if (use_dict) s.dictwin[BR_LANE] = t.dict_hash[(((first4 * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
+#pragma unroll
+    for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) ((u32x4*)s.win)[j * 64 + BR_LANE] = v[j];
     m.win_base = p0;
     BR_SYNC();
+#if defined(BR_CHAIN_PROFILE)
+    m.t_refill += BR_TICK() - tp0;
+    m.n_refill++;
+#endif
   }
+  m.pos = p0;
+  m.version = cache_version;
+  m.nbucket[0] = m.nbucket[1] = kRowEntries;  // (the generic fold walks the whole row; kRowEnd entries end the walk)
+  const uint32_t w = (uint32_t)BR_LANE >> 5, c = (uint32_t)BR_LANE & 31u;
+  const uint32_t cur = p0 + w;
+  const uint32_t max_length = pos_end - cur;
+  const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+  const uint8_t* cur_data = t.text + cur;
+  const bool is_cache = c < ndist;
+  const bool is_ring = !is_cache && c < ndist + kRowEntries;
+  const bool is_dict = use_dict && c >= ndist + kRowDictLane && c < ndist + kRowDictLane + 2;
+  uint32_t prev = 0xffffffffu, limit = max_length;
+  const uint8_t* src = nullptr;
+  if (is_cache) {
+    const int64_t b = (int64_t)cache[c];
+    if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+  } else if (is_ring) {
+    prev = s.win[(cur - m.win_base) * kRowEntries + (c - ndist)];  // kRowEnd == "no candidate"
+  } else if (is_dict) {
+    const uint32_t item = s.dictwin[(cur - m.win_base) * 2 + (c - ndist - kRowDictLane)];
+    prev = item;
+    if (item != 0) {
+      const uint32_t wlen = item & 0x1f;
+      if (wlen <= max_length) {
+        src = t.dict_data + t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
+        limit = wlen;
+      }
+    }
+  }
+  if (!is_dict && prev != 0xffffffffu) src = t.text + prev;
+#if defined(BR_CHAIN_PROFILE)
+  m.t_setup += BR_TICK() - tp0;
+#endif
+  m.r_len = src ? br_match_len_wide(src, cur_data, limit) : 0u;
+  m.r_prev = prev;
+}
+#endif
+
+template <bool kH9, bool kRows>
+BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, uint32_t p0,
+                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
+#if !defined(BROTLI_HOST_EMU)
+  if constexpr (kRows) {
+    br_probe_pair_rows<kH9>(P, t, s, m, p0, cache, cache_version, pos_end);
+    return;
+  }
+#endif
+  const uint32_t ndist = P.ndist;
+  const uint32_t block_size = 1u << P.block_bits;
+  const uint32_t ndict = (P.use_dictionary && !m.no_dict) ? 2u : 0u;
   uint32_t n[2];
-  for (int w = 0; w < 2; ++w) {
-    const uint32_t g = s.win[p0 + w - m.win_base][0];
-    const uint32_t num_copy = s.win[p0 + w - m.win_base][1] & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
-    m.g[w] = g;
-    m.nbucket[w] = num_copy < block_size ? num_copy : block_size;
-    n[w] = ndist + m.nbucket[w] + ndict;
+#if defined(BR_CHAIN_PROFILE)
+  const unsigned long long tp0 = BR_TICK();
+#endif
+  if (kRows) {
+#if defined(BROTLI_HOST_EMU)
+    for (int w = 0; w < 2; ++w) {
+      uint32_t nb = 0;
+      if (p0 + w < P.total_bytes)
+        while (nb < kRowEntries && t.rows[(size_t)(p0 + w) * kRowEntries + nb] != kRowEnd) ++nb;
+      m.g[w] = 0;
+      m.nbucket[w] = nb;
+    }
+#else
+    // candidate rows of the positions from p0 on: contiguous, 64 bytes per position
+    if (p0 < m.win_base || p0 + 1 >= m.win_base + kRowWindow) {
+      BR_SYNC();
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      for (uint32_t i = BR_LANE; i < kRowWindow * (kRowEntries / 4); i += BR_NLANES) {
+        const uint32_t q = p0 + i / (kRowEntries / 4);
+        u32x4 v = {kRowEnd, kRowEnd, kRowEnd, kRowEnd};
+        if (q < P.total_bytes) v = __builtin_nontemporal_load((const u32x4*)t.rows + (size_t)q * (kRowEntries / 4) + (i % (kRowEntries / 4)));
+        ((u32x4*)s.win)[i] = v;
+      }
+      m.win_base = p0;
+      BR_SYNC();
+#if defined(BR_CHAIN_PROFILE)
+      m.t_refill += BR_TICK() - tp0;
+      m.n_refill++;
+#endif
+    }
+    {
+      const uint32_t l = (uint32_t)BR_LANE;
+      const uint32_t e = l < 2 * kRowEntries ? s.win[(p0 - m.win_base + l / kRowEntries) * kRowEntries + (l % kRowEntries)] : kRowEnd;
+      const unsigned long long valid = __ballot(e != kRowEnd);
+      // (entries are packed from the front: the number of valid ones is where the row ends)
+      m.g[0] = m.g[1] = 0;
+      m.nbucket[0] = (uint32_t)__popcll(valid & 0xffffull);
+      m.nbucket[1] = (uint32_t)__popcll((valid >> kRowEntries) & 0xffffull);
+    }
+#endif
+  } else {
+    // rank records of the positions around p0: one coalesced load serves the next ~60 positions
+    if (p0 < m.win_base || p0 + 1 >= m.win_base + kInfoWindow) {
+      BR_SYNC();
+      for (uint32_t i = BR_LANE; i < kInfoWindow; i += BR_NLANES) {
+        const uint32_t q = p0 + i;
+        const bool ok = q < P.total_bytes;
+        s.win[2 * i] = ok ? t.info[2 * (size_t)q] : 0u;
+        s.win[2 * i + 1] = ok ? t.info[2 * (size_t)q + 1] : 0u;
+      }
+      m.win_base = p0;
+      BR_SYNC();
+    }
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t g = s.win[2 * (p0 + w - m.win_base)];
+      const uint32_t num_copy = s.win[2 * (p0 + w - m.win_base) + 1] & 0xffffu;  // num[key] is u16 and wraps (mod.rs:1752-1760)
+      m.g[w] = g;
+      m.nbucket[w] = num_copy < block_size ? num_copy : block_size;
+    }
   }
+  for (int w = 0; w < 2; ++w) n[w] = ndist + m.nbucket[w] + ndict;
+#if defined(BR_CHAIN_PROFILE)
+  m.t_setup += BR_TICK() - tp0;
+#endif
   m.pos = p0;
   m.version = cache_version;
   const uint32_t total = n[0] + n[1];
@@ -403,7 +554,17 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     const bool is_dict = !is_cache && !is_bucket;
     // step 1 (one memory round trip for every kind of candidate): where does the candidate live?
     uint32_t q = 0, item = 0;
-    if (is_bucket) q = t.sorted[m.g[w] - 1 - (c - ndist)];
+    if (is_bucket) {
+      if (kRows) {
+#if defined(BROTLI_HOST_EMU)
+        q = t.rows[(size_t)cur * kRowEntries + (c - ndist)];
+#else
+        q = s.win[(cur - m.win_base) * kRowEntries + (c - ndist)];
+#endif
+      } else {
+        q = t.sorted[m.g[w] - 1 - (c - ndist)];
+      }
+    }
     if (is_dict) {
       // static dictionary probe i (SearchInStaticDictionary, mod.rs:1942-1988)
       const uint32_t key = (((br_load32(cur_data) * 0x1e35a7bdu) >> (32 - 14)) << 1) + (c - ndist - m.nbucket[w]);
@@ -436,8 +597,8 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
 }
 
 // Phase 2: fold the candidates of probe slot w in the reference's order, then the static dictionary stage.
-template <bool kH9>
-BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const ProbeMeta& m, uint32_t w,
+template <bool kH9, bool kRows>
+BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const ProbeMeta& m, uint32_t w,
                                   DictState& ds, uint32_t blk_end) {
   const uint32_t cur = m.pos + w;
   const uint32_t max_length = blk_end - cur;
@@ -521,7 +682,51 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   const uint32_t brk = P.dict_break;
   bool walk_broken = false;
   bool folded = false;
-  if (ncand <= 64) {
+  if constexpr (kRows) {
+    // The candidates of this position are in the registers of its half of the wave (br_probe_pair_rows); entries behind
+    // the end of the row hold kRowEnd and never take part.
+    const uint32_t c = (uint32_t)BR_LANE & 31u;
+    const bool in_range = ((uint32_t)BR_LANE >> 5) == w && c < ndist + kRowEntries;
+    const bool is_cache = c < ndist;
+    const uint32_t prev = in_range ? m.r_prev : 0xffffffffu;
+    const uint32_t unbroken = in_range ? m.r_len : 0u;
+    const bool has = prev != 0xffffffffu;
+    const bool special_lane = has && (((prev & P.ring_mask) + unbroken > P.ring_mask) || unbroken == max_length ||
+                                      ((prev & P.ring_mask) < brk && (prev & P.ring_mask) + unbroken > brk));
+    const bool cur_near_wrap = (cur & P.ring_mask) + max_length > P.ring_mask;
+    if (!cur_near_wrap && __ballot(special_lane) == 0) {
+      folded = true;
+      const uint32_t backward = cur - prev;
+      const uint32_t score = is_cache ? br_score_cache<kH9>(P, unbroken, c & 15u) : br_score_ring<kH9>(P, unbroken, has ? backward : 1u);
+      const bool type_ok = is_cache ? (unbroken >= 3 || (unbroken == 2 && c < 2)) : unbroken >= 4;
+      unsigned long long live = __ballot(has && type_ok);
+      uint32_t best_lane = 64;
+      while (live != 0) {
+        const unsigned long long mm = live & __ballot(unbroken > best_len && score > best_score);
+        if (mm == 0) break;
+        const uint32_t f = (uint32_t)__ffsll((long long)mm) - 1u;
+        best_len = BR_READLANE(unbroken, f);
+        best_score = BR_READLANE(score, f);
+        best_lane = f;
+        live = f >= 63 ? 0ull : (mm >> (f + 1)) << (f + 1);
+      }
+      if (best_lane != 64) {
+        out.len = best_len;
+        out.distance = BR_READLANE(backward, best_lane);
+        out.score = best_score;
+        out.found = true;
+      }
+    } else {
+      // rare (a candidate next to a ring-buffer wrap, the block end or the end of a custom dictionary): hand the
+      // candidates to the general fold below through LDS
+      BR_SYNC();
+      if (in_range) {
+        s.cand_prev[w][c] = m.r_prev;
+        s.cand_len[w][c] = m.r_len;
+      }
+      BR_SYNC();
+    }
+  } else if (ncand <= 64) {
     // Fast path (all candidates in one pass of the wave, nothing near a ring-buffer wrap, the block end or the
     // custom-dictionary boundary): straight-line scoring, then a loop whose body is two compares, a mask AND,
     // a find-first-set and two lane reads.
@@ -617,6 +822,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     const bool dead = ds.matches < (ds.lookups >> 7);
     const uint32_t seen = dead ? 2u : 1u;
     ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
+    if (m.no_dict) return out;  // switched off for good under exact counters: nobody needs the virtual bookkeeping
     if (dead && ds.vwould) return out;
     if (dead) {
       if ((int32_t)ds.vlookups > ds.vmaxdef) ds.vmaxdef = (int32_t)ds.vlookups;
@@ -626,8 +832,14 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     }
     uint32_t threshold = out.score;
     for (uint32_t i = 0; i < 2; ++i) {
+#if !defined(BROTLI_HOST_EMU)
+      const uint32_t dict_lane = 32u * w + ndist + kRowDictLane + i;
+      const uint32_t item = kRows ? BR_READLANE(m.r_prev, dict_lane) : BR_UNIFORM(s.cand_prev[w][ncand + i]);
+      const uint32_t matchlen = kRows ? BR_READLANE(m.r_len, dict_lane) : BR_UNIFORM(s.cand_len[w][ncand + i]);
+#else
       const uint32_t item = BR_UNIFORM(s.cand_prev[w][ncand + i]);
       const uint32_t matchlen = BR_UNIFORM(s.cand_len[w][ncand + i]);
+#endif
       if (dead) ds.vlookups++; else ds.lookups++;
       if (item == 0) continue;
       const uint32_t len = item & 0x1f;
@@ -657,23 +869,23 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
 }
 
 // search(x) for the parse loop: reuses the speculative second slot when it is still valid
-template <bool kH9>
-BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, ProbeMeta& m, DictState& ds,
+template <bool kH9, bool kRows>
+BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, DictState& ds,
                               uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end) {
 #if defined(BR_CHAIN_PROFILE)
   unsigned long long t0 = BR_TICK();
   if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) {
-    SearchResult r = br_fold_probe<kH9>(P, t, s, m, 1, ds, blk_end);
+    SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 1, ds, blk_end);
     m.t_fold += BR_TICK() - t0;
     m.n_fold++;
     return r;
   }
   BR_SYNC();
-  br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end);
+  br_probe_pair<kH9, kRows>(P, t, s, m, x, cache, cache_version, blk_end);
   unsigned long long t1 = BR_TICK();
   m.t_probe += t1 - t0;
   m.n_probe++;
-  SearchResult r = br_fold_probe<kH9>(P, t, s, m, 0, ds, blk_end);
+  SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 0, ds, blk_end);
   m.t_fold += BR_TICK() - t1;
   m.n_fold++;
   return r;
@@ -681,10 +893,10 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
     BR_SYNC();  // every lane is done reading the previous probe
-    br_probe_pair<kH9>(P, t, s, m, x, cache, cache_version, blk_end);
+    br_probe_pair<kH9, kRows>(P, t, s, m, x, cache, cache_version, blk_end);
     w = 0;
   }
-  return br_fold_probe<kH9>(P, t, s, m, w, ds, blk_end);
+  return br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end);
 #endif
 }
 
@@ -757,8 +969,8 @@ struct FlagWriter {
 
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
-template <bool kH9>
-BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment& seg_in,
+template <bool kH9, bool kRows>
+BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment& seg_in,
                                  const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
   Segment seg;
@@ -800,8 +1012,13 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   probe.pos = 0xffffffffu;
   probe.version = 0;
   probe.win_base = 0xffffff00u;
+  probe.r_prev = 0xffffffffu;
+  probe.r_len = 0;
+  // Once the throttle (matches < lookups >> 7, mod.rs:1957-1960) has tripped it stays tripped: nothing is looked up any
+  // more, so neither counter moves.  With exact counters at the entry the chain need not even keep the virtual books.
+  probe.no_dict = (P.use_dictionary && BR_UNIFORM(entry.dict_exact) && ds.matches < (ds.lookups >> 7)) ? 1u : 0u;
 #if defined(BR_CHAIN_PROFILE)
-  probe.t_probe = probe.t_fold = probe.n_probe = probe.n_fold = 0;
+  probe.t_probe = probe.t_fold = probe.n_probe = probe.n_fold = probe.t_setup = probe.t_refill = probe.n_refill = 0;
   const unsigned long long t_begin = BR_TICK();
 #endif
   Command* cmds = t.cmds + (size_t)seg.cmd_base;
@@ -844,14 +1061,14 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   }
 
   while (position + htl < pos_end && position < seg.end) {
-    SearchResult sr = br_search<kH9>(P, t, s, probe, ds, position, dc, cache_version, pos_end);
+    SearchResult sr = br_search<kH9, kRows>(P, t, s, probe, ds, position, dc, cache_version, pos_end);
     n_searches++;
     if (sr.found) {
       int delayed = 0;
       bool next_probed, next_stored = true;
       uint32_t special = 0;  // bit j: the search j positions before the match start was not inserted (H9 ring end)
       for (;;) {
-        SearchResult sr2 = br_search<kH9>(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end);
+        SearchResult sr2 = br_search<kH9, kRows>(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end);
         n_searches++;
         next_probed = true;
         if (kH9) next_stored = sr2.stored;
@@ -937,6 +1154,13 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     insert_length += pos_end - position;
     position = pos_end;
   }
+#if !defined(BROTLI_HOST_EMU)
+  if (BR_LANE == 0 && t.work) {
+    atomicAdd(t.work + 0, (unsigned long long)(position - BR_UNIFORM(entry.pos)));
+    atomicAdd(t.work + 1, (unsigned long long)n_searches);
+    if (fw.enabled) atomicAdd(t.work + 2, (unsigned long long)n_cmds);
+  }
+#endif
   if (BR_LANE == 0) {
     exit_out.pos = position;
     exit_out.apply = apply;
@@ -968,6 +1192,10 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     atomicAdd(&g_chain_prof[4], probe.n_fold);
     atomicAdd(&g_chain_prof[5], 1ull);
     atomicAdd(&g_chain_prof[6], (unsigned long long)n_cmds);
+    atomicAdd(&g_chain_prof[7], probe.t_setup);
+    atomicAdd(&g_chain_prof[8], probe.t_refill);
+    atomicAdd(&g_chain_prof[9], probe.n_refill);
+    atomicAdd(&g_chain_prof[10], (unsigned long long)n_searches);
   }
 #endif
   next.pos = position;
@@ -991,8 +1219,8 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
 // they are not scheduled themselves: a change that would otherwise creep forward one segment per round (each
 // round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
 // written to entries[] so that the host resolver sees what it was parsed with.
-template <bool kH9>
-BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9>& s, const Segment* segments,
+template <bool kH9, bool kRows>
+BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment* segments,
                            SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
   SegEntry entry = entries[k];
   // a chain takes on at most max_continuation further segments' worth of searches (one search every other byte is
@@ -1011,7 +1239,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
   for (;;) {
     const Segment seg = segments[k];
     SegEntry next;
-    const uint32_t ret = br_parse_segment<kH9>(P, t, s, seg, entry, exits[k], next);
+    const uint32_t ret = br_parse_segment<kH9, kRows>(P, t, s, seg, entry, exits[k], next);
     const uint32_t cost = ret & 0x0fffffffu, np = ret >> 28;
     if (first) {
       const uint32_t per_segment = (seg.end - seg.start) / 2;

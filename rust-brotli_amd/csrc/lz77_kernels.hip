@@ -16,6 +16,7 @@
 
 #include "device_api.h"
 #include "lz77_chain.h"
+#include "lz77_rows.h"
 #include "device_scan.h"
 
 namespace brotli_mi355x {
@@ -111,9 +112,13 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint16_t* __restrict__
 // stable scatter: elements keep their input order inside each digit.  The tile is first reordered by digit in LDS, then
 // written out run by run, so that the lanes of a wave write neighbouring addresses (a direct scatter writes one isolated
 // 2- and 4-byte element per digit and round).
+// `tags`: optional third column (16-bit tag of every position, br_tag16): computed from the text in the first pass
+// (tags_in == nullptr, text != nullptr), carried along in the second.
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                         uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                        uint32_t shift, uint32_t num_tiles, const uint32_t* __restrict__ offsets) {
+                                                        uint32_t shift, uint32_t num_tiles, const uint32_t* __restrict__ offsets,
+                                                        const uint8_t* __restrict__ text, const uint16_t* __restrict__ tags_in,
+                                                        uint16_t* __restrict__ tags_out) {
   __shared__ uint32_t gbase[256];   // where digit d of this tile goes in the output
   __shared__ uint32_t lstart[256];  // where digit d starts inside the reordered tile
   __shared__ uint32_t run[256];     // next free local slot of digit d
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restric
   __shared__ uint32_t wave_total[4];
   __shared__ uint16_t skey[kSortTile];
   __shared__ uint32_t sval[kSortTile];
+  __shared__ uint16_t stagv[kSortTile];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t tile_base = blockIdx.x * kSortTile;
   const uint32_t tile_n = n - tile_base < kSortTile ? n - tile_base : kSortTile;
@@ -147,11 +153,12 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restric
   for (uint32_t r = 0; r < 16; ++r) {
     const uint32_t i = tile_base + r * 256 + tid;
     const bool valid = i < n;
-    uint32_t key = 0, val = 0, d = 0;
+    uint32_t key = 0, val = 0, d = 0, tag = 0;
     if (valid) {
       key = keys_in[i];
       val = vals_in ? vals_in[i] : i;
       d = (key >> shift) & 255u;
+      if (tags_out) tag = tags_in ? tags_in[i] : br_tag16(br_load32(text + val));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) wcount[w][lane * 4 + j] = 0;
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restric
       for (int i2 = 0; i2 < w; ++i2) at += wcount[i2][d];
       skey[at] = (uint16_t)key;
       sval[at] = val;
+      if (tags_out) stagv[at] = (uint16_t)tag;
     }
     __syncthreads();
     run[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint16_t* __restric
     const uint32_t dst = gbase[d] + (at - lstart[d]);
     keys_out[dst] = (uint16_t)key;
     vals_out[dst] = sval[at];
+    if (tags_out) tags_out[dst] = stagv[at];
   }
 }
 
@@ -191,7 +200,7 @@ size_t lz77_sort_tmp_bytes(uint32_t total_bytes) {
   const size_t tiles = (n + kSortTile - 1) / kSortTile + 1;
   // ping-pong keys + values, digit histograms, scan scratch
   // (the incremental re-rank uses the same scratch for two u32 arrays in (key,pos) index space)
-  return n * 8 + 1024 + tiles * 256 * 4 + (tiles * 256 / kScanTile + 1024) * 8 + (n / kScanTile + 1024) * 8 + 4096;
+  return n * 10 + 2048 + tiles * 256 * 4 + (tiles * 256 / kScanTile + 1024) * 8 + (n / kScanTile + 1024) * 8 + 4096;
 }
 
 void lz77_key_ranges(const Lz77Params& P, const Lz77Buffers& B);
@@ -205,6 +214,8 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   tmp += ((size_t)n * 2 + 255) & ~(size_t)255;
   uint32_t* vals_tmp = (uint32_t*)tmp;
   tmp += ((size_t)n * 4 + 255) & ~(size_t)255;
+  uint16_t* tags_tmp = (uint16_t*)tmp;
+  tmp += ((size_t)n * 2 + 255) & ~(size_t)255;
   uint32_t* hist = (uint32_t*)tmp;
   tmp += (size_t)tiles * 256 * 4;
   uint32_t* scratch = (uint32_t*)tmp;
@@ -212,11 +223,12 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, BR_STREAM, B.keys, n, 0u, tiles, hist);
   exclusive_scan_u32(hist, tiles * 256, scratch);
   hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, BR_STREAM, B.keys, (const uint32_t*)nullptr, keys_tmp, vals_tmp, n, 0u, tiles,
-                     hist);
+                     hist, (const uint8_t*)B.text, (const uint16_t*)nullptr, B.stag ? tags_tmp : (uint16_t*)nullptr);
   // pass 2: high 8 bits, tmp -> by_key / sorted_keys
   hipLaunchKernelGGL(k_radix_hist, dim3(tiles), dim3(256), 0, BR_STREAM, keys_tmp, n, 8u, tiles, hist);
   exclusive_scan_u32(hist, tiles * 256, scratch);
-  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, BR_STREAM, keys_tmp, vals_tmp, B.sorted_keys, B.by_key, n, 8u, tiles, hist);
+  hipLaunchKernelGGL(k_radix_scatter, dim3(tiles), dim3(256), 0, BR_STREAM, keys_tmp, vals_tmp, B.sorted_keys, B.by_key, n, 8u, tiles, hist,
+                     (const uint8_t*)B.text, (const uint16_t*)tags_tmp, B.stag);
   HIP_CHECK(hipGetLastError());
   lz77_key_ranges(P, B);
 }
@@ -518,6 +530,502 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------ candidate rows
+// See kRowEntries in lz77_types.h and lz77_rows.h.  rows[p] is a pure function of the per-slot bytes (stored bit, wrap
+// mark) of the slots in front of p's slot in (key, position) order: the lookback ends after `depth` stored slots, so a
+// flag change reaches the rows of the next `depth` stored positions of its key and no further.
+struct RowArgs {
+  const uint32_t* by_key;
+  const uint16_t* sorted_keys;
+  const uint16_t* stag;
+  const uint8_t* fbits;
+  const unsigned long long* smask;  // stored bits, one word per 64 slots
+  const uint32_t* gprev;            // per 64 slots: 1 + the last stored slot in front of them
+  const uint32_t* key_first;
+  const uint32_t* key_last;
+  uint32_t* rows;
+  const uint8_t* flags;  // newest per-position flags (the searched bit decides who is affected by a changed row)
+  uint32_t n, depth, max_backward_limit;
+  uint32_t validate;     // compare with the row in memory and mark the chains that searched a position whose row changed
+  SegGeometry geo;
+  uint8_t* dirty;
+  const uint32_t* ctl;   // conditional launches: run only if ctl[kCtlNeedFull] != 0
+  uint32_t* walk_counter;  // == ctl, writable (k_update_rows)
+  uint32_t conditional;
+};
+// device-side control words of lz77_rows_update
+enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtlWords = 4 };
+
+__device__ __forceinline__ void row_changed(const RowArgs& a, uint32_t p) {
+  if (p < a.geo.first_block_start) return;
+  if (a.flags[p] & kFlagSearched) {
+    mark_dirty(p, a.geo, a.dirty);
+  } else {
+    const uint32_t k = chain_in_front_if_near_boundary(p, a.geo);
+    if (k != 0xffffffffu) a.dirty[k] = 1;
+  }
+}
+
+// All rows: one workgroup per tile of kRowTile slots (+ the kRowHalo slots in front of it), everything staged in LDS.
+// The stored slots of the span are compacted first, so that the lookback of a slot is a walk over consecutive compact
+// entries (no skipping of unstored slots, at most `depth` steps); every wave stages the rows of 64 slots in LDS and
+// writes them out as whole 64-byte lines.
+static constexpr uint32_t kRowTile = kScanTile, kRowHalo = 256, kRowSpan = kRowTile + kRowHalo;
+static_assert(kRowSpan == 256 * 5, "five span entries per thread");
+
+__global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
+  if (a.conditional && a.ctl[kCtlNeedFull] == 0) return;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ uint32_t s_pos[kRowSpan];
+  __shared__ uint32_t s_tk[kRowSpan];  // tag | key << 16
+  __shared__ uint8_t s_fb[kRowSpan];
+  __shared__ uint16_t s_rank[kRowSpan];  // stored slots of the span in front of each entry
+  __shared__ uint2 c_ent[kRowSpan];      // the stored slots, compacted: {position | wrap mark << 31, tag | key << 16}
+  __shared__ uint32_t wave_sum[4];
+  __shared__ uint8_t s_slow[4][64];
+  __shared__ alignas(16) uint32_t rowbuf[4][64 * kRowEntries];
+  const uint32_t base = blockIdx.x * kRowTile;
+  const uint32_t lo = base >= kRowHalo ? base - kRowHalo : 0u;
+  const uint32_t hi = min(base + kRowTile, a.n);
+  const uint32_t span = hi - lo;
+  for (uint32_t e = threadIdx.x; e < span; e += 256) {
+    const uint32_t i = lo + e;
+    s_pos[e] = a.by_key[i];
+    s_tk[e] = (uint32_t)a.stag[i] | ((uint32_t)a.sorted_keys[i] << 16);
+    s_fb[e] = a.fbits[i];
+  }
+  __syncthreads();
+  {
+    uint32_t f[5], local = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint32_t e = threadIdx.x * 5 + j;
+      f[j] = e < span ? (s_fb[e] & kSlotStored) : 0u;
+      local += f[j];
+    }
+    uint32_t x = local;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_sum[w] = x;
+    __syncthreads();
+    uint32_t g = x - local;
+    for (int i = 0; i < w; ++i) g += wave_sum[i];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint32_t e = threadIdx.x * 5 + j;
+      if (e < span) {
+        s_rank[e] = (uint16_t)g;
+        if (f[j]) c_ent[g] = make_uint2(s_pos[e] | ((s_fb[e] & kSlotWrap) ? 0x80000000u : 0u), s_tk[e]);
+      }
+      g += f[j];
+    }
+  }
+  __syncthreads();
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  SlotsInMemory sl{a.by_key, a.fbits, a.stag, a.smask, a.gprev};
+  for (uint32_t r = 0; r < kRowTile / 256; ++r) {
+    const uint32_t e = (base - lo) + w * 256 + r * 64 + lane;
+    const bool valid = lo + e < hi;
+    bool slow = false;
+    if (valid) {
+      const uint32_t p = s_pos[e], tk = s_tk[e];
+      const uint32_t key = tk >> 16, tag = tk & 0xffffu;
+      const uint32_t max_backward = p < a.max_backward_limit ? p : a.max_backward_limit;
+      uint32_t* out = &rowbuf[w][lane * kRowEntries];
+      uint32_t k = s_rank[e], n = 0, seen = 0;
+      const uint32_t depth = (s_fb[e] & kSlotWrap) ? 0u : a.depth;
+      while (seen < depth) {
+        if (k == 0) {
+          // out of staged slots: slots of this key in front of the span need the slow walk through memory
+          slow = lo > 0 && (s_tk[0] >> 16) == key;
+          break;
+        }
+        --k;
+        const uint2 ent = c_ent[k];
+        if ((ent.y >> 16) != key) break;
+        const uint32_t q = ent.x & 0x7fffffffu;
+        if (p - q > max_backward) break;
+        ++seen;
+        if ((ent.y & 0xffffu) == tag) out[n++] = q;
+        if (ent.x >> 31) break;
+      }
+      if (slow) {
+        if (br_build_row(sl, a.rows, a.max_backward_limit, lo + e, a.key_first[key], a.depth, a.validate != 0) && a.validate) row_changed(a, p);
+      } else {
+        for (; n < kRowEntries; ++n) out[n] = kRowEnd;
+      }
+    }
+    s_slow[w][lane] = (!valid || slow) ? 1 : 0;
+    __syncthreads();
+    // the 64 rows of this wave go out as 256 pieces of 16 bytes: four lanes write one 64-byte line
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t idx = it * 64 + lane;
+      const uint32_t row = idx >> 2, part = idx & 3u;
+      const bool go = s_slow[w][row] == 0;
+      bool diff = false;
+      uint32_t p2 = 0;
+      if (go) {
+        p2 = s_pos[(base - lo) + w * 256 + r * 64 + row];
+        const u32x4 v = ((const u32x4*)rowbuf[w])[idx];
+        u32x4* dst = (u32x4*)(a.rows + (size_t)p2 * kRowEntries) + part;
+        if (a.validate) {
+          const u32x4 old = *dst;
+          diff = old.x != v.x || old.y != v.y || old.z != v.z || old.w != v.w;
+          if (diff) *dst = v;
+        } else {
+          *dst = v;
+        }
+      }
+      if (a.validate) {
+        const unsigned long long m = __ballot(diff);
+        if (go && part == 0 && ((m >> (lane & ~3u)) & 0xfull) != 0) row_changed(a, p2);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fbits_tile_sums(const uint8_t* __restrict__ fbits, uint32_t n, const uint8_t* __restrict__ big_tile,
+                                                          uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t base = blockIdx.x * kRowTile + threadIdx.x * 4;
+  uint32_t local = 0;
+  if (base < n) {
+    uint32_t v = *(const uint32_t*)(fbits + base) & 0x01010101u;  // (the array is padded by 64 bytes)
+    for (uint32_t j = 0; j < 4; ++j)
+      if (base + j >= n) v &= ~(0xffu << (8 * j));
+    local = (v * 0x01010101u) >> 24;
+  }
+  const uint32_t total = block_sum_256(local, wave_sum);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+  (void)big_tile;
+}
+
+__global__ __launch_bounds__(256) void k_row_key_bases(const uint8_t* __restrict__ fbits, const uint32_t* __restrict__ tile_offsets,
+                                                        const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
+                                                        uint32_t* __restrict__ key_base) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 65536) return;
+  const uint32_t i0 = key_first[k];
+  if (key_last[k] - i0 < 65536u || key_last[k] <= i0) return;  // only keys whose counter can wrap
+  const uint32_t tile = i0 / kRowTile;
+  uint32_t g = tile_offsets[tile];
+  for (uint32_t i = tile * kRowTile; i < i0; ++i) g += fbits[i] & kSlotStored;
+  key_base[k] = g;
+}
+
+// tiles that hold slots of a key with >= 65 536 slots
+__global__ __launch_bounds__(256) void k_flag_big_tiles(const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
+                                                         uint8_t* __restrict__ big_tile) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 65536) return;
+  const uint32_t i0 = key_first[k], i1 = key_last[k];
+  if (i1 <= i0 || i1 - i0 < 65536u) return;
+  for (uint32_t t = i0 / kRowTile; t <= (i1 - 1) / kRowTile; ++t) big_tile[t] = 1;
+}
+
+// Wrap marks (kSlotWrap) of the keys whose counter can wrap, from the exact count of stored slots in front of every slot.  append: every
+// slot whose mark changes is added to the list of changed slots behind the real ones (its neighbourhood has to be
+// rebuilt like that of a flipped slot).
+__global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits, uint32_t n, const uint8_t* __restrict__ big_tile,
+                                                     const uint32_t* __restrict__ tile_offsets, const uint16_t* __restrict__ sorted_keys,
+                                                     const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
+                                                     const uint32_t* __restrict__ key_base, uint32_t append,
+                                                     uint32_t* __restrict__ changed_slot, const uint32_t* __restrict__ changed_count, uint32_t cap,
+                                                     uint32_t* __restrict__ ctl) {
+  if (!big_tile[blockIdx.x]) return;
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t base = blockIdx.x * kRowTile + threadIdx.x * 4;
+  uint32_t f[4], local = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[j] = base + j < n ? fbits[base + j] : 0u;
+    local += f[j] & kSlotStored;
+  }
+  uint32_t x = local;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_sum[w] = x;
+  __syncthreads();
+  uint32_t g = tile_offsets[blockIdx.x] + x - local;
+  for (int i = 0; i < w; ++i) g += wave_sum[i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t i = base + j;
+    if (i < n) {
+      const uint32_t key = sorted_keys[i];
+      bool want = false;
+      if (key_last[key] - key_first[key] >= 65536u) {
+        const uint32_t count = g - key_base[key];  // stored slots of the key in front of this one
+        want = count != 0 && (count & 0xffffu) == 0;
+      }
+      if (want != ((f[j] & kSlotWrap) != 0)) {
+        fbits[i] = (uint8_t)(f[j] ^ kSlotWrap);
+        if (append) {
+          const uint32_t real = *changed_count;
+          const uint32_t at = real + atomicAdd(&ctl[kCtlVirtual], 1u);
+          if (real <= cap && at < cap) changed_slot[at] = i; else atomicMax(&ctl[kCtlNeedFull], 1u);
+        }
+      }
+    }
+    g += f[j] & kSlotStored;
+  }
+}
+
+// stored bits from scratch (list overflow): a random one-byte gather per slot; the wrap marks are set afterwards
+__global__ __launch_bounds__(256) void k_regather_fbits(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
+                                                         uint8_t* __restrict__ fbits, const uint32_t* __restrict__ ctl) {
+  if (ctl[kCtlNeedFull] != 2) return;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    fbits[i] = (uint8_t)((flags[by_key[i]] & 1u) | (fbits[i] & kSlotWrap));
+}
+
+// One thread per changed position: find its slot (binary search in its key's slot range), flip the stored bit there.
+__global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict__ changed_pos, const uint32_t* __restrict__ changed_count,
+                                                      uint32_t cap, const uint16_t* __restrict__ keys, const uint32_t* __restrict__ key_first,
+                                                      const uint32_t* __restrict__ key_last, const uint32_t* __restrict__ by_key,
+                                                      const uint8_t* __restrict__ flags_new, uint8_t* __restrict__ fbits,
+                                                      uint32_t* __restrict__ changed_slot, uint32_t* __restrict__ ctl) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = *changed_count;
+  if (n > cap) {
+    if (i == 0) atomicMax(&ctl[kCtlNeedFull], 2u);
+    return;
+  }
+  if (i >= n) return;
+  const uint32_t p = changed_pos[i];
+  const uint32_t key = keys[p];
+  uint32_t lo = key_first[key], hi = key_last[key];
+  while (lo + 1 < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (by_key[mid] <= p) lo = mid; else hi = mid;
+  }
+  fbits[lo] = (uint8_t)((flags_new[p] & 1u) | kSlotChanged | (fbits[lo] & kSlotWrap));
+  changed_slot[i] = lo;
+}
+
+// One wavefront per changed slot s (flipped, or wrap mark moved): rebuild the rows of the slots behind it that can
+// have s in their lookback, i.e. up to the `depth`-th slot behind s that is stored and did not change itself in this
+// round (such slots are stored in the old AND in the new flag state, so `depth` of them push s out of the ring in both).
+__global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* __restrict__ changed_slot,
+                                                     const uint32_t* __restrict__ changed_count, const uint16_t* __restrict__ keys) {
+  if (a.ctl[kCtlNeedFull] != 0) return;
+  const uint32_t n = *changed_count + a.ctl[kCtlVirtual];
+  SlotsInMemory sl{a.by_key, a.fbits, a.stag, a.smask, a.gprev};
+  for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+    // A change in front of a long stretch of unstored slots reaches every row of the stretch, and several such changes
+    // walk the same stretch again and again: when the walks add up to a good part of all rows, the full rebuild behind
+    // this kernel is the cheaper way (what was updated here has been checked and marked already).
+    if (a.walk_counter[kCtlWalked] > a.n / 4) {
+      if (threadIdx.x == 0) atomicMax(&a.walk_counter[kCtlNeedFull], 1u);
+      return;
+    }
+    const uint32_t s = changed_slot[item];
+    const uint32_t key = keys[a.by_key[s]];
+    const uint32_t kf = a.key_first[key], kl = a.key_last[key];
+    uint32_t stable = 0;
+    // (slot s itself is rebuilt as well: its own row changes when its wrap mark does)
+    for (uint32_t base = s; base < kl && stable < a.depth; base += 64) {
+      const uint32_t i = base + threadIdx.x;
+      const bool in = i < kl;
+      const bool st = in && i != s && (a.fbits[i] & (kSlotStored | kSlotChanged)) == kSlotStored;
+      const unsigned long long m = __ballot(st);
+      const uint32_t before = (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (in && stable + before < a.depth) {
+        if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true)) row_changed(a, a.by_key[i]);
+      }
+      stable += (uint32_t)__popcll(m);
+      if (threadIdx.x == 0) atomicAdd(&a.walk_counter[kCtlWalked], 64u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_clear_flip_marks(const uint32_t* __restrict__ changed_slot, const uint32_t* __restrict__ changed_count,
+                                                           uint32_t cap, uint8_t* __restrict__ fbits) {
+  const uint32_t n = *changed_count;
+  if (n > cap) return;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) fbits[changed_slot[i]] &= (uint8_t)~kSlotChanged;
+}
+
+static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bool validate, const SegGeometry* geo, uint8_t* dirty_dev) {
+  RowArgs a{};
+  a.by_key = B.by_key;
+  a.sorted_keys = B.sorted_keys;
+  a.stag = B.stag;
+  a.fbits = B.fbits;
+  a.key_first = B.key_first;
+  a.key_last = B.key_last;
+  a.rows = B.rows;
+  a.flags = B.flags[which];
+  a.n = P.total_bytes;
+  a.depth = 1u << P.block_bits;
+  a.max_backward_limit = P.max_backward_limit;
+  a.validate = validate ? 1 : 0;
+  if (geo) a.geo = *geo;
+  a.dirty = dirty_dev;
+  a.ctl = B.row_ctl;
+  a.walk_counter = B.row_ctl;
+  a.smask = B.smask;
+  a.gprev = B.gprev;
+  return a;
+}
+
+// ---- stored-bit masks and skip pointers (SlotsInMemory::prev_stored) from the per-slot bytes ----
+__global__ __launch_bounds__(256) void k_slot_masks(const uint8_t* __restrict__ fbits, uint32_t n, unsigned long long* __restrict__ smask,
+                                                     uint32_t* __restrict__ glast) {
+  const uint32_t groups = (n + 63) / 64;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
+    unsigned long long m = 0;
+    const uint4* src = (const uint4*)(fbits + (size_t)g * 64);  // (the array is padded by 64 bytes)
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint4 v = src[q];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        // gather bit 0 of the four bytes of a word into four adjacent bits
+        const uint32_t b = w[k] & 0x01010101u;
+        const uint32_t nib = (b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xfu;
+        m |= (unsigned long long)nib << (q * 16 + k * 4);
+      }
+    }
+    if ((size_t)g * 64 + 64 > n) m &= (1ull << (n - g * 64)) - 1ull;
+    smask[g] = m;
+    glast[g] = m ? g * 64 + 64 - (uint32_t)__builtin_clzll(m) : 0u;
+  }
+}
+
+// exclusive prefix MAXIMUM of a uint32 array, in place (same shape as exclusive_scan_u32)
+__global__ __launch_bounds__(256) void k_maxscan_tiles(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ tile_max) {
+  __shared__ uint32_t wave_max[4];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (base + j < n) ? data[base + j] : 0;
+  const uint32_t local = max(max(v[0], v[1]), max(v[2], v[3]));
+  uint32_t x = local;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x = max(x, y);
+  }
+  if (lane == 63) wave_max[w] = x;
+  __syncthreads();
+  uint32_t before = 0;  // maximum over everything in front of this thread's four elements
+  for (int i = 0; i < w; ++i) before = max(before, wave_max[i]);
+  const uint32_t prev_lane = __shfl_up(x, 1, 64);
+  if (lane > 0) before = max(before, prev_lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (base + j < n) data[base + j] = before;
+    before = max(before, v[j]);
+  }
+  if (threadIdx.x == 255 && tile_max) tile_max[blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], x));
+}
+__global__ __launch_bounds__(256) void k_maxscan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ tile_before) {
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  const uint32_t add = tile_before[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < n) data[base + j] = max(data[base + j], add);
+}
+static void exclusive_maxscan_u32(uint32_t* data, uint32_t n, uint32_t* scratch) {
+  if (n == 0) return;
+  const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_maxscan_tiles, dim3(tiles), dim3(256), 0, BR_STREAM, data, n, tiles > 1 ? scratch : (uint32_t*)nullptr);
+  if (tiles > 1) {
+    exclusive_maxscan_u32(scratch, tiles, scratch + tiles);
+    hipLaunchKernelGGL(k_maxscan_add, dim3(tiles), dim3(256), 0, BR_STREAM, data, n, scratch);
+  }
+}
+
+// smask / gprev from the current per-slot bytes (after every change of stored bits)
+static void launch_slot_masks(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  const uint32_t groups = (n + 63) / 64;
+  uint32_t blocks = (groups + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_slot_masks, dim3(blocks), dim3(256), 0, BR_STREAM, B.fbits, n, B.smask, B.gprev);
+  // (scratch: behind the tile sums of the wrap-mark pass in sort_tmp)
+  uint32_t* scratch = (uint32_t*)B.sort_tmp + ((size_t)n / kScanTile + 4096);
+  exclusive_maxscan_u32(B.gprev, groups, scratch);
+}
+
+// wrap marks from the current stored bits (keys with >= 65 536 slots only)
+static void launch_wrap_marks(const Lz77Params& P, const Lz77Buffers& B, bool append) {
+  const uint32_t n = P.total_bytes;
+  const uint32_t tiles = (n + kRowTile - 1) / kRowTile;
+  uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
+  uint32_t* scratch = tile_sums + tiles + 64;
+  hipLaunchKernelGGL(k_fbits_tile_sums, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums);
+  exclusive_scan_u32(tile_sums, tiles, scratch);
+  hipLaunchKernelGGL(k_row_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
+  hipLaunchKernelGGL(k_mark_wraps, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums, B.sorted_keys, B.key_first, B.key_last,
+                     B.key_base, append ? 1u : 0u, B.changed_slot, B.changed_count, B.changed_cap, B.row_ctl);
+}
+
+void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const RankInitialHint* initial, bool has_big_keys) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0) return;
+  if ((1u << P.block_bits) > kRowEntries) throw std::runtime_error("candidate rows: ring deeper than a row");
+  InitialFlagGeometry ig{};
+  if (initial) {
+    ig.enabled = 1;
+    ig.first_block_start = initial->first_block_start;
+    ig.prefix_bytes = P.prefix_bytes;
+    ig.block_bytes = initial->block_bytes;
+    ig.total_bytes = n;
+    ig.prefix_stored_end = (initial->prefix_is_dictionary && P.prefix_bytes > P.htl - 1) ? P.prefix_bytes - (P.htl - 1) : 0;
+  }
+  const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+  uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
+  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
+  HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
+  if (has_big_keys) {
+    HIP_CHECK(hipMemsetAsync(B.big_tile, 0, tiles + 64, BR_STREAM));
+    hipLaunchKernelGGL(k_flag_big_tiles, dim3(256), dim3(256), 0, BR_STREAM, B.key_first, B.key_last, B.big_tile);
+    launch_wrap_marks(P, B, false);
+  }
+  launch_slot_masks(P, B);
+  RowArgs a = row_args(P, B, which, false, nullptr, nullptr);
+  hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
+  HIP_CHECK(hipGetLastError());
+}
+
+void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int next, const SegGeometry& geo, uint8_t* dirty_dev,
+                      bool has_big_keys) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0) return;
+  const uint32_t cap = B.changed_cap;
+  HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
+  // (B.changed_keys holds POSITIONS here, B.changed_count their number -- see lz77_diff_flags)
+  const uint32_t flip_blocks = (cap + 255) / 256;
+  hipLaunchKernelGGL(k_apply_flips, dim3(flip_blocks), dim3(256), 0, BR_STREAM, B.changed_keys, B.changed_count, cap, B.keys, B.key_first,
+                     B.key_last, B.by_key, B.flags[next], B.fbits, B.changed_slot, B.row_ctl);
+  uint32_t gather_blocks = (n + 255) / 256;
+  if (gather_blocks > 8192) gather_blocks = 8192;
+  hipLaunchKernelGGL(k_regather_fbits, dim3(gather_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.flags[next], n, B.fbits, B.row_ctl);
+  if (has_big_keys) launch_wrap_marks(P, B, true);
+  launch_slot_masks(P, B);
+  RowArgs a = row_args(P, B, next, true, &geo, dirty_dev);
+  hipLaunchKernelGGL(k_update_rows, dim3(cap < 65536u ? cap : 65536u), dim3(64), 0, BR_STREAM, a, B.changed_slot, B.changed_count, B.keys);
+  a.conditional = 1;
+  hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
+  hipLaunchKernelGGL(k_clear_flip_marks, dim3(flip_blocks < 1024u ? flip_blocks : 1024u), dim3(256), 0, BR_STREAM, B.changed_slot, B.changed_count,
+                     cap, B.fbits);
+  HIP_CHECK(hipGetLastError());
+  (void)prev;
+}
+
 // ------------------------------------------------------------------------------------------ parse
 struct ParseArgs {
   Lz77Params P;
@@ -537,22 +1045,23 @@ struct ParseTiming {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<uint32_t> counts;  // chains per launch
   uint64_t segments = 0;
+  unsigned long long* work_dev = nullptr;  // [4] what the chains did since the last lz77_parse_timing (ChainTables::work)
 };
 static ParseTiming& parse_timing() {
   static thread_local ParseTiming t;
   return t;
 }
 
-template <bool kH9>
+template <bool kH9, bool kRows>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_segments(ParseArgs a) {
-  __shared__ ChainScratchT<kH9> scratch;
+  __shared__ ChainScratchT<kH9, kRows> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
   // window and the rank rows its chains touch stay in that XCD's L2
   uint32_t item = blockIdx.x;
   if (a.per_xcd) item = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
   if (item >= a.count) return;
   const uint32_t k = a.list ? a.list[item] : a.first_segment + item;
-  br_parse_chain<kH9>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+  br_parse_chain<kH9, kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
 }
 
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
@@ -564,6 +1073,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.text = B.text;
   a.T.info = B.info[rbuf];
   a.T.sorted = B.sorted[rbuf];
+  a.T.rows = B.rows;
   a.T.flags_next = B.flags[flags_out];
   a.T.cmds = B.cmds;
   a.T.dict_hash = dt.dict_hash;
@@ -572,6 +1082,14 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   a.T.dist_postfix_bits = P.dist_postfix_bits;
   a.T.num_direct_distance_codes = P.num_direct_distance_codes;
+  {
+    ParseTiming& ptw = parse_timing();
+    if (!ptw.work_dev) {
+      HIP_CHECK(hipMalloc((void**)&ptw.work_dev, 4 * sizeof(unsigned long long)));
+      HIP_CHECK(hipMemsetAsync(ptw.work_dev, 0, 4 * sizeof(unsigned long long), BR_STREAM));
+    }
+    a.T.work = ptw.work_dev;
+  }
   a.segments = segments;
   a.entries = entries;
   a.exits = exits;
@@ -592,9 +1110,11 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
   static const uint32_t lds_pad = getenv("BROTLI_MI355X_LDS_PAD") ? (uint32_t)atoi(getenv("BROTLI_MI355X_LDS_PAD")) : 0u;  // occupancy experiments
   if (P.hasher_kind == 9) {
-    hipLaunchKernelGGL(k_parse_segments<true>, dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    hipLaunchKernelGGL((k_parse_segments<true, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+  } else if (B.rows) {
+    hipLaunchKernelGGL((k_parse_segments<false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else {
-    hipLaunchKernelGGL(k_parse_segments<false>, dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    hipLaunchKernelGGL((k_parse_segments<false, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   }
   HIP_CHECK(hipEventRecord(e1, BR_STREAM));
   HIP_CHECK(hipGetLastError());
@@ -625,7 +1145,7 @@ void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int
 // flag arrays in one streaming pass is far cheaper than having every chain read the old flag of each position.)
 __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next, uint32_t n,
                                                      const uint16_t* __restrict__ keys, uint32_t* __restrict__ changed_keys,
-                                                     uint32_t* __restrict__ changed_count, uint32_t cap) {
+                                                     uint32_t* __restrict__ changed_count, uint32_t cap, uint32_t emit_positions) {
   const uint32_t words = (n + 15) / 16;  // both arrays are padded by 64 bytes
   const uint32_t lane = threadIdx.x & 63u;
   // (the loop bound is wave-uniform: all lanes of a wave take part in the scan below)
@@ -657,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
     if (mine == 0 || idx >= cap) continue;
     for (uint32_t j = 0; j < 16; ++j) {
       if ((d[j >> 2] >> (8 * (j & 3))) & 1u) {
-        if (idx < cap) changed_keys[idx] = keys[wi * 16 + j];
+        if (idx < cap) changed_keys[idx] = emit_positions ? wi * 16 + j : (uint32_t)keys[wi * 16 + j];
         ++idx;
       }
     }
@@ -670,8 +1190,9 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
   if (n == 0) return;
   uint32_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  // with candidate rows the list holds the changed POSITIONS (consumed on the device by lz77_rows_update)
   hipLaunchKernelGGL(k_diff_flags, dim3(blocks), dim3(256), 0, BR_STREAM, B.flags[prev], B.flags[next], n, B.keys, B.changed_keys, B.changed_count,
-                     kChangedCap);
+                     B.rows ? B.changed_cap : kChangedCap, B.rows ? 1u : 0u);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -721,17 +1242,28 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
 }
 
 #if defined(BR_CHAIN_PROFILE)
-__device__ unsigned long long g_chain_prof[8];
+__device__ unsigned long long g_chain_prof[16];
 #endif
 
-void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {
+void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments, uint64_t* work) {
+  {
+    ParseTiming& ptw = parse_timing();
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (ptw.work_dev) {
+      HIP_CHECK(hipMemcpyAsync(h, ptw.work_dev, sizeof(h), hipMemcpyDeviceToHost, BR_STREAM));
+      HIP_CHECK(hipStreamSynchronize(BR_STREAM));
+      HIP_CHECK(hipMemsetAsync(ptw.work_dev, 0, sizeof(h), BR_STREAM));
+    }
+    if (work)
+      for (int i = 0; i < 3; ++i) work[i] = h[i];
+  }
 #if defined(BR_CHAIN_PROFILE)
   {
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_chain_prof), sizeof(h)));
-    fprintf(stderr, "chain profile: segments %llu total ticks %llu probe %llu (%llu calls) fold %llu (%llu calls) cmds %llu\n", h[5], h[0], h[1], h[3],
-            h[2], h[4], h[6]);
-    unsigned long long z[8] = {0};
+    fprintf(stderr, "chain profile: segments %llu total ticks %llu probe %llu (%llu calls; setup %llu, of which refill %llu in %llu refills) fold %llu (%llu calls) cmds %llu searches %llu\n",
+            h[5], h[0], h[1], h[3], h[7], h[8], h[9], h[2], h[4], h[6], h[10]);
+    unsigned long long z[16] = {0};
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_prof), z, sizeof(z)));
   }
 #endif

@@ -35,6 +35,13 @@ void Lz77Stage::Release() {
     dev_free(B_.sorted[0]);
     dev_free(B_.sorted[1]);
     dev_free(B_.key_base);
+    dev_free(B_.stag);
+    dev_free(B_.rows);
+    dev_free(B_.changed_slot);
+    dev_free(B_.row_ctl);
+    dev_free(B_.big_tile);
+    dev_free(B_.smask);
+    dev_free(B_.gprev);
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
     dev_free(B_.cmds);
@@ -93,12 +100,27 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.fbits = (uint8_t*)dev_alloc_uninit(M + 64);
   B_.key_first = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.key_last = (uint32_t*)dev_alloc((65536 + 1) * 4);
-  B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
   B_.changed_count = (uint32_t*)dev_alloc(64);
-  B_.info[0] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
-  B_.info[1] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
-  B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
-  B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
+  // Ring depth 16 (quality 5): position-indexed candidate rows (lz77_chain.h); deeper rings keep the rank structures.
+  use_rows_ = P_.hasher_kind != 9 && (1u << P_.block_bits) <= kRowEntries && getenv("BROTLI_MI355X_NO_ROWS") == nullptr;
+  if (use_rows_) {
+    B_.changed_cap = (uint32_t)std::max<size_t>(kChangedCap, M / 32);
+    B_.changed_keys = (uint32_t*)dev_alloc_uninit((size_t)B_.changed_cap * 4 + 64);
+    B_.changed_slot = (uint32_t*)dev_alloc_uninit((size_t)B_.changed_cap * 4 + 64);
+    B_.row_ctl = (uint32_t*)dev_alloc(64);
+    B_.big_tile = (uint8_t*)dev_alloc(M / 1024 + 128);
+    B_.smask = (unsigned long long*)dev_alloc_uninit((M / 64 + 2) * 8 + 64);
+    B_.gprev = (uint32_t*)dev_alloc_uninit((M / 64 + 2) * 4 + 64);
+    B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
+    B_.rows = (uint32_t*)dev_alloc_uninit(M * kRowEntries * 4 + 64);
+  } else {
+    B_.changed_cap = kChangedCap;
+    B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
+    B_.info[0] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
+    B_.info[1] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
+    B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
+    B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
+  }
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
   B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
@@ -724,7 +746,8 @@ void Lz77Stage::Run() {
   dev_d2h_async(key_first_.data(), B_.key_first, 65537 * 4);
   dev_d2h_async(key_last_.data(), B_.key_last, 65537 * 4);
   dev_sync();
-  tm.stop(&stats_.ms_sort);
+  has_big_keys_ = false;
+  for (uint32_t key = 0; key < 65536 && !has_big_keys_; ++key) has_big_keys_ = key_last_[key] - key_first_[key] >= 65536u;
   tm.stop(&stats_.ms_sort);
   RunRounds(true);
   tm.stop(&stats_.ms_resolve);
@@ -779,10 +802,16 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   int which = 0, rbuf = 0;
   {
     RankInitialHint hint{segments_[0].blk_start, block_bytes_, (carry_ && carry_->valid) ? 0u : 1u};
-    lz77_rank_flags(P_, B_, which, rbuf, &hint);
+    if (use_rows_) {
+      lz77_rows_init(P_, B_, which, &hint, has_big_keys_);
+    } else {
+      lz77_rank_flags(P_, B_, which, rbuf, &hint);
+    }
   }
   tm.stop(&stats_.ms_rank);
-  if (selftest) SelfTestRank(which, rbuf);
+  if (selftest) {
+    if (use_rows_) SelfTestRows(which); else SelfTestRank(which, rbuf);
+  }
   // ---- warm-up: a dry run over the tail of every segment gives a good first guess of the state in which the
   // parse leaves it (greedy parses re-synchronise quickly), so that the first full round already starts
   // almost every chain from its true entry.
@@ -851,7 +880,9 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   std::vector<uint8_t> entry_streak(nseg, 0), was_dirty, cand_dirty, pending(nseg, 0), sched(nseg, 0);
   for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
   uint32_t count = nseg;
-  const uint32_t max_rounds = nseg + 8;
+  // (every round fixes at least the first segment that was still wrong, so nseg rounds always suffice; the override
+  // makes an experiment that does not converge fail fast)
+  const uint32_t max_rounds = getenv("BROTLI_MI355X_MAX_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_MAX_ROUNDS")) : nseg + 8;
   bool done = false;
   bool restart = false;
   bool full_round = true;
@@ -891,12 +922,21 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     uint32_t n_changed = 0;
     dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
     dev_d2h_async(&n_changed, B_.changed_count, 4);
-    dev_d2h_async(changed_all.data(), B_.changed_keys, (size_t)kChangedCap * 4);
+    if (!use_rows_) dev_d2h_async(changed_all.data(), B_.changed_keys, (size_t)kChangedCap * 4);
     if (!full_round) {
       dev_d2h_async(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
       dev_d2h_async(sched.data(), dirty_dev, nseg);
     }
-    dev_sync();
+    if (use_rows_) {
+      // the rows are brought up to date on the device (it decides by itself between the incremental and the full
+      // rebuild) while the host chains the exits together: wait for the copies only
+      dev_mark();
+      dev_memset(dirty_dev, 0, nseg);
+      lz77_rows_update(P_, B_, which, which ^ 1, geo, dirty_dev, has_big_keys_);
+      dev_wait_mark();
+    } else {
+      dev_sync();
+    }
     if (!full_round) {
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
       uint32_t n_cont = 0, n_def0 = 0, n_def2 = 0;
@@ -916,7 +956,9 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
     // the rank structures are brought up to date on the device while the host chains the exits together
-    if (n_changed != 0) {
+    if (use_rows_) {
+      if (n_changed != 0) (n_changed <= B_.changed_cap ? stats_.incremental_ranks : stats_.full_ranks)++;
+    } else if (n_changed != 0) {
       // few changes: re-rank only the keys concerned, in place; otherwise rebuild everything into the other buffer
       // and diff the two
       std::vector<uint32_t> changed;
@@ -1059,8 +1101,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search did not reach a fixed point");
   final_flags_ = which;
   if (selftest) {
-    // the incrementally maintained rank structures must equal a rebuild from the final flags
-    SelfTestRank(which, rbuf);
+    // the incrementally maintained rank structures / rows must equal a rebuild from the final flags
+    if (use_rows_) SelfTestRows(which); else SelfTestRank(which, rbuf);
   }
   tm.stop(&stats_.ms_resolve);
   if (getenv("BROTLI_MI355X_DEBUG_EXITS"))
@@ -1127,6 +1169,62 @@ void Lz77Stage::SelfTestRank(int which, int rbuf) {
       if (sorted[first + local] != p) throw std::runtime_error("selftest: sorted mismatch at slot " + std::to_string(i));
       local++;
     }
+  }
+}
+
+// Candidate rows against a host recomputation from the flags (BROTLI_MI355X_SELFTEST=1): after the initial build and
+// after the last round, i.e. after every incremental update in between.
+void Lz77Stage::SelfTestRows(int which) {
+  const uint32_t n = P_.total_bytes;
+  std::vector<uint16_t> skeys(n);
+  std::vector<uint32_t> by_key(n), rows((size_t)n * kRowEntries);
+  std::vector<uint8_t> flags(n), fbits(n), text((size_t)n + 64, 0);
+  dev_sync();
+  dev_d2h(skeys.data(), B_.sorted_keys, (size_t)n * 2);
+  dev_d2h(by_key.data(), B_.by_key, (size_t)n * 4);
+  dev_d2h(rows.data(), B_.rows, (size_t)n * kRowEntries * 4);
+  dev_d2h(flags.data(), B_.flags[which], n);
+  dev_d2h(fbits.data(), B_.fbits, n);
+  dev_d2h(text.data(), B_.text, n);
+  auto tag = [&](uint32_t p) {
+    uint32_t v;
+    memcpy(&v, text.data() + p, 4);
+    return (uint32_t)((v * 0x9E3779B1u) >> 16);
+  };
+  const uint32_t depth = 1u << P_.block_bits;
+  uint32_t first = 0, stored_before = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t p = by_key[i];
+    if (i == 0 || skeys[i - 1] != skeys[i]) {
+      first = i;
+      stored_before = 0;
+    }
+    if ((fbits[i] & 1) != (flags[p] & 1)) throw std::runtime_error("selftest: fbits mismatch at slot " + std::to_string(i));
+    if (fbits[i] & 2) throw std::runtime_error("selftest: leftover change mark at slot " + std::to_string(i));
+    {
+      const bool big = key_last_[skeys[i]] - key_first_[skeys[i]] >= 65536u;
+      const bool want_wrap = big && stored_before != 0 && (stored_before & 0xffffu) == 0;
+      if (want_wrap != ((fbits[i] & 4) != 0)) throw std::runtime_error("selftest: wrap mark mismatch at slot " + std::to_string(i));
+    }
+    const uint32_t max_backward = std::min(p, P_.max_backward_limit);
+    const uint32_t d = std::min(depth, stored_before & 0xffffu);
+    std::vector<uint32_t> want;
+    uint32_t seen = 0;
+    for (uint32_t j = i; j > first && seen < d;) {
+      --j;
+      if (!(flags[by_key[j]] & 1)) continue;
+      if (p - by_key[j] > max_backward) break;
+      ++seen;
+      if (tag(by_key[j]) == tag(p)) want.push_back(by_key[j]);
+    }
+    for (size_t c = 0; c <= want.size() && c < kRowEntries; ++c) {
+      const uint32_t have = rows[(size_t)p * kRowEntries + c];
+      const uint32_t expect = c < want.size() ? want[c] : kRowEnd;
+      if (have != expect)
+        throw std::runtime_error("selftest: row of position " + std::to_string(p) + " entry " + std::to_string(c) + ": " + std::to_string(have) +
+                                 " instead of " + std::to_string(expect));
+    }
+    stored_before += flags[p] & 1;
   }
 }
 

@@ -104,6 +104,7 @@ class Lz77Stage {
   void Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, const std::vector<uint8_t>* only_after_dirty);
   void SelfTestSort();
   void SelfTestRank(int which, int rbuf);
+  void SelfTestRows(int which);
   void Release();
 
   EncoderParams params_;
@@ -170,6 +171,8 @@ class Lz77Stage {
   uint32_t dict_death_seg_ = 0xffffffffu;
   uint32_t dict_flips_ = 0;
   bool owns_buffers_ = false;
+  bool use_rows_ = false;      // quality 5: candidate rows instead of rank structures (device_api.h)
+  bool has_big_keys_ = false;  // some hash key owns >= 65 536 positions (the u16 ring counter of the reference wraps)
 };
 
 }  // namespace brotli_mi355x

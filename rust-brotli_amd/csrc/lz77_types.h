@@ -49,6 +49,10 @@ struct Lz77Params {
   uint32_t reserved;
 };
 
+// candidate rows (lz77_chain.h): entries per position, end-of-row marker
+static constexpr uint32_t kRowEntries = 16;
+static constexpr uint32_t kRowEnd = 0xffffffffu;
+
 enum SegmentFlags : uint32_t {
   kSegFirstInBlock = 1u,
   kSegLastInBlock = 2u,

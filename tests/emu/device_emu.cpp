@@ -14,6 +14,7 @@
 
 #include "../../rust-brotli_amd/csrc/device_api.h"
 #include "../../rust-brotli_amd/csrc/lz77_chain.h"
+#include "../../rust-brotli_amd/csrc/lz77_rows.h"
 #include "../../tables/brotli_tables.h"
 
 namespace brotli_mi355x {
@@ -37,6 +38,9 @@ void dev_d2h(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes)
 void dev_d2h_async(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 void dev_d2d(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
 void dev_sync() {}
+void dev_mark() {}
+void dev_wait_mark() {}
+size_t dev_trim_pool() { return 0; }
 const char* dev_name() { return "host-emulation"; }
 
 const DeviceTables& dev_tables() {
@@ -98,6 +102,7 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   for (uint32_t i = 0; i < n; ++i) {
     B.by_key[i] = idx[i];
     B.sorted_keys[i] = B.keys[idx[i]];
+    if (B.stag) B.stag[i] = (uint16_t)br_tag16(br_load32(B.text + idx[i]));
   }
   memset(B.key_first, 0, 65537 * 4);
   memset(B.key_last, 0, 65537 * 4);
@@ -187,6 +192,97 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   }
 }
 
+// ---- candidate rows: the same algorithm as the kernels of lz77_kernels.hip, one slot at a time ----
+static void emu_row_changed(const Lz77Buffers& B, int which, uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
+  if (p < geo.first_block_start) return;
+  if (B.flags[which][p] & kFlagSearched) {
+    emu_mark_dirty(p, geo, dirty);
+  } else {
+    const uint32_t k = emu_chain_in_front(p, geo);
+    if (k != 0xffffffffu) dirty[k] = 1;
+  }
+}
+
+static void emu_slot_masks(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes, groups = (n + 63) / 64;
+  uint32_t last = 0;
+  for (uint32_t g = 0; g < groups; ++g) {
+    unsigned long long m = 0;
+    for (uint32_t b = 0; b < 64 && g * 64 + b < n; ++b)
+      if (B.fbits[g * 64 + b] & 1u) m |= 1ull << b;
+    B.smask[g] = m;
+    B.gprev[g] = last;
+    if (m) last = g * 64 + 64 - (uint32_t)__builtin_clzll(m);
+  }
+}
+
+static void emu_build_all_rows(const Lz77Params& P, const Lz77Buffers& B, int which, bool validate, const SegGeometry* geo, uint8_t* dirty) {
+  const uint32_t n = P.total_bytes;
+  const uint32_t depth0 = 1u << P.block_bits;
+  SlotsInMemory sl{B.by_key, B.fbits, B.stag, B.smask, B.gprev};
+  uint32_t kf = 0, stored_before = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (i == 0 || B.sorted_keys[i - 1] != B.sorted_keys[i]) {
+      kf = i;
+      stored_before = 0;
+    }
+    const uint32_t key = B.sorted_keys[i];
+    uint32_t depth = depth0;
+    if (B.key_last[key] - kf >= 65536u) depth = std::min(depth, stored_before & 0xffffu);
+    if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, validate) && validate) emu_row_changed(B, which, B.by_key[i], *geo, dirty);
+    stored_before += B.fbits[i] & 1u;
+  }
+}
+
+void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const RankInitialHint*, bool) {
+  for (uint32_t i = 0; i < P.total_bytes; ++i) B.fbits[i] = B.flags[which][B.by_key[i]] & 1u;
+  emu_slot_masks(P, B);
+  emu_build_all_rows(P, B, which, false, nullptr, nullptr);
+}
+
+void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int next, const SegGeometry& geo, uint8_t* dirty, bool) {
+  (void)prev;
+  const uint32_t n = *B.changed_count, cap = B.changed_cap;
+  const uint32_t depth = 1u << P.block_bits;
+  // EMU_ROWS_FULL=1 forces the full rebuild (so that both paths get exercised by the CPU sweeps)
+  static const bool force_full = getenv("EMU_ROWS_FULL") != nullptr;
+  bool need_full = n > cap || force_full;
+  if (n > cap) {
+    for (uint32_t i = 0; i < P.total_bytes; ++i) B.fbits[i] = B.flags[next][B.by_key[i]] & 1u;
+  } else {
+    for (uint32_t c = 0; c < n; ++c) {
+      const uint32_t p = B.changed_keys[c];
+      const uint32_t key = B.keys[p];
+      uint32_t lo = B.key_first[key], hi = B.key_last[key];
+      if (hi - lo >= 65536u) need_full = true;
+      while (lo + 1 < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (B.by_key[mid] <= p) lo = mid; else hi = mid;
+      }
+      B.fbits[lo] = (uint8_t)((B.flags[next][p] & 1u) | 2u);
+      B.changed_slot[c] = lo;
+    }
+  }
+  emu_slot_masks(P, B);
+  if (!need_full) {
+    SlotsInMemory sl{B.by_key, B.fbits, B.stag, B.smask, B.gprev};
+    for (uint32_t c = 0; c < n; ++c) {
+      const uint32_t s = B.changed_slot[c];
+      const uint32_t key = B.keys[B.by_key[s]];
+      const uint32_t kf = B.key_first[key], kl = B.key_last[key];
+      uint32_t stable = 0;
+      for (uint32_t i = s + 1; i < kl && stable < depth; ++i) {
+        if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, true)) emu_row_changed(B, next, B.by_key[i], geo, dirty);
+        if ((B.fbits[i] & 3u) == 1u) ++stable;
+      }
+    }
+  } else {
+    emu_build_all_rows(P, B, next, true, &geo, dirty);
+  }
+  if (n <= cap)
+    for (uint32_t c = 0; c < n; ++c) B.fbits[B.changed_slot[c]] &= 1u;
+}
+
 static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, SegEntry* entries,
                       SegExit* exits, uint32_t first_segment, const uint32_t* list, uint8_t* sched, uint32_t count) {
   const DeviceTables& dt = dev_tables();
@@ -194,6 +290,8 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.text = B.text;
   T.info = B.info[rbuf];
   T.sorted = B.sorted[rbuf];
+  T.rows = B.rows;
+  T.work = nullptr;
   T.flags_next = B.flags[which ^ 1];
   T.cmds = B.cmds;
   T.dict_hash = dt.dict_hash;
@@ -202,14 +300,17 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
-  ChainScratchT<false> scratch;
-  ChainScratchT<true> scratch9;
+  ChainScratchT<false, false> scratch;
+  ChainScratchT<false, true> scratch_rows;
+  ChainScratchT<true, false> scratch9;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
     if (P.hasher_kind == 9) {
-      br_parse_chain<true>(P, T, scratch9, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+      br_parse_chain<true, false>(P, T, scratch9, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+    } else if (B.rows) {
+      br_parse_chain<false, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
     } else {
-      br_parse_chain<false>(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+      br_parse_chain<false, false>(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
     }
   }
 }
@@ -249,7 +350,8 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
   }
 }
 
-void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments) {
+void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments, uint64_t* work) {
+  if (work) work[0] = work[1] = work[2] = 0;
   *total_ms = 0;
   *launches = 0;
   *segments = 0;
@@ -293,7 +395,7 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
   uint32_t count = 0;
   for (uint32_t q = 0; q < P.total_bytes; ++q) {
     if ((B.flags[prev][q] ^ B.flags[next][q]) & 1) {
-      if (count < kChangedCap) B.changed_keys[count] = B.keys[q];
+      if (count < B.changed_cap) B.changed_keys[count] = B.rows ? q : (uint32_t)B.keys[q];
       count++;
     }
   }

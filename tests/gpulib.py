@@ -5,7 +5,7 @@ import os
 import emu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "rust-brotli_amd", "libbrotli_mi355x.so")
+LIB_PATH = os.environ.get("BROTLI_MI355X_LIB") or os.path.join(ROOT, "rust-brotli_amd", "libbrotli_mi355x.so")
 _lib = None
 
 

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, data, lgwin, out_path):
+def _worker(rank, world, port, data, lgwin, out_path, nshards=0, extra_params=()):
     import ctypes
     import importlib.util
     import torch.distributed as dist
@@ -45,9 +45,17 @@ def _worker(rank, world, port, data, lgwin, out_path):
     so = os.path.join(emu.EMU_DIR, "libbrotli_emu.so")
     library = mod.Library(so)
     enc = multi.ShardEncoder(ctypes.CDLL(so))
-    lo, start, end = multi.shard_window(len(data), rank, world, lgwin)
-    stream = multi.compress_sharded(dist, library, enc, [(Q, 5), (W, lgwin)], lgwin, data[lo:start], data[start:end], end - start,
-                                    False, rank, world, "cpu")
+    params = [(Q, 5), (W, lgwin)] + list(extra_params)
+    if nshards:
+        # more shards than ranks, dealt round-robin (bench.py's config 4 path): some ranks idle in the last round
+        def shard_input(s):
+            lo, start, end = multi.shard_window(len(data), s, nshards, lgwin)
+            return data[lo:start], data[start:end], end - start, False
+        stream = multi.compress_multi_over_ranks(dist, library, enc, params, len(data), nshards, rank, world, "cpu", shard_input)
+    else:
+        lo, start, end = multi.shard_window(len(data), rank, world, lgwin)
+        stream = multi.compress_sharded(dist, library, enc, params, lgwin, data[lo:start], data[start:end], end - start,
+                                        False, rank, world, "cpu")
     if rank == 0:
         with open(out_path, "wb") as f:
             f.write(stream)
@@ -66,3 +74,30 @@ def test_two_ranks_gloo(tmp_path, lgwin, size):
     got = open(out, "rb").read()
     assert got == orc.compress_multi(data, [(Q, 5), (W, lgwin)], 2)
     assert orc.decompress(got, len(data)) == data
+
+
+def test_four_ranks_five_uneven_shards(tmp_path):
+    """world_size 4, five shards of uneven size (the input length is not a multiple of 5) dealt round-robin: the second
+    round has one busy rank and three that contribute an empty payload to the gather"""
+    import torch.multiprocessing as mp
+    import emu
+    emu.build()
+    data = synth.mixed(1000003, seed=5)
+    out = str(tmp_path / "stream.br")
+    mp.spawn(_worker, args=(4, _free_port(), data, 22, out, 5), nprocs=4, join=True)
+    got = open(out, "rb").read()
+    assert got == orc.compress_multi(data, [(Q, 5), (W, 22)], 5)
+    assert orc.decompress(got, len(data)) == data
+
+
+def test_empty_shards_and_magic_number(tmp_path):
+    """an input shorter than the number of shards (empty shards), and BROTLI_PARAM_MAGIC_NUMBER: only the first shard
+    carries the magic block (compress_part clears it for the others, threading/mod.rs:354-357)"""
+    import torch.multiprocessing as mp
+    import emu
+    emu.build()
+    for data, nshards, extra in ((b"abc", 4, ()), (synth.markov_text(300000, 9), 3, ((169, 1),))):
+        out = str(tmp_path / "stream.br")
+        mp.spawn(_worker, args=(2, _free_port(), data, 22, out, nshards, extra), nprocs=2, join=True)
+        got = open(out, "rb").read()
+        assert got == orc.compress_multi(data, [(Q, 5), (W, 22)] + list(extra), nshards)
