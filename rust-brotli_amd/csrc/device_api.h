@@ -66,12 +66,13 @@ struct Lz77Buffers {
   uint32_t* key_first;  // per key: first / one-past-last slot in (key,pos) order  [65536 + 1] each
   uint32_t* key_last;
   uint32_t* changed_keys;  // keys whose stored flags changed in the last parse launch(es) [kChangedCap]
-  uint32_t* changed_count; // [1]
+  uint32_t* changed_count; // [1]; word 8: sampled count of run starts (lz77_compute_keys)
   // candidate rows (ring depth <= 16, i.e. quality 5; null otherwise -- then info / sorted are used instead)
   uint16_t* stag;       // br_tag16 of by_key[i]                           [total_bytes]
   uint32_t* rows;       // per position kRowEntries candidates             [16 * total_bytes]
   uint32_t* changed_slot;  // slot of every changed position                [changed_cap]
   uint32_t* row_ctl;    // device-side control words of lz77_rows_update    [4]
+  uint32_t* run_end;    // optional run table (lz77_run_table), null when the input has no long runs  [total_bytes]
   unsigned long long* smask;  // stored bits of the slots, one word per 64 slots      [total_bytes / 64 + 2]
   uint32_t* gprev;      // per 64 slots: 1 + last stored slot in front of them           [total_bytes / 64 + 2]
   uint8_t* big_tile;    // per 1024 slots: holds slots of a key with >= 65 536 slots  [total_bytes / 1024 + 64]
@@ -87,8 +88,11 @@ struct Lz77Buffers {
 
 size_t lz77_sort_tmp_bytes(uint32_t total_bytes);
 
-// hash key of every position (mod.rs:990-992 H5, :1138-1140 H6)
+// hash key of every position (mod.rs:990-992 H5, :1138-1140 H6); also samples how much of the input lies in runs of one
+// byte (B.changed_count[8])
 void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B);
+// run_end[p] for every position (see ChainTables::run_end); needs B.run_end allocated
+void lz77_run_table(const Lz77Params& P, const Lz77Buffers& B);
 // first guess of the stored flags (both buffers): prefix positions, stitch positions and block tails are
 // static, everything else is assumed stored
 // (prefix_flags_host: optional stored flags of the first prefix_flags_bytes positions, for the continuation of a

@@ -71,6 +71,10 @@ struct ChainTables {
   // measurement (bench.py roofline): per launch-set totals of what the chains actually did -- [0] positions walked,
   // [1] searches, [2] commands written.  Null in the host emulation.
   unsigned long long* work;
+  // optional (inputs with long runs of one byte, e.g. zero fill): run_end[p] = first position behind p whose byte differs
+  // from text[p].  Lets the match-length code jump over a run instead of comparing it 32 bytes at a time for every one
+  // of the ~20 candidates of a position (all of which match to the end of the block inside a run).
+  const uint32_t* run_end;
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -354,12 +358,16 @@ extern __device__ unsigned long long g_chain_prof[16];
 #endif
 
 #if defined(BROTLI_HOST_EMU)
-BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit) { return br_match_len(a, b, limit); }
+BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit, const uint32_t* = nullptr, uint32_t = 0, uint32_t = 0) {
+  return br_match_len(a, b, limit);
+}
 #else
 // Common prefix of a and b, at most `limit`: the first 32 bytes of both sides are fetched in one go (four independent
 // 16-byte loads, one memory round trip; both buffers are padded so reading past `limit` is harmless), only longer
 // matches fall back to the 8-byte loop.
-BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit) {
+// run_end / a_pos / b_pos: optional run table and the text positions of a and b (see ChainTables::run_end)
+BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit, const uint32_t* run_end = nullptr, uint32_t a_pos = 0,
+                                  uint32_t b_pos = 0) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2), aligned(1)));
   const u64x2 a0 = *(const u64x2*)a, a1 = *(const u64x2*)(a + 16);
   const u64x2 b0 = *(const u64x2*)b, b1 = *(const u64x2*)(b + 16);
@@ -373,6 +381,20 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
   if (n >= 32 && limit > 32) {
     // long matches (runs, repeats): 32 bytes per trip while they last, then the 8-byte loop for the remainder
     uint32_t i = 32;
+    if (run_end != nullptr) {
+      // both sides start with 32 equal bytes; if those are one and the same byte, both sit in runs of it: the shorter
+      // run ends the match, and only when they end together does the comparison go on behind them
+      const unsigned long long pat = (a0.x & 0xffull) * 0x0101010101010101ull;
+      if (a0.x == pat && a0.y == pat && a1.x == pat && a1.y == pat) {
+        const uint32_t ra = run_end[a_pos] - a_pos, rb = run_end[b_pos] - b_pos;
+        if (ra != rb) {
+          const uint32_t r = ra < rb ? ra : rb;
+          return r < limit ? r : limit;
+        }
+        if (ra >= limit) return limit;
+        i = ra;
+      }
+    }
     while (i + 32 <= limit) {
       const u64x2 c0 = *(const u64x2*)(a + i), c1 = *(const u64x2*)(a + i + 16);
       const u64x2 d0 = *(const u64x2*)(b + i), d1 = *(const u64x2*)(b + i + 16);
@@ -457,7 +479,7 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
 #if defined(BR_CHAIN_PROFILE)
   m.t_setup += BR_TICK() - tp0;
 #endif
-  m.r_len = src ? br_match_len_wide(src, cur_data, limit) : 0u;
+  m.r_len = src ? br_match_len_wide(src, cur_data, limit, is_dict ? nullptr : t.run_end, prev, cur) : 0u;
   m.r_prev = prev;
 }
 #endif
@@ -589,7 +611,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     }
     if (!is_dict && prev != 0xffffffffu) src = t.text + prev;
     // step 2 (second round trip): measure the common prefix
-    const uint32_t len = src ? br_match_len_wide(src, cur_data, limit) : 0u;
+    const uint32_t len = src ? br_match_len_wide(src, cur_data, limit, is_dict ? nullptr : t.run_end, prev, cur) : 0u;
     s.cand_prev[w][c] = prev;
     s.cand_len[w][c] = len;
   }

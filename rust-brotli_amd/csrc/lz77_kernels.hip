@@ -28,12 +28,19 @@ void hip_check(hipError_t e, const char* what) {
 // ------------------------------------------------------------------------------------------ keys
 __global__ __launch_bounds__(256) void k_compute_keys(const uint8_t* __restrict__ text, uint16_t* __restrict__ keys,
                                                       uint32_t n, uint32_t valid_n, uint32_t kind, uint32_t bucket_bits,
-                                                      uint64_t hash_mask) {
+                                                      uint64_t hash_mask, uint32_t* __restrict__ run_samples) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     uint32_t key = 0xffffu;
     if (i < valid_n) {
+      // sample (every 64th position): does a run of one byte start here?  Enough of those switch on the run table.
+      if ((i & 63u) == 0 && i + 16 <= n) {
+        const uint64_t v = br_load64(text + i);
+        // (the count only matters up to the threshold the host compares it with: no need to hammer one address)
+        if (v == (v & 0xffull) * 0x0101010101010101ull && br_load64(text + i + 8) == v && *(volatile uint32_t*)run_samples < 4096u)
+          atomicAdd(run_samples, 1u);
+      }
       if (kind == 6) {
         const uint64_t v = (br_load64(text + i) & hash_mask) * 0x1fe35a7bd3579bd3ull;
         key = (uint32_t)(v >> (64 - bucket_bits));
@@ -53,8 +60,9 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   if (n == 0) return;
   uint32_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  HIP_CHECK(hipMemsetAsync(B.changed_count + 8, 0, 4, BR_STREAM));
   hipLaunchKernelGGL(k_compute_keys, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, B.keys, n, valid_n, P.hasher_kind, P.bucket_bits,
-                     hash_mask);
+                     hash_mask, B.changed_count + 8);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -571,6 +579,7 @@ __device__ __forceinline__ void row_changed(const RowArgs& a, uint32_t p) {
 // entries (no skipping of unstored slots, at most `depth` steps); every wave stages the rows of 64 slots in LDS and
 // writes them out as whole 64-byte lines.
 static constexpr uint32_t kRowTile = kScanTile, kRowHalo = 256, kRowSpan = kRowTile + kRowHalo;
+static constexpr uint32_t kMaxRowWalk = 2048;  // slots one change may walk in k_update_rows before the full rebuild takes over
 static_assert(kRowSpan == 256 * 5, "five span entries per thread");
 
 __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
@@ -654,12 +663,12 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
         if (ent.x >> 31) break;
       }
       if (slow) {
-        if (br_build_row(sl, a.rows, a.max_backward_limit, lo + e, a.key_first[key], a.depth, a.validate != 0) && a.validate) row_changed(a, p);
+        br_collect_row(sl, a.max_backward_limit, lo + e, a.key_first[key], a.depth, out);
       } else {
         for (; n < kRowEntries; ++n) out[n] = kRowEnd;
       }
     }
-    s_slow[w][lane] = (!valid || slow) ? 1 : 0;
+    s_slow[w][lane] = valid ? 0 : 1;
     __syncthreads();
     // the 64 rows of this wave go out as 256 pieces of 16 bytes: four lanes write one 64-byte line
     for (uint32_t it = 0; it < 4; ++it) {
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
                                                       uint32_t cap, const uint16_t* __restrict__ keys, const uint32_t* __restrict__ key_first,
                                                       const uint32_t* __restrict__ key_last, const uint32_t* __restrict__ by_key,
                                                       const uint8_t* __restrict__ flags_new, uint8_t* __restrict__ fbits,
-                                                      uint32_t* __restrict__ changed_slot, uint32_t* __restrict__ ctl) {
+                                                      uint32_t* __restrict__ changed_slot, uint32_t* __restrict__ ctl, uint32_t total_slots) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = *changed_count;
   if (n > cap) {
@@ -801,6 +810,8 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
     return;
   }
   if (i >= n) return;
+  // many changes: one pass over all rows is cheaper than a walk per change
+  if (i == 0 && n > total_slots / 256) atomicMax(&ctl[kCtlNeedFull], 1u);
   const uint32_t p = changed_pos[i];
   const uint32_t key = keys[p];
   uint32_t lo = key_first[key], hi = key_last[key];
@@ -824,7 +835,7 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
     // A change in front of a long stretch of unstored slots reaches every row of the stretch, and several such changes
     // walk the same stretch again and again: when the walks add up to a good part of all rows, the full rebuild behind
     // this kernel is the cheaper way (what was updated here has been checked and marked already).
-    if (a.walk_counter[kCtlWalked] > a.n / 4) {
+    if (a.walk_counter[kCtlWalked] > a.n / 16 || *(volatile const uint32_t*)&a.ctl[kCtlNeedFull] != 0) {
       if (threadIdx.x == 0) atomicMax(&a.walk_counter[kCtlNeedFull], 1u);
       return;
     }
@@ -834,6 +845,12 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
     uint32_t stable = 0;
     // (slot s itself is rebuilt as well: its own row changes when its wrap mark does)
     for (uint32_t base = s; base < kl && stable < a.depth; base += 64) {
+      if (base - s >= kMaxRowWalk) {
+        // a stretch of unstored slots (e.g. an extended copy through zero fill): every row of it changes, and every
+        // change in front of it would walk it again -- leave it to the full rebuild
+        if (threadIdx.x == 0) atomicMax(&a.walk_counter[kCtlNeedFull], 1u);
+        return;
+      }
       const uint32_t i = base + threadIdx.x;
       const bool in = i < kl;
       const bool st = in && i != s && (a.fbits[i] & (kSlotStored | kSlotChanged)) == kSlotStored;
@@ -1010,7 +1027,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   // (B.changed_keys holds POSITIONS here, B.changed_count their number -- see lz77_diff_flags)
   const uint32_t flip_blocks = (cap + 255) / 256;
   hipLaunchKernelGGL(k_apply_flips, dim3(flip_blocks), dim3(256), 0, BR_STREAM, B.changed_keys, B.changed_count, cap, B.keys, B.key_first,
-                     B.key_last, B.by_key, B.flags[next], B.fbits, B.changed_slot, B.row_ctl);
+                     B.key_last, B.by_key, B.flags[next], B.fbits, B.changed_slot, B.row_ctl, n);
   uint32_t gather_blocks = (n + 255) / 256;
   if (gather_blocks > 8192) gather_blocks = 8192;
   hipLaunchKernelGGL(k_regather_fbits, dim3(gather_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.flags[next], n, B.fbits, B.row_ctl);
@@ -1024,6 +1041,43 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
                      cap, B.fbits);
   HIP_CHECK(hipGetLastError());
   (void)prev;
+}
+
+// ------------------------------------------------------------------------------------------ run table
+// run_end[p] = first position behind p whose byte differs from text[p] (ChainTables::run_end): a maximum scan over the
+// positions in REVERSE order (j = n - 1 - p) of "a run ends here".
+__global__ __launch_bounds__(256) void k_run_marks(const uint8_t* __restrict__ text, uint32_t n, uint32_t* __restrict__ marks) {
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const uint32_t p = n - 1 - j;
+    marks[j] = (p + 1 >= n || text[p + 1] != text[p]) ? j + 1 : 0u;
+  }
+}
+__global__ __launch_bounds__(256) void k_run_finish(const uint8_t* __restrict__ text, uint32_t n, uint32_t* __restrict__ data) {
+  // data[j] = exclusive prefix maximum of the marks; position p <-> j = n - 1 - p: every thread turns one pair around
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < (n + 1) / 2; p += gridDim.x * blockDim.x) {
+    const uint32_t q = n - 1 - p;
+    auto end_of = [&](uint32_t pos, uint32_t excl) {
+      const uint32_t j = n - 1 - pos;
+      const uint32_t own = (pos + 1 >= n || text[pos + 1] != text[pos]) ? j + 1 : 0u;
+      const uint32_t m = excl > own ? excl : own;  // 1 + reversed index of the last position of the run
+      return n - m + 1;
+    };
+    const uint32_t xp = data[n - 1 - p], xq = data[n - 1 - q];
+    const uint32_t ep = end_of(p, xp), eq = end_of(q, xq);
+    data[p] = ep;
+    if (q != p) data[q] = eq;
+  }
+}
+
+void lz77_run_table(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0 || !B.run_end) return;
+  uint32_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_run_marks, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, n, B.run_end);
+  exclusive_maxscan_u32(B.run_end, n, (uint32_t*)B.sort_tmp);
+  hipLaunchKernelGGL(k_run_finish, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, n, B.run_end);
+  HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------ parse
@@ -1074,6 +1128,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.info = B.info[rbuf];
   a.T.sorted = B.sorted[rbuf];
   a.T.rows = B.rows;
+  a.T.run_end = B.run_end;
   a.T.flags_next = B.flags[flags_out];
   a.T.cmds = B.cmds;
   a.T.dict_hash = dt.dict_hash;

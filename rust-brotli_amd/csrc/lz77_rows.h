@@ -41,19 +41,15 @@ struct SlotsInMemory {
 // WITH the nearest stored slot that has bit 2 (the first insertion after the wrap).
 static constexpr uint32_t kSlotStored = 1, kSlotChanged = 2, kSlotWrap = 4;
 
-// Writes the row of slot i, whose key owns the slots from kf on: the (up to) `depth` nearest stored slots in front of
-// it -- what the bucket ring of the reference holds when the position is searched (AdvHasher::FindLongestMatch,
-// mod.rs:1744-1793) -- cut where the bucket walk breaks (backward > max_backward, :1769-1776), without the entries
-// whose tag differs (FindMatchLengthWithLimitMin4 returns 0 for them, static_dict.rs:134-147); the rest of the row is
-// filled with kRowEnd.  compare: only differing words are written; returns whether the row in memory changed.
+// The row of slot i, whose key owns the slots from kf on: the (up to) `depth` nearest stored slots in front of it -- what
+// the bucket ring of the reference holds when the position is searched (AdvHasher::FindLongestMatch, mod.rs:1744-1793)
+// -- cut where the bucket walk breaks (backward > max_backward, :1769-1776), without the entries whose tag differs
+// (FindMatchLengthWithLimitMin4 returns 0 for them, static_dict.rs:134-147); the rest of the row is kRowEnd.
 template <typename Slots>
-BR_DEV bool br_build_row(const Slots& sl, uint32_t* rows, uint32_t max_backward_limit, uint32_t i, uint32_t kf, uint32_t depth,
-                         bool compare) {
+BR_DEV void br_collect_row(const Slots& sl, uint32_t max_backward_limit, uint32_t i, uint32_t kf, uint32_t depth, uint32_t* out) {
   const uint32_t p = sl.pos(i), tag = sl.tag(i);
   const uint32_t max_backward = p < max_backward_limit ? p : max_backward_limit;
-  uint32_t* row = rows + (size_t)p * kRowEntries;
   uint32_t n = 0, seen = 0;
-  bool changed = false;
   if (sl.fb(i) & kSlotWrap) depth = 0;
   for (uint32_t j = i; seen < depth;) {
     const uint32_t nj = sl.prev_stored(j);
@@ -63,19 +59,24 @@ BR_DEV bool br_build_row(const Slots& sl, uint32_t* rows, uint32_t max_backward_
     const uint32_t q = sl.pos(j);
     if (p - q > max_backward) break;
     ++seen;
-    if (sl.tag(j) == tag) {
-      if (!compare || row[n] != q) {
-        changed = true;
-        row[n] = q;
-      }
-      ++n;
-    }
+    if (sl.tag(j) == tag) out[n++] = q;
     if (fb & kSlotWrap) break;
   }
-  for (; n < kRowEntries; ++n) {
-    if (!compare || row[n] != kRowEnd) {
+  for (; n < kRowEntries; ++n) out[n] = kRowEnd;
+}
+
+// Writes the row of slot i to rows[].  compare: only differing words are written; returns whether the row in memory changed.
+template <typename Slots>
+BR_DEV bool br_build_row(const Slots& sl, uint32_t* rows, uint32_t max_backward_limit, uint32_t i, uint32_t kf, uint32_t depth,
+                         bool compare) {
+  uint32_t fresh[kRowEntries];
+  br_collect_row(sl, max_backward_limit, i, kf, depth, fresh);
+  uint32_t* row = rows + (size_t)sl.pos(i) * kRowEntries;
+  bool changed = false;
+  for (uint32_t n = 0; n < kRowEntries; ++n) {
+    if (!compare || row[n] != fresh[n]) {
       changed = true;
-      row[n] = kRowEnd;
+      row[n] = fresh[n];
     }
   }
   return changed;

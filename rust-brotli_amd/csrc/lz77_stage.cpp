@@ -40,6 +40,7 @@ void Lz77Stage::Release() {
     dev_free(B_.changed_slot);
     dev_free(B_.row_ctl);
     dev_free(B_.big_tile);
+    dev_free(B_.run_end);
     dev_free(B_.smask);
     dev_free(B_.gprev);
     dev_free(B_.flags[0]);
@@ -657,7 +658,9 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
       // Resolve(), on the dry run's last command.  A wrong guess is caught there.
       const SegExit& x = wexits[i];
       e.ext_allowed = 0;
-      if (x.n_cmds > 0 && x.insert_len == 0) {
+      // (the dry run is not told that its segment ends the block, so it does not add the unsearched tail of the block to
+      // its pending literals: only a copy that reaches the very end of the block leaves nothing pending)
+      if (x.n_cmds > 0 && x.insert_len == 0 && x.pos >= segments_[ks[i]].blk_end) {
         const uint64_t cmd_dist = (uint64_t)(int64_t)x.cache[0];
         if (x.last_dist_code < 16 || (uint64_t)x.last_dist_code - 15 == cmd_dist) {
           const uint64_t lpp = (uint64_t)segments_[ks[i] + 1].blk_start - x.last_copy_len;
@@ -745,7 +748,31 @@ void Lz77Stage::Run() {
   key_last_.resize(65537);
   dev_d2h_async(key_first_.data(), B_.key_first, 65537 * 4);
   dev_d2h_async(key_last_.data(), B_.key_last, 65537 * 4);
+  uint32_t run_samples = 0;
+  dev_d2h_async(&run_samples, B_.changed_count + 8, 4);
   dev_sync();
+  // long runs of one byte (zero fill ...): every candidate of every position inside a run matches to the end of the
+  // block; the run table lets the chains jump over a run instead of comparing it 32 bytes at a time (lz77_chain.h).
+  // One sample in 64 positions: 64 samples ~ 4 KiB of runs.
+  if (run_samples >= 64 && getenv("BROTLI_MI355X_NO_RUN_TABLE") == nullptr) {
+    if (!B_.run_end) B_.run_end = (uint32_t*)dev_alloc_uninit((size_t)P_.total_bytes * 4 + 64);
+    lz77_run_table(P_, B_);
+    if (getenv("BROTLI_MI355X_SELFTEST")) {
+      const uint32_t n = P_.total_bytes;
+      std::vector<uint32_t> got(n);
+      std::vector<uint8_t> text(n);
+      dev_d2h(got.data(), B_.run_end, (size_t)n * 4);
+      dev_d2h(text.data(), B_.text, n);
+      uint32_t end = n;
+      for (uint32_t p = n; p-- > 0;) {
+        if (!(p + 1 < n && text[p + 1] == text[p])) end = p + 1;
+        if (got[p] != end) throw std::runtime_error("selftest: run table wrong at position " + std::to_string(p));
+      }
+    }
+  } else if (B_.run_end) {
+    dev_free(B_.run_end);
+    B_.run_end = nullptr;
+  }
   has_big_keys_ = false;
   for (uint32_t key = 0; key < 65536 && !has_big_keys_; ++key) has_big_keys_ = key_last_[key] - key_first_[key] >= 65536u;
   tm.stop(&stats_.ms_sort);

@@ -73,6 +73,13 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
     }
     B.keys[i] = (uint16_t)key;
   }
+  B.changed_count[8] = 0;  // (the emulation never asks for the run table: its match-length code has no use for it)
+}
+
+void lz77_run_table(const Lz77Params& P, const Lz77Buffers& B) {
+  const uint32_t n = P.total_bytes;
+  if (!B.run_end) return;
+  for (uint32_t p = n; p-- > 0;) B.run_end[p] = (p + 1 < n && B.text[p + 1] == B.text[p]) ? B.run_end[p + 1] : p + 1;
 }
 
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
@@ -291,6 +298,7 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.info = B.info[rbuf];
   T.sorted = B.sorted[rbuf];
   T.rows = B.rows;
+  T.run_end = nullptr;
   T.work = nullptr;
   T.flags_next = B.flags[which ^ 1];
   T.cmds = B.cmds;
