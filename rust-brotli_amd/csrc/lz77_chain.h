@@ -844,7 +844,13 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     const bool dead = ds.matches < (ds.lookups >> 7);
     const uint32_t seen = dead ? 2u : 1u;
     ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
-    if (m.no_dict) return out;  // switched off for good under exact counters: nobody needs the virtual bookkeeping
+    if (m.no_dict) {
+      // switched off for good under the exact counters of this round: no probes, no virtual bookkeeping.  Should a later
+      // pass of the resolver find the dictionary still alive here (something changed upstream), this parse says
+      // nothing about what a live dictionary would have done: mode 4 = "ran blind", valid only while the dictionary is off.
+      ds.mode = 4;
+      return out;
+    }
     if (dead && ds.vwould) return out;
     if (dead) {
       if ((int32_t)ds.vlookups > ds.vmaxdef) ds.vmaxdef = (int32_t)ds.vlookups;
@@ -1300,7 +1306,9 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
       const bool no_match = exits[k + 1].dict_matches == old.dict_matches;  // none used (mode 1) / none possible (mode 2)
       const bool stays_alive = 128ll * (long long)next.dict_matches - (long long)next.dict_lookups + 127 >= (long long)maxdef;
       if (mode != 0) {
-        if (dead) {
+        if (mode == 4) {
+          same = dead;  // parsed blind: only good for a dictionary that is off
+        } else if (dead) {
           same = mode == 2 || (mode == 1 && no_match);
         } else if (old.dict_lookups == next.dict_lookups && old.dict_matches == next.dict_matches) {
           same = true;

@@ -248,7 +248,7 @@ struct DictTracker {
     }
     const bool no_match = x.dict_matches == used.dict_matches;
     if (state == kDead || state == kUnknown) {
-      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || (x.dict_mode == 1 && no_match);
+      const bool ok = x.dict_mode == 0 || x.dict_mode == 2 || x.dict_mode == 4 || (x.dict_mode == 1 && no_match);
       if (!ok) flips++;
       return ok;
     }
@@ -258,6 +258,11 @@ struct DictTracker {
     State next = state;
     switch (x.dict_mode) {
       case 0:
+        break;
+      case 4:  // parsed blind under an "off" that does not hold here (any more): redo it with the books open
+        ok = false;
+        next = kFuzzy;
+        slack += kSlackPerChain;
         break;
       case 1:  // found the dictionary on at every consult under the counters it was given
         if (exact || stays_alive) {

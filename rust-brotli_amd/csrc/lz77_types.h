@@ -115,7 +115,8 @@ struct SegExit {
                             // reference cannot encode them (GetCopyLengthCode, command.rs:91-93) and fails
   uint32_t n_searches;
   uint32_t last_copy_len;   // copy_len of last emitted command (low 25 bits)
-  uint32_t dict_mode;       // 0 no consult, 1 alive at every consult, 2 dead at every consult, 3 mixed
+  uint32_t dict_mode;       // 0 no consult, 1 alive at every consult, 2 dead at every consult, 3 mixed,
+                            // 4 ran without the dictionary and without the books (exact "off" at the entry)
   int32_t dict_maxdef;      // mode 1: max over consults of (local lookups - 128 * local matches)
   uint32_t n_pushes;        // number of dist-cache pushes in this segment, saturated at 4
   uint32_t tail_kind, tail_base, tail_p1;  // the step that carried the parse past the segment end (-> next entry's head_*)

@@ -125,3 +125,14 @@ def test_lazy_probe_across_a_segment_boundary(L):
     d = open(os.path.join(GOLDEN, "lazy_probe_across_segments.bin"), "rb").read()
     assert check("lazy probe", d, 5, 22, seg=256, lib=L)
     assert check("lazy probe", d, 5, 22, seg=512, lib=L)
+
+
+def test_dictionary_still_alive_where_a_chain_ran_blind(L):
+    """Found by the device sweep (fuzz_gpu.py 200 6, case 69): chains entered with exact "dictionary off" counters skip
+    the dictionary probes and the virtual bookkeeping (mode 4).  When a later pass of the resolver moves the point where
+    the throttle trips further down the stream, such a parse says nothing about what a live dictionary would have
+    found and has to be redone; taking it for a "no dictionary match possible" parse gave a stream 423 bytes short."""
+    pool = synth.silesia_like(6 << 20, 79, min_segment=8 << 10, max_segment=256 << 10)
+    data = pool[1146783:1146783 + 2328561]
+    out, _ = emu.encode_stream(L, data, [(Q, 9), (W, 17), (SH, len(data))], segment_bytes=4096)
+    assert out == orc.compress(data, 9, 17)
