@@ -11,13 +11,23 @@
  * parameters outside the accelerated set, or on a machine without a usable gfx950 device, fail
  * (BROTLI_FALSE / 0 / NULL) and print the reason on stderr.
  *
- * Streaming: input handed over with BROTLI_OPERATION_PROCESS is buffered (the encoder owns a copy, as the
- * reference's ring buffer does); output is produced at BROTLI_OPERATION_FLUSH (everything handed over so far,
- * byte-identical to what the reference emits for the same flush points, encode.rs:2940-2975 + 1541-1566) and at
- * BROTLI_OPERATION_FINISH.  A flushed stream keeps its whole input on the host and re-indexes it at every flush
- * (cost proportional to the stream so far; at most 1 GiB), and cannot be combined with a custom dictionary or the
- * catable / appendable modes.  BROTLI_OPERATION_EMIT_METADATA (encode.rs:2579-2685) flushes pending input the same
- * way and writes the payload (<= 16 MiB) as a metadata block.
+ * Streaming (bounded memory): input handed over with BROTLI_OPERATION_PROCESS is copied into the encoder (as the
+ * reference copies it into its ring buffer).  Where the reference runs encode_data whenever a 64 KiB input block is
+ * full (encode.rs:2959-2964), this encoder waits until a batch has piled up (64 MiB; BROTLI_MI355X_STREAM_BATCH bytes),
+ * then encodes the meta-blocks that the reference's flush rule (encode.rs:2454-2477) closes within the whole blocks
+ * received so far and makes their bytes available at once: BrotliEncoderHasMoreOutput() becomes true in the middle of a
+ * stream, before any FLUSH / FINISH.  Of what has been encoded only a window is kept as the LZ77 prefix of the next
+ * piece (one to two ring-buffer sizes, 8..16 MiB at lgwin 22), together with the state the reference carries: distance
+ * cache, static-dictionary throttle counters, which window positions are in the hash table, the per-key insertion
+ * counters, the open last byte of the output.  Memory is therefore bounded by window + batch however long the stream;
+ * the bytes are those of the reference's stream encoder fed with the same writes (tests/test_streaming.py).
+ * BROTLI_OPERATION_FLUSH encodes everything received so far (byte-identical to the reference's flush,
+ * encode.rs:2940-2975 + 1541-1566) at a cost proportional to window + new input; BROTLI_OPERATION_EMIT_METADATA
+ * (encode.rs:2579-2685) flushes pending input the same way and writes the payload (<= 16 MiB) as a metadata block.
+ * Limits: one stream may be up to 3 GiB long (the reference's hasher reset at its 3 GiB position wrap,
+ * encode.rs:1623-1631, is not reproduced yet: longer streams are refused, not mis-encoded); streams with a custom
+ * dictionary or in the catable / appendable modes are buffered whole until BROTLI_OPERATION_FINISH (at most 2 GiB) and
+ * cannot be flushed.  All input offered to a call is always consumed (*available_in becomes 0).
  */
 #ifndef BROTLI_MI355X_H_
 #define BROTLI_MI355X_H_

@@ -49,10 +49,12 @@ struct BrotliEncoderStateStruct {
   size_t output_pos;
   uint64_t total_out;
   uint64_t total_in;
-  // BROTLI_OPERATION_FLUSH: `input` keeps the whole stream, [0, encoded_upto) of it is already in the output
+  // `input` = the window of the stream so far that the next piece needs as its LZ77 prefix ([0, encoded_upto), already in
+  // the output) followed by the input that has not been encoded yet.  Older bytes are dropped (bounded memory).
   size_t encoded_upto;
   StreamCarry carry;
   bool metadata_draining;  // an EMIT_METADATA operation whose output has not been fully taken yet
+  size_t next_batch_try;   // PROCESS: do not try another partial piece before this much input is pending
 };
 
 struct BrotliEncoderWorkPoolStruct {
@@ -74,16 +76,39 @@ size_t BlockSize(const EncoderParams& user) {
   return (size_t)1 << p.lgblock;
 }
 
-// Runs the device encoder over everything buffered since the last flush (FLUSH: finish = false, FINISH: true).
-bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = false, size_t metadata_size = 0) {
+// How much input BROTLI_OPERATION_PROCESS lets pile up before it encodes a piece of the stream on its own (the device wants
+// big pieces; the reference encodes whenever a 64 KiB block is full, encode.rs:2959-2964).
+size_t StreamBatchBytes() {
+  static const size_t v = getenv("BROTLI_MI355X_STREAM_BATCH") ? (size_t)strtoull(getenv("BROTLI_MI355X_STREAM_BATCH"), nullptr, 10) : ((size_t)64 << 20);
+  return v;
+}
+
+// Streams that can be encoded piece by piece without a flush: no custom dictionary, not catable / appendable (their
+// pieces would need the dictionary-end rule and the raw head carried along; such streams are buffered until FINISH).
+bool Streamable(const BrotliEncoderState* s) { return !s->has_dictionary && !s->params.catable && !s->params.appendable; }
+
+// Runs the device encoder over the input buffered since the last piece.  FLUSH: finish = false, FINISH: finish = true;
+// partial (PROCESS): only the meta-blocks that close by themselves within the whole input blocks buffered so far.
+bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = false, size_t metadata_size = 0, bool partial = false,
+                    bool last_block_processed_early = false) {
   try {
     EncodeRequest req;
     req.params = s->params;
+    req.last_block_processed_early = last_block_processed_early;
     req.input = s->input.data() + s->encoded_upto;
     req.input_size = s->input.size() - s->encoded_upto;
+    if (partial) {
+      const size_t block = BlockSize(s->params);
+      req.input_size = req.input_size / block * block;
+      if (req.input_size == 0) return true;
+    }
     req.finish = finish;
+    req.partial = partial;
     req.emit_metadata = emit_metadata;
     req.metadata_size = metadata_size;
+    size_t consumed = req.input_size, keep_from = 0;
+    req.consumed_out = &consumed;
+    req.keep_from_out = &keep_from;
     const bool flushed_stream = !finish || s->carry.valid;
     if (flushed_stream) {
       if (s->has_dictionary || s->params.catable || s->params.appendable)
@@ -116,7 +141,17 @@ bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = fal
       s->output_pos = 0;
     }
     EncodeStream(req, &s->output, nullptr);
-    s->encoded_upto = s->input.size();
+    s->encoded_upto += consumed;
+    if (keep_from != 0) {
+      // the next piece only needs a window of what has been encoded: forget the rest
+      s->input.erase(s->input.begin(), s->input.begin() + (ptrdiff_t)keep_from);
+      s->encoded_upto -= keep_from;
+    }
+    if (partial) {
+      // nothing closed: wait for (a good deal) more input before trying again
+      const size_t pending = s->input.size() - s->encoded_upto;
+      s->next_batch_try = consumed == 0 ? pending * 2 : 0;
+    }
     return true;
   } catch (const std::exception& e) {
     SetError("BrotliEncoderCompressStream", e.what());
@@ -267,6 +302,7 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, br
   s->total_out = 0;
   s->total_in = 0;
   s->encoded_upto = 0;
+  s->next_batch_try = 0;
   s->metadata_draining = false;
   return s;
 }
@@ -306,7 +342,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     } else {
     if (!s->first_encode_seen) {
       s->first_encode_seen = true;
-      if (s->params.size_hint == 0) s->params.size_hint = std::min<size_t>(s->input.size(), (size_t)1 << 30);
+      if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
     }
     const size_t n_meta = *available_in;
     if (!EncodeBuffered(s, false, true, n_meta)) return BROTLI_FALSE;
@@ -318,6 +354,9 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
   }
   if (s->stream_state != kProcessing && *available_in != 0) return BROTLI_FALSE;  // encode.rs:2918-2922
   if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA) {
+    // FINISH without input right behind a full input block: the reference has run that block through encode_data already
+    // (it does so as soon as a block is full, encode.rs:2959-2964), not knowing it was the last one
+    const bool early_last = op == BROTLI_OPERATION_FINISH && *available_in == 0 && s->total_in != 0 && (s->total_in % BlockSize(s->params)) == 0;
     if (*available_in != 0) {
       s->input.insert(s->input.end(), *next_in, *next_in + *available_in);
       s->total_in += *available_in;
@@ -326,19 +365,26 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     }
     // size_hint as update_size_hint would see it at the first encode_data (encode.rs:1604-1620, 2970):
     // everything received up to the end of the call in which the first input block fills up
-    if (!s->first_encode_seen && (s->input.size() >= BlockSize(s->params) || op != BROTLI_OPERATION_PROCESS)) {
+    if (!s->first_encode_seen && (s->total_in >= BlockSize(s->params) || op != BROTLI_OPERATION_PROCESS)) {
       s->first_encode_seen = true;
-      if (s->params.size_hint == 0) s->params.size_hint = std::min<size_t>(s->input.size(), (size_t)1 << 30);
+      if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
     }
     if (op == BROTLI_OPERATION_FINISH) {
-      if (!EncodeBuffered(s, true)) return BROTLI_FALSE;
+      if (!EncodeBuffered(s, true, false, 0, false, early_last)) return BROTLI_FALSE;
       s->stream_state = kFinished;
       std::vector<uint8_t>().swap(s->input);
     } else if (op == BROTLI_OPERATION_FLUSH) {
       // everything handed over so far becomes decodable output (encode.rs:2940-2975 with force_flush, then the
       // injected byte-alignment block :1541-1566); the encoder keeps the stream so far as the window of what follows
       // (repeated FLUSH calls that only drain output must not encode again)
-      if (!(s->carry.valid && s->encoded_upto == s->input.size()) && !EncodeBuffered(s, false)) return BROTLI_FALSE;
+      // (a partial piece leaves the output on a bit boundary: the flush padding is still owed then)
+      if (!(s->carry.valid && s->encoded_upto == s->input.size() && s->carry.tail_nbits == 0) && !EncodeBuffered(s, false)) return BROTLI_FALSE;
+    } else if (Streamable(s) && s->first_encode_seen) {
+      // PROCESS: once a batch worth of input has piled up, the meta-blocks that are complete within it are encoded and
+      // their output becomes available (BrotliEncoderHasMoreOutput); the bytes of the still open meta-block stay
+      // buffered, together with the window the next piece needs -- memory stays bounded however long the stream is
+      const size_t pending = s->input.size() - s->encoded_upto;
+      if (pending >= StreamBatchBytes() && pending >= s->next_batch_try && !EncodeBuffered(s, false, false, 0, true)) return BROTLI_FALSE;
     }
   }
   // push output (inject_flush_or_push_output, encode.rs:1568-1598)
@@ -376,6 +422,7 @@ const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* s, size_t* size) {
     s->output_pos += consumed;
     s->total_out += consumed;
     *size = consumed;
+    if (AvailableOut(s) == 0) s->metadata_draining = false;  // check_flush_complete, encode.rs:3018-3022
     return result;
   }
   *size = 0;

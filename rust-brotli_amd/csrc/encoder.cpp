@@ -252,6 +252,11 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
     if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
   }
+  // The reference maps stream positions from 3 GiB on back into [1 GiB, 3 GiB) and empties its hash table whenever
+  // that mapping jumps backwards, i.e. at 3, 5, 7 ... GiB (WrapPosition / update_last_processed_pos / HasherReset,
+  // encode.rs:1623-1631, 1705-1710, 2472-2474).  That reset is not reproduced yet: refuse instead of diverging.
+  if ((continuing ? req.carry_in->stream_base : 0) + (uint64_t)req.prefix_size + (uint64_t)n > (3ull << 30))
+    throw std::runtime_error("brotli_mi355x: streams longer than 3 GiB are not supported yet (the reference resets its hasher at the 3 GiB position wrap)");
   const char* why = nullptr;
   if (!IsAccelerated(p, &why)) throw std::runtime_error(std::string("brotli_mi355x: ") + why);
   bool catable = p.catable;
@@ -281,6 +286,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       hb.put(7, (uint64_t)(((lgwin - 8) << 4) | 1));
     }
   }
+  if (continuing && req.carry_in->tail_nbits) hb.put(req.carry_in->tail_nbits, req.carry_in->tail_bits);  // the open last byte of the piece in front
   if (p.magic_number && !continuing) WriteMetadataMetaBlock(p, &hb);
   if (!continuing && req.finish && n == 0 && p.byte_align && p.appendable && !p.catable && (hb.pos & 7) != 0) {
     hb.put(6, 6);
@@ -331,6 +337,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     if (req.carry_out) {
       StreamCarry& co = *req.carry_out;
       if (continuing) co = *req.carry_in;
+      co.tail_bits = co.tail_nbits = 0;  // (this piece ends byte aligned: flush padding or the end of the stream)
       if (!co.valid) {
         co.valid = true;
         co.hasher = p.hasher;
@@ -367,7 +374,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   const uint32_t segment_bytes = req.segment_bytes ? req.segment_bytes : ChooseSegmentBytes(n);
   {
     Clock c;
-    lz.SetStreamState(continuing ? req.carry_in : nullptr, req.finish);
+    lz.SetStreamState(continuing ? req.carry_in : nullptr, req.finish, req.partial && !req.finish, req.last_block_processed_early);
     lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, segment_bytes);
     stats.ms_phase[9] = c.lap(prof);
   }
@@ -396,7 +403,17 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     stats.searches = lz.stats().searches;
     const std::vector<MetaBlockPlan>& plans = lz.metablocks();
     const uint32_t n_mb = (uint32_t)plans.size();
-    const uint32_t K = lz.num_commands();
+    const bool partial = req.partial && !req.finish;
+    if (partial && n_mb == 0) {
+      // no meta-block closes within this input: nothing is emitted, nothing changes, the caller comes back with more
+      if (req.consumed_out) *req.consumed_out = 0;
+      if (req.keep_from_out) *req.keep_from_out = 0;
+      if (req.direct_size) *req.direct_size = 0;
+      if (stats_out) *stats_out = stats;
+      return;
+    }
+    // (in a partial piece the commands of the meta-block that is still open are not used)
+    const uint32_t K = partial ? plans.back().cmd_offset + plans.back().n_cmds : lz.num_commands();
     uint64_t L64 = 0;
     for (const MetaBlockPlan& mp : plans) L64 += mp.n_literals;
     const uint32_t L = (uint32_t)L64;
@@ -626,10 +643,14 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       stats.fallback_retries++;
       continue;
     }
-    if (!req.finish) WriteOpenTail(req, &bits);
+    if (req.finish && lz.needs_empty_last()) WriteEmptyLastBlocks(p, &bits);
+    if (!req.finish && !partial) WriteOpenTail(req, &bits);
     // ---- emission
-    const size_t total_bytes = (size_t)((bits.pos + 7) >> 3);
-    const size_t out_words = total_bytes / 8 + 4;
+    const size_t all_bytes = (size_t)((bits.pos + 7) >> 3);
+    // a partial piece hands out whole bytes only; its last, incomplete byte goes into the carry
+    const uint32_t tail_nbits = partial ? (uint32_t)(bits.pos & 7) : 0u;
+    const size_t total_bytes = tail_nbits ? all_bytes - 1 : all_bytes;
+    const size_t out_words = all_bytes / 8 + 4;
     B.out_words = mm.alloc<uint64_t>(out_words);
     dev_h2d(B.mb_out_bit, mb_out_bit.data(), (n_mb + 1) * 8);
     mb_emit(B);
@@ -663,18 +684,47 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       dev_d2h(result.data(), B.out_words, total_bytes);
     }
     stats.ms_phase[8] += clk.lap(prof);
+    const uint32_t resume = partial ? lz.resume_pos() : M;  // text position where the next piece takes over
+    if (req.consumed_out) *req.consumed_out = resume - prefix_bytes;
     if (req.carry_out) {
-      // state for the next piece of the stream: distance cache, dictionary counters, what is in the hash table
+      // State for the next piece of the stream: distance cache, dictionary counters, what is in the hash table.  Only a
+      // window of the stream so far is kept as the next prefix: at least one ring buffer of bytes (matches reach back
+      // max_backward < ring size, and the byte one ring revolution back is what the reference's ring buffer holds behind
+      // the end of a block), starting at a multiple of the ring size, so that ring-buffer indices stay what they were.
       StreamCarry co;
       co.valid = true;
       co.hasher = p.hasher;
       co.size_hint = p.size_hint;
       memcpy(co.dist_cache, plans.back().dist_cache_after, sizeof(co.dist_cache));
-      lz.FinalDictState(&co.dict_lookups, &co.dict_matches, &co.dict_dead);
-      co.stored.resize(M);
-      lz.DumpFlags(co.stored.data(), M);
+      if (partial) {
+        co.dict_lookups = plans.back().dict_lookups_after;
+        co.dict_matches = plans.back().dict_matches_after;
+        co.dict_dead = plans.back().dict_dead_after;
+      } else {
+        lz.FinalDictState(&co.dict_lookups, &co.dict_matches, &co.dict_dead);
+      }
+      const uint64_t ring = (uint64_t)lz.device_params().ring_mask + 1;
+      const uint64_t old_base = continuing ? req.carry_in->stream_base : 0;
+      const uint64_t abs_resume = old_base + resume;
+      uint64_t new_base = old_base;
+      if (abs_resume >= 2 * ring && !getenv("BROTLI_MI355X_KEEP_WHOLE_STREAM")) new_base = (abs_resume - ring) / ring * ring;
+      const uint32_t keep_from = (uint32_t)(new_base - old_base);
+      co.stream_base = new_base;
+      if (keep_from != 0 || (continuing && req.carry_in->key_counts.size() == 65536)) lz.KeyCountsBefore(keep_from, &co.key_counts);
+      std::vector<uint8_t> all(M);
+      lz.DumpFlags(all.data(), M);
+      co.stored.assign(all.begin() + keep_from, all.begin() + resume);
       for (uint8_t& f : co.stored) f &= 1;
+      if (tail_nbits) {
+        uint8_t last = 0;
+        dev_d2h(&last, (const uint8_t*)B.out_words + total_bytes, 1);
+        co.tail_bits = last & ((1u << tail_nbits) - 1u);
+        co.tail_nbits = tail_nbits;
+      }
+      if (req.keep_from_out) *req.keep_from_out = keep_from;
       *req.carry_out = std::move(co);
+    } else if (req.keep_from_out) {
+      *req.keep_from_out = 0;
     }
     stats.metablocks = n_mb;
     stats.commands = K;

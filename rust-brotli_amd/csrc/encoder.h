@@ -58,6 +58,16 @@ struct EncodeRequest {
   const StreamCarry* carry_in = nullptr;
   StreamCarry* carry_out = nullptr;
   bool finish = true;
+  // Bounded-memory streaming (BROTLI_OPERATION_PROCESS with a lot of input buffered): with finish = false and partial =
+  // true the piece is NOT flushed.  Only the meta-blocks that the reference's flush rule closes by itself within the
+  // input are emitted (whole input blocks must be handed over); *consumed_out tells how much of the input they cover --
+  // the rest has to be offered again, in front of more input.  The output ends on a bit, not a byte boundary: the
+  // incomplete last byte travels in the carry.  *keep_from_out: how many leading bytes of prefix + input the caller may
+  // drop -- the next piece's prefix starts there (StreamCarry::stream_base).  Both also work for flushed pieces.
+  bool partial = false;
+  bool last_block_processed_early = false;  // see Lz77Stage::SetStreamState
+  size_t* consumed_out = nullptr;
+  size_t* keep_from_out = nullptr;
   // BROTLI_OPERATION_EMIT_METADATA (with finish = false): instead of the flush padding, the header of a metadata block
   // of metadata_size bytes is written (encode.rs:2545-2575); the caller appends the bytes themselves
   bool emit_metadata = false;

@@ -309,11 +309,21 @@ __global__ __launch_bounds__(256) void k_key_bases(const uint8_t* __restrict__ f
   key_base[k] = g;
 }
 
+// Second word of an info record: how many entries of the key's ring the reference looks at -- its u16 counter num[key]
+// (mod.rs:1752-1760) counts the insertions since the start of the STREAM (base = those in front of this text), but no
+// more entries than were inserted within this text can be reached (older ones lie beyond max_backward: the text of a
+// later piece of a stream starts at least a window in front of its input).
+__device__ __forceinline__ uint32_t ring_count(uint32_t local_rank, uint32_t base) {
+  const uint32_t num = (local_rank + base) & 0xffffu;
+  return num < local_rank ? num : local_rank;
+}
+
 // pass B: local ranks -> sorted / info
 __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__ by_key, const uint16_t* __restrict__ sorted_keys,
                                                      const uint8_t* __restrict__ fbits, uint32_t n, const uint32_t* __restrict__ tile_offsets,
                                                      const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_base,
-                                                     uint32_t* __restrict__ sorted, uint2* __restrict__ info) {
+                                                     uint32_t* __restrict__ sorted, uint2* __restrict__ info,
+                                                     const uint32_t* __restrict__ count_base) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
   uint32_t pos[4], f[4], key[4];
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
     if (base + j < n) {
       const uint32_t lr = g - key_base[key[j]];
       const uint32_t slot = key_first[key[j]] + lr;
-      info[pos[j]] = make_uint2(slot, lr);
+      info[pos[j]] = make_uint2(slot, ring_count(lr, count_base ? count_base[key[j]] : 0u));
       if (f[j]) sorted[slot] = pos[j];
       g += f[j];
     }
@@ -383,7 +393,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
-                     B.sorted[rbuf], (uint2*)B.info[rbuf]);
+                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -492,7 +502,8 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
                                                        const uint8_t* __restrict__ flags, const uint32_t* __restrict__ sorted,
                                                        const uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
                                                        const uint32_t* __restrict__ sorted_tmp, SegGeometry geo,
-                                                       uint8_t* __restrict__ dirty) {
+                                                       uint8_t* __restrict__ dirty, const uint32_t* __restrict__ count_base,
+                                                       const uint16_t* __restrict__ keys) {
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
     if (!searched && in_front == 0xffffffffu) continue;
     const uint2 a = info[p];
     const uint32_t rb = rank_tmp[i];
-    const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(rb & 0xffffu, geo.block_size);
+    const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(ring_count(rb, count_base ? count_base[keys[p]] : 0u), geo.block_size);
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted[a.x - 1 - j] == sorted_tmp[c.key_lo + rb - 1 - j];
     if (!same && br_row_change_matters(text, p, sorted + a.x - 1, na, sorted_tmp + c.key_lo + rb - 1, nb)) {
@@ -514,12 +525,13 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
 
 __global__ __launch_bounds__(256) void k_rerank_commit(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ by_key,
                                                         const uint8_t* __restrict__ flags, uint32_t* __restrict__ sorted,
-                                                        uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp) {
+                                                        uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
+                                                        const uint32_t* __restrict__ count_base, const uint16_t* __restrict__ keys) {
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
     const uint32_t rb = rank_tmp[i];
-    info[p] = make_uint2(c.key_lo + rb, rb);
+    info[p] = make_uint2(c.key_lo + rb, ring_count(rb, count_base ? count_base[keys[p]] : 0u));
     if (flags[p] & 1u) sorted[c.key_lo + rb] = p;
   }
 }
@@ -532,9 +544,9 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], sums_dev);
   hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
   hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, BR_STREAM, B.text, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
-                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev);
+                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev, B.count_base, B.keys);
   hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
-                     (uint2*)B.info[rbuf], rank_tmp);
+                     (uint2*)B.info[rbuf], rank_tmp, B.count_base, B.keys);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -716,11 +728,11 @@ __global__ __launch_bounds__(256) void k_fbits_tile_sums(const uint8_t* __restri
 
 __global__ __launch_bounds__(256) void k_row_key_bases(const uint8_t* __restrict__ fbits, const uint32_t* __restrict__ tile_offsets,
                                                         const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
-                                                        uint32_t* __restrict__ key_base) {
+                                                        uint32_t* __restrict__ key_base, uint32_t all_keys) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= 65536) return;
   const uint32_t i0 = key_first[k];
-  if (key_last[k] - i0 < 65536u || key_last[k] <= i0) return;  // only keys whose counter can wrap
+  if (key_last[k] <= i0 || (!all_keys && key_last[k] - i0 < 65536u)) return;  // only keys whose counter can wrap
   const uint32_t tile = i0 / kRowTile;
   uint32_t g = tile_offsets[tile];
   for (uint32_t i = tile * kRowTile; i < i0; ++i) g += fbits[i] & kSlotStored;
@@ -729,11 +741,11 @@ __global__ __launch_bounds__(256) void k_row_key_bases(const uint8_t* __restrict
 
 // tiles that hold slots of a key with >= 65 536 slots
 __global__ __launch_bounds__(256) void k_flag_big_tiles(const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
-                                                         uint8_t* __restrict__ big_tile) {
+                                                         uint8_t* __restrict__ big_tile, uint32_t all_keys) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= 65536) return;
   const uint32_t i0 = key_first[k], i1 = key_last[k];
-  if (i1 <= i0 || i1 - i0 < 65536u) return;
+  if (i1 <= i0 || (!all_keys && i1 - i0 < 65536u)) return;
   for (uint32_t t = i0 / kRowTile; t <= (i1 - 1) / kRowTile; ++t) big_tile[t] = 1;
 }
 
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits,
                                                      const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
                                                      const uint32_t* __restrict__ key_base, uint32_t append,
                                                      uint32_t* __restrict__ changed_slot, const uint32_t* __restrict__ changed_count, uint32_t cap,
-                                                     uint32_t* __restrict__ ctl) {
+                                                     uint32_t* __restrict__ ctl, const uint32_t* __restrict__ count_base) {
   if (!big_tile[blockIdx.x]) return;
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kRowTile + threadIdx.x * 4;
@@ -772,8 +784,9 @@ __global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits,
     if (i < n) {
       const uint32_t key = sorted_keys[i];
       bool want = false;
-      if (key_last[key] - key_first[key] >= 65536u) {
-        const uint32_t count = g - key_base[key];  // stored slots of the key in front of this one
+      if (count_base != nullptr || key_last[key] - key_first[key] >= 65536u) {
+        // insertions into the key's ring in front of this slot, since the start of the stream
+        const uint32_t count = g - key_base[key] + (count_base ? count_base[key] : 0u);
         want = count != 0 && (count & 0xffffu) == 0;
       }
       if (want != ((f[j] & kSlotWrap) != 0)) {
@@ -985,9 +998,10 @@ static void launch_wrap_marks(const Lz77Params& P, const Lz77Buffers& B, bool ap
   uint32_t* scratch = tile_sums + tiles + 64;
   hipLaunchKernelGGL(k_fbits_tile_sums, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums);
   exclusive_scan_u32(tile_sums, tiles, scratch);
-  hipLaunchKernelGGL(k_row_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
+  hipLaunchKernelGGL(k_row_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base,
+                     B.count_base ? 1u : 0u);
   hipLaunchKernelGGL(k_mark_wraps, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums, B.sorted_keys, B.key_first, B.key_last,
-                     B.key_base, append ? 1u : 0u, B.changed_slot, B.changed_count, B.changed_cap, B.row_ctl);
+                     B.key_base, append ? 1u : 0u, B.changed_slot, B.changed_count, B.changed_cap, B.row_ctl, B.count_base);
 }
 
 void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const RankInitialHint* initial, bool has_big_keys) {
@@ -1009,7 +1023,7 @@ void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const 
   HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
   if (has_big_keys) {
     HIP_CHECK(hipMemsetAsync(B.big_tile, 0, tiles + 64, BR_STREAM));
-    hipLaunchKernelGGL(k_flag_big_tiles, dim3(256), dim3(256), 0, BR_STREAM, B.key_first, B.key_last, B.big_tile);
+    hipLaunchKernelGGL(k_flag_big_tiles, dim3(256), dim3(256), 0, BR_STREAM, B.key_first, B.key_last, B.big_tile, B.count_base ? 1u : 0u);
     launch_wrap_marks(P, B, false);
   }
   launch_slot_masks(P, B);
@@ -1041,6 +1055,27 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
                      cap, B.fbits);
   HIP_CHECK(hipGetLastError());
   (void)prev;
+}
+
+// ------------------------------------------------------------------------------------------ key counts
+// one wavefront per key: stored positions of the key in front of text position `upto`
+__global__ __launch_bounds__(64) void k_key_counts(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags,
+                                                    const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
+                                                    const uint32_t* __restrict__ base, uint32_t upto, uint32_t* __restrict__ out) {
+  const uint32_t key = blockIdx.x;
+  uint32_t local = 0;
+  for (uint32_t i = key_first[key] + threadIdx.x; i < key_last[key]; i += 64) {
+    const uint32_t p = by_key[i];
+    if (p < upto) local += flags[p] & 1u;  // (slots are in position order, but a strided lane cannot stop early for the others)
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if (threadIdx.x == 0) out[key] = local + (base ? base[key] : 0u);
+}
+
+void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out_dev) {
+  (void)P;
+  hipLaunchKernelGGL(k_key_counts, dim3(65536), dim3(64), 0, BR_STREAM, B.by_key, B.flags[which], B.key_first, B.key_last, B.count_base, upto, out_dev);
+  HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------ run table

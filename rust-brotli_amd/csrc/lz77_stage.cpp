@@ -41,6 +41,8 @@ void Lz77Stage::Release() {
     dev_free(B_.row_ctl);
     dev_free(B_.big_tile);
     dev_free(B_.run_end);
+    dev_free(count_base_dev_);
+    count_base_dev_ = nullptr;
     dev_free(B_.smask);
     dev_free(B_.gprev);
     dev_free(B_.flags[0]);
@@ -390,6 +392,8 @@ bool Lz77Stage::Resolve(bool final_pass) {
   uint32_t last_insert_len = 0;
   uint64_t num_commands = 0, num_literals = 0;
   uint32_t last_flush_pos = P_.prefix_bytes + raw_head_bytes_;
+  resume_pos_ = last_flush_pos;
+  needs_empty_last_ = false;
   DictTracker dict;
   dict.use = P_.use_dictionary != 0;
   if (carry_ && carry_->valid) {
@@ -532,10 +536,18 @@ bool Lz77Stage::Resolve(bool final_pass) {
     memcpy(cache, cur_cache, sizeof(cache));
     last_insert_len = carry;
     // ---- meta-block flush rule, encode.rs:2454-2483
-    const bool is_last = (k1 + 1 == nseg);
+    const bool batch_end = (k1 + 1 == nseg);
+    bool is_last = batch_end && !partial_;
     const size_t processed_bytes = be - last_flush_pos;
     const bool next_fits = processed_bytes + block_bytes_ <= max_mb;
+    if (is_last && early_last_ && !(next_fits && num_literals < max_literals && num_commands < max_commands)) {
+      // the flush rule had closed this meta-block before anybody knew that the stream ends here
+      is_last = false;
+      needs_empty_last_ = true;
+    }
     if (!is_last && next_fits && num_literals < max_literals && num_commands < max_commands) {
+      // (partial piece: the meta-block that is still open when the input runs out is left to the next piece)
+      if (batch_end) break;
       k = k1 + 1;
       continue;
     }
@@ -576,7 +588,11 @@ bool Lz77Stage::Resolve(bool final_pass) {
     mb.uncompressed = !compress;
     if (!compress) memcpy(cache, saved_cache, sizeof(cache));  // encode.rs:1994, 2142
     memcpy(mb.dist_cache_after, cache, sizeof(cache));
+    mb.dict_lookups_after = dict.L;
+    mb.dict_matches_after = dict.M;
+    mb.dict_dead_after = dict.state == DictTracker::kDead || dict.state == DictTracker::kUnknown || (dict.use && dict.M < (dict.L >> 7));
     metablocks_.push_back(mb);
+    resume_pos_ = be;
     memcpy(saved_cache, cache, sizeof(cache));
     num_commands = 0;
     num_literals = 0;
@@ -780,6 +796,15 @@ void Lz77Stage::Run() {
   }
   has_big_keys_ = false;
   for (uint32_t key = 0; key < 65536 && !has_big_keys_; ++key) has_big_keys_ = key_last_[key] - key_first_[key] >= 65536u;
+  // a later piece of a stream: the ring counters of the reference have been running since the start of the stream
+  if (carry_ && carry_->valid && carry_->key_counts.size() == 65536) {
+    if (!count_base_dev_) count_base_dev_ = (uint32_t*)dev_alloc(65536 * 4);
+    dev_h2d(count_base_dev_, carry_->key_counts.data(), 65536 * 4);
+    B_.count_base = count_base_dev_;
+    has_big_keys_ = true;
+  } else {
+    B_.count_base = nullptr;
+  }
   tm.stop(&stats_.ms_sort);
   RunRounds(true);
   tm.stop(&stats_.ms_resolve);
@@ -1224,17 +1249,18 @@ void Lz77Stage::SelfTestRows(int which) {
     return (uint32_t)((v * 0x9E3779B1u) >> 16);
   };
   const uint32_t depth = 1u << P_.block_bits;
-  uint32_t first = 0, stored_before = 0;
+  uint32_t first = 0, stored_before = 0, local_before = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t p = by_key[i];
     if (i == 0 || skeys[i - 1] != skeys[i]) {
       first = i;
-      stored_before = 0;
+      stored_before = B_.count_base ? carry_->key_counts[skeys[i]] : 0u;
+      local_before = 0;
     }
     if ((fbits[i] & 1) != (flags[p] & 1)) throw std::runtime_error("selftest: fbits mismatch at slot " + std::to_string(i));
     if (fbits[i] & 2) throw std::runtime_error("selftest: leftover change mark at slot " + std::to_string(i));
     {
-      const bool big = key_last_[skeys[i]] - key_first_[skeys[i]] >= 65536u;
+      const bool big = B_.count_base != nullptr || key_last_[skeys[i]] - key_first_[skeys[i]] >= 65536u;
       const bool want_wrap = big && stored_before != 0 && (stored_before & 0xffffu) == 0;
       if (want_wrap != ((fbits[i] & 4) != 0)) throw std::runtime_error("selftest: wrap mark mismatch at slot " + std::to_string(i));
     }
@@ -1257,7 +1283,17 @@ void Lz77Stage::SelfTestRows(int which) {
                                  " instead of " + std::to_string(expect));
     }
     stored_before += flags[p] & 1;
+    local_before += flags[p] & 1;
   }
+  (void)local_before;
+}
+
+void Lz77Stage::KeyCountsBefore(uint32_t upto, std::vector<uint32_t>* out) {
+  uint32_t* dev = (uint32_t*)dev_alloc(65536 * 4);
+  lz77_key_counts(P_, B_, final_flags_, upto, dev);
+  out->resize(65536);
+  dev_d2h(out->data(), dev, 65536 * 4);
+  dev_free(dev);
 }
 
 void Lz77Stage::Gather() {

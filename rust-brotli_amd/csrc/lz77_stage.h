@@ -28,6 +28,9 @@ struct MetaBlockPlan {
   bool is_last;
   int32_t dist_cache_after[4];
   int32_t saved_dist_cache[4];  // dist cache at the start of the meta-block (for IR-free storing)
+  // static-dictionary throttle state behind the meta-block (where a later batch of the stream resumes)
+  uint32_t dict_lookups_after, dict_matches_after;
+  bool dict_dead_after;
 };
 
 struct Lz77Stats {
@@ -49,9 +52,16 @@ struct StreamCarry {
   int32_t dist_cache[4] = {4, 11, 15, 16};
   uint32_t dict_lookups = 0, dict_matches = 0;
   bool dict_dead = false;
-  std::vector<uint8_t> stored;  // per byte of the stream so far: bit 0 = the position is in the hash table
+  std::vector<uint8_t> stored;  // per byte of the kept part of the stream: bit 0 = the position is in the hash table
   HasherParams hasher;          // fixed by the first encode_data (encode.rs:1125-1161)
   size_t size_hint = 0;
+  // ---- bounded-memory streaming: only a window of the stream so far is kept as the prefix of the next piece
+  uint64_t stream_base = 0;     // stream position of the first kept byte; a multiple of the ring-buffer size, so that
+                                // ring-buffer indices (position & ring_mask) of the kept bytes are what they were
+  std::vector<uint32_t> key_counts;  // per hash key: positions stored in the hash table in front of stream_base (the
+                                     // reference's u16 ring counter num[key] counts from the start of the stream)
+  uint32_t tail_bits = 0, tail_nbits = 0;  // last, incomplete byte of the output so far (a piece that ends on a
+                                           // meta-block boundary without a flush is not byte aligned)
 };
 
 class Lz77Stage {
@@ -72,10 +82,24 @@ class Lz77Stage {
   void ForceUncompressed(uint32_t index) { forced_uncompressed_.push_back(index); }
   // continuation of a stream after a flush: the prefix is the stream so far, `carry` its state; stream_is_last = false
   // keeps the ISLAST bit off the final meta-block (more input may follow)
-  void SetStreamState(const StreamCarry* carry, bool stream_is_last) {
+  void SetStreamState(const StreamCarry* carry, bool stream_is_last, bool partial = false, bool last_block_processed_early = false) {
     carry_ = carry;
     stream_is_last_ = stream_is_last;
+    partial_ = partial;
+    early_last_ = last_block_processed_early && stream_is_last;
   }
+  // last_block_processed_early: the stream ends exactly at the end of an input block that the reference had already
+  // run through encode_data (is_last = false) when the FINISH operation came without further input.  Whether the
+  // meta-block got closed there was then up to the flush rule; if it was, the stream ends with an EMPTY last meta-block
+  // (needs_empty_last()), if not, the open meta-block becomes the last one (encode.rs:2454-2483, 2940-2975).
+  bool needs_empty_last() const { return needs_empty_last_; }
+  // partial = true: more input of the same stream follows without a flush in between.  Only the meta-blocks that the
+  // flush rule (encode.rs:2454-2477) closes by itself are planned; resume_pos() is where the first open one starts --
+  // the next piece starts there again.
+  uint32_t resume_pos() const { return resume_pos_; }
+  // stored positions per hash key in front of text position `upto` (added to the carried-in counts): the key_counts of
+  // the next piece when it keeps text[upto ..) as its prefix
+  void KeyCountsBefore(uint32_t upto, std::vector<uint32_t>* out);
   // state after Run() for the next continuation (dist cache comes from metablocks().back())
   void FinalDictState(uint32_t* lookups, uint32_t* matches, bool* dead) const {
     *lookups = final_dict_lookups_;
@@ -124,6 +148,9 @@ class Lz77Stage {
   int final_flags_ = 0;
   const StreamCarry* carry_ = nullptr;
   bool stream_is_last_ = true;
+  bool partial_ = false;
+  bool early_last_ = false, needs_empty_last_ = false;
+  uint32_t resume_pos_ = 0;
   uint32_t final_dict_lookups_ = 0, final_dict_matches_ = 0;
   bool final_dict_dead_ = false;
   std::map<uint32_t, SegEntry> block_entry_guess_, saved_block_guess_;  // by block start
@@ -171,6 +198,7 @@ class Lz77Stage {
   uint32_t dict_death_seg_ = 0xffffffffu;
   uint32_t dict_flips_ = 0;
   bool owns_buffers_ = false;
+  uint32_t* count_base_dev_ = nullptr;  // carried-in ring counters per key (StreamCarry::key_counts)
   bool use_rows_ = false;      // quality 5: candidate rows instead of rank structures (device_api.h)
   bool has_big_keys_ = false;  // some hash key owns >= 65 536 positions (the u16 ring counter of the reference wraps)
 };

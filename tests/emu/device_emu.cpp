@@ -120,6 +120,22 @@ void lz77_sort_by_key(const Lz77Params& P, const Lz77Buffers& B) {
   }
 }
 
+// see ring_count in lz77_kernels.hip
+static uint32_t emu_ring_count(uint32_t local_rank, uint32_t base) {
+  const uint32_t num = (local_rank + base) & 0xffffu;
+  return num < local_rank ? num : local_rank;
+}
+
+void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out) {
+  for (uint32_t key = 0; key < 65536; ++key) {
+    uint32_t c = B.count_base ? B.count_base[key] : 0u;
+    for (uint32_t i = B.key_first[key]; i < B.key_last[key]; ++i)
+      if (B.by_key[i] < upto) c += B.flags[which][B.by_key[i]] & 1u;
+    out[key] = c;
+  }
+  (void)P;
+}
+
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint*) {
   const uint32_t n = P.total_bytes;
   uint32_t first = 0, local = 0;
@@ -130,7 +146,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
       local = 0;
     }
     B.info[rbuf][2 * (size_t)pos] = first + local;
-    B.info[rbuf][2 * (size_t)pos + 1] = local;
+    B.info[rbuf][2 * (size_t)pos + 1] = emu_ring_count(local, B.count_base ? B.count_base[B.sorted_keys[i]] : 0u);
     if (B.flags[which][pos] & 1) B.sorted[rbuf][first + local++] = pos;
   }
 }
@@ -182,7 +198,8 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
       if (!searched && in_front == 0xffffffffu) continue;
       const uint32_t ax = B.info[rbuf][2 * (size_t)p], ay = B.info[rbuf][2 * (size_t)p + 1];
       const uint32_t rb = new_rank[i - lo];
-      const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(rb & 0xffffu, geo.block_size);
+      const uint32_t cb = B.count_base ? B.count_base[B.keys[p]] : 0u;
+      const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(emu_ring_count(rb, cb), geo.block_size);
       bool same = na == nb;
       for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf][ax - 1 - j] == new_sorted[rb - 1 - j];
       if (!same && br_row_change_matters(B.text, p, B.sorted[rbuf] + ax - 1, na, new_sorted.data() + rb - 1, nb)) {
@@ -193,7 +210,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t p = B.by_key[i];
       B.info[rbuf][2 * (size_t)p] = lo + new_rank[i - lo];
-      B.info[rbuf][2 * (size_t)p + 1] = new_rank[i - lo];
+      B.info[rbuf][2 * (size_t)p + 1] = emu_ring_count(new_rank[i - lo], B.count_base ? B.count_base[B.keys[p]] : 0u);
     }
     for (size_t j = 0; j < new_sorted.size(); ++j) B.sorted[rbuf][lo + j] = new_sorted[j];
   }
@@ -231,11 +248,11 @@ static void emu_build_all_rows(const Lz77Params& P, const Lz77Buffers& B, int wh
   for (uint32_t i = 0; i < n; ++i) {
     if (i == 0 || B.sorted_keys[i - 1] != B.sorted_keys[i]) {
       kf = i;
-      stored_before = 0;
+      stored_before = B.count_base ? B.count_base[B.sorted_keys[i]] : 0u;
     }
     const uint32_t key = B.sorted_keys[i];
     uint32_t depth = depth0;
-    if (B.key_last[key] - kf >= 65536u) depth = std::min(depth, stored_before & 0xffffu);
+    if (B.count_base || B.key_last[key] - kf >= 65536u) depth = std::min(depth, stored_before & 0xffffu);
     if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, validate) && validate) emu_row_changed(B, which, B.by_key[i], *geo, dirty);
     stored_before += B.fbits[i] & 1u;
   }
@@ -261,7 +278,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
       const uint32_t p = B.changed_keys[c];
       const uint32_t key = B.keys[p];
       uint32_t lo = B.key_first[key], hi = B.key_last[key];
-      if (hi - lo >= 65536u) need_full = true;
+      if (hi - lo >= 65536u || B.count_base) need_full = true;
       while (lo + 1 < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
         if (B.by_key[mid] <= p) lo = mid; else hi = mid;
