@@ -185,6 +185,39 @@ const char* BrotliMi355xDeviceName(void);
 /* Message of the last failure on the calling thread ("" if none). */
 const char* BrotliMi355xLastError(void);
 
+/* ---- BroCatli: concatenation of catable / appendable brotli streams, fed and drained piecewise --------------------
+ * c/brotli/broccoli.h, src/ffi/broccoli.rs:55-175 (state machine src/concat/mod.rs:274-608).  Same names, signatures
+ * and result codes as the reference; the state object is the same 256-byte by-value struct. */
+typedef struct BroccoliState_ {
+  void* unused;
+  unsigned char data[248];
+} BroccoliState;
+
+typedef enum BroccoliResult_ {
+  BroccoliSuccess = 0,
+  BroccoliNeedsMoreInput = 1,
+  BroccoliNeedsMoreOutput = 2,
+  BroccoliBrotliFileNotCraftedForAppend = 124,
+  BroccoliInvalidWindowSize = 125,
+  BroccoliWindowSizeLargerThanPreviousFile = 126,
+  BroccoliBrotliFileNotCraftedForConcatenation = 127
+} BroccoliResult;
+
+BroccoliState BroccoliCreateInstance(void);                                   /* broccoli.rs:56 */
+BroccoliState BroccoliCreateInstanceWithWindowSize(uint8_t window_size);      /* broccoli.rs:60 */
+void BroccoliDestroyInstance(BroccoliState state);                            /* broccoli.rs:67 */
+void BroccoliNewBrotliFile(BroccoliState* state);                             /* broccoli.rs:70 */
+BroccoliResult BroccoliConcatStream(BroccoliState* state, size_t* available_in, const uint8_t** input_buf_ptr,
+                                    size_t* available_out, uint8_t** output_buf_ptr);  /* broccoli.rs:82 */
+BroccoliResult BroccoliConcatStreaming(BroccoliState* state, size_t* available_in, const uint8_t* input_buf,
+                                       size_t* available_out, uint8_t* output_buf);    /* broccoli.rs:110 */
+BroccoliResult BroccoliConcatFinish(BroccoliState* state, size_t* available_out, uint8_t** output_buf);   /* broccoli.rs:133 */
+BroccoliResult BroccoliConcatFinished(BroccoliState* state, size_t* available_out, uint8_t* output_buf);  /* broccoli.rs:156 */
+
+/* returns the device memory the calling thread's encoder calls have pooled (and do not use at the moment) to the
+ * driver; the number of bytes released.  Not part of the reference ABI. */
+size_t BrotliMi355xTrimPool(void);
+
 #ifdef __cplusplus
 }
 #endif

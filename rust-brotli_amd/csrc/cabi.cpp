@@ -324,6 +324,15 @@ void BrotliEncoderDestroyInstance(BrotliEncoderState* state) {
   }
 }
 
+size_t BrotliMi355xTrimPool(void) {
+  try {
+    return dev_trim_pool();
+  } catch (const std::exception& e) {
+    SetError("BrotliMi355xTrimPool", e.what());
+    return 0;
+  }
+}
+
 size_t BrotliEncoderMaxCompressedSize(size_t input_size) { return MaxCompressedSize(input_size); }
 size_t BrotliEncoderMaxCompressedSizeMulti(size_t input_size, size_t num_threads) { return MaxCompressedSizeMulti(input_size, num_threads); }
 uint32_t BrotliEncoderVersion(void) { return 0x01000f01u; }

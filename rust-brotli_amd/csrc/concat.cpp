@@ -179,6 +179,7 @@ bool ChunkStitcher::Append(const ChunkView& in, ByteSink* out, BodyCopy* body) {
     memcpy(pending, realigned, pending_len);
   }
   out->append(pending, pending + pending_len);
+  if (out->overflow()) return false;  // caller-owned buffer too small: nothing sensible can follow
   any_bytes_emitted_ = true;
   // the last byte may still change (next chunk / end of stream): take it back
   last_byte_sanitized_ = false;
@@ -209,6 +210,42 @@ bool ChunkStitcher::Append(const ChunkView& in, ByteSink* out, BodyCopy* body) {
   }
   last_bytes_[0] = in.at(in_offset + to_copy - 2);
   last_bytes_[1] = in.at(in_offset + to_copy - 1);
+  return true;
+}
+
+bool ChunkStitcher::InitWithWindowSize(uint8_t ws) {
+  uint8_t b0 = 0, b1 = 0, len = 0;
+  if (ws > 24) {
+    b0 = 17;
+    b1 = (uint8_t)(ws | 64 | 128);
+    len = 2;
+  } else if (ws == 16) {
+    b0 = 1 | 2 | 4;
+    len = 1;
+  } else if (ws > 17) {
+    b0 = (uint8_t)((3 + (ws - 18) * 2) | (16 | 32));
+    len = 1;
+  } else {
+    switch (ws) {
+      case 15: b0 = 0x71 | 0x80; break;
+      case 14: b0 = 0x61 | 0x80; break;
+      case 13: b0 = 0x51 | 0x80; break;
+      case 12: b0 = 0x41 | 0x80; break;
+      case 11: b0 = 0x31 | 0x80; break;
+      case 10: b0 = 0x21 | 0x80; break;
+      case 17: b0 = 0x1 | 0x80; break;
+      default: return false;
+    }
+    b1 = 1;
+    len = 2;
+  }
+  last_bytes_[0] = b0;
+  last_bytes_[1] = b1;
+  last_bytes_len_ = len;
+  last_byte_bit_offset_ = 0;
+  last_byte_sanitized_ = false;
+  any_bytes_emitted_ = false;
+  window_size_ = ws;
   return true;
 }
 

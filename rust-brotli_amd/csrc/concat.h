@@ -28,10 +28,11 @@ class ByteSink {
     else size_ += n;
     return at;
   }
-  uint8_t back() const { return vec_ ? vec_->back() : buf_[size_ - 1]; }
+  // (a caller-owned buffer that has overflowed, or is still empty, has no last byte to look at or take back)
+  uint8_t back() const { return vec_ ? vec_->back() : ((overflow_ || size_ == 0) ? (uint8_t)0 : buf_[size_ - 1]); }
   void pop_back() {
     if (vec_) vec_->pop_back();
-    else --size_;
+    else if (!overflow_ && size_ != 0) --size_;
   }
   size_t size() const { return vec_ ? vec_->size() : size_; }
   bool overflow() const { return overflow_; }
@@ -81,6 +82,11 @@ class ChunkStitcher {
   bool any_bytes_emitted_ = false;
   uint8_t last_byte_bit_offset_ = 0;
   uint8_t window_size_ = 0;
+
+ public:
+  // BroCatli::try_new_with_window_size (concat/mod.rs:232-272): the output stream starts with a header that announces
+  // this window and an empty last meta-block, which the first real file then replaces; false = invalid window size
+  bool InitWithWindowSize(uint8_t log_window_size);
 };
 
 }  // namespace brotli_mi355x

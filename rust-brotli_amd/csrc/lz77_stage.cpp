@@ -358,7 +358,7 @@ static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const Seg
 
 bool Lz77Stage::Resolve(bool final_pass) {
   const uint32_t nseg = (uint32_t)segments_.size();
-  next_entries_.assign(nseg, SegEntry{});
+  next_entries_.resize(nseg);  // (every element is written below)
   dbg_mismatch_ = dbg_counts_;
   memset(dbg_counts_, 0, sizeof(dbg_counts_));
   memset(dbg_first_, 0, sizeof(dbg_first_));
@@ -446,7 +446,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
       mark(k0, cache_same && u.ext_allowed == E.ext_allowed, (uint8_t)((ext_same ? 0 : 1) | (cache_same ? 0 : 2)));
     }
     next_entries_[k0] = E;
-    block_entry_guess_[bs] = E;
+    if (record_block_guess_) block_entry_guess_[bs] = E;  // (only the pass after round 0 can lead to the coarse restart that reads it)
     // ---- chain through the segments of the block
     uint32_t carry = last_insert_len;  // literals pending when the segment is entered
     int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
@@ -1060,6 +1060,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     tm.stop(&stats_.ms_rank);
     const auto host_t0 = std::chrono::steady_clock::now();
+    record_block_guess_ = round == 0 && allow_restart;
     Resolve(false);
     const auto host_t1 = std::chrono::steady_clock::now();
     host_resolve_ms_ += std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();

@@ -148,6 +148,7 @@ class Lz77Stage {
   int final_flags_ = 0;
   const StreamCarry* carry_ = nullptr;
   bool stream_is_last_ = true;
+  bool record_block_guess_ = false;
   bool partial_ = false;
   bool early_last_ = false, needs_empty_last_ = false;
   uint32_t resume_pos_ = 0;
