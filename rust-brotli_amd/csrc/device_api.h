@@ -166,6 +166,9 @@ void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint3
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 // work[3] (optional): what those launches did -- positions walked, searches, commands written (all chains, re-parses included)
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments, uint64_t* work = nullptr);
+// the same for all input blocks and all 13 sampling phases at once: out[(b * 13 + r) * 256 + v] (see the kernel)
+void lz77_block_sample_histograms(const uint8_t* text, const uint32_t* block_start_dev, const uint32_t* block_end_dev, uint32_t num_blocks,
+                                  uint32_t* out_dev);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]

@@ -1426,6 +1426,28 @@ __global__ __launch_bounds__(256) void k_sample_histogram(const uint8_t* __restr
   if (h[threadIdx.x]) atomicAdd(&histo[threadIdx.x], h[threadIdx.x]);
 }
 
+// Every-13th-byte histograms of all input blocks at once, for each of the 13 possible sampling phases: out[(b * 13 + r) *
+// 256 + v] = number of offsets o in block b with o % 13 == r and byte v.  should_compress (encode.rs:1325-1354) samples a
+// meta-block from its own start, so the phase of a block depends on which meta-block it ends up in; with all phases at
+// hand the host composes the histogram of any meta-block without another trip to the device.
+__global__ __launch_bounds__(256) void k_block_sample_histograms(const uint8_t* __restrict__ text, const uint32_t* __restrict__ block_start,
+                                                                  const uint32_t* __restrict__ block_end, uint32_t* __restrict__ out) {
+  __shared__ uint32_t h[13 * 256];
+  for (uint32_t i = threadIdx.x; i < 13 * 256; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint32_t bs = block_start[blockIdx.x], be = block_end[blockIdx.x];
+  for (uint32_t o = threadIdx.x; bs + o < be; o += 256) atomicAdd(&h[(o % 13u) * 256u + text[bs + o]], 1u);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 13 * 256; i += 256) out[(size_t)blockIdx.x * 13 * 256 + i] = h[i];
+}
+
+void lz77_block_sample_histograms(const uint8_t* text, const uint32_t* block_start_dev, const uint32_t* block_end_dev, uint32_t num_blocks,
+                                  uint32_t* out_dev) {
+  if (num_blocks == 0) return;
+  hipLaunchKernelGGL(k_block_sample_histograms, dim3(num_blocks), dim3(256), 0, BR_STREAM, text, block_start_dev, block_end_dev, out_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev) {
   HIP_CHECK(hipMemsetAsync(histo256_dev, 0, 256 * 4, BR_STREAM));
   const uint32_t samples = (bytes + 12) / 13;

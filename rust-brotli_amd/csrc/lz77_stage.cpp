@@ -356,6 +356,39 @@ static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const Seg
   x->tail_p1 = position > seg.end ? tail_p1 : 0u;
 }
 
+// Every-13th-byte histogram of the meta-block [start, end) (should_compress, encode.rs:1325-1354), composed on the host
+// from per-block histograms for all 13 sampling phases, which the device computes once per Run() when the first
+// literal-only meta-block shows up (incompressible input has dozens of them, and every pass of the resolver asks).
+void Lz77Stage::SampledHistogram(uint32_t start, uint32_t end, uint32_t* histo) {
+  const uint32_t nblocks = (uint32_t)block_segment_bytes_.size();
+  if (block_histos_.empty()) {
+    std::vector<uint32_t> bs(nblocks), be(nblocks);
+    for (uint32_t b = 0; b < nblocks; ++b) {
+      const Segment& g = segments_[block_first_segment_[b]];
+      bs[b] = g.blk_start;
+      be[b] = g.blk_end;
+    }
+    uint32_t* bounds_dev = (uint32_t*)dev_alloc((size_t)nblocks * 8 + 64);
+    uint32_t* out_dev = (uint32_t*)dev_alloc_uninit((size_t)nblocks * 13 * 256 * 4 + 64);
+    dev_h2d(bounds_dev, bs.data(), (size_t)nblocks * 4);
+    dev_h2d(bounds_dev + nblocks, be.data(), (size_t)nblocks * 4);
+    lz77_block_sample_histograms(B_.text, bounds_dev, bounds_dev + nblocks, nblocks, out_dev);
+    block_histos_.resize((size_t)nblocks * 13 * 256);
+    dev_d2h(block_histos_.data(), out_dev, block_histos_.size() * 4);
+    dev_free(bounds_dev);
+    dev_free(out_dev);
+    block_starts_ = bs;
+  }
+  memset(histo, 0, 256 * 4);
+  // blocks are contiguous: find the first one by its start
+  uint32_t b = (uint32_t)(std::lower_bound(block_starts_.begin(), block_starts_.end(), start) - block_starts_.begin());
+  for (; b < nblocks && block_starts_[b] < end; ++b) {
+    const uint32_t phase = (13u - (block_starts_[b] - start) % 13u) % 13u;  // offsets o in the block with (block start + o - start) % 13 == 0
+    const uint32_t* h = block_histos_.data() + ((size_t)b * 13 + phase) * 256;
+    for (uint32_t v = 0; v < 256; ++v) histo[v] += h[v];
+  }
+}
+
 bool Lz77Stage::Resolve(bool final_pass) {
   const uint32_t nseg = (uint32_t)segments_.size();
   next_entries_.resize(nseg);  // (every element is written below)
@@ -574,11 +607,11 @@ bool Lz77Stage::Resolve(bool final_pass) {
       auto it = should_compress_cache.find(key);
       if (it == should_compress_cache.end()) {
         uint32_t histo[256];
-        lz77_sample_histogram(B_.text, mb.start, bytes, histo_dev_);
-        dev_d2h(histo, histo_dev_, sizeof(histo));
+        SampledHistogram(mb.start, mb.end, histo);
         const float threshold = (float)bytes * 7.92f / 13.0f;
         const bool c = !(HostBitsEntropy(histo, 256) > threshold);
         it = should_compress_cache.emplace(key, c).first;
+        if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "  should_compress sampled [%u,+%u) -> %d\n", key.first, key.second, (int)c);
       }
       compress = it->second;
     }
@@ -756,6 +789,7 @@ void Lz77Stage::Run() {
   Timer total(true);
   Timer tm(prof);
   should_compress_cache_.clear();
+  block_histos_.clear();
   const uint32_t nseg = (uint32_t)segments_.size();
   if (nseg == 0) {
     metablocks_.clear();

@@ -382,6 +382,13 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments,
   *segments = 0;
 }
 
+void lz77_block_sample_histograms(const uint8_t* text, const uint32_t* block_start, const uint32_t* block_end, uint32_t num_blocks,
+                                  uint32_t* out) {
+  memset(out, 0, (size_t)num_blocks * 13 * 256 * 4);
+  for (uint32_t b = 0; b < num_blocks; ++b)
+    for (uint32_t o = 0; block_start[b] + o < block_end[b]; ++o) out[((size_t)b * 13 + o % 13) * 256 + text[block_start[b] + o]]++;
+}
+
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo) {
   memset(histo, 0, 256 * 4);
   const uint32_t samples = (bytes + 12) / 13;
