@@ -118,6 +118,24 @@ def _suite(lib):
         got = with_ops(a, ops, [(Q, 5), (W, 22)])
         assert got == orc.stream_with_flushes(a, [(Q, 5), (W, 22)], ops), ops
         assert orc.decompress(b"".join(got), len(a)) == a
+    # two metadata blocks whose output is fetched with BrotliEncoderTakeOutput (available_out = 0): the second one used to
+    # be refused because the "metadata still draining" state was only cleared by BrotliEncoderCompressStream
+    import ctypes
+    e = lib.encoder(params=[(Q, 5), (W, 22)])
+    got = bytearray()
+    for meta in (b"first block", b"second block"):
+        buf = ctypes.create_string_buffer(meta, len(meta))
+        avail_in, next_in = ctypes.c_size_t(len(meta)), ctypes.c_void_p(ctypes.addressof(buf))
+        avail_out, next_out = ctypes.c_size_t(0), ctypes.c_void_p(0)
+        assert lib.lib.BrotliEncoderCompressStream(e._s, 3, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                                   ctypes.byref(next_out), None), meta
+        while lib.lib.BrotliEncoderHasMoreOutput(e._s):
+            n = ctypes.c_size_t(0)
+            ptr = lib.lib.BrotliEncoderTakeOutput(e._s, ctypes.byref(n))
+            got += ctypes.string_at(ptr, n.value)
+    got += e.finish()
+    e.close()
+    assert bytes(got) == b"".join(orc.stream_with_flushes(b"", [(Q, 5), (W, 22)], [(0, b"first block"), (0, b"second block")]))
     # BrotliEncoderSetCustomDictionary fixes the hasher parameters on the spot (ensure_initialized inside set_custom_dictionary,
     # encode.rs:1234): with no size hint set, an input of more than 1 MiB still gets the 14-bit bucket table; found by
     # the fuzz sweep
