@@ -24,8 +24,8 @@
  * BROTLI_OPERATION_FLUSH encodes everything received so far (byte-identical to the reference's flush,
  * encode.rs:2940-2975 + 1541-1566) at a cost proportional to window + new input; BROTLI_OPERATION_EMIT_METADATA
  * (encode.rs:2579-2685) flushes pending input the same way and writes the payload (<= 16 MiB) as a metadata block.
- * Limits: one stream may be up to 3 GiB long (the reference's hasher reset at its 3 GiB position wrap,
- * encode.rs:1623-1631, is not reproduced yet: longer streams are refused, not mis-encoded); streams with a custom
+ * A stream may be of any length: the hasher reset of the reference at its position wraps (3, 5, 7 ... GiB,
+ * encode.rs:1623-1631, 1705-1710) is reproduced.  Streams with a custom
  * dictionary or in the catable / appendable modes are buffered whole until BROTLI_OPERATION_FINISH (at most 2 GiB) and
  * cannot be flushed.  All input offered to a call is always consumed (*available_in becomes 0).
  */

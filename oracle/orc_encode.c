@@ -393,11 +393,18 @@ static int should_compress(const uint8_t* data, size_t mask, uint64_t last_flush
   return 1;
 }
 
+/* TEST SWITCH (tests/test_streaming.py): log2 of the unit of the position wrap, 30 (GiB) in the reference.  The
+   reference folds stream positions from 3 units on back into [1, 3) units and empties its hash table whenever the folded
+   position jumps backwards (at 3, 5, 7 ... units).  Scaling the unit down lets the tests drive a stream through several
+   wraps with megabytes instead of gigabytes of input (window and ring buffer must then be smaller than one unit). */
+int orc_test_wrap_shift = 30;
+
 /* encode.rs:1623-1631 */
 static uint32_t wrap_position(uint64_t position) {
+  const int sh = orc_test_wrap_shift;
   uint32_t result = (uint32_t)position;
-  uint64_t gb = position >> 30;
-  if (gb > 2) result = (result & ((1u << 30) - 1)) | ((uint32_t)((gb - 1) & 1) + 1) << 30;
+  uint64_t gb = position >> sh;
+  if (gb > 2) result = (result & ((1u << sh) - 1)) | ((uint32_t)((gb - 1) & 1) + 1) << sh;
   return result;
 }
 

@@ -72,6 +72,7 @@ struct Lz77Buffers {
   uint32_t* rows;       // per position kRowEntries candidates             [16 * total_bytes]
   uint32_t* changed_slot;  // slot of every changed position                [changed_cap]
   uint32_t* row_ctl;    // device-side control words of lz77_rows_update    [4]
+  uint32_t* reset_counts;      // Lz77Params::reset_pos != 0: per key, stored positions in front of reset_vis  [65536]
   const uint32_t* count_base;  // optional, per key: positions stored in front of the text (a later piece of a stream)  [65536]
   uint32_t* run_end;    // optional run table (lz77_run_table), null when the input has no long runs  [total_bytes]
   unsigned long long* smask;  // stored bits of the slots, one word per 64 slots      [total_bytes / 64 + 2]
@@ -162,7 +163,7 @@ struct CacheCheck {
 };
 void lz77_check_cache(const Lz77Params& P, const Lz77Buffers& B, int which, const CacheCheck* items_dev, uint32_t count, uint8_t* ok_dev);
 // out[key] = (base ? base[key] : 0) + number of positions < upto of that key whose stored bit is set in flags[which]
-void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out_dev);
+void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out_dev, bool with_base = true);
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 // work[3] (optional): what those launches did -- positions walked, searches, commands written (all chains, re-parses included)
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments, uint64_t* work = nullptr);

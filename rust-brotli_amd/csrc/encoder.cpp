@@ -219,6 +219,24 @@ void WriteOpenTail(const EncodeRequest& req, Bits* bits) {
   }
 }
 
+// The reference maps stream positions from 3 GiB on back into [1 GiB, 3 GiB) and empties its hash table whenever that
+// mapping jumps backwards, i.e. when the input position passes 3, 5, 7 ... GiB (WrapPosition / update_last_processed_pos
+// / HasherReset, encode.rs:1623-1631, 1705-1710, 2472-2474): the block that starts there searches an empty table (into
+// which StitchToPreviousBlock has just put the three positions in front of it).
+// BROTLI_MI355X_TEST_WRAP_SHIFT: log2 of the unit (30 = GiB); the tests scale it down together with the oracle's.
+namespace {
+int WrapShift() {
+  static const int v = getenv("BROTLI_MI355X_TEST_WRAP_SHIFT") ? atoi(getenv("BROTLI_MI355X_TEST_WRAP_SHIFT")) : 30;
+  return v;
+}
+// largest reset position <= pos (0 if there is none)
+uint64_t LastHasherResetAtOrBelow(uint64_t pos) {
+  const uint64_t unit = 1ull << WrapShift();
+  if (pos < 3 * unit) return 0;
+  return 3 * unit + (pos - 3 * unit) / (2 * unit) * (2 * unit);
+}
+}  // namespace
+
 uint32_t ChooseSegmentBytes(size_t input_bytes) {
   if (input_bytes <= ((size_t)4 << 20)) return 512;
   if (input_bytes <= ((size_t)16 << 20)) return 1024;
@@ -252,11 +270,6 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
     if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
   }
-  // The reference maps stream positions from 3 GiB on back into [1 GiB, 3 GiB) and empties its hash table whenever
-  // that mapping jumps backwards, i.e. at 3, 5, 7 ... GiB (WrapPosition / update_last_processed_pos / HasherReset,
-  // encode.rs:1623-1631, 1705-1710, 2472-2474).  That reset is not reproduced yet: refuse instead of diverging.
-  if ((continuing ? req.carry_in->stream_base : 0) + (uint64_t)req.prefix_size + (uint64_t)n > (3ull << 30))
-    throw std::runtime_error("brotli_mi355x: streams longer than 3 GiB are not supported yet (the reference resets its hasher at the 3 GiB position wrap)");
   const char* why = nullptr;
   if (!IsAccelerated(p, &why)) throw std::runtime_error(std::string("brotli_mi355x: ") + why);
   bool catable = p.catable;
@@ -376,6 +389,16 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     Clock c;
     lz.SetStreamState(continuing ? req.carry_in : nullptr, req.finish, req.partial && !req.finish, req.last_block_processed_early);
     lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, segment_bytes);
+    {
+      // a hasher reset inside this input?  (One that coincides with its start has been applied to the carry already.)
+      const uint64_t base = continuing ? req.carry_in->stream_base : 0;
+      const uint64_t reset = LastHasherResetAtOrBelow(base + M - 1);
+      if (reset > base + prefix_bytes) {
+        if (LastHasherResetAtOrBelow(reset - 1) > base + prefix_bytes)
+          throw std::runtime_error("brotli_mi355x: two hasher resets (position wraps) inside one piece of a stream");
+        lz.SetHasherReset((uint32_t)(reset - base));
+      }
+    }
     stats.ms_phase[9] = c.lap(prof);
   }
   for (;;) {  // repeated only when a compressed meta-block turns out larger than its raw form
@@ -710,9 +733,21 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       if (abs_resume >= 2 * ring && !getenv("BROTLI_MI355X_KEEP_WHOLE_STREAM")) new_base = (abs_resume - ring) / ring * ring;
       const uint32_t keep_from = (uint32_t)(new_base - old_base);
       co.stream_base = new_base;
-      if (keep_from != 0 || (continuing && req.carry_in->key_counts.size() == 65536)) lz.KeyCountsBefore(keep_from, &co.key_counts);
       std::vector<uint8_t> all(M);
       lz.DumpFlags(all.data(), M);
+      // a hasher reset at or in front of the resume point wipes what lies before it (minus the three stitched positions)
+      const uint64_t reset = LastHasherResetAtOrBelow(abs_resume);
+      if (reset > old_base) {
+        const uint32_t vis = (uint32_t)(reset - old_base) - 3;
+        for (uint32_t q = 0; q < vis && q < resume; ++q) all[q] = 0;
+        if (keep_from > vis) {
+          lz.KeyCountsBetween(vis, keep_from, &co.key_counts);
+        } else {
+          co.key_counts.assign(65536, 0);
+        }
+      } else if (keep_from != 0 || (continuing && req.carry_in->key_counts.size() == 65536)) {
+        lz.KeyCountsBefore(keep_from, &co.key_counts);
+      }
       co.stored.assign(all.begin() + keep_from, all.begin() + resume);
       for (uint8_t& f : co.stored) f &= 1;
       if (tail_nbits) {

@@ -313,9 +313,22 @@ __global__ __launch_bounds__(256) void k_key_bases(const uint8_t* __restrict__ f
 // (mod.rs:1752-1760) counts the insertions since the start of the STREAM (base = those in front of this text), but no
 // more entries than were inserted within this text can be reached (older ones lie beyond max_backward: the text of a
 // later piece of a stream starts at least a window in front of its input).
+// (positions behind a hasher reset, Lz77Params::reset_pos: only the insertions since the reset count, and nothing older
+// can be reached)
+__device__ __forceinline__ uint32_t ring_count_at(uint32_t p, uint32_t local_rank, uint32_t key, const uint32_t* count_base, uint32_t reset_pos,
+                                                  const uint32_t* reset_counts);
 __device__ __forceinline__ uint32_t ring_count(uint32_t local_rank, uint32_t base) {
   const uint32_t num = (local_rank + base) & 0xffffu;
   return num < local_rank ? num : local_rank;
+}
+
+__device__ __forceinline__ uint32_t ring_count_at(uint32_t p, uint32_t local_rank, uint32_t key, const uint32_t* count_base, uint32_t reset_pos,
+                                                  const uint32_t* reset_counts) {
+  if (reset_pos != 0 && p >= reset_pos) {
+    const uint32_t since = local_rank - reset_counts[key];
+    return since & 0xffffu;  // (since <= local_rank: what was inserted before the reset is out of reach)
+  }
+  return ring_count(local_rank, count_base ? count_base[key] : 0u);
 }
 
 // pass B: local ranks -> sorted / info
@@ -323,7 +336,8 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
                                                      const uint8_t* __restrict__ fbits, uint32_t n, const uint32_t* __restrict__ tile_offsets,
                                                      const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_base,
                                                      uint32_t* __restrict__ sorted, uint2* __restrict__ info,
-                                                     const uint32_t* __restrict__ count_base) {
+                                                     const uint32_t* __restrict__ count_base, uint32_t reset_pos,
+                                                     const uint32_t* __restrict__ reset_counts) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
   uint32_t pos[4], f[4], key[4];
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
     if (base + j < n) {
       const uint32_t lr = g - key_base[key[j]];
       const uint32_t slot = key_first[key[j]] + lr;
-      info[pos[j]] = make_uint2(slot, ring_count(lr, count_base ? count_base[key[j]] : 0u));
+      info[pos[j]] = make_uint2(slot, ring_count_at(pos[j], lr, key[j], count_base, reset_pos, reset_counts));
       if (f[j]) sorted[slot] = pos[j];
       g += f[j];
     }
@@ -389,11 +403,12 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
+  if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
-                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base);
+                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base, P.reset_pos, B.reset_counts);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -503,7 +518,8 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
                                                        const uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
                                                        const uint32_t* __restrict__ sorted_tmp, SegGeometry geo,
                                                        uint8_t* __restrict__ dirty, const uint32_t* __restrict__ count_base,
-                                                       const uint16_t* __restrict__ keys) {
+                                                       const uint16_t* __restrict__ keys, uint32_t reset_pos,
+                                                       const uint32_t* __restrict__ reset_counts) {
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
     if (!searched && in_front == 0xffffffffu) continue;
     const uint2 a = info[p];
     const uint32_t rb = rank_tmp[i];
-    const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(ring_count(rb, count_base ? count_base[keys[p]] : 0u), geo.block_size);
+    const uint32_t na = min(a.y & 0xffffu, geo.block_size), nb = min(ring_count_at(p, rb, keys[p], count_base, reset_pos, reset_counts), geo.block_size);
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted[a.x - 1 - j] == sorted_tmp[c.key_lo + rb - 1 - j];
     if (!same && br_row_change_matters(text, p, sorted + a.x - 1, na, sorted_tmp + c.key_lo + rb - 1, nb)) {
@@ -526,12 +542,13 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
 __global__ __launch_bounds__(256) void k_rerank_commit(const RerankChunk* __restrict__ chunks, const uint32_t* __restrict__ by_key,
                                                         const uint8_t* __restrict__ flags, uint32_t* __restrict__ sorted,
                                                         uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
-                                                        const uint32_t* __restrict__ count_base, const uint16_t* __restrict__ keys) {
+                                                        const uint32_t* __restrict__ count_base, const uint16_t* __restrict__ keys,
+                                                        uint32_t reset_pos, const uint32_t* __restrict__ reset_counts) {
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
     const uint32_t rb = rank_tmp[i];
-    info[p] = make_uint2(c.key_lo + rb, ring_count(rb, count_base ? count_base[keys[p]] : 0u));
+    info[p] = make_uint2(c.key_lo + rb, ring_count_at(p, rb, keys[p], count_base, reset_pos, reset_counts));
     if (flags[p] & 1u) sorted[c.key_lo + rb] = p;
   }
 }
@@ -541,12 +558,13 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   if (num_chunks == 0 || P.total_bytes == 0) return;
   uint32_t* rank_tmp = (uint32_t*)B.sort_tmp;
   uint32_t* sorted_tmp = rank_tmp + (((size_t)P.total_bytes + 63) & ~(size_t)63);
+  if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], sums_dev);
   hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
   hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, BR_STREAM, B.text, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
-                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev, B.count_base, B.keys);
+                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev, B.count_base, B.keys, P.reset_pos, B.reset_counts);
   hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
-                     (uint2*)B.info[rbuf], rank_tmp, B.count_base, B.keys);
+                     (uint2*)B.info[rbuf], rank_tmp, B.count_base, B.keys, P.reset_pos, B.reset_counts);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -566,6 +584,7 @@ struct RowArgs {
   uint32_t* rows;
   const uint8_t* flags;  // newest per-position flags (the searched bit decides who is affected by a changed row)
   uint32_t n, depth, max_backward_limit;
+  uint32_t reset_pos, reset_vis;  // Lz77Params
   uint32_t validate;     // compare with the row in memory and mark the chains that searched a position whose row changed
   SegGeometry geo;
   uint8_t* dirty;
@@ -656,6 +675,7 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
       const uint32_t p = s_pos[e], tk = s_tk[e];
       const uint32_t key = tk >> 16, tag = tk & 0xffffu;
       const uint32_t max_backward = p < a.max_backward_limit ? p : a.max_backward_limit;
+      const uint32_t oldest = p >= a.reset_pos ? a.reset_vis : 0u;
       uint32_t* out = &rowbuf[w][lane * kRowEntries];
       uint32_t k = s_rank[e], n = 0, seen = 0;
       const uint32_t depth = (s_fb[e] & kSlotWrap) ? 0u : a.depth;
@@ -669,13 +689,13 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
         const uint2 ent = c_ent[k];
         if ((ent.y >> 16) != key) break;
         const uint32_t q = ent.x & 0x7fffffffu;
-        if (p - q > max_backward) break;
+        if (p - q > max_backward || q < oldest) break;
         ++seen;
         if ((ent.y & 0xffffu) == tag) out[n++] = q;
         if (ent.x >> 31) break;
       }
       if (slow) {
-        br_collect_row(sl, a.max_backward_limit, lo + e, a.key_first[key], a.depth, out);
+        br_collect_row(sl, a.max_backward_limit, lo + e, a.key_first[key], a.depth, out, a.reset_pos, a.reset_vis);
       } else {
         for (; n < kRowEntries; ++n) out[n] = kRowEnd;
       }
@@ -757,7 +777,9 @@ __global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits,
                                                      const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
                                                      const uint32_t* __restrict__ key_base, uint32_t append,
                                                      uint32_t* __restrict__ changed_slot, const uint32_t* __restrict__ changed_count, uint32_t cap,
-                                                     uint32_t* __restrict__ ctl, const uint32_t* __restrict__ count_base) {
+                                                     uint32_t* __restrict__ ctl, const uint32_t* __restrict__ count_base,
+                                                     const uint32_t* __restrict__ by_key, uint32_t reset_pos,
+                                                     const uint32_t* __restrict__ reset_counts) {
   if (!big_tile[blockIdx.x]) return;
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kRowTile + threadIdx.x * 4;
@@ -784,9 +806,11 @@ __global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits,
     if (i < n) {
       const uint32_t key = sorted_keys[i];
       bool want = false;
-      if (count_base != nullptr || key_last[key] - key_first[key] >= 65536u) {
-        // insertions into the key's ring in front of this slot, since the start of the stream
-        const uint32_t count = g - key_base[key] + (count_base ? count_base[key] : 0u);
+      if (count_base != nullptr || reset_pos != 0 || key_last[key] - key_first[key] >= 65536u) {
+        // insertions into the key's ring in front of this slot: since the start of the stream, or since the hasher reset
+        uint32_t count = g - key_base[key];
+        if (reset_pos != 0 && by_key[i] >= reset_pos) count -= reset_counts[key];
+        else count += count_base ? count_base[key] : 0u;
         want = count != 0 && (count & 0xffffu) == 0;
       }
       if (want != ((f[j] & kSlotWrap) != 0)) {
@@ -870,7 +894,7 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
       const unsigned long long m = __ballot(st);
       const uint32_t before = (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
       if (in && stable + before < a.depth) {
-        if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true)) row_changed(a, a.by_key[i]);
+        if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true, a.reset_pos, a.reset_vis)) row_changed(a, a.by_key[i]);
       }
       stable += (uint32_t)__popcll(m);
       if (threadIdx.x == 0) atomicAdd(&a.walk_counter[kCtlWalked], 64u);
@@ -898,6 +922,8 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.n = P.total_bytes;
   a.depth = 1u << P.block_bits;
   a.max_backward_limit = P.max_backward_limit;
+  a.reset_pos = P.reset_pos;
+  a.reset_vis = P.reset_vis;
   a.validate = validate ? 1 : 0;
   if (geo) a.geo = *geo;
   a.dirty = dirty_dev;
@@ -998,10 +1024,12 @@ static void launch_wrap_marks(const Lz77Params& P, const Lz77Buffers& B, bool ap
   uint32_t* scratch = tile_sums + tiles + 64;
   hipLaunchKernelGGL(k_fbits_tile_sums, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums);
   exclusive_scan_u32(tile_sums, tiles, scratch);
+  const bool all_keys = B.count_base != nullptr || P.reset_pos != 0;
   hipLaunchKernelGGL(k_row_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base,
-                     B.count_base ? 1u : 0u);
+                     all_keys ? 1u : 0u);
   hipLaunchKernelGGL(k_mark_wraps, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums, B.sorted_keys, B.key_first, B.key_last,
-                     B.key_base, append ? 1u : 0u, B.changed_slot, B.changed_count, B.changed_cap, B.row_ctl, B.count_base);
+                     B.key_base, append ? 1u : 0u, B.changed_slot, B.changed_count, B.changed_cap, B.row_ctl, B.count_base, B.by_key, P.reset_pos,
+                     B.reset_counts);
 }
 
 void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const RankInitialHint* initial, bool has_big_keys) {
@@ -1021,9 +1049,11 @@ void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const 
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
   HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
+  if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   if (has_big_keys) {
     HIP_CHECK(hipMemsetAsync(B.big_tile, 0, tiles + 64, BR_STREAM));
-    hipLaunchKernelGGL(k_flag_big_tiles, dim3(256), dim3(256), 0, BR_STREAM, B.key_first, B.key_last, B.big_tile, B.count_base ? 1u : 0u);
+    hipLaunchKernelGGL(k_flag_big_tiles, dim3(256), dim3(256), 0, BR_STREAM, B.key_first, B.key_last, B.big_tile,
+                       (B.count_base || P.reset_pos) ? 1u : 0u);
     launch_wrap_marks(P, B, false);
   }
   launch_slot_masks(P, B);
@@ -1045,6 +1075,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   uint32_t gather_blocks = (n + 255) / 256;
   if (gather_blocks > 8192) gather_blocks = 8192;
   hipLaunchKernelGGL(k_regather_fbits, dim3(gather_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.flags[next], n, B.fbits, B.row_ctl);
+  if (P.reset_pos) lz77_key_counts(P, B, next, P.reset_vis, B.reset_counts, false);
   if (has_big_keys) launch_wrap_marks(P, B, true);
   launch_slot_masks(P, B);
   RowArgs a = row_args(P, B, next, true, &geo, dirty_dev);
@@ -1072,9 +1103,10 @@ __global__ __launch_bounds__(64) void k_key_counts(const uint32_t* __restrict__ 
   if (threadIdx.x == 0) out[key] = local + (base ? base[key] : 0u);
 }
 
-void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out_dev) {
+void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out_dev, bool with_base) {
   (void)P;
-  hipLaunchKernelGGL(k_key_counts, dim3(65536), dim3(64), 0, BR_STREAM, B.by_key, B.flags[which], B.key_first, B.key_last, B.count_base, upto, out_dev);
+  hipLaunchKernelGGL(k_key_counts, dim3(65536), dim3(64), 0, BR_STREAM, B.by_key, B.flags[which], B.key_first, B.key_last,
+                     with_base ? B.count_base : (const uint32_t*)nullptr, upto, out_dev);
   HIP_CHECK(hipGetLastError());
 }
 

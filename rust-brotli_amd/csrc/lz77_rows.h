@@ -46,8 +46,10 @@ static constexpr uint32_t kSlotStored = 1, kSlotChanged = 2, kSlotWrap = 4;
 // -- cut where the bucket walk breaks (backward > max_backward, :1769-1776), without the entries whose tag differs
 // (FindMatchLengthWithLimitMin4 returns 0 for them, static_dict.rs:134-147); the rest of the row is kRowEnd.
 template <typename Slots>
-BR_DEV void br_collect_row(const Slots& sl, uint32_t max_backward_limit, uint32_t i, uint32_t kf, uint32_t depth, uint32_t* out) {
+BR_DEV void br_collect_row(const Slots& sl, uint32_t max_backward_limit, uint32_t i, uint32_t kf, uint32_t depth, uint32_t* out,
+                           uint32_t reset_pos = 0, uint32_t reset_vis = 0) {
   const uint32_t p = sl.pos(i), tag = sl.tag(i);
+  const uint32_t oldest = p >= reset_pos ? reset_vis : 0u;  // nothing inserted before a hasher reset is seen behind it
   const uint32_t max_backward = p < max_backward_limit ? p : max_backward_limit;
   uint32_t n = 0, seen = 0;
   if (sl.fb(i) & kSlotWrap) depth = 0;
@@ -57,7 +59,7 @@ BR_DEV void br_collect_row(const Slots& sl, uint32_t max_backward_limit, uint32_
     j = nj - 1;
     const uint32_t fb = sl.fb(j);
     const uint32_t q = sl.pos(j);
-    if (p - q > max_backward) break;
+    if (p - q > max_backward || q < oldest) break;
     ++seen;
     if (sl.tag(j) == tag) out[n++] = q;
     if (fb & kSlotWrap) break;
@@ -68,9 +70,9 @@ BR_DEV void br_collect_row(const Slots& sl, uint32_t max_backward_limit, uint32_
 // Writes the row of slot i to rows[].  compare: only differing words are written; returns whether the row in memory changed.
 template <typename Slots>
 BR_DEV bool br_build_row(const Slots& sl, uint32_t* rows, uint32_t max_backward_limit, uint32_t i, uint32_t kf, uint32_t depth,
-                         bool compare) {
+                         bool compare, uint32_t reset_pos = 0, uint32_t reset_vis = 0) {
   uint32_t fresh[kRowEntries];
-  br_collect_row(sl, max_backward_limit, i, kf, depth, fresh);
+  br_collect_row(sl, max_backward_limit, i, kf, depth, fresh, reset_pos, reset_vis);
   uint32_t* row = rows + (size_t)sl.pos(i) * kRowEntries;
   bool changed = false;
   for (uint32_t n = 0; n < kRowEntries; ++n) {

@@ -43,6 +43,7 @@ void Lz77Stage::Release() {
     dev_free(B_.run_end);
     dev_free(count_base_dev_);
     count_base_dev_ = nullptr;
+    dev_free(B_.reset_counts);
     dev_free(B_.smask);
     dev_free(B_.gprev);
     dev_free(B_.flags[0]);
@@ -125,6 +126,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
   }
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
+  B_.reset_counts = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.flags[0] = (uint8_t*)dev_alloc(M + 64);
   B_.flags[1] = (uint8_t*)dev_alloc(M + 64);
   cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
@@ -839,6 +841,7 @@ void Lz77Stage::Run() {
   } else {
     B_.count_base = nullptr;
   }
+  if (P_.reset_pos) has_big_keys_ = true;  // (the ring counters start over inside this text: wrap marks for every key)
   tm.stop(&stats_.ms_sort);
   RunRounds(true);
   tm.stop(&stats_.ms_resolve);
@@ -1284,29 +1287,32 @@ void Lz77Stage::SelfTestRows(int which) {
     return (uint32_t)((v * 0x9E3779B1u) >> 16);
   };
   const uint32_t depth = 1u << P_.block_bits;
-  uint32_t first = 0, stored_before = 0, local_before = 0;
+  uint32_t first = 0, stored_before = 0, local_before = 0, since_reset = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t p = by_key[i];
     if (i == 0 || skeys[i - 1] != skeys[i]) {
       first = i;
       stored_before = B_.count_base ? carry_->key_counts[skeys[i]] : 0u;
       local_before = 0;
+      since_reset = 0;
     }
+    const uint32_t counter = (P_.reset_pos != 0 && p >= P_.reset_pos) ? since_reset : stored_before;
     if ((fbits[i] & 1) != (flags[p] & 1)) throw std::runtime_error("selftest: fbits mismatch at slot " + std::to_string(i));
     if (fbits[i] & 2) throw std::runtime_error("selftest: leftover change mark at slot " + std::to_string(i));
     {
-      const bool big = B_.count_base != nullptr || key_last_[skeys[i]] - key_first_[skeys[i]] >= 65536u;
-      const bool want_wrap = big && stored_before != 0 && (stored_before & 0xffffu) == 0;
+      const bool big = P_.reset_pos != 0 || B_.count_base != nullptr || key_last_[skeys[i]] - key_first_[skeys[i]] >= 65536u;
+      const bool want_wrap = big && counter != 0 && (counter & 0xffffu) == 0;
       if (want_wrap != ((fbits[i] & 4) != 0)) throw std::runtime_error("selftest: wrap mark mismatch at slot " + std::to_string(i));
     }
     const uint32_t max_backward = std::min(p, P_.max_backward_limit);
-    const uint32_t d = std::min(depth, stored_before & 0xffffu);
+    const uint32_t d = std::min(depth, counter & 0xffffu);
+    const uint32_t oldest = p >= P_.reset_pos ? P_.reset_vis : 0u;
     std::vector<uint32_t> want;
     uint32_t seen = 0;
     for (uint32_t j = i; j > first && seen < d;) {
       --j;
       if (!(flags[by_key[j]] & 1)) continue;
-      if (p - by_key[j] > max_backward) break;
+      if (p - by_key[j] > max_backward || by_key[j] < oldest) break;
       ++seen;
       if (tag(by_key[j]) == tag(p)) want.push_back(by_key[j]);
     }
@@ -1319,8 +1325,20 @@ void Lz77Stage::SelfTestRows(int which) {
     }
     stored_before += flags[p] & 1;
     local_before += flags[p] & 1;
+    if (P_.reset_pos != 0 && p >= P_.reset_vis) since_reset += flags[p] & 1;
   }
   (void)local_before;
+}
+
+void Lz77Stage::KeyCountsBetween(uint32_t from, uint32_t upto, std::vector<uint32_t>* out) {
+  uint32_t* dev = (uint32_t*)dev_alloc(2 * 65536 * 4);
+  lz77_key_counts(P_, B_, final_flags_, upto, dev, false);
+  lz77_key_counts(P_, B_, final_flags_, from, dev + 65536, false);
+  std::vector<uint32_t> both(2 * 65536);
+  dev_d2h(both.data(), dev, both.size() * 4);
+  dev_free(dev);
+  out->resize(65536);
+  for (uint32_t k = 0; k < 65536; ++k) (*out)[k] = both[k] - both[65536 + k];
 }
 
 void Lz77Stage::KeyCountsBefore(uint32_t upto, std::vector<uint32_t>* out) {

@@ -97,6 +97,14 @@ class Lz77Stage {
   // flush rule (encode.rs:2454-2477) closes by itself are planned; resume_pos() is where the first open one starts --
   // the next piece starts there again.
   uint32_t resume_pos() const { return resume_pos_; }
+  // text position (a block start inside the input, or 0) at which the reference's hasher is reset by its 32-bit position
+  // wrap (Lz77Params::reset_pos); call after Setup()
+  void SetHasherReset(uint32_t pos) {
+    P_.reset_pos = pos;
+    P_.reset_vis = pos >= 3 ? pos - 3 : 0;
+  }
+  // stored positions per key in [from, upto) without the carried-in counts
+  void KeyCountsBetween(uint32_t from, uint32_t upto, std::vector<uint32_t>* out);
   // stored positions per hash key in front of text position `upto` (added to the carried-in counts): the key_counts of
   // the next piece when it keeps text[upto ..) as its prefix
   void KeyCountsBefore(uint32_t upto, std::vector<uint32_t>* out);

@@ -46,6 +46,10 @@ struct Lz77Params {
   uint32_t cmd_slab_stride;     // commands reserved per segment
   uint32_t dist_postfix_bits;   // params.dist (encode.rs:2169-2190)
   uint32_t num_direct_distance_codes;
+  // Hasher reset inside this text (0 = none): the reference empties its hash table when its 32-bit position wraps
+  // (encode.rs:1623-1631, 1705-1710, 2472-2474).  Searches at positions >= reset_pos see only what was inserted from
+  // reset_vis on (= reset_pos - 3: StitchToPreviousBlock re-inserts the last three positions of the block in front).
+  uint32_t reset_pos, reset_vis;
   uint32_t reserved;
 };
 

@@ -126,9 +126,9 @@ static uint32_t emu_ring_count(uint32_t local_rank, uint32_t base) {
   return num < local_rank ? num : local_rank;
 }
 
-void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out) {
+void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint32_t upto, uint32_t* out, bool with_base) {
   for (uint32_t key = 0; key < 65536; ++key) {
-    uint32_t c = B.count_base ? B.count_base[key] : 0u;
+    uint32_t c = (with_base && B.count_base) ? B.count_base[key] : 0u;
     for (uint32_t i = B.key_first[key]; i < B.key_last[key]; ++i)
       if (B.by_key[i] < upto) c += B.flags[which][B.by_key[i]] & 1u;
     out[key] = c;
@@ -136,7 +136,13 @@ void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint3
   (void)P;
 }
 
+static uint32_t emu_ring_count_at(const Lz77Params& P, const Lz77Buffers& B, uint32_t p, uint32_t local_rank, uint32_t key) {
+  if (P.reset_pos != 0 && p >= P.reset_pos) return (local_rank - B.reset_counts[key]) & 0xffffu;
+  return emu_ring_count(local_rank, B.count_base ? B.count_base[key] : 0u);
+}
+
 void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RankInitialHint*) {
+  if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   const uint32_t n = P.total_bytes;
   uint32_t first = 0, local = 0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -146,7 +152,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
       local = 0;
     }
     B.info[rbuf][2 * (size_t)pos] = first + local;
-    B.info[rbuf][2 * (size_t)pos + 1] = emu_ring_count(local, B.count_base ? B.count_base[B.sorted_keys[i]] : 0u);
+    B.info[rbuf][2 * (size_t)pos + 1] = emu_ring_count_at(P, B, pos, local, B.sorted_keys[i]);
     if (B.flags[which][pos] & 1) B.sorted[rbuf][first + local++] = pos;
   }
 }
@@ -177,8 +183,8 @@ static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
 
 void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RerankChunk* chunks, uint32_t num_chunks,
                       uint32_t* sums, const SegGeometry& geo, uint8_t* dirty) {
-  (void)P;
   (void)sums;
+  if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   const uint8_t* flags = B.flags[which];
   for (uint32_t e = 0; e < num_chunks; ++e) {
     if (chunks[e].first_sum != chunks[e].my_sum) continue;  // one pass per key, at its first chunk
@@ -198,8 +204,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
       if (!searched && in_front == 0xffffffffu) continue;
       const uint32_t ax = B.info[rbuf][2 * (size_t)p], ay = B.info[rbuf][2 * (size_t)p + 1];
       const uint32_t rb = new_rank[i - lo];
-      const uint32_t cb = B.count_base ? B.count_base[B.keys[p]] : 0u;
-      const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(emu_ring_count(rb, cb), geo.block_size);
+      const uint32_t na = std::min(ay & 0xffffu, geo.block_size), nb = std::min(emu_ring_count_at(P, B, p, rb, B.keys[p]), geo.block_size);
       bool same = na == nb;
       for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf][ax - 1 - j] == new_sorted[rb - 1 - j];
       if (!same && br_row_change_matters(B.text, p, B.sorted[rbuf] + ax - 1, na, new_sorted.data() + rb - 1, nb)) {
@@ -210,7 +215,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t p = B.by_key[i];
       B.info[rbuf][2 * (size_t)p] = lo + new_rank[i - lo];
-      B.info[rbuf][2 * (size_t)p + 1] = emu_ring_count(new_rank[i - lo], B.count_base ? B.count_base[B.keys[p]] : 0u);
+      B.info[rbuf][2 * (size_t)p + 1] = emu_ring_count_at(P, B, p, new_rank[i - lo], B.keys[p]);
     }
     for (size_t j = 0; j < new_sorted.size(); ++j) B.sorted[rbuf][lo + j] = new_sorted[j];
   }
@@ -244,17 +249,22 @@ static void emu_build_all_rows(const Lz77Params& P, const Lz77Buffers& B, int wh
   const uint32_t n = P.total_bytes;
   const uint32_t depth0 = 1u << P.block_bits;
   SlotsInMemory sl{B.by_key, B.fbits, B.stag, B.smask, B.gprev};
-  uint32_t kf = 0, stored_before = 0;
+  uint32_t kf = 0, stored_before = 0, since_reset = 0;
   for (uint32_t i = 0; i < n; ++i) {
     if (i == 0 || B.sorted_keys[i - 1] != B.sorted_keys[i]) {
       kf = i;
       stored_before = B.count_base ? B.count_base[B.sorted_keys[i]] : 0u;
+      since_reset = 0;
     }
     const uint32_t key = B.sorted_keys[i];
     uint32_t depth = depth0;
-    if (B.count_base || B.key_last[key] - kf >= 65536u) depth = std::min(depth, stored_before & 0xffffu);
-    if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, validate) && validate) emu_row_changed(B, which, B.by_key[i], *geo, dirty);
+    // (searches behind a hasher reset count the insertions from reset_vis on; those in front of it all of them)
+    const uint32_t count = (P.reset_pos != 0 && B.by_key[i] >= P.reset_pos) ? since_reset : stored_before;
+    if (P.reset_pos || B.count_base || B.key_last[key] - kf >= 65536u) depth = std::min(depth, count & 0xffffu);
+    if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, validate, P.reset_pos, P.reset_vis) && validate)
+      emu_row_changed(B, which, B.by_key[i], *geo, dirty);
     stored_before += B.fbits[i] & 1u;
+    if (P.reset_pos != 0 && B.by_key[i] >= P.reset_vis) since_reset += B.fbits[i] & 1u;
   }
 }
 
@@ -278,7 +288,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
       const uint32_t p = B.changed_keys[c];
       const uint32_t key = B.keys[p];
       uint32_t lo = B.key_first[key], hi = B.key_last[key];
-      if (hi - lo >= 65536u || B.count_base) need_full = true;
+      if (hi - lo >= 65536u || B.count_base || P.reset_pos) need_full = true;
       while (lo + 1 < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
         if (B.by_key[mid] <= p) lo = mid; else hi = mid;
@@ -296,7 +306,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
       const uint32_t kf = B.key_first[key], kl = B.key_last[key];
       uint32_t stable = 0;
       for (uint32_t i = s + 1; i < kl && stable < depth; ++i) {
-        if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, true)) emu_row_changed(B, next, B.by_key[i], geo, dirty);
+        if (br_build_row(sl, B.rows, P.max_backward_limit, i, kf, depth, true, P.reset_pos, P.reset_vis)) emu_row_changed(B, next, B.by_key[i], geo, dirty);
         if ((B.fbits[i] & 3u) == 1u) ++stable;
       }
     }

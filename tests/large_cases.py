@@ -33,6 +33,12 @@ for _n in (2, 4, 8):
                                                     bench_only=True)
 
 
+# a single stream longer than the reference's 32-bit position wrap (hasher reset at 3 GiB), fed CompressorWriter style in
+# 4 MiB writes: bounded-memory streaming at full scale (tests/test_streaming.py has the scaled-down versions)
+CASES["stream_4GiB_q5_w22"] = dict(make=lambda: synth.markov_text(4 << 30, 0x5EED00000000000A), quality=5, lgwin=22, writer_chunk=4 << 20,
+                                   bench_only=True)
+
+
 def make_input(name, frozen=None):
     """the input of case `name`; multi-shard cases use the seed recorded in tests/golden/large_hashes.json"""
     case = CASES[name]

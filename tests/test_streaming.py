@@ -55,9 +55,13 @@ print("OK flush in a trimmed stream")
 '''
 
 
-def _run(kind, cases, batch):
+def _run(kind, cases, batch, wrap_shift=0):
     env = dict(os.environ, BROTLI_MI355X_STREAM_BATCH=str(batch))
     code = _DRIVER % dict(tests=HERE, kind=kind, cases=repr(cases))
+    if wrap_shift:
+        # scale the position wrap of the reference (3, 5, 7 ... GiB) down to MiB, in the product and in the oracle
+        env["BROTLI_MI355X_TEST_WRAP_SHIFT"] = str(wrap_shift)
+        code = code.replace("lib = test_cabi._load", "import ctypes; ctypes.c_int.in_dll(orc.lib(), 'orc_test_wrap_shift').value = %d\nlib = test_cabi._load" % wrap_shift)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=3000)
     sys.stdout.write(r.stdout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -86,3 +90,20 @@ def test_streaming_pieces_gpu():
 def test_streaming_default_batches_gpu():
     """the default 64 MiB batches at lgwin 22: a 200 MiB stream fed in 4 MiB writes"""
     _run("gpu", [("markov 200 MiB q5 w22", "synth.markov_text(200 << 20, 7)", 5, 22, 4 << 20)], 64 << 20)
+
+
+WRAP_CASES = [
+    # unit 1 MiB: the hasher is reset when the stream passes 3, 5 and 7 MiB (encode.rs:1623-1631, 1705-1710) -- once
+    # inside a piece, once exactly between two pieces, with the candidate rows (q5) and with the rank structures (q7)
+    ("markov 8 MiB q5 w17, wraps at 3/5/7 MiB", "synth.markov_text(8 << 20, 21)", 5, 17, 65536),
+    ("mixed 6 MiB q7 w17, wraps at 3/5 MiB", "synth.mixed(6 << 20, 22)", 7, 17, 50000),
+]
+
+
+def test_hasher_reset_at_position_wrap_emu():
+    _run("emu", WRAP_CASES, 512 << 10, wrap_shift=20)
+
+
+@pytest.mark.gpu
+def test_hasher_reset_at_position_wrap_gpu():
+    _run("gpu", WRAP_CASES, 512 << 10, wrap_shift=20)

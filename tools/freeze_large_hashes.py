@@ -30,7 +30,9 @@ def main():
             data = case["make"]() if seed is None else case["make"](seed)
             t1 = time.time()
             try:
-                if case.get("shards"):
+                if case.get("writer_chunk"):
+                    out = orc.writer_compress(data, case["quality"], case["lgwin"], chunk=case["writer_chunk"])
+                elif case.get("shards"):
                     out = orc.compress_multi(data, [(1, case["quality"]), (2, case["lgwin"])], case["shards"])
                 else:
                     out = orc.compress(data, case["quality"], case["lgwin"])
