@@ -103,3 +103,35 @@ def test_silesia_like_64MiB_multi_8_shards_against_live_oracle(L):
     got = bytes(brotli_mi355x.default_library().BrotliCompress(data, {1: 5, 2: 22}, 8))
     assert got == orc.compress_multi(data, [(1, 5), (2, 22)], 8)
     assert orc.decompress(got, len(data)) == data
+
+
+def test_stream_4GiB_bounded_memory(L):
+    """A single 4 GiB stream fed CompressorWriter style (4 MiB writes, then FINISH) through BrotliEncoderCompressStream:
+    encoded batch by batch with only a window of the stream kept (the encoder's input buffer never exceeds window + batch),
+    through the reference's hasher reset at the 3 GiB position wrap (encode.rs:1623-1631, 1705-1710), output handed out
+    during PROCESS -- and the same bytes as the oracle's stream encoder fed the same way (frozen: it needs three minutes)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "rust-brotli_amd"))
+    import brotli_mi355x
+    name = "stream_4GiB_q5_w22"
+    data = _input(name)
+    lib = brotli_mi355x.default_library()
+    e = lib.encoder(params=[(Q, 5), (W, 22)])
+    h = hashlib.sha256()
+    total = 0
+    chunk = large_cases.CASES[name]["writer_chunk"]
+    early = 0
+    for i in range(0, len(data), chunk):
+        e.write(data[i:i + chunk])
+        if e._out:
+            h.update(e._out)
+            total += len(e._out)
+            early = total
+            e._out = bytearray()
+    tail = e.finish()
+    e.close()
+    h.update(tail)
+    total += len(tail)
+    assert early > total // 2, "PROCESS did not hand out output mid-stream"
+    assert total == FROZEN[name]["stream_bytes"]
+    assert h.hexdigest() == FROZEN[name]["stream_sha256"]
