@@ -465,15 +465,17 @@ BR_DEV void mb_append_bits(BitSink& out, const uint64_t* words, uint32_t nbits) 
 }
 
 // ---- K6: header of one meta-block (store_meta_block up to the entropy codes, brotli_bit_stream.rs:2074-2191)
-BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch* sc) {
+// staging != nullptr: the bits are composed there (zeroed by the caller, e.g. in LDS) instead of in B.header_words
+BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch* sc, uint64_t* staging = nullptr) {
   const MbDesc d = B.descs[m];
   MbResult& r = B.results[m];
   if (d.uncompressed) {
     r.header_bits = 0;
     return;
   }
-  uint64_t* words = B.header_words + (size_t)m * kHeaderWords;
-  for (uint32_t i = 0; i < kHeaderWords; ++i) words[i] = 0;
+  uint64_t* words = staging ? staging : B.header_words + (size_t)m * kHeaderWords;
+  if (!staging)
+    for (uint32_t i = 0; i < kHeaderWords; ++i) words[i] = 0;
   BitSink out;
   out.words = words;
   out.pos = 0;

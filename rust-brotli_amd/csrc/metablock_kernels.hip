@@ -176,10 +176,43 @@ void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs
   HIP_CHECK(hipGetLastError());
 }
 
+// The header of a meta-block is a sequential bit string (block-split codes, context map, then the serialised trees that
+// k_build_codes prepared): one lane composes it -- in LDS, where a read-modify-write of the word under the cursor costs
+// a few cycles instead of a trip to L2 -- and the wave copies the finished words out.  Headers that might not fit the
+// LDS buffer (hundreds of literal histograms) are composed in global memory as before.
 __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
+  constexpr uint32_t kLdsWords = 5120;            // 40 KiB
+  constexpr uint64_t kOtherBits = 160u * 1024u;   // generous bound for everything but the trees (a 16 Ki-entry context map)
+  __shared__ uint64_t lw[kLdsWords];
+  __shared__ HuffmanScratch sc_lds;  // (the scratch of the small trees -- block-split codes, context map -- as well)
+  __shared__ uint32_t s_bits;
   const uint32_t m = blockIdx.x;
-  if (m >= B.n_mb || threadIdx.x != 0) return;
-  mb_item_write_header(B, m, B.huff_scratch + m);
+  if (m >= B.n_mb) return;
+  const MbDesc d = B.descs[m];
+  uint64_t* global_words = B.header_words + (size_t)m * kHeaderWords;
+  if (d.uncompressed) {
+    if (threadIdx.x == 0) mb_item_write_header(B, m, B.huff_scratch + m, global_words);
+    return;
+  }
+  uint32_t trees = 0;
+  for (uint32_t kind = 0; kind < 3; ++kind)
+    for (uint32_t i = threadIdx.x; i < B.results[m].num_histos[kind]; i += 64) trees += B.tree_nbits[kind][d.histo_base[kind] + i];
+  for (int off = 32; off > 0; off >>= 1) trees += __shfl_down(trees, off, 64);
+  trees = (uint32_t)__shfl((int)trees, 0, 64);
+  const bool in_lds = (uint64_t)trees + kOtherBits <= (uint64_t)kLdsWords * 64;
+  uint64_t* stage = in_lds ? lw : global_words;
+  const uint32_t clear_words = in_lds ? kLdsWords : kHeaderWords;
+  for (uint32_t i = threadIdx.x; i < clear_words; i += 64) stage[i] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mb_item_write_header(B, m, &sc_lds, stage);
+    s_bits = B.results[m].header_bits;
+  }
+  __syncthreads();
+  if (in_lds) {
+    const uint32_t words = (s_bits + 63) / 64 + 1;
+    for (uint32_t i = threadIdx.x; i < words && i < kLdsWords; i += 64) global_words[i] = lw[i];
+  }
 }
 
 void mb_write_headers(const MbBuffers& B) {
