@@ -90,7 +90,10 @@ static constexpr uint32_t kMaxContinuation = 4;
 // differs.  The rows of a segment are contiguous in memory: the chain streams them through an LDS window instead of
 // chasing rank -> bucket row through two dependent random loads, and a flag change touches the rows of the next <= 16
 // stored positions of its key only (lz77_update_rows).
-static constexpr uint32_t kRowWindow = 32;  // positions held in LDS
+#if !defined(BR_ROW_WINDOW)
+#define BR_ROW_WINDOW 32
+#endif
+static constexpr uint32_t kRowWindow = BR_ROW_WINDOW;  // positions held in LDS
 BR_DEV uint32_t br_tag16(uint32_t first_four_bytes) { return (first_four_bytes * 0x9E3779B1u) >> 16; }
 
 template <bool kH9, bool kRows = false>
@@ -425,8 +428,9 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
     BR_SYNC();
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // dictionary hash items of the window positions (SearchInStaticDictionary, mod.rs:1942-1988): lane = 2 * position + probe
-    uint32_t first4 = 0;
-    if (use_dict) first4 = br_load32(t.text + p0 + (BR_LANE >> 1));
+    uint32_t first4[kRowWindow * 2 / 64];
+#pragma unroll
+    for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j) first4[j] = use_dict ? br_load32(t.text + min(p0 + j * 32 + ((uint32_t)BR_LANE >> 1), P.total_bytes)) : 0u;  // (the text is padded by 64 bytes)
     u32x4 v[kRowWindow * (kRowEntries / 4) / 64];
 #pragma unroll
     for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) {
@@ -436,7 +440,11 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
       v[j] = none;
       if (q < P.total_bytes) v[j] = __builtin_nontemporal_load((const u32x4*)t.rows + (size_t)q * (kRowEntries / 4) + (i % (kRowEntries / 4)));
     }
-    if (use_dict) s.dictwin[BR_LANE] = t.dict_hash[(((first4 * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
+    if (use_dict) {
+#pragma unroll
+      for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j)
+        s.dictwin[j * 64 + BR_LANE] = t.dict_hash[(((first4[j] * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
+    }
 #pragma unroll
     for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) ((u32x4*)s.win)[j * 64 + BR_LANE] = v[j];
     m.win_base = p0;

@@ -1173,8 +1173,11 @@ static ParseTiming& parse_timing() {
   return t;
 }
 
+#if !defined(BR_PARSE_WAVES)
+#define BR_PARSE_WAVES 8
+#endif
 template <bool kH9, bool kRows>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_segments(ParseArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BR_PARSE_WAVES, BR_PARSE_WAVES))) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratchT<kH9, kRows> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
   // window and the rank rows its chains touch stay in that XCD's L2

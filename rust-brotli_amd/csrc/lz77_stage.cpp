@@ -305,7 +305,7 @@ struct DictTracker {
         }
         break;
     }
-    if (getenv("BROTLI_MI355X_DEBUG_DICT") && (!ok || next != state))
+    if ((!ok || next != state) && getenv("BROTLI_MI355X_DEBUG_DICT"))
       fprintf(stderr, "  dict seg %u: state %d->%d L %u M %u slack %lld used (%u,%u,%u) exit (%u,%u) mode %u maxdef %d ok %d\n", k, (int)state,
               (int)next, L, M, (long long)slack, used.dict_lookups, used.dict_matches, used.dict_exact, x.dict_lookups, x.dict_matches,
               x.dict_mode, x.dict_maxdef, (int)ok);
@@ -481,7 +481,6 @@ bool Lz77Stage::Resolve(bool final_pass) {
       mark(k0, cache_same && u.ext_allowed == E.ext_allowed, (uint8_t)((ext_same ? 0 : 1) | (cache_same ? 0 : 2)));
     }
     next_entries_[k0] = E;
-    if (record_block_guess_) block_entry_guess_[bs] = E;  // (only the pass after round 0 can lead to the coarse restart that reads it)
     // ---- chain through the segments of the block
     uint32_t carry = last_insert_len;  // literals pending when the segment is entered
     int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
@@ -981,8 +980,19 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   bool restart = false;
   bool full_round = true;
   uint32_t last_death_seg = 0xffffffffu;
+  // BROTLI_MI355X_TIMELINE: host timestamps of every round (ms since the first round started)
+  static const bool timeline = getenv("BROTLI_MI355X_TIMELINE") != nullptr;
+  const auto tl0 = std::chrono::steady_clock::now();
+  std::string tl;
+  auto stamp = [&](const char* what) {
+    if (!timeline) return;
+    char buf[64];
+    snprintf(buf, sizeof(buf), " %s %.3f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
+    tl += buf;
+  };
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
     stats_.rounds++;
+    stamp("| round");
     tm.stop(&stats_.ms_resolve);
     // upload the entries of the segments to parse, run them, fetch their exits
     if (full_round) {
@@ -993,6 +1003,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       dev_h2d(dirty_dev, sched.data(), nseg);
     }
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+    stamp("uploaded");
     if (full_round) {
       lz77_parse_round(P_, B_, which, rbuf, 0);
     } else {
@@ -1026,8 +1037,11 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       // rebuild) while the host chains the exits together: wait for the copies only
       dev_mark();
       dev_memset(dirty_dev, 0, nseg);
+      stamp("launched");
       lz77_rows_update(P_, B_, which, which ^ 1, geo, dirty_dev, has_big_keys_);
+      stamp("rows-queued");
       dev_wait_mark();
+      stamp("exits-here");
     } else {
       dev_sync();
     }
@@ -1097,11 +1111,12 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     tm.stop(&stats_.ms_rank);
     const auto host_t0 = std::chrono::steady_clock::now();
-    record_block_guess_ = round == 0 && allow_restart;
     Resolve(false);
     const auto host_t1 = std::chrono::steady_clock::now();
     host_resolve_ms_ += std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();
+    stamp("resolved");
     const uint32_t rechecked = RecheckCacheOnly(which);
+    stamp("rechecked");
     stats_.cache_rechecks += rechecked;
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
     uint32_t n_dirty_entry = 0, n_dirty_valid = 0;
@@ -1125,6 +1140,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         dirty[k] |= cand_dirty[k];
       }
       tm.stop(&stats_.ms_rank);
+      stamp("dirty-here");
     }
     // the static dictionary got switched off at segment dict_death_seg_ and many chains behind it ran in the
     // wrong regime: they are re-parsed anyway; refresh their entry guesses with a dry run in the new regime
@@ -1175,17 +1191,22 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u | block-first: cache %u ext %u | head %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dbg_first_[0], dbg_first_[1], dbg_first_[2], dict_death_seg_, predicted_death_, dict_flips_);
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u), predicted literal runs %u, cache rechecks passed %u\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid, predicted_runs_, rechecked);
     host_schedule_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
+    stamp("scheduled");
     if (count == 0) {
       done = true;
       break;
     }
     full_round = false;
   }
+  if (timeline) fprintf(stderr, "round timeline:%s\n", tl.c_str());
   dev_free(dirty_dev);
   dev_free(list_dev);
   dev_free(geo_tables);
   if (restart) {
-    saved_block_guess_ = block_entry_guess_;  // what the pass so far says about the state at every block start
+    // what the pass so far says about the state at every block start
+    saved_block_guess_.clear();
+    for (uint32_t k = 0; k < nseg; ++k)
+      if (segments_[k].flags & kSegFirstInBlock) saved_block_guess_[segments_[k].blk_start] = next_entries_[k];
     // Hardly any guess held: this input does not re-synchronise (incompressible stretches, data whose parse hangs on
     // the distance cache).  Parse it one chain per input block instead -- nothing is guessed inside a block then.
     Resegment(segment_bytes_);

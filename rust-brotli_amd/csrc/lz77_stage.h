@@ -157,13 +157,12 @@ class Lz77Stage {
   int final_flags_ = 0;
   const StreamCarry* carry_ = nullptr;
   bool stream_is_last_ = true;
-  bool record_block_guess_ = false;
   bool partial_ = false;
   bool early_last_ = false, needs_empty_last_ = false;
   uint32_t resume_pos_ = 0;
   uint32_t final_dict_lookups_ = 0, final_dict_matches_ = 0;
   bool final_dict_dead_ = false;
-  std::map<uint32_t, SegEntry> block_entry_guess_, saved_block_guess_;  // by block start
+  std::map<uint32_t, SegEntry> saved_block_guess_;  // by block start
   size_t cmds_bytes_ = 0;
   std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
   std::vector<SegEntry> entries_;   // entries used by the most recent parse

@@ -89,6 +89,29 @@ struct BitSink {
   }
 };
 
+// BR_CODES_PROFILE (experiment builds only): cycles per phase of the Huffman jobs, summed in g_codes_prof[phase] and
+// the slowest job's in g_codes_prof[16 + phase]; printed by mb_build_codes
+#if defined(BR_CODES_PROFILE) && !defined(BROTLI_HOST_EMU)
+extern __device__ unsigned long long g_codes_prof[32];
+struct CodesPhaseClock {
+  unsigned long long last;
+  BR_DEV CodesPhaseClock() : last(__builtin_readcyclecounter()) {}
+  BR_DEV void mark(int phase) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63u) == 0) {
+      atomicAdd(&g_codes_prof[phase], now - last);
+      atomicMax(&g_codes_prof[16 + phase], now - last);
+    }
+    last = __builtin_readcyclecounter();
+  }
+};
+#define BR_PHASE_CLOCK() CodesPhaseClock br_phase_clock
+#define BR_PHASE(k) br_phase_clock.mark(k)
+#else
+#define BR_PHASE_CLOCK()
+#define BR_PHASE(k)
+#endif
+
 // ---------------------------------------------------------------------------------------------- Huffman
 struct HuffmanTree {
   uint32_t total_count_;
@@ -180,8 +203,38 @@ BR_DEV void br_create_huffman_tree(const uint32_t* data, uint32_t length, int tr
   sentinel.total_count_ = 0xffffffffu;
   sentinel.index_left_ = -1;
   sentinel.index_right_or_value_ = -1;
+#if !defined(BROTLI_HOST_EMU)
+  // cooperative build: the sort's scratch is free again when the nodes are merged and holds the parent links then
+  uint16_t* parent = (uint16_t*)coop_tmp;
+  static_assert(sizeof(HuffmanTree) * 704 >= sizeof(uint16_t) * (2 * 704 + 2), "parent links fit the sort scratch");
+#endif
+  BR_PHASE_CLOCK();
   for (uint32_t count_limit = 1;; count_limit *= 2) {
     uint32_t n = 0;
+    BR_PHASE(15);
+#if !defined(BROTLI_HOST_EMU)
+    if (coop_tmp != nullptr) {
+      // the leaves in descending symbol order: lane l of a chunk takes the l-th symbol from its top, the leaf's slot is the
+      // number of used symbols above it
+      const uint32_t lane = threadIdx.x & 63u;
+      for (uint32_t top = length; top != 0; top = top > 64 ? top - 64 : 0) {
+        const bool valid = lane < top;
+        const uint32_t i = valid ? top - 1 - lane : 0u;
+        const uint32_t v = valid ? data[i] : 0u;
+        const unsigned long long m = __ballot(v != 0);
+        if (v != 0) {
+          HuffmanTree leaf;
+          leaf.total_count_ = v > count_limit ? v : count_limit;
+          leaf.index_left_ = -1;
+          leaf.index_right_or_value_ = (int16_t)i;
+          tree[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = leaf;
+        }
+        n += (uint32_t)__popcll(m);
+      }
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+    } else
+#endif
     for (uint32_t i = length; i != 0;) {
       --i;
       if (data[i] != 0) {
@@ -195,7 +248,9 @@ BR_DEV void br_create_huffman_tree(const uint32_t* data, uint32_t length, int tr
       depth[tree[0].index_right_or_value_] = 1;
       break;
     }
+    BR_PHASE(0);
     br_sort_huffman_tree_items(tree, n, coop_tmp);
+    BR_PHASE(1);
     tree[n] = sentinel;
     tree[n + 1] = sentinel;
     uint32_t i = 0, j = n + 1;
@@ -216,29 +271,92 @@ BR_DEV void br_create_huffman_tree(const uint32_t* data, uint32_t length, int tr
       tree[j_end].index_left_ = (int16_t)left;
       tree[j_end].index_right_or_value_ = (int16_t)right;
       tree[j_end + 1] = sentinel;
+#if !defined(BROTLI_HOST_EMU)
+      if (parent != nullptr) parent[left] = parent[right] = (uint16_t)j_end;
+#endif
     }
-    if (br_set_depth((int)(2 * n - 1), tree, depth, tree_limit)) break;
+    BR_PHASE(2);
+    bool fits;
+#if !defined(BROTLI_HOST_EMU)
+    if (parent != nullptr) {
+      // BrotliSetDepth from the leaves: every lane climbs from its leaves to the root (node 2n-1) and gives up beyond
+      // tree_limit levels -- the same depths as the traversal from the root, and the same verdict
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t lane = threadIdx.x & 63u, root = 2 * n - 1;
+      bool too_deep = false;
+      for (uint32_t e = lane; e < n; e += 64) {
+        uint32_t p = e, d = 0;
+        while (p != root && d <= (uint32_t)tree_limit) {
+          p = parent[p];
+          d++;
+        }
+        if (p != root || d > (uint32_t)tree_limit) {
+          too_deep = true;
+        } else {
+          depth[tree[e].index_right_or_value_] = (uint8_t)d;
+        }
+      }
+      fits = __ballot(too_deep) == 0ull;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+    } else
+#endif
+    fits = br_set_depth((int)(2 * n - 1), tree, depth, tree_limit);
+    BR_PHASE(3);
+    if (fits) break;
   }
 }
 
 // BrotliOptimizeHuffmanCountsForRle, entropy_encode.rs:211-345.  good_for_rle: 704 bytes of scratch.
-BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts, uint8_t* good_for_rle) {
+// (a / b for operands that mostly fit 32 bits: the 64-bit division is a long software routine on the device)
+BR_DEV uint64_t br_div_u64(uint64_t a, uint64_t b) {
+  if (((a | b) >> 32) == 0) return (uint64_t)((uint32_t)a / (uint32_t)b);
+  return a / b;
+}
+
+// coop (device): called by all 64 lanes of a wavefront in lock step on the same buffers; the counting passes are shared out
+BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts, uint8_t* good_for_rle, bool coop = false) {
   uint32_t nonzero_count = 0;
   const uint64_t streak_limit = 1240;
-  for (uint32_t i = 0; i < length; ++i)
-    if (counts[i] != 0) nonzero_count++;
-  if (nonzero_count < 16) return;
-  while (length != 0 && counts[length - 1] == 0) length--;
-  if (length == 0) return;
+  uint32_t nonzeros = 0;
+  uint32_t smallest_nonzero = 1u << 30;
+#if !defined(BROTLI_HOST_EMU)
+  if (coop) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t last = 0, smallest = 1u << 30;
+    for (uint32_t base = 0; base < length; base += 64) {
+      const uint32_t i = base + lane;
+      const uint32_t v = i < length ? counts[i] : 0u;
+      const unsigned long long m = __ballot(v != 0);
+      nonzero_count += (uint32_t)__popcll(m);
+      if (m != 0) last = base + 64u - (uint32_t)__builtin_clzll(m);  // one past the last used symbol
+      if (v != 0 && v < smallest) smallest = v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)smallest, off, 64);
+      smallest = o < smallest ? o : smallest;
+    }
+    if (nonzero_count < 16) return;
+    length = last;
+    nonzeros = nonzero_count;  // (the symbols trimmed off the end were unused)
+    smallest_nonzero = smallest;
+  } else
+#endif
   {
-    uint32_t nonzeros = 0;
-    uint32_t smallest_nonzero = 1u << 30;
+    for (uint32_t i = 0; i < length; ++i)
+      if (counts[i] != 0) nonzero_count++;
+    if (nonzero_count < 16) return;
+    while (length != 0 && counts[length - 1] == 0) length--;
+    if (length == 0) return;
     for (uint32_t i = 0; i < length; ++i) {
       if (counts[i] != 0) {
         nonzeros++;
         if (smallest_nonzero > counts[i]) smallest_nonzero = counts[i];
       }
     }
+  }
+  {
     if (nonzeros < 5) return;
     if (smallest_nonzero < 4) {
       const uint32_t zeros = length - nonzeros;
@@ -249,6 +367,13 @@ BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts
     }
     if (nonzeros < 28) return;
   }
+#if !defined(BROTLI_HOST_EMU)
+  if (coop) {
+    for (uint32_t i = threadIdx.x & 63u; i < 704; i += 64) good_for_rle[i] = 0;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+  } else
+#endif
   for (uint32_t i = 0; i < 704; ++i) good_for_rle[i] = 0;
   {
     uint32_t symbol = counts[0];
@@ -272,7 +397,7 @@ BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts
     if (i == length || good_for_rle[i] != 0 || (i != 0 && good_for_rle[i - 1] != 0) ||
         (uint64_t)(uint32_t)(256u * counts[i]) - limit + streak_limit >= 2 * streak_limit) {
       if (stride >= 4 || (stride >= 3 && sum == 0)) {
-        uint64_t count = (sum + stride / 2) / stride;
+        uint64_t count = br_div_u64(sum + stride / 2, stride);
         if (count == 0) count = 1;
         if (sum == 0) count = 0;
         for (uint64_t k = 0; k < stride; ++k) counts[i - k - 1] = (uint32_t)count;
@@ -290,7 +415,7 @@ BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts
     stride++;
     if (i != length) {
       sum += counts[i];
-      if (stride >= 4) limit = (256 * sum + stride / 2) / stride;
+      if (stride >= 4) limit = br_div_u64(256 * sum + stride / 2, stride);
       if (stride == 4) limit += 120;
     }
   }
@@ -415,6 +540,9 @@ BR_DEV void br_write_huffman_tree(const uint8_t* depth, uint32_t length, uint32_
 
 // BrotliReverseBits / BrotliConvertBitDepthsToSymbols, entropy_encode.rs:527-575
 BR_DEV uint16_t br_reverse_bits(uint32_t num_bits, uint16_t bits) {
+#if !defined(BROTLI_HOST_EMU)
+  if (num_bits != 0) return (uint16_t)(__builtin_bitreverse32((uint32_t)bits) >> (32u - num_bits));  // (1..15 bits: the same value)
+#endif
   const uint32_t kLut[16] = {0x0, 0x8, 0x4, 0xc, 0x2, 0xa, 0x6, 0xe, 0x1, 0x9, 0x5, 0xd, 0x3, 0xb, 0x7, 0xf};
   uint32_t retval = kLut[bits & 0xf];
   for (uint32_t i = 4; i < num_bits; i += 4) {
@@ -440,6 +568,46 @@ BR_DEV void br_convert_bit_depths_to_symbols(const uint8_t* depth, uint32_t len,
   for (uint32_t i = 0; i < len; ++i)
     if (depth[i] != 0) bits[i] = br_reverse_bits(depth[i], next_code[depth[i]]++);
 }
+#if !defined(BROTLI_HOST_EMU)
+// the same by all 64 lanes of a wavefront (depth / bits in LDS or global memory): lane k keeps the running next_code[k];
+// a symbol's code is next_code[its depth] plus the number of symbols of that depth in front of it
+BR_DEV void br_convert_bit_depths_to_symbols_coop(const uint8_t* depth, uint32_t len, uint16_t* bits) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t cnt = 0;
+  for (uint32_t base = 0; base < len; base += 64) {
+    const uint32_t i = base + lane;
+    const uint32_t d = i < len ? depth[i] : 0u;
+#pragma unroll
+    for (uint32_t k = 1; k < 16; ++k) {
+      const unsigned long long m = __ballot(d == k);
+      if (lane == k) cnt += (uint32_t)__popcll(m);
+    }
+  }
+  uint32_t code = 0, running = 0;
+#pragma unroll
+  for (uint32_t k = 1; k < 16; ++k) {
+    const uint32_t c_prev = k == 1 ? 0u : (uint32_t)__shfl((int)cnt, (int)(k - 1), 64);
+    code = (code + c_prev) << 1;
+    if (lane == k) running = code;
+  }
+  for (uint32_t base = 0; base < len; base += 64) {
+    const uint32_t i = base + lane;
+    const uint32_t d = i < len ? depth[i] : 0u;
+    const uint32_t next = (uint32_t)__shfl((int)running, (int)d, 64);
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 16; ++k) {
+      const unsigned long long m = __ballot(d == k);
+      if (d == k) rank = (uint32_t)__popcll(m & below);
+      if (lane == k) running += (uint32_t)__popcll(m);
+    }
+    if (d != 0) bits[i] = br_reverse_bits(d, (uint16_t)(next + rank));
+  }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+#endif
 
 // Scratch for one Huffman build (per thread, in global memory)
 struct HuffmanScratch {
@@ -465,8 +633,11 @@ BR_DEV void br_store_huffman_tree(const uint8_t* depths, uint32_t num, HuffmanSc
     code_length_bitdepth_symbols[i] = 0;
     huffman_tree_histogram[i] = 0;
   }
+  BR_PHASE_CLOCK();
   br_write_huffman_tree(depths, num, &huffman_tree_size, sc->rle_tree, sc->rle_extra);
+  BR_PHASE(4);
   for (uint32_t i = 0; i < huffman_tree_size; ++i) huffman_tree_histogram[sc->rle_tree[i]]++;
+  BR_PHASE(5);
   int num_codes = 0;
   uint32_t code = 0;
   for (uint32_t i = 0; i < 18; ++i) {
@@ -500,6 +671,7 @@ BR_DEV void br_store_huffman_tree(const uint8_t* depths, uint32_t num, HuffmanSc
     }
   }
   if (num_codes == 1) code_length_bitdepth[code] = 0;
+  BR_PHASE(6);
   for (uint32_t i = 0; i < huffman_tree_size; ++i) {
     const uint32_t ix = sc->rle_tree[i];
     out.put(code_length_bitdepth[ix], code_length_bitdepth_symbols[ix]);
@@ -509,6 +681,7 @@ BR_DEV void br_store_huffman_tree(const uint8_t* depths, uint32_t num, HuffmanSc
       out.put(3, sc->rle_extra[i]);
     }
   }
+  BR_PHASE(7);
 }
 
 // BuildAndStoreHuffmanTree, brotli_bit_stream.rs:1445-1498 (+ StoreSimpleHuffmanTree :1401-1443)
@@ -536,8 +709,14 @@ BR_DEV void br_build_and_store_huffman_tree(const uint32_t* histogram, uint32_t 
     return;
   }
   for (uint32_t i = 0; i < histogram_length; ++i) depth[i] = 0;
+  BR_PHASE_CLOCK();
   br_create_huffman_tree(histogram, histogram_length, 15, sc->tree, depth, coop ? sc->sort_tmp : nullptr);
+  BR_PHASE(14);
+#if !defined(BROTLI_HOST_EMU)
+  if (coop) br_convert_bit_depths_to_symbols_coop(depth, histogram_length, bits); else
+#endif
   br_convert_bit_depths_to_symbols(depth, histogram_length, bits);
+  BR_PHASE(8);
   if (count <= 4) {
     out.put(2, 1);
     out.put(2, count - 1);

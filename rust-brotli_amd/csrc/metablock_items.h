@@ -426,7 +426,9 @@ BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols,
   // BrotliOptimizeHistograms (metablock.rs:1076-1108): literal 256, command 704, distance min(alphabet, 544)
   uint32_t opt_len = row;
   if (kind == kSplitDistance) opt_len = num_distance_symbols < kNumDistanceHistoSymbols ? num_distance_symbols : kNumDistanceHistoSymbols;
-  br_optimize_huffman_counts_for_rle(opt_len, h, sc->good_for_rle);
+  BR_PHASE_CLOCK();
+  br_optimize_huffman_counts_for_rle(opt_len, h, sc->good_for_rle, coop);
+  BR_PHASE(9);
   // build_and_store_entropy_codes (brotli_bit_stream.rs:1860-1889): histogram_length = row (distance:
   // num_effective_distance_symbols), alphabet_size = 256 / 704 / num_distance_symbols
   uint32_t hist_len = row, alphabet = row;
@@ -442,7 +444,9 @@ BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols,
   BitSink sink;
   sink.words = words;
   sink.pos = 0;
+  BR_PHASE(10);
   br_build_and_store_huffman_tree(h, hist_len, alphabet, sc, depth, bits, sink, coop);
+  BR_PHASE(11);
   return (uint32_t)sink.pos;
 }
 

@@ -134,6 +134,9 @@ void mb_split_chains(const MbBuffers& B, bool wide) {
   HIP_CHECK(hipGetLastError());
 }
 
+#if defined(BR_CODES_PROFILE)
+__device__ unsigned long long g_codes_prof[32];
+#endif
 // The Huffman construction is sequential, data-dependent control flow: 64 different histograms in the lanes of one
 // wavefront would serialise on every divergent branch.  One histogram per wavefront (lane 0 works) puts the jobs
 // on different SIMDs instead, where they really run concurrently.
@@ -174,6 +177,18 @@ void mb_build_codes(const MbBuffers& B, const CodeJob* jobs_dev, uint32_t n_jobs
   if (n_jobs == 0) return;
   hipLaunchKernelGGL(k_build_codes, dim3(n_jobs), dim3(64), 0, BR_STREAM, B, jobs_dev, n_jobs);
   HIP_CHECK(hipGetLastError());
+#if defined(BR_CODES_PROFILE)
+  {
+    unsigned long long h[32];
+    HIP_CHECK(hipStreamSynchronize(BR_STREAM));
+    HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_codes_prof), sizeof(h)));
+    fprintf(stderr, "codes profile (%u jobs), cycles sum / slowest job:", n_jobs);
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d] %llu / %llu", i, h[i], h[16 + i]);
+    fprintf(stderr, "\n");
+    unsigned long long z[32] = {0};
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_codes_prof), z, sizeof(z)));
+  }
+#endif
 }
 
 // The header of a meta-block is a sequential bit string (block-split codes, context map, then the serialised trees that
