@@ -197,6 +197,8 @@ def config4(torch, dist, bm, lib, enc, rank, world, frozen, steps):
     if dist:
         dist.barrier()
     elapsed = time.time() - t0
+    if comp is not None:
+        comp = bytes(comp)  # (a view of the encoder's output buffer until here: the next encode overwrites it)
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -277,7 +279,7 @@ def main():
 
     def one_step():
         if not shard_job:
-            comp = enc.encode(params, b"", dev.data_ptr(), len(chunk), True)
+            comp = enc.encode(params, b"", dev.data_ptr(), len(chunk), True, copy=False)
         else:
             comp = job.step(params, prefix, dev.data_ptr(), len(chunk))  # compressed shards gathered GPU to GPU, stitched on rank 0
         return comp, list(st)

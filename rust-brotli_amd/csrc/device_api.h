@@ -30,6 +30,11 @@ void dev_d2d(void* dst, const void* src, size_t bytes);
 void dev_sync();
 void dev_mark();       // records a point in the calling thread's stream ...
 void dev_wait_mark();  // ... and waits until everything queued before the last mark has finished (later work keeps running)
+// page-locked host memory for the buffers that go back and forth every round (copies to and from pageable memory are
+// staged by the runtime and block the caller)
+void* dev_host_alloc(size_t bytes);
+void dev_host_free(void* p);
+void dev_pool_counters(double* out4, bool reset);  // hipMalloc calls / ms, hipFree calls / ms of the calling thread
 size_t dev_trim_pool();  // returns the pooled, currently unused device memory of the calling thread to the driver; bytes freed
 const char* dev_name();  // "hip:gfx950 ..." or "host-emulation"
 
@@ -123,6 +128,13 @@ void lz77_parse_round(const Lz77Params& P, const Lz77Buffers& B, int which, int 
 // changes (br_parse_chain), rewrites B.entries for them and marks them 3
 void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const uint32_t* list_dev, uint8_t* sched_dev,
                      uint32_t count);
+// list rounds move only what changed between host and device:
+// B.entries[index_dev[i]] = entries_dev[i] for i < count
+void lz77_scatter_entries(const Lz77Buffers& B, const uint32_t* index_dev, const SegEntry* entries_dev, uint32_t count);
+// after lz77_parse_list: exits_out[i] = B.exits[list_dev[i]] for i < count, and the segments that chains continued into
+// (sched_dev[k] == 3) appended in any order to cont_index / cont_exits / cont_entries, their number in *cont_count
+void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, const uint8_t* sched_dev, uint32_t num_segments,
+                         SegExit* exits_out, uint32_t* cont_count, uint32_t* cont_index, SegExit* cont_exits, SegEntry* cont_entries);
 // lists the keys of the positions whose stored flag differs between flags[prev] and flags[next] in B.changed_keys /
 // B.changed_count (the count may exceed kChangedCap; only the first kChangedCap entries are kept)
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next);
@@ -178,6 +190,34 @@ void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t nu
 
 // applies extend_last_command / trailing insert-only fix-ups to the gathered commands
 void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n);
+
+// grow-only array in page-locked host memory (contents are not preserved by resize_discard)
+template <typename T>
+struct PinnedArray {
+  T* ptr = nullptr;
+  size_t cap = 0, n = 0;
+  PinnedArray() = default;
+  PinnedArray(const PinnedArray&) = delete;
+  PinnedArray& operator=(const PinnedArray&) = delete;
+  ~PinnedArray() { dev_host_free(ptr); }
+  void resize_discard(size_t count) {
+    if (count > cap) {
+      dev_host_free(ptr);
+      cap = count + count / 4 + 16;
+      ptr = (T*)dev_host_alloc(cap * sizeof(T));
+    }
+    n = count;
+  }
+  void assign(size_t count, const T& v) {
+    resize_discard(count);
+    for (size_t i = 0; i < count; ++i) ptr[i] = v;
+  }
+  T* data() { return ptr; }
+  const T* data() const { return ptr; }
+  size_t size() const { return n; }
+  T& operator[](size_t i) { return ptr[i]; }
+  const T& operator[](size_t i) const { return ptr[i]; }
+};
 
 }  // namespace brotli_mi355x
 #endif

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -43,6 +44,26 @@ size_t RoundUp(size_t bytes) {
 }
 }  // namespace
 
+// what the driver was asked for (BROTLI_MI355X_TIMELINE): [0] hipMalloc calls, [1] ms in them, [2] hipFree calls, [3] ms
+static thread_local double g_pool_counters[4] = {0, 0, 0, 0};
+void dev_pool_counters(double* out, bool reset) {
+  for (int i = 0; i < 4; ++i) {
+    out[i] = g_pool_counters[i];
+    if (reset) g_pool_counters[i] = 0;
+  }
+}
+namespace {
+struct DriverCallClock {
+  int slot;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit DriverCallClock(int s) : slot(s) {}
+  ~DriverCallClock() {
+    g_pool_counters[slot] += 1;
+    g_pool_counters[slot + 1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+}  // namespace
+
 static void* AllocBlock(size_t bytes);
 void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 16;
@@ -73,6 +94,7 @@ static void* AllocBlock(size_t bytes) {
     }
   }
   if (!p) {
+    DriverCallClock clock(0);
     hipError_t e = hipMalloc(&p, cap);
     if (e != hipSuccess) {
       // give pooled memory back to the driver and retry once
@@ -100,16 +122,56 @@ void dev_free(void* p) {
   std::lock_guard<std::mutex> lock(P.mu);
   auto it = P.capacity.find(p);
   if (it == P.capacity.end()) {
+    DriverCallClock clock(2);
     (void)hipFree(p);
     return;
   }
   if (P.pooled_bytes + it->second > Pool::kMaxPooled) {
+    DriverCallClock clock(2);
     P.capacity.erase(it);
     (void)hipFree(p);
     return;
   }
   P.free_blocks.emplace(it->second, p);
   P.pooled_bytes += it->second;
+}
+// page-locked host blocks are pooled like the device blocks (hipHostMalloc costs a fraction of a millisecond)
+namespace {
+struct HostPool {
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, size_t> capacity;
+  ~HostPool() {
+    for (auto& kv : free_blocks) (void)hipHostFree(kv.second);
+  }
+};
+HostPool& host_pool() {
+  static thread_local HostPool p;
+  return p;
+}
+}  // namespace
+void* dev_host_alloc(size_t bytes) {
+  const size_t cap = RoundUp(bytes ? bytes : 16);
+  HostPool& P = host_pool();
+  auto it = P.free_blocks.lower_bound(cap);
+  if (it != P.free_blocks.end() && it->first <= cap + cap / 4) {
+    void* p = it->second;
+    P.free_blocks.erase(it);
+    return p;
+  }
+  void* p = nullptr;
+  HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+  P.capacity[p] = cap;
+  return p;
+}
+void dev_host_free(void* p) {
+  if (!p) return;
+  HostPool& P = host_pool();
+  auto it = P.capacity.find(p);
+  if (it == P.capacity.end()) {
+    (void)hipHostFree(p);
+    return;
+  }
+  P.free_blocks.emplace(it->second, p);
 }
 void dev_memset(void* p, int value, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemsetAsync(p, value, bytes, BR_STREAM));

@@ -1,5 +1,6 @@
 // encoder.cpp -- see encoder.h
 #include "encoder.h"
+#include "timeline.h"
 
 #include <math.h>
 #include <string.h>
@@ -178,7 +179,8 @@ void DecideContexts(const uint32_t* s, int quality, size_t size_hint, size_t len
 
 struct Clock {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  double lap(bool sync) {
+  double lap(bool sync, const char* what = nullptr) {
+    if (what) timeline().stamp(what);
     if (sync) dev_sync();
     auto t1 = std::chrono::steady_clock::now();
     double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -247,6 +249,10 @@ uint32_t ChooseSegmentBytes(size_t input_bytes) {
 void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeStats* stats_out) {
   EncodeStats stats;
   Clock total_clock;
+  timeline().begin();
+  struct TimelineEnd {
+    ~TimelineEnd() { timeline().end(); }
+  } timeline_end;
   const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
   EncoderParams p = req.params;
   const size_t n = req.input_size;
@@ -321,7 +327,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       dev_h2d(text + prefix_bytes, req.input, n);
     }
   }
-  stats.ms_phase[0] = total_clock.lap(prof);
+  stats.ms_phase[0] = total_clock.lap(prof, "input-copied");
 
   struct RawCopy {
     uint64_t dst_byte;
@@ -399,14 +405,14 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         lz.SetHasherReset((uint32_t)(reset - base));
       }
     }
-    stats.ms_phase[9] = c.lap(prof);
+    stats.ms_phase[9] = c.lap(prof, "lz77-setup");
   }
   for (;;) {  // repeated only when a compressed meta-block turns out larger than its raw form
     HostBits bits = hb;  // stream position after the head pieces
     bits.pos = head_bits;
     Clock clk;
     lz.Run();
-    stats.ms_lz77 += clk.lap(prof);
+    stats.ms_lz77 += clk.lap(prof, "lz77-done");
     {
       double ms;
       uint32_t launches;
@@ -593,15 +599,15 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     B.ctxmap_scratch = mm.alloc<uint32_t>((size_t)n_mb * 2 * 256 * 64);
     B.mb_out_bit = mm.alloc<uint64_t>(n_mb + 1);
     dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
-    stats.ms_phase[1] += clk.lap(prof);
+    stats.ms_phase[1] += clk.lap(prof, "mb1");
     mb_granule_histograms(B);
-    stats.ms_phase[2] += clk.lap(prof);
+    stats.ms_phase[2] += clk.lap(prof, "mb2");
     bool wide = false;
     for (uint32_t m = 0; m < n_mb; ++m) wide = wide || (!descs[m].uncompressed && descs[m].num_contexts > 3);
     mb_split_chains(B, wide);
     std::vector<MbResult> results(n_mb);
     dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
-    stats.ms_phase[3] += clk.lap(prof);
+    stats.ms_phase[3] += clk.lap(prof, "mb3");
     // Huffman codes: one job per histogram
     std::vector<CodeJob> jobs;
     for (uint32_t m = 0; m < n_mb; ++m) {
@@ -613,9 +619,9 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     CodeJob* jobs_dev = mm.alloc<CodeJob>(jobs.size() + 1);
     dev_h2d(jobs_dev, jobs.data(), jobs.size() * sizeof(CodeJob));
     mb_build_codes(B, jobs_dev, (uint32_t)jobs.size());
-    stats.ms_phase[4] += clk.lap(prof);
+    stats.ms_phase[4] += clk.lap(prof, "mb4");
     mb_write_headers(B);
-    stats.ms_phase[5] += clk.lap(prof);
+    stats.ms_phase[5] += clk.lap(prof, "mb5");
     mb_symbol_bits(B, scan_scratch);
     std::vector<uint32_t> body_off(n_mb + 1);
     mb_gather_at_metablock_starts(B, B.cmd_nbits, boundary_words);
@@ -628,7 +634,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
                 m, descs[m].start, descs[m].end, descs[m].n_symbols[1], descs[m].n_symbols[0], descs[m].num_contexts, results[m].num_blocks[0],
                 results[m].num_types[0], results[m].num_blocks[1], results[m].num_types[1], results[m].num_blocks[2], results[m].num_types[2],
                 results[m].header_bits);
-    stats.ms_phase[6] += clk.lap(prof);
+    stats.ms_phase[6] += clk.lap(prof, "mb6");
 
     // ---- layout of the stream (WriteMetaBlockInternal, encode.rs:1941-2167)
     std::vector<uint64_t> mb_out_bit(n_mb + 1, 0);
@@ -691,7 +697,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         mb_copy_bits(B.out_words, bp.pos, tmp, bp.nbits);
       }
     }
-    stats.ms_phase[7] += clk.lap(prof);
+    stats.ms_phase[7] += clk.lap(prof, "mb7");
     if (req.direct_out) {
       if (total_bytes > req.direct_capacity) throw std::runtime_error("brotli_mi355x: output buffer too small");
       if (req.direct_out_on_device) {
@@ -706,7 +712,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       result.resize(total_bytes);
       dev_d2h(result.data(), B.out_words, total_bytes);
     }
-    stats.ms_phase[8] += clk.lap(prof);
+    stats.ms_phase[8] += clk.lap(prof, "mb8");
     const uint32_t resume = partial ? lz.resume_pos() : M;  // text position where the next piece takes over
     if (req.consumed_out) *req.consumed_out = resume - prefix_bytes;
     if (req.carry_out) {

@@ -1309,6 +1309,45 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(256) void k_scatter_entries(SegEntry* __restrict__ entries, const uint32_t* __restrict__ index,
+                                                          const SegEntry* __restrict__ src, uint32_t count) {
+  // 16 words per entry: one thread per word
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 16u) return;
+  ((uint32_t*)(entries + index[t >> 4]))[t & 15u] = ((const uint32_t*)src)[t];
+}
+
+void lz77_scatter_entries(const Lz77Buffers& B, const uint32_t* index_dev, const SegEntry* entries_dev, uint32_t count) {
+  static_assert(sizeof(SegEntry) == 64, "k_scatter_entries copies 16 words per entry");
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_scatter_entries, dim3((count * 16u + 255) / 256), dim3(256), 0, BR_STREAM, B.entries, index_dev, entries_dev, count);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_gather_results(const SegExit* __restrict__ exits, const SegEntry* __restrict__ entries,
+                                                         const uint32_t* __restrict__ list, uint32_t count, const uint8_t* __restrict__ sched,
+                                                         uint32_t num_segments, SegExit* __restrict__ exits_out, uint32_t* __restrict__ cont_count,
+                                                         uint32_t* __restrict__ cont_index, SegExit* __restrict__ cont_exits,
+                                                         SegEntry* __restrict__ cont_entries) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) exits_out[t] = exits[list[t]];
+  if (t < num_segments && sched[t] == 3) {
+    const uint32_t j = atomicAdd(cont_count, 1u);
+    cont_index[j] = t;
+    cont_exits[j] = exits[t];
+    cont_entries[j] = entries[t];
+  }
+}
+
+void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, const uint8_t* sched_dev, uint32_t num_segments,
+                         SegExit* exits_out, uint32_t* cont_count, uint32_t* cont_index, SegExit* cont_exits, SegEntry* cont_entries) {
+  HIP_CHECK(hipMemsetAsync(cont_count, 0, 4, BR_STREAM));
+  const uint32_t n = count > num_segments ? count : num_segments;
+  hipLaunchKernelGGL(k_gather_results, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.exits, B.entries, list_dev, count, sched_dev, num_segments,
+                     exits_out, cont_count, cont_index, cont_exits, cont_entries);
+  HIP_CHECK(hipGetLastError());
+}
+
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
   const uint32_t n = P.total_bytes;
   HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, BR_STREAM));

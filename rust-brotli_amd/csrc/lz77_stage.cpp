@@ -1,5 +1,6 @@
 // lz77_stage.cpp -- see lz77_stage.h
 #include "lz77_stage.h"
+#include "timeline.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -730,7 +731,7 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
 // Segments whose entry changed in the distance cache only and whose parse found nothing to copy: instead of parsing
 // them again, ask the device whether any of the new cache distances would match at a searched position.  If not, the
 // old parse holds for the new entry as it stands (no command to re-code, the cache passes through).
-uint32_t Lz77Stage::RecheckCacheOnly(int which) {
+uint32_t Lz77Stage::RecheckCacheOnly(int which, std::vector<uint32_t>* accepted) {
   if (P_.hasher_kind == 9) return 0;
   const uint32_t nseg = (uint32_t)segments_.size();
   std::vector<CacheCheck> items;
@@ -758,6 +759,7 @@ uint32_t Lz77Stage::RecheckCacheOnly(int which) {
     if (!ok[i]) continue;
     const uint32_t k = items[i].segment;
     memcpy(entries_[k].cache, items[i].cache, sizeof(items[i].cache));
+    if (accepted) accepted->push_back(k);  // (the device's copy of this entry is stale now)
     dirty_entry_[k] = 0;
     ++cleared;
   }
@@ -806,7 +808,9 @@ void Lz77Stage::Run() {
   dev_d2h_async(key_last_.data(), B_.key_last, 65537 * 4);
   uint32_t run_samples = 0;
   dev_d2h_async(&run_samples, B_.changed_count + 8, 4);
+  timeline().stamp("sort-queued");
   dev_sync();
+  timeline().stamp("sorted");
   // long runs of one byte (zero fill ...): every candidate of every position inside a run matches to the end of the
   // block; the run table lets the chains jump over a run instead of comparing it 32 bytes at a time (lz77_chain.h).
   // One sample in 64 positions: 64 samples ~ 4 KiB of runs.
@@ -842,9 +846,12 @@ void Lz77Stage::Run() {
   }
   if (P_.reset_pos) has_big_keys_ = true;  // (the ring counters start over inside this text: wrap marks for every key)
   tm.stop(&stats_.ms_sort);
+  timeline().stamp("rounds");
   RunRounds(true);
   tm.stop(&stats_.ms_resolve);
+  timeline().stamp("gather");
   Gather();
+  timeline().stamp("gathered");
   tm.stop(&stats_.ms_gather);
   total.stop(&stats_.ms_total);
   if (prof)
@@ -902,6 +909,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
   }
   tm.stop(&stats_.ms_rank);
+  timeline().stamp("index-queued");
   if (selftest) {
     if (use_rows_) SelfTestRows(which); else SelfTestRank(which, rbuf);
   }
@@ -911,6 +919,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   if (const char* w = getenv("BROTLI_MI355X_WARMUP")) warmup_bytes_ = (uint32_t)atoi(w);
   if (nseg > 1 && warmup_bytes_ > 0) {
     Warmup(0, false, which, rbuf, nullptr);
+    timeline().stamp("warmed-up");
     if (P_.use_dictionary && warm_lookups_.size() == nseg) {
       // forecast of the segment in which the static dictionary gets switched off (matches < lookups >> 7,
       // mod.rs:1957-1960); chains behind it start with the "off" guess.  A wrong forecast only costs re-parses of
@@ -965,10 +974,35 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   geo.num_segments = nseg;
   geo.block_size = 1u << P_.block_bits;
   uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
-  uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
+  uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 8 + 64);  // (listed segments + entries accepted by RecheckCacheOnly)
   std::vector<uint8_t> dirty(nseg, 0);
   std::vector<uint32_t> list(nseg);
-  std::vector<SegEntry> used_entries(nseg);
+  // list rounds: compact transfers (lz77_scatter_entries / lz77_gather_results)
+  static constexpr uint32_t kContFirst = 64;
+  const uint32_t cont_cap = std::max(nseg, kContFirst);
+  SegEntry* up_entries_dev = (SegEntry*)dev_alloc_uninit((size_t)nseg * 2 * sizeof(SegEntry) + 64);
+  SegExit* got_exits_dev = (SegExit*)dev_alloc_uninit((size_t)nseg * sizeof(SegExit) + 64);
+  uint32_t* cont_count_dev = (uint32_t*)dev_alloc(64);
+  uint32_t* cont_index_dev = (uint32_t*)dev_alloc((size_t)cont_cap * 4 + 64);
+  SegExit* cont_exits_dev = (SegExit*)dev_alloc_uninit((size_t)cont_cap * sizeof(SegExit) + 64);
+  SegEntry* cont_entries_dev = (SegEntry*)dev_alloc_uninit((size_t)cont_cap * sizeof(SegEntry) + 64);
+  std::vector<uint32_t> also_upload;
+  RoundBuffers& rb = round_buffers_;  // page-locked, kept from call to call
+  rb.up_index.resize_discard((size_t)nseg * 2);
+  rb.up_entries.resize_discard((size_t)nseg * 2);
+  rb.got_exits.resize_discard(nseg);
+  rb.cont_index.resize_discard(cont_cap);
+  rb.cont_exits.resize_discard(cont_cap);
+  rb.cont_entries.resize_discard(cont_cap);
+  rb.counts.resize_discard(4);
+  uint32_t* up_index = rb.up_index.data();
+  SegEntry* up_entries = rb.up_entries.data();
+  SegExit* got_exits = rb.got_exits.data();
+  uint32_t* cont_index = rb.cont_index.data();
+  SegExit* cont_exits = rb.cont_exits.data();
+  SegEntry* cont_entries = rb.cont_entries.data();
+  volatile uint32_t* counts = rb.counts.data();  // [0] flag changes, [1] segments continued into
+  const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
   std::vector<uint32_t> changed_all(kChangedCap);
   std::vector<uint8_t> entry_streak(nseg, 0), was_dirty, cand_dirty, pending(nseg, 0), sched(nseg, 0);
   for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
@@ -980,16 +1014,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   bool restart = false;
   bool full_round = true;
   uint32_t last_death_seg = 0xffffffffu;
-  // BROTLI_MI355X_TIMELINE: host timestamps of every round (ms since the first round started)
-  static const bool timeline = getenv("BROTLI_MI355X_TIMELINE") != nullptr;
-  const auto tl0 = std::chrono::steady_clock::now();
-  std::string tl;
-  auto stamp = [&](const char* what) {
-    if (!timeline) return;
-    char buf[64];
-    snprintf(buf, sizeof(buf), " %s %.3f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
-    tl += buf;
-  };
+  auto stamp = [&](const char* what) { timeline().stamp(what); };  // BROTLI_MI355X_TIMELINE
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
     stats_.rounds++;
     stamp("| round");
@@ -998,10 +1023,19 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     if (full_round) {
       dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
     } else {
-      dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
-      dev_h2d(list_dev, list.data(), (size_t)count * 4);
+      // only the entries the host changed since the last launch: those of the listed segments and those whose distance
+      // cache RecheckCacheOnly() accepted
+      const uint32_t n_up = count + (uint32_t)also_upload.size();
+      for (uint32_t i = 0; i < n_up; ++i) {
+        up_index[i] = i < count ? list[i] : also_upload[i - count];
+        up_entries[i] = entries_[up_index[i]];
+      }
+      dev_h2d(list_dev, up_index, (size_t)n_up * 4);
+      dev_h2d(up_entries_dev, up_entries, (size_t)n_up * sizeof(SegEntry));
+      lz77_scatter_entries(B_, list_dev, up_entries_dev, n_up);
       dev_h2d(dirty_dev, sched.data(), nseg);
     }
+    also_upload.clear();
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     stamp("uploaded");
     if (full_round) {
@@ -1024,14 +1058,21 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     // everything the host needs from this launch in one round trip: exit records, the change list, and -- in list
     // rounds -- the entries and marks of the segments that chains continued into
-    uint32_t n_changed = 0;
-    dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
-    dev_d2h_async(&n_changed, B_.changed_count, 4);
-    if (!use_rows_) dev_d2h_async(changed_all.data(), B_.changed_keys, (size_t)kChangedCap * 4);
-    if (!full_round) {
-      dev_d2h_async(used_entries.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));
-      dev_d2h_async(sched.data(), dirty_dev, nseg);
+    counts[0] = counts[1] = 0;
+    if (full_round) {
+      dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
+    } else {
+      // the exits of the listed segments, and exit + rewritten entry of the segments that chains continued into (the
+      // first kContFirst of them ride along; more are rare and fetched afterwards)
+      lz77_gather_results(B_, list_dev, count, dirty_dev, nseg, got_exits_dev, cont_count_dev, cont_index_dev, cont_exits_dev, cont_entries_dev);
+      dev_d2h_async(got_exits, got_exits_dev, (size_t)count * sizeof(SegExit));
+      dev_d2h_async((void*)(counts + 1), cont_count_dev, 4);
+      dev_d2h_async(cont_index, cont_index_dev, (size_t)kContFirst * 4);
+      dev_d2h_async(cont_exits, cont_exits_dev, (size_t)kContFirst * sizeof(SegExit));
+      dev_d2h_async(cont_entries, cont_entries_dev, (size_t)kContFirst * sizeof(SegEntry));
     }
+    dev_d2h_async((void*)counts, B_.changed_count, 4);
+    if (!use_rows_) dev_d2h_async(changed_all.data(), B_.changed_keys, (size_t)kChangedCap * 4);
     if (use_rows_) {
       // the rows are brought up to date on the device (it decides by itself between the incremental and the full
       // rebuild) while the host chains the exits together: wait for the copies only
@@ -1045,19 +1086,21 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     } else {
       dev_sync();
     }
+    const uint32_t n_changed = counts[0], n_cont = counts[1];
     if (!full_round) {
+      for (uint32_t i = 0; i < count; ++i) exits_[list[i]] = got_exits[i];
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
-      uint32_t n_cont = 0, n_def0 = 0, n_def2 = 0;
-      for (uint32_t k = 0; k < nseg; ++k) {
-        n_cont += sched[k] == 3;
-        n_def2 += sched[k] == 2;
+      if (n_cont > kContFirst) {
+        dev_d2h(cont_index, cont_index_dev, (size_t)n_cont * 4);
+        dev_d2h(cont_exits, cont_exits_dev, (size_t)n_cont * sizeof(SegExit));
+        dev_d2h(cont_entries, cont_entries_dev, (size_t)n_cont * sizeof(SegEntry));
       }
-      (void)n_def0;
-      if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "  continued into %u segments, %u forced ones not reached\n", n_cont, n_def2);
-      for (uint32_t k = 0; k < nseg; ++k) {
-        if (sched[k] != 3) continue;
+      if (debug) fprintf(stderr, "  continued into %u segments\n", n_cont);
+      for (uint32_t i = 0; i < n_cont; ++i) {
+        const uint32_t k = cont_index[i];
         pending[k] = 0;
-        entries_[k] = used_entries[k];
+        exits_[k] = cont_exits[i];
+        entries_[k] = cont_entries[i];
         stats_.segments_parsed++;
       }
     }
@@ -1115,7 +1158,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     const auto host_t1 = std::chrono::steady_clock::now();
     host_resolve_ms_ += std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();
     stamp("resolved");
-    const uint32_t rechecked = RecheckCacheOnly(which);
+    const uint32_t rechecked = RecheckCacheOnly(which, &also_upload);
     stamp("rechecked");
     stats_.cache_rechecks += rechecked;
     for (uint32_t k = 0; k < nseg; ++k) dirty[k] = dirty_entry_[k] | pending[k];
@@ -1198,10 +1241,15 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     full_round = false;
   }
-  if (timeline) fprintf(stderr, "round timeline:%s\n", tl.c_str());
   dev_free(dirty_dev);
   dev_free(list_dev);
   dev_free(geo_tables);
+  dev_free(up_entries_dev);
+  dev_free(got_exits_dev);
+  dev_free(cont_count_dev);
+  dev_free(cont_index_dev);
+  dev_free(cont_exits_dev);
+  dev_free(cont_entries_dev);
   if (restart) {
     // what the pass so far says about the state at every block start
     saved_block_guess_.clear();

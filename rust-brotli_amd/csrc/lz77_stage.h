@@ -167,7 +167,12 @@ class Lz77Stage {
   std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
   std::vector<SegEntry> entries_;   // entries used by the most recent parse
   std::vector<SegEntry> next_entries_;
-  std::vector<SegExit> exits_;
+  PinnedArray<SegExit> exits_;  // (written by the device every round)
+  struct RoundBuffers {  // what list rounds move between host and device (RunRounds)
+    PinnedArray<uint32_t> up_index, cont_index, counts;
+    PinnedArray<SegEntry> up_entries, cont_entries;
+    PinnedArray<SegExit> got_exits, cont_exits;
+  } round_buffers_;
   std::vector<MetaBlockPlan> metablocks_;
   std::vector<uint32_t> forced_uncompressed_;
   struct Patch {
@@ -201,7 +206,7 @@ class Lz77Stage {
   uint32_t first_dirty_ = 0;
   std::vector<uint8_t> predicted_entry_;  // the entry chained for segment k comes out of a predicted literal run
   std::vector<uint8_t> entry_reason_;  // why dirty_entry_[k] is set, see Resolve()
-  uint32_t RecheckCacheOnly(int which);
+  uint32_t RecheckCacheOnly(int which, std::vector<uint32_t>* accepted = nullptr);
   double host_resolve_ms_ = 0, host_schedule_ms_ = 0;  // BROTLI_MI355X_PROFILE
   uint32_t predicted_runs_ = 0;  // segments whose exit the last Resolve() predicted (literal spree arithmetic)
   std::vector<uint8_t> dirty_entry_;

@@ -41,6 +41,11 @@ void dev_sync() {}
 void dev_mark() {}
 void dev_wait_mark() {}
 size_t dev_trim_pool() { return 0; }
+void* dev_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
+void dev_host_free(void* p) { free(p); }
+void dev_pool_counters(double* out, bool) {
+  for (int i = 0; i < 4; ++i) out[i] = 0;
+}
 const char* dev_name() { return "host-emulation"; }
 
 const DeviceTables& dev_tables() {
@@ -431,6 +436,24 @@ void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t nu
   for (uint32_t k = 0; k < num_segments; ++k)
     for (uint32_t i = 0; i < counts[k]; ++i)
       out[offsets[k] + i] = br_finish_command(B.cmds[(size_t)B.segments[k].cmd_base + i], P.num_direct_distance_codes, P.dist_postfix_bits);
+}
+
+void lz77_scatter_entries(const Lz77Buffers& B, const uint32_t* index, const SegEntry* entries, uint32_t count) {
+  for (uint32_t i = 0; i < count; ++i) B.entries[index[i]] = entries[i];
+}
+
+void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list, uint32_t count, const uint8_t* sched, uint32_t num_segments,
+                         SegExit* exits_out, uint32_t* cont_count, uint32_t* cont_index, SegExit* cont_exits, SegEntry* cont_entries) {
+  for (uint32_t i = 0; i < count; ++i) exits_out[i] = B.exits[list[i]];
+  uint32_t n = 0;
+  for (uint32_t k = num_segments; k-- > 0;) {  // (any order will do: the host must not rely on one)
+    if (sched[k] != 3) continue;
+    cont_index[n] = k;
+    cont_exits[n] = B.exits[k];
+    cont_entries[n] = B.entries[k];
+    ++n;
+  }
+  *cont_count = n;
 }
 
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
