@@ -614,7 +614,7 @@ static constexpr uint32_t kMaxRowWalk = 2048;  // slots one change may walk in k
 static_assert(kRowSpan == 256 * 5, "five span entries per thread");
 
 __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
-  if (a.conditional && a.ctl[kCtlNeedFull] == 0) return;
+  if (a.conditional == 1 && a.ctl[kCtlNeedFull] == 0) return;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   __shared__ uint32_t s_pos[kRowSpan];
   __shared__ uint32_t s_tk[kRowSpan];  // tag | key << 16
@@ -622,7 +622,6 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
   __shared__ uint16_t s_rank[kRowSpan];  // stored slots of the span in front of each entry
   __shared__ uint2 c_ent[kRowSpan];      // the stored slots, compacted: {position | wrap mark << 31, tag | key << 16}
   __shared__ uint32_t wave_sum[4];
-  __shared__ uint8_t s_slow[4][64];
   __shared__ alignas(16) uint32_t rowbuf[4][64 * kRowEntries];
   const uint32_t base = blockIdx.x * kRowTile;
   const uint32_t lo = base >= kRowHalo ? base - kRowHalo : 0u;
@@ -676,49 +675,70 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
       const uint32_t key = tk >> 16, tag = tk & 0xffffu;
       const uint32_t max_backward = p < a.max_backward_limit ? p : a.max_backward_limit;
       const uint32_t oldest = p >= a.reset_pos ? a.reset_vis : 0u;
+      // (the row is staged with its groups of four words permuted -- word j of lane l at j ^ swz(l) -- so that the lanes of
+      // a wave, which all write "their" j-th word at the same time, spread over the LDS banks)
       uint32_t* out = &rowbuf[w][lane * kRowEntries];
-      uint32_t k = s_rank[e], n = 0, seen = 0;
+      const uint32_t swz = ((lane >> 2) & 3u) << 2;
+      const uint32_t k0 = s_rank[e];
+      uint32_t n = 0;
       const uint32_t depth = (s_fb[e] & kSlotWrap) ? 0u : a.depth;
-      while (seen < depth) {
-        if (k == 0) {
-          // out of staged slots: slots of this key in front of the span need the slow walk through memory
-          slow = lo > 0 && (s_tk[0] >> 16) == key;
-          break;
+      // the candidates are the `depth` compact entries in front of the slot: fetched together, judged in order
+      uint2 ent[kRowEntries];
+#pragma unroll
+      for (uint32_t j = 0; j < kRowEntries; ++j) ent[j] = c_ent[k0 > j ? k0 - 1 - j : 0u];
+      bool live = true;
+#pragma unroll
+      for (uint32_t j = 0; j < kRowEntries; ++j) {
+        const bool wanted = live && j < depth;
+        // out of staged slots: slots of this key in front of the span need the slow walk through memory
+        if (wanted && k0 <= j) slow = lo > 0 && (s_tk[0] >> 16) == key;
+        const uint32_t q = ent[j].x & 0x7fffffffu;
+        const bool ok = wanted && k0 > j && (ent[j].y >> 16) == key && p - q <= max_backward && q >= oldest;
+        if (ok && (ent[j].y & 0xffffu) == tag) {
+          out[n ^ swz] = q;
+          n++;
         }
-        --k;
-        const uint2 ent = c_ent[k];
-        if ((ent.y >> 16) != key) break;
-        const uint32_t q = ent.x & 0x7fffffffu;
-        if (p - q > max_backward || q < oldest) break;
-        ++seen;
-        if ((ent.y & 0xffffu) == tag) out[n++] = q;
-        if (ent.x >> 31) break;
+        live = ok && (ent[j].x >> 31) == 0;
       }
       if (slow) {
         br_collect_row(sl, a.max_backward_limit, lo + e, a.key_first[key], a.depth, out, a.reset_pos, a.reset_vis);
+        uint32_t tmp[kRowEntries];
+#pragma unroll
+        for (uint32_t j = 0; j < kRowEntries; ++j) tmp[j] = out[j];
+#pragma unroll
+        for (uint32_t j = 0; j < kRowEntries; ++j) out[j ^ swz] = tmp[j];
       } else {
-        for (; n < kRowEntries; ++n) out[n] = kRowEnd;
+        for (; n < kRowEntries; ++n) out[n ^ swz] = kRowEnd;
       }
     }
-    s_slow[w][lane] = valid ? 0 : 1;
-    __syncthreads();
+    const unsigned long long rows_ready = __ballot(valid);
+    // (rowbuf[w] belongs to this wave alone and the LDS serves a wave in order: no workgroup barrier, which would also
+    // wait for the row stores of the previous pass to land)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // the 64 rows of this wave go out as 256 pieces of 16 bytes: four lanes write one 64-byte line
     for (uint32_t it = 0; it < 4; ++it) {
       const uint32_t idx = it * 64 + lane;
       const uint32_t row = idx >> 2, part = idx & 3u;
-      const bool go = s_slow[w][row] == 0;
+      const bool go = ((rows_ready >> row) & 1ull) != 0;
       bool diff = false;
       uint32_t p2 = 0;
       if (go) {
         p2 = s_pos[(base - lo) + w * 256 + r * 64 + row];
-        const u32x4 v = ((const u32x4*)rowbuf[w])[idx];
+        const u32x4 v = ((const u32x4*)rowbuf[w])[row * 4 + (part ^ ((row >> 2) & 3u))];
         u32x4* dst = (u32x4*)(a.rows + (size_t)p2 * kRowEntries) + part;
         if (a.validate) {
           const u32x4 old = *dst;
           diff = old.x != v.x || old.y != v.y || old.z != v.z || old.w != v.w;
           if (diff) *dst = v;
         } else {
+#if defined(BR_ROWS_PROBE)
+          if (a.conditional != 2) *dst = v;  // (timing experiment: everything but the stores)
+          else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *dst = v;
+#else
           *dst = v;
+#endif
         }
       }
       if (a.validate) {
@@ -726,7 +746,9 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
         if (go && part == 0 && ((m >> (lane & ~3u)) & 0xfull) != 0) row_changed(a, p2);
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -1059,6 +1081,10 @@ void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const 
   launch_slot_masks(P, B);
   RowArgs a = row_args(P, B, which, false, nullptr, nullptr);
   hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
+#if defined(BR_ROWS_PROBE)
+  a.conditional = 2;
+  hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
+#endif
   HIP_CHECK(hipGetLastError());
 }
 
