@@ -7,7 +7,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -207,6 +213,114 @@ void CompressChunk(const EncoderParams& user_params, const uint8_t* input, size_
   EncodeStream(req, out, nullptr);
 }
 
+// Host threads that keep several chunks of one BrotliEncoderCompressMulti call in flight on the device.  A chunk's
+// LZ77 rounds leave the device idle while the host resolves them, and its late rounds run a handful of wavefronts:
+// two or three chunks side by side fill those gaps.  The helpers live as long as the process (their device memory
+// pools and streams are per thread and are reused from call to call); BROTLI_MI355X_SHARD_WORKERS sets how many
+// chunks run at once (default 4, 1 = one after the other on the calling thread).
+class ShardWorkers {
+ public:
+  static ShardWorkers& Get() {
+    // (never destroyed: the helpers wait on its condition variable until the process ends, and tearing down their
+    // device memory pools from a static destructor would race the runtime's own shutdown)
+    static ShardWorkers* w = new ShardWorkers;
+    return *w;
+  }
+  // runs job(0) ... job(count - 1), each exactly once, on the calling thread and the helpers; rethrows the first exception
+  void Run(size_t count, const std::function<void(size_t)>& job) {
+    const size_t workers = std::min(count, WorkerCount());
+    if (workers <= 1) {
+      for (size_t i = 0; i < count; ++i) job(i);
+      return;
+    }
+    std::lock_guard<std::mutex> one_call_at_a_time(run_mu_);
+    Batch b;
+    b.count = count;
+    b.job = &job;
+    b.device = dev_current_device();
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      while (num_threads_ + 1 < workers) {
+        std::thread([this] { Loop(); }).detach();
+        ++num_threads_;
+      }
+      batch_ = &b;
+      b.helpers_wanted = workers - 1;
+      ++generation_;
+    }
+    cv_.notify_all();
+    Work(&b);
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      done_cv_.wait(lock, [&] { return b.helpers_in == 0 && b.helpers_wanted == 0; });
+      batch_ = nullptr;
+    }
+    if (b.error) std::rethrow_exception(b.error);
+  }
+
+ private:
+  struct Batch {
+    size_t count = 0;
+    const std::function<void(size_t)>* job = nullptr;
+    int device = 0;
+    std::atomic<size_t> next{0};
+    size_t helpers_wanted = 0, helpers_in = 0;  // (under mu_)
+    std::exception_ptr error;                   // (under mu_)
+  };
+  static size_t WorkerCount() {
+    static const size_t n = [] {
+      const char* e = getenv("BROTLI_MI355X_SHARD_WORKERS");
+      const long v = e ? atol(e) : 4;
+      return (size_t)std::min<long>(std::max<long>(v, 1), 8);
+    }();
+    return n;
+  }
+  void Work(Batch* b) {
+    for (;;) {
+      const size_t i = b->next.fetch_add(1);
+      if (i >= b->count) return;
+      try {
+        (*b->job)(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (!b->error) b->error = std::current_exception();
+        b->next.store(b->count);  // nobody starts another chunk
+      }
+    }
+  }
+  void Loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      Batch* b = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return generation_ != seen && batch_ != nullptr && batch_->helpers_wanted > 0; });
+        seen = generation_;
+        b = batch_;
+        b->helpers_wanted--;
+        b->helpers_in++;
+      }
+      try {
+        dev_use_device(b->device);
+        Work(b);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (!b->error) b->error = std::current_exception();
+      }
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        b->helpers_in--;
+      }
+      done_cv_.notify_all();
+    }
+  }
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  size_t num_threads_ = 0;
+  Batch* batch_ = nullptr;
+  uint64_t generation_ = 0;
+};
+
 bool ParamsFromLists(size_t num_params, const BrotliEncoderParameter* keys, const uint32_t* values, EncoderParams* p) {
   for (size_t i = 0; i < num_params; ++i)
     if (!SetParameter(p, (int)keys[i], values[i])) return false;
@@ -229,11 +343,14 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
     } else {
       EncoderParams params;
       if (!ParamsFromLists(num_params, keys, values, &params)) return 0;
+      // the chunks are independent streams (compress_multi hands them to a worker pool, threading/mod.rs:333-453):
+      // a few of them are in flight on the device at a time, each on the stream of its host thread
+      std::vector<std::vector<uint8_t>> chunks(num_threads);
+      ShardWorkers::Get().Run(num_threads, [&](size_t t) { CompressChunk(params, input, input_size, false, t, num_threads, &chunks[t], nullptr); });
       ChunkStitcher stitcher;
       for (size_t t = 0; t < num_threads; ++t) {
-        std::vector<uint8_t> chunk;
-        CompressChunk(params, input, input_size, false, t, num_threads, &chunk, nullptr);
-        if (!stitcher.Append(chunk.data(), chunk.size(), &out)) throw std::runtime_error("chunk cannot be concatenated");
+        if (!stitcher.Append(chunks[t].data(), chunks[t].size(), &out)) throw std::runtime_error("chunk cannot be concatenated");
+        std::vector<uint8_t>().swap(chunks[t]);
       }
       stitcher.Finish(&out);
     }

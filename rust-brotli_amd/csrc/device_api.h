@@ -36,6 +36,8 @@ void* dev_host_alloc(size_t bytes);
 void dev_host_free(void* p);
 void dev_pool_counters(double* out4, bool reset);  // hipMalloc calls / ms, hipFree calls / ms of the calling thread
 size_t dev_trim_pool();  // returns the pooled, currently unused device memory of the calling thread to the driver; bytes freed
+int dev_current_device();        // the calling thread's device (helper threads adopt their caller's)
+void dev_use_device(int device);
 const char* dev_name();  // "hip:gfx950 ..." or "host-emulation"
 
 // Static read-only tables resident on the device (dictionary, dictionary hash, log tables ...).

@@ -235,6 +235,13 @@ size_t dev_trim_pool() {
   return bytes;
 }
 
+int dev_current_device() {
+  int d = 0;
+  HIP_CHECK(hipGetDevice(&d));
+  return d;
+}
+void dev_use_device(int device) { HIP_CHECK(hipSetDevice(device)); }
+
 const char* dev_name() {
   static std::string name;
   static std::once_flag once;

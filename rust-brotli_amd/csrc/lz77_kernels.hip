@@ -614,7 +614,7 @@ static constexpr uint32_t kMaxRowWalk = 2048;  // slots one change may walk in k
 static_assert(kRowSpan == 256 * 5, "five span entries per thread");
 
 __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
-  if (a.conditional == 1 && a.ctl[kCtlNeedFull] == 0) return;
+  if (a.conditional && a.ctl[kCtlNeedFull] == 0) return;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   __shared__ uint32_t s_pos[kRowSpan];
   __shared__ uint32_t s_tk[kRowSpan];  // tag | key << 16
@@ -733,12 +733,7 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
           diff = old.x != v.x || old.y != v.y || old.z != v.z || old.w != v.w;
           if (diff) *dst = v;
         } else {
-#if defined(BR_ROWS_PROBE)
-          if (a.conditional != 2) *dst = v;  // (timing experiment: everything but the stores)
-          else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *dst = v;
-#else
           *dst = v;
-#endif
         }
       }
       if (a.validate) {
@@ -1081,10 +1076,6 @@ void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const 
   launch_slot_masks(P, B);
   RowArgs a = row_args(P, B, which, false, nullptr, nullptr);
   hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
-#if defined(BR_ROWS_PROBE)
-  a.conditional = 2;
-  hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
-#endif
   HIP_CHECK(hipGetLastError());
 }
 

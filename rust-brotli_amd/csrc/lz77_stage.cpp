@@ -885,6 +885,16 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   tm.stop(&stats_.ms_init);
   const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
   if (selftest) SelfTestSort();
+  int which = 0, rbuf = 0;
+  // (the index build is queued first: the device works on it while the host prepares the entries)
+  {
+    RankInitialHint hint{segments_[0].blk_start, block_bytes_, (carry_ && carry_->valid) ? 0u : 1u};
+    if (use_rows_) {
+      lz77_rows_init(P_, B_, which, &hint, has_big_keys_);
+    } else {
+      lz77_rank_flags(P_, B_, which, rbuf, &hint);
+    }
+  }
   // first guess of the entries: every chain starts at its segment start with the default cache
   entries_.assign(nseg, SegEntry{});
   for (uint32_t k = 0; k < nseg; ++k) {
@@ -899,15 +909,6 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
   }
   exits_.assign(nseg, SegExit{});
-  int which = 0, rbuf = 0;
-  {
-    RankInitialHint hint{segments_[0].blk_start, block_bytes_, (carry_ && carry_->valid) ? 0u : 1u};
-    if (use_rows_) {
-      lz77_rows_init(P_, B_, which, &hint, has_big_keys_);
-    } else {
-      lz77_rank_flags(P_, B_, which, rbuf, &hint);
-    }
-  }
   tm.stop(&stats_.ms_rank);
   timeline().stamp("index-queued");
   if (selftest) {

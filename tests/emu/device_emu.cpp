@@ -41,6 +41,8 @@ void dev_sync() {}
 void dev_mark() {}
 void dev_wait_mark() {}
 size_t dev_trim_pool() { return 0; }
+int dev_current_device() { return 0; }
+void dev_use_device(int) {}
 void* dev_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
 void dev_host_free(void* p) { free(p); }
 void dev_pool_counters(double* out, bool) {

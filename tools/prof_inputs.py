@@ -11,6 +11,7 @@ import gpulib  # noqa: E402
 import synth  # noqa: E402
 
 N = int(os.environ.get("PROF_MIB", "64")) << 20
+Q = int(os.environ.get("PROF_Q", "5"))
 GEN = {
     "text": lambda: synth.markov_text(N),
     "random": lambda: synth.random_bytes(N),
@@ -23,9 +24,10 @@ GEN = {
 L = gpulib.lib()
 for name in (sys.argv[1:] or list(GEN)):
     data = GEN[name]()
-    emu.encode_stream(L, data, [(1, 5), (2, 22), (5, len(data))])  # warm the pools
+    emu.encode_stream(L, data, [(1, Q), (2, 22), (5, len(data))])  # warm the pools
     t = time.time()
-    out, st = emu.encode_stream(L, data, [(1, 5), (2, 22), (5, len(data))])
+    out, st = emu.encode_stream(L, data, [(1, Q), (2, 22), (5, len(data))])
     dt = time.time() - t
-    print("== %s: %d -> %d bytes, %.1f ms (%.0f MB/s), rounds %d, lz77 %.1f ms, metablock %.1f ms" %
-          (name, len(data), len(out), dt * 1e3, len(data) / dt / 1e6, st["lz77_rounds"], st["ms_lz77"], st["ms_metablock"]), flush=True)
+    print("== %s: %d -> %d bytes, %.1f ms (%.0f MB/s), rounds %d, lz77 %.1f ms, metablock %.1f ms; final parse: %d searches, %d commands, %d literals" %
+          (name, len(data), len(out), dt * 1e3, len(data) / dt / 1e6, st["lz77_rounds"], st["ms_lz77"], st["ms_metablock"],
+           st.get("searches", -1), st.get("commands", -1), st.get("literals", -1)), flush=True)
