@@ -193,7 +193,8 @@ void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t nu
 // applies extend_last_command / trailing insert-only fix-ups to the gathered commands
 void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n);
 
-// grow-only array in page-locked host memory (contents are not preserved by resize_discard)
+// grow-only array in page-locked host memory (contents are not preserved by resize_discard).  Copies from and to it are
+// truly asynchronous: wait (dev_sync / dev_wait_mark) before rewriting the source of an upload or letting the array go.
 template <typename T>
 struct PinnedArray {
   T* ptr = nullptr;

@@ -173,6 +173,7 @@ void dev_host_free(void* p) {
   }
   P.free_blocks.emplace(it->second, p);
 }
+static void wait_stream();
 void dev_memset(void* p, int value, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemsetAsync(p, value, bytes, BR_STREAM));
 }
@@ -185,13 +186,31 @@ void dev_d2h_async(void* dst, const void* src, size_t bytes) {
 void dev_d2h(void* dst, const void* src, size_t bytes) {
   if (bytes) {
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, BR_STREAM));
-    HIP_CHECK(hipStreamSynchronize(BR_STREAM));
+    wait_stream();
   }
 }
 void dev_d2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, BR_STREAM));
 }
-void dev_sync() { HIP_CHECK(hipStreamSynchronize(BR_STREAM)); }
+// The waits of the encoder are short (a launch, a copy) and sit on its critical path: they poll instead of sleeping on
+// an interrupt (BROTLI_MI355X_BLOCKING_WAIT=1 restores the runtime's own wait).
+static bool polling_waits() {
+  static const bool on = getenv("BROTLI_MI355X_BLOCKING_WAIT") == nullptr;
+  return on;
+}
+static void wait_stream() {
+  if (!polling_waits()) {
+    HIP_CHECK(hipStreamSynchronize(BR_STREAM));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipStreamQuery(BR_STREAM);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    __builtin_ia32_pause();
+  }
+}
+void dev_sync() { wait_stream(); }
 
 namespace {
 struct Mark {
@@ -212,7 +231,17 @@ void dev_mark() {
 }
 void dev_wait_mark() {
   Mark& m = mark();
-  if (m.ev) HIP_CHECK(hipEventSynchronize(m.ev));
+  if (!m.ev) return;
+  if (!polling_waits()) {
+    HIP_CHECK(hipEventSynchronize(m.ev));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipEventQuery(m.ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    __builtin_ia32_pause();
+  }
 }
 
 // gives the pooled (currently unused) device memory of the calling thread back to the driver

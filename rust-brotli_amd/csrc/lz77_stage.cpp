@@ -141,7 +141,9 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   gather_offsets_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
   gather_counts_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
   owns_buffers_ = true;
-  dev_h2d(B_.segments, segments_.data(), segments_.size() * sizeof(Segment));
+  segments_upload_.resize_discard(segments_.size());
+  memcpy(segments_upload_.data(), segments_.data(), segments_.size() * sizeof(Segment));
+  dev_h2d(B_.segments, segments_upload_.data(), segments_.size() * sizeof(Segment));
 }
 
 void Lz77Stage::BuildSegments() {
@@ -658,8 +660,13 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
     if (!only_after_dirty || ((*only_after_dirty)[k] && (*only_after_dirty)[k + 1])) ks.push_back(k);
   const uint32_t count = (uint32_t)ks.size();
   if (count == 0) return;
-  std::vector<Segment> wsegs(count);
-  std::vector<SegEntry> wentries(count);
+  // (page-locked like everything that moves every call: copies from pageable memory go through the runtime's staging)
+  PinnedArray<Segment> wsegs;
+  PinnedArray<SegEntry> wentries;
+  PinnedArray<SegExit> wexits;
+  wsegs.resize_discard(count);
+  wentries.resize_discard(count);
+  wexits.resize_discard(count);
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = ks[i];
     Segment g = segments_[k];
@@ -680,7 +687,6 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
   dev_h2d(wsegs_dev, wsegs.data(), count * sizeof(Segment));
   dev_h2d(wentries_dev, wentries.data(), count * sizeof(SegEntry));
   lz77_parse_custom(P_, B_, which, rbuf, wsegs_dev, wentries_dev, wexits_dev, count);
-  std::vector<SegExit> wexits(count);
   dev_d2h(wexits.data(), wexits_dev, count * sizeof(SegExit));
   dev_free(wsegs_dev);
   dev_free(wentries_dev);
@@ -802,8 +808,8 @@ void Lz77Stage::Run() {
   lz77_compute_keys(P_, B_);
   tm.stop(&stats_.ms_keys);
   lz77_sort_by_key(P_, B_);
-  key_first_.resize(65537);
-  key_last_.resize(65537);
+  key_first_.resize_discard(65537);
+  key_last_.resize_discard(65537);
   dev_d2h_async(key_first_.data(), B_.key_first, 65537 * 4);
   dev_d2h_async(key_last_.data(), B_.key_last, 65537 * 4);
   uint32_t run_samples = 0;
@@ -874,7 +880,9 @@ void Lz77Stage::Resegment(uint32_t segment_bytes) {
     B_.cmds = (Command*)dev_alloc_uninit(need);
     cmds_bytes_ = need;
   }
-  dev_h2d(B_.segments, segments_.data(), segments_.size() * sizeof(Segment));
+  segments_upload_.resize_discard(segments_.size());
+  memcpy(segments_upload_.data(), segments_.data(), segments_.size() * sizeof(Segment));
+  dev_h2d(B_.segments, segments_upload_.data(), segments_.size() * sizeof(Segment));
 }
 
 void Lz77Stage::RunRounds(bool allow_restart) {

@@ -164,8 +164,9 @@ class Lz77Stage {
   bool final_dict_dead_ = false;
   std::map<uint32_t, SegEntry> saved_block_guess_;  // by block start
   size_t cmds_bytes_ = 0;
-  std::vector<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
-  std::vector<SegEntry> entries_;   // entries used by the most recent parse
+  PinnedArray<uint32_t> key_first_, key_last_;  // host copy of the slot range of every key
+  PinnedArray<Segment> segments_upload_;        // page-locked staging of segments_ on its way to the device
+  PinnedArray<SegEntry> entries_;   // entries used by the most recent parse (page-locked: uploaded whole in round 0)
   std::vector<SegEntry> next_entries_;
   PinnedArray<SegExit> exits_;  // (written by the device every round)
   struct RoundBuffers {  // what list rounds move between host and device (RunRounds)

@@ -83,7 +83,7 @@ void mb_granule_histograms(const MbBuffers& B) {
 }
 
 void mb_split_chains(const MbBuffers& B, bool /*wide*/) {
-  static SplitScratch S;
+  static thread_local SplitScratch S;  // (BrotliEncoderCompressMulti runs chunks on several host threads)
   for (uint32_t m = 0; m < B.n_mb; ++m)
     for (uint32_t kind = 0; kind < 3; ++kind) mb_item_split_chain(B, m, kind, S);
 }
