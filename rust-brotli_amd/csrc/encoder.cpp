@@ -319,12 +319,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   DevMem mem;
   const uint32_t M = prefix_bytes + (uint32_t)n;
   uint8_t* text = mem.alloc<uint8_t>((size_t)M + 64);
-  if (prefix_bytes) dev_h2d(text, req.prefix + (req.prefix_size - prefix_bytes), prefix_bytes);
+  if (prefix_bytes) dev_h2d_bulk(text, req.prefix + (req.prefix_size - prefix_bytes), prefix_bytes);
   if (n) {
     if (req.input_on_device) {
       dev_d2d(text + prefix_bytes, req.input, n);
     } else {
-      dev_h2d(text + prefix_bytes, req.input, n);
+      dev_h2d_bulk(text + prefix_bytes, req.input, n);
     }
   }
   stats.ms_phase[0] = total_clock.lap(prof, "input-copied");
@@ -704,13 +704,13 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         dev_d2d(req.direct_out, B.out_words, total_bytes);
         dev_sync();
       } else {
-        dev_d2h(req.direct_out, B.out_words, total_bytes);
+        dev_d2h_bulk(req.direct_out, B.out_words, total_bytes);
       }
       *req.direct_size = total_bytes;
       wrote_direct = true;
     } else {
       result.resize(total_bytes);
-      dev_d2h(result.data(), B.out_words, total_bytes);
+      dev_d2h_bulk(result.data(), B.out_words, total_bytes);
     }
     stats.ms_phase[8] += clk.lap(prof, "mb8");
     const uint32_t resume = partial ? lz.resume_pos() : M;  // text position where the next piece takes over

@@ -41,6 +41,8 @@ void dev_sync() {}
 void dev_mark() {}
 void dev_wait_mark() {}
 size_t dev_trim_pool() { return 0; }
+void dev_h2d_bulk(void* dst, const void* src, size_t bytes) { dev_h2d(dst, src, bytes); }
+void dev_d2h_bulk(void* dst, const void* src, size_t bytes) { dev_d2h(dst, src, bytes); }
 int dev_current_device() { return 0; }
 void dev_use_device(int) {}
 void* dev_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
