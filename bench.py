@@ -383,6 +383,26 @@ def main():
         sec, _ = timed_steps(e2e_step, args.steps, 1, torch)
         line["e2e"] = {"what": "pinned host -> HBM copy of the input + the step (the output always lands in host memory)",
                        "ms_per_step": round(sec * 1e3, 3), "value": round(total / sec / 1e6, 2), "unit": "MB/s"}
+        # what a drop-in caller of the C ABI sees: BrotliEncoderCompress with input and output in ordinary (pageable) memory
+        try:
+            cabi = lib.lib.BrotliEncoderCompress
+            cabi.restype = ctypes.c_int
+            cabi.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p]
+            src = ctypes.create_string_buffer(chunk, len(chunk))
+            cap = len(chunk) + len(chunk) // 4 + 4096
+            dst = ctypes.create_string_buffer(cap)
+
+            def abi_step():
+                n_out = ctypes.c_size_t(cap)
+                if cabi(QUALITY, LGWIN, 0, len(chunk), src, ctypes.byref(n_out), dst) != 1:
+                    raise RuntimeError("BrotliEncoderCompress failed")
+                return n_out.value
+            sec, n_out = timed_steps(abi_step, args.steps, 2, torch)
+            line["e2e"]["c_abi_pageable"] = {"what": "BrotliEncoderCompress(quality, lgwin, mode, size, in, &out_size, out), both buffers pageable",
+                                             "ms_per_step": round(sec * 1e3, 3), "value": round(total / sec / 1e6, 2), "unit": "MB/s",
+                                             "same_bytes_as_the_step": bytes(dst.raw[:n_out]) == comp}
+        except Exception as e:
+            line["e2e"]["c_abi_pageable"] = {"error": repr(e)}
     if not args.no_cpu_baseline and not shard_job:  # (the CPU leg is reported at N = 1 only)
         base, ref_bytes = cpu_baseline(stream)
         line["cpu_baseline"] = base
