@@ -147,10 +147,16 @@ def other_workloads(torch, bm, lib, enc, frozen):
             dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
             params = [(bm.BROTLI_PARAM_QUALITY, case["quality"]), (bm.BROTLI_PARAM_LGWIN, case["lgwin"]),
                       (bm.BROTLI_PARAM_SIZE_HINT, min(len(data), 1 << 30))]
-            sec, out = timed_steps(lambda: enc.encode(params, b"", dev.data_ptr(), len(data), True), 2, 1, torch)
-            entry["residency"] = "input resident in HBM"
+            cap = len(data) + len(data) // 4 + 4096
+            pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()  # (as in the headline step: page-locked output buffer)
+            saved = (enc._out, enc._out_owner)
+            enc.use_output_buffer(pinned.data_ptr(), cap, pinned)
+            sec, out = timed_steps(lambda: enc.encode(params, b"", dev.data_ptr(), len(data), True, copy=False), 2, 1, torch)
+            out = bytes(out)
+            enc._out, enc._out_owner = saved
+            entry["residency"] = "input resident in HBM, output to page-locked host memory"
             entry["lz77_rounds"] = enc.stats[0]
-            del dev
+            del dev, pinned
         entry.update({"value": round(len(data) / sec / 1e6, 1), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 2), "compressed_bytes": len(out),
                       "identical_to_cpu_oracle": hashlib.sha256(out).hexdigest() == frozen[name]["stream_sha256"],
                       "input_generated_in_s": round(gen_s, 1)})
@@ -268,6 +274,11 @@ def main():
     torch.cuda.synchronize()
 
     enc = multi.ShardEncoder(lib.lib, args.segment_bytes)
+    # the compressed stream lands in page-locked host memory (a caller that hands over ordinary memory is measured
+    # separately: e2e.c_abi_pageable)
+    out_cap = len(chunk) + len(chunk) // 4 + 4096
+    out_pinned = torch.empty(out_cap, dtype=torch.uint8).pin_memory()
+    enc.use_output_buffer(out_pinned.data_ptr(), out_cap, out_pinned)
     work_fn = lib.lib.brotli_mi355x_last_parse_work
     work_fn.argtypes = [ctypes.POINTER(ctypes.c_double)]
     work_fn.restype = None

@@ -49,6 +49,13 @@ class ShardEncoder(object):
         self.stats = (ctypes.c_double * 32)()
         self._err = ctypes.create_string_buffer(512)
         self._out = None
+        self._out_owner = None
+
+    def use_output_buffer(self, address, nbytes, owner):
+        """Have encode() deliver into caller memory (e.g. a page-locked torch tensor, which the library fills by DMA instead of
+        bouncing the stream through its own staging buffers); `owner` is kept alive with the encoder."""
+        self._out = (ctypes.c_char * nbytes).from_address(address)
+        self._out_owner = owner
 
     def encode(self, params, prefix, chunk, nbytes, on_device, copy=True):
         """chunk: device address (on_device) or bytes.  Returns the compressed shard as bytes -- or, with copy=False, as a

@@ -28,7 +28,7 @@ void dev_d2h(void* dst, const void* src, size_t bytes);        // copy + wait
 // bulk transfers between the caller's (ordinary, pageable) memory and the device: chunks are bounced through two
 // page-locked buffers so that the host copy of one overlaps the bus transfer of the other (the runtime's own path for
 // pageable memory moves 64 MiB in ~28 ms); memory that is already page-locked is copied directly.  dev_d2h_bulk
-// returns when the data has arrived (it only bounces when BROTLI_MI355X_BULK asks for it, see device_runtime.hip).
+// returns when the data has arrived.
 void dev_h2d_bulk(void* dst, const void* src, size_t bytes);
 void dev_d2h_bulk(void* dst, const void* src, size_t bytes);
 void dev_d2h_async(void* dst, const void* src, size_t bytes);  // several copies, then one dev_sync()

@@ -28,7 +28,7 @@ struct Pool {
   std::multimap<size_t, void*> free_blocks;  // capacity -> block
   std::unordered_map<void*, size_t> capacity;  // every live block handed out or pooled
   size_t pooled_bytes = 0;
-  static constexpr size_t kMaxPooled = (size_t)96 << 30;
+  static constexpr size_t kMaxPooled = (size_t)192 << 30;  // (a 1 GiB piece alone needs ~90 GiB; of 288)
   ~Pool() {
     for (auto& kv : free_blocks) (void)hipFree(kv.second);  // (errors at process exit are of no consequence)
   }
@@ -205,12 +205,7 @@ struct Bounce {
   }
   void wait(int i) {
     if (!busy[i]) return;
-    for (;;) {
-      const hipError_t e = hipEventQuery(ev[i]);
-      if (e == hipSuccess) break;
-      if (e != hipErrorNotReady) HIP_CHECK(e);
-      __builtin_ia32_pause();
-    }
+    HIP_CHECK(hipEventSynchronize(ev[i]));
     busy[i] = false;
   }
 };
@@ -228,11 +223,11 @@ bool is_page_locked(const void* p) {
 }
 }  // namespace
 // BROTLI_MI355X_BULK: bit 0 = bounce uploads, bit 1 = bounce downloads.  Measured on 64 MiB in / 16 MB out per call
-// (tools/host_path.py): neither 48 ms per call, uploads only 29 ms, downloads only 28 ms, both 30 ms -- but a download
-// into a buffer the caller reuses goes at bus speed directly (the runtime keeps it registered), so only uploads are
-// bounced by default.
+// (tools/host_path.py, bench.py's c_abi_pageable): with neither 48 ms per call; with both 30 ms.  Bouncing only one
+// direction gave 28-29 ms in one harness and 48 ms in another -- the runtime's own path for pageable memory is the
+// part that is not dependable, so both directions are bounced unless the caller's buffer is page-locked.
 static int bulk_mode() {
-  static const int m = getenv("BROTLI_MI355X_BULK") ? atoi(getenv("BROTLI_MI355X_BULK")) : 1;
+  static const int m = getenv("BROTLI_MI355X_BULK") ? atoi(getenv("BROTLI_MI355X_BULK")) : 3;
   return m;
 }
 void dev_h2d_bulk(void* dst, const void* src, size_t bytes) {
@@ -284,10 +279,11 @@ void dev_d2h_bulk(void* dst, const void* src, size_t bytes) {
 void dev_d2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, BR_STREAM));
 }
-// The waits of the encoder are short (a launch, a copy) and sit on its critical path: they poll instead of sleeping on
-// an interrupt (BROTLI_MI355X_BLOCKING_WAIT=1 restores the runtime's own wait).
+// BROTLI_MI355X_POLLING_WAIT=1: poll (hipStreamQuery / hipEventQuery) instead of sleeping in the runtime's wait.  Off by
+// default: a caller that polls in a tight loop keeps the runtime from feeding large copies (1 GiB host to host went from
+// 2.1 to 4.9 s), and the short waits between LZ77 rounds gained nothing measurable from it.
 static bool polling_waits() {
-  static const bool on = getenv("BROTLI_MI355X_BLOCKING_WAIT") == nullptr;
+  static const bool on = getenv("BROTLI_MI355X_POLLING_WAIT") != nullptr;
   return on;
 }
 static void wait_stream() {

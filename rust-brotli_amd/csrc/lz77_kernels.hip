@@ -864,8 +864,9 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
     return;
   }
   if (i >= n) return;
-  // many changes: one pass over all rows (2 ms per 64 Mi slots) is cheaper than a walk per change (20-30 ns each)
-  if (i == 0 && n > total_slots / 1024) atomicMax(&ctl[kCtlNeedFull], 1u);
+  // many changes: one pass over all rows is cheaper than a walk per change.  (Tried total_slots / 1024 with a walk budget
+  // of n / 64: 64 MiB of random bytes went from 70 to 55 ms, 1 GiB of them from 1.8 to 3.4 s.)
+  if (i == 0 && n > total_slots / 256) atomicMax(&ctl[kCtlNeedFull], 1u);
   const uint32_t p = changed_pos[i];
   const uint32_t key = keys[p];
   uint32_t lo = key_first[key], hi = key_last[key];
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
     // A change in front of a long stretch of unstored slots reaches every row of the stretch, and several such changes
     // walk the same stretch again and again: when the walks add up to a good part of all rows, the full rebuild behind
     // this kernel is the cheaper way (what was updated here has been checked and marked already).
-    if (a.walk_counter[kCtlWalked] > a.n / 64 || *(volatile const uint32_t*)&a.ctl[kCtlNeedFull] != 0) {
+    if (a.walk_counter[kCtlWalked] > a.n / 16 || *(volatile const uint32_t*)&a.ctl[kCtlNeedFull] != 0) {
       if (threadIdx.x == 0) atomicMax(&a.walk_counter[kCtlNeedFull], 1u);
       return;
     }
