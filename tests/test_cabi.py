@@ -224,3 +224,23 @@ def test_concurrent_calls_from_threads():
         t.join()
     assert not errors, errors
     assert results == expected
+
+
+def _multi_shards_in_flight(lib):
+    """BrotliEncoderCompressMulti keeps several shards in flight on helper threads (cabi.cpp, ShardWorkers): the stitched
+    stream must be the oracle's compress_multi whatever order the shards finish in -- repeated, because a race between
+    the helpers would only show now and then"""
+    cases = [(synth.mixed(1000003, seed=5), 5, 22, 8), (synth.markov_text(700001, 3), 6, 20, 5), (synth.mixed(300000, seed=9), 9, 20, 8)]
+    for data, q, w, shards in cases:
+        want = orc.compress_multi(data, [(Q, q), (W, w)], shards)
+        for _ in range(4):
+            assert bytes(lib.BrotliCompress(data, {Q: q, W: w}, shards)) == want
+
+
+def test_multi_shards_in_flight_emulation():
+    _multi_shards_in_flight(_load("emu"))
+
+
+@pytest.mark.gpu
+def test_multi_shards_in_flight_gpu():
+    _multi_shards_in_flight(_load("gpu"))
