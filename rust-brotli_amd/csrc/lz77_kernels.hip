@@ -593,7 +593,9 @@ struct RowArgs {
   uint32_t conditional;
 };
 // device-side control words of lz77_rows_update
-enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtlWords = 4 };
+enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtlWrapKeyFlip = 3, kCtlWords = 4 };
+// kCtlWrapKeyFlip: some flag flipped in a key whose ring counter can wrap (>= 65 536 slots; every key when the counters
+// run on from the stream in front or start over at a hasher reset) -- only then can wrap marks have moved this round
 
 __device__ __forceinline__ void row_changed(const RowArgs& a, uint32_t p) {
   if (p < a.geo.first_block_start) return;
@@ -748,7 +750,8 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_fbits_tile_sums(const uint8_t* __restrict__ fbits, uint32_t n, const uint8_t* __restrict__ big_tile,
-                                                          uint32_t* __restrict__ tile_sums) {
+                                                          uint32_t* __restrict__ tile_sums, const uint32_t* __restrict__ skip_unless) {
+  if (skip_unless && *skip_unless == 0) return;  // (round update without a flip in a key that can wrap)
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kRowTile + threadIdx.x * 4;
   uint32_t local = 0;
@@ -765,7 +768,9 @@ __global__ __launch_bounds__(256) void k_fbits_tile_sums(const uint8_t* __restri
 
 __global__ __launch_bounds__(256) void k_row_key_bases(const uint8_t* __restrict__ fbits, const uint32_t* __restrict__ tile_offsets,
                                                         const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last,
-                                                        uint32_t* __restrict__ key_base, uint32_t all_keys) {
+                                                        uint32_t* __restrict__ key_base, uint32_t all_keys,
+                                                        const uint32_t* __restrict__ skip_unless) {
+  if (skip_unless && *skip_unless == 0) return;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= 65536) return;
   const uint32_t i0 = key_first[k];
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits,
                                                      uint32_t* __restrict__ ctl, const uint32_t* __restrict__ count_base,
                                                      const uint32_t* __restrict__ by_key, uint32_t reset_pos,
                                                      const uint32_t* __restrict__ reset_counts) {
+  if (append && ctl[kCtlWrapKeyFlip] == 0) return;
   if (!big_tile[blockIdx.x]) return;
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kRowTile + threadIdx.x * 4;
@@ -856,11 +862,15 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
                                                       uint32_t cap, const uint16_t* __restrict__ keys, const uint32_t* __restrict__ key_first,
                                                       const uint32_t* __restrict__ key_last, const uint32_t* __restrict__ by_key,
                                                       const uint8_t* __restrict__ flags_new, uint8_t* __restrict__ fbits,
-                                                      uint32_t* __restrict__ changed_slot, uint32_t* __restrict__ ctl, uint32_t total_slots) {
+                                                      uint32_t* __restrict__ changed_slot, uint32_t* __restrict__ ctl, uint32_t total_slots,
+                                                      uint32_t all_keys) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = *changed_count;
   if (n > cap) {
-    if (i == 0) atomicMax(&ctl[kCtlNeedFull], 2u);
+    if (i == 0) {
+      atomicMax(&ctl[kCtlNeedFull], 2u);
+      atomicMax(&ctl[kCtlWrapKeyFlip], 1u);  // (the list is incomplete: anything may have flipped)
+    }
     return;
   }
   if (i >= n) return;
@@ -870,6 +880,7 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
   const uint32_t p = changed_pos[i];
   const uint32_t key = keys[p];
   uint32_t lo = key_first[key], hi = key_last[key];
+  if (all_keys || hi - lo >= 65536u) atomicMax(&ctl[kCtlWrapKeyFlip], 1u);
   while (lo + 1 < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
     if (by_key[mid] <= p) lo = mid; else hi = mid;
@@ -1040,11 +1051,12 @@ static void launch_wrap_marks(const Lz77Params& P, const Lz77Buffers& B, bool ap
   const uint32_t tiles = (n + kRowTile - 1) / kRowTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
-  hipLaunchKernelGGL(k_fbits_tile_sums, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums);
+  const uint32_t* skip_unless = append ? B.row_ctl + kCtlWrapKeyFlip : (const uint32_t*)nullptr;
+  hipLaunchKernelGGL(k_fbits_tile_sums, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums, skip_unless);
   exclusive_scan_u32(tile_sums, tiles, scratch);
   const bool all_keys = B.count_base != nullptr || P.reset_pos != 0;
   hipLaunchKernelGGL(k_row_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base,
-                     all_keys ? 1u : 0u);
+                     all_keys ? 1u : 0u, skip_unless);
   hipLaunchKernelGGL(k_mark_wraps, dim3(tiles), dim3(256), 0, BR_STREAM, B.fbits, n, B.big_tile, tile_sums, B.sorted_keys, B.key_first, B.key_last,
                      B.key_base, append ? 1u : 0u, B.changed_slot, B.changed_count, B.changed_cap, B.row_ctl, B.count_base, B.by_key, P.reset_pos,
                      B.reset_counts);
@@ -1089,7 +1101,8 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   // (B.changed_keys holds POSITIONS here, B.changed_count their number -- see lz77_diff_flags)
   const uint32_t flip_blocks = (cap + 255) / 256;
   hipLaunchKernelGGL(k_apply_flips, dim3(flip_blocks), dim3(256), 0, BR_STREAM, B.changed_keys, B.changed_count, cap, B.keys, B.key_first,
-                     B.key_last, B.by_key, B.flags[next], B.fbits, B.changed_slot, B.row_ctl, n);
+                     B.key_last, B.by_key, B.flags[next], B.fbits, B.changed_slot, B.row_ctl, n,
+                     (B.count_base != nullptr || P.reset_pos != 0) ? 1u : 0u);
   uint32_t gather_blocks = (n + 255) / 256;
   if (gather_blocks > 8192) gather_blocks = 8192;
   hipLaunchKernelGGL(k_regather_fbits, dim3(gather_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.flags[next], n, B.fbits, B.row_ctl);
