@@ -347,12 +347,20 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
       // a few of them are in flight on the device at a time, each on the stream of its host thread
       std::vector<std::vector<uint8_t>> chunks(num_threads);
       ShardWorkers::Get().Run(num_threads, [&](size_t t) { CompressChunk(params, input, input_size, false, t, num_threads, &chunks[t], nullptr); });
+      // stitched straight into the caller's buffer
       ChunkStitcher stitcher;
+      ByteSink sink(encoded, *encoded_size);
       for (size_t t = 0; t < num_threads; ++t) {
-        if (!stitcher.Append(chunks[t].data(), chunks[t].size(), &out)) throw std::runtime_error("chunk cannot be concatenated");
+        if (!stitcher.Append(chunks[t].data(), chunks[t].size(), &sink)) throw std::runtime_error("chunk cannot be concatenated");
         std::vector<uint8_t>().swap(chunks[t]);
       }
-      stitcher.Finish(&out);
+      stitcher.Finish(&sink);
+      if (sink.overflow()) {
+        SetError("BrotliEncoderCompressMulti", "insufficient output space");
+        return 0;
+      }
+      *encoded_size = sink.size();
+      return 1;
     }
     if (out.size() > *encoded_size) {
       SetError("BrotliEncoderCompressMulti", "insufficient output space");

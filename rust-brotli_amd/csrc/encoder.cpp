@@ -383,6 +383,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         memcpy(req.direct_out, result.data(), result.size());
       }
       *req.direct_size = result.size();
+    } else if (out->empty()) {
+      out->swap(result);
     } else {
       out->insert(out->end(), result.begin(), result.end());
     }
@@ -783,6 +785,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         memcpy(req.direct_out, result.data(), result.size());
       }
       *req.direct_size = result.size();
+    } else if (out->empty()) {
+      out->swap(result);
     } else {
       out->insert(out->end(), result.begin(), result.end());
     }
