@@ -92,6 +92,12 @@ struct Lz77Buffers {
   uint32_t* gprev;      // per 64 slots: 1 + last stored slot in front of them           [total_bytes / 64 + 2]
   uint8_t* big_tile;    // per 1024 slots: holds slots of a key with >= 65 536 slots  [total_bytes / 1024 + 64]
   uint32_t changed_cap; // entries in changed_keys / changed_slot
+  // rank-structure chains (qualities 6-9): log of every search (ChainTables::search_log, kSearchLogWords words per
+  // position) and the list of searched positions whose candidate list changed in this round (lz77_recheck_searches)
+  uint32_t* search_log = nullptr;
+  uint32_t* recheck_list = nullptr;
+  uint32_t* recheck_count = nullptr;
+  uint32_t recheck_cap = 0;
   uint8_t* flags[2];    // stored flags, double buffered                   [total_bytes + 64]
   Command* cmds;        // num_segments * cmd_slab_stride
   Segment* segments;    // num_segments
@@ -157,6 +163,10 @@ struct SegGeometry {
 };
 void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
                    uint8_t* dirty_dev);
+// After lz77_validate / lz77_rerank_keys with B.recheck_list set: those two only LIST the searched positions whose
+// candidate list changed in a way that could matter; this repeats the search of every listed position under the rank
+// structures rbuf (br_recheck_search) and marks the segment dirty when it finds something else than the chain found.
+void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, const SegGeometry& geo, uint8_t* dirty_dev);
 // incremental form of rank + validate: re-ranks the listed chunks (all slots of every changed key, cut into pieces of
 // kRerankChunk slots, keys in ascending order) of sorted[rbuf] / info[rbuf] in place from flags[which] and marks the
 // segments that searched a position of those keys whose candidate list changed.  sums_dev: num_chunks words of scratch.

@@ -75,6 +75,11 @@ struct ChainTables {
   // from text[p].  Lets the match-length code jump over a run instead of comparing it 32 bytes at a time for every one
   // of the ~20 candidates of a position (all of which match to the end of the block inside a run).
   const uint32_t* run_end;
+  // optional (rank-structure chains, qualities 6-9): kSearchLogWords words per position, written by every search of a
+  // real (not dry-run) parse -- the distance cache it ran with and what the cache + ring stages found.  Lets the
+  // validation after a flag change repeat single searches (lz77_recheck_searches) instead of re-parsing every segment
+  // whose candidate lists were touched.
+  uint32_t* search_log = nullptr;
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -351,6 +356,7 @@ struct ProbeMeta {
   // kRows on the device: the candidate of THIS lane (lanes 0..31 serve p0, lanes 32..63 p0 + 1; see br_probe_pair_rows)
   uint32_t r_prev, r_len;
   uint32_t no_dict;   // the static dictionary is known to be switched off for good: no probes, no bookkeeping
+  uint32_t log_on = 0;  // write ChainTables::search_log
 #if defined(BR_CHAIN_PROFILE)
   unsigned long long t_probe, t_fold, n_probe, n_fold, t_setup, t_refill, n_refill;
 #endif
@@ -629,7 +635,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
 // Phase 2: fold the candidates of probe slot w in the reference's order, then the static dictionary stage.
 template <bool kH9, bool kRows>
 BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const ProbeMeta& m, uint32_t w,
-                                  DictState& ds, uint32_t blk_end) {
+                                  DictState& ds, uint32_t blk_end, SearchResult* before_dictionary = nullptr, bool candidates_only = false) {
   const uint32_t cur = m.pos + w;
   const uint32_t max_length = blk_end - cur;
   const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
@@ -847,6 +853,8 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     }
   }
 #endif
+  if (before_dictionary) *before_dictionary = out;
+  if (candidates_only) return out;
   if (!out.found && P.use_dictionary) {
     // SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false), on the probed items
     const bool dead = ds.matches < (ds.lookups >> 7);
@@ -904,6 +912,18 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   return out;
 }
 
+// one record of ChainTables::search_log
+BR_DEV void br_log_search(uint32_t* rec, const int32_t* cache, const SearchResult& found_before_dictionary) {
+  for (int i = 0; i < 4; ++i) rec[i] = (uint32_t)cache[i];
+  rec[4] = found_before_dictionary.len;
+  rec[5] = found_before_dictionary.distance;
+  rec[6] = found_before_dictionary.score;
+  rec[7] = (found_before_dictionary.found ? 1u : 0u) | (found_before_dictionary.stored ? 2u : 0u);
+}
+BR_DEV bool br_same_as_logged(const uint32_t* rec, const SearchResult& r) {
+  return rec[4] == r.len && rec[5] == r.distance && rec[6] == r.score && rec[7] == ((r.found ? 1u : 0u) | (r.stored ? 2u : 0u));
+}
+
 // search(x) for the parse loop: reuses the speculative second slot when it is still valid
 template <bool kH9, bool kRows>
 BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, DictState& ds,
@@ -911,7 +931,9 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
 #if defined(BR_CHAIN_PROFILE)
   unsigned long long t0 = BR_TICK();
   if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) {
-    SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 1, ds, blk_end);
+    SearchResult pre;
+    SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 1, ds, blk_end, &pre);
+    if (!kRows && m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
     m.t_fold += BR_TICK() - t0;
     m.n_fold++;
     return r;
@@ -921,7 +943,9 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
   unsigned long long t1 = BR_TICK();
   m.t_probe += t1 - t0;
   m.n_probe++;
-  SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 0, ds, blk_end);
+  SearchResult pre;
+  SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 0, ds, blk_end, &pre);
+  if (!kRows && m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
   m.t_fold += BR_TICK() - t1;
   m.n_fold++;
   return r;
@@ -932,7 +956,14 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
     br_probe_pair<kH9, kRows>(P, t, s, m, x, cache, cache_version, blk_end);
     w = 0;
   }
-  return br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end);
+  if constexpr (!kRows) {
+    SearchResult pre;
+    const SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end, &pre);
+    if (m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
+    return r;
+  } else {
+    return br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end);
+  }
 #endif
 }
 
@@ -956,6 +987,40 @@ BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
       dc[15] = next_last + 3;
     }
   }
+}
+
+// Repeats the cache and ring stages of the search a chain ran at position p -- with the distance cache it had then
+// (ChainTables::search_log) and the candidate lists of NOW -- and says whether they find what they found then.  Used by
+// the validation after a flag change (lz77_recheck_searches): a segment is parsed again only if one of its searches
+// comes out differently, not whenever one of its candidate lists was touched.
+template <bool kH9>
+BR_DEV bool br_recheck_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, false>& s, uint32_t p, uint32_t blk_end) {
+  const uint32_t* rec = t.search_log + (size_t)p * kSearchLogWords;
+  BR_SYNC();
+  int32_t* dc = s.dc;
+  for (int i = 0; i < 4; ++i) dc[i] = (int32_t)BR_UNIFORM(rec[i]);
+  for (int i = 4; i < 16; ++i) dc[i] = 0;
+  br_prepare_distance_cache(dc, P.ndist);
+  ProbeMeta m;
+  m.pos = 0xffffffffu;
+  m.version = 0;
+  m.win_base = 0xffffff00u;
+  m.r_prev = 0xffffffffu;
+  m.r_len = 0;
+  m.no_dict = 1;  // (the dictionary stage comes after what is compared here)
+  m.log_on = 0;
+  DictState ds;
+  ds.lookups = ds.lookups0 = ds.matches = ds.matches0 = 0;
+  ds.mode = 0;
+  ds.maxdef = 0;
+  ds.vlookups = 0;
+  ds.vwould = 0;
+  ds.vmaxdef = 0;
+  BR_SYNC();
+  br_probe_pair<kH9, false>(P, t, s, m, p, dc, 0, blk_end);
+  SearchResult now;
+  br_fold_probe<kH9, false>(P, t, s, m, 0, ds, blk_end, &now, true);
+  return br_same_as_logged(rec, now);
 }
 
 struct FlagWriter {
@@ -1053,6 +1118,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   // Once the throttle (matches < lookups >> 7, mod.rs:1957-1960) has tripped it stays tripped: nothing is looked up any
   // more, so neither counter moves.  With exact counters at the entry the chain need not even keep the virtual books.
   probe.no_dict = (P.use_dictionary && BR_UNIFORM(entry.dict_exact) && ds.matches < (ds.lookups >> 7)) ? 1u : 0u;
+  probe.log_on = (!kRows && t.search_log != nullptr && fw.enabled) ? 1u : 0u;
 #if defined(BR_CHAIN_PROFILE)
   probe.t_probe = probe.t_fold = probe.n_probe = probe.n_fold = probe.t_setup = probe.t_refill = probe.n_refill = 0;
   const unsigned long long t_begin = BR_TICK();

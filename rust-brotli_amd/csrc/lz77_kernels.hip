@@ -512,6 +512,20 @@ __global__ __launch_bounds__(256) void k_rerank_apply(const RerankChunk* __restr
   }
 }
 
+// a searched position whose candidate list changed: queued for lz77_recheck_searches, or -- no list, list full -- its
+// segment is parsed again
+__device__ __forceinline__ void list_or_mark(uint32_t p, const SegGeometry& geo, uint8_t* dirty, uint32_t* recheck_list, uint32_t* recheck_count,
+                                             uint32_t recheck_cap) {
+  if (recheck_list != nullptr) {
+    const uint32_t at = atomicAdd(recheck_count, 1u);
+    if (at < recheck_cap) {
+      recheck_list[at] = p;
+      return;
+    }
+  }
+  mark_dirty(p, geo, dirty);
+}
+
 __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict__ text, const RerankChunk* __restrict__ chunks,
                                                        const uint32_t* __restrict__ by_key,
                                                        const uint8_t* __restrict__ flags, const uint32_t* __restrict__ sorted,
@@ -519,7 +533,8 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
                                                        const uint32_t* __restrict__ sorted_tmp, SegGeometry geo,
                                                        uint8_t* __restrict__ dirty, const uint32_t* __restrict__ count_base,
                                                        const uint16_t* __restrict__ keys, uint32_t reset_pos,
-                                                       const uint32_t* __restrict__ reset_counts) {
+                                                       const uint32_t* __restrict__ reset_counts, uint32_t* __restrict__ recheck_list,
+                                                       uint32_t* __restrict__ recheck_count, uint32_t recheck_cap) {
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(256) void k_rerank_check(const uint8_t* __restrict_
     bool same = na == nb;
     for (uint32_t j = 0; same && j < na; ++j) same = sorted[a.x - 1 - j] == sorted_tmp[c.key_lo + rb - 1 - j];
     if (!same && br_row_change_matters(text, p, sorted + a.x - 1, na, sorted_tmp + c.key_lo + rb - 1, nb)) {
-      if (searched) mark_dirty(p, geo, dirty);
+      if (searched) list_or_mark(p, geo, dirty, recheck_list, recheck_count, recheck_cap);
       else dirty[in_front] = 1;
     }
   }
@@ -562,7 +577,8 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   hipLaunchKernelGGL(k_rerank_count, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], sums_dev);
   hipLaunchKernelGGL(k_rerank_apply, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, sums_dev, B.by_key, B.flags[which], rank_tmp, sorted_tmp);
   hipLaunchKernelGGL(k_rerank_check, dim3(num_chunks), dim3(256), 0, BR_STREAM, B.text, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
-                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev, B.count_base, B.keys, P.reset_pos, B.reset_counts);
+                     (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev, B.count_base, B.keys, P.reset_pos, B.reset_counts,
+                     B.recheck_list, B.recheck_count, B.recheck_cap);
   hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
                      (uint2*)B.info[rbuf], rank_tmp, B.count_base, B.keys, P.reset_pos, B.reset_counts);
   HIP_CHECK(hipGetLastError());
@@ -1230,6 +1246,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.sorted = B.sorted[rbuf];
   a.T.rows = B.rows;
   a.T.run_end = B.run_end;
+  a.T.search_log = B.rows ? nullptr : B.search_log;
   a.T.flags_next = B.flags[flags_out];
   a.T.cmds = B.cmds;
   a.T.dict_hash = dt.dict_hash;
@@ -1397,7 +1414,8 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
 __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ text, const uint8_t* __restrict__ flags, const uint2* __restrict__ info_old,
                                                    const uint32_t* __restrict__ sorted_old, const uint2* __restrict__ info_new,
                                                    const uint32_t* __restrict__ sorted_new, uint32_t n, SegGeometry geo,
-                                                   uint8_t* __restrict__ dirty) {
+                                                   uint8_t* __restrict__ dirty, uint32_t* __restrict__ recheck_list,
+                                                   uint32_t* __restrict__ recheck_count, uint32_t recheck_cap) {
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     if (p < geo.first_block_start) continue;
     const bool searched = (flags[p] & kFlagSearched) != 0;
@@ -1419,7 +1437,7 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ te
     }
     if (same) continue;
     if (br_row_change_matters(text, p, sorted_old + a.x - 1, na, sorted_new + b.x - 1, nb)) {
-      if (searched) mark_dirty(p, geo, dirty);
+      if (searched) list_or_mark(p, geo, dirty, recheck_list, recheck_count, recheck_cap);
       else dirty[in_front] = 1;
     }
   }
@@ -1432,7 +1450,66 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
   uint32_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, B.flags[which], (const uint2*)B.info[rbuf_old], B.sorted[rbuf_old],
-                     (const uint2*)B.info[rbuf_new], B.sorted[rbuf_new], n, geo, dirty_dev);
+                     (const uint2*)B.info[rbuf_new], B.sorted[rbuf_new], n, geo, dirty_dev, B.recheck_list, B.recheck_count, B.recheck_cap);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ single searches again
+struct RecheckArgs {
+  Lz77Params P;
+  ChainTables T;
+  const uint32_t* list;
+  const uint32_t* count;
+  uint32_t cap;
+  SegGeometry geo;
+  uint8_t* dirty;
+};
+template <bool kH9>
+__global__ __launch_bounds__(64) void k_recheck_searches(RecheckArgs a) {
+  __shared__ ChainScratchT<kH9, false> scratch;
+  uint32_t n = *a.count;
+  if (n > a.cap) n = a.cap;
+  for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+    const uint32_t p = a.list[item];
+    const uint32_t blk = (p - a.geo.first_block_start) / a.geo.block_bytes;
+    const uint64_t end64 = (uint64_t)a.geo.first_block_start + (uint64_t)(blk + 1) * a.geo.block_bytes;
+    const uint32_t blk_end = end64 < a.P.total_bytes ? (uint32_t)end64 : a.P.total_bytes;
+    const bool same = br_recheck_search<kH9>(a.P, a.T, scratch, p, blk_end);
+    if (!same && threadIdx.x == 0) mark_dirty(p, a.geo, a.dirty);
+  }
+}
+
+void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, const SegGeometry& geo, uint8_t* dirty_dev) {
+  if (B.recheck_list == nullptr || B.search_log == nullptr || B.rows != nullptr) return;
+  const DeviceTables& dt = dev_tables();
+  RecheckArgs a;
+  a.P = P;
+  a.T.text = B.text;
+  a.T.info = B.info[rbuf];
+  a.T.sorted = B.sorted[rbuf];
+  a.T.rows = nullptr;
+  a.T.run_end = B.run_end;
+  a.T.search_log = B.search_log;
+  a.T.flags_next = nullptr;
+  a.T.cmds = nullptr;
+  a.T.dict_hash = dt.dict_hash;
+  a.T.dict_data = dt.dict_data;
+  a.T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  a.T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  a.T.dist_postfix_bits = P.dist_postfix_bits;
+  a.T.num_direct_distance_codes = P.num_direct_distance_codes;
+  a.T.work = nullptr;
+  a.list = B.recheck_list;
+  a.count = B.recheck_count;
+  a.cap = B.recheck_cap;
+  a.geo = geo;
+  a.dirty = dirty_dev;
+  const uint32_t grid = B.recheck_cap < 16384u ? B.recheck_cap : 16384u;
+  if (P.hasher_kind == 9) {
+    hipLaunchKernelGGL((k_recheck_searches<true>), dim3(grid), dim3(64), 0, BR_STREAM, a);
+  } else {
+    hipLaunchKernelGGL((k_recheck_searches<false>), dim3(grid), dim3(64), 0, BR_STREAM, a);
+  }
   HIP_CHECK(hipGetLastError());
 }
 

@@ -35,6 +35,10 @@ void Lz77Stage::Release() {
     dev_free(B_.info[1]);
     dev_free(B_.sorted[0]);
     dev_free(B_.sorted[1]);
+    dev_free(B_.search_log);
+    dev_free(B_.recheck_list);
+    dev_free(B_.recheck_count);
+    B_.search_log = B_.recheck_list = B_.recheck_count = nullptr;
     dev_free(B_.key_base);
     dev_free(B_.stag);
     dev_free(B_.rows);
@@ -125,6 +129,13 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.info[1] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
     B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
     B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
+    // every search is logged so that a flag change can be answered by repeating single searches (lz77_recheck_searches)
+    if (getenv("BROTLI_MI355X_NO_RECHECK") == nullptr) {
+      B_.search_log = (uint32_t*)dev_alloc(M * kSearchLogWords * 4 + 64);
+      B_.recheck_cap = (uint32_t)std::max<size_t>(4096, M / 8);
+      B_.recheck_list = (uint32_t*)dev_alloc_uninit((size_t)B_.recheck_cap * 4 + 64);
+      B_.recheck_count = (uint32_t*)dev_alloc(64);
+    }
   }
   B_.key_base = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.reset_counts = (uint32_t*)dev_alloc((65536 + 1) * 4);
@@ -1139,6 +1150,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         incremental = affected <= (uint64_t)P_.total_bytes * inc_pct / 100;
       }
       dev_memset(dirty_dev, 0, nseg);
+      if (B_.recheck_count) dev_memset(B_.recheck_count, 0, 4);
       if (incremental) {
         std::vector<RerankChunk> chunks;
         for (uint32_t key : changed) {
@@ -1160,6 +1172,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         rbuf ^= 1;
         stats_.full_ranks++;
       }
+      // (the two above only listed the searched positions whose candidate list changed: their searches are repeated)
+      lz77_recheck_searches(P_, B_, rbuf, geo, dirty_dev);
     }
     tm.stop(&stats_.ms_rank);
     const auto host_t0 = std::chrono::steady_clock::now();

@@ -87,6 +87,10 @@ enum HeadKind : uint32_t {
 };
 
 // Parse state handed to a chain when it starts (speculated, then confirmed by the host resolver).
+// One record of the search log (ChainTables::search_log, rank-structure chains): [0..3] the distance cache the search ran
+// with, [4] len, [5] distance, [6] score of what the cache + ring stages found, [7] bit 0 found, bit 1 stored.
+static constexpr uint32_t kSearchLogWords = 8;
+
 struct SegEntry {
   uint32_t pos;         // loop-top position where the true parse enters this segment
   uint32_t apply;       // apply_random_heuristics (mod.rs:2407, 2492)

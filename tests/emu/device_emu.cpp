@@ -190,6 +190,50 @@ static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
   if (k > 0 && (off % seg_bytes) < 8) dirty[k - 1] = 1;
 }
 
+// a searched position whose candidate list changed (see list_or_mark in lz77_kernels.hip)
+static void emu_list_or_mark(const Lz77Buffers& B, uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
+  if (B.recheck_list != nullptr) {
+    const uint32_t at = (*B.recheck_count)++;
+    if (at < B.recheck_cap) {
+      B.recheck_list[at] = p;
+      return;
+    }
+  }
+  emu_mark_dirty(p, geo, dirty);
+}
+
+void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, const SegGeometry& geo, uint8_t* dirty) {
+  if (B.recheck_list == nullptr || B.search_log == nullptr || B.rows != nullptr) return;
+  const DeviceTables& dt = dev_tables();
+  ChainTables T;
+  T.text = B.text;
+  T.info = B.info[rbuf];
+  T.sorted = B.sorted[rbuf];
+  T.rows = nullptr;
+  T.run_end = nullptr;
+  T.work = nullptr;
+  T.search_log = B.search_log;
+  T.flags_next = nullptr;
+  T.cmds = nullptr;
+  T.dict_hash = dt.dict_hash;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.dist_postfix_bits = P.dist_postfix_bits;
+  T.num_direct_distance_codes = P.num_direct_distance_codes;
+  ChainScratchT<false, false> scratch;
+  ChainScratchT<true, false> scratch9;
+  const uint32_t n = *B.recheck_count < B.recheck_cap ? *B.recheck_count : B.recheck_cap;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t p = B.recheck_list[i];
+    const uint32_t blk = (p - geo.first_block_start) / geo.block_bytes;
+    const uint64_t end64 = (uint64_t)geo.first_block_start + (uint64_t)(blk + 1) * geo.block_bytes;
+    const uint32_t blk_end = end64 < P.total_bytes ? (uint32_t)end64 : P.total_bytes;
+    const bool same = P.hasher_kind == 9 ? br_recheck_search<true>(P, T, scratch9, p, blk_end) : br_recheck_search<false>(P, T, scratch, p, blk_end);
+    if (!same) emu_mark_dirty(p, geo, dirty);
+  }
+}
+
 void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const RerankChunk* chunks, uint32_t num_chunks,
                       uint32_t* sums, const SegGeometry& geo, uint8_t* dirty) {
   (void)sums;
@@ -217,7 +261,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
       bool same = na == nb;
       for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf][ax - 1 - j] == new_sorted[rb - 1 - j];
       if (!same && br_row_change_matters(B.text, p, B.sorted[rbuf] + ax - 1, na, new_sorted.data() + rb - 1, nb)) {
-        if (searched) emu_mark_dirty(p, geo, dirty);
+        if (searched) emu_list_or_mark(B, p, geo, dirty);
         else dirty[in_front] = 1;
       }
     }
@@ -336,6 +380,7 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.rows = B.rows;
   T.run_end = nullptr;
   T.work = nullptr;
+  T.search_log = B.rows ? nullptr : B.search_log;
   T.flags_next = B.flags[which ^ 1];
   T.cmds = B.cmds;
   T.dict_hash = dt.dict_hash;
@@ -389,7 +434,7 @@ void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbu
     for (uint32_t j = 0; same && j < na; ++j) same = B.sorted[rbuf_old][ga - 1 - j] == B.sorted[rbuf_new][gb - 1 - j];
     if (same) continue;
     if (!br_row_change_matters(B.text, p, B.sorted[rbuf_old] + ga - 1, na, B.sorted[rbuf_new] + gb - 1, nb)) continue;
-    if (searched) emu_mark_dirty(p, geo, dirty);
+    if (searched) emu_list_or_mark(B, p, geo, dirty);
     else dirty[in_front] = 1;
   }
 }
