@@ -95,4 +95,6 @@ def encode_stream(L, data, params, prefix=b"", continuation=True, segment_bytes=
              "fallback_retries", "ms_lz77", "ms_metablock", "ms_total"]
     d = {k: st[i] for i, k in enumerate(names)}
     d["ms_phase"] = [st[10 + i] for i in range(16)]
+    d["chains_launched"] = st[28]  # over all launches: warm-up dry runs, round 0, re-parses
+    d["num_segments"] = st[29]
     return out.raw[:n], d
