@@ -94,6 +94,7 @@ struct Lz77Buffers {
   uint32_t changed_cap; // entries in changed_keys / changed_slot
   // rank-structure chains (qualities 6-9): log of every search (ChainTables::search_log, kSearchLogWords words per
   // position) and the list of searched positions whose candidate list changed in this round (lz77_recheck_searches)
+  uint16_t* sorted_tag[2] = {nullptr, nullptr};  // br_tag16 of every entry of sorted[] (needs stag)
   uint32_t* search_log = nullptr;
   uint32_t* recheck_list = nullptr;
   uint32_t* recheck_count = nullptr;

@@ -59,6 +59,11 @@ struct ChainTables {
   const uint32_t* info;        // per position: {rank among the stored positions in (key,pos) order,
                                //                number of stored positions of the same key before it}
   const uint32_t* sorted;      // stored positions in (key,pos) order
+  // optional, parallel to sorted: 16-bit hash of the first four bytes at every entry (br_tag16).  A ring entry takes part in
+  // the search only if its first four bytes equal those at the searched position (FindMatchLengthWithLimitMin4,
+  // static_dict.rs:134-147): entries with another tag are not even fetched.  Deep rings (256 entries at quality 9) hold
+  // mostly such entries -- 15 hash bits for four bytes -- and their text gathers were what the parse was waiting for.
+  const uint16_t* sorted_tag = nullptr;
   const uint32_t* rows;        // kRows chains: per position kRowEntries candidate positions, newest first, 0xffffffff-terminated
   uint8_t* flags_next;         // stored flags produced by this round
   Command* cmds;
@@ -111,6 +116,8 @@ struct ChainScratchT {  // one per wavefront (LDS on the device)
   int32_t dc[16];                // distance cache incl. the derived entries (mod.rs:632-651); lanes index it by candidate
   uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
   uint32_t cand_len[2][kMaxCandidates + 2];
+  // !kRows, device: the candidates whose text has to be fetched (slot numbers, see br_probe_pair)
+  uint16_t fetch_list[kRows ? 2 : 2 * (kMaxCandidates + 2)];
   uint32_t keep[12];  // br_parse_chain: what the previous parse of the segment being redone left behind
 };
 
@@ -578,6 +585,97 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
   m.pos = p0;
   m.version = cache_version;
   const uint32_t total = n[0] + n[1];
+#if !defined(BROTLI_HOST_EMU)
+  if constexpr (!kRows) {
+    // Deep rings (up to 2 x 274 candidates at quality 9) in three steps instead of one dependent load chain per 64
+    // candidates: (1) all ring entries and their tags are requested at once, (2) every candidate gets its `prev`, and
+    // those whose text must be looked at -- valid cache distances, ring entries in reach whose tag equals that of the
+    // searched position, dictionary items -- are compacted into a list, (3) the list is worked off 64 entries at a time
+    // (typically two trips).  Same results as the loop below, slot for slot.
+    constexpr uint32_t kMaxTrips = (2u * (uint32_t)(ChainScratchT<kH9, kRows>::kMaxCandidates + 2) + 63u) / 64u;
+    const uint32_t lane = (uint32_t)BR_LANE;
+    const uint32_t tag_of[2] = {br_tag16(br_load32(t.text + p0)), br_tag16(br_load32(t.text + p0 + 1))};
+    uint32_t ring_q[kMaxTrips], ring_tag[kMaxTrips];
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxTrips; ++k) {
+      const uint32_t slot = k * 64u + lane;
+      ring_q[k] = 0;
+      ring_tag[k] = 0;
+      if (slot < total) {
+        const uint32_t w = slot < n[0] ? 0u : 1u;
+        const uint32_t c = slot - (w ? n[0] : 0u);
+        if (c >= ndist && c < ndist + m.nbucket[w]) {
+          const uint32_t at = m.g[w] - 1 - (c - ndist);
+          ring_q[k] = t.sorted[at];
+          ring_tag[k] = t.sorted_tag != nullptr ? (uint32_t)t.sorted_tag[at] : tag_of[w];
+        }
+      }
+    }
+    uint32_t listed = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kMaxTrips; ++k) {
+      const uint32_t slot = k * 64u + lane;
+      bool fetch = false;
+      if (slot < total) {
+        const uint32_t w = slot < n[0] ? 0u : 1u;
+        const uint32_t c = slot - (w ? n[0] : 0u);
+        const uint32_t cur = p0 + w;
+        const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+        uint32_t prev = 0xffffffffu;
+        if (c < ndist) {
+          const int64_t b = (int64_t)cache[c];
+          if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+          fetch = prev != 0xffffffffu;
+        } else if (c < ndist + m.nbucket[w]) {
+          if (cur - ring_q[k] <= max_backward) prev = ring_q[k];  // else: marks the point where the bucket walk breaks
+          fetch = prev != 0xffffffffu && ring_tag[k] == tag_of[w];
+        } else {
+          // static dictionary probe (SearchInStaticDictionary, mod.rs:1942-1988): the item is fetched in step 3
+          prev = 0;
+          fetch = true;
+        }
+        s.cand_prev[w][c] = prev;
+        s.cand_len[w][c] = 0;
+      }
+      const unsigned long long mask = __ballot(fetch);
+      if (fetch) s.fetch_list[listed + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)slot;
+      listed += (uint32_t)__popcll(mask);
+    }
+    BR_SYNC();
+    for (uint32_t first = 0; first < listed; first += 64) {
+      const uint32_t i = first + lane;
+      if (i < listed) {
+        const uint32_t slot = s.fetch_list[i];
+        const uint32_t w = slot < n[0] ? 0u : 1u;
+        const uint32_t c = slot - (w ? n[0] : 0u);
+        const uint32_t cur = p0 + w;
+        const uint32_t max_length = pos_end - cur;
+        const uint8_t* cur_data = t.text + cur;
+        const bool is_dict = c >= ndist + m.nbucket[w];
+        uint32_t prev = s.cand_prev[w][c], limit = max_length;
+        const uint8_t* src = nullptr;
+        if (is_dict) {
+          const uint32_t key = (((br_load32(cur_data) * 0x1e35a7bdu) >> (32 - 14)) << 1) + (c - ndist - m.nbucket[w]);
+          const uint32_t item = t.dict_hash[key];
+          prev = item;
+          s.cand_prev[w][c] = item;
+          if (item != 0) {
+            const uint32_t wlen = item & 0x1f;
+            if (wlen <= max_length) {
+              src = t.dict_data + t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
+              limit = wlen;
+            }
+          }
+        } else {
+          src = t.text + prev;
+        }
+        if (src) s.cand_len[w][c] = br_match_len_wide(src, cur_data, limit, is_dict ? nullptr : t.run_end, prev, cur);
+      }
+    }
+    BR_SYNC();
+    return;
+  }
+#endif
   for (uint32_t slot = BR_LANE; slot < total; slot += BR_NLANES) {
     const uint32_t w = slot < n[0] ? 0u : 1u;
     const uint32_t c = slot - (w ? n[0] : 0u);
@@ -590,6 +688,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     const bool is_dict = !is_cache && !is_bucket;
     // step 1 (one memory round trip for every kind of candidate): where does the candidate live?
     uint32_t q = 0, item = 0;
+    bool other_tag = false;
     if (is_bucket) {
       if (kRows) {
 #if defined(BROTLI_HOST_EMU)
@@ -599,6 +698,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
 #endif
       } else {
         q = t.sorted[m.g[w] - 1 - (c - ndist)];
+        if (t.sorted_tag != nullptr) other_tag = t.sorted_tag[m.g[w] - 1 - (c - ndist)] != br_tag16(br_load32(cur_data));
       }
     }
     if (is_dict) {
@@ -623,7 +723,8 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
         }
       }
     }
-    if (!is_dict && prev != 0xffffffffu) src = t.text + prev;
+    // (a ring entry with another tag starts with other bytes: a match of length 0 as far as the search is concerned)
+    if (!is_dict && prev != 0xffffffffu && !other_tag) src = t.text + prev;
     // step 2 (second round trip): measure the common prefix
     const uint32_t len = src ? br_match_len_wide(src, cur_data, limit, is_dict ? nullptr : t.run_end, prev, cur) : 0u;
     s.cand_prev[w][c] = prev;

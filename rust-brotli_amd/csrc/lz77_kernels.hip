@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
                                                      const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_base,
                                                      uint32_t* __restrict__ sorted, uint2* __restrict__ info,
                                                      const uint32_t* __restrict__ count_base, uint32_t reset_pos,
-                                                     const uint32_t* __restrict__ reset_counts) {
+                                                     const uint32_t* __restrict__ reset_counts, const uint16_t* __restrict__ stag,
+                                                     uint16_t* __restrict__ sorted_tag) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
   uint32_t pos[4], f[4], key[4];
@@ -373,7 +374,10 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
       const uint32_t lr = g - key_base[key[j]];
       const uint32_t slot = key_first[key[j]] + lr;
       info[pos[j]] = make_uint2(slot, ring_count_at(pos[j], lr, key[j], count_base, reset_pos, reset_counts));
-      if (f[j]) sorted[slot] = pos[j];
+      if (f[j]) {
+        sorted[slot] = pos[j];
+        if (sorted_tag) sorted_tag[slot] = stag[base + j];
+      }
       g += f[j];
     }
   }
@@ -408,7 +412,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
-                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base, P.reset_pos, B.reset_counts);
+                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base, P.reset_pos, B.reset_counts, B.stag, B.stag ? B.sorted_tag[rbuf] : nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -558,13 +562,17 @@ __global__ __launch_bounds__(256) void k_rerank_commit(const RerankChunk* __rest
                                                         const uint8_t* __restrict__ flags, uint32_t* __restrict__ sorted,
                                                         uint2* __restrict__ info, const uint32_t* __restrict__ rank_tmp,
                                                         const uint32_t* __restrict__ count_base, const uint16_t* __restrict__ keys,
-                                                        uint32_t reset_pos, const uint32_t* __restrict__ reset_counts) {
+                                                        uint32_t reset_pos, const uint32_t* __restrict__ reset_counts,
+                                                        const uint16_t* __restrict__ stag, uint16_t* __restrict__ sorted_tag) {
   const RerankChunk c = chunks[blockIdx.x];
   for (uint32_t i = c.begin + threadIdx.x; i < c.end; i += 256) {
     const uint32_t p = by_key[i];
     const uint32_t rb = rank_tmp[i];
     info[p] = make_uint2(c.key_lo + rb, ring_count_at(p, rb, keys[p], count_base, reset_pos, reset_counts));
-    if (flags[p] & 1u) sorted[c.key_lo + rb] = p;
+    if (flags[p] & 1u) {
+      sorted[c.key_lo + rb] = p;
+      if (sorted_tag) sorted_tag[c.key_lo + rb] = stag[i];
+    }
   }
 }
 
@@ -580,7 +588,8 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
                      (const uint2*)B.info[rbuf], rank_tmp, sorted_tmp, geo, dirty_dev, B.count_base, B.keys, P.reset_pos, B.reset_counts,
                      B.recheck_list, B.recheck_count, B.recheck_cap);
   hipLaunchKernelGGL(k_rerank_commit, dim3(num_chunks), dim3(256), 0, BR_STREAM, chunks_dev, B.by_key, B.flags[which], B.sorted[rbuf],
-                     (uint2*)B.info[rbuf], rank_tmp, B.count_base, B.keys, P.reset_pos, B.reset_counts);
+                     (uint2*)B.info[rbuf], rank_tmp, B.count_base, B.keys, P.reset_pos, B.reset_counts, B.stag,
+                     B.stag ? B.sorted_tag[rbuf] : nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1223,8 +1232,10 @@ static ParseTiming& parse_timing() {
 #if !defined(BR_PARSE_WAVES)
 #define BR_PARSE_WAVES 8
 #endif
+// (quality 9 walks up to 256 ring entries per search through LDS staging and wants registers more than waves: 6 per SIMD
+// measured 8 % faster than 8, which the fixed-layout quality-5 probe prefers)
 template <bool kH9, bool kRows>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BR_PARSE_WAVES, BR_PARSE_WAVES))) void k_parse_segments(ParseArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kH9 ? 6 : BR_PARSE_WAVES, kH9 ? 6 : BR_PARSE_WAVES))) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratchT<kH9, kRows> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
   // window and the rank rows its chains touch stay in that XCD's L2
@@ -1244,6 +1255,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.text = B.text;
   a.T.info = B.info[rbuf];
   a.T.sorted = B.sorted[rbuf];
+  a.T.sorted_tag = (!B.rows && B.stag) ? B.sorted_tag[rbuf] : nullptr;
   a.T.rows = B.rows;
   a.T.run_end = B.run_end;
   a.T.search_log = B.rows ? nullptr : B.search_log;
@@ -1487,6 +1499,7 @@ void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, 
   a.T.text = B.text;
   a.T.info = B.info[rbuf];
   a.T.sorted = B.sorted[rbuf];
+  a.T.sorted_tag = B.stag ? B.sorted_tag[rbuf] : nullptr;
   a.T.rows = nullptr;
   a.T.run_end = B.run_end;
   a.T.search_log = B.search_log;

@@ -35,6 +35,9 @@ void Lz77Stage::Release() {
     dev_free(B_.info[1]);
     dev_free(B_.sorted[0]);
     dev_free(B_.sorted[1]);
+    dev_free(B_.sorted_tag[0]);
+    dev_free(B_.sorted_tag[1]);
+    B_.sorted_tag[0] = B_.sorted_tag[1] = nullptr;
     dev_free(B_.search_log);
     dev_free(B_.recheck_list);
     dev_free(B_.recheck_count);
@@ -129,6 +132,12 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.info[1] = (uint32_t*)dev_alloc_uninit(M * 8 + 64);
     B_.sorted[0] = (uint32_t*)dev_alloc(M * 4 + 64);
     B_.sorted[1] = (uint32_t*)dev_alloc(M * 4 + 64);
+    // tags of the ring entries (ChainTables::sorted_tag): candidates that start with other bytes are not fetched
+    if (getenv("BROTLI_MI355X_NO_TAGS") == nullptr) {
+      B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
+      B_.sorted_tag[0] = (uint16_t*)dev_alloc(M * 2 + 64);
+      B_.sorted_tag[1] = (uint16_t*)dev_alloc(M * 2 + 64);
+    }
     // every search is logged so that a flag change can be answered by repeating single searches (lz77_recheck_searches)
     if (getenv("BROTLI_MI355X_NO_RECHECK") == nullptr) {
       B_.search_log = (uint32_t*)dev_alloc(M * kSearchLogWords * 4 + 64);
