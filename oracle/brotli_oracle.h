@@ -100,6 +100,20 @@ int orc_writer_compress(int quality, int lgwin, size_t chunk, size_t input_size,
                         size_t* encoded_size, uint8_t* encoded, OrcStats* stats_out,
                         OrcMetablockTrace cb, void* opaque);
 
+/* BrotliCompressCustomIo feeding pattern (src/enc/mod.rs:225-345): parameters set, PROCESS per `chunk` bytes read, FINISH
+   without input at the end.  This is how the reference's integration tests (src/bin/integration_tests.rs:310-338) feed
+   the encoder, so their exact size pins apply to it. */
+int orc_reader_compress(const int* param_keys, const uint32_t* param_values, size_t num_params, size_t chunk,
+                        size_t input_size, const uint8_t* input, size_t* encoded_size, uint8_t* encoded,
+                        OrcStats* stats_out, OrcMetablockTrace cb, void* opaque);
+
+/* BrotliCompressCustomIo feeding pattern (src/enc/mod.rs:225-345): parameters set, PROCESS per `chunk` bytes read, FINISH
+   without input at the end.  This is how the reference's integration tests (src/bin/integration_tests.rs:310-338) feed
+   the encoder, so their exact size pins apply to it. */
+int orc_reader_compress(const int* param_keys, const uint32_t* param_values, size_t num_params, size_t chunk,
+                        size_t input_size, const uint8_t* input, size_t* encoded_size, uint8_t* encoded,
+                        OrcStats* stats_out, OrcMetablockTrace cb, void* opaque);
+
 /* compress_multi: reference src/enc/threading/mod.rs:333-661 + src/concat/mod.rs.  Runs the
    shards sequentially on one thread (results are independent of thread scheduling). */
 int orc_compress_multi(const int* param_keys, const uint32_t* param_values, size_t num_params,

@@ -176,23 +176,8 @@ static int compute_lg_block(const EncoderParams* params) {
 
 static int compute_rb_bits(const EncoderParams* params) { return 1 + ORC_MAX(params->lgwin, params->lgblock); }
 
-/* metablock.rs:28-60 + encode.rs:2169-2190 */
-static void choose_distance_params(EncoderParams* params) {
-  uint32_t ndirect = 0, npostfix = 0;
-  if (params->quality >= 4) {
-    if (params->mode == 2 /* FONT */) {
-      npostfix = 1;
-      ndirect = 12;
-    } else {
-      npostfix = params->dist.distance_postfix_bits;
-      ndirect = params->dist.num_direct_distance_codes;
-    }
-    uint32_t ndirect_msb = (ndirect >> npostfix) & 0x0f;
-    if (npostfix > 3 || ndirect > 120 || (ndirect_msb << npostfix) != ndirect) {
-      npostfix = 0;
-      ndirect = 0;
-    }
-  }
+/* metablock.rs:28-60 */
+void orc_init_distance_params(EncoderParams* params, uint32_t npostfix, uint32_t ndirect) {
   params->dist.distance_postfix_bits = npostfix;
   params->dist.num_direct_distance_codes = ndirect;
   uint32_t alphabet_size = 16 + ndirect + (24u << (npostfix + 1));
@@ -211,6 +196,26 @@ static void choose_distance_params(EncoderParams* params) {
   }
   params->dist.alphabet_size = alphabet_size;
   params->dist.max_distance = max_distance;
+}
+
+/* encode.rs:2169-2190 */
+static void choose_distance_params(EncoderParams* params) {
+  uint32_t ndirect = 0, npostfix = 0;
+  if (params->quality >= 4) {
+    if (params->mode == 2 /* FONT */) {
+      npostfix = 1;
+      ndirect = 12;
+    } else {
+      npostfix = params->dist.distance_postfix_bits;
+      ndirect = params->dist.num_direct_distance_codes;
+    }
+    uint32_t ndirect_msb = (ndirect >> npostfix) & 0x0f;
+    if (npostfix > 3 || ndirect > 120 || (ndirect_msb << npostfix) != ndirect) {
+      npostfix = 0;
+      ndirect = 0;
+    }
+  }
+  orc_init_distance_params(params, npostfix, ndirect);
 }
 
 /* encode.rs:603-625 */
@@ -549,6 +554,7 @@ static void write_meta_block_internal(OrcEncoder* s, const uint8_t* data, size_t
     abort();
   } else {
     MetaBlockSplit mb;
+    EncoderParams block_params = *params;
     if (params->quality < 10) {
       size_t num_literal_contexts = 1;
       const uint32_t* literal_context_map = NULL;
@@ -560,15 +566,16 @@ static void write_meta_block_internal(OrcEncoder* s, const uint8_t* data, size_t
                                   literal_context_mode, num_literal_contexts, literal_context_map, s->commands_,
                                   s->num_commands_, &mb);
     } else {
-      fprintf(stderr, "oracle: quality >= 10 not restated\n");
-      abort();
+      /* the distance-parameter search of BrotliBuildMetaBlock works on a per-meta-block copy (encode.rs:1961) */
+      orc_build_meta_block(data, wrapped_last_flush_pos, mask, &block_params, s->prev_byte_, s->prev_byte2_, s->commands_,
+                           s->num_commands_, literal_context_mode, &mb);
     }
     {
-      size_t num_effective_dist_codes = params->dist.alphabet_size;
+      size_t num_effective_dist_codes = block_params.dist.alphabet_size;
       if (num_effective_dist_codes > ORC_NUM_DISTANCE_HISTO_SYMBOLS) num_effective_dist_codes = ORC_NUM_DISTANCE_HISTO_SYMBOLS;
       orc_optimize_histograms(num_effective_dist_codes, &mb);
     }
-    orc_store_meta_block(data, wrapped_last_flush_pos, bytes, mask, s->prev_byte_, s->prev_byte2_, is_last, params,
+    orc_store_meta_block(data, wrapped_last_flush_pos, bytes, mask, s->prev_byte_, s->prev_byte2_, is_last, &block_params,
                          literal_context_mode, s->commands_, s->num_commands_, &mb, storage_ix, storage);
     orc_metablock_destroy(&mb);
   }
@@ -634,6 +641,45 @@ static void extend_last_command(OrcEncoder* s, uint32_t* bytes, uint32_t* wrappe
                         (last_command->dist_prefix_ & 0x3ff) == 0, &last_command->cmd_prefix_);
   }
 }
+
+/* utf8_util.rs:3-43 */
+static size_t parse_as_utf8(const uint8_t* input, size_t size, int32_t* symbol) {
+  if ((input[0] & 0x80) == 0) {
+    if (input[0] > 0) {
+      *symbol = input[0];
+      return 1;
+    }
+  }
+  if (size > 1 && (input[0] & 0xe0) == 0xc0 && (input[1] & 0xc0) == 0x80) {
+    *symbol = ((input[0] & 0x1f) << 6) | (input[1] & 0x3f);
+    if (*symbol > 0x7f) return 2;
+  }
+  if (size > 2 && (input[0] & 0xf0) == 0xe0 && (input[1] & 0xc0) == 0x80 && (input[2] & 0xc0) == 0x80) {
+    *symbol = ((input[0] & 0x0f) << 12) | ((input[1] & 0x3f) << 6) | (input[2] & 0x3f);
+    if (*symbol > 0x7ff) return 3;
+  }
+  if (size > 3 && (input[0] & 0xf8) == 0xf0 && (input[1] & 0xc0) == 0x80 && (input[2] & 0xc0) == 0x80 &&
+      (input[3] & 0xc0) == 0x80) {
+    *symbol = ((input[0] & 0x07) << 18) | ((input[1] & 0x3f) << 12) | ((input[2] & 0x3f) << 6) | (input[3] & 0x3f);
+    if (*symbol > 0xffff && *symbol <= 0x10ffff) return 4;
+  }
+  *symbol = 0x110000 | input[0];
+  return 1;
+}
+
+/* utf8_util.rs:45-62 */
+int orc_is_mostly_utf8(const uint8_t* data, size_t pos, size_t mask, size_t length, float min_fraction) {
+  size_t size_utf8 = 0;
+  size_t i = 0;
+  while (i < length) {
+    int32_t symbol;
+    size_t bytes_read = parse_as_utf8(&data[(pos + i) & mask], length - i, &symbol);
+    i += bytes_read;
+    if (symbol < 0x110000) size_utf8 += bytes_read;
+  }
+  return (float)size_utf8 > min_fraction * (float)length;
+}
+#define is_mostly_utf8 orc_is_mostly_utf8
 
 /* encode.rs:2214-2543 */
 static int encode_data(OrcEncoder* s, int is_last, int force_flush, size_t* out_size) {
@@ -721,7 +767,14 @@ static int encode_data(OrcEncoder* s, int is_last, int force_flush, size_t* out_
     case 4: literal_context_mode = ORC_CONTEXT_MSB6; break;
     case 5: literal_context_mode = ORC_CONTEXT_UTF8; break;
     case 6: literal_context_mode = ORC_CONTEXT_SIGNED; break;
-    default: break;
+    default:
+      /* the reference hands ChooseContextMode the ring buffer allocation itself (data_mo, encode.rs:2427-2433), not the
+         slice behind buffer_index that every other consumer gets: the UTF-8 census runs over bytes shifted by two */
+      if (s->params.quality >= 10 &&
+          !is_mostly_utf8(s->ringbuffer_.data_mo, wrap_position(s->last_flush_pos_), mask,
+                          (size_t)(s->input_pos_ - s->last_flush_pos_), 0.75f))
+        literal_context_mode = ORC_CONTEXT_SIGNED;
+      break;
   }
   if (s->num_commands_ != 0 && s->last_insert_len_ == 0) extend_last_command(s, &bytes, &wrapped_last_processed_pos);
   orc_create_backward_references(bytes, wrapped_last_processed_pos, s->ringbuffer_.data_mo + s->ringbuffer_.buffer_index,
@@ -929,7 +982,7 @@ static int process_metadata(OrcEncoder* s, size_t* available_in, const uint8_t**
 int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, const uint8_t** next_in,
                                 size_t* available_out, uint8_t** next_out, size_t* total_out) {
   if (!ensure_initialized(s)) return 0;
-  if (s->params.quality < 4 || s->params.quality > 9) return 0; /* only q4..q9 are restated */
+  if (s->params.quality < 4) return 0; /* q0..q3 are not restated */
   if (s->remaining_metadata_bytes_ != 0xffffffffu) {
     if (*available_in != (size_t)s->remaining_metadata_bytes_) return 0;
     if (op != ORC_OP_EMIT_METADATA) return 0;
@@ -940,7 +993,7 @@ int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, con
   }
   if (s->stream_state_ == STREAM_METADATA_HEAD || s->stream_state_ == STREAM_METADATA_BODY) return 0;
   if (s->stream_state_ != STREAM_PROCESSING && *available_in != 0) return 0;
-  if (s->params.quality < 4 || s->params.quality > 9) return 0; /* only q4..q9 are restated */
+  if (s->params.quality < 4) return 0; /* q0..q3 are not restated */
   for (;;) {
     size_t remaining_block_size;
     {
@@ -1034,7 +1087,10 @@ int orc_encoder_compress(int quality, int lgwin, int mode, size_t input_size, co
     encoded[0] = 6;
     return 1;
   }
-  if (quality == 10) return 0; /* q9.5 not restated */
+  /* encode.rs:1468-1481: quality 10 through the one-shot entry runs the encoder at quality 9 with a hasher made ahead of
+     time from {q9_5, quality 10} -- ChooseHasher gives that H9 with the parameters quality 9 would get anyway, and a
+     fresh hasher is zeroed (:1147), so the call is a quality-9 call */
+  if (quality == 10) quality = 9;
   {
     OrcEncoder* s = orc_encoder_create();
     size_t available_in = input_size;
@@ -1093,6 +1149,38 @@ int orc_writer_compress(int quality, int lgwin, size_t chunk, size_t input_size,
     const uint8_t* next_in = input + input_size;
     ok = orc_encoder_compress_stream(s, ORC_OP_FINISH, &available_in, &next_in, &available_out, &next_out, &total_out);
     if (ok && !orc_encoder_is_finished(s) && available_out == 0) ok = 0;
+  }
+  *encoded_size = total_out;
+  if (stats_out) *stats_out = s->stats;
+  orc_encoder_destroy(s);
+  return ok;
+}
+
+/* BrotliCompressCustomIoCustomDict feeding pattern (src/enc/mod.rs:225-345; what `brotli::BrotliCompress` and the
+   reference's integration tests use): the parameter struct is copied in, the input is read in `chunk`-byte pieces, each
+   handed over with PROCESS, and FINISH follows with no input once the reader is dry. */
+int orc_reader_compress(const int* param_keys, const uint32_t* param_values, size_t num_params, size_t chunk,
+                        size_t input_size, const uint8_t* input, size_t* encoded_size, uint8_t* encoded,
+                        OrcStats* stats_out, OrcMetablockTrace cb, void* opaque) {
+  OrcEncoder* s = orc_encoder_create();
+  size_t available_out = *encoded_size;
+  uint8_t* next_out = encoded;
+  size_t total_out = 0;
+  size_t off = 0;
+  int ok = 1;
+  for (size_t i = 0; i < num_params; ++i) orc_encoder_set_parameter(s, param_keys[i], param_values[i]);
+  orc_encoder_set_trace(s, cb, opaque);
+  if (chunk == 0) chunk = input_size ? input_size : 1;
+  for (;;) {
+    size_t available_in = ORC_MIN(chunk, input_size - off);
+    const uint8_t* next_in = input + off;
+    int op = available_in == 0 ? ORC_OP_FINISH : ORC_OP_PROCESS;
+    off += available_in;
+    do {
+      ok = orc_encoder_compress_stream(s, op, &available_in, &next_in, &available_out, &next_out, &total_out);
+      if (ok && available_out == 0 && (available_in != 0 || orc_encoder_has_more_output(s))) ok = 0; /* buffer too small */
+    } while (ok && (available_in != 0 || (op == ORC_OP_FINISH && !orc_encoder_is_finished(s))));
+    if (!ok || orc_encoder_is_finished(s)) break;
   }
   *encoded_size = total_out;
   if (stats_out) *stats_out = s->stats;

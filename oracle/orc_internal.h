@@ -171,6 +171,17 @@ void orc_write_padding_meta_block(size_t* storage_ix, uint8_t* storage);
 void orc_write_empty_last_meta_block(size_t* storage_ix, uint8_t* storage);
 void orc_write_metadata_meta_block(const EncoderParams* params, size_t* storage_ix, uint8_t* storage);
 
+/* metablock.rs:133-307 (quality >= 10), orc_hq_metablock.c */
+void orc_build_meta_block(const uint8_t* ringbuffer, size_t pos, size_t mask, EncoderParams* params, uint8_t prev_byte,
+                          uint8_t prev_byte2, Command* cmds, size_t num_commands, int literal_context_mode,
+                          MetaBlockSplit* mb);
+float orc_population_cost(const uint32_t* data, size_t data_size, size_t total_count); /* bit_cost.rs:76-211 */
+void orc_init_distance_params(EncoderParams* params, uint32_t npostfix, uint32_t ndirect); /* metablock.rs:28-60 */
+void orc_prefix_encode_copy_distance(size_t distance_code, size_t num_direct_codes, uint64_t postfix_bits,
+                                     uint16_t* code, uint32_t* extra_bits); /* command.rs:134-173 */
+uint32_t orc_command_distance_context(const Command* c);                   /* command.rs:28-36 */
+int orc_is_mostly_utf8(const uint8_t* data, size_t pos, size_t mask, size_t length, float min_fraction);
+
 uint8_t orc_context(uint8_t p1, uint8_t p2, int mode);
 enum { ORC_CONTEXT_LSB6 = 0, ORC_CONTEXT_MSB6 = 1, ORC_CONTEXT_UTF8 = 2, ORC_CONTEXT_SIGNED = 3 };
 

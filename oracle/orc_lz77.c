@@ -169,8 +169,8 @@ void orc_get_length_code(size_t insertlen, size_t copylen, int use_last_distance
 }
 
 /* command.rs:134-173 */
-static void prefix_encode_copy_distance(size_t distance_code, size_t num_direct_codes, uint64_t postfix_bits,
-                                        uint16_t* code, uint32_t* extra_bits) {
+void orc_prefix_encode_copy_distance(size_t distance_code, size_t num_direct_codes, uint64_t postfix_bits,
+                                     uint16_t* code, uint32_t* extra_bits) {
   if (distance_code < 16 + num_direct_codes) {
     *code = (uint16_t)distance_code;
     *extra_bits = 0;
@@ -194,7 +194,7 @@ void orc_command_init(Command* self, const DistanceParams* dist, size_t insertle
   self->insert_len_ = (uint32_t)insertlen;
   int8_t delta = (int8_t)((int32_t)copylen_code - (int32_t)copylen);
   self->copy_len_ = (uint32_t)copylen | ((uint32_t)(uint8_t)delta << 25);
-  prefix_encode_copy_distance(distance_code, dist->num_direct_distance_codes, dist->distance_postfix_bits,
+  orc_prefix_encode_copy_distance(distance_code, dist->num_direct_distance_codes, dist->distance_postfix_bits,
                               &self->dist_prefix_, &self->dist_extra_);
   orc_get_length_code(insertlen, copylen_code, (self->dist_prefix_ & 0x3ff) == 0, &self->cmd_prefix_);
 }

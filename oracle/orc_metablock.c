@@ -1144,7 +1144,7 @@ static void store_command_extra(const Command* cmd, size_t* storage_ix, uint8_t*
 }
 
 /* command.rs:28-36 */
-static uint32_t command_distance_context(const Command* c) {
+uint32_t orc_command_distance_context(const Command* c) {
   uint32_t r = (uint32_t)(c->cmd_prefix_ >> 6);
   uint32_t cc = (uint32_t)(c->cmd_prefix_ & 7);
   if ((r == 0 || r == 2 || r == 4 || r == 7) && cc <= 2) return cc;
@@ -1231,7 +1231,7 @@ void orc_store_meta_block(const uint8_t* input, size_t start_pos, size_t length,
         if (mb->distance_context_map_size == 0) {
           block_encoder_store_symbol(&distance_enc, dist_code, storage_ix, storage);
         } else {
-          block_encoder_store_symbol_with_context(&distance_enc, dist_code, command_distance_context(&cmd),
+          block_encoder_store_symbol_with_context(&distance_enc, dist_code, orc_command_distance_context(&cmd),
                                                   mb->distance_context_map, storage_ix, storage, 2);
         }
         orc_write_bits(distnumextra, distextra, storage_ix, storage);

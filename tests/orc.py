@@ -106,6 +106,29 @@ def writer_compress(data, quality=5, lgwin=22, chunk=0, with_stats=False, trace=
     return (res, st.as_dict()) if with_stats else res
 
 
+def reader_compress(data, params, chunk=4096, with_stats=False):
+    """BrotliCompressCustomIo feeding pattern (what the reference's integration tests use): PROCESS per `chunk` bytes,
+    then FINISH without input.  params: list of (ORC_PARAM_*, value)."""
+    L = lib()
+    L.orc_reader_compress.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t,
+                                      ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p,
+                                      ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.POINTER(OrcStats),
+                                      ctypes.c_void_p, ctypes.c_void_p]
+    keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
+    vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
+    cap = L.orc_max_compressed_size(len(data)) + 1024
+    out = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(cap)
+    st = OrcStats()
+    ok = L.orc_reader_compress(keys, vals, len(params), chunk, len(data), data, ctypes.byref(n), out, ctypes.byref(st),
+                               None, None)
+    if not ok:
+        raise RuntimeError("oracle reader compress failed")
+    res = out.raw[:n.value]
+    _check_panic()
+    return (res, st.as_dict()) if with_stats else res
+
+
 def compress_multi(data, params, num_threads):
     L = lib()
     keys = (ctypes.c_int * len(params))(*[k for k, _ in params])

@@ -1,6 +1,7 @@
 """The oracle (CPU restatement of the reference) against the reference's own pins:
   * encoder_compress(q9, lgwin16, alice29) == 51737 bytes        (src/enc/encode.rs:3073-3099)
   * compress_multi size bounds on random_then_unicode             (src/bin/test_threading.rs:91-110)
+  * "quality 9.5" exact sizes on random_then_unicode               (src/bin/integration_tests.rs:397-428)
   * round trips through an independent decoder (libbrotlidec)
 plus the frozen sha256 of its own outputs (tests/golden/oracle_hashes.json)."""
 import glob
@@ -32,6 +33,20 @@ def test_compress_multi_bounds():
     for nt, q, bound in ((3, 5, 144325), (5, 9, 139126)):
         c = orc.compress_multi(d, [(Q, q), (MAGIC, 1)], nt)
         assert len(c) <= bound
+        assert orc.decompress(c, len(d)) == d
+
+
+def test_reference_kat_quality_9_5():
+    """src/bin/integration_tests.rs:397-428: roundtrip_helper(RANDOM_THEN_UNICODE, 10, 28, q9_5) == 130036 bytes and
+    (11, 22, q9_5) == 129715 (std build, f32).  q9_5 keeps the greedy LZ77 stage (H9 at quality 10; H6 with 512-deep
+    rings and 16 cache candidates at quality 11, encode.rs:834-893) and runs the quality >= 10 meta-block builder behind it:
+    distance-parameter search, BrotliSplitBlock, BrotliClusterHistograms, BrotliPopulationCost (orc_hq_metablock.c).
+    The helper feeds 4096-byte reads with size_hint 2 MiB through BrotliCompressCustomIo (orc.reader_compress)."""
+    d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
+    Q9_5, HINT = 150, 5
+    for q, w, size in ((10, 28, 130036), (11, 22, 129715)):
+        c = orc.reader_compress(d, [(Q, q), (Q9_5, 1), (W, w), (HINT, 2048 * 1024)], chunk=4096)
+        assert len(c) == size
         assert orc.decompress(c, len(d)) == d
 
 
