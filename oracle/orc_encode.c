@@ -360,7 +360,7 @@ void orc_encoder_set_custom_dictionary(OrcEncoder* s, size_t size, const uint8_t
   copy_input_to_ring_buffer(s, dict_size, dict);
   s->last_flush_pos_ = dict_size;
   s->last_processed_pos_ = dict_size;
-  orc_hasher_prepend_dictionary(&s->hasher_, &s->params, dict_size, dict, &s->stats);
+  orc_hasher_prepend_dictionary(&s->hasher_, &s->params, s->custom_dictionary_size, dict_size, dict, &s->stats);
 }
 
 /* encode.rs:1272-1299 */
@@ -757,7 +757,7 @@ static int encode_data(OrcEncoder* s, int is_last, int force_flush, size_t* out_
   {
     uint8_t* data = s->ringbuffer_.data_mo + s->ringbuffer_.buffer_index;
     /* InitOrStitchToPreviousBlock, encode.rs:1301-1323 */
-    orc_hasher_setup(&s->hasher_, &s->params, data, wrapped_last_processed_pos, bytes, is_last);
+    orc_hasher_setup(&s->hasher_, &s->params, s->custom_dictionary_size, data, wrapped_last_processed_pos, bytes, is_last);
     orc_hasher_stitch(&s->hasher_, bytes, wrapped_last_processed_pos, data, mask, &s->stats);
   }
   /* ChooseContextMode, encode.rs:1357-1377: UTF8 unless forced (q<10) */

@@ -80,6 +80,11 @@ typedef struct {
   size_t bucket_count;
   uint16_t* num;
   uint32_t* buckets;
+  /* H10 (kind 10): hash_to_binary_tree.rs:108-122 */
+  size_t window_mask_;
+  uint32_t invalid_pos_;
+  size_t ringbuffer_break;
+  uint32_t* forest;
 } Hasher;
 
 typedef struct {
@@ -91,13 +96,31 @@ typedef struct {
 
 void orc_hasher_free(Hasher* h);
 void orc_choose_hasher(EncoderParams* params);                 /* encode.rs:834-893 */
-void orc_hasher_setup(Hasher* h, EncoderParams* params, const uint8_t* data, size_t position,
+void orc_hasher_setup(Hasher* h, EncoderParams* params, size_t ringbuffer_break, const uint8_t* data, size_t position,
                       size_t input_size, int is_last);        /* encode.rs:1125-1161 */
 void orc_hasher_reset(Hasher* h);                              /* encode.rs:1118-1123 */
 void orc_hasher_stitch(Hasher* h, size_t num_bytes, size_t position, const uint8_t* rb, size_t mask,
                        OrcStats* st);                          /* mod.rs:210-222 */
-void orc_hasher_prepend_dictionary(Hasher* h, EncoderParams* params, size_t size,
+void orc_hasher_prepend_dictionary(Hasher* h, EncoderParams* params, size_t ringbuffer_break, size_t size,
                                    const uint8_t* dict, OrcStats* st); /* encode.rs:1163-1194 */
+/* H10 + Zopfli (orc_zopfli.c) and the all-matches dictionary search (orc_static_dict.c) */
+int orc_h10_init(Hasher* h, const EncoderParams* params, size_t ringbuffer_break);
+int orc_h10_prepare(Hasher* h);
+void orc_h10_store(Hasher* h, const uint8_t* data, size_t mask, size_t ix);
+void orc_h10_stitch(Hasher* h, size_t num_bytes, size_t position, const uint8_t* ringbuffer, size_t ringbuffer_mask);
+void orc_create_zopfli_backward_references(size_t num_bytes, size_t position, const uint8_t* ringbuffer,
+                                           size_t ringbuffer_mask, size_t ringbuffer_break, const EncoderParams* params,
+                                           Hasher* hasher, int32_t* dist_cache, size_t* last_insert_len,
+                                           Command* commands, size_t* num_commands, size_t* num_literals);
+void orc_create_hq_zopfli_backward_references(size_t num_bytes, size_t position, const uint8_t* ringbuffer,
+                                              size_t ringbuffer_mask, size_t ringbuffer_break,
+                                              const EncoderParams* params, Hasher* hasher, int32_t* dist_cache,
+                                              size_t* last_insert_len, Command* commands, size_t* num_commands,
+                                              size_t* num_literals);
+int orc_find_all_static_dictionary_matches(const uint8_t* data, size_t min_length, size_t max_length,
+                                           uint32_t* matches); /* static_dict.rs:309-1300 */
+uint16_t orc_combine_length_codes(uint16_t inscode, uint16_t copycode, int use_last_distance); /* command.rs:110-125 */
+extern int orc_reference_would_panic;
 
 /* mod.rs:2376-2552 (+dispatcher 2553-2803) */
 void orc_create_backward_references(size_t num_bytes, size_t position, const uint8_t* ringbuffer,

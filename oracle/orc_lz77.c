@@ -152,7 +152,7 @@ uint16_t orc_get_copy_length_code(size_t copylen) {
 }
 
 /* command.rs:110-125 */
-static uint16_t combine_length_codes(uint16_t inscode, uint16_t copycode, int use_last_distance) {
+uint16_t orc_combine_length_codes(uint16_t inscode, uint16_t copycode, int use_last_distance) {
   uint16_t bits64 = (uint16_t)((copycode & 0x7u) | ((inscode & 0x7u) << 3));
   if (use_last_distance && inscode < 8 && copycode < 16) {
     return (copycode < 8) ? bits64 : (uint16_t)(bits64 | 64);
@@ -164,7 +164,7 @@ static uint16_t combine_length_codes(uint16_t inscode, uint16_t copycode, int us
 }
 
 void orc_get_length_code(size_t insertlen, size_t copylen, int use_last_distance, uint16_t* code) {
-  *code = combine_length_codes(orc_get_insert_length_code(insertlen), orc_get_copy_length_code(copylen),
+  *code = orc_combine_length_codes(orc_get_insert_length_code(insertlen), orc_get_copy_length_code(copylen),
                                use_last_distance);
 }
 
@@ -235,6 +235,7 @@ uint32_t orc_command_copy_len_code(const Command* c) {
 void orc_hasher_free(Hasher* h) {
   free(h->num);
   free(h->buckets);
+  free(h->forest);
   memset(h, 0, sizeof(*h));
 }
 
@@ -286,10 +287,11 @@ void orc_choose_hasher(EncoderParams* params) {
 
 /* encode.rs:968-1117 (InitializeH5/H6/H9, BrotliMakeHasher). Types 40/41/42 are not implemented by
    the reference and fall back to InitializeH6 with whatever hasher params are current (:1115). */
-static int make_hasher(Hasher* h, const EncoderParams* params) {
+static int make_hasher(Hasher* h, const EncoderParams* params, size_t ringbuffer_break) {
   int t = params->hasher.type_;
   memset(h, 0, sizeof(*h));
   h->params = params->hasher;
+  if (t == 10) return orc_h10_init(h, params, ringbuffer_break); /* InitializeH10, orc_zopfli.c */
   h->literal_byte_score = params->hasher.literal_byte_score ? (uint32_t)params->hasher.literal_byte_score : 540u;
   if (t == 9) {
     h->kind = 9;
@@ -299,8 +301,8 @@ static int make_hasher(Hasher* h, const EncoderParams* params) {
     h->kind = 5;
     h->bucket_bits = params->hasher.bucket_bits;
     h->block_bits = params->hasher.block_bits;
-  } else if (t == 2 || t == 3 || t == 4 || t == 54 || t == 10) {
-    return 0; /* not restated: q<5 / q>=10 hashers are outside the oracle's scope */
+  } else if (t == 2 || t == 3 || t == 4 || t == 54) {
+    return 0; /* not restated: the q<5 hashers are outside the oracle's scope */
   } else {
     h->kind = 6;
     h->bucket_bits = params->hasher.bucket_bits;
@@ -336,7 +338,7 @@ static inline size_t hash_bytes(const Hasher* h, const uint8_t* data) {
 }
 
 static inline size_t hash_type_length(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
-static inline size_t store_lookahead(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
+static inline size_t store_lookahead(const Hasher* h) { return h->kind == 6 ? 8 : (h->kind == 10 ? 128 : 4); }
 
 /* test hook: when set, map[ix] |= 1 for every position inserted into the hash table and |= 2 for every position
    FindLongestMatch runs on (lets tests compare the device's stored / searched flags with the truth) */
@@ -349,6 +351,11 @@ void orc_set_debug_store_map(uint8_t* map, size_t size) {
 
 /* mod.rs:1644-1656 / 879-887 */
 static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, size_t ix, OrcStats* st) {
+  if (h->kind == 10) {
+    orc_h10_store(h, data, mask, ix);
+    st->positions_stored++;
+    return;
+  }
   size_t key = hash_bytes(h, data + (ix & mask));
   size_t minor_ix = (size_t)(h->num[key] & h->block_mask);
   h->buckets[minor_ix + (key << h->block_bits)] = (uint32_t)ix;
@@ -359,6 +366,7 @@ static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, siz
 
 /* mod.rs:1491-1510 (AdvHasher::Prepare), :898-906 (H9::Prepare). Returns 1 if newly prepared. */
 static int hasher_prepare(Hasher* h, int one_shot, size_t input_size, const uint8_t* data) {
+  if (h->kind == 10) return orc_h10_prepare(h);
   if (h->is_prepared_ != 0) return 0;
   if (h->kind == 9) {
     memset(h->num, 0, h->bucket_count * sizeof(uint16_t));
@@ -375,12 +383,12 @@ static int hasher_prepare(Hasher* h, int one_shot, size_t input_size, const uint
 }
 
 /* encode.rs:1125-1161 */
-void orc_hasher_setup(Hasher* h, EncoderParams* params, const uint8_t* data, size_t position,
+void orc_hasher_setup(Hasher* h, EncoderParams* params, size_t ringbuffer_break, const uint8_t* data, size_t position,
                       size_t input_size, int is_last) {
   int one_shot = (position == 0 && is_last);
   if (h->kind == 0) {
     orc_choose_hasher(params);
-    if (!make_hasher(h, params)) abort();
+    if (!make_hasher(h, params, ringbuffer_break)) abort();
     h->params = params->hasher;
     h->is_prepared_ = 1; /* relies on zero-initialised tables (encode.rs:1147) */
   } else {
@@ -396,6 +404,10 @@ void orc_hasher_setup(Hasher* h, EncoderParams* params, const uint8_t* data, siz
 /* mod.rs:210-222 */
 void orc_hasher_stitch(Hasher* h, size_t num_bytes, size_t position, const uint8_t* rb, size_t mask,
                        OrcStats* st) {
+  if (h->kind == 10) {
+    orc_h10_stitch(h, num_bytes, position, rb, mask); /* StitchToPreviousBlockH10, hq.rs:254-300 */
+    return;
+  }
   if (num_bytes >= hash_type_length(h) - 1 && position >= 3) {
     hasher_store(h, rb, mask, position - 3, st);
     hasher_store(h, rb, mask, position - 2, st);
@@ -404,9 +416,9 @@ void orc_hasher_stitch(Hasher* h, size_t num_bytes, size_t position, const uint8
 }
 
 /* encode.rs:1163-1194 + mod.rs:224-229 (StoreLookaheadThenStore, mask = usize::MAX) */
-void orc_hasher_prepend_dictionary(Hasher* h, EncoderParams* params, size_t size, const uint8_t* dict,
-                                   OrcStats* st) {
-  orc_hasher_setup(h, params, dict, 0, size, 0);
+void orc_hasher_prepend_dictionary(Hasher* h, EncoderParams* params, size_t ringbuffer_break, size_t size,
+                                   const uint8_t* dict, OrcStats* st) {
+  orc_hasher_setup(h, params, ringbuffer_break, dict, 0, size, 0);
   size_t overlap = store_lookahead(h) - 1;
   if (size > overlap) {
     for (size_t i = 0; i < size - overlap; ++i) hasher_store(h, dict, ~(size_t)0, i, st);
@@ -696,6 +708,16 @@ void orc_create_backward_references(size_t num_bytes, size_t position, const uin
                                     const EncoderParams* params, Hasher* hasher, int32_t* dist_cache,
                                     size_t* last_insert_len, Command* commands, size_t* num_commands,
                                     size_t* num_literals, OrcStats* st) {
+  if (hasher->kind == 10) { /* dispatcher, mod.rs:2576-2620 */
+    if (params->quality >= 11) {
+      orc_create_hq_zopfli_backward_references(num_bytes, position, ringbuffer, ringbuffer_mask, ringbuffer_break, params,
+                                               hasher, dist_cache, last_insert_len, commands, num_commands, num_literals);
+    } else {
+      orc_create_zopfli_backward_references(num_bytes, position, ringbuffer, ringbuffer_mask, ringbuffer_break, params,
+                                            hasher, dist_cache, last_insert_len, commands, num_commands, num_literals);
+    }
+    return;
+  }
   const int use_dictionary = params->use_dictionary;
   const size_t gap = 0;
   const size_t max_backward_limit = ((size_t)1 << params->lgwin) - 16;

@@ -2,6 +2,7 @@
   * encoder_compress(q9, lgwin16, alice29) == 51737 bytes        (src/enc/encode.rs:3073-3099)
   * compress_multi size bounds on random_then_unicode             (src/bin/test_threading.rs:91-110)
   * "quality 9.5" exact sizes on random_then_unicode               (src/bin/integration_tests.rs:397-428)
+  * alice29 at quality 10 / 11 == 47488 / 46493 bytes               (src/bin/integration_tests.rs:401-449)
   * round trips through an independent decoder (libbrotlidec)
 plus the frozen sha256 of its own outputs (tests/golden/oracle_hashes.json)."""
 import glob
@@ -47,6 +48,36 @@ def test_reference_kat_quality_9_5():
     for q, w, size in ((10, 28, 130036), (11, 22, 129715)):
         c = orc.reader_compress(d, [(Q, q), (Q9_5, 1), (W, w), (HINT, 2048 * 1024)], chunk=4096)
         assert len(c) == size
+        assert orc.decompress(c, len(d)) == d
+
+
+def test_reference_kat_quality_10_and_11():
+    """src/bin/integration_tests.rs:430-449 with the constants of :408-413 (std build, f32): alice29 through
+    roundtrip_helper(.., 10, 22, false) == 47488 bytes and (.., 11, 22, false) == 46493.  That is the H10 binary-tree
+    hasher, FindAllMatchesH10 with BrotliFindAllStaticDictionaryMatches, the Zopfli shortest path (one pass at quality
+    10, two with the command-derived cost model at 11), the literal cost model, and the quality >= 10 meta-block builder
+    (orc_zopfli.c, orc_static_dict.c, orc_hq_metablock.c).  size_hint is 2 MiB for inputs above 100 000 bytes."""
+    a = synth.alice()
+    HINT = 5
+    for q, size in ((10, 47488), (11, 46493)):
+        c = orc.reader_compress(a, [(Q, q), (W, 22), (HINT, 2048 * 1024)], chunk=4096)
+        assert len(c) == size
+        assert orc.decompress(c, len(a)) == a
+
+
+def test_round_trips_quality_10_11():
+    files = sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))) + [os.path.join(GOLDEN, "random_then_unicode")]
+    for f in files:
+        d = open(f, "rb").read()
+        for q, w in ((10, 16), (11, 22)):
+            c = orc.reader_compress(d, [(Q, q), (W, w)], chunk=65536)
+            assert orc.decompress(c, len(d)) == d, (f, q, w)
+    # one-shot and custom-dictionary / multi-shard paths at the high qualities
+    d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
+    assert orc.decompress(orc.compress(d, 11, 22), len(d)) == d
+    assert orc.compress(d, 10, 22) == orc.compress(d, 9, 22)  # encoder_compress runs quality 10 as 9 (encode.rs:1468)
+    for q in (10, 11):
+        c = orc.compress_multi(d, [(Q, q), (W, 22)], 3)
         assert orc.decompress(c, len(d)) == d
 
 
