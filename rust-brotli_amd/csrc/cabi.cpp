@@ -611,6 +611,9 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
     encoded[0] = 6;
     return BROTLI_TRUE;
   }
+  // encode.rs:1468-1481: the one-shot entry runs quality 10 ("9.5") at quality 9, with an H9 hasher made ahead of time from
+  // {q9_5, quality 10} -- the hasher quality 9 selects anyway.  (Quality 10 / 11 through the stream API are Zopfli.)
+  if (quality == 10) quality = 9;
   bool ok = false;
   std::vector<uint8_t> out;
   try {

@@ -39,6 +39,8 @@ def _suite(lib):
     # one-shot == oracle one-shot
     assert lib.compress(a, 5, 22) == orc.compress(a, 5, 22)
     assert lib.compress(b"", 5, 22) == b"\x06"
+    # quality 10 through the one-shot entry is the reference's "9.5": it runs at quality 9 (encode.rs:1468-1481)
+    assert lib.compress(a, 10, 22) == orc.compress(a, 10, 22) == orc.compress(a, 9, 22)
     assert lib.BrotliEncoderVersion() == 0x01000f01
     # streaming in 4096-byte writes == CompressorWriter feeding pattern of the oracle
     e = lib.encoder(params=[(Q, 5), (W, 22)])
