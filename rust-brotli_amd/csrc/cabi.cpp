@@ -343,6 +343,18 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
     } else {
       EncoderParams params;
       if (!ParamsFromLists(num_params, keys, values, &params)) return 0;
+      if (params.favor_cpu_efficiency) {
+        // threading/mod.rs:456-542: one hasher is filled with the whole input in front of every shard and handed to its
+        // encoder instead of priming it from the shard's prefix.  While a shard starts within the window that is the same
+        // table (the reference asserts it in debug builds, encode.rs:1249-1268) and the same stream.  Further in, the shared
+        // table holds FILE offsets where the shard encoder works with ring-buffer positions (its prefix is cut to the
+        // window, encode.rs:1243-1246): the reference's own assertion fails there and its release build searches junk
+        // candidates.  That state is not reproduced; such a call is refused rather than answered with other bytes.
+        const int lgwin = std::min(std::max(params.lgwin, 10), params.large_window ? 30 : 24);
+        const size_t last_start = (num_threads - 1) * input_size / num_threads;
+        if (last_start > ((size_t)1 << lgwin) - 16)
+          throw std::runtime_error("favor_cpu_efficiency with shards that start beyond the window is not supported (the reference's shared hasher is inconsistent there)");
+      }
       // the chunks are independent streams (compress_multi hands them to a worker pool, threading/mod.rs:333-453):
       // a few of them are in flight on the device at a time, each on the stream of its host thread
       std::vector<std::vector<uint8_t>> chunks(num_threads);

@@ -59,6 +59,13 @@ def _suite(lib):
         assert orc.decompress(got, len(d)) == d
     got = bytes(lib.BrotliCompress(d, {Q: 5, MAGIC: 1}, 3))
     assert len(got) <= 144325  # src/bin/test_threading.rs:99-102
+    # favor_cpu_efficiency (threading/mod.rs:456-542): the shared hasher equals the per-shard one while every shard starts
+    # inside the window (asserted by the reference itself, encode.rs:1249-1268), so the stream is compress_multi's; with a
+    # shard beyond the window the reference's table is inconsistent and the call is refused
+    FAVOR = 171
+    assert bytes(lib.BrotliCompress(d, {Q: 5, W: 22, FAVOR: 1}, 3)) == orc.compress_multi(d, [(Q, 5), (W, 22)], 3)
+    with pytest.raises(Exception):
+        lib.BrotliCompress(d, {Q: 5, W: 17, FAVOR: 1}, 3)
     # tiny inputs with more threads than bytes (src/bin/test_threading.rs:111-150)
     for data in (b"", b"x", b"xy", b"xyz", d[:17]):
         for nt in (2, 5):
