@@ -1,15 +1,22 @@
-/* oracle/brotli_oracle.h -- CPU restatement of rust-brotli's encoder path (qualities 4..9).
+/* oracle/brotli_oracle.h -- CPU restatement of rust-brotli's encoder path (qualities 2..11, incl. "9.5").
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product (rust-brotli_amd/, include/) may include,
  * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
  * and only as the checker / the timed CPU baseline.
  *
- * Parity status: the reference (Rust) cannot be built in this environment (no cargo/rustc).
- * The oracle is pinned by the reference's own known-answer test
- *   encoder_compress(q9, lgwin16, alice29.txt) == 51737 bytes   (src/enc/encode.rs:3073-3099)
- * by the compress_multi size bounds of src/bin/test_threading.rs:91-110, and by round trips
- * through an independent decoder (libbrotlidec).  For q5/lgwin22 single streams the reference
- * holds no byte/size pin, so byte parity there is "unpinned" beyond those anchors.
+ * Parity status: the reference (Rust) cannot be built in this environment (no cargo/rustc).  The oracle is pinned by
+ * every exact number the reference's own tests hold for this path (tests/test_oracle.py):
+ *   encoder_compress(q9, lgwin16, alice29.txt) == 51737 bytes                    (src/enc/encode.rs:3073-3099)
+ *   random_then_unicode, q10 + q9_5 / q11 + q9_5  == 130036 / 129715 bytes       (src/bin/integration_tests.rs:397-428)
+ *   alice29.txt, q10 / q11 (H10 + Zopfli)         == 47488 / 46493 bytes         (src/bin/integration_tests.rs:401-449)
+ * by the compress_multi size bounds of src/bin/test_threading.rs:91-110, by byte identity with Google's libbrotlienc
+ * 1.0.9 at qualities 5..8 modulo four documented source differences (tests/test_oracle_vs_libbrotlienc.py), and by
+ * round trips through an independent decoder (libbrotlidec).
+ * Files: orc_lz77.c (hashers H5/H6/H9, greedy parse), orc_zopfli.c (H10, Zopfli), orc_static_dict.c (all-matches
+ * dictionary search), orc_metablock.c (greedy meta-block builder, Huffman, bit stream), orc_hq_metablock.c (quality >= 10
+ * block splitter + clustering), orc_encode.c (stream state machine), orc_multi.c (compress_multi + BroCatli).
+ * Qualities 2..4 (BasicHasher H2/H3/H4/H54, store_meta_block_fast / _trivial) are byte-identical to libbrotlienc 1.0.9
+ * modulo two more documented source differences.  Not restated: qualities 0 and 1 (compress_fragment*).
  */
 #ifndef BROTLI_ORACLE_H_
 #define BROTLI_ORACLE_H_

@@ -549,9 +549,12 @@ static void write_meta_block_internal(OrcEncoder* s, const uint8_t* data, size_t
   uint16_t last_bytes = (uint16_t)((storage[saved_byte_location + 1] << 8) | storage[saved_byte_location]);
   uint8_t last_bytes_bits = (uint8_t)*storage_ix;
   int kind = 0;
-  if (params->quality <= 3) {
-    fprintf(stderr, "oracle: quality < 4 not restated\n");
-    abort();
+  if (params->quality <= 2) {
+    orc_store_meta_block_fast(data, wrapped_last_flush_pos, bytes, mask, is_last, params, s->commands_, s->num_commands_,
+                              storage_ix, storage);
+  } else if (params->quality < 4) {
+    orc_store_meta_block_trivial(data, wrapped_last_flush_pos, bytes, mask, is_last, params, s->commands_,
+                                 s->num_commands_, storage_ix, storage);
   } else {
     MetaBlockSplit mb;
     EncoderParams block_params = *params;
@@ -742,8 +745,8 @@ static int encode_data(OrcEncoder* s, int is_last, int force_flush, size_t* out_
     delta = unprocessed_input_size(s);
   }
   uint32_t wrapped_last_processed_pos = wrap_position(s->last_processed_pos_);
-  if (s->params.quality < 4) {
-    fprintf(stderr, "oracle: quality < 4 not restated\n");
+  if (s->params.quality < 2) {
+    fprintf(stderr, "oracle: qualities 0 and 1 (compress_fragment*) are not restated\n");
     abort();
   }
   {
@@ -982,7 +985,7 @@ static int process_metadata(OrcEncoder* s, size_t* available_in, const uint8_t**
 int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, const uint8_t** next_in,
                                 size_t* available_out, uint8_t** next_out, size_t* total_out) {
   if (!ensure_initialized(s)) return 0;
-  if (s->params.quality < 4) return 0; /* q0..q3 are not restated */
+  if (s->params.quality < 2) return 0; /* q0 / q1 (compress_fragment*) are not restated */
   if (s->remaining_metadata_bytes_ != 0xffffffffu) {
     if (*available_in != (size_t)s->remaining_metadata_bytes_) return 0;
     if (op != ORC_OP_EMIT_METADATA) return 0;
@@ -993,7 +996,7 @@ int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, con
   }
   if (s->stream_state_ == STREAM_METADATA_HEAD || s->stream_state_ == STREAM_METADATA_BODY) return 0;
   if (s->stream_state_ != STREAM_PROCESSING && *available_in != 0) return 0;
-  if (s->params.quality < 4) return 0; /* q0..q3 are not restated */
+  if (s->params.quality < 2) return 0; /* q0 / q1 (compress_fragment*) are not restated */
   for (;;) {
     size_t remaining_block_size;
     {

@@ -80,6 +80,8 @@ typedef struct {
   size_t bucket_count;
   uint16_t* num;
   uint32_t* buckets;
+  /* BasicHasher (kinds 2, 3, 4, 54): mod.rs:237-596 */
+  int sweep, basic_use_dictionary, basic_hash_len;
   /* H10 (kind 10): hash_to_binary_tree.rs:108-122 */
   size_t window_mask_;
   uint32_t invalid_pos_;
@@ -187,6 +189,13 @@ void orc_store_meta_block(const uint8_t* input, size_t start_pos, size_t length,
                           int literal_context_mode, const Command* commands, size_t n_commands,
                           MetaBlockSplit* mb, size_t* storage_ix, uint8_t* storage);
 /* brotli_bit_stream.rs:2775-2833 */
+/* brotli_bit_stream.rs:2345-2465 (quality 3) and :2578-2742 (quality 2) */
+void orc_store_meta_block_trivial(const uint8_t* input, size_t start_pos, size_t length, size_t mask, int is_last,
+                                  const EncoderParams* params, const Command* commands, size_t n_commands,
+                                  size_t* storage_ix, uint8_t* storage);
+void orc_store_meta_block_fast(const uint8_t* input, size_t start_pos, size_t length, size_t mask, int is_last,
+                               const EncoderParams* params, const Command* commands, size_t n_commands,
+                               size_t* storage_ix, uint8_t* storage);
 void orc_store_uncompressed_meta_block(int is_final_block, const uint8_t* input, size_t position,
                                        size_t mask, size_t len, size_t* storage_ix, uint8_t* storage);
 void orc_write_bits(unsigned n_bits, uint64_t bits, size_t* pos, uint8_t* array);

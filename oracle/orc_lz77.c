@@ -42,6 +42,8 @@ static inline uint64_t load64(const uint8_t* p) {
 
 static const uint32_t kHashMul32 = 0x1e35a7bdu;
 static const uint64_t kHashMul64Long = 0x1fe35a7bd3579bd3ull;
+static const uint64_t kHashMul64 = 0x1e35a7bd1e35a7bdull;
+#define IS_BASIC(h) ((h)->kind == 2 || (h)->kind == 3 || (h)->kind == 4 || (h)->kind == 54)
 
 /* static_dict.rs:125-132 */
 static size_t find_match_length_with_limit(const uint8_t* s1, const uint8_t* s2, size_t limit) {
@@ -302,7 +304,16 @@ static int make_hasher(Hasher* h, const EncoderParams* params, size_t ringbuffer
     h->bucket_bits = params->hasher.bucket_bits;
     h->block_bits = params->hasher.block_bits;
   } else if (t == 2 || t == 3 || t == 4 || t == 54) {
-    return 0; /* not restated: the q<5 hashers are outside the oracle's scope */
+    /* InitializeH2/H3/H4/H54, encode.rs:895-966 + the BasicHashComputer impls mod.rs:437-560: zeroed tables of
+       (1 << BUCKET_BITS) + BUCKET_SWEEP entries */
+    h->kind = t;
+    h->bucket_bits = t == 54 ? 20 : (t == 4 ? 17 : 16);
+    h->sweep = t == 2 ? 1 : (t == 3 ? 2 : 4);
+    h->basic_use_dictionary = (t == 2 || t == 4);
+    h->basic_hash_len = t == 54 ? 7 : 5;
+    h->bucket_count = ((size_t)1 << h->bucket_bits) + (size_t)h->sweep;
+    h->buckets = (uint32_t*)calloc(h->bucket_count, sizeof(uint32_t));
+    return h->buckets != NULL;
   } else {
     h->kind = 6;
     h->bucket_bits = params->hasher.bucket_bits;
@@ -322,6 +333,11 @@ void orc_hasher_reset(Hasher* h) {
 }
 
 static inline size_t hash_bytes(const Hasher* h, const uint8_t* data) {
+  if (IS_BASIC(h)) {
+    /* mod.rs:437-441, 482-486, 502-506, 527-531 */
+    uint64_t v = (load64(data) << (64 - 8 * h->basic_hash_len)) * kHashMul64;
+    return (size_t)(v >> (64 - h->bucket_bits));
+  }
   if (h->kind == 6) {
     /* mod.rs:1138-1140, 1521-1525 */
     uint64_t v = (load64(data) & h->hash_mask) * kHashMul64Long;
@@ -337,8 +353,25 @@ static inline size_t hash_bytes(const Hasher* h, const uint8_t* data) {
   }
 }
 
-static inline size_t hash_type_length(const Hasher* h) { return h->kind == 6 ? 8 : 4; }
-static inline size_t store_lookahead(const Hasher* h) { return h->kind == 6 ? 8 : (h->kind == 10 ? 128 : 4); }
+/* TEST SWITCH (tests/test_oracle_vs_libbrotlienc.py only; 0 = rust-brotli).  C 1.0.9 (hash_longest_match_quickly_inc.h)
+   spreads the BUCKET_SWEEP slots of a key eight entries apart and wraps them inside the table: position ix goes to slot
+   (key + (ix & ((BUCKET_SWEEP - 1) << 3))) & BUCKET_MASK, and a search looks at (key + (i << 3)) & BUCKET_MASK.  It also
+   takes a candidate only when it beats the score found so far, where rust-brotli (a port of an older C version,
+   mod.rs:322-327, 391-440) uses the slots key .. key + BUCKET_SWEEP - 1 and accepts the last-distance / single-slot match
+   unconditionally. */
+int orc_test_c109_basic_layout = 0;
+static inline size_t basic_slot(const Hasher* h, size_t key, size_t i) {
+  if (orc_test_c109_basic_layout && h->sweep > 1) return (key + (i << 3)) & (((size_t)1 << h->bucket_bits) - 1);
+  return key + i;
+}
+static inline size_t basic_slot_of(const Hasher* h, size_t key, size_t ix) {
+  return basic_slot(h, key, (ix >> 3) % (size_t)h->sweep);
+}
+
+static inline size_t hash_type_length(const Hasher* h) { return (h->kind == 6 || IS_BASIC(h)) ? 8 : 4; }
+static inline size_t store_lookahead(const Hasher* h) {
+  return (h->kind == 6 || IS_BASIC(h)) ? 8 : (h->kind == 10 ? 128 : 4);
+}
 
 /* test hook: when set, map[ix] |= 1 for every position inserted into the hash table and |= 2 for every position
    FindLongestMatch runs on (lets tests compare the device's stored / searched flags with the truth) */
@@ -356,6 +389,12 @@ static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, siz
     st->positions_stored++;
     return;
   }
+  if (IS_BASIC(h)) { /* mod.rs:322-327 */
+    size_t bkey = hash_bytes(h, data + (ix & mask));
+    h->buckets[basic_slot_of(h, bkey, ix)] = (uint32_t)ix;
+    st->positions_stored++;
+    return;
+  }
   size_t key = hash_bytes(h, data + (ix & mask));
   size_t minor_ix = (size_t)(h->num[key] & h->block_mask);
   h->buckets[minor_ix + (key << h->block_bits)] = (uint32_t)ix;
@@ -368,6 +407,19 @@ static inline void hasher_store(Hasher* h, const uint8_t* data, size_t mask, siz
 static int hasher_prepare(Hasher* h, int one_shot, size_t input_size, const uint8_t* data) {
   if (h->kind == 10) return orc_h10_prepare(h);
   if (h->is_prepared_ != 0) return 0;
+  if (IS_BASIC(h)) { /* mod.rs:336-357 */
+    size_t partial_prepare_threshold = ((size_t)4 << h->bucket_bits) >> 7;
+    if (one_shot && input_size <= partial_prepare_threshold) {
+      for (size_t i = 0; i < input_size; ++i) {
+        size_t key = hash_bytes(h, data + i);
+        for (int j = 0; j < h->sweep; ++j) h->buckets[key + (size_t)j] = 0;
+      }
+    } else {
+      memset(h->buckets, 0, h->bucket_count * sizeof(uint32_t));
+    }
+    h->is_prepared_ = 1;
+    return 1;
+  }
   if (h->kind == 9) {
     memset(h->num, 0, h->bucket_count * sizeof(uint16_t));
   } else {
@@ -668,10 +720,123 @@ static int h9_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* d
   return is_match_found;
 }
 
+/* StoreRange: mod.rs:328-332 with StoreRangeOptBasic :254-285 for the basic hashers (which stores the MASKED position of
+   the positions it takes in fours), a plain loop for the others */
+/* TEST SWITCH (tests/test_oracle_vs_libbrotlienc.py only; 0 = rust-brotli): C 1.0.9 stores a range position by position
+   (hash_longest_match_quickly_inc.h StoreRange).  rust-brotli's StoreRangeOptBasic takes four positions at a time and files
+   all four under the sweep slot of the FIRST one ((i >> 3) % BUCKET_SWEEP with i the chunk start, mod.rs:264-279), and
+   writes the masked position. */
+int orc_test_c109_basic_store_range = 0;
+static void hasher_store_range(Hasher* h, const uint8_t* data, size_t mask, size_t ix_start, size_t ix_end, OrcStats* st) {
+  size_t i = ix_start;
+  if (IS_BASIC(h) && ix_end >= ix_start + 16 && !orc_test_c109_basic_store_range) {
+    size_t chunk_count = (ix_end - ix_start) / 4;
+    for (size_t chunk_id = 0; chunk_id < chunk_count; ++chunk_id) {
+      size_t p = (ix_start + chunk_id * 4) & mask;
+      size_t off = (p >> 3) % (size_t)h->sweep;
+      for (size_t b = 0; b < 4; ++b) {
+        h->buckets[hash_bytes(h, data + p + b) + off] = (uint32_t)p + (uint32_t)b;
+        st->positions_stored++;
+      }
+    }
+    i = ix_start + chunk_count * 4;
+  }
+  for (; i < ix_end; ++i) hasher_store(h, data, mask, i, st);
+}
+
+/* mod.rs:359-473 */
+static int basic_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* data, size_t ring_buffer_mask,
+                                    size_t ring_buffer_break, const int32_t* distance_cache, size_t cur_ix,
+                                    size_t max_length, size_t max_backward, size_t gap, size_t max_distance,
+                                    HasherSearchResult* out, OrcStats* st) {
+  const uint32_t lbs = h->literal_byte_score;
+  const size_t best_len_in = out->len;
+  const size_t cur_ix_masked = cur_ix & ring_buffer_mask;
+  const size_t key = hash_bytes(h, &data[cur_ix_masked]);
+  int compare_char = data[cur_ix_masked + best_len_in];
+  uint64_t best_score = out->score;
+  size_t best_len = best_len_in;
+  const size_t cached_backward = (size_t)(int64_t)distance_cache[0];
+  size_t prev_ix = cur_ix - cached_backward;
+  int is_match_found = 0;
+  const size_t mask32 = (size_t)(uint32_t)ring_buffer_mask;
+  st->positions_searched++;
+  if (orc_debug_store_map && cur_ix < orc_debug_store_map_size) orc_debug_store_map[cur_ix] |= 3;
+  out->len_x_code = 0;
+  if (prev_ix < cur_ix) {
+    prev_ix &= mask32;
+    if (compare_char == data[prev_ix + best_len]) {
+      size_t unbroken_len = find_match_length_with_limit_min4(&data[prev_ix], &data[cur_ix_masked], max_length);
+      if (unbroken_len != 0 &&
+          !(orc_test_c109_basic_layout && !(best_score < backward_reference_score_using_last_distance(unbroken_len, lbs)))) {
+        size_t len = fix_unbroken_len(unbroken_len, prev_ix, ring_buffer_break);
+        best_score = backward_reference_score_using_last_distance(len, lbs);
+        best_len = len;
+        out->len = len;
+        out->distance = cached_backward;
+        out->score = best_score;
+        compare_char = data[cur_ix_masked + best_len];
+        if (h->sweep == 1) {
+          h->buckets[key] = (uint32_t)cur_ix;
+          return 1;
+        }
+        is_match_found = 1;
+      }
+    }
+  }
+  if (h->sweep == 1) {
+    prev_ix = h->buckets[key];
+    h->buckets[key] = (uint32_t)cur_ix;
+    size_t backward = cur_ix - prev_ix;
+    prev_ix &= mask32;
+    if (compare_char != data[prev_ix + best_len_in]) return 0;
+    if (backward == 0 || backward > max_backward) return 0;
+    size_t unbroken_len = find_match_length_with_limit_min4(&data[prev_ix], &data[cur_ix_masked], max_length);
+    if (unbroken_len != 0 &&
+        !(orc_test_c109_basic_layout && !(best_score < backward_reference_score(unbroken_len, backward, lbs)))) {
+      size_t len = fix_unbroken_len(unbroken_len, prev_ix, ring_buffer_break);
+      out->len = len;
+      out->distance = backward;
+      out->score = backward_reference_score(len, backward, lbs);
+      return 1;
+    }
+  } else {
+    for (int j = 0; j < h->sweep; ++j) {
+      size_t p = h->buckets[basic_slot(h, key, (size_t)j)];
+      size_t backward = cur_ix - p;
+      p &= mask32;
+      if (compare_char != data[p + best_len]) continue;
+      if (backward == 0 || backward > max_backward) continue;
+      size_t unbroken_len = find_match_length_with_limit_min4(&data[p], &data[cur_ix_masked], max_length);
+      if (unbroken_len != 0) {
+        size_t len = fix_unbroken_len(unbroken_len, p, ring_buffer_break);
+        uint64_t score = backward_reference_score(len, backward, lbs);
+        if (best_score < score) {
+          best_score = score;
+          best_len = len;
+          out->len = best_len;
+          out->distance = backward;
+          out->score = score;
+          compare_char = data[cur_ix_masked + best_len];
+          is_match_found = 1;
+        }
+      }
+    }
+  }
+  if (use_dictionary && h->basic_use_dictionary && !is_match_found)
+    is_match_found = search_in_static_dictionary(h, &data[cur_ix_masked], max_length, max_backward + gap, max_distance,
+                                                 out, 1, st);
+  h->buckets[basic_slot_of(h, key, cur_ix)] = (uint32_t)cur_ix;
+  return is_match_found;
+}
+
 static inline int find_longest_match(Hasher* h, int use_dictionary, const uint8_t* data, size_t mask,
                                      size_t rb_break, const int32_t* dc, size_t cur_ix, size_t max_length,
                                      size_t max_backward, size_t gap, size_t max_distance,
                                      HasherSearchResult* out, OrcStats* st) {
+  if (IS_BASIC(h))
+    return basic_find_longest_match(h, use_dictionary, data, mask, rb_break, dc, cur_ix, max_length, max_backward, gap,
+                                    max_distance, out, st);
   if (h->kind == 9)
     return h9_find_longest_match(h, use_dictionary, data, mask, rb_break, dc, cur_ix, max_length, max_backward,
                                  gap, max_distance, out, st);
@@ -681,6 +846,7 @@ static inline int find_longest_match(Hasher* h, int use_dictionary, const uint8_
 
 /* mod.rs:632-651 */
 static void prepare_distance_cache(const Hasher* h, int32_t* distance_cache) {
+  if (IS_BASIC(h)) return; /* mod.rs:297-298 */
   int num_distances = h->kind == 9 ? 16 : h->params.num_last_distances_to_check;
   if (num_distances > 4) {
     int32_t last_distance = distance_cache[0];
@@ -785,7 +951,7 @@ void orc_create_backward_references(size_t num_bytes, size_t position, const uin
         size_t a = position + 2, b = ORC_MIN(position + sr.len, store_end);
         if (orc_test_c109_rle_store_rule && sr.distance < (sr.len >> 2))
           a = ORC_MIN(b, ORC_MAX(a, position + sr.len - (sr.distance << 2)));
-        for (size_t i = a; i < b; ++i) hasher_store(hasher, ringbuffer, ringbuffer_mask, i, st);
+        hasher_store_range(hasher, ringbuffer, ringbuffer_mask, a, b, st);
       }
       position += sr.len;
     } else {

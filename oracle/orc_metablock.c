@@ -383,6 +383,10 @@ static inline int sort_cmp(const HuffmanTree* v0, const HuffmanTree* v1) {
 }
 
 /* entropy_encode.rs:71-116 */
+static int sort_simple = 0; /* SimpleSortHuffmanTree (brotli_bit_stream.rs:917-923): by count only */
+static inline int sort_cmp_sel(const HuffmanTree* v0, const HuffmanTree* v1) {
+  return sort_simple ? v0->total_count_ < v1->total_count_ : sort_cmp(v0, v1);
+}
 static void sort_huffman_tree_items(HuffmanTree* items, size_t n) {
   static const size_t gaps[6] = {132, 57, 23, 10, 4, 1};
   if (n < 13) {
@@ -390,7 +394,7 @@ static void sort_huffman_tree_items(HuffmanTree* items, size_t n) {
       HuffmanTree tmp = items[i];
       size_t k = i;
       size_t j = i - 1;
-      while (sort_cmp(&tmp, &items[j])) {
+      while (sort_cmp_sel(&tmp, &items[j])) {
         items[k] = items[j];
         k = j;
         if (j-- == 0) break;
@@ -403,7 +407,7 @@ static void sort_huffman_tree_items(HuffmanTree* items, size_t n) {
       for (size_t i = gap; i < n; ++i) {
         size_t j = i;
         HuffmanTree tmp = items[i];
-        for (; j >= gap && sort_cmp(&tmp, &items[j - gap]); j -= gap) items[j] = items[j - gap];
+        for (; j >= gap && sort_cmp_sel(&tmp, &items[j - gap]); j -= gap) items[j] = items[j - gap];
         items[j] = tmp;
       }
     }
@@ -1244,6 +1248,241 @@ void orc_store_meta_block(const uint8_t* input, size_t start_pos, size_t length,
   free(command_enc.bits_);
   free(literal_enc.depths_);
   free(literal_enc.bits_);
+  if (is_last) jump_to_byte_boundary(storage_ix, storage);
+}
+
+/* ------------------------------------------------------------------ quality 2 / 3 writers */
+#include "../tables/brotli_fast_tables.h"
+
+/* brotli_bit_stream.rs:925-1121 */
+static void build_and_store_huffman_tree_fast(const uint32_t* histogram, size_t histogram_total, size_t max_bits,
+                                              uint8_t* depth, uint16_t* bits, size_t* storage_ix, uint8_t* storage) {
+  uint64_t count = 0;
+  uint64_t symbols[4] = {0, 0, 0, 0};
+  uint64_t length = 0;
+  size_t total = histogram_total;
+  while (total != 0) {
+    if (histogram[length] != 0) {
+      if (count < 4) symbols[count] = length;
+      ++count;
+      total -= histogram[length];
+    }
+    ++length;
+  }
+  if (count <= 1) {
+    orc_write_bits(4, 1, storage_ix, storage);
+    orc_write_bits((unsigned)max_bits, symbols[0], storage_ix, storage);
+    depth[symbols[0]] = 0;
+    bits[symbols[0]] = 0;
+    return;
+  }
+  memset(depth, 0, length);
+  {
+    HuffmanTree* tree = (HuffmanTree*)malloc((2 * length + 1) * sizeof(HuffmanTree));
+    const HuffmanTree sentinel = {0xffffffffu, -1, -1};
+    for (uint32_t count_limit = 1;; count_limit *= 2) {
+      uint32_t node_index = 0;
+      for (uint64_t l = length; l != 0;) {
+        --l;
+        if (histogram[l] != 0) {
+          tree[node_index].total_count_ = histogram[l] >= count_limit ? histogram[l] : count_limit;
+          tree[node_index].index_left_ = -1;
+          tree[node_index].index_right_or_value_ = (int16_t)l;
+          ++node_index;
+        }
+      }
+      {
+        int n = (int)node_index;
+        int i = 0, j = n + 1, k;
+        sort_simple = 1;
+        sort_huffman_tree_items(tree, (size_t)n);
+        sort_simple = 0;
+        tree[node_index + 1] = sentinel;
+        tree[node_index] = sentinel;
+        node_index += 2;
+        for (k = n - 1; k > 0; --k) {
+          int left, right;
+          if (tree[i].total_count_ <= tree[j].total_count_) {
+            left = i++;
+          } else {
+            left = j++;
+          }
+          if (tree[i].total_count_ <= tree[j].total_count_) {
+            right = i++;
+          } else {
+            right = j++;
+          }
+          tree[node_index - 1].total_count_ = tree[left].total_count_ + tree[right].total_count_;
+          tree[node_index - 1].index_left_ = (int16_t)left;
+          tree[node_index - 1].index_right_or_value_ = (int16_t)right;
+          tree[node_index] = sentinel;
+          ++node_index;
+        }
+        if (set_depth(2 * n - 1, tree, depth, 14)) break;
+      }
+    }
+    free(tree);
+  }
+  convert_bit_depths_to_symbols(depth, (size_t)length, bits);
+  if (count <= 4) {
+    orc_write_bits(2, 1, storage_ix, storage);
+    orc_write_bits(2, count - 1, storage_ix, storage);
+    for (size_t i = 0; i < count; ++i)
+      for (size_t j = i + 1; j < count; ++j)
+        if (depth[symbols[j]] < depth[symbols[i]]) {
+          uint64_t t = symbols[j];
+          symbols[j] = symbols[i];
+          symbols[i] = t;
+        }
+    for (size_t i = 0; i < count; ++i) orc_write_bits((unsigned)max_bits, symbols[i], storage_ix, storage);
+    if (count == 4) orc_write_bits(1, depth[symbols[0]] == 1 ? 1 : 0, storage_ix, storage);
+  } else {
+    uint8_t previous_value = 8;
+    orc_write_bits(40, 0xff55555554ull, storage_ix, storage); /* StoreStaticCodeLengthCode :913-915 */
+    for (uint64_t i = 0; i < length;) {
+      const uint8_t value = depth[i];
+      uint64_t reps = 1;
+      for (uint64_t k = i + 1; k < length && depth[k] == value; ++k) ++reps;
+      i += reps;
+      if (value == 0) {
+        orc_write_bits(kZeroRepsDepth[reps], kZeroRepsBits[reps], storage_ix, storage);
+      } else {
+        if (previous_value != value) {
+          orc_write_bits(kCodeLengthDepth[value], kCodeLengthBits[value], storage_ix, storage);
+          --reps;
+        }
+        if (reps < 3) {
+          while (reps != 0) {
+            --reps;
+            orc_write_bits(kCodeLengthDepth[value], kCodeLengthBits[value], storage_ix, storage);
+          }
+        } else {
+          reps -= 3;
+          orc_write_bits(kNonZeroRepsDepth[reps], kNonZeroRepsBits[reps], storage_ix, storage);
+        }
+        previous_value = value;
+      }
+    }
+  }
+}
+
+/* brotli_bit_stream.rs:2263-2290 */
+static void build_histograms(const uint8_t* input, size_t start_pos, size_t mask, const Command* commands,
+                             size_t n_commands, uint32_t* lit_histo, size_t* lit_total, uint32_t* cmd_histo,
+                             size_t* cmd_total, uint32_t* dist_histo, size_t* dist_total) {
+  size_t pos = start_pos;
+  for (size_t i = 0; i < n_commands; ++i) {
+    const Command cmd = commands[i];
+    cmd_histo[cmd.cmd_prefix_]++;
+    ++*cmd_total;
+    for (size_t j = cmd.insert_len_; j != 0; --j) {
+      lit_histo[input[pos & mask]]++;
+      ++*lit_total;
+      ++pos;
+    }
+    pos += orc_command_copy_len(&cmd);
+    if (orc_command_copy_len(&cmd) != 0 && cmd.cmd_prefix_ >= 128) {
+      dist_histo[cmd.dist_prefix_ & 0x03ff]++;
+      ++*dist_total;
+    }
+  }
+}
+
+/* brotli_bit_stream.rs:2292-2343 */
+static void store_data_with_huffman_codes(const uint8_t* input, size_t start_pos, size_t mask, const Command* commands,
+                                          size_t n_commands, const uint8_t* lit_depth, const uint16_t* lit_bits,
+                                          const uint8_t* cmd_depth, const uint16_t* cmd_bits, const uint8_t* dist_depth,
+                                          const uint16_t* dist_bits, size_t* storage_ix, uint8_t* storage) {
+  size_t pos = start_pos;
+  for (size_t i = 0; i < n_commands; ++i) {
+    const Command cmd = commands[i];
+    const size_t cmd_code = cmd.cmd_prefix_;
+    orc_write_bits(cmd_depth[cmd_code], cmd_bits[cmd_code], storage_ix, storage);
+    store_command_extra(&cmd, storage_ix, storage);
+    for (size_t j = cmd.insert_len_; j != 0; --j) {
+      const uint8_t literal = input[pos & mask];
+      orc_write_bits(lit_depth[literal], lit_bits[literal], storage_ix, storage);
+      ++pos;
+    }
+    pos += orc_command_copy_len(&cmd);
+    if (orc_command_copy_len(&cmd) != 0 && cmd.cmd_prefix_ >= 128) {
+      const size_t dist_code = cmd.dist_prefix_ & 0x03ff;
+      const uint32_t distnumextra = (uint32_t)cmd.dist_prefix_ >> 10;
+      orc_write_bits(dist_depth[dist_code], dist_bits[dist_code], storage_ix, storage);
+      orc_write_bits(distnumextra, cmd.dist_extra_, storage_ix, storage);
+    }
+  }
+}
+
+#define ORC_MAX_SIMPLE_DISTANCE_ALPHABET_SIZE 140
+
+/* brotli_bit_stream.rs:2345-2465 (quality 3) */
+void orc_store_meta_block_trivial(const uint8_t* input, size_t start_pos, size_t length, size_t mask, int is_last,
+                                  const EncoderParams* params, const Command* commands, size_t n_commands,
+                                  size_t* storage_ix, uint8_t* storage) {
+  uint32_t lit_histo[256] = {0}, cmd_histo[704] = {0}, dist_histo[ORC_NUM_DISTANCE_HISTO_SYMBOLS] = {0};
+  size_t lit_total = 0, cmd_total = 0, dist_total = 0;
+  uint8_t lit_depth[256] = {0}, cmd_depth[704] = {0}, dist_depth[ORC_MAX_SIMPLE_DISTANCE_ALPHABET_SIZE] = {0};
+  uint16_t lit_bits[256] = {0}, cmd_bits[704] = {0}, dist_bits[ORC_MAX_SIMPLE_DISTANCE_ALPHABET_SIZE] = {0};
+  HuffmanTree* tree = (HuffmanTree*)malloc((2 * 704 + 1) * sizeof(HuffmanTree));
+  size_t num_distance_symbols = params->dist.alphabet_size;
+  store_compressed_meta_block_header(is_last, length, storage_ix, storage);
+  build_histograms(input, start_pos, mask, commands, n_commands, lit_histo, &lit_total, cmd_histo, &cmd_total, dist_histo,
+                   &dist_total);
+  orc_write_bits(13, 0, storage_ix, storage);
+  build_and_store_huffman_tree(lit_histo, 256, 256, tree, lit_depth, lit_bits, storage_ix, storage);
+  build_and_store_huffman_tree(cmd_histo, 704, 704, tree, cmd_depth, cmd_bits, storage_ix, storage);
+  build_and_store_huffman_tree(dist_histo, ORC_MAX_SIMPLE_DISTANCE_ALPHABET_SIZE, num_distance_symbols, tree, dist_depth,
+                               dist_bits, storage_ix, storage);
+  free(tree);
+  store_data_with_huffman_codes(input, start_pos, mask, commands, n_commands, lit_depth, lit_bits, cmd_depth, cmd_bits,
+                                dist_depth, dist_bits, storage_ix, storage);
+  if (is_last) jump_to_byte_boundary(storage_ix, storage);
+}
+
+/* brotli_bit_stream.rs:2578-2742 (quality 2) */
+void orc_store_meta_block_fast(const uint8_t* input, size_t start_pos, size_t length, size_t mask, int is_last,
+                               const EncoderParams* params, const Command* commands, size_t n_commands,
+                               size_t* storage_ix, uint8_t* storage) {
+  uint32_t num_distance_symbols = params->dist.alphabet_size;
+  uint32_t distance_alphabet_bits = orc_log2_floor_nonzero((uint64_t)num_distance_symbols - 1) + 1;
+  store_compressed_meta_block_header(is_last, length, storage_ix, storage);
+  orc_write_bits(13, 0, storage_ix, storage);
+  if (n_commands <= 128) {
+    uint32_t histogram[256] = {0};
+    size_t pos = start_pos, num_literals = 0;
+    uint8_t lit_depth[256] = {0};
+    uint16_t lit_bits[256] = {0};
+    for (size_t i = 0; i < n_commands; ++i) {
+      const Command cmd = commands[i];
+      for (size_t j = cmd.insert_len_; j != 0; --j) {
+        histogram[input[pos & mask]]++;
+        ++pos;
+      }
+      num_literals += cmd.insert_len_;
+      pos += orc_command_copy_len(&cmd);
+    }
+    build_and_store_huffman_tree_fast(histogram, num_literals, 8, lit_depth, lit_bits, storage_ix, storage);
+    orc_write_bits(56, 0x0092624416307003ull, storage_ix, storage); /* StoreStaticCommandHuffmanTree :2467-2470 */
+    orc_write_bits(3, 0, storage_ix, storage);
+    orc_write_bits(28, 0x0369dc03, storage_ix, storage); /* StoreStaticDistanceHuffmanTree :2472-2474 */
+    store_data_with_huffman_codes(input, start_pos, mask, commands, n_commands, lit_depth, lit_bits,
+                                  kStaticCommandCodeDepth, kStaticCommandCodeBits, kStaticDistanceCodeDepth,
+                                  kStaticDistanceCodeBits, storage_ix, storage);
+  } else {
+    uint32_t lit_histo[256] = {0}, cmd_histo[704] = {0}, dist_histo[ORC_NUM_DISTANCE_HISTO_SYMBOLS] = {0};
+    size_t lit_total = 0, cmd_total = 0, dist_total = 0;
+    uint8_t lit_depth[256] = {0}, cmd_depth[704] = {0}, dist_depth[ORC_NUM_DISTANCE_HISTO_SYMBOLS] = {0};
+    uint16_t lit_bits[256] = {0}, cmd_bits[704] = {0}, dist_bits[ORC_NUM_DISTANCE_HISTO_SYMBOLS] = {0};
+    build_histograms(input, start_pos, mask, commands, n_commands, lit_histo, &lit_total, cmd_histo, &cmd_total,
+                     dist_histo, &dist_total);
+    build_and_store_huffman_tree_fast(lit_histo, lit_total, 8, lit_depth, lit_bits, storage_ix, storage);
+    build_and_store_huffman_tree_fast(cmd_histo, cmd_total, 10, cmd_depth, cmd_bits, storage_ix, storage);
+    build_and_store_huffman_tree_fast(dist_histo, dist_total, distance_alphabet_bits, dist_depth, dist_bits, storage_ix,
+                                      storage);
+    store_data_with_huffman_codes(input, start_pos, mask, commands, n_commands, lit_depth, lit_bits, cmd_depth, cmd_bits,
+                                  dist_depth, dist_bits, storage_ix, storage);
+  }
   if (is_last) jump_to_byte_boundary(storage_ix, storage);
 }
 

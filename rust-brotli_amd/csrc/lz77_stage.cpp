@@ -751,6 +751,36 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
       }
     }
   }
+  if (!only_after_dirty && getenv("BROTLI_MI355X_NO_SPREE_GUESS") == nullptr) {
+    // A dry run that found nothing to copy in the tail of its segment says "incompressible here", but the state it ends in
+    // is that of a spree begun at the tail's start; in the real parse the spree began wherever the last copy ended --
+    // blocks away in random data -- and where it steps (every 9th, every 17th position, mod.rs:2529-2546) is a matter of
+    // that phase.  Carry the phase along instead: from the entry guessed for segment k (the block start, the end of a
+    // copy the previous dry run saw, or this same arithmetic one segment earlier) through a segment k without copies.
+    // Like every entry this is a guess that the first parse verifies; on incompressible input it spares the round that
+    // parses every segment a second time, and the flag changes (row rebuilds) that go with it.
+    for (uint32_t i = 0; i < count; ++i) {
+      const uint32_t k = ks[i];
+      if (wexits[i].n_cmds != 0) continue;
+      if (segments_[k + 1].flags & kSegFirstInBlock) continue;
+      SegEntry from = entries_[k];
+      if (segments_[k].flags & kSegFirstInBlock) {
+        if (from.ext_allowed) continue;  // (how far extend_last_command gets is not known yet)
+        from.pos = segments_[k].blk_start;
+        from.apply = from.pos + P_.spree_window;
+        from.head_kind = kHeadNone;
+        from.head_base = from.head_p1 = 0;
+      }
+      SegExit x{};
+      PredictLiteralRun(P_, segments_[k], from, &x);
+      SegEntry& e = entries_[k + 1];
+      e.pos = x.pos;
+      e.apply = x.apply;
+      e.head_kind = x.tail_kind;
+      e.head_base = x.tail_base;
+      e.head_p1 = x.tail_p1;
+    }
+  }
   stats_.segments_parsed += (uint64_t)count * warmup_bytes_ / segment_bytes_;
 }
 

@@ -16,6 +16,16 @@ by default (= rust-brotli's behaviour, the one the product reproduces):
   orc_test_c109_hasher_choice   H6 from size_hint >= 1 MiB in C, > 4 MiB in rust-brotli; H5 bucket bits 14 below quality 7
                                 at every size in C, only up to 1 MiB in rust-brotli (src/enc/encode.rs:863-893)
 
+Qualities 2..4 (BasicHasher H2 / H3 / H4 / H54, the quality 2 / 3 meta-block writers) add two more, because rust-brotli
+ports an older C version of that hasher than 1.0.9:
+
+  orc_test_c109_basic_layout       C 1.0.9 keeps the BUCKET_SWEEP slots of a key 8 entries apart, wrapped inside the table,
+                                   and takes the last-distance / single-slot candidate only if it beats the score so far;
+                                   rust-brotli uses slots key .. key + BUCKET_SWEEP - 1 and takes them unconditionally
+                                   (src/enc/backward_references/mod.rs:322-327, 376-440)
+  orc_test_c109_basic_store_range  rust-brotli's StoreRangeOptBasic files four positions at a time under the sweep slot of
+                                   the first one and stores masked positions (mod.rs:254-285); C stores one by one
+
 With all four switched to the C behaviour the oracle is BYTE-IDENTICAL to libbrotlienc on every input below, at qualities
 5..8 and several window sizes: hashing (H5 with 14 / 15 bucket bits, H6), bucket rings, the static dictionary, lazy
 matching, the distance cache, command coding, context modelling, greedy block splitting, histogram optimisation, Huffman
@@ -33,6 +43,7 @@ import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = ("orc_test_c109_rle_store_rule", "orc_test_c109_spree_tail", "orc_test_c109_entropy", "orc_test_c109_hasher_choice")
+LOW_QUALITY_SWITCHES = SWITCHES + ("orc_test_c109_basic_layout", "orc_test_c109_basic_store_range")
 
 
 @pytest.fixture(scope="module")
@@ -124,3 +135,24 @@ def test_identical_to_libbrotlienc_modulo_the_four_source_differences(genc, qual
                 assert mine == theirs, (name, quality, lgwin, len(mine), len(theirs))
     # and the switches are off again: the oracle is back to rust-brotli's behaviour
     assert len(orc.compress(synth.alice(), 5, 22)) == 52808
+
+
+@pytest.mark.parametrize("quality", [2, 3, 4])
+def test_low_qualities_identical_to_libbrotlienc_modulo_the_source_differences(genc, quality):
+    """H2 (quality 2, store_meta_block_fast with BrotliBuildAndStoreHuffmanTreeFast and the static command / distance
+    codes), H3 (quality 3, store_meta_block_trivial), H4 and -- from size_hint 1 MiB -- H54 (quality 4, greedy block
+    splitter without context modelling); lgblock 14 and the delayed-symbol flush rule below quality 4."""
+    inputs = fixture_files() + [
+        ("markov 1 MiB", synth.markov_text(1 << 20)),
+        ("markov 2 MiB", synth.markov_text(2 << 20)),
+        ("mixed 3 MiB", synth.mixed(3 << 20)),
+        ("stretches 5 MiB", synth.stretches(5 << 20)),
+    ]
+    with c109_behaviour(*LOW_QUALITY_SWITCHES):
+        for name, data in inputs:
+            for lgwin in ((22, 18) if len(data) > (1 << 20) else (22, 24, 18, 16)):
+                mine, theirs = orc.compress(data, quality, lgwin), genc(data, quality, lgwin)
+                assert mine == theirs, (name, quality, lgwin, len(mine), len(theirs))
+    # without the switches: rust-brotli's own behaviour, which must at least decode
+    for name, data in inputs[:4]:
+        assert orc.decompress(orc.compress(data, quality, 22), len(data)) == data
