@@ -1274,8 +1274,15 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       if (!dirty[k]) continue;
       const bool must_redo = pending[k] || (!cand_dirty.empty() && cand_dirty[k]);  // its candidates changed
       // (an entry predicted through a literal spree is as good as it gets: such a segment always gets its own chain)
+      // (nor is a segment without copies whose entry differs in the distance cache alone left to its predecessor: a
+      // chain that arrives there and sees the old parse come out again stops walking -- "passes the cache along",
+      // br_parse_chain -- on the understanding that the cache composed here is verified for all such segments side by
+      // side.  Deferring them as well made a changed cache creep through incompressible data two segments per round at
+      // quality 9, where no lz77_check_cache answers for them: 74 rounds for 4 MiB of random bytes.)
+      const bool passes_cache_along = entry_reason_[k] == 2 && exits_[k].n_cmds == 0 && exits_[k].ext_len == 0 &&
+                                      getenv("BROTLI_MI355X_DEFER_CACHE_ONLY") == nullptr;
       const bool defer = (aggressive || entry_streak[k] >= 2) && !(segments_[k].flags & kSegFirstInBlock) && k > 0 && was_dirty[k - 1] &&
-                         !predicted_entry_[k];
+                         !predicted_entry_[k] && !passes_cache_along;
       if (defer) {
         sched[k] = must_redo ? 2 : 0;
         pending[k] = must_redo;  // stays owed until some chain really gets here
