@@ -150,3 +150,22 @@ def test_quality9_flag_changes_are_answered_by_single_searches(L):
     # warm-up dry runs (384 of every 1024 bytes) + round 0 come to 1.375 chains per segment; the rest are re-parses
     # (about 60 with the re-check, about 1050 under the coarse rule)
     assert st["segments_parsed"] - 1.375 * nseg < 0.05 * nseg, st
+
+
+def test_incompressible_input_converges_in_a_few_rounds(L):
+    """Round counts are a property of the algorithm, not of the device, so the emulation build measures them.  Two rules of
+    the host resolver keep incompressible input from being parsed over and over: the entry guessed behind a tail without
+    copies carries the literal-spree phase by arithmetic (Lz77Stage::Warmup; before: every segment of random input parsed
+    twice, 12 rounds at quality 5), and a segment without copies whose entry differs in the distance cache alone always
+    gets its own chain (RunRounds; before: the change crept two segments per round at quality 9, 74 rounds on 4 MiB)."""
+    data = synth.random_bytes(4 << 20)
+    nseg = len(data) // 2048
+    for q, max_rounds, max_parses in ((5, 8, 1.6), (9, 12, 4.5)):
+        mbs, st = emu.lz77_trace(L, data, quality=q, lgwin=22, segment_bytes=2048)
+        assert st["rounds"] <= max_rounds, (q, st)
+        assert st["segments_parsed"] <= max_parses * nseg, (q, st)
+    out, _ = emu.encode_stream(L, data[:1 << 20], [(Q, 9), (W, 22), (SH, 1 << 20)])
+    assert out == orc.compress(data[:1 << 20], 9, 22)
+    lit = synth.stretches(3 << 20)
+    _, st = emu.lz77_trace(L, lit, quality=9, lgwin=22, segment_bytes=2048)
+    assert st["rounds"] <= 8, st  # 29 before

@@ -110,6 +110,26 @@ def test_frozen_hashes():
     assert got == frozen
 
 
+def test_frozen_hashes_low_and_high_qualities():
+    """streams frozen when the restatement reproduced the reference's exact sizes (qualities 10 / 11 / "9.5") and was
+    byte-identical to libbrotlienc modulo the documented differences (qualities 2..4): a regression guard"""
+    frozen = json.load(open(os.path.join(GOLDEN, "oracle_hashes_q2_4_q10_11.json")))
+    a = synth.alice()
+    d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
+    HINT, Q95 = 5, 150
+    got = {}
+    for q in (2, 3, 4):
+        got["alice29 q%d w22" % q] = hashlib.sha256(orc.compress(a, q, 22)).hexdigest()
+    got["markov1M q4 w22 (H54)"] = hashlib.sha256(orc.compress(synth.markov_text(1 << 20), 4, 22)).hexdigest()
+    for q, size in ((10, 47488), (11, 46493)):
+        c = orc.reader_compress(a, [(Q, q), (W, 22), (HINT, 2048 * 1024)])
+        got["alice29 reader4096 q%d w22 hint2M (%d)" % (q, size)] = hashlib.sha256(c).hexdigest()
+    for q, w, size in ((10, 28, 130036), (11, 22, 129715)):
+        c = orc.reader_compress(d, [(Q, q), (Q95, 1), (W, w), (HINT, 2048 * 1024)])
+        got["random_then_unicode reader4096 q%d q9_5 w%d hint2M (%d)" % (q, w, size)] = hashlib.sha256(c).hexdigest()
+    assert got == frozen
+
+
 def test_log2f_restatement_matches_libm():
     """the device uses a restated glibc log2f; it must equal libm on the values FastLog2 can see"""
     import ctypes
