@@ -981,11 +981,89 @@ static int process_metadata(OrcEncoder* s, size_t* available_in, const uint8_t**
   return 1;
 }
 
+/* encode.rs:1643-1700 (MaxHashTableSize, HashTableSize, GetHashTableInternal): a zeroed table per call */
+static int32_t* get_hash_table(int quality, size_t input_size, size_t* table_size) {
+  size_t max_table_size = quality == 0 ? ((size_t)1 << 15) : ((size_t)1 << 17);
+  size_t htsize = 256;
+  while (htsize < max_table_size && htsize < input_size) htsize <<= 1;
+  if (quality == 0 && (htsize & 0xaaaaa) == 0) htsize <<= 1;
+  *table_size = htsize;
+  return (int32_t*)calloc(htsize, sizeof(int32_t));
+}
+
+/* encode.rs:2706-2861 (qualities 0 and 1: no ring buffer, the caller's input is compressed in place) */
+static int compress_stream_fast(OrcEncoder* s, int op, size_t* available_in, const uint8_t** next_in,
+                                size_t* available_out, uint8_t** next_out, size_t* total_out) {
+  const size_t block_size_limit = (size_t)1 << s->params.lgwin;
+  const size_t buf_size = ORC_MIN((size_t)1 << 17, ORC_MIN(*available_in, block_size_limit));
+  uint32_t* command_buf = NULL;
+  uint8_t* literal_buf = NULL;
+  if (s->params.quality != 0 && s->params.quality != 1) return 0;
+  if (s->params.quality == 0) {
+    fprintf(stderr, "oracle: quality 0 (compress_fragment) is not restated\n");
+    return 0;
+  }
+  command_buf = (uint32_t*)calloc(buf_size ? buf_size : 1, sizeof(uint32_t));
+  literal_buf = (uint8_t*)calloc(buf_size ? buf_size : 1, 1);
+  for (;;) {
+    if (inject_flush_or_push_output(s, available_out, next_out, total_out)) continue;
+    if (s->available_out_ == 0 && s->stream_state_ == STREAM_PROCESSING && (*available_in != 0 || op != ORC_OP_PROCESS)) {
+      const size_t block_size = ORC_MIN(block_size_limit, *available_in);
+      const int is_last = *available_in == block_size && op == ORC_OP_FINISH;
+      const int force_flush = *available_in == block_size && op == ORC_OP_FLUSH;
+      const size_t max_out_size = 2 * block_size + 503;
+      int inplace = 1;
+      uint8_t* storage;
+      size_t storage_ix = s->last_bytes_bits_;
+      size_t table_size = 0;
+      if (force_flush && block_size == 0) {
+        s->stream_state_ = STREAM_FLUSH_REQUESTED;
+        continue;
+      }
+      if (max_out_size <= *available_out) {
+        storage = *next_out;
+      } else {
+        inplace = 0;
+        get_brotli_storage(s, max_out_size);
+        storage = s->storage_;
+      }
+      storage[0] = (uint8_t)s->last_bytes_;
+      storage[1] = (uint8_t)(s->last_bytes_ >> 8);
+      int32_t* table = get_hash_table(s->params.quality, block_size, &table_size);
+      orc_compress_fragment_two_pass(*next_in, block_size, is_last, command_buf, literal_buf, table, table_size,
+                                     &storage_ix, storage);
+      free(table);
+      *next_in += block_size;
+      *available_in -= block_size;
+      if (inplace) {
+        size_t out_bytes = storage_ix >> 3;
+        *next_out += out_bytes;
+        *available_out -= out_bytes;
+        s->total_out_ += out_bytes;
+        if (total_out) *total_out = (size_t)s->total_out_;
+      } else {
+        s->next_out_kind = NEXT_OUT_STORAGE;
+        s->next_out_off = 0;
+        s->available_out_ = storage_ix >> 3;
+      }
+      s->last_bytes_ = (uint16_t)(storage[storage_ix >> 3] | (storage[1 + (storage_ix >> 3)] << 8));
+      s->last_bytes_bits_ = (uint8_t)(storage_ix & 7);
+      if (force_flush) s->stream_state_ = STREAM_FLUSH_REQUESTED;
+      if (is_last) s->stream_state_ = STREAM_FINISHED;
+      continue;
+    }
+    break;
+  }
+  free(command_buf);
+  free(literal_buf);
+  check_flush_complete(s);
+  return 1;
+}
+
 /* encode.rs:2873-2995 */
 int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, const uint8_t** next_in,
                                 size_t* available_out, uint8_t** next_out, size_t* total_out) {
   if (!ensure_initialized(s)) return 0;
-  if (s->params.quality < 2) return 0; /* q0 / q1 (compress_fragment*) are not restated */
   if (s->remaining_metadata_bytes_ != 0xffffffffu) {
     if (*available_in != (size_t)s->remaining_metadata_bytes_) return 0;
     if (op != ORC_OP_EMIT_METADATA) return 0;
@@ -996,7 +1074,9 @@ int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, con
   }
   if (s->stream_state_ == STREAM_METADATA_HEAD || s->stream_state_ == STREAM_METADATA_BODY) return 0;
   if (s->stream_state_ != STREAM_PROCESSING && *available_in != 0) return 0;
-  if (s->params.quality < 2) return 0; /* q0 / q1 (compress_fragment*) are not restated */
+  if ((s->params.quality == 0 || s->params.quality == 1) && !s->params.catable)
+    return compress_stream_fast(s, op, available_in, next_in, available_out, next_out, total_out);
+  if (s->params.quality < 2) return 0; /* catable streams at quality 0 / 1 take the ring-buffer path: not restated */
   for (;;) {
     size_t remaining_block_size;
     {

@@ -214,6 +214,17 @@ void orc_prefix_encode_copy_distance(size_t distance_code, size_t num_direct_cod
 uint32_t orc_command_distance_context(const Command* c);                   /* command.rs:28-36 */
 int orc_is_mostly_utf8(const uint8_t* data, size_t pos, size_t mask, size_t length, float min_fraction);
 
+/* entropy coder pieces shared with orc_fragment.c */
+void orc_create_huffman_tree(const uint32_t* data, size_t length, int tree_limit, uint8_t* depth);
+void orc_store_huffman_tree(const uint8_t* depths, size_t num, size_t* storage_ix, uint8_t* storage);
+void orc_convert_bit_depths_to_symbols(const uint8_t* depth, size_t len, uint16_t* bits);
+void orc_build_and_store_huffman_tree_fast(const uint32_t* histogram, size_t histogram_total, size_t max_bits,
+                                           uint8_t* depth, uint16_t* bits, size_t* storage_ix, uint8_t* storage);
+/* compress_fragment_two_pass.rs (quality 1), orc_fragment.c */
+void orc_compress_fragment_two_pass(const uint8_t* input, size_t input_size, int is_last, uint32_t* command_buf,
+                                    uint8_t* literal_buf, int32_t* table, size_t table_size, size_t* storage_ix,
+                                    uint8_t* storage);
+
 uint8_t orc_context(uint8_t p1, uint8_t p2, int mode);
 enum { ORC_CONTEXT_LSB6 = 0, ORC_CONTEXT_MSB6 = 1, ORC_CONTEXT_UTF8 = 2, ORC_CONTEXT_SIGNED = 3 };
 

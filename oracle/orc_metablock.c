@@ -1559,3 +1559,22 @@ void orc_write_metadata_meta_block(const EncoderParams* params, size_t* storage_
   orc_write_bits(8, 1 /* VERSION, src/lib.rs:67 */, storage_ix, storage);
   for (size_t i = 0; i < count; ++i) orc_write_bits(8, b128[i], storage_ix, storage);
 }
+
+/* ------------------------------------------------------------------ exports for orc_fragment.c (qualities 0 / 1) */
+void orc_create_huffman_tree(const uint32_t* data, size_t length, int tree_limit, uint8_t* depth) {
+  HuffmanTree* tree = (HuffmanTree*)malloc((2 * length + 1) * sizeof(HuffmanTree));
+  create_huffman_tree(data, length, tree_limit, tree, depth);
+  free(tree);
+}
+void orc_store_huffman_tree(const uint8_t* depths, size_t num, size_t* storage_ix, uint8_t* storage) {
+  HuffmanTree* tree = (HuffmanTree*)malloc((2 * 704 + 1) * sizeof(HuffmanTree));
+  store_huffman_tree(depths, num, tree, storage_ix, storage);
+  free(tree);
+}
+void orc_convert_bit_depths_to_symbols(const uint8_t* depth, size_t len, uint16_t* bits) {
+  convert_bit_depths_to_symbols(depth, len, bits);
+}
+void orc_build_and_store_huffman_tree_fast(const uint32_t* histogram, size_t histogram_total, size_t max_bits,
+                                           uint8_t* depth, uint16_t* bits, size_t* storage_ix, uint8_t* storage) {
+  build_and_store_huffman_tree_fast(histogram, histogram_total, max_bits, depth, bits, storage_ix, storage);
+}
