@@ -1,4 +1,4 @@
-/* oracle/brotli_oracle.h -- CPU restatement of rust-brotli's encoder path (qualities 1..11, incl. "9.5").
+/* oracle/brotli_oracle.h -- CPU restatement of rust-brotli's encoder path (qualities 0..11, incl. "9.5").
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product (rust-brotli_amd/, include/) may include,
  * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
@@ -16,8 +16,8 @@
  * dictionary search), orc_metablock.c (greedy meta-block builder, Huffman, bit stream), orc_hq_metablock.c (quality >= 10
  * block splitter + clustering), orc_encode.c (stream state machine), orc_multi.c (compress_multi + BroCatli).
  * Qualities 2..4 (BasicHasher H2/H3/H4/H54, store_meta_block_fast / _trivial) are byte-identical to libbrotlienc 1.0.9
- * modulo two more documented source differences, quality 1 (orc_fragment.c: compress_fragment_two_pass) modulo one.
- * Not restated: quality 0 (compress_fragment).
+ * modulo two more documented source differences, qualities 0 and 1 (orc_fragment.c: compress_fragment,
+ * compress_fragment_two_pass) modulo one each.  Not restated: catable streams at quality 0 / 1.
  */
 #ifndef BROTLI_ORACLE_H_
 #define BROTLI_ORACLE_H_

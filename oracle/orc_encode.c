@@ -45,6 +45,11 @@ struct OrcEncoder {
   size_t available_out_;
   uint64_t total_out_;
   uint8_t tiny_buf_[16];
+  /* quality 0: the command code carried from one fragment to the next (encode.rs:172-176) */
+  uint8_t cmd_depths_[128];
+  uint16_t cmd_bits_[128];
+  uint8_t cmd_code_[512];
+  size_t cmd_code_numbits_;
   uint32_t remaining_metadata_bytes_;
   int stream_state_;
   int is_last_block_emitted_;
@@ -260,6 +265,7 @@ static int ensure_initialized(OrcEncoder* s) {
     if (!(s->params.catable && s->params.bare_stream))
       encode_window_bits(lgwin, s->params.large_window, &s->last_bytes_, &s->last_bytes_bits_);
   }
+  if (s->params.quality == 0) orc_init_command_prefix_codes(s->cmd_depths_, s->cmd_bits_, s->cmd_code_, &s->cmd_code_numbits_);
   if (s->params.catable) {
     for (int i = 0; i < 16; ++i) s->dist_cache_[i] = 0x7ffffff0;
     for (int i = 0; i < 4; ++i) s->saved_dist_cache_[i] = 0x7ffffff0;
@@ -999,10 +1005,6 @@ static int compress_stream_fast(OrcEncoder* s, int op, size_t* available_in, con
   uint32_t* command_buf = NULL;
   uint8_t* literal_buf = NULL;
   if (s->params.quality != 0 && s->params.quality != 1) return 0;
-  if (s->params.quality == 0) {
-    fprintf(stderr, "oracle: quality 0 (compress_fragment) is not restated\n");
-    return 0;
-  }
   command_buf = (uint32_t*)calloc(buf_size ? buf_size : 1, sizeof(uint32_t));
   literal_buf = (uint8_t*)calloc(buf_size ? buf_size : 1, 1);
   for (;;) {
@@ -1030,8 +1032,13 @@ static int compress_stream_fast(OrcEncoder* s, int op, size_t* available_in, con
       storage[0] = (uint8_t)s->last_bytes_;
       storage[1] = (uint8_t)(s->last_bytes_ >> 8);
       int32_t* table = get_hash_table(s->params.quality, block_size, &table_size);
-      orc_compress_fragment_two_pass(*next_in, block_size, is_last, command_buf, literal_buf, table, table_size,
-                                     &storage_ix, storage);
+      if (s->params.quality == 0) {
+        orc_compress_fragment_fast(*next_in, block_size, is_last, table, table_size, s->cmd_depths_, s->cmd_bits_,
+                                   &s->cmd_code_numbits_, s->cmd_code_, &storage_ix, storage);
+      } else {
+        orc_compress_fragment_two_pass(*next_in, block_size, is_last, command_buf, literal_buf, table, table_size,
+                                       &storage_ix, storage);
+      }
       free(table);
       *next_in += block_size;
       *available_in -= block_size;

@@ -225,6 +225,12 @@ void orc_compress_fragment_two_pass(const uint8_t* input, size_t input_size, int
                                     uint8_t* literal_buf, int32_t* table, size_t table_size, size_t* storage_ix,
                                     uint8_t* storage);
 
+/* compress_fragment.rs (quality 0) + InitCommandPrefixCodes (encode.rs:627-659), orc_fragment.c */
+void orc_init_command_prefix_codes(uint8_t* cmd_depths, uint16_t* cmd_bits, uint8_t* cmd_code, size_t* cmd_code_numbits);
+void orc_compress_fragment_fast(const uint8_t* input, size_t input_size, int is_last, int32_t* table, size_t table_size,
+                                uint8_t* cmd_depth, uint16_t* cmd_bits, size_t* cmd_code_numbits, uint8_t* cmd_code,
+                                size_t* storage_ix, uint8_t* storage);
+
 uint8_t orc_context(uint8_t p1, uint8_t p2, int mode);
 enum { ORC_CONTEXT_LSB6 = 0, ORC_CONTEXT_MSB6 = 1, ORC_CONTEXT_UTF8 = 2, ORC_CONTEXT_SIGNED = 3 };
 

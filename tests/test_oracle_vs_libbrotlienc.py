@@ -26,7 +26,9 @@ ports an older C version of that hasher than 1.0.9:
   orc_test_c109_basic_store_range  rust-brotli's StoreRangeOptBasic files four positions at a time under the sweep slot of
                                    the first one and stores masked positions (mod.rs:254-285); C stores one by one
 
-Quality 1 (the two-pass fragment compressor) has one:
+Quality 0 (the one-pass fragment compressor) differs only in ShouldMergeBlock, which rust-brotli evaluates in f32
+(orc_test_c109_merge_block_double; no decision on the inputs below flips because of it).  Quality 1 (the two-pass
+fragment compressor) has one:
 
   orc_test_c109_two_pass_min_match with a 2^15-entry table C still matches 4 bytes (B <= 15), rust-brotli switches to 6
                                    (`$table_bits < 15`, src/enc/compress_fragment_two_pass.rs:723)
@@ -49,7 +51,7 @@ import synth
 HERE = os.path.dirname(os.path.abspath(__file__))
 SWITCHES = ("orc_test_c109_rle_store_rule", "orc_test_c109_spree_tail", "orc_test_c109_entropy", "orc_test_c109_hasher_choice")
 LOW_QUALITY_SWITCHES = SWITCHES + ("orc_test_c109_basic_layout", "orc_test_c109_basic_store_range",
-                                   "orc_test_c109_two_pass_min_match")
+                                   "orc_test_c109_two_pass_min_match", "orc_test_c109_merge_block_double")
 
 
 @pytest.fixture(scope="module")
@@ -143,9 +145,10 @@ def test_identical_to_libbrotlienc_modulo_the_four_source_differences(genc, qual
     assert len(orc.compress(synth.alice(), 5, 22)) == 52808
 
 
-@pytest.mark.parametrize("quality", [1, 2, 3, 4])
+@pytest.mark.parametrize("quality", [0, 1, 2, 3, 4])
 def test_low_qualities_identical_to_libbrotlienc_modulo_the_source_differences(genc, quality):
-    """Quality 1: compress_fragment_two_pass (CreateCommands, the 128-symbol command code, BuildAndStoreHuffmanTreeFast) behind
+    """Quality 0: compress_fragment (one pass, the command code carried from block to block, merged blocks).
+    Quality 1: compress_fragment_two_pass (CreateCommands, the 128-symbol command code, BuildAndStoreHuffmanTreeFast) behind
     the ring-buffer-less stream path of encode.rs:2706-2861.
     H2 (quality 2, store_meta_block_fast with BrotliBuildAndStoreHuffmanTreeFast and the static command / distance
     codes), H3 (quality 3, store_meta_block_trivial), H4 and -- from size_hint 1 MiB -- H54 (quality 4, greedy block
