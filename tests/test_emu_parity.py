@@ -169,3 +169,20 @@ def test_incompressible_input_converges_in_a_few_rounds(L):
     lit = synth.stretches(3 << 20)
     _, st = emu.lz77_trace(L, lit, quality=9, lgwin=22, segment_bytes=2048)
     assert st["rounds"] <= 8, st  # 29 before
+
+
+@pytest.mark.oracle_as_is
+@pytest.mark.xfail(reason="known divergence: the reference's StoreRangeOptBatch writes masked positions into the H5 rings "
+                          "(mod.rs:1163-1232), which end FindLongestMatch's bucket walk past the first ring revolution; the "
+                          "device path stores absolute positions like the C encoder (DESIGN.md section 6)", strict=False)
+def test_known_divergence_h5_past_the_first_ring_revolution(L):
+    """1 MiB at lgwin 17 (256 KiB ring) with the H5 hasher: against the oracle AS IT IS.  Every other product test runs the
+    oracle with orc_test_c109_adv_store_range on (tests/conftest.py), under which the same input is byte-identical:"""
+    data = synth.markov_text(1 << 20)
+    out, _ = emu.encode_stream(L, data, [(Q, 5), (W, 17), (SH, len(data))])
+    old = orc.set_h5_absolute_store_range(True)
+    try:
+        assert out == orc.compress(data, 5, 17)  # the product's view: identical
+    finally:
+        orc.set_h5_absolute_store_range(bool(old))
+    assert out == orc.compress(data, 5, 17)      # the reference as it is: differs (xfail)

@@ -110,6 +110,31 @@ def test_frozen_hashes():
     assert got == frozen
 
 
+def test_h5_store_range_masks_positions():
+    """AdvHasher::StoreRangeOptBatch (mod.rs:1163-1232, the H5 family: StoreLookahead 4) files the positions a copy covers
+    four at a time -- and writes the MASKED position into the bucket.  Once the input is longer than the ring buffer
+    (2 << max(lgwin, lgblock) bytes) such an entry looks further away than max_backward (backward = cur_ix - entry,
+    :1763-1775) and ends the walk through its bucket: the reference loses most of its candidates there.  C stores absolute
+    positions (test switch).  Below the ring size, and for H6 (lookahead 8) and H9, nothing changes."""
+    import ctypes
+    cell = ctypes.c_int.in_dll(orc.lib(), "orc_test_c109_adv_store_range")
+    text = synth.markov_text(3 << 20)
+    sizes = {}
+    for c_style in (0, 1):
+        cell.value = c_style
+        try:
+            sizes[c_style] = {w: len(orc.compress(text, 5, w)) for w in (18, 22)}
+            small = orc.compress(text[:500000], 5, 18)  # shorter than the 512 KiB ring
+            sizes[c_style]["small"] = len(small)
+        finally:
+            cell.value = 0
+    assert sizes[0][22] == sizes[1][22]           # 8 MiB ring: never wraps on 3 MiB
+    assert sizes[0]["small"] == sizes[1]["small"]  # no revolution yet
+    assert sizes[0][18] > 1.2 * sizes[1][18]       # 512 KiB ring: 1 092 273 vs 871 791 bytes
+    out = orc.compress(text, 5, 18)
+    assert orc.decompress(out, len(text)) == text
+
+
 def test_frozen_hashes_low_and_high_qualities():
     """streams frozen when the restatement reproduced the reference's exact sizes (qualities 10 / 11 / "9.5") and was
     byte-identical to libbrotlienc modulo the documented differences (qualities 2..4): a regression guard"""

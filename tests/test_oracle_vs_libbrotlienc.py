@@ -33,7 +33,13 @@ fragment compressor) has one:
   orc_test_c109_two_pass_min_match with a 2^15-entry table C still matches 4 bytes (B <= 15), rust-brotli switches to 6
                                    (`$table_bits < 15`, src/enc/compress_fragment_two_pass.rs:723)
 
-With all four switched to the C behaviour the oracle is BYTE-IDENTICAL to libbrotlienc on every input below, at qualities
+A fifth one shows only on inputs longer than the ring buffer with an H5 hasher (here: lgwin 18 and more than 512 KiB):
+
+  orc_test_c109_adv_store_range rust-brotli's StoreRangeOptBatch writes MASKED positions into the H5 bucket rings
+                                (mod.rs:1163-1232); past the first revolution of the ring buffer they end the bucket walk
+                                of FindLongestMatch.  C stores absolute positions.
+
+With these switched to the C behaviour the oracle is BYTE-IDENTICAL to libbrotlienc on every input below, at qualities
 5..8 and several window sizes: hashing (H5 with 14 / 15 bucket bits, H6), bucket rings, the static dictionary, lazy
 matching, the distance cache, command coding, context modelling, greedy block splitting, histogram optimisation, Huffman
 trees, context maps and bit emission of the restatement all agree with an implementation written by other people.
@@ -49,7 +55,8 @@ import orc
 import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SWITCHES = ("orc_test_c109_rle_store_rule", "orc_test_c109_spree_tail", "orc_test_c109_entropy", "orc_test_c109_hasher_choice")
+SWITCHES = ("orc_test_c109_rle_store_rule", "orc_test_c109_spree_tail", "orc_test_c109_entropy", "orc_test_c109_hasher_choice",
+            "orc_test_c109_adv_store_range")
 LOW_QUALITY_SWITCHES = SWITCHES + ("orc_test_c109_basic_layout", "orc_test_c109_basic_store_range",
                                    "orc_test_c109_two_pass_min_match", "orc_test_c109_merge_block_double")
 
