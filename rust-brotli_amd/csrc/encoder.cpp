@@ -757,7 +757,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         lz.KeyCountsBefore(keep_from, &co.key_counts);
       }
       co.stored.assign(all.begin() + keep_from, all.begin() + resume);
-      for (uint8_t& f : co.stored) f &= 1;
+      for (uint8_t& f : co.stored) f &= 5;  // stored, and "stored as a masked position" (kFlagMasked; never set unless modelled)
       if (tail_nbits) {
         uint8_t last = 0;
         dev_d2h(&last, (const uint8_t*)B.out_words + total_bytes, 1);

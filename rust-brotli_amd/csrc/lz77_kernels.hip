@@ -84,6 +84,9 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
 
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
                      uint32_t prefix_flags_bytes) {
+  // (kFlagMasked is written by the chains, but the row and flag-diff kernels below only look at the stored bit so far)
+  if (P.masked_from != kNeverMasked)
+    throw std::runtime_error("brotli_mi355x: masked H5 ring entries (BROTLI_MI355X_MASKED_H5) are not supported by the gfx950 kernels yet");
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, BR_STREAM));
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), BR_STREAM));  // StoreLookaheadThenStore, mod.rs:224-229

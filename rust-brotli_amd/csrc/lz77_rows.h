@@ -39,7 +39,9 @@ struct SlotsInMemory {
 // entries (mod.rs:1752-1760): where the counter has just wrapped to 0 it sees nothing, after that only the insertions
 // since the wrap.  So a slot with bit 2 has an empty row, and walking back from any other slot the candidates end
 // WITH the nearest stored slot that has bit 2 (the first insertion after the wrap).
-static constexpr uint32_t kSlotStored = 1, kSlotChanged = 2, kSlotWrap = 4;
+// bit 3 = the slot's ring entry is a masked position (kFlagMasked): it is never a candidate, and the lookback of every
+// later slot ends when it reaches it -- for the reference it lies further back than max_backward (mod.rs:1763-1775).
+static constexpr uint32_t kSlotStored = 1, kSlotChanged = 2, kSlotWrap = 4, kSlotMasked = 8;
 
 // The row of slot i, whose key owns the slots from kf on: the (up to) `depth` nearest stored slots in front of it -- what
 // the bucket ring of the reference holds when the position is searched (AdvHasher::FindLongestMatch, mod.rs:1744-1793)
@@ -59,7 +61,7 @@ BR_DEV void br_collect_row(const Slots& sl, uint32_t max_backward_limit, uint32_
     j = nj - 1;
     const uint32_t fb = sl.fb(j);
     const uint32_t q = sl.pos(j);
-    if (p - q > max_backward || q < oldest) break;
+    if (p - q > max_backward || q < oldest || (fb & kSlotMasked)) break;
     ++seen;
     if (sl.tag(j) == tag) out[n++] = q;
     if (fb & kSlotWrap) break;

@@ -115,6 +115,17 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.changed_count = (uint32_t*)dev_alloc(64);
   // Ring depth 16 (quality 5): position-indexed candidate rows (lz77_chain.h); deeper rings keep the rank structures.
   use_rows_ = P_.hasher_kind != 9 && (1u << P_.block_bits) <= kRowEntries && getenv("BROTLI_MI355X_NO_ROWS") == nullptr;
+  // Masked H5 ring entries (Lz77Params::masked_from; DESIGN.md section 6 "Known divergence").  Staged: the chain code, the
+  // row lookback (br_collect_row) and this driver model them and the emulation build proves the result against the oracle
+  // as it is; the gfx950 row / flag kernels do not take the third flag bit yet, so the device seam refuses it and the
+  // switch is off by default.  Quality 5 (candidate rows) only.
+  P_.masked_from = kNeverMasked;
+  if (getenv("BROTLI_MI355X_MASKED_H5") != nullptr && P_.hasher_kind == 5 && use_rows_) {
+    const uint64_t ring = (uint64_t)P_.ring_mask + 1;
+    const uint64_t base = (carry_ && carry_->valid) ? carry_->stream_base : 0;  // stream position of text position 0
+    if (base >= ring) P_.masked_from = 0;
+    else if (base + P_.total_bytes > ring) P_.masked_from = (uint32_t)(ring - base);
+  }
   if (use_rows_) {
     B_.changed_cap = (uint32_t)std::max<size_t>(kChangedCap, M / 32);
     B_.changed_keys = (uint32_t*)dev_alloc_uninit((size_t)B_.changed_cap * 4 + 64);

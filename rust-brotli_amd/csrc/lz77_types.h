@@ -50,8 +50,13 @@ struct Lz77Params {
   // (encode.rs:1623-1631, 1705-1710, 2472-2474).  Searches at positions >= reset_pos see only what was inserted from
   // reset_vis on (= reset_pos - 3: StitchToPreviousBlock re-inserts the last three positions of the block in front).
   uint32_t reset_pos, reset_vis;
-  uint32_t reserved;
+  // First position from which the entries that the reference's StoreRangeOptBatch writes into an H5 bucket ring are MASKED
+  // positions (mod.rs:1163-1232: the stream position has passed the ring-buffer size); such an entry ends the bucket walk
+  // of every later search (kFlagMasked, lz77_chain.h).  kNeverMasked: not an H5 hasher, input shorter than the ring, or
+  // the modelling is switched off ("Known divergence").
+  uint32_t masked_from;
 };
+static constexpr uint32_t kNeverMasked = 0xffffffffu;
 
 // candidate rows (lz77_chain.h): entries per position, end-of-row marker
 static constexpr uint32_t kRowEntries = 16;

@@ -298,6 +298,9 @@ static void emu_slot_masks(const Lz77Params& P, const Lz77Buffers& B) {
   }
 }
 
+// per-slot byte from a flag byte: stored bit, and kSlotMasked for kFlagMasked (lz77_rows.h)
+static inline uint8_t emu_fb(uint8_t flag) { return (uint8_t)((flag & 1u) | ((flag & kFlagMasked) ? kSlotMasked : 0u)); }
+
 static void emu_build_all_rows(const Lz77Params& P, const Lz77Buffers& B, int which, bool validate, const SegGeometry* geo, uint8_t* dirty) {
   const uint32_t n = P.total_bytes;
   const uint32_t depth0 = 1u << P.block_bits;
@@ -322,7 +325,7 @@ static void emu_build_all_rows(const Lz77Params& P, const Lz77Buffers& B, int wh
 }
 
 void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const RankInitialHint*, bool) {
-  for (uint32_t i = 0; i < P.total_bytes; ++i) B.fbits[i] = B.flags[which][B.by_key[i]] & 1u;
+  for (uint32_t i = 0; i < P.total_bytes; ++i) B.fbits[i] = emu_fb(B.flags[which][B.by_key[i]]);
   emu_slot_masks(P, B);
   emu_build_all_rows(P, B, which, false, nullptr, nullptr);
 }
@@ -335,7 +338,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   static const bool force_full = getenv("EMU_ROWS_FULL") != nullptr;
   bool need_full = n > cap || force_full;
   if (n > cap) {
-    for (uint32_t i = 0; i < P.total_bytes; ++i) B.fbits[i] = B.flags[next][B.by_key[i]] & 1u;
+    for (uint32_t i = 0; i < P.total_bytes; ++i) B.fbits[i] = emu_fb(B.flags[next][B.by_key[i]]);
   } else {
     for (uint32_t c = 0; c < n; ++c) {
       const uint32_t p = B.changed_keys[c];
@@ -346,7 +349,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
         const uint32_t mid = lo + (hi - lo) / 2;
         if (B.by_key[mid] <= p) lo = mid; else hi = mid;
       }
-      B.fbits[lo] = (uint8_t)((B.flags[next][p] & 1u) | 2u);
+      B.fbits[lo] = (uint8_t)(emu_fb(B.flags[next][p]) | 2u);
       B.changed_slot[c] = lo;
     }
   }
@@ -367,7 +370,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
     emu_build_all_rows(P, B, next, true, &geo, dirty);
   }
   if (n <= cap)
-    for (uint32_t c = 0; c < n; ++c) B.fbits[B.changed_slot[c]] &= 1u;
+    for (uint32_t c = 0; c < n; ++c) B.fbits[B.changed_slot[c]] &= (uint8_t)(kSlotStored | kSlotMasked);
 }
 
 static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, SegEntry* entries,
@@ -508,7 +511,7 @@ void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list, uint32_t co
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
   uint32_t count = 0;
   for (uint32_t q = 0; q < P.total_bytes; ++q) {
-    if ((B.flags[prev][q] ^ B.flags[next][q]) & 1) {
+    if ((B.flags[prev][q] ^ B.flags[next][q]) & (kFlagStored | kFlagMasked)) {
       if (count < B.changed_cap) B.changed_keys[count] = B.rows ? q : (uint32_t)B.keys[q];
       count++;
     }

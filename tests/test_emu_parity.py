@@ -186,3 +186,22 @@ def test_known_divergence_h5_past_the_first_ring_revolution(L):
     finally:
         orc.set_h5_absolute_store_range(bool(old))
     assert out == orc.compress(data, 5, 17)      # the reference as it is: differs (xfail)
+
+
+@pytest.mark.oracle_as_is
+def test_masked_h5_entries_modelled_on_the_emulation_build(L):
+    """The staged fix for the known divergence above (BROTLI_MI355X_MASKED_H5=1, off by default because the gfx950 row and
+    flag-diff kernels do not take the third flag bit yet): the chains mark the positions the reference's StoreRangeOptBatch
+    files as masked entries (kFlagMasked, FlagWriter::copy_value), the row lookback ends at them (br_collect_row), the bit
+    travels with the stored flags of a stream's window.  Against the oracle AS IT IS: one-shot, shards, trimmed streams."""
+    import test_cabi
+    os.environ["BROTLI_MI355X_MASKED_H5"] = "1"
+    try:
+        for data, w in ((synth.markov_text(1 << 20), 17), (synth.mixed(1 << 20), 17), (synth.markov_text(2 << 20)[:1500000], 18)):
+            out, _ = emu.encode_stream(L, data, [(Q, 5), (W, w), (SH, len(data))])
+            assert out == orc.compress(data, 5, w)
+        lib = test_cabi._load("emu")
+        t = synth.markov_text(900000, 2)
+        assert bytes(lib.BrotliCompress(t, {Q: 5, W: 17}, 3)) == orc.compress_multi(t, [(Q, 5), (W, 17)], 3)
+    finally:
+        del os.environ["BROTLI_MI355X_MASKED_H5"]
