@@ -84,9 +84,10 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
 
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
                      uint32_t prefix_flags_bytes) {
-  // (kFlagMasked is written by the chains, but the row and flag-diff kernels below only look at the stored bit so far)
-  if (P.masked_from != kNeverMasked)
-    throw std::runtime_error("brotli_mi355x: masked H5 ring entries (BROTLI_MI355X_MASKED_H5) are not supported by the gfx950 kernels yet");
+  // (masked H5 ring entries, Lz77Params::masked_from: the candidate-row kernels take kFlagMasked -- written at the end of
+  // round 2 without a GPU to run them on, hence still behind BROTLI_MI355X_MASKED_H5 -- the rank structures do not)
+  if (P.masked_from != kNeverMasked && B.rows == nullptr)
+    throw std::runtime_error("brotli_mi355x: masked H5 ring entries are modelled for the candidate rows (quality 5) only");
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, BR_STREAM));
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), BR_STREAM));  // StoreLookaheadThenStore, mod.rs:224-229
@@ -268,7 +269,7 @@ struct InitialFlagGeometry {
 
 __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
                                                       uint8_t* __restrict__ fbits, uint32_t* __restrict__ tile_sums,
-                                                      InitialFlagGeometry ig) {
+                                                      InitialFlagGeometry ig, uint32_t masked_bits) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
   uint32_t local = 0, packed = 0;
@@ -285,8 +286,10 @@ __global__ __launch_bounds__(256) void k_rank_gather(const uint32_t* __restrict_
           known = p + 16 < ig.prefix_stored_end;
         }
       }
-      f = known ? 1u : (flags[p] & 1u);
-      packed |= f << (8 * j);
+      const uint32_t fl = known ? 1u : (uint32_t)flags[p];
+      f = fl & 1u;
+      // (candidate rows with masked H5 entries modelled: kFlagMasked becomes kSlotMasked, lz77_rows.h)
+      packed |= (f | ((masked_bits && (fl & kFlagMasked)) ? kSlotMasked : 0u)) << (8 * j);
       local += f;
     }
   if (base < n) *(uint32_t*)(fbits + base) = packed;
@@ -411,7 +414,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
   if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
-  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
+  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig, 0u);
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
@@ -612,7 +615,7 @@ struct RowArgs {
   uint32_t* rows;
   const uint8_t* flags;  // newest per-position flags (the searched bit decides who is affected by a changed row)
   uint32_t n, depth, max_backward_limit;
-  uint32_t reset_pos, reset_vis;  // Lz77Params
+  uint32_t reset_pos, reset_vis, ring_mask;  // Lz77Params
   uint32_t validate;     // compare with the row in memory and mark the chains that searched a position whose row changed
   SegGeometry geo;
   uint8_t* dirty;
@@ -688,7 +691,9 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
       const uint32_t e = threadIdx.x * 5 + j;
       if (e < span) {
         s_rank[e] = (uint16_t)g;
-        if (f[j]) c_ent[g] = make_uint2(s_pos[e] | ((s_fb[e] & kSlotWrap) ? 0x80000000u : 0u), s_tk[e]);
+        // (a masked H5 entry goes in with the masked position the reference's ring holds: `p - q <= max_backward` fails for
+        // it below, which ends the lookback there like the reference's bucket walk -- br_collect_row does the same)
+        if (f[j]) c_ent[g] = make_uint2(((s_fb[e] & kSlotMasked) ? (s_pos[e] & a.ring_mask) : s_pos[e]) | ((s_fb[e] & kSlotWrap) ? 0x80000000u : 0u), s_tk[e]);
       }
       g += f[j];
     }
@@ -877,12 +882,15 @@ __global__ __launch_bounds__(256) void k_mark_wraps(uint8_t* __restrict__ fbits,
   }
 }
 
+// stored bit, and kSlotMasked for kFlagMasked (set by the chains only where masked H5 entries are modelled, Lz77Params::masked_from)
+__device__ __forceinline__ uint32_t slot_bits_of_flag(uint32_t flag) { return (flag & 1u) | ((flag & kFlagMasked) ? kSlotMasked : 0u); }
+
 // stored bits from scratch (list overflow): a random one-byte gather per slot; the wrap marks are set afterwards
 __global__ __launch_bounds__(256) void k_regather_fbits(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
                                                          uint8_t* __restrict__ fbits, const uint32_t* __restrict__ ctl) {
   if (ctl[kCtlNeedFull] != 2) return;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    fbits[i] = (uint8_t)((flags[by_key[i]] & 1u) | (fbits[i] & kSlotWrap));
+    fbits[i] = (uint8_t)(slot_bits_of_flag(flags[by_key[i]]) | (fbits[i] & kSlotWrap));
 }
 
 // One thread per changed position: find its slot (binary search in its key's slot range), flip the stored bit there.
@@ -913,7 +921,7 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
     const uint32_t mid = lo + (hi - lo) / 2;
     if (by_key[mid] <= p) lo = mid; else hi = mid;
   }
-  fbits[lo] = (uint8_t)((flags_new[p] & 1u) | kSlotChanged | (fbits[lo] & kSlotWrap));
+  fbits[lo] = (uint8_t)(slot_bits_of_flag(flags_new[p]) | kSlotChanged | (fbits[lo] & kSlotWrap));
   changed_slot[i] = lo;
 }
 
@@ -981,6 +989,7 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.max_backward_limit = P.max_backward_limit;
   a.reset_pos = P.reset_pos;
   a.reset_vis = P.reset_vis;
+  a.ring_mask = P.ring_mask;
   a.validate = validate ? 1 : 0;
   if (geo) a.geo = *geo;
   a.dirty = dirty_dev;
@@ -1105,7 +1114,8 @@ void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const 
   }
   const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
-  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig);
+  hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig,
+                     P.masked_from != kNeverMasked ? 1u : 0u);
   HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
   if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   if (has_big_keys) {
@@ -1342,10 +1352,12 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
     uint32_t d[4] = {0, 0, 0, 0};
     if (wi < words) {
       const uint4 a = ((const uint4*)prev)[wi], b = ((const uint4*)next)[wi];
-      d[0] = (a.x ^ b.x) & 0x01010101u;
-      d[1] = (a.y ^ b.y) & 0x01010101u;
-      d[2] = (a.z ^ b.z) & 0x01010101u;
-      d[3] = (a.w ^ b.w) & 0x01010101u;
+      // a position changed if its stored bit or its "stored as a masked position" bit (kFlagMasked) did: one mark per byte
+      d[0] = (a.x ^ b.x) & 0x05050505u;
+      d[1] = (a.y ^ b.y) & 0x05050505u;
+      d[2] = (a.z ^ b.z) & 0x05050505u;
+      d[3] = (a.w ^ b.w) & 0x05050505u;
+      for (uint32_t j = 0; j < 4; ++j) d[j] = (d[j] | (d[j] >> 2)) & 0x01010101u;
       // bytes past n are padding
       for (uint32_t j = 0; j < 16; ++j)
         if (wi * 16 + j >= n) d[j >> 2] &= ~(1u << (8 * (j & 3)));
