@@ -56,6 +56,9 @@ static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 // Lz77Params::masked_from): a stored entry like any other for the ring counters, but the bucket walk of every later search
 // ends when it reaches it.  Only ever set together with kFlagStored.
 static constexpr uint8_t kFlagMasked = 4;
+// how the rank structures (sorted[], qualities 6..8) hold such an entry: position | kMaskedEntry.  `cur - q <= max_backward`
+// fails for it in br_probe_pair, which is where the reference's walk breaks too.
+static constexpr uint32_t kMaskedEntry = 0x80000000u;
 static constexpr uint32_t kMinScore = 30 * 8 * 8 + 100;  // mod.rs:2408-2410
 
 struct ChainTables {
@@ -207,6 +210,7 @@ BR_DEV bool br_row_change_matters(const uint8_t* text, uint32_t p, const uint32_
       q = qb;
       ++j;
     }
+    if (q & kMaskedEntry) return true;  // a masked ring entry ends the bucket walk whatever its text is
     if (br_load32(text + q) == head) return true;
   }
   return false;
@@ -1228,7 +1232,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   uint32_t tail_kind = kHeadNone, tail_base = 0, tail_p1 = 0;
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
-  fw.masked_from = (!kH9 && kRows) ? P.masked_from : kNeverMasked;
+  fw.masked_from = !kH9 ? P.masked_from : kNeverMasked;
   uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0, n_bad = 0;
   uint32_t last_dist_code = 0xffffffffu, last_copy_len = 0;
   uint32_t cache_version = 0;

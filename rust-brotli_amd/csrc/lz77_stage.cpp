@@ -118,9 +118,9 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   // Masked H5 ring entries (Lz77Params::masked_from; DESIGN.md section 6 "Known divergence").  Staged: the chain code, the
   // row lookback (br_collect_row) and this driver model them and the emulation build proves the result against the oracle
   // as it is; the gfx950 row / flag kernels do not take the third flag bit yet, so the device seam refuses it and the
-  // switch is off by default.  Quality 5 (candidate rows) only.
+  // switch is off by default.  (The rank structures of qualities 6..8 take them on the emulation build only so far.)
   P_.masked_from = kNeverMasked;
-  if (getenv("BROTLI_MI355X_MASKED_H5") != nullptr && P_.hasher_kind == 5 && use_rows_) {
+  if (getenv("BROTLI_MI355X_MASKED_H5") != nullptr && P_.hasher_kind == 5) {
     const uint64_t ring = (uint64_t)P_.ring_mask + 1;
     const uint64_t base = (carry_ && carry_->valid) ? carry_->stream_base : 0;  // stream position of text position 0
     if (base >= ring) P_.masked_from = 0;

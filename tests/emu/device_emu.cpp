@@ -162,7 +162,7 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
     }
     B.info[rbuf][2 * (size_t)pos] = first + local;
     B.info[rbuf][2 * (size_t)pos + 1] = emu_ring_count_at(P, B, pos, local, B.sorted_keys[i]);
-    if (B.flags[which][pos] & 1) B.sorted[rbuf][first + local++] = pos;
+    if (B.flags[which][pos] & 1) B.sorted[rbuf][first + local++] = (B.flags[which][pos] & kFlagMasked) ? (pos | kMaskedEntry) : pos;
   }
 }
 
@@ -247,7 +247,7 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
     std::vector<uint32_t> new_sorted, new_rank(hi - lo);
     for (uint32_t i = lo; i < hi; ++i) {
       new_rank[i - lo] = (uint32_t)new_sorted.size();
-      if (flags[B.by_key[i]] & 1) new_sorted.push_back(B.by_key[i]);
+      if (flags[B.by_key[i]] & 1) new_sorted.push_back((flags[B.by_key[i]] & kFlagMasked) ? (B.by_key[i] | kMaskedEntry) : B.by_key[i]);
     }
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t p = B.by_key[i];

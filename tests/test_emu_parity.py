@@ -200,6 +200,11 @@ def test_masked_h5_entries_modelled_on_the_emulation_build(L):
         for data, w in ((synth.markov_text(1 << 20), 17), (synth.mixed(1 << 20), 17), (synth.markov_text(2 << 20)[:1500000], 18)):
             out, _ = emu.encode_stream(L, data, [(Q, 5), (W, w), (SH, len(data))])
             assert out == orc.compress(data, 5, w)
+        # qualities 6..8 (rank structures: the ring entry is held as position | kMaskedEntry, the probe breaks on it)
+        data = synth.mixed(1 << 20)
+        for q in (6, 8):
+            out, _ = emu.encode_stream(L, data, [(Q, q), (W, 17), (SH, len(data))])
+            assert out == orc.compress(data, q, 17)
         lib = test_cabi._load("emu")
         t = synth.markov_text(900000, 2)
         assert bytes(lib.BrotliCompress(t, {Q: 5, W: 17}, 3)) == orc.compress_multi(t, [(Q, 5), (W, 17)], 3)
