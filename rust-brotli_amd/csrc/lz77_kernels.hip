@@ -84,10 +84,8 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
 
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
                      uint32_t prefix_flags_bytes) {
-  // (masked H5 ring entries, Lz77Params::masked_from: the candidate-row kernels take kFlagMasked -- written at the end of
-  // round 2 without a GPU to run them on, hence still behind BROTLI_MI355X_MASKED_H5 -- the rank structures do not)
-  if (P.masked_from != kNeverMasked && B.rows == nullptr)
-    throw std::runtime_error("brotli_mi355x: masked H5 ring entries are modelled for the candidate rows (quality 5) only");
+  // (masked H5 ring entries, Lz77Params::masked_from: the row and rank kernels below take kFlagMasked -- written at the end
+  // of round 2 without a GPU to run them on, hence still behind BROTLI_MI355X_MASKED_H5)
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, BR_STREAM));
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), BR_STREAM));  // StoreLookaheadThenStore, mod.rs:224-229
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
                                                      uint32_t* __restrict__ sorted, uint2* __restrict__ info,
                                                      const uint32_t* __restrict__ count_base, uint32_t reset_pos,
                                                      const uint32_t* __restrict__ reset_counts, const uint16_t* __restrict__ stag,
-                                                     uint16_t* __restrict__ sorted_tag) {
+                                                     uint16_t* __restrict__ sorted_tag, const uint8_t* __restrict__ flags_if_masked) {
   __shared__ uint32_t wave_sum[4];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4;
   uint32_t pos[4], f[4], key[4];
@@ -381,7 +379,8 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
       const uint32_t slot = key_first[key[j]] + lr;
       info[pos[j]] = make_uint2(slot, ring_count_at(pos[j], lr, key[j], count_base, reset_pos, reset_counts));
       if (f[j]) {
-        sorted[slot] = pos[j];
+        // (a masked H5 ring entry is held as position | kMaskedEntry: the probe breaks on it, lz77_chain.h)
+        sorted[slot] = pos[j] | ((flags_if_masked != nullptr && (flags_if_masked[pos[j]] & kFlagMasked)) ? kMaskedEntry : 0u);
         if (sorted_tag) sorted_tag[slot] = stag[base + j];
       }
       g += f[j];
@@ -414,11 +413,13 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   uint32_t* scratch = tile_sums + tiles + 64;
   if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
+  // (the rank passes sum the per-slot bytes as they are: no kSlotMasked here, k_rank_apply reads kFlagMasked from the flags)
   hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig, 0u);
   exclusive_scan_u32(tile_sums, tiles, scratch);
   hipLaunchKernelGGL(k_key_bases, dim3(256), dim3(256), 0, BR_STREAM, B.fbits, tile_sums, B.key_first, B.key_last, B.key_base);
   hipLaunchKernelGGL(k_rank_apply, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.fbits, n, tile_sums, B.key_first, B.key_base,
-                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base, P.reset_pos, B.reset_counts, B.stag, B.stag ? B.sorted_tag[rbuf] : nullptr);
+                     B.sorted[rbuf], (uint2*)B.info[rbuf], B.count_base, P.reset_pos, B.reset_counts, B.stag, B.stag ? B.sorted_tag[rbuf] : nullptr,
+                     P.masked_from != kNeverMasked ? (const uint8_t*)B.flags[which] : (const uint8_t*)nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -487,14 +488,17 @@ __global__ __launch_bounds__(256) void k_rerank_apply(const RerankChunk* __restr
   __syncthreads();
   for (uint32_t tile = c.begin; tile < c.end; tile += kScanTile) {
     const uint32_t base = tile + threadIdx.x * 4;
-    uint32_t pos[4], f[4], local = 0;
+    uint32_t pos[4], f[4], masked[4], local = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       pos[j] = 0;
       f[j] = 0;
+      masked[j] = 0;
       if (base + j < c.end) {
         pos[j] = by_key[base + j];
-        f[j] = flags[pos[j]] & 1u;
+        const uint32_t fl = flags[pos[j]];
+        f[j] = fl & 1u;
+        masked[j] = (fl & kFlagMasked) ? kMaskedEntry : 0u;
       }
       local += f[j];
     }
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256) void k_rerank_apply(const RerankChunk* __restr
     for (int j = 0; j < 4; ++j) {
       if (base + j < c.end) {
         rank_tmp[base + j] = g;
-        if (f[j]) sorted_tmp[c.key_lo + g] = pos[j];
+        if (f[j]) sorted_tmp[c.key_lo + g] = pos[j] | masked[j];
         g += f[j];
       }
     }
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(256) void k_rerank_commit(const RerankChunk* __rest
     const uint32_t rb = rank_tmp[i];
     info[p] = make_uint2(c.key_lo + rb, ring_count_at(p, rb, keys[p], count_base, reset_pos, reset_counts));
     if (flags[p] & 1u) {
-      sorted[c.key_lo + rb] = p;
+      sorted[c.key_lo + rb] = p | ((flags[p] & kFlagMasked) ? kMaskedEntry : 0u);
       if (sorted_tag) sorted_tag[c.key_lo + rb] = stag[i];
     }
   }
