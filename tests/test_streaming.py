@@ -55,10 +55,14 @@ print("OK flush in a trimmed stream")
 '''
 
 
-def _run(kind, cases, batch, wrap_shift=0):
+def _run(kind, cases, batch, wrap_shift=0, masked_h5=False):
     # (the child compares the product with the oracle: in the product's view of the masked H5 store-range entries,
     # tests/orc.py -- the conftest fixture does not reach a subprocess)
     env = dict(os.environ, BROTLI_MI355X_STREAM_BATCH=str(batch), ORC_H5_ABSOLUTE_STORE_RANGE="1")
+    if masked_h5:
+        # the staged model of the masked H5 ring entries against the oracle as it is
+        env["BROTLI_MI355X_MASKED_H5"] = "1"
+        del env["ORC_H5_ABSOLUTE_STORE_RANGE"]
     code = _DRIVER % dict(tests=HERE, kind=kind, cases=repr(cases))
     if wrap_shift:
         # scale the position wrap of the reference (3, 5, 7 ... GiB) down to MiB, in the product and in the oracle
@@ -100,6 +104,13 @@ WRAP_CASES = [
     ("markov 8 MiB q5 w17, wraps at 3/5/7 MiB", "synth.markov_text(8 << 20, 21)", 5, 17, 65536),
     ("mixed 6 MiB q7 w17, wraps at 3/5 MiB", "synth.mixed(6 << 20, 22)", 7, 17, 50000),
 ]
+
+
+def test_streaming_pieces_emu_masked_h5():
+    """trimmed windows, carried masked flags (StreamCarry), a flush in a trimmed stream and the hasher reset at a position
+    wrap -- with BROTLI_MI355X_MASKED_H5=1 the emulation build equals the oracle AS IT IS on H5 streams that pass the ring size"""
+    _run("emu", CASES[:2] + CASES[3:4], 512 << 10, masked_h5=True)
+    _run("emu", WRAP_CASES[:1], 512 << 10, wrap_shift=20, masked_h5=True)
 
 
 def test_hasher_reset_at_position_wrap_emu():
