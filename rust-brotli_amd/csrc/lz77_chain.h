@@ -56,6 +56,7 @@ static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 // Lz77Params::masked_from): a stored entry like any other for the ring counters, but the bucket walk of every later search
 // ends when it reaches it.  Only ever set together with kFlagStored.
 static constexpr uint8_t kFlagMasked = 4;
+// (written by the chains only in builds with BR_MODEL_MASKED_H5, lz77_types.h)
 // how the rank structures (sorted[], qualities 6..8) hold such an entry: position | kMaskedEntry.  `cur - q <= max_backward`
 // fails for it in br_probe_pair, which is where the reference's walk breaks too.
 static constexpr uint32_t kMaskedEntry = 0x80000000u;
@@ -1138,7 +1139,6 @@ struct FlagWriter {
   uint32_t hi;       // writes are clipped to positions < hi (the end of the chain's own segment)
   uint32_t tail_lo;  // positions >= tail_lo inside the block get the stitch flag
   uint8_t tail_value;
-  uint32_t masked_from;  // Lz77Params::masked_from
   BR_DEV void put(uint32_t q, uint8_t v) {
     if (q < hi) next[q] = v;
   }
@@ -1155,21 +1155,26 @@ struct FlagWriter {
   // What StoreRange(first, min(copy_end, store_end)) of a copy leaves at position q >= first = copy start + 2
   // (mod.rs:2516-2521): stored up to store_end; the H5 family files the first 4 * floor(n / 4) positions of a range of
   // n >= 8 through StoreRangeOptBatch, which writes masked positions (mod.rs:1163-1232) -- see kFlagMasked.
-  BR_DEV uint8_t copy_value(uint32_t q, uint32_t first, uint32_t copy_end, uint32_t store_end) const {
+  // (masked_from = Lz77Params::masked_from, handed in at the call so that it does not occupy a register through the parse loop)
+  BR_DEV uint8_t copy_value(uint32_t q, uint32_t first, uint32_t copy_end, uint32_t store_end, uint32_t masked_from) const {
+#if BR_MODEL_MASKED_H5
     const uint32_t last = copy_end < store_end ? copy_end : store_end;
     if (q >= last) return unstored(q);
     if (q >= masked_from && last >= first + 8 && q < first + ((last - first) & ~3u)) return (uint8_t)(kFlagStored | kFlagMasked);
     return kFlagStored;
+#else
+    return q < store_end ? (uint8_t)1 : unstored(q);  // (q < copy_end at every call)
+#endif
   }
   // the StoreRange part [first, copy_end) of a copy
-  BR_DEV void copy_range(uint32_t first, uint32_t copy_end, uint32_t store_end) {
+  BR_DEV void copy_range(uint32_t first, uint32_t copy_end, uint32_t store_end, uint32_t masked_from) {
     if (!enabled) return;
     const uint32_t b = copy_end > hi ? hi : copy_end;
-    for (uint32_t q = first + BR_LANE; q < b; q += BR_NLANES) put(q, copy_value(q, first, copy_end, store_end));
+    for (uint32_t q = first + BR_LANE; q < b; q += BR_NLANES) put(q, copy_value(q, first, copy_end, store_end, masked_from));
   }
   // the part [a, b) of the step described by (kind, base, p1) -- see HeadKind; for a copy b is where it ends
   template <bool kH9>
-  BR_DEV void head(uint32_t kind, uint32_t base, uint32_t p1, uint32_t a, uint32_t b, uint32_t store_end) {
+  BR_DEV void head(uint32_t kind, uint32_t base, uint32_t p1, uint32_t a, uint32_t b, uint32_t store_end, uint32_t masked_from) {
     if (!enabled || kind == kHeadNone) return;
     const uint32_t step_end = b;
     if (b > hi) b = hi;
@@ -1181,7 +1186,7 @@ struct FlagWriter {
         // (the H9 ring-end case, see SearchResult::stored)
         if (q <= base) v = (kH9 && base - q < 8 && ((p1 >> (8 + base - q)) & 1u)) ? kFlagSearched : (uint8_t)(kFlagStored | kFlagSearched);
         else if (q == base + 1) v = (p1 & 1u) ? ((kH9 && (p1 & 4u)) ? kFlagSearched : (uint8_t)(kFlagStored | kFlagSearched)) : unstored(q);
-        else v = copy_value(q, base + 2, step_end, store_end);
+        else v = copy_value(q, base + 2, step_end, store_end, masked_from);
       } else if (kind == kHeadUnstored) {
         v = unstored(q);
       } else if (kind == kHeadVec4) {
@@ -1232,7 +1237,6 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   uint32_t tail_kind = kHeadNone, tail_base = 0, tail_p1 = 0;
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg.flags & kSegTailStitched) ? 1 : 0;
-  fw.masked_from = !kH9 ? P.masked_from : kNeverMasked;
   uint32_t n_cmds = 0, n_lits = 0, n_searches = 0, ext_len = 0, n_pushes = 0, n_bad = 0;
   uint32_t last_dist_code = 0xffffffffu, last_copy_len = 0;
   uint32_t cache_version = 0;
@@ -1286,7 +1290,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     tail_kind = BR_UNIFORM(entry.head_kind);
     tail_base = BR_UNIFORM(entry.head_base);
     tail_p1 = BR_UNIFORM(entry.head_p1);
-    if (position > seg.start) fw.template head<kH9>(tail_kind, tail_base, tail_p1, seg.start, position, store_end);
+    if (position > seg.start) fw.template head<kH9>(tail_kind, tail_base, tail_p1, seg.start, position, store_end, kH9 ? kNeverMasked : P.masked_from);
   }
 
   while (position + htl < pos_end && position < seg.end) {
@@ -1340,7 +1344,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
       fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);
       if (sr.len > 1)
         fw.one(position + 1, next_probed ? ((!kH9 || next_stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched) : fw.unstored(position + 1));
-      if (sr.len > 2) fw.copy_range(position + 2, position + sr.len, store_end);
+      if (sr.len > 2) fw.copy_range(position + 2, position + sr.len, store_end, kH9 ? kNeverMasked : P.masked_from);
       position += sr.len;
     } else {
       fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);

@@ -121,6 +121,8 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   // switch is off by default.  (The rank structures of qualities 6..8 take them on the emulation build only so far.)
   P_.masked_from = kNeverMasked;
   if (getenv("BROTLI_MI355X_MASKED_H5") != nullptr && P_.hasher_kind == 5) {
+    if (!BR_MODEL_MASKED_H5)
+      throw std::runtime_error("brotli_mi355x: BROTLI_MI355X_MASKED_H5 needs a library built with -DBR_MODEL_MASKED_H5=1 (make variant NAME=masked EXTRA=-DBR_MODEL_MASKED_H5=1)");
     const uint64_t ring = (uint64_t)P_.ring_mask + 1;
     const uint64_t base = (carry_ && carry_->valid) ? carry_->stream_base : 0;  // stream position of text position 0
     if (base >= ring) P_.masked_from = 0;

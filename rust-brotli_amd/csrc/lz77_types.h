@@ -57,6 +57,13 @@ struct Lz77Params {
   uint32_t masked_from;
 };
 static constexpr uint32_t kNeverMasked = 0xffffffffu;
+// The chains write kFlagMasked only in builds that ask for it (-DBR_MODEL_MASKED_H5=1: the emulation build, and `make variant
+// NAME=masked EXTRA=-DBR_MODEL_MASKED_H5=1`): the default gfx950 library keeps the parse kernel's code exactly as it was
+// measured in round 2 until the model has run on hardware; Lz77Stage refuses BROTLI_MI355X_MASKED_H5 on a library built
+// without it.
+#if !defined(BR_MODEL_MASKED_H5)
+#define BR_MODEL_MASKED_H5 0
+#endif
 
 // candidate rows (lz77_chain.h): entries per position, end-of-row marker
 static constexpr uint32_t kRowEntries = 16;
