@@ -110,6 +110,16 @@ def test_frozen_hashes():
     assert got == frozen
 
 
+@pytest.mark.parametrize("q", list(range(12)))
+def test_every_quality_round_trips_on_mixed_content(q):
+    """the oracle covers every quality of the reference encoder: 0 / 1 (fragment compressors), 2-4 (BasicHasher), 5-9
+    (H5 / H6 / H9, greedy meta-blocks), 10 / 11 (H10 + Zopfli, block splitter + clustering)"""
+    data = synth.mixed(768 << 10, 11) + synth.silesia_like(256 << 10, 12, 8 << 10, 64 << 10)
+    for w in (16, 22):
+        out = orc.stream_compress(data, [(Q, q), (W, w)])[0]
+        assert orc.decompress(out, len(data)) == data, (q, w)
+
+
 def test_h5_store_range_masks_positions():
     """AdvHasher::StoreRangeOptBatch (mod.rs:1163-1232, the H5 family: StoreLookahead 4) files the positions a copy covers
     four at a time -- and writes the MASKED position into the bucket.  Once the input is longer than the ring buffer
