@@ -114,6 +114,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.key_last = (uint32_t*)dev_alloc((65536 + 1) * 4);
   B_.changed_count = (uint32_t*)dev_alloc(64);
   // Ring depth 16 (quality 5): position-indexed candidate rows (lz77_chain.h); deeper rings keep the rank structures.
+  substitute_inherited_pushes_ = getenv("BROTLI_MI355X_PUSH_SUBSTITUTION") != nullptr;
   use_rows_ = P_.hasher_kind != 9 && (1u << P_.block_bits) <= kRowEntries && getenv("BROTLI_MI355X_NO_ROWS") == nullptr;
   // Masked H5 ring entries (Lz77Params::masked_from; DESIGN.md section 6 "Known divergence").  Staged: the chain code, the
   // row lookback (br_collect_row) and this driver model them and the emulation build proves the result against the oracle
@@ -550,6 +551,27 @@ bool Lz77Stage::Resolve(bool final_pass) {
       // merely pass the cache along in one round instead of one segment per round.
       int32_t out_cache[4];
       for (uint32_t i = 0; i < 4; ++i) out_cache[i] = i < X.n_pushes ? X.cache[i] : cur_cache[i - X.n_pushes];
+      // The pushes themselves can be inherited too: a copy found through the last-distance codes 1..3 pushes a value it
+      // took FROM the cache (mod.rs:1751-1794, command.rs:48-68), and text that repeats an earlier passage at distance A
+      // keeps A alive that way through hundreds of commands.  Experiment (BROTLI_MI355X_PUSH_SUBSTITUTION=1, off by
+      // default): when the entry cache of this pass holds A where the chain had A', guess that an A' among the chain's
+      // pushes follows.  By value alone an inherited A' cannot be told from one the hash search found afresh, and the
+      // guess is wrong for the latter: measured on the emulation build it takes a round off synth.mixed and adds two to
+      // finely mixed Silesia-like input.  What is needed is the provenance from the chain itself (a note per cache slot of
+      // the exit: inherited from entry slot s / fresh); until then the moving front is followed by a chain instead
+      // ("cache front" in RunRounds).  Once the entries agree nothing is substituted, so the fixed point is untouched.
+      if (substitute_inherited_pushes_ && X.n_pushes != 0 && memcmp(used.cache, cur_cache, sizeof(cur_cache)) != 0) {
+        for (uint32_t i = 0; i < 4 && i < X.n_pushes; ++i) {
+          int hit = -1;
+          bool ambiguous = false;
+          for (int c = 0; c < 4; ++c) {
+            if (used.cache[c] != out_cache[i]) continue;
+            if (hit < 0) hit = c;
+            else if (cur_cache[c] != cur_cache[hit]) ambiguous = true;
+          }
+          if (hit >= 0 && !ambiguous) out_cache[i] = cur_cache[hit];
+        }
+      }
       if (j == k0 && X.ext_len > 0 && last_cmd.valid) {
         if (!patches_.empty() && patches_.back().segment == last_cmd.seg && patches_.back().index == last_cmd.idx) {
           patches_.back().ext += X.ext_len;
@@ -1077,6 +1099,10 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
   std::vector<uint32_t> changed_all(kChangedCap);
   std::vector<uint8_t> entry_streak(nseg, 0), was_dirty, cand_dirty, pending(nseg, 0), sched(nseg, 0);
+  // cache_wave[k]: segment k was parsed in the last launch from an entry that differed from its previous one in the
+  // distance cache alone (by a chain of its own, or by a chain that walked into it) -- see "cache front" below
+  std::vector<uint8_t> cache_wave(nseg, 0), cache_wave_next(nseg, 0);
+  const bool follow_cache_fronts = getenv("BROTLI_MI355X_NO_CACHE_FRONTS") == nullptr;
   for (uint32_t k = 0; k < nseg; ++k) list[k] = k;
   uint32_t count = nseg;
   // (every round fixes at least the first segment that was still wrong, so nseg rounds always suffice; the override
@@ -1173,6 +1199,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         pending[k] = 0;
         exits_[k] = cont_exits[i];
         entries_[k] = cont_entries[i];
+        cache_wave[k] = 1;
         stats_.segments_parsed++;
       }
     }
@@ -1270,22 +1297,61 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     // segment whose entry was wrong twice in a row, and whose predecessor is being redone as well, is left to that
     // predecessor's chain, which continues into it with its real exit state (br_parse_chain).
     for (uint32_t k = 0; k < nseg; ++k) entry_streak[k] = dirty_entry_[k] ? (uint8_t)std::min<uint32_t>(entry_streak[k] + 1u, 255u) : (uint8_t)0;
-    if (getenv("BROTLI_MI355X_DEBUG_MAP")) {
+    if (const char* first = getenv("BROTLI_MI355X_DEBUG_MAP")) {  // value = first segment of the window shown (default 16)
+      const uint32_t a = std::max<uint32_t>((uint32_t)atoi(first), 0u) ? (uint32_t)atoi(first) : 16u;
       std::string m;
-      for (uint32_t k = 16; k < 48 && k < nseg; ++k) m += dirty_entry_[k] ? (pending[k] ? 'P' : 'E') : (dirty[k] ? 'c' : '.');
-      fprintf(stderr, "  map[16..48) %s\n", m.c_str());
-      for (uint32_t k = 16; k < 24 && k < nseg; ++k)
-        fprintf(stderr, "    seg %u used pos %u apply %u head %u/%u | chained pos %u apply %u head %u/%u | exit pos %u\n", k, entries_[k].pos, entries_[k].apply,
-                entries_[k].head_kind, entries_[k].head_base, next_entries_[k].pos, next_entries_[k].apply, next_entries_[k].head_kind,
-                next_entries_[k].head_base, exits_[k].pos);
+      for (uint32_t k = a; k < a + 32 && k < nseg; ++k) m += dirty_entry_[k] ? (pending[k] ? 'P' : 'E') : (dirty[k] ? 'c' : '.');
+      fprintf(stderr, "  map[%u..%u) %s\n", a, a + 32, m.c_str());
+      for (uint32_t k = a; k < a + 12 && k < nseg; ++k)
+        fprintf(stderr, "    seg %u [%u,%u) used pos %u apply %u head %u/%u cache %d %d %d %d | chained pos %u apply %u head %u/%u cache %d %d %d %d | exit pos %u cmds %u searches %u\n",
+                k, segments_[k].start, segments_[k].end, entries_[k].pos, entries_[k].apply, entries_[k].head_kind, entries_[k].head_base,
+                entries_[k].cache[0], entries_[k].cache[1], entries_[k].cache[2], entries_[k].cache[3], next_entries_[k].pos,
+                next_entries_[k].apply, next_entries_[k].head_kind, next_entries_[k].head_base, next_entries_[k].cache[0],
+                next_entries_[k].cache[1], next_entries_[k].cache[2], next_entries_[k].cache[3], exits_[k].pos, exits_[k].n_cmds,
+                exits_[k].n_searches);
+    }
+    if (const char* path = getenv("BROTLI_MI355X_DEBUG_DIRTY")) {  // one line per round: why each segment is dirty
+      if (FILE* f = fopen(path, "a")) {
+        std::string m(nseg, '.');
+        for (uint32_t k = 0; k < nseg; ++k) {
+          const bool c = !cand_dirty.empty() && cand_dirty[k];
+          m[k] = dirty_entry_[k] ? (c ? 'B' : (pending[k] ? 'P' : 'E')) : (c ? 'c' : (dirty[k] ? 'p' : '.'));
+        }
+        // (second half of the line: bit 1 = the distance cache at the entry differed, bit 0 = anything else)
+        std::string why(nseg, '0');
+        for (uint32_t k = 0; k < nseg; ++k) why[k] = (char)('0' + (entry_reason_[k] & 3));
+        fprintf(f, "%s %s\n", m.c_str(), why.c_str());
+        fclose(f);
+      }
     }
     was_dirty = dirty;
     const bool aggressive = false;
     count = 0;
+    // Cache front: text that repeats an earlier passage keeps that passage's distance alive in the cache through the
+    // last-distance codes, for hundreds of commands and across any number of segments.  When the cache guessed at the head
+    // of such a stretch was wrong (another occurrence of the passage), every segment hands the stale distance to the next:
+    // segment k is re-parsed with the right cache in round r, k + 1 learns of it in round r + 1, and so on -- one segment
+    // per round, while the segments ahead are re-parsed round after round with the stale cache because their candidates
+    // keep changing (synth.mixed, 16 MiB at quality 5: 50 rounds).  Where the front is seen moving -- k differs in the cache
+    // alone now, k - 1 did one round ago -- the segments behind k that are only owed a re-parse are left to k's chain, which
+    // walks on with the real cache for as long as it arrives with another state than they were parsed with (br_parse_chain).
+    bool front_run = false;
+    cache_wave_next.assign(nseg, 0);
     for (uint32_t k = 0; k < nseg; ++k) {
       sched[k] = 0;
-      if (!dirty[k]) continue;
+      if (segments_[k].flags & kSegFirstInBlock) front_run = false;
+      if (!dirty[k]) {
+        front_run = false;
+        continue;
+      }
       const bool must_redo = pending[k] || (!cand_dirty.empty() && cand_dirty[k]);  // its candidates changed
+      if (front_run && !dirty_entry_[k]) {
+        sched[k] = 2;
+        pending[k] = 1;
+        dirty[k] = 0;
+        continue;
+      }
+      front_run = false;
       // (an entry predicted through a literal spree is as good as it gets: such a segment always gets its own chain)
       // (nor is a segment without copies whose entry differs in the distance cache alone left to its predecessor: a
       // chain that arrives there and sees the old parse come out again stops walking -- "passes the cache along",
@@ -1306,7 +1372,11 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       sched[k] = 1;
       list[count++] = k;
       entries_[k] = next_entries_[k];
+      const bool cache_only = dirty_entry_[k] && entry_reason_[k] == 2;
+      cache_wave_next[k] = cache_only;
+      front_run = follow_cache_fronts && cache_only && k > 0 && !(segments_[k].flags & kSegFirstInBlock) && cache_wave[k - 1];
     }
+    cache_wave.swap(cache_wave_next);
     if (regime_flip) {
       last_death_seg = dict_death_seg_;
       if (warmup_bytes_ > 0 && dict_death_seg_ + 2 < nseg) {

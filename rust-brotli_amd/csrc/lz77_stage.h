@@ -207,6 +207,7 @@ class Lz77Stage {
   uint32_t first_dirty_ = 0;
   std::vector<uint8_t> predicted_entry_;  // the entry chained for segment k comes out of a predicted literal run
   std::vector<uint8_t> entry_reason_;  // why dirty_entry_[k] is set, see Resolve()
+  bool substitute_inherited_pushes_ = false;  // Resolve(): pushed distances that came out of the entry cache follow it
   uint32_t RecheckCacheOnly(int which, std::vector<uint32_t>* accepted = nullptr);
   double host_resolve_ms_ = 0, host_schedule_ms_ = 0;  // BROTLI_MI355X_PROFILE
   uint32_t predicted_runs_ = 0;  // segments whose exit the last Resolve() predicted (literal spree arithmetic)
