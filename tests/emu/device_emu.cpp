@@ -373,6 +373,12 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
     for (uint32_t c = 0; c < n; ++c) B.fbits[B.changed_slot[c]] &= (uint8_t)(kSlotStored | kSlotMasked);
 }
 
+// (the device launcher reads the same variable, lz77_kernels.hip)
+static uint32_t emu_continuation() {
+  static const uint32_t tuned = getenv("BROTLI_MI355X_CONT") ? (uint32_t)atoi(getenv("BROTLI_MI355X_CONT")) : kMaxContinuation;
+  return tuned;
+}
+
 static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments, SegEntry* entries,
                       SegExit* exits, uint32_t first_segment, const uint32_t* list, uint8_t* sched, uint32_t count) {
   const DeviceTables& dt = dev_tables();
@@ -398,11 +404,11 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
     if (P.hasher_kind == 9) {
-      br_parse_chain<true, false>(P, T, scratch9, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+      br_parse_chain<true, false>(P, T, scratch9, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     } else if (B.rows) {
-      br_parse_chain<false, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+      br_parse_chain<false, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     } else {
-      br_parse_chain<false, false>(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : kMaxContinuation);
+      br_parse_chain<false, false>(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     }
   }
 }
