@@ -1255,6 +1255,17 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       lz77_recheck_searches(P_, B_, rbuf, geo, dirty_dev);
     }
     tm.stop(&stats_.ms_rank);
+    if (const char* path = getenv("BROTLI_MI355X_DEBUG_FRONT")) {  // what the launch made of the segments at the frontier
+      if (FILE* f = fopen(path, "a")) {
+        uint32_t front = 0;  // first segment that was owed a re-parse when this launch was scheduled: all before it are final
+        while (!was_dirty.empty() && front < nseg && !was_dirty[front]) ++front;
+        fprintf(f, "R %u %u", round, front);
+        for (uint32_t k = front; k < nseg && k < front + 24; ++k)
+          fprintf(f, " %u:%u:%u:%u", k, exits_[k].pos, exits_[k].n_cmds, round == 0 ? 1u : (uint32_t)sched[k]);
+        fprintf(f, "\n");
+        fclose(f);
+      }
+    }
     const auto host_t0 = std::chrono::steady_clock::now();
     Resolve(false);
     const auto host_t1 = std::chrono::steady_clock::now();
@@ -1388,6 +1399,14 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     host_schedule_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
     stamp("scheduled");
     if (count == 0) {
+      if (const char* path = getenv("BROTLI_MI355X_DEBUG_FRONT")) {
+        if (FILE* f = fopen(path, "a")) {
+          fprintf(f, "FINAL");
+          for (uint32_t k = 0; k < nseg; ++k) fprintf(f, " %u:%u", exits_[k].pos, exits_[k].n_cmds);
+          fprintf(f, "\n");
+          fclose(f);
+        }
+      }
       done = true;
       break;
     }
