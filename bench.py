@@ -212,8 +212,8 @@ def config4(torch, dist, bm, lib, enc, rank, world, frozen, steps):
     if dist:
         dist.barrier()
     elapsed = time.time() - t0
-    if comp is not None:
-        comp = bytes(comp)  # (a view of the encoder's output buffer until here: the next encode overwrites it)
+    if out is not None:
+        out = bytes(out)  # (a view of the encoder's output buffer until here: the next encode overwrites it)
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -341,7 +341,10 @@ def main():
 
     c4 = None
     if not args.no_extras and (world > 1 or args.config4):
-        c4 = config4(torch, dist, bm, lib, enc, rank, world, frozen, 1)
+        try:
+            c4 = config4(torch, dist, bm, lib, enc, rank, world, frozen, 1)
+        except Exception as e:  # the headline must not die with an extra (every rank takes the same path: no collective is left hanging)
+            c4 = {"error": repr(e)} if rank == 0 else None
     if rank != 0:
         if dist:
             dist.destroy_process_group()
