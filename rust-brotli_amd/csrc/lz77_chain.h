@@ -46,6 +46,8 @@
 #define BR_READLANE(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))
 #endif
 
+#include "lz77_live.h"
+
 namespace brotli_mi355x {
 
 static constexpr int kMaxCandidatesH9 = 16 + 256;  // ndist <= 16, ring depth <= 256 (H9, quality 9)
@@ -56,7 +58,7 @@ static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 // Lz77Params::masked_from): a stored entry like any other for the ring counters, but the bucket walk of every later search
 // ends when it reaches it.  Only ever set together with kFlagStored.
 static constexpr uint8_t kFlagMasked = 4;
-// (written by the chains only in builds with BR_MODEL_MASKED_H5, lz77_types.h)
+// (written by live chains only, lz77_live.h: where masked entries exist the parse runs on private copies of the rings)
 // how the rank structures (sorted[], qualities 6..8) hold such an entry: position | kMaskedEntry.  `cur - q <= max_backward`
 // fails for it in br_probe_pair, which is where the reference's walk breaks too.
 static constexpr uint32_t kMaskedEntry = 0x80000000u;
@@ -93,6 +95,11 @@ struct ChainTables {
   // validation after a flag change repeat single searches (lz77_recheck_searches) instead of re-parsing every segment
   // whose candidate lists were touched.
   uint32_t* search_log = nullptr;
+  // live chains (lz77_live.h): table k belongs to the chain of segment k
+  const uint16_t* keys = nullptr;     // hash key of every position
+  uint16_t* live_num = nullptr;       // [tables][1 << bucket_bits]
+  uint32_t* live_buckets = nullptr;   // [tables][(1 << bucket_bits) << block_bits]
+  uint8_t* live_consulted = nullptr;  // [tables][2 << bucket_bits]: entries looked at | ring counter mattered
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -373,6 +380,11 @@ struct ProbeMeta {
   uint32_t r_prev, r_len;
   uint32_t no_dict;   // the static dictionary is known to be switched off for good: no probes, no bookkeeping
   uint32_t log_on = 0;  // write ChainTables::search_log
+  // live chains: key and ring counter of the two probed positions as the probe found them (the position is filed when its
+  // search is folded, br_search), what to note in LiveRing::consulted when that happens (bit 0: the walk went beyond the
+  // chain's own entries, bit 1: it ran out of entries, i.e. the ring counter mattered), and a window of 64 hash keys
+  uint32_t live_key[2], live_n[2], live_mark[2];
+  uint32_t kwin_base, kwin;
 #if defined(BR_CHAIN_PROFILE)
   unsigned long long t_probe, t_fold, n_probe, n_fold, t_setup, t_refill, n_refill;
 #endif
@@ -514,11 +526,94 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
 }
 #endif
 
-template <bool kH9, bool kRows>
-BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, uint32_t p0,
-                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
+
 #if !defined(BROTLI_HOST_EMU)
-  if constexpr (kRows) {
+// Live chains, ring depth <= 16: the lane layout of br_probe_pair_rows, the ring entries read from the chain's own table
+// (lz77_live.h).  Two memory round trips per probe: ring counters + bucket rows of both positions, then the candidate
+// text.  The hash keys come from a window of 64 keys held one per lane.  Position p0 is filed when its search is folded
+// (br_search), i.e. before p0 + 1 is searched: when both have the same key, the second half of the wave sees p0 as its
+// newest entry.
+template <bool kH9>
+BR_DEV void br_probe_pair_live16(const Lz77Params& P, const ChainTables& t, const LiveRing& lr, ProbeMeta& m, uint32_t p0, const int32_t* cache,
+                                 uint32_t cache_version, uint32_t pos_end) {
+  const uint32_t ndist = P.ndist;
+  const bool use_dict = P.use_dictionary && !m.no_dict;
+  const uint32_t lane = (uint32_t)BR_LANE;
+  if (p0 < m.kwin_base || p0 + 1 >= m.kwin_base + 64u) {
+    m.kwin_base = p0;
+    m.kwin = (uint32_t)lr.keys[min(p0 + lane, P.total_bytes)];  // (the key array is padded)
+  }
+  const uint32_t k0 = BR_READLANE(m.kwin, p0 - m.kwin_base);
+  // (a position without a key -- fewer than 4 bytes in front of the end of the text -- is never searched)
+  const bool second = p0 + 1 + P.htl <= P.total_bytes;
+  const uint32_t k1 = second ? BR_READLANE(m.kwin, p0 + 1 - m.kwin_base) : k0;
+  const bool same = second && k1 == k0;
+  const uint32_t w = lane >> 5, c = lane & 31u;
+  const uint32_t key = w ? k1 : k0;
+  const uint32_t depth = 1u << lr.bits;
+  const uint32_t raw_n = (uint32_t)BR_LIVE_LD16(lr.num + key);
+  const uint32_t n0 = BR_READLANE(raw_n, 0), n1 = (BR_READLANE(raw_n, 32) + (same ? 1u : 0u)) & 0xffffu;
+  const uint32_t n = w ? n1 : n0;
+  const uint32_t visible = !(w && !second) ? (n < depth ? n : depth) : 0u;
+  const uint32_t cur = p0 + w;
+  const uint32_t max_length = pos_end - cur;
+  const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+  const uint8_t* cur_data = t.text + cur;
+  const bool is_cache = c < ndist;
+  const uint32_t i = c - ndist;  // ring entry number, newest first
+  const bool is_ring = !is_cache && i < visible;
+  uint32_t e = kLiveBreak;
+  if (is_ring) e = (w && same && i == 0) ? p0 : BR_LIVE_LD32(lr.buckets + (((size_t)key << lr.bits) | ((n - 1u - i) & (depth - 1u))));
+  // the bucket walk ends with the first entry that is masked or out of reach (mod.rs:1763-1775)
+  const bool brk = is_ring && (e >= kLiveBreak || cur - e > max_backward);
+  const unsigned long long brk_mask = __ballot(brk);
+  const uint32_t brk_half = (uint32_t)(brk_mask >> (32u * w));
+  const uint32_t first_brk = brk_half ? (uint32_t)__ffs((int)brk_half) - 1u : 32u;  // lane number within the half
+  const bool examined = is_ring && c <= first_brk;
+  const unsigned long long beyond_own = __ballot(examined && (e < lr.own_from || e == kLiveBreak));
+  // (fewer entries than the ring is deep and no break: the walk ran out of entries, so the counter itself mattered)
+  m.live_mark[0] = (((uint32_t)beyond_own != 0u) ? 1u : 0u) | ((n0 < depth && (uint32_t)brk_mask == 0u) ? 3u : 0u);
+  m.live_mark[1] = (((uint32_t)(beyond_own >> 32) != 0u) ? 1u : 0u) | ((n1 < depth && (uint32_t)(brk_mask >> 32) == 0u) ? 3u : 0u);
+  m.live_key[0] = k0;
+  m.live_key[1] = k1;
+  m.live_n[0] = n0;
+  m.live_n[1] = n1;
+  m.pos = p0;
+  m.version = cache_version;
+  m.nbucket[0] = m.nbucket[1] = kRowEntries;
+  const bool is_dict = use_dict && c >= ndist + kRowDictLane && c < ndist + kRowDictLane + 2;
+  uint32_t prev = 0xffffffffu, limit = max_length;
+  const uint8_t* src = nullptr;
+  if (is_cache) {
+    const int64_t b = (int64_t)cache[c];
+    if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
+  } else if (is_ring) {
+    if (c < first_brk) prev = e;
+  } else if (is_dict) {
+    const uint32_t item = t.dict_hash[(((br_load32(cur_data) * 0x1e35a7bdu) >> (32 - 14)) << 1) + (c - ndist - kRowDictLane)];
+    prev = item;
+    if (item != 0) {
+      const uint32_t wlen = item & 0x1f;
+      if (wlen <= max_length) {
+        src = t.dict_data + t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
+        limit = wlen;
+      }
+    }
+  }
+  if (!is_dict && prev != 0xffffffffu) src = t.text + prev;
+  m.r_len = src ? br_match_len_wide(src, cur_data, limit, is_dict ? nullptr : t.run_end, prev, cur) : 0u;
+  m.r_prev = prev;
+}
+#endif
+
+template <bool kH9, bool kRows, bool kLive = false>
+BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, uint32_t p0,
+                          const int32_t* cache, uint32_t cache_version, uint32_t pos_end, const LiveRing* live = nullptr) {
+#if !defined(BROTLI_HOST_EMU)
+  if constexpr (kRows && kLive) {
+    br_probe_pair_live16<kH9>(P, t, *live, m, p0, cache, cache_version, pos_end);
+    return;
+  } else if constexpr (kRows) {
     br_probe_pair_rows<kH9>(P, t, s, m, p0, cache, cache_version, pos_end);
     return;
   }
@@ -530,7 +625,43 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
 #if defined(BR_CHAIN_PROFILE)
   const unsigned long long tp0 = BR_TICK();
 #endif
-  if (kRows) {
+  // live chains: ring entry i (newest first) of probe slot w, see br_probe_pair_live16
+  bool live_same = false;
+  auto live_entry = [&](uint32_t w, uint32_t i) -> uint32_t {
+    if (w && live_same && i == 0) return p0;
+    return BR_LIVE_LD32(live->buckets + (((size_t)m.live_key[w] << live->bits) | ((m.live_n[w] - 1u - i) & (block_size - 1u))));
+  };
+  if constexpr (kLive) {
+    const bool second = p0 + 1 + P.htl <= P.total_bytes;
+    const uint32_t k0 = BR_UNIFORM(live->keys[p0]);
+    const uint32_t k1 = second ? BR_UNIFORM(live->keys[p0 + 1]) : k0;
+    live_same = second && k1 == k0;
+    const uint32_t n0 = BR_UNIFORM(BR_LIVE_LD16(live->num + k0));
+    const uint32_t n1 = second ? ((live_same ? n0 + 1u : BR_UNIFORM(BR_LIVE_LD16(live->num + k1))) & 0xffffu) : 0u;
+    m.live_key[0] = k0;
+    m.live_key[1] = k1;
+    m.live_n[0] = n0;
+    m.live_n[1] = n1;
+    m.g[0] = m.g[1] = 0;
+    m.nbucket[0] = n0 < block_size ? n0 : block_size;
+    m.nbucket[1] = n1 < block_size ? n1 : block_size;
+    m.live_mark[0] = m.live_mark[1] = 0;
+#if defined(BROTLI_HOST_EMU)
+    // what to note in LiveRing::consulted when the search is folded: did the walk go beyond the chain's own entries, did
+    // it run out of entries (then the ring counter itself mattered)
+    for (uint32_t w = 0; w < 2; ++w) {
+      const uint32_t cur = p0 + w;
+      const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+      bool broke = false, beyond = false;
+      for (uint32_t i = 0; i < m.nbucket[w] && !broke; ++i) {
+        const uint32_t q = live_entry(w, i);
+        beyond = beyond || q < live->own_from || q == kLiveBreak;
+        broke = q >= kLiveBreak || cur - q > max_backward;
+      }
+      m.live_mark[w] = (beyond ? 1u : 0u) | ((m.live_n[w] < block_size && !broke) ? 3u : 0u);
+    }
+#endif
+  } else if (kRows) {
 #if defined(BROTLI_HOST_EMU)
     for (int w = 0; w < 2; ++w) {
       uint32_t nb = 0;
@@ -614,11 +745,40 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
         const uint32_t w = slot < n[0] ? 0u : 1u;
         const uint32_t c = slot - (w ? n[0] : 0u);
         if (c >= ndist && c < ndist + m.nbucket[w]) {
-          const uint32_t at = m.g[w] - 1 - (c - ndist);
-          ring_q[k] = t.sorted[at];
-          ring_tag[k] = t.sorted_tag != nullptr ? (uint32_t)t.sorted_tag[at] : tag_of[w];
+          if constexpr (kLive) {
+            ring_q[k] = live_entry(w, c - ndist);
+            ring_tag[k] = tag_of[w];
+          } else {
+            const uint32_t at = m.g[w] - 1 - (c - ndist);
+            ring_q[k] = t.sorted[at];
+            ring_tag[k] = t.sorted_tag != nullptr ? (uint32_t)t.sorted_tag[at] : tag_of[w];
+          }
         }
       }
+    }
+    if constexpr (kLive) {
+      // marks for LiveRing::consulted (see the emulation twin above): slots ascend with the trips, so the first trip with a
+      // break in it holds the first break of that position
+      bool broke[2] = {false, false}, beyond[2] = {false, false};
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxTrips; ++k) {
+        const uint32_t slot = k * 64u + lane;
+        const uint32_t w = slot < n[0] ? 0u : 1u;
+        const uint32_t c = slot - (w ? n[0] : 0u);
+        const bool ring = slot < total && c >= ndist && c < ndist + m.nbucket[w];
+        const uint32_t cur = p0 + w;
+        const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+        const bool brk = ring && (ring_q[k] >= kLiveBreak || cur - ring_q[k] > max_backward);
+        const bool init = ring && (ring_q[k] < live->own_from || ring_q[k] == kLiveBreak);
+        for (uint32_t ww = 0; ww < 2; ++ww) {
+          if (broke[ww]) continue;
+          const unsigned long long bm = __ballot(brk && w == ww);
+          const unsigned long long upto = bm ? ((bm & (0ull - bm)) << 1) - 1ull : ~0ull;  // lanes up to and including the first break
+          if (__ballot(init && w == ww) & upto) beyond[ww] = true;
+          if (bm) broke[ww] = true;
+        }
+      }
+      for (uint32_t ww = 0; ww < 2; ++ww) m.live_mark[ww] = (beyond[ww] ? 1u : 0u) | ((m.live_n[ww] < block_size && !broke[ww]) ? 3u : 0u);
     }
     uint32_t listed = 0;
 #pragma unroll
@@ -636,7 +796,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
           if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
           fetch = prev != 0xffffffffu;
         } else if (c < ndist + m.nbucket[w]) {
-          if (cur - ring_q[k] <= max_backward) prev = ring_q[k];  // else: marks the point where the bucket walk breaks
+          if (cur - ring_q[k] <= max_backward && !(kLive && ring_q[k] >= kLiveBreak)) prev = ring_q[k];  // else: marks the point where the bucket walk breaks
           fetch = prev != 0xffffffffu && ring_tag[k] == tag_of[w];
         } else {
           // static dictionary probe (SearchInStaticDictionary, mod.rs:1942-1988): the item is fetched in step 3
@@ -699,7 +859,9 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     uint32_t q = 0, item = 0;
     bool other_tag = false;
     if (is_bucket) {
-      if (kRows) {
+      if (kLive) {
+        q = live_entry(w, c - ndist);
+      } else if (kRows) {
 #if defined(BROTLI_HOST_EMU)
         q = t.rows[(size_t)cur * kRowEntries + (c - ndist)];
 #else
@@ -721,7 +883,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
       const int64_t b = (int64_t)cache[c];
       if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
     } else if (is_bucket) {
-      if (cur - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
+      if (cur - q <= max_backward && !(kLive && q >= kLiveBreak)) prev = q;  // else: marks the point where the bucket walk breaks
     } else {
       prev = item;
       if (item != 0) {
@@ -1035,46 +1197,49 @@ BR_DEV bool br_same_as_logged(const uint32_t* rec, const SearchResult& r) {
 }
 
 // search(x) for the parse loop: reuses the speculative second slot when it is still valid
-template <bool kH9, bool kRows>
+template <bool kH9, bool kRows, bool kLive = false>
 BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, DictState& ds,
-                              uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end) {
+                              uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end, const LiveRing* live = nullptr) {
 #if defined(BR_CHAIN_PROFILE)
-  unsigned long long t0 = BR_TICK();
-  if (m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1) {
-    SearchResult pre;
-    SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 1, ds, blk_end, &pre);
-    if (!kRows && m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
-    m.t_fold += BR_TICK() - t0;
-    m.n_fold++;
-    return r;
-  }
-  BR_SYNC();
-  br_probe_pair<kH9, kRows>(P, t, s, m, x, cache, cache_version, blk_end);
-  unsigned long long t1 = BR_TICK();
-  m.t_probe += t1 - t0;
-  m.n_probe++;
-  SearchResult pre;
-  SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, 0, ds, blk_end, &pre);
-  if (!kRows && m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
-  m.t_fold += BR_TICK() - t1;
-  m.n_fold++;
-  return r;
-#else
+  const unsigned long long t0 = BR_TICK();
+#endif
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
-    BR_SYNC();  // every lane is done reading the previous probe
-    br_probe_pair<kH9, kRows>(P, t, s, m, x, cache, cache_version, blk_end);
+    BR_SYNC();  // every lane is done reading the previous probe (live chains: and what was filed since is in memory)
+    br_probe_pair<kH9, kRows, kLive>(P, t, s, m, x, cache, cache_version, blk_end, live);
     w = 0;
+#if defined(BR_CHAIN_PROFILE)
+    m.t_probe += BR_TICK() - t0;
+    m.n_probe++;
+#endif
   }
+#if defined(BR_CHAIN_PROFILE)
+  const unsigned long long t1 = BR_TICK();
+#endif
+  SearchResult r;
   if constexpr (!kRows) {
     SearchResult pre;
-    const SearchResult r = br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end, &pre);
-    if (m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
-    return r;
+    r = br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end, &pre);
+    if (!kLive && m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
   } else {
-    return br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end);
+    r = br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end);
   }
+  if constexpr (kLive) {
+    // FindLongestMatch files the position it has just searched (mod.rs:1794-1795) ...
+    br_live_insert(*live, m.live_key[w], m.live_n[w], x);
+    // ... and the validation needs to know which materialised rings this parse really hangs on (lz77_live.h)
+    if (live->consulted != nullptr && m.live_mark[w] != 0 && BR_LANE == 0) {
+      if (m.live_mark[w] & 1u) BR_LIVE_ST8(live->consulted + m.live_key[w], 1);
+      if (m.live_mark[w] & 2u) BR_LIVE_ST8(live->consulted + ((size_t)1 << P.bucket_bits) + m.live_key[w], 1);
+    }
+    if (m.live_n[w] == 0xffffu && live->consulted != nullptr && BR_LANE == 0)  // the ring counter wraps: how far it had got mattered
+      BR_LIVE_ST8(live->consulted + ((size_t)1 << P.bucket_bits) + m.live_key[w], 1);
+  }
+#if defined(BR_CHAIN_PROFILE)
+  m.t_fold += BR_TICK() - t1;
+  m.n_fold++;
 #endif
+  return r;
 }
 
 // adv_prepare_distance_cache, mod.rs:632-651
@@ -1154,26 +1319,29 @@ struct FlagWriter {
   }
   // What StoreRange(first, min(copy_end, store_end)) of a copy leaves at position q >= first = copy start + 2
   // (mod.rs:2516-2521): stored up to store_end; the H5 family files the first 4 * floor(n / 4) positions of a range of
-  // n >= 8 through StoreRangeOptBatch, which writes masked positions (mod.rs:1163-1232) -- see kFlagMasked.
+  // n >= 8 through StoreRangeOptBatch, which writes masked positions (mod.rs:1163-1232) -- see kFlagMasked.  kMasked: the
+  // chain models them (live chains; every other chain runs where no masked entry can exist, Lz77Params::masked_from).
   // (masked_from = Lz77Params::masked_from, handed in at the call so that it does not occupy a register through the parse loop)
+  template <bool kMasked>
   BR_DEV uint8_t copy_value(uint32_t q, uint32_t first, uint32_t copy_end, uint32_t store_end, uint32_t masked_from) const {
-#if BR_MODEL_MASKED_H5
-    const uint32_t last = copy_end < store_end ? copy_end : store_end;
-    if (q >= last) return unstored(q);
-    if (q >= masked_from && last >= first + 8 && q < first + ((last - first) & ~3u)) return (uint8_t)(kFlagStored | kFlagMasked);
-    return kFlagStored;
-#else
-    return q < store_end ? (uint8_t)1 : unstored(q);  // (q < copy_end at every call)
-#endif
+    if constexpr (kMasked) {
+      const uint32_t last = copy_end < store_end ? copy_end : store_end;
+      if (q >= last) return unstored(q);
+      if (q >= masked_from && last >= first + 8 && q < first + ((last - first) & ~3u)) return (uint8_t)(kFlagStored | kFlagMasked);
+      return kFlagStored;
+    } else {
+      return q < store_end ? (uint8_t)1 : unstored(q);  // (q < copy_end at every call)
+    }
   }
   // the StoreRange part [first, copy_end) of a copy
+  template <bool kMasked>
   BR_DEV void copy_range(uint32_t first, uint32_t copy_end, uint32_t store_end, uint32_t masked_from) {
     if (!enabled) return;
     const uint32_t b = copy_end > hi ? hi : copy_end;
-    for (uint32_t q = first + BR_LANE; q < b; q += BR_NLANES) put(q, copy_value(q, first, copy_end, store_end, masked_from));
+    for (uint32_t q = first + BR_LANE; q < b; q += BR_NLANES) put(q, copy_value<kMasked>(q, first, copy_end, store_end, masked_from));
   }
   // the part [a, b) of the step described by (kind, base, p1) -- see HeadKind; for a copy b is where it ends
-  template <bool kH9>
+  template <bool kH9, bool kMasked>
   BR_DEV void head(uint32_t kind, uint32_t base, uint32_t p1, uint32_t a, uint32_t b, uint32_t store_end, uint32_t masked_from) {
     if (!enabled || kind == kHeadNone) return;
     const uint32_t step_end = b;
@@ -1186,7 +1354,7 @@ struct FlagWriter {
         // (the H9 ring-end case, see SearchResult::stored)
         if (q <= base) v = (kH9 && base - q < 8 && ((p1 >> (8 + base - q)) & 1u)) ? kFlagSearched : (uint8_t)(kFlagStored | kFlagSearched);
         else if (q == base + 1) v = (p1 & 1u) ? ((kH9 && (p1 & 4u)) ? kFlagSearched : (uint8_t)(kFlagStored | kFlagSearched)) : unstored(q);
-        else v = copy_value(q, base + 2, step_end, store_end, masked_from);
+        else v = copy_value<kMasked>(q, base + 2, step_end, store_end, masked_from);
       } else if (kind == kHeadUnstored) {
         v = unstored(q);
       } else if (kind == kHeadVec4) {
@@ -1201,9 +1369,9 @@ struct FlagWriter {
 
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
-template <bool kH9, bool kRows>
+template <bool kH9, bool kRows, bool kLive = false>
 BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment& seg_in,
-                                 const SegEntry& entry, SegExit& exit_out, SegEntry& next) {
+                                 const SegEntry& entry, SegExit& exit_out, SegEntry& next, const LiveRing* live = nullptr) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
   Segment seg;
   seg.start = BR_UNIFORM(seg_in.start);
@@ -1246,6 +1414,8 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   probe.win_base = 0xffffff00u;
   probe.r_prev = 0xffffffffu;
   probe.r_len = 0;
+  probe.kwin_base = 0xffffff00u;
+  probe.kwin = 0;
   // Once the throttle (matches < lookups >> 7, mod.rs:1957-1960) has tripped it stays tripped: nothing is looked up any
   // more, so neither counter moves.  With exact counters at the entry the chain need not even keep the virtual books.
   probe.no_dict = (P.use_dictionary && BR_UNIFORM(entry.dict_exact) && ds.matches < (ds.lookups >> 7)) ? 1u : 0u;
@@ -1290,18 +1460,18 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     tail_kind = BR_UNIFORM(entry.head_kind);
     tail_base = BR_UNIFORM(entry.head_base);
     tail_p1 = BR_UNIFORM(entry.head_p1);
-    if (position > seg.start) fw.template head<kH9>(tail_kind, tail_base, tail_p1, seg.start, position, store_end, kH9 ? kNeverMasked : P.masked_from);
+    if (position > seg.start) fw.template head<kH9, kLive>(tail_kind, tail_base, tail_p1, seg.start, position, store_end, kH9 ? kNeverMasked : P.masked_from);
   }
 
   while (position + htl < pos_end && position < seg.end) {
-    SearchResult sr = br_search<kH9, kRows>(P, t, s, probe, ds, position, dc, cache_version, pos_end);
+    SearchResult sr = br_search<kH9, kRows, kLive>(P, t, s, probe, ds, position, dc, cache_version, pos_end, live);
     n_searches++;
     if (sr.found) {
       int delayed = 0;
       bool next_probed, next_stored = true;
       uint32_t special = 0;  // bit j: the search j positions before the match start was not inserted (H9 ring end)
       for (;;) {
-        SearchResult sr2 = br_search<kH9, kRows>(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end);
+        SearchResult sr2 = br_search<kH9, kRows, kLive>(P, t, s, probe, ds, position + 1, dc, cache_version, pos_end, live);
         n_searches++;
         next_probed = true;
         if (kH9) next_stored = sr2.stored;
@@ -1344,7 +1514,10 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
       fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);
       if (sr.len > 1)
         fw.one(position + 1, next_probed ? ((!kH9 || next_stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched) : fw.unstored(position + 1));
-      if (sr.len > 2) fw.copy_range(position + 2, position + sr.len, store_end, kH9 ? kNeverMasked : P.masked_from);
+      if (sr.len > 2) {
+        fw.template copy_range<kLive>(position + 2, position + sr.len, store_end, kH9 ? kNeverMasked : P.masked_from);
+        if constexpr (kLive) br_live_store_copy(*live, position + 2, position + sr.len < store_end ? position + sr.len : store_end, P.masked_from);
+      }
       position += sr.len;
     } else {
       fw.one(position, (!kH9 || sr.stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched);
@@ -1366,6 +1539,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
             const uint8_t v = ((q - position) & 3) == 0;
             fw.put(q, v);
           }
+          if constexpr (kLive) br_live_store(*live, position, 4, 4, 1, 0);
           insert_length += 16;
           position += 16;
         } else {
@@ -1376,6 +1550,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
             const uint8_t v = ((q - position) & 1) == 0;
             fw.put(q, v);
           }
+          if constexpr (kLive) br_live_store(*live, position, 2, 4, 1, 0);
           insert_length += 8;
           position += 8;
         }
@@ -1545,6 +1720,49 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
     }
     entry = next;
   }
+}
+
+// One live chain (lz77_live.h): parses input block k -- live chains are cut one per block -- on private copy k of the bucket
+// rings, which the launcher has materialised for text position segments[first].blk_start, first = k - min(k, warm_blocks).
+// warm_blocks > 0 (the first round, when the flags of the earlier blocks are a guess and nothing else): the chain first runs
+// dry through the warm_blocks blocks in front of its own, so that what it sees of the recent past is its own exact
+// stores rather than that guess; a parse heals from a wrong history within ~100 KB.  The entry it then uses
+// for block k (the distance cache the dry run arrived with) is written back to entries[k] for the host resolver.
+template <bool kRows>
+BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratchT<false, kRows>& s, const Segment* segments, SegEntry* entries,
+                          SegExit* exits, uint32_t k, uint32_t warm_blocks) {
+  LiveRing lr;
+  const size_t keys_per_table = (size_t)1 << P.bucket_bits;
+  lr.num = t.live_num + (size_t)k * keys_per_table;
+  lr.buckets = t.live_buckets + (((size_t)k * keys_per_table) << P.block_bits);
+  lr.keys = t.keys;
+  lr.bits = P.block_bits;
+  lr.bucket_bits = P.bucket_bits;
+  lr.consulted = nullptr;
+  lr.own_from = 0;
+  SegEntry entry = entries[k];
+  uint32_t j = k > warm_blocks ? k - warm_blocks : 0u;
+  if (j < k) {
+    SegEntry e = entries[j];
+    for (; j < k; ++j) {
+      Segment seg = segments[j];
+      seg.flags |= kSegWarmup;
+      e.pos = seg.blk_start;
+      e.ext_allowed = 0;
+      SegEntry next;
+      br_parse_segment<false, kRows, true>(P, t, s, seg, e, exits[k], next, &lr);
+      // StitchToPreviousBlock of the block that follows files the last three positions (mod.rs:210-222)
+      if (seg.flags & kSegTailStitched) br_live_store(lr, seg.blk_end - 3u, 1, 3, 1, 0);
+      e = next;
+    }
+    for (int i = 0; i < 4; ++i) entry.cache[i] = e.cache[i];
+    BR_SYNC();
+    if (BR_LANE == 0) entries[k] = entry;
+  }
+  lr.consulted = t.live_consulted != nullptr ? t.live_consulted + (size_t)k * 2 * keys_per_table : nullptr;
+  lr.own_from = BR_UNIFORM(segments[k].blk_start);
+  SegEntry next;
+  br_parse_segment<false, kRows, true>(P, t, s, segments[k], entry, exits[k], next, &lr);
 }
 
 }  // namespace brotli_mi355x

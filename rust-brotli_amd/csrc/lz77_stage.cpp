@@ -49,6 +49,15 @@ void Lz77Stage::Release() {
     dev_free(B_.row_ctl);
     dev_free(B_.big_tile);
     dev_free(B_.run_end);
+    dev_free(L_.num);
+    dev_free(L_.buckets);
+    dev_free(L_.consulted);
+    dev_free(L_.rank[0]);
+    dev_free(L_.rank[1]);
+    dev_free(L_.entry[0]);
+    dev_free(L_.entry[1]);
+    dev_free(L_.changed_key);
+    L_ = LiveBuffers{};
     dev_free(count_base_dev_);
     count_base_dev_ = nullptr;
     dev_free(B_.reset_counts);
@@ -116,19 +125,39 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   // Ring depth 16 (quality 5): position-indexed candidate rows (lz77_chain.h); deeper rings keep the rank structures.
   substitute_inherited_pushes_ = getenv("BROTLI_MI355X_PUSH_SUBSTITUTION") != nullptr;
   use_rows_ = P_.hasher_kind != 9 && (1u << P_.block_bits) <= kRowEntries && getenv("BROTLI_MI355X_NO_ROWS") == nullptr;
-  // Masked H5 ring entries (Lz77Params::masked_from; DESIGN.md section 6 "Known divergence").  Staged: the chain code, the
-  // row lookback (br_collect_row) and this driver model them and the emulation build proves the result against the oracle
-  // as it is; the gfx950 row / flag kernels do not take the third flag bit yet, so the device seam refuses it and the
-  // switch is off by default.  (The rank structures of qualities 6..8 take them on the emulation build only so far.)
+  // Masked H5 ring entries (AdvHasher::StoreRangeOptBatch, mod.rs:1163-1232): from the stream position at which they start
+  // to exist -- one ring-buffer size -- the candidates of a search hang on the exact parse in front of it, and the text is
+  // parsed by live chains, one per input block, each on a private copy of the reference's bucket rings (lz77_live.h).
+  // BROTLI_MI355X_LIVE=1 runs them on any AdvHasher input (test aid).
   P_.masked_from = kNeverMasked;
-  if (getenv("BROTLI_MI355X_MASKED_H5") != nullptr && P_.hasher_kind == 5) {
-    if (!BR_MODEL_MASKED_H5)
-      throw std::runtime_error("brotli_mi355x: BROTLI_MI355X_MASKED_H5 needs a library built with -DBR_MODEL_MASKED_H5=1 (make variant NAME=masked EXTRA=-DBR_MODEL_MASKED_H5=1)");
+  if (P_.hasher_kind == 5) {
     const uint64_t ring = (uint64_t)P_.ring_mask + 1;
     const uint64_t base = (carry_ && carry_->valid) ? carry_->stream_base : 0;  // stream position of text position 0
     if (base >= ring) P_.masked_from = 0;
     else if (base + P_.total_bytes > ring) P_.masked_from = (uint32_t)(ring - base);
   }
+  use_live_ = P_.hasher_kind != 9 && (P_.masked_from != kNeverMasked || getenv("BROTLI_MI355X_LIVE") != nullptr);
+  if (use_live_) {
+    use_rows_ = false;
+    if (segment_bytes_ != block_bytes_) {  // one chain per input block
+      segment_bytes_ = block_bytes_;
+      P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
+      BuildSegments();
+      P_.num_segments = (uint32_t)segments_.size();
+    }
+    const size_t K = (size_t)1 << P_.bucket_bits, T = segments_.size();
+    L_.tables = (uint32_t)T;
+    L_.num = (uint16_t*)dev_alloc_uninit(T * K * 2 + 64);
+    L_.buckets = (uint32_t*)dev_alloc_uninit(((T * K) << P_.block_bits) * 4 + 64);
+    L_.consulted = (uint8_t*)dev_alloc(T * K * 2 + 64);
+    for (int i = 0; i < 2; ++i) {
+      L_.rank[i] = (uint32_t*)dev_alloc_uninit((M + 1) * 4 + 64);
+      L_.entry[i] = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
+    }
+    L_.changed_key = (uint8_t*)dev_alloc(65536 + 64);
+    B_.changed_cap = kChangedCap;
+    B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
+  } else
   if (use_rows_) {
     B_.changed_cap = (uint32_t)std::max<size_t>(kChangedCap, M / 32);
     B_.changed_keys = (uint32_t*)dev_alloc_uninit((size_t)B_.changed_cap * 4 + 64);
@@ -970,7 +999,110 @@ void Lz77Stage::Resegment(uint32_t segment_bytes) {
   dev_h2d(B_.segments, segments_upload_.data(), segments_.size() * sizeof(Segment));
 }
 
+// first guess of the entries: every chain starts at its segment start with the default cache
+void Lz77Stage::InitEntries() {
+  const uint32_t nseg = (uint32_t)segments_.size();
+  entries_.assign(nseg, SegEntry{});
+  for (uint32_t k = 0; k < nseg; ++k) {
+    SegEntry& e = entries_[k];
+    e.pos = segments_[k].start;
+    e.apply = segments_[k].start + P_.spree_window;
+    const int32_t d[4] = {4, 11, 15, 16};
+    for (int i = 0; i < 4; ++i) e.cache[i] = (carry_ && carry_->valid) ? carry_->dist_cache[i] : (params_.catable ? 0x7ffffff0 : d[i]);
+    if (k != 0) {
+      e.dict_lookups = DictTracker::kAliveL;
+      e.dict_matches = DictTracker::kAliveM;
+    }
+  }
+  exits_.assign(nseg, SegExit{});
+}
+
+// The rounds of live chains (lz77_live.h): one chain per input block, each on a private copy of the bucket rings that is
+// materialised for its block start from the flags of the round before.  Round 0 has only a guess of those flags: its
+// chains start a few blocks early and run dry up to their block.  After every round the host resolver chains the exits
+// (entry states, as in RunRounds) and the device compares, for every ring a chain looked at beyond its own entries, what
+// it was materialised from with what the new flags say; a block is parsed again when either differs.  The first block
+// that is still wrong has an exact entry and exact rings, so every round settles at least one block; since a parse heals
+// from a wrong history within ~100 KB, it settles almost all of them.
+void Lz77Stage::RunLive() {
+  const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
+  const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
+  Timer tm(prof);
+  const uint32_t nseg = (uint32_t)segments_.size();
+  InitFlags();
+  InitEntries();
+  tm.stop(&stats_.ms_init);
+  uint32_t warm = 2;
+  if (const char* w = getenv("BROTLI_MI355X_LIVE_WARM")) warm = (uint32_t)atoi(w);
+  uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
+  uint32_t* start_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
+  uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
+  PinnedArray<uint32_t> list, start;
+  PinnedArray<uint8_t> dirty_tab;
+  list.resize_discard(nseg);
+  start.resize_discard(nseg);
+  dirty_tab.resize_discard(nseg);
+  std::vector<uint8_t> dirty(nseg, 1);
+  int which = 0;
+  lz77_live_index(P_, B_, L_, which);
+  const uint32_t max_rounds = getenv("BROTLI_MI355X_MAX_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_MAX_ROUNDS")) : nseg + 8;
+  bool done = false;
+  for (uint32_t round = 0; round < max_rounds && !done; ++round) {
+    stats_.rounds++;
+    const uint32_t w = round == 0 ? warm : 0u;
+    uint32_t count = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+      if (!dirty[k]) continue;
+      list[count] = k;
+      start[count] = segments_[k > w ? k - w : 0u].blk_start;
+      if (round != 0) entries_[k] = next_entries_[k];
+      ++count;
+    }
+    dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
+    dev_h2d(list_dev, list.data(), (size_t)count * 4);
+    dev_h2d(start_dev, start.data(), (size_t)count * 4);
+    lz77_live_materialise(P_, B_, L_, which, list_dev, start_dev, count);
+    dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+    tm.stop(&stats_.ms_rank);
+    lz77_live_parse(P_, B_, L_, which, list_dev, count, w);
+    stats_.segments_parsed += (uint64_t)count * (1 + w);
+    lz77_live_index(P_, B_, L_, which ^ 1);
+    dev_memset(dirty_dev, 0, nseg);
+    if (round != 0) lz77_live_validate(P_, B_, L_, which, which ^ 1, dirty_dev);
+    dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
+    if (w != 0) dev_d2h_async(entries_.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));  // (the dry runs chose the distance caches)
+    dev_d2h_async(dirty_tab.data(), dirty_dev, nseg);
+    dev_sync();
+    tm.stop(&stats_.ms_parse);
+    which ^= 1;
+    const auto host_t0 = std::chrono::steady_clock::now();
+    Resolve(false);
+    host_resolve_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    uint32_t n_entry = 0, n_rings = 0, n_dirty = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+      // (nothing of round 0 is verified: its rings came out of dry runs over guessed flags)
+      dirty[k] = (round == 0 || dirty_entry_[k] || dirty_tab[k]) ? 1 : 0;
+      n_entry += dirty_entry_[k];
+      n_rings += dirty_tab[k];
+      n_dirty += dirty[k];
+    }
+    if (debug) fprintf(stderr, "live round %u: parsed %u of %u blocks; to redo %u (entry %u, rings %u)\n", round, count, nseg, n_dirty, n_entry, n_rings);
+    tm.stop(&stats_.ms_resolve);
+    done = n_dirty == 0;
+  }
+  dev_free(list_dev);
+  dev_free(start_dev);
+  dev_free(dirty_dev);
+  if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search (live chains) did not reach a fixed point");
+  final_flags_ = which;
+  for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
+}
+
 void Lz77Stage::RunRounds(bool allow_restart) {
+  if (use_live_) {
+    RunLive();
+    return;
+  }
   const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
   Timer tm(prof);
   const uint32_t nseg = (uint32_t)segments_.size();
@@ -988,20 +1120,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       lz77_rank_flags(P_, B_, which, rbuf, &hint);
     }
   }
-  // first guess of the entries: every chain starts at its segment start with the default cache
-  entries_.assign(nseg, SegEntry{});
-  for (uint32_t k = 0; k < nseg; ++k) {
-    SegEntry& e = entries_[k];
-    e.pos = segments_[k].start;
-    e.apply = segments_[k].start + P_.spree_window;
-    const int32_t d[4] = {4, 11, 15, 16};
-    for (int i = 0; i < 4; ++i) e.cache[i] = (carry_ && carry_->valid) ? carry_->dist_cache[i] : (params_.catable ? 0x7ffffff0 : d[i]);
-    if (k != 0) {
-      e.dict_lookups = DictTracker::kAliveL;
-      e.dict_matches = DictTracker::kAliveM;
-    }
-  }
-  exits_.assign(nseg, SegExit{});
+  InitEntries();
   tm.stop(&stats_.ms_rank);
   timeline().stamp("index-queued");
   if (selftest) {

@@ -130,6 +130,8 @@ class Lz77Stage {
   void BuildSegments();
   void Resegment(uint32_t segment_bytes);
   void RunRounds(bool allow_restart);
+  void RunLive();
+  void InitEntries();
   void InitFlags();
   bool Resolve(bool final_pass);
   void Gather();
@@ -143,6 +145,8 @@ class Lz77Stage {
   EncoderParams params_;
   Lz77Params P_{};
   Lz77Buffers B_{};
+  LiveBuffers L_{};    // live chains (lz77_live.h)
+  bool use_live_ = false;
   uint32_t input_bytes_ = 0;
   uint32_t raw_head_bytes_ = 0;
   uint32_t segment_bytes_ = 4096;

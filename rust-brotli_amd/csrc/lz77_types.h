@@ -52,19 +52,11 @@ struct Lz77Params {
   uint32_t reset_pos, reset_vis;
   // First position from which the entries that the reference's StoreRangeOptBatch writes into an H5 bucket ring are MASKED
   // positions (mod.rs:1163-1232: the stream position has passed the ring-buffer size); such an entry ends the bucket walk
-  // of every later search (kFlagMasked, lz77_chain.h).  kNeverMasked: not an H5 hasher, input shorter than the ring, or
-  // the modelling is switched off ("Known divergence").
+  // of every later search (kFlagMasked, lz77_chain.h).  kNeverMasked: not an H5 hasher, or the text ends inside the first
+  // ring-buffer revolution of the stream.  Anything else is parsed by live chains (lz77_live.h).
   uint32_t masked_from;
 };
 static constexpr uint32_t kNeverMasked = 0xffffffffu;
-// The chains write kFlagMasked only in builds that ask for it (-DBR_MODEL_MASKED_H5=1: the emulation build, and `make variant
-// NAME=masked EXTRA=-DBR_MODEL_MASKED_H5=1`): the default gfx950 library keeps the parse kernel's code exactly as it was
-// measured in round 2 until the model has run on hardware; Lz77Stage refuses BROTLI_MI355X_MASKED_H5 on a library built
-// without it.
-#if !defined(BR_MODEL_MASKED_H5)
-#define BR_MODEL_MASKED_H5 0
-#endif
-
 // candidate rows (lz77_chain.h): entries per position, end-of-row marker
 static constexpr uint32_t kRowEntries = 16;
 static constexpr uint32_t kRowEnd = 0xffffffffu;

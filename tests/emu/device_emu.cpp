@@ -99,6 +99,9 @@ void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_b
   if (P0 > htl - 1) memset(f, 1, P0 - (htl - 1));
   if (prefix_flags_host && prefix_flags_bytes) memcpy(f, prefix_flags_host, prefix_flags_bytes);
   if (M > first_block_start) memset(f + first_block_start, 1, M - first_block_start);
+  // (live chains: where masked entries exist most positions lie inside copies and are filed as such)
+  if (P.masked_from != kNeverMasked && M > std::max(first_block_start, P.masked_from))
+    memset(f + std::max(first_block_start, P.masked_from), kFlagStored | kFlagMasked, M - std::max(first_block_start, P.masked_from));
   for (uint32_t k = 0; k < P.num_segments; ++k) {
     const Segment& g = B.segments[k];
     if (!(g.flags & kSegFirstInBlock)) continue;
@@ -426,6 +429,84 @@ void lz77_parse_list(const Lz77Params& P, const Lz77Buffers& B, int which, int r
 void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf, const Segment* segments_dev,
                        SegEntry* entries_dev, SegExit* exits_dev, uint32_t count) {
   run_parse(P, B, which, rbuf, segments_dev, entries_dev, exits_dev, 0, nullptr, nullptr, count);
+}
+
+// ---- live chains (lz77_live.h)
+static LiveIndex emu_live_index(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which) {
+  LiveIndex ix;
+  ix.by_key = B.by_key;
+  ix.rank = L.rank[which];
+  ix.entry = L.entry[which];
+  ix.key_first = B.key_first;
+  ix.key_last = B.key_last;
+  ix.count_base = B.count_base;
+  ix.reset_pos = P.reset_pos;
+  ix.reset_vis = P.reset_vis;
+  return ix;
+}
+
+void lz77_live_index(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which) {
+  const uint32_t n = P.total_bytes;
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t pos = B.by_key[i];
+    const uint8_t f = B.flags[which][pos];
+    L.rank[which][i] = r;
+    if (f & kFlagStored) L.entry[which][r++] = (f & kFlagMasked) ? kLiveBreak : pos;
+  }
+  L.rank[which][n] = r;
+}
+
+void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* list, const uint32_t* start,
+                           uint32_t count) {
+  const LiveIndex ix = emu_live_index(P, B, L, which);
+  const size_t K = (size_t)1 << P.bucket_bits;
+  for (uint32_t i = 0; i < count; ++i) {
+    const size_t k = list[i];
+    for (uint32_t key = 0; key < K; ++key)
+      br_live_materialise_key(ix, key, start[i], P.block_bits, L.num + k * K, L.buckets + ((k * K) << P.block_bits), L.consulted + k * 2 * K, (uint32_t)K);
+  }
+}
+
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* list, uint32_t count,
+                     uint32_t warm_blocks) {
+  const DeviceTables& dt = dev_tables();
+  ChainTables T;
+  T.text = B.text;
+  T.info = nullptr;
+  T.sorted = nullptr;
+  T.rows = nullptr;
+  T.run_end = nullptr;
+  T.work = nullptr;
+  T.flags_next = B.flags[which ^ 1];
+  T.cmds = B.cmds;
+  T.dict_hash = dt.dict_hash;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.dist_postfix_bits = P.dist_postfix_bits;
+  T.num_direct_distance_codes = P.num_direct_distance_codes;
+  T.keys = B.keys;
+  T.live_num = L.num;
+  T.live_buckets = L.buckets;
+  T.live_consulted = L.consulted;
+  ChainScratchT<false, false> scratch;
+  for (uint32_t i = 0; i < count; ++i) br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, list[i], warm_blocks);
+}
+
+void lz77_live_validate(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int prev, int next, uint8_t* dirty) {
+  memset(L.changed_key, 0, 65536);
+  for (uint32_t q = 0; q < P.total_bytes; ++q)
+    if ((B.flags[prev][q] ^ B.flags[next][q]) & (kFlagStored | kFlagMasked)) L.changed_key[B.keys[q]] = 1;
+  const LiveIndex a = emu_live_index(P, B, L, prev), b = emu_live_index(P, B, L, next);
+  const size_t K = (size_t)1 << P.bucket_bits;
+  for (uint32_t k = 0; k < L.tables; ++k) {
+    const uint8_t* noted = L.consulted + (size_t)k * 2 * K;
+    for (uint32_t key = 0; key < K && !dirty[k]; ++key) {
+      if (!L.changed_key[key] || !(noted[key] | noted[K + key])) continue;
+      if (br_live_ring_differs(a, b, key, B.segments[k].blk_start, 1u << P.block_bits, noted[key] != 0, noted[K + key] != 0)) dirty[k] = 1;
+    }
+  }
 }
 
 void lz77_validate(const Lz77Params& P, const Lz77Buffers& B, int which, int rbuf_old, int rbuf_new, const SegGeometry& geo,
