@@ -207,28 +207,34 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
 void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out);
 
-// ---- live chains (lz77_live.h): one chain per input block on a private copy of the reference's bucket rings ----
+// ---- live chains (lz77_live.h): chains that parse a span of input blocks on a private copy of the reference's bucket rings ----
 struct LiveBuffers {
   uint16_t* num = nullptr;       // [tables][1 << bucket_bits]
   uint32_t* buckets = nullptr;   // [tables][(1 << bucket_bits) << block_bits]
-  uint8_t* consulted = nullptr;  // [tables][2 << bucket_bits]: ring looked at beyond the chain's own entries | ring counter mattered
-  uint32_t* rank[2] = {nullptr, nullptr};   // per flags buffer: prefix count of the stored slots ((key, position) order) [total_bytes + 1]
-  uint32_t* entry[2] = {nullptr, nullptr};  // per flags buffer: ring entries of the stored slots, compacted          [total_bytes]
+  uint32_t* slot_of = nullptr;   // slot of every position in (key, position) order (inverse of by_key)   [total_bytes]
+  uint32_t* rank[2] = {nullptr, nullptr};   // per flags buffer: prefix count of the stored slots          [total_bytes + 1]
+  uint32_t* entry[2] = {nullptr, nullptr};  // per flags buffer: ring entries of the stored slots, compacted [total_bytes]
   uint8_t* changed_key = nullptr;           // [65536]
-  uint32_t tables = 0;                      // = number of segments (input blocks)
+  uint32_t tables = 0;                      // one per span
+  uint32_t span_blocks = 1;                 // blocks per span; table t serves the blocks [t * span_blocks, (t + 1) * span_blocks)
 };
+// slot_of from by_key (once per text)
+void lz77_live_slots(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L);
 // rank[which] / entry[which] from flags[which]
 void lz77_live_index(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which);
-// table list[i] := the rings as a search at text position start[i] finds them under flags[which] (needs lz77_live_index(which));
-// also clears what the chain of that table noted in `consulted`
-void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* list_dev,
+// for every listed block first[i]: its span's table := the rings as a search at text position start[i] finds them under
+// flags[which] (needs lz77_live_index(which))
+void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev,
                            const uint32_t* start_dev, uint32_t count);
-// parses the listed blocks, chain list[i] on table list[i] (br_parse_live); flags are written to flags[which ^ 1]
-void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* list_dev, uint32_t count,
+// one chain per listed block first[i]: parses from there to the end of its span (br_parse_live); flags go to flags[which ^ 1],
+// every search is logged in B.search_log, the entries the chains derive for the later blocks of a span to B.entries
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count,
                      uint32_t warm_blocks);
-// dirty[k] = 1 for every block k whose chain looked at a ring that is not the same under flags[next] as under flags[prev]
-// (both indexed); rings are compared as materialised for the block start
-void lz77_live_validate(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int prev, int next, uint8_t* dirty_dev);
+// Repeats logged searches against the rings that flags[next] imply (needs lz77_live_index(next)) and sets dirty[block] = 1 where
+// one comes out differently.  prev < 0: every search of every block; otherwise the searches of the blocks with
+// reparsed[block] != 0 and, elsewhere, those whose hash key had a flag change between flags[prev] and flags[next].
+void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int prev, int next, const SegGeometry& geo,
+                      const uint8_t* reparsed_dev, uint8_t* dirty_dev);
 
 // applies extend_last_command / trailing insert-only fix-ups to the gathered commands
 void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n);

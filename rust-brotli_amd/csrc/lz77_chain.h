@@ -99,7 +99,6 @@ struct ChainTables {
   const uint16_t* keys = nullptr;     // hash key of every position
   uint16_t* live_num = nullptr;       // [tables][1 << bucket_bits]
   uint32_t* live_buckets = nullptr;   // [tables][(1 << bucket_bits) << block_bits]
-  uint8_t* live_consulted = nullptr;  // [tables][2 << bucket_bits]: entries looked at | ring counter mattered
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -381,9 +380,8 @@ struct ProbeMeta {
   uint32_t no_dict;   // the static dictionary is known to be switched off for good: no probes, no bookkeeping
   uint32_t log_on = 0;  // write ChainTables::search_log
   // live chains: key and ring counter of the two probed positions as the probe found them (the position is filed when its
-  // search is folded, br_search), what to note in LiveRing::consulted when that happens (bit 0: the walk went beyond the
-  // chain's own entries, bit 1: it ran out of entries, i.e. the ring counter mattered), and a window of 64 hash keys
-  uint32_t live_key[2], live_n[2], live_mark[2];
+  // search is folded, br_search), and a window of 64 hash keys, one per lane
+  uint32_t live_key[2], live_n[2];
   uint32_t kwin_base, kwin;
 #if defined(BR_CHAIN_PROFILE)
   unsigned long long t_probe, t_fold, n_probe, n_fold, t_setup, t_refill, n_refill;
@@ -569,11 +567,6 @@ BR_DEV void br_probe_pair_live16(const Lz77Params& P, const ChainTables& t, cons
   const unsigned long long brk_mask = __ballot(brk);
   const uint32_t brk_half = (uint32_t)(brk_mask >> (32u * w));
   const uint32_t first_brk = brk_half ? (uint32_t)__ffs((int)brk_half) - 1u : 32u;  // lane number within the half
-  const bool examined = is_ring && c <= first_brk;
-  const unsigned long long beyond_own = __ballot(examined && (e < lr.own_from || e == kLiveBreak));
-  // (fewer entries than the ring is deep and no break: the walk ran out of entries, so the counter itself mattered)
-  m.live_mark[0] = (((uint32_t)beyond_own != 0u) ? 1u : 0u) | ((n0 < depth && (uint32_t)brk_mask == 0u) ? 3u : 0u);
-  m.live_mark[1] = (((uint32_t)(beyond_own >> 32) != 0u) ? 1u : 0u) | ((n1 < depth && (uint32_t)(brk_mask >> 32) == 0u) ? 3u : 0u);
   m.live_key[0] = k0;
   m.live_key[1] = k1;
   m.live_n[0] = n0;
@@ -645,22 +638,6 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     m.g[0] = m.g[1] = 0;
     m.nbucket[0] = n0 < block_size ? n0 : block_size;
     m.nbucket[1] = n1 < block_size ? n1 : block_size;
-    m.live_mark[0] = m.live_mark[1] = 0;
-#if defined(BROTLI_HOST_EMU)
-    // what to note in LiveRing::consulted when the search is folded: did the walk go beyond the chain's own entries, did
-    // it run out of entries (then the ring counter itself mattered)
-    for (uint32_t w = 0; w < 2; ++w) {
-      const uint32_t cur = p0 + w;
-      const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
-      bool broke = false, beyond = false;
-      for (uint32_t i = 0; i < m.nbucket[w] && !broke; ++i) {
-        const uint32_t q = live_entry(w, i);
-        beyond = beyond || q < live->own_from || q == kLiveBreak;
-        broke = q >= kLiveBreak || cur - q > max_backward;
-      }
-      m.live_mark[w] = (beyond ? 1u : 0u) | ((m.live_n[w] < block_size && !broke) ? 3u : 0u);
-    }
-#endif
   } else if (kRows) {
 #if defined(BROTLI_HOST_EMU)
     for (int w = 0; w < 2; ++w) {
@@ -755,30 +732,6 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
           }
         }
       }
-    }
-    if constexpr (kLive) {
-      // marks for LiveRing::consulted (see the emulation twin above): slots ascend with the trips, so the first trip with a
-      // break in it holds the first break of that position
-      bool broke[2] = {false, false}, beyond[2] = {false, false};
-#pragma unroll
-      for (uint32_t k = 0; k < kMaxTrips; ++k) {
-        const uint32_t slot = k * 64u + lane;
-        const uint32_t w = slot < n[0] ? 0u : 1u;
-        const uint32_t c = slot - (w ? n[0] : 0u);
-        const bool ring = slot < total && c >= ndist && c < ndist + m.nbucket[w];
-        const uint32_t cur = p0 + w;
-        const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
-        const bool brk = ring && (ring_q[k] >= kLiveBreak || cur - ring_q[k] > max_backward);
-        const bool init = ring && (ring_q[k] < live->own_from || ring_q[k] == kLiveBreak);
-        for (uint32_t ww = 0; ww < 2; ++ww) {
-          if (broke[ww]) continue;
-          const unsigned long long bm = __ballot(brk && w == ww);
-          const unsigned long long upto = bm ? ((bm & (0ull - bm)) << 1) - 1ull : ~0ull;  // lanes up to and including the first break
-          if (__ballot(init && w == ww) & upto) beyond[ww] = true;
-          if (bm) broke[ww] = true;
-        }
-      }
-      for (uint32_t ww = 0; ww < 2; ++ww) m.live_mark[ww] = (beyond[ww] ? 1u : 0u) | ((m.live_n[ww] < block_size && !broke[ww]) ? 3u : 0u);
     }
     uint32_t listed = 0;
 #pragma unroll
@@ -1217,24 +1170,15 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
   const unsigned long long t1 = BR_TICK();
 #endif
   SearchResult r;
-  if constexpr (!kRows) {
+  if constexpr (!kRows || kLive) {
     SearchResult pre;
     r = br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end, &pre);
-    if (!kLive && m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
+    if (m.log_on && BR_LANE == 0) br_log_search(t.search_log + (size_t)x * kSearchLogWords, cache, pre);
   } else {
     r = br_fold_probe<kH9, kRows>(P, t, s, m, w, ds, blk_end);
   }
-  if constexpr (kLive) {
-    // FindLongestMatch files the position it has just searched (mod.rs:1794-1795) ...
-    br_live_insert(*live, m.live_key[w], m.live_n[w], x);
-    // ... and the validation needs to know which materialised rings this parse really hangs on (lz77_live.h)
-    if (live->consulted != nullptr && m.live_mark[w] != 0 && BR_LANE == 0) {
-      if (m.live_mark[w] & 1u) BR_LIVE_ST8(live->consulted + m.live_key[w], 1);
-      if (m.live_mark[w] & 2u) BR_LIVE_ST8(live->consulted + ((size_t)1 << P.bucket_bits) + m.live_key[w], 1);
-    }
-    if (m.live_n[w] == 0xffffu && live->consulted != nullptr && BR_LANE == 0)  // the ring counter wraps: how far it had got mattered
-      BR_LIVE_ST8(live->consulted + ((size_t)1 << P.bucket_bits) + m.live_key[w], 1);
-  }
+  // FindLongestMatch files the position it has just searched (mod.rs:1794-1795)
+  if constexpr (kLive) br_live_insert(*live, m.live_key[w], m.live_n[w], x);
 #if defined(BR_CHAIN_PROFILE)
   m.t_fold += BR_TICK() - t1;
   m.n_fold++;
@@ -1369,9 +1313,15 @@ struct FlagWriter {
 
 // One chain: parses segment `seg` from `entry`, writes commands, flags and `exit`.
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
+// what a live chain needs of a block's parse to enter the next block by itself (extend_last_command, encode.rs:2435-2437)
+struct BlockTail {
+  uint32_t n_cmds, insert_len, last_dist_code, last_copy_len;
+};
+
 template <bool kH9, bool kRows, bool kLive = false>
 BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment& seg_in,
-                                 const SegEntry& entry, SegExit& exit_out, SegEntry& next, const LiveRing* live = nullptr) {
+                                 const SegEntry& entry, SegExit& exit_out, SegEntry& next, const LiveRing* live = nullptr,
+                                 BlockTail* tail = nullptr) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
   Segment seg;
   seg.start = BR_UNIFORM(seg_in.start);
@@ -1419,7 +1369,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   // Once the throttle (matches < lookups >> 7, mod.rs:1957-1960) has tripped it stays tripped: nothing is looked up any
   // more, so neither counter moves.  With exact counters at the entry the chain need not even keep the virtual books.
   probe.no_dict = (P.use_dictionary && BR_UNIFORM(entry.dict_exact) && ds.matches < (ds.lookups >> 7)) ? 1u : 0u;
-  probe.log_on = (!kRows && t.search_log != nullptr && fw.enabled) ? 1u : 0u;
+  probe.log_on = ((!kRows || kLive) && t.search_log != nullptr && fw.enabled) ? 1u : 0u;
 #if defined(BR_CHAIN_PROFILE)
   probe.t_probe = probe.t_fold = probe.n_probe = probe.n_fold = probe.t_setup = probe.t_refill = probe.n_refill = 0;
   const unsigned long long t_begin = BR_TICK();
@@ -1606,6 +1556,12 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     atomicAdd(&g_chain_prof[10], (unsigned long long)n_searches);
   }
 #endif
+  if (tail != nullptr) {
+    tail->n_cmds = n_cmds;
+    tail->insert_len = insert_length;
+    tail->last_dist_code = last_dist_code;
+    tail->last_copy_len = last_copy_len;
+  }
   next.pos = position;
   next.apply = apply;
   for (int i = 0; i < 4; ++i) next.cache[i] = dc[i];
@@ -1722,47 +1678,151 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
   }
 }
 
-// One live chain (lz77_live.h): parses input block k -- live chains are cut one per block -- on private copy k of the bucket
-// rings, which the launcher has materialised for text position segments[first].blk_start, first = k - min(k, warm_blocks).
-// warm_blocks > 0 (the first round, when the flags of the earlier blocks are a guess and nothing else): the chain first runs
-// dry through the warm_blocks blocks in front of its own, so that what it sees of the recent past is its own exact
-// stores rather than that guess; a parse heals from a wrong history within ~100 KB.  The entry it then uses
-// for block k (the distance cache the dry run arrived with) is written back to entries[k] for the host resolver.
+// One live chain (lz77_live.h): parses the input blocks [first, last) -- live chains are cut one segment per block -- on
+// private copy `table` of the bucket rings, which the launcher has materialised for the start of block first - min(first,
+// warm_blocks).  warm_blocks > 0 (the first round, when the flags of the earlier blocks are a guess and nothing else): the
+// chain first runs dry through those blocks, so that what it sees of the recent past is its own exact stores rather
+// than that guess.  From the second block on the chain derives the entry by itself -- the state it arrives with, and
+// extend_last_command under the rule of encode.rs:2435-2437 on the understanding that the meta-block goes on -- and
+// writes it to entries[] for the host resolver, which replays the flush rule and has the blocks behind a wrong guess
+// parsed again.
 template <bool kRows>
 BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratchT<false, kRows>& s, const Segment* segments, SegEntry* entries,
-                          SegExit* exits, uint32_t k, uint32_t warm_blocks) {
+                          SegExit* exits, uint32_t first, uint32_t last, uint32_t table, uint32_t warm_blocks) {
   LiveRing lr;
   const size_t keys_per_table = (size_t)1 << P.bucket_bits;
-  lr.num = t.live_num + (size_t)k * keys_per_table;
-  lr.buckets = t.live_buckets + (((size_t)k * keys_per_table) << P.block_bits);
+  lr.num = t.live_num + (size_t)table * keys_per_table;
+  lr.buckets = t.live_buckets + (((size_t)table * keys_per_table) << P.block_bits);
   lr.keys = t.keys;
   lr.bits = P.block_bits;
-  lr.bucket_bits = P.bucket_bits;
-  lr.consulted = nullptr;
-  lr.own_from = 0;
-  SegEntry entry = entries[k];
-  uint32_t j = k > warm_blocks ? k - warm_blocks : 0u;
-  if (j < k) {
+  SegEntry entry = entries[first];
+  SegEntry next;
+  uint32_t j = first > warm_blocks ? first - warm_blocks : 0u;
+  if (j < first) {
     SegEntry e = entries[j];
-    for (; j < k; ++j) {
+    for (; j < first; ++j) {
       Segment seg = segments[j];
       seg.flags |= kSegWarmup;
       e.pos = seg.blk_start;
       e.ext_allowed = 0;
-      SegEntry next;
-      br_parse_segment<false, kRows, true>(P, t, s, seg, e, exits[k], next, &lr);
+      br_parse_segment<false, kRows, true>(P, t, s, seg, e, exits[first], next, &lr);
       // StitchToPreviousBlock of the block that follows files the last three positions (mod.rs:210-222)
       if (seg.flags & kSegTailStitched) br_live_store(lr, seg.blk_end - 3u, 1, 3, 1, 0);
       e = next;
     }
     for (int i = 0; i < 4; ++i) entry.cache[i] = e.cache[i];
     BR_SYNC();
-    if (BR_LANE == 0) entries[k] = entry;
+    if (BR_LANE == 0) entries[first] = entry;
   }
-  lr.consulted = t.live_consulted != nullptr ? t.live_consulted + (size_t)k * 2 * keys_per_table : nullptr;
-  lr.own_from = BR_UNIFORM(segments[k].blk_start);
-  SegEntry next;
-  br_parse_segment<false, kRows, true>(P, t, s, segments[k], entry, exits[k], next, &lr);
+  for (j = first; j < last; ++j) {
+    const Segment seg = segments[j];
+    BlockTail tail;
+    br_parse_segment<false, kRows, true>(P, t, s, seg, entry, exits[j], next, &lr, &tail);
+    if (j + 1 == last) break;
+    if (seg.flags & kSegTailStitched) br_live_store(lr, seg.blk_end - 3u, 1, 3, 1, 0);
+    // the entry of the next block as Lz77Stage::Resolve derives it while the meta-block stays open
+    const uint32_t was_exact = entry.dict_exact;
+    entry = next;
+    entry.pos = BR_UNIFORM(seg.blk_end);
+    entry.insert_len = tail.insert_len;
+    entry.dict_exact = was_exact;
+    entry.head_kind = kHeadNone;
+    entry.head_base = entry.head_p1 = 0;
+    entry.ext_allowed = 0;
+    if (tail.n_cmds != 0 && tail.insert_len == 0) {
+      const uint64_t cmd_dist = (uint64_t)(int64_t)next.cache[0];
+      if (tail.last_dist_code < 16 || (uint64_t)tail.last_dist_code - 15 == cmd_dist) {
+        const uint64_t lpp = (uint64_t)seg.blk_end - tail.last_copy_len;
+        const uint64_t max_distance = lpp < P.max_backward_limit ? lpp : P.max_backward_limit;
+        if (cmd_dist <= max_distance) entry.ext_allowed = 1;
+      }
+    }
+    BR_SYNC();
+    if (BR_LANE == 0) entries[j + 1] = entry;
+  }
+}
+
+// Repeats the cache and ring stages of the search a live chain ran at position p -- with the distance cache it had then
+// (ChainTables::search_log) and the ring that the flags behind `ix` imply for that position -- and says whether they find
+// what they found then (lz77_live_verify).
+template <bool kRows>
+BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const LiveIndex& ix, ChainScratchT<false, kRows>& s, uint32_t p,
+                             uint32_t blk_end) {
+  const uint32_t* rec = t.search_log + (size_t)p * kSearchLogWords;
+  BR_SYNC();
+  int32_t* dc = s.dc;
+  for (int i = 0; i < 4; ++i) dc[i] = (int32_t)BR_UNIFORM(rec[i]);
+  for (int i = 4; i < 16; ++i) dc[i] = 0;
+  br_prepare_distance_cache(dc, P.ndist);
+  ProbeMeta m;
+  m.pos = p;
+  m.version = 0;
+  m.win_base = 0xffffff00u;
+  m.no_dict = 1;  // (the dictionary stage comes after what is compared here)
+  m.log_on = 0;
+  m.g[0] = m.g[1] = 0;
+  DictState ds;
+  ds.lookups = ds.lookups0 = ds.matches = ds.matches0 = 0;
+  ds.mode = 0;
+  ds.maxdef = 0;
+  ds.vlookups = 0;
+  ds.vwould = 0;
+  ds.vmaxdef = 0;
+  const uint32_t depth = 1u << P.block_bits;
+  const uint32_t key = BR_UNIFORM(t.keys[p]);
+  const LiveRingAt ring = br_live_ring_at_slot(ix, key, p, BR_UNIFORM(ix.slot_of[p]), depth);
+  const uint32_t ndist = P.ndist;
+  const uint32_t max_length = blk_end - p;
+  const uint32_t max_backward = p < P.max_backward_limit ? p : P.max_backward_limit;
+  const uint8_t* cur_data = t.text + p;
+  BR_SYNC();
+#if !defined(BROTLI_HOST_EMU)
+  if constexpr (kRows) {
+    // the lane layout of br_probe_pair_rows, first half only
+    const uint32_t lane = (uint32_t)BR_LANE, c = lane & 31u;
+    const bool half0 = lane < 32u;
+    const bool is_cache = half0 && c < ndist;
+    const uint32_t i = c - ndist;
+    const bool is_ring = half0 && !is_cache && i < ring.visible;
+    uint32_t e = kLiveBreak;
+    if (is_ring) e = br_live_ring_entry(ix, ring, i);
+    const bool brk = is_ring && (e >= kLiveBreak || p - e > max_backward);
+    const uint32_t brk_half = (uint32_t)__ballot(brk);
+    const uint32_t first_brk = brk_half ? (uint32_t)__ffs((int)brk_half) - 1u : 32u;
+    uint32_t prev = 0xffffffffu;
+    if (is_cache) {
+      const int64_t b = (int64_t)dc[c];
+      if (b > 0 && b <= (int64_t)max_backward) prev = p - (uint32_t)b;
+    } else if (is_ring && c < first_brk) {
+      prev = e;
+    }
+    m.r_len = prev != 0xffffffffu ? br_match_len_wide(t.text + prev, cur_data, max_length, t.run_end, prev, p) : 0u;
+    m.r_prev = prev;
+    m.nbucket[0] = m.nbucket[1] = kRowEntries;
+  } else
+#endif
+  {
+    // candidates through LDS, like br_probe_pair
+    m.nbucket[0] = ring.visible;
+    m.nbucket[1] = 0;
+    const uint32_t total = ndist + ring.visible;
+    for (uint32_t c = BR_LANE; c < total; c += BR_NLANES) {
+      uint32_t prev = 0xffffffffu;
+      if (c < ndist) {
+        const int64_t b = (int64_t)dc[c];
+        if (b > 0 && b <= (int64_t)max_backward) prev = p - (uint32_t)b;
+      } else {
+        const uint32_t q = br_live_ring_entry(ix, ring, c - ndist);
+        if (q < kLiveBreak && p - q <= max_backward) prev = q;  // else: marks the point where the bucket walk breaks
+      }
+      s.cand_prev[0][c] = prev;
+      s.cand_len[0][c] = prev != 0xffffffffu ? br_match_len_wide(t.text + prev, cur_data, max_length, t.run_end, prev, p) : 0u;
+    }
+    BR_SYNC();
+  }
+  SearchResult now;
+  br_fold_probe<false, kRows>(P, t, s, m, 0, ds, blk_end, &now, true);
+  return br_same_as_logged(rec, now);
 }
 
 }  // namespace brotli_mi355x

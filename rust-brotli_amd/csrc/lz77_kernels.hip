@@ -1702,4 +1702,234 @@ void lz77_patch_commands(Command* cmds, const CmdPatch* patches_dev, uint32_t n)
   HIP_CHECK(hipGetLastError());
 }
 
+
+// ------------------------------------------------------------------------------------------ live chains (lz77_live.h)
+static LiveIndex live_index_of(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which) {
+  LiveIndex ix;
+  ix.by_key = B.by_key;
+  ix.rank = L.rank[which];
+  ix.entry = L.entry[which];
+  ix.key_first = B.key_first;
+  ix.key_last = B.key_last;
+  ix.slot_of = L.slot_of;
+  ix.count_base = B.count_base;
+  ix.reset_pos = P.reset_pos;
+  ix.reset_vis = P.reset_vis;
+  return ix;
+}
+
+static ChainTables live_chain_tables(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int flags_out) {
+  const DeviceTables& dt = dev_tables();
+  ChainTables T;
+  T.text = B.text;
+  T.info = nullptr;
+  T.sorted = nullptr;
+  T.sorted_tag = nullptr;
+  T.rows = nullptr;
+  T.run_end = B.run_end;
+  T.search_log = B.search_log;
+  T.flags_next = B.flags[flags_out];
+  T.cmds = B.cmds;
+  T.dict_hash = dt.dict_hash;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.dist_postfix_bits = P.dist_postfix_bits;
+  T.num_direct_distance_codes = P.num_direct_distance_codes;
+  T.work = nullptr;
+  T.keys = B.keys;
+  T.live_num = L.num;
+  T.live_buckets = L.buckets;
+  return T;
+}
+
+__global__ __launch_bounds__(256) void k_live_slots(const uint32_t* __restrict__ by_key, uint32_t n, uint32_t* __restrict__ slot_of) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slot_of[by_key[i]] = i;
+}
+
+void lz77_live_slots(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L) {
+  const uint32_t n = P.total_bytes;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_live_slots, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.by_key, n, L.slot_of);
+  HIP_CHECK(hipGetLastError());
+}
+
+// per slot: the stored / masked bits of its position (fbits) and the stored bit as a word for the prefix count
+__global__ __launch_bounds__(256) void k_live_gather(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ flags, uint32_t n,
+                                                      uint8_t* __restrict__ fbits, uint32_t* __restrict__ rank) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  uint32_t f = 0;
+  if (i < n) {
+    f = flags[by_key[i]] & (kFlagStored | kFlagMasked);
+    fbits[i] = (uint8_t)f;
+  }
+  rank[i] = f & 1u;
+}
+__global__ __launch_bounds__(256) void k_live_compact(const uint32_t* __restrict__ by_key, const uint8_t* __restrict__ fbits,
+                                                       const uint32_t* __restrict__ rank, uint32_t n, uint32_t* __restrict__ entry) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = fbits[i];
+  if (f & kFlagStored) entry[rank[i]] = (f & kFlagMasked) ? kLiveBreak : by_key[i];
+}
+
+void lz77_live_index(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which) {
+  const uint32_t n = P.total_bytes;
+  hipLaunchKernelGGL(k_live_gather, dim3((n + 256) / 256), dim3(256), 0, BR_STREAM, B.by_key, (const uint8_t*)B.flags[which], n, B.fbits, L.rank[which]);
+  exclusive_scan_u32(L.rank[which], n + 1, (uint32_t*)B.sort_tmp);
+  if (n) hipLaunchKernelGGL(k_live_compact, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.by_key, (const uint8_t*)B.fbits, (const uint32_t*)L.rank[which], n, L.entry[which]);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_live_materialise(LiveIndex ix, const uint32_t* __restrict__ first, const uint32_t* __restrict__ start,
+                                                           uint32_t span_blocks, uint32_t bucket_bits, uint32_t block_bits, uint16_t* __restrict__ num,
+                                                           uint32_t* __restrict__ buckets) {
+  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t K = (size_t)1 << bucket_bits;
+  if (key >= K) return;
+  const size_t t = first[blockIdx.y] / span_blocks;
+  br_live_materialise_key(ix, key, start[blockIdx.y], block_bits, num + t * K, buckets + ((t * K) << block_bits));
+}
+
+void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev,
+                           const uint32_t* start_dev, uint32_t count) {
+  if (count == 0) return;
+  const uint32_t K = 1u << P.bucket_bits;
+  for (uint32_t done = 0; done < count; done += 32768) {  // (grid.y is limited to 65535)
+    const uint32_t part = count - done < 32768u ? count - done : 32768u;
+    hipLaunchKernelGGL(k_live_materialise, dim3((K + 255) / 256, part), dim3(256), 0, BR_STREAM, live_index_of(P, B, L, which), first_dev + done,
+                       start_dev + done, L.span_blocks, P.bucket_bits, P.block_bits, L.num, L.buckets);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+struct LiveParseArgs {
+  Lz77Params P;
+  ChainTables T;
+  const Segment* segments;
+  SegEntry* entries;
+  SegExit* exits;
+  const uint32_t* first;
+  uint32_t count, span_blocks, warm_blocks;
+};
+// (a launch has at most a few thousand of these chains, each of them bound by the latency of its own dependent loads:
+// registers matter more than waves per SIMD)
+template <bool kRows>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_parse_live(LiveParseArgs a) {
+  __shared__ ChainScratchT<false, kRows> scratch;
+  const uint32_t item = blockIdx.x;
+  if (item >= a.count) return;
+  const uint32_t first = a.first[item];
+  const uint32_t table = first / a.span_blocks;
+  uint32_t last = (table + 1) * a.span_blocks;
+  if (last > a.P.num_segments) last = a.P.num_segments;
+  br_parse_live<kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, first, last, table, a.warm_blocks);
+}
+
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count,
+                     uint32_t warm_blocks) {
+  if (count == 0) return;
+  LiveParseArgs a;
+  a.P = P;
+  a.T = live_chain_tables(P, B, L, which ^ 1);
+  a.segments = B.segments;
+  a.entries = B.entries;
+  a.exits = B.exits;
+  a.first = first_dev;
+  a.count = count;
+  a.span_blocks = L.span_blocks;
+  a.warm_blocks = warm_blocks;
+  if ((1u << P.block_bits) <= kRowEntries) {
+    hipLaunchKernelGGL((k_parse_live<true>), dim3(count), dim3(64), 0, BR_STREAM, a);
+  } else {
+    hipLaunchKernelGGL((k_parse_live<false>), dim3(count), dim3(64), 0, BR_STREAM, a);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_live_changed_keys(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next, uint32_t n,
+                                                            const uint16_t* __restrict__ keys, uint8_t* __restrict__ changed_key) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n && ((prev[q] ^ next[q]) & (kFlagStored | kFlagMasked))) changed_key[keys[q]] = 1;
+}
+// the searched positions that have to be looked at again
+__global__ __launch_bounds__(256) void k_live_list(const uint8_t* __restrict__ flags, uint32_t n, uint32_t from, const uint16_t* __restrict__ keys,
+                                                    const uint8_t* __restrict__ changed_key, const uint8_t* __restrict__ reparsed, uint32_t prefix_bytes,
+                                                    uint32_t block_bytes, uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t cap) {
+  const uint32_t p = from + blockIdx.x * blockDim.x + threadIdx.x;
+  bool take = false;
+  if (p < n && (flags[p] & kFlagSearched)) take = changed_key == nullptr || reparsed[(p - prefix_bytes) / block_bytes] != 0 || changed_key[keys[p]] != 0;
+  const unsigned long long m = __ballot(take);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
+  if (take) {
+    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (at < cap) list[at] = p;
+  }
+}
+
+struct LiveVerifyArgs {
+  Lz77Params P;
+  ChainTables T;
+  LiveIndex ix;
+  const uint32_t* list;
+  const uint32_t* count;
+  uint32_t cap;
+  uint32_t prefix_bytes, block_bytes;
+  uint8_t* dirty;
+};
+template <bool kRows>
+__global__ __launch_bounds__(64) void k_live_verify(LiveVerifyArgs a) {
+  __shared__ ChainScratchT<false, kRows> scratch;
+  uint32_t n = *a.count;
+  if (n > a.cap) n = a.cap;
+  for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+    const uint32_t p = a.list[item];
+    const uint32_t blk = (p - a.prefix_bytes) / a.block_bytes;
+    if (*(volatile uint8_t*)(a.dirty + blk)) continue;  // (already owed a re-parse)
+    const uint64_t end64 = (uint64_t)a.prefix_bytes + (uint64_t)(blk + 1) * a.block_bytes;
+    const uint32_t blk_end = end64 < a.P.total_bytes ? (uint32_t)end64 : a.P.total_bytes;
+    const bool same = br_verify_search<kRows>(a.P, a.T, a.ix, scratch, p, blk_end);
+    if (!same && threadIdx.x == 0) a.dirty[blk] = 1;
+  }
+}
+
+void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int prev, int next, const SegGeometry& geo,
+                      const uint8_t* reparsed_dev, uint8_t* dirty_dev) {
+  const uint32_t n = P.total_bytes;
+  if (n <= geo.first_block_start) return;
+  if (prev >= 0) {
+    HIP_CHECK(hipMemsetAsync(L.changed_key, 0, 65536, BR_STREAM));
+    hipLaunchKernelGGL(k_live_changed_keys, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, (const uint8_t*)B.flags[prev], (const uint8_t*)B.flags[next], n,
+                       (const uint16_t*)B.keys, L.changed_key);
+  }
+  HIP_CHECK(hipMemsetAsync(B.recheck_count, 0, 4, BR_STREAM));
+  const uint32_t span = n - geo.first_block_start;
+  hipLaunchKernelGGL(k_live_list, dim3((span + 255) / 256), dim3(256), 0, BR_STREAM, (const uint8_t*)B.flags[next], n, geo.first_block_start,
+                     (const uint16_t*)B.keys, prev >= 0 ? (const uint8_t*)L.changed_key : (const uint8_t*)nullptr, reparsed_dev, geo.prefix_bytes,
+                     geo.block_bytes, B.recheck_list, B.recheck_count, B.recheck_cap);
+  LiveVerifyArgs a;
+  a.P = P;
+  a.T = live_chain_tables(P, B, L, next);
+  a.ix = live_index_of(P, B, L, next);
+  a.list = B.recheck_list;
+  a.count = B.recheck_count;
+  a.cap = B.recheck_cap;
+  a.prefix_bytes = geo.prefix_bytes;
+  a.block_bytes = geo.block_bytes;
+  a.dirty = dirty_dev;
+  const uint32_t grid = B.recheck_cap < 32768u ? B.recheck_cap : 32768u;
+  if ((1u << P.block_bits) <= kRowEntries) {
+    hipLaunchKernelGGL((k_live_verify<true>), dim3(grid), dim3(64), 0, BR_STREAM, a);
+  } else {
+    hipLaunchKernelGGL((k_live_verify<false>), dim3(grid), dim3(64), 0, BR_STREAM, a);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace brotli_mi355x

@@ -14,9 +14,14 @@
 // with the masked entries, Store4Vec4 / StoreEvenVec4).  The copy is MATERIALISED at the block start from the stored /
 // masked flags of all earlier positions (positions sorted by (key, position) + a prefix count of the stored flags: the
 // last `depth` stored positions of every key in front of the block, and the ring counter).  Flags of earlier blocks
-// come from the previous round, so the scheme is still speculate + verify -- but a chain's own stores are exact, and a
-// changed flag can only invalidate a block through a ring it materialised AND looked at beyond its own entries
-// (`consulted`, one byte per key and block).  Shared by the gfx950 kernels and the host emulation (test infrastructure).
+// come from the previous round, so the scheme is still speculate + verify -- but a chain's own stores are exact.  A chain
+// runs through a SPAN of several blocks (longer than the healing distance), so that what a wrong history does to the
+// head of a span has died out before its tail, which is what the next span sees most of.
+// Verification is separate and fully parallel: every search is logged (distance cache, what the cache and ring stages
+// found); afterwards each search is repeated on its own against the ring that the flags of NOW imply for its position
+// (br_live_ring_at, same index), and a block is parsed again only if one of its searches comes out differently.  When
+// every search of every block checks out and the entries chain, the flags are a fixed point of the sequential parse.
+// Shared by the gfx950 kernels and the host emulation (test infrastructure).
 #ifndef BROTLI_MI355X_LZ77_LIVE_H_
 #define BROTLI_MI355X_LZ77_LIVE_H_
 
@@ -33,11 +38,7 @@ static constexpr uint32_t kLiveBreak = 0xfffffffeu;   // materialised: a masked 
 struct LiveRing {
   uint16_t* num;        // [1 << bucket_bits]
   uint32_t* buckets;    // [(1 << bucket_bits) << block_bits]
-  uint8_t* consulted;   // [2 << bucket_bits]: [key] a walk went beyond the chain's own entries, [keys + key] the ring counter
-                        // mattered (a walk ran out of entries, or the counter wrapped); null while nothing is recorded (dry runs)
-  uint32_t bucket_bits;
   const uint16_t* keys; // hash key of every text position
-  uint32_t own_from;    // entries >= own_from (and kLiveMasked) were filed by this chain, everything else was materialised
   uint32_t bits;        // block_bits: ring depth = 1 << bits
 };
 
@@ -78,7 +79,6 @@ BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint
     const uint32_t n = lr.num[key];
     lr.buckets[((size_t)key << lr.bits) | (n & (depth - 1u))] = (q >= masked_lo && q < masked_hi) ? kLiveMasked : q;
     lr.num[key] = (uint16_t)(n + 1u);
-    if (n == 0xffffu && lr.consulted != nullptr) lr.consulted[((size_t)1 << lr.bucket_bits) + key] = 1;  // the counter wraps
   }
 #else
   for (uint32_t first = 0; first < count; first += 64) {
@@ -104,10 +104,7 @@ BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint
     if (active) {
       if (rank + depth >= cnt)  // (more than `depth` of one key in the batch: the later ones overwrite the earlier)
         BR_LIVE_ST32(lr.buckets + (((size_t)key << lr.bits) | ((n + rank) & (depth - 1u))), (q >= masked_lo && q < masked_hi) ? kLiveMasked : q);
-      if (rank + 1 == cnt) {
-        BR_LIVE_ST16(lr.num + key, n + cnt);
-        if (n + cnt > 0xffffu && lr.consulted != nullptr) BR_LIVE_ST8(lr.consulted + ((size_t)1 << lr.bucket_bits) + key, 1);  // the counter wraps
-      }
+      if (rank + 1 == cnt) BR_LIVE_ST16(lr.num + key, n + cnt);
     }
   }
 #endif
@@ -131,6 +128,7 @@ struct LiveIndex {
   const uint32_t* entry;  // [total]
   const uint32_t* key_first;
   const uint32_t* key_last;
+  const uint32_t* slot_of;     // slot of every position (inverse of by_key)
   const uint32_t* count_base;  // optional: stored positions per key in front of the text (a later piece of a stream)
   uint32_t reset_pos, reset_vis;  // Lz77Params
 };
@@ -150,9 +148,9 @@ BR_DEV uint32_t br_live_lower_bound(const uint32_t* by_key, uint32_t lo, uint32_
 struct LiveRingAt {
   uint32_t num, visible, here, top;
 };
-BR_DEV LiveRingAt br_live_ring_at(const LiveIndex& ix, uint32_t key, uint32_t x, uint32_t depth) {
-  const uint32_t kf = ix.key_first[key], kl = ix.key_last[key];
-  const uint32_t idx = br_live_lower_bound(ix.by_key, kf, kl, x);
+// idx = first slot of the key whose position is >= x
+BR_DEV LiveRingAt br_live_ring_at_slot(const LiveIndex& ix, uint32_t key, uint32_t x, uint32_t idx, uint32_t depth) {
+  const uint32_t kf = ix.key_first[key];
   uint32_t lo = kf, base = ix.count_base ? ix.count_base[key] : 0u;
   if (ix.reset_pos != 0 && x >= ix.reset_pos) {  // the table was emptied at reset_pos; reset_vis.. were filed again
     lo = br_live_lower_bound(ix.by_key, kf, idx, ix.reset_vis);
@@ -165,29 +163,17 @@ BR_DEV LiveRingAt br_live_ring_at(const LiveIndex& ix, uint32_t key, uint32_t x,
   r.visible = r.num < depth ? r.num : depth;
   return r;
 }
+BR_DEV LiveRingAt br_live_ring_at(const LiveIndex& ix, uint32_t key, uint32_t x, uint32_t depth) {
+  return br_live_ring_at_slot(ix, key, x, br_live_lower_bound(ix.by_key, ix.key_first[key], ix.key_last[key], x), depth);
+}
 BR_DEV uint32_t br_live_ring_entry(const LiveIndex& ix, const LiveRingAt& r, uint32_t i) { return i < r.here ? ix.entry[r.top - 1u - i] : kLiveBreak; }
 
-// Fills one ring of a table (and clears what the chain noted about it last time).
-BR_DEV void br_live_materialise_key(const LiveIndex& ix, uint32_t key, uint32_t x, uint32_t bits, uint16_t* num, uint32_t* buckets, uint8_t* consulted,
-                                    uint32_t keys_per_table) {
+// Fills one ring of a table.
+BR_DEV void br_live_materialise_key(const LiveIndex& ix, uint32_t key, uint32_t x, uint32_t bits, uint16_t* num, uint32_t* buckets) {
   const uint32_t depth = 1u << bits;
   const LiveRingAt r = br_live_ring_at(ix, key, x, depth);
   num[key] = (uint16_t)r.num;
   for (uint32_t i = 0; i < r.visible; ++i) buckets[((size_t)key << bits) | ((r.num - 1u - i) & (depth - 1u))] = br_live_ring_entry(ix, r, i);
-  consulted[key] = 0;
-  consulted[keys_per_table + key] = 0;
-}
-
-// Does the ring of `key` at text position x differ between two flag states, as far as a chain that noted (entries looked at
-// beyond its own, ring counter mattered) could tell?
-BR_DEV bool br_live_ring_differs(const LiveIndex& a, const LiveIndex& b, uint32_t key, uint32_t x, uint32_t depth, bool entries, bool counter) {
-  const LiveRingAt ra = br_live_ring_at(a, key, x, depth), rb = br_live_ring_at(b, key, x, depth);
-  if (counter && ra.num != rb.num) return true;
-  if (!entries) return false;
-  if (ra.visible != rb.visible) return true;
-  for (uint32_t i = 0; i < ra.visible; ++i)
-    if (br_live_ring_entry(a, ra, i) != br_live_ring_entry(b, rb, i)) return true;
-  return false;
 }
 
 }  // namespace brotli_mi355x

@@ -51,7 +51,7 @@ void Lz77Stage::Release() {
     dev_free(B_.run_end);
     dev_free(L_.num);
     dev_free(L_.buckets);
-    dev_free(L_.consulted);
+    dev_free(L_.slot_of);
     dev_free(L_.rank[0]);
     dev_free(L_.rank[1]);
     dev_free(L_.entry[0]);
@@ -145,15 +145,25 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
       BuildSegments();
       P_.num_segments = (uint32_t)segments_.size();
     }
-    const size_t K = (size_t)1 << P_.bucket_bits, T = segments_.size();
+    // Blocks per chain.  A parse heals from a wrong history within ~100 KB: spans are a multiple of that, so that
+    // what the guessed flags in front of a span do to its head has died out before its tail.
+    uint32_t span = 8;
+    if (const char* e = getenv("BROTLI_MI355X_LIVE_SPAN")) span = std::max(1, atoi(e));
+    const size_t K = (size_t)1 << P_.bucket_bits, T = (segments_.size() + span - 1) / span;
+    L_.span_blocks = span;
     L_.tables = (uint32_t)T;
     L_.num = (uint16_t*)dev_alloc_uninit(T * K * 2 + 64);
     L_.buckets = (uint32_t*)dev_alloc_uninit(((T * K) << P_.block_bits) * 4 + 64);
-    L_.consulted = (uint8_t*)dev_alloc(T * K * 2 + 64);
+    L_.slot_of = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
     for (int i = 0; i < 2; ++i) {
       L_.rank[i] = (uint32_t*)dev_alloc_uninit((M + 1) * 4 + 64);
       L_.entry[i] = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
     }
+    // every search is logged; the verification repeats them one by one (lz77_live_verify)
+    B_.search_log = (uint32_t*)dev_alloc(M * kSearchLogWords * 4 + 64);
+    B_.recheck_cap = (uint32_t)(M + 4096);  // (every position can be a searched one)
+    B_.recheck_list = (uint32_t*)dev_alloc_uninit((size_t)B_.recheck_cap * 4 + 64);
+    B_.recheck_count = (uint32_t*)dev_alloc(64);
     L_.changed_key = (uint8_t*)dev_alloc(65536 + 64);
     B_.changed_cap = kChangedCap;
     B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
@@ -1017,82 +1027,112 @@ void Lz77Stage::InitEntries() {
   exits_.assign(nseg, SegExit{});
 }
 
-// The rounds of live chains (lz77_live.h): one chain per input block, each on a private copy of the bucket rings that is
-// materialised for its block start from the flags of the round before.  Round 0 has only a guess of those flags: its
-// chains start a few blocks early and run dry up to their block.  After every round the host resolver chains the exits
-// (entry states, as in RunRounds) and the device compares, for every ring a chain looked at beyond its own entries, what
-// it was materialised from with what the new flags say; a block is parsed again when either differs.  The first block
-// that is still wrong has an exact entry and exact rings, so every round settles at least one block; since a parse heals
-// from a wrong history within ~100 KB, it settles almost all of them.
+// The rounds of live chains (lz77_live.h).  A chain parses a span of input blocks on a private copy of the bucket rings,
+// materialised for the block it starts at from the flags of the round before.  Round 0 has only a guess of those flags: its
+// chains start a few blocks early and run dry up to their span.  After every round the host resolver chains the exits
+// (entry states, as in RunRounds) and the device repeats the logged searches against the rings the new flags imply; a span
+// is parsed again from its first block whose entry or searches do not hold.  The first block that is still wrong has
+// an exact entry and exact rings, so every round settles at least one block; since a parse heals from a wrong history
+// within ~100 KB, it settles almost all of them.
 void Lz77Stage::RunLive() {
   const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
   const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
   Timer tm(prof);
   const uint32_t nseg = (uint32_t)segments_.size();
+  const uint32_t span = L_.span_blocks, nspan = L_.tables;
   InitFlags();
   InitEntries();
   tm.stop(&stats_.ms_init);
   uint32_t warm = 2;
   if (const char* w = getenv("BROTLI_MI355X_LIVE_WARM")) warm = (uint32_t)atoi(w);
-  uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
-  uint32_t* start_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
+  SegGeometry geo{};
+  geo.prefix_bytes = P_.prefix_bytes;
+  geo.first_block_start = segments_[0].blk_start;
+  geo.block_bytes = block_bytes_;
+  geo.num_blocks = nseg;
+  geo.num_segments = nseg;
+  geo.block_size = 1u << P_.block_bits;
+  uint32_t* first_dev = (uint32_t*)dev_alloc((size_t)nspan * 4 + 64);
+  uint32_t* start_dev = (uint32_t*)dev_alloc((size_t)nspan * 4 + 64);
   uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
-  PinnedArray<uint32_t> list, start;
-  PinnedArray<uint8_t> dirty_tab;
-  list.resize_discard(nseg);
-  start.resize_discard(nseg);
-  dirty_tab.resize_discard(nseg);
-  std::vector<uint8_t> dirty(nseg, 1);
+  uint8_t* reparsed_dev = (uint8_t*)dev_alloc(nseg + 64);
+  PinnedArray<uint32_t> first, start;
+  PinnedArray<uint8_t> failed, reparsed;
+  first.resize_discard(nspan);
+  start.resize_discard(nspan);
+  failed.resize_discard(nseg);
+  reparsed.resize_discard(nseg);
+  std::vector<uint32_t> redo_from(nspan);  // per span: first block to parse again (nseg: none)
+  for (uint32_t t = 0; t < nspan; ++t) redo_from[t] = t * span;
   int which = 0;
+  critical_blocks_ = 0;
+  lz77_live_slots(P_, B_, L_);
   lz77_live_index(P_, B_, L_, which);
   const uint32_t max_rounds = getenv("BROTLI_MI355X_MAX_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_MAX_ROUNDS")) : nseg + 8;
   bool done = false;
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
     stats_.rounds++;
     const uint32_t w = round == 0 ? warm : 0u;
-    uint32_t count = 0;
-    for (uint32_t k = 0; k < nseg; ++k) {
-      if (!dirty[k]) continue;
-      list[count] = k;
-      start[count] = segments_[k > w ? k - w : 0u].blk_start;
-      if (round != 0) entries_[k] = next_entries_[k];
+    uint32_t count = 0, longest = 0;
+    uint64_t blocks = 0;
+    for (uint32_t k = 0; k < nseg; ++k) reparsed[k] = 0;
+    for (uint32_t t = 0; t < nspan; ++t) {
+      const uint32_t f = redo_from[t];
+      if (f >= nseg) continue;
+      const uint32_t last = std::min(nseg, (t + 1) * span);
+      first[count] = f;
+      start[count] = segments_[f > w ? f - w : 0u].blk_start;
+      // (the chain derives the entries of the later blocks by itself and writes them back)
+      if (round != 0) entries_[f] = next_entries_[f];
+      for (uint32_t k = f; k < last; ++k) reparsed[k] = 1;
+      blocks += last - f + std::min(f, w);
+      longest = std::max(longest, last - f + std::min(f, w));
       ++count;
     }
     dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
-    dev_h2d(list_dev, list.data(), (size_t)count * 4);
+    dev_h2d(first_dev, first.data(), (size_t)count * 4);
     dev_h2d(start_dev, start.data(), (size_t)count * 4);
-    lz77_live_materialise(P_, B_, L_, which, list_dev, start_dev, count);
+    dev_h2d(reparsed_dev, reparsed.data(), nseg);
+    lz77_live_materialise(P_, B_, L_, which, first_dev, start_dev, count);
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     tm.stop(&stats_.ms_rank);
-    lz77_live_parse(P_, B_, L_, which, list_dev, count, w);
-    stats_.segments_parsed += (uint64_t)count * (1 + w);
+    lz77_live_parse(P_, B_, L_, which, first_dev, count, w);
+    stats_.segments_parsed += blocks;
+    critical_blocks_ += longest;
+    tm.stop(&stats_.ms_parse);
     lz77_live_index(P_, B_, L_, which ^ 1);
     dev_memset(dirty_dev, 0, nseg);
-    if (round != 0) lz77_live_validate(P_, B_, L_, which, which ^ 1, dirty_dev);
+    lz77_live_verify(P_, B_, L_, round == 0 ? -1 : which, which ^ 1, geo, reparsed_dev, dirty_dev);
     dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
-    if (w != 0) dev_d2h_async(entries_.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));  // (the dry runs chose the distance caches)
-    dev_d2h_async(dirty_tab.data(), dirty_dev, nseg);
+    dev_d2h_async(entries_.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));  // (the chains chose the entries inside their spans)
+    dev_d2h_async(failed.data(), dirty_dev, nseg);
     dev_sync();
-    tm.stop(&stats_.ms_parse);
+    tm.stop(&stats_.ms_rank);
     which ^= 1;
     const auto host_t0 = std::chrono::steady_clock::now();
     Resolve(false);
     host_resolve_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-    uint32_t n_entry = 0, n_rings = 0, n_dirty = 0;
-    for (uint32_t k = 0; k < nseg; ++k) {
-      // (nothing of round 0 is verified: its rings came out of dry runs over guessed flags)
-      dirty[k] = (round == 0 || dirty_entry_[k] || dirty_tab[k]) ? 1 : 0;
-      n_entry += dirty_entry_[k];
-      n_rings += dirty_tab[k];
-      n_dirty += dirty[k];
+    uint32_t n_entry = 0, n_failed = 0, n_redo = 0;
+    for (uint32_t t = 0; t < nspan; ++t) {
+      redo_from[t] = nseg;
+      const uint32_t last = std::min(nseg, (t + 1) * span);
+      for (uint32_t k = t * span; k < last; ++k) {
+        n_entry += dirty_entry_[k];
+        n_failed += failed[k];
+        if ((dirty_entry_[k] || failed[k]) && redo_from[t] == nseg) redo_from[t] = k;
+      }
+      if (redo_from[t] != nseg) n_redo += last - redo_from[t];
     }
-    if (debug) fprintf(stderr, "live round %u: parsed %u of %u blocks; to redo %u (entry %u, rings %u)\n", round, count, nseg, n_dirty, n_entry, n_rings);
+    if (debug)
+      fprintf(stderr, "live round %u: %u chains over %llu blocks of %u, longest %u (critical path so far %u blocks); blocks with a wrong entry %u, with a search that does not hold %u; to redo %u\n",
+              round, count, (unsigned long long)blocks, nseg, longest, critical_blocks_, n_entry, n_failed, n_redo);
     tm.stop(&stats_.ms_resolve);
-    done = n_dirty == 0;
+    done = n_redo == 0;
   }
-  dev_free(list_dev);
+  dev_free(first_dev);
   dev_free(start_dev);
   dev_free(dirty_dev);
+  dev_free(reparsed_dev);
   if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search (live chains) did not reach a fixed point");
   final_flags_ = which;
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;

@@ -439,10 +439,39 @@ static LiveIndex emu_live_index(const Lz77Params& P, const Lz77Buffers& B, const
   ix.entry = L.entry[which];
   ix.key_first = B.key_first;
   ix.key_last = B.key_last;
+  ix.slot_of = L.slot_of;
   ix.count_base = B.count_base;
   ix.reset_pos = P.reset_pos;
   ix.reset_vis = P.reset_vis;
   return ix;
+}
+
+static ChainTables emu_chain_tables(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int flags_out) {
+  const DeviceTables& dt = dev_tables();
+  ChainTables T;
+  T.text = B.text;
+  T.info = nullptr;
+  T.sorted = nullptr;
+  T.rows = nullptr;
+  T.run_end = nullptr;
+  T.work = nullptr;
+  T.search_log = B.search_log;
+  T.flags_next = B.flags[flags_out];
+  T.cmds = B.cmds;
+  T.dict_hash = dt.dict_hash;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.dist_postfix_bits = P.dist_postfix_bits;
+  T.num_direct_distance_codes = P.num_direct_distance_codes;
+  T.keys = B.keys;
+  T.live_num = L.num;
+  T.live_buckets = L.buckets;
+  return T;
+}
+
+void lz77_live_slots(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L) {
+  for (uint32_t i = 0; i < P.total_bytes; ++i) L.slot_of[B.by_key[i]] = i;
 }
 
 void lz77_live_index(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which) {
@@ -457,55 +486,44 @@ void lz77_live_index(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffer
   L.rank[which][n] = r;
 }
 
-void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* list, const uint32_t* start,
+void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first, const uint32_t* start,
                            uint32_t count) {
   const LiveIndex ix = emu_live_index(P, B, L, which);
   const size_t K = (size_t)1 << P.bucket_bits;
   for (uint32_t i = 0; i < count; ++i) {
-    const size_t k = list[i];
-    for (uint32_t key = 0; key < K; ++key)
-      br_live_materialise_key(ix, key, start[i], P.block_bits, L.num + k * K, L.buckets + ((k * K) << P.block_bits), L.consulted + k * 2 * K, (uint32_t)K);
+    const size_t t = first[i] / L.span_blocks;
+    for (uint32_t key = 0; key < K; ++key) br_live_materialise_key(ix, key, start[i], P.block_bits, L.num + t * K, L.buckets + ((t * K) << P.block_bits));
   }
 }
 
-void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* list, uint32_t count,
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first, uint32_t count,
                      uint32_t warm_blocks) {
-  const DeviceTables& dt = dev_tables();
-  ChainTables T;
-  T.text = B.text;
-  T.info = nullptr;
-  T.sorted = nullptr;
-  T.rows = nullptr;
-  T.run_end = nullptr;
-  T.work = nullptr;
-  T.flags_next = B.flags[which ^ 1];
-  T.cmds = B.cmds;
-  T.dict_hash = dt.dict_hash;
-  T.dict_data = dt.dict_data;
-  T.dict_offsets_by_length = dt.dict_offsets_by_length;
-  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
-  T.dist_postfix_bits = P.dist_postfix_bits;
-  T.num_direct_distance_codes = P.num_direct_distance_codes;
-  T.keys = B.keys;
-  T.live_num = L.num;
-  T.live_buckets = L.buckets;
-  T.live_consulted = L.consulted;
+  const ChainTables T = emu_chain_tables(P, B, L, which ^ 1);
   ChainScratchT<false, false> scratch;
-  for (uint32_t i = 0; i < count; ++i) br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, list[i], warm_blocks);
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t t = first[i] / L.span_blocks;
+    const uint32_t last = std::min<uint32_t>((t + 1) * L.span_blocks, P.num_segments);
+    br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t, warm_blocks);
+  }
 }
 
-void lz77_live_validate(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int prev, int next, uint8_t* dirty) {
-  memset(L.changed_key, 0, 65536);
-  for (uint32_t q = 0; q < P.total_bytes; ++q)
-    if ((B.flags[prev][q] ^ B.flags[next][q]) & (kFlagStored | kFlagMasked)) L.changed_key[B.keys[q]] = 1;
-  const LiveIndex a = emu_live_index(P, B, L, prev), b = emu_live_index(P, B, L, next);
-  const size_t K = (size_t)1 << P.bucket_bits;
-  for (uint32_t k = 0; k < L.tables; ++k) {
-    const uint8_t* noted = L.consulted + (size_t)k * 2 * K;
-    for (uint32_t key = 0; key < K && !dirty[k]; ++key) {
-      if (!L.changed_key[key] || !(noted[key] | noted[K + key])) continue;
-      if (br_live_ring_differs(a, b, key, B.segments[k].blk_start, 1u << P.block_bits, noted[key] != 0, noted[K + key] != 0)) dirty[k] = 1;
-    }
+void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int prev, int next, const SegGeometry& geo,
+                      const uint8_t* reparsed, uint8_t* dirty) {
+  if (prev >= 0) {
+    memset(L.changed_key, 0, 65536);
+    for (uint32_t q = 0; q < P.total_bytes; ++q)
+      if ((B.flags[prev][q] ^ B.flags[next][q]) & (kFlagStored | kFlagMasked)) L.changed_key[B.keys[q]] = 1;
+  }
+  const LiveIndex ix = emu_live_index(P, B, L, next);
+  const ChainTables T = emu_chain_tables(P, B, L, next);
+  ChainScratchT<false, false> scratch;
+  for (uint32_t p = geo.first_block_start; p < P.total_bytes; ++p) {
+    if (!(B.flags[next][p] & kFlagSearched)) continue;
+    const uint32_t block = (p - geo.prefix_bytes) / geo.block_bytes;
+    if (dirty[block]) continue;
+    if (prev >= 0 && !reparsed[block] && !L.changed_key[B.keys[p]]) continue;
+    const uint32_t blk_end = std::min<uint64_t>(P.total_bytes, (uint64_t)geo.prefix_bytes + ((uint64_t)block + 1) * geo.block_bytes);
+    if (!br_verify_search<false>(P, T, ix, scratch, p, blk_end)) dirty[block] = 1;
   }
 }
 
