@@ -35,11 +35,6 @@ import os
 import sys
 import time
 
-# The oracle as the CHECKER of the product runs in the product's view of one reference behaviour the device path does not
-# model yet (masked H5 store-range entries past the first ring revolution, tests/orc.py / DESIGN.md section 6).  None of the
-# bench workloads but the multi-shard one (shards under an H5 hasher) is touched by it; the CPU baseline leg times a
-# one-shot H6 workload and is the same either way.
-os.environ.setdefault("ORC_H5_ABSOLUTE_STORE_RANGE", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -136,7 +131,7 @@ def other_workloads(torch, bm, lib, enc, frozen):
     """BASELINE configs[2], [4], zero fill, and configs[3] cut to 1 GiB, at their stated sizes on this one GPU"""
     import large_cases
     res = []
-    for name in ("c3_enwik_256MiB_q9", "c5_xorshift_1GiB_q5", "zero_1GiB_q5", "c4_silesia_1GiB_multi8"):
+    for name in ("c3_enwik_256MiB_q9", "c5_xorshift_1GiB_q5", "zero_1GiB_q5", "c4_silesia_1GiB_multi8_hinted", "c4_silesia_128MiB_multi8_h5"):
         if name not in frozen:
             continue
         case = large_cases.CASES[name]
@@ -147,11 +142,13 @@ def other_workloads(torch, bm, lib, enc, frozen):
         if case.get("shards"):
             # host buffers in, host buffer out (BrotliEncoderCompressMulti C ABI): the PCIe copies are inside the time
             params = {bm.BROTLI_PARAM_QUALITY: case["quality"], bm.BROTLI_PARAM_LGWIN: case["lgwin"]}
-            sec, out = timed_steps(lambda: bytes(lib.BrotliCompress(data, params, case["shards"])), 1, 1, torch)
-            entry["residency"] = "host to host through BrotliEncoderCompressMulti (%d shards back to back on one GPU)" % case["shards"]
-            entry["known_divergence"] = ("shards run under an H5 hasher and are longer than the ring buffer: the frozen hash is the "
-                                         "oracle's with absolute H5 store-range entries (the product's behaviour, as in C), not the "
-                                         "reference's masked ones -- DESIGN.md section 6")
+            if case.get("hint"):
+                params[bm.BROTLI_PARAM_SIZE_HINT] = case["hint"]
+            sec, out = timed_steps(lambda: bytes(lib.BrotliCompress(data, params, case["shards"])), 1, 0 if not case.get("hint") else 1, torch)
+            entry["residency"] = "host to host through BrotliEncoderCompressMulti (%d shards on one GPU)" % case["shards"]
+            entry["hasher"] = ("H6 shards: the caller states the input size (BROTLI_PARAM_SIZE_HINT, as c/brotli.c does)" if case.get("hint") else
+                               "H5 shards (no size hint): masked ring entries past the 8 MiB ring buffer, every shard parsed by one live chain -- "
+                               "the speed of one wavefront per shard (DESIGN.md)")
         else:
             dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
             params = [(bm.BROTLI_PARAM_QUALITY, case["quality"]), (bm.BROTLI_PARAM_LGWIN, case["lgwin"]),
@@ -179,7 +176,7 @@ def config4(torch, dist, bm, lib, enc, rank, world, frozen, steps):
     import large_cases
     import synth
     from brotli_mi355x import multi
-    name = "c4_silesia_1GiB_multi8"
+    name = "c4_silesia_1GiB_multi8_hinted"
     if name not in frozen:
         return {"workload": name, "skipped": "no frozen oracle hash (tools/freeze_large_hashes.py)"}
     total, nshards = frozen[name]["input_bytes"], 8
@@ -191,7 +188,7 @@ def config4(torch, dist, bm, lib, enc, rank, world, frozen, steps):
         piece = synth.silesia_range(plan, lo, end)
         mine[s] = (piece[:start - lo], torch.frombuffer(bytearray(piece[start - lo:]), dtype=torch.uint8).cuda(), end - start)
     gen_s = time.time() - t0
-    params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN)]
+    params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN), (bm.BROTLI_PARAM_SIZE_HINT, min(total, 1 << 30))]
 
     def shard_input(s):
         prefix, dev, nbytes = mine[s]
@@ -220,8 +217,8 @@ def config4(torch, dist, bm, lib, enc, rank, world, frozen, steps):
         elapsed = float(tmax.item())
     if rank != 0:
         return None
-    return {"workload": "1 GiB Silesia-like mix (SURVEY 8d C4 recipe), quality=5, lgwin=22, BrotliEncoderCompressMulti semantics with 8 shards of "
-                        "128 MiB dealt round-robin to %d GPU(s), gathered over RCCL, stitched on rank 0" % world,
+    return {"workload": "1 GiB Silesia-like mix (SURVEY 8d C4 recipe), quality=5, lgwin=22, size hint = input size, BrotliEncoderCompressMulti "
+                        "semantics with 8 shards of 128 MiB dealt round-robin to %d GPU(s), gathered over RCCL, stitched on rank 0" % world,
             "scaling": "strong", "n_gpus": world, "steps": steps, "value": round(total * steps / elapsed / 1e6, 1), "unit": "MB/s",
             "ms_per_step": round(elapsed / steps * 1e3, 1), "compressed_bytes": len(out),
             "identical_to_cpu_oracle": hashlib.sha256(out).hexdigest() == frozen[name]["stream_sha256"],
@@ -291,9 +288,10 @@ def main():
     work_fn = lib.lib.brotli_mi355x_last_parse_work
     work_fn.argtypes = [ctypes.POINTER(ctypes.c_double)]
     work_fn.restype = None
-    params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN)]
-    if not shard_job:
-        params.append((bm.BROTLI_PARAM_SIZE_HINT, per_gpu))  # BrotliEncoderCompress sets SIZE_HINT = input size
+    # (BrotliEncoderCompress sets SIZE_HINT = input size; the shard job states the size of the whole stream the same way, like
+    # c/brotli.c: without it the shards' hashers are H5, whose masked ring entries serialise the parse -- config4_h5 in
+    # other_workloads measures that)
+    params = [(bm.BROTLI_PARAM_QUALITY, QUALITY), (bm.BROTLI_PARAM_LGWIN, LGWIN), (bm.BROTLI_PARAM_SIZE_HINT, min(total, 1 << 30))]
     st = enc.stats
     job = multi.DeviceShardJob(dist, lib, enc, rank, world, per_gpu) if shard_job else None
 
@@ -375,7 +373,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%d MiB synthetic English-like text per GPU (word-bigram Markov over alice29 tokens), quality=5, lgwin=22, "
                                "%s" % (args.mib, "one-shot BrotliEncoderCompress semantics (H6 hasher)" if not shard_job else
-                                       "one stream of %d MiB, compress_multi shard per GPU + RCCL gather + BroCatli stitch" % (total >> 20)),
+                                       "one stream of %d MiB, size hint = stream size, compress_multi shard per GPU + RCCL gather + BroCatli stitch" % (total >> 20)),
                    "input_bytes_total": total, "compressed_bytes": len(comp), "ratio": round(total / max(1, len(comp)), 4),
                    "segment_bytes": int(seg_bytes), "lz77_rounds_per_step": agg["rounds"] / args.steps,
                    "stage_ms_last_step": {"lz77": round(lz_ms, 2), "metablock": round(mb_ms, 2), "phases": [round(x, 2) for x in phases], "library_total": round(lib_ms, 2)}},
@@ -395,7 +393,7 @@ def main():
                      "searches_final_parse": S, "commands": K},
     }
     if shard_job and world > 1:
-        key = "text_%dx64MiB_multi%d" % (world, world)
+        key = "text_%dx64MiB_multi%d_hinted" % (world, world)
         if key in frozen and args.mib == 64:
             line["config"]["identical_to_cpu_oracle"] = hashlib.sha256(comp).hexdigest() == frozen[key]["stream_sha256"]
     if not args.no_extras and not shard_job:

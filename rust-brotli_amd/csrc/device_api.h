@@ -215,6 +215,7 @@ struct LiveBuffers {
   uint32_t* rank[2] = {nullptr, nullptr};   // per flags buffer: prefix count of the stored slots          [total_bytes + 1]
   uint32_t* entry[2] = {nullptr, nullptr};  // per flags buffer: ring entries of the stored slots, compacted [total_bytes]
   uint8_t* changed_key = nullptr;           // [65536]
+  LiveBlockState* state = nullptr;          // [blocks] meta-block books at every block entry (ChainTables::live_state)
   uint32_t tables = 0;                      // one per span
   uint32_t span_blocks = 1;                 // blocks per span; table t serves the blocks [t * span_blocks, (t + 1) * span_blocks)
 };
@@ -228,8 +229,7 @@ void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const Live
                            const uint32_t* start_dev, uint32_t count);
 // one chain per listed block first[i]: parses from there to the end of its span (br_parse_live); flags go to flags[which ^ 1],
 // every search is logged in B.search_log, the entries the chains derive for the later blocks of a span to B.entries
-void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count,
-                     uint32_t warm_blocks);
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count);
 // Repeats logged searches against the rings that flags[next] imply (needs lz77_live_index(next)) and sets dirty[block] = 1 where
 // one comes out differently.  prev < 0: every search of every block; otherwise the searches of the blocks with
 // reparsed[block] != 0 and, elsewhere, those whose hash key had a flag change between flags[prev] and flags[next].

@@ -99,6 +99,7 @@ struct ChainTables {
   const uint16_t* keys = nullptr;     // hash key of every position
   uint16_t* live_num = nullptr;       // [tables][1 << bucket_bits]
   uint32_t* live_buckets = nullptr;   // [tables][(1 << bucket_bits) << block_bits]
+  LiveBlockState* live_state = nullptr;  // [blocks]: the meta-block books at the entry of every block (read for the first one)
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -1315,7 +1316,7 @@ struct FlagWriter {
 // `next` receives (in every lane) the entry state this parse hands to the following segment.
 // what a live chain needs of a block's parse to enter the next block by itself (extend_last_command, encode.rs:2435-2437)
 struct BlockTail {
-  uint32_t n_cmds, insert_len, last_dist_code, last_copy_len;
+  uint32_t n_cmds, n_lits, insert_len, ext_len, last_dist_code, last_copy_len;
 };
 
 template <bool kH9, bool kRows, bool kLive = false>
@@ -1558,6 +1559,8 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
 #endif
   if (tail != nullptr) {
     tail->n_cmds = n_cmds;
+    tail->n_lits = n_lits;
+    tail->ext_len = ext_len;
     tail->insert_len = insert_length;
     tail->last_dist_code = last_dist_code;
     tail->last_copy_len = last_copy_len;
@@ -1679,16 +1682,15 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
 }
 
 // One live chain (lz77_live.h): parses the input blocks [first, last) -- live chains are cut one segment per block -- on
-// private copy `table` of the bucket rings, which the launcher has materialised for the start of block first - min(first,
-// warm_blocks).  warm_blocks > 0 (the first round, when the flags of the earlier blocks are a guess and nothing else): the
-// chain first runs dry through those blocks, so that what it sees of the recent past is its own exact stores rather
-// than that guess.  From the second block on the chain derives the entry by itself -- the state it arrives with, and
-// extend_last_command under the rule of encode.rs:2435-2437 on the understanding that the meta-block goes on -- and
-// writes it to entries[] for the host resolver, which replays the flush rule and has the blocks behind a wrong guess
-// parsed again.
+// private copy `table` of the bucket rings, which the launcher has materialised for the start of block `first`.  From
+// the second block on the chain derives the entry by itself, the way Lz77Stage::Resolve does: the state it arrives
+// with, the meta-block flush rule (encode.rs:2454-2477) and extend_last_command (encode.rs:2435-2437) on its own books
+// (LiveBlockState).  What it cannot know -- a meta-block that ends up stored uncompressed hands the distance cache of
+// its start to the next one (encode.rs:1994, 2142) -- shows as a wrong entry when the host resolver replays the exits,
+// and the stream is parsed again from that block.  The entries used go to entries[], the books to live_state[].
 template <bool kRows>
 BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratchT<false, kRows>& s, const Segment* segments, SegEntry* entries,
-                          SegExit* exits, uint32_t first, uint32_t last, uint32_t table, uint32_t warm_blocks) {
+                          SegExit* exits, uint32_t first, uint32_t last, uint32_t table) {
   LiveRing lr;
   const size_t keys_per_table = (size_t)1 << P.bucket_bits;
   lr.num = t.live_num + (size_t)table * keys_per_table;
@@ -1697,48 +1699,59 @@ BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratc
   lr.bits = P.block_bits;
   SegEntry entry = entries[first];
   SegEntry next;
-  uint32_t j = first > warm_blocks ? first - warm_blocks : 0u;
-  if (j < first) {
-    SegEntry e = entries[j];
-    for (; j < first; ++j) {
-      Segment seg = segments[j];
-      seg.flags |= kSegWarmup;
-      e.pos = seg.blk_start;
-      e.ext_allowed = 0;
-      br_parse_segment<false, kRows, true>(P, t, s, seg, e, exits[first], next, &lr);
-      // StitchToPreviousBlock of the block that follows files the last three positions (mod.rs:210-222)
-      if (seg.flags & kSegTailStitched) br_live_store(lr, seg.blk_end - 3u, 1, 3, 1, 0);
-      e = next;
-    }
-    for (int i = 0; i < 4; ++i) entry.cache[i] = e.cache[i];
-    BR_SYNC();
-    if (BR_LANE == 0) entries[first] = entry;
-  }
-  for (j = first; j < last; ++j) {
+  LiveBlockState st = t.live_state[first];
+  uint32_t carry = BR_UNIFORM(entry.insert_len);  // literals pending at the entry of the block
+  const uint32_t max_mb = P.max_metablock_bytes, limit = max_mb / 8;
+  for (uint32_t j = first; j < last; ++j) {
     const Segment seg = segments[j];
     BlockTail tail;
     br_parse_segment<false, kRows, true>(P, t, s, seg, entry, exits[j], next, &lr, &tail);
     if (j + 1 == last) break;
-    if (seg.flags & kSegTailStitched) br_live_store(lr, seg.blk_end - 3u, 1, 3, 1, 0);
-    // the entry of the next block as Lz77Stage::Resolve derives it while the meta-block stays open
+    if (P.reset_pos != 0 && BR_UNIFORM(seg.blk_end) == P.reset_pos) br_live_reset(lr, P.bucket_bits);  // the block that starts there searches an empty table
+    if (seg.flags & kSegTailStitched) br_live_store(lr, seg.blk_end - 3u, 1, 3, 1, 0);  // StitchToPreviousBlock, mod.rs:210-222
+    // ---- the books, as in Lz77Stage::Resolve
+    if (tail.ext_len != 0 && st.last_valid) st.last_copy_len += tail.ext_len;
+    st.mb_cmds += tail.n_cmds;
+    st.mb_lits += tail.n_lits;
+    if (tail.n_cmds != 0) {
+      st.mb_lits += carry;
+      carry = tail.insert_len;
+      st.last_valid = 1;
+      st.last_dist_code = tail.last_dist_code;
+      st.last_copy_len = tail.last_copy_len;
+    } else {
+      carry += tail.insert_len;
+    }
+    const uint32_t be = BR_UNIFORM(seg.blk_end);
+    const bool next_fits = (uint64_t)(be - st.mb_start) + P.block_bytes <= (uint64_t)max_mb;
+    if (!(next_fits && st.mb_lits < limit && st.mb_cmds < limit)) {  // the meta-block is closed here
+      st.mb_start = be;
+      st.mb_cmds = st.mb_lits = 0;
+      st.last_valid = 0;
+      carry = 0;  // (pending literals went into its trailing insert-only command)
+    }
+    // ---- the entry of the next block
     const uint32_t was_exact = entry.dict_exact;
     entry = next;
-    entry.pos = BR_UNIFORM(seg.blk_end);
-    entry.insert_len = tail.insert_len;
+    entry.pos = be;
+    entry.insert_len = carry;
     entry.dict_exact = was_exact;
     entry.head_kind = kHeadNone;
     entry.head_base = entry.head_p1 = 0;
     entry.ext_allowed = 0;
-    if (tail.n_cmds != 0 && tail.insert_len == 0) {
+    if (st.mb_cmds != 0 && carry == 0 && st.last_valid) {
       const uint64_t cmd_dist = (uint64_t)(int64_t)next.cache[0];
-      if (tail.last_dist_code < 16 || (uint64_t)tail.last_dist_code - 15 == cmd_dist) {
-        const uint64_t lpp = (uint64_t)seg.blk_end - tail.last_copy_len;
+      if (st.last_dist_code < 16 || (uint64_t)st.last_dist_code - 15 == cmd_dist) {
+        const uint64_t lpp = (uint64_t)be - st.last_copy_len;
         const uint64_t max_distance = lpp < P.max_backward_limit ? lpp : P.max_backward_limit;
         if (cmd_dist <= max_distance) entry.ext_allowed = 1;
       }
     }
     BR_SYNC();
-    if (BR_LANE == 0) entries[j + 1] = entry;
+    if (BR_LANE == 0) {
+      entries[j + 1] = entry;
+      t.live_state[j + 1] = st;
+    }
   }
 }
 

@@ -1740,6 +1740,7 @@ static ChainTables live_chain_tables(const Lz77Params& P, const Lz77Buffers& B, 
   T.keys = B.keys;
   T.live_num = L.num;
   T.live_buckets = L.buckets;
+  T.live_state = L.state;
   return T;
 }
 
@@ -1812,7 +1813,7 @@ struct LiveParseArgs {
   SegEntry* entries;
   SegExit* exits;
   const uint32_t* first;
-  uint32_t count, span_blocks, warm_blocks;
+  uint32_t count, span_blocks;
 };
 // (a launch has at most a few thousand of these chains, each of them bound by the latency of its own dependent loads:
 // registers matter more than waves per SIMD)
@@ -1825,11 +1826,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
   const uint32_t table = first / a.span_blocks;
   uint32_t last = (table + 1) * a.span_blocks;
   if (last > a.P.num_segments) last = a.P.num_segments;
-  br_parse_live<kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, first, last, table, a.warm_blocks);
+  br_parse_live<kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, first, last, table);
 }
 
-void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count,
-                     uint32_t warm_blocks) {
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count) {
   if (count == 0) return;
   LiveParseArgs a;
   a.P = P;
@@ -1840,7 +1840,6 @@ void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffer
   a.first = first_dev;
   a.count = count;
   a.span_blocks = L.span_blocks;
-  a.warm_blocks = warm_blocks;
   if ((1u << P.block_bits) <= kRowEntries) {
     hipLaunchKernelGGL((k_parse_live<true>), dim3(count), dim3(64), 0, BR_STREAM, a);
   } else {

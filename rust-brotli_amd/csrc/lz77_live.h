@@ -110,6 +110,16 @@ BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint
 #endif
 }
 
+// HasherReset at the reference's 32-bit position wrap (encode.rs:1623-1631, 1705-1710): Prepare() zeroes the ring counters,
+// the bucket contents stay but are never looked at again (mod.rs:1491-1510)
+BR_DEV void br_live_reset(const LiveRing& lr, uint32_t bucket_bits) {
+  BR_SYNC();
+  const uint32_t words = 1u << (bucket_bits - 1);  // two counters per 32-bit word
+  uint32_t* w = (uint32_t*)lr.num;
+  for (uint32_t i = BR_LANE; i < words; i += BR_NLANES) BR_LIVE_ST32(w + i, 0u);
+  BR_SYNC();
+}
+
 // What StoreRange(first, last) of a copy files as masked entries (FlagWriter::copy_value says the same per position):
 // the first 4 * floor(n / 4) positions of a range of n >= 8, from masked_from on.
 BR_DEV void br_live_store_copy(const LiveRing& lr, uint32_t first, uint32_t last, uint32_t masked_from) {

@@ -57,6 +57,7 @@ void Lz77Stage::Release() {
     dev_free(L_.entry[0]);
     dev_free(L_.entry[1]);
     dev_free(L_.changed_key);
+    dev_free(L_.state);
     L_ = LiveBuffers{};
     dev_free(count_base_dev_);
     count_base_dev_ = nullptr;
@@ -109,6 +110,8 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   P_.dist_postfix_bits = params.dist.distance_postfix_bits;
   P_.num_direct_distance_codes = params.dist.num_direct_distance_codes;
   P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
+  P_.block_bytes = block_bytes_;
+  P_.max_metablock_bytes = (uint32_t)MaxMetablockSize(params);
   BuildSegments();
   P_.num_segments = (uint32_t)segments_.size();
 
@@ -145,25 +148,30 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
       BuildSegments();
       P_.num_segments = (uint32_t)segments_.size();
     }
-    // Blocks per chain.  A parse heals from a wrong history within ~100 KB: spans are a multiple of that, so that
-    // what the guessed flags in front of a span do to its head has died out before its tail.
-    uint32_t span = 8;
-    if (const char* e = getenv("BROTLI_MI355X_LIVE_SPAN")) span = std::max(1, atoi(e));
-    const size_t K = (size_t)1 << P_.bucket_bits, T = (segments_.size() + span - 1) / span;
-    L_.span_blocks = span;
-    L_.tables = (uint32_t)T;
-    L_.num = (uint16_t*)dev_alloc_uninit(T * K * 2 + 64);
-    L_.buckets = (uint32_t*)dev_alloc_uninit(((T * K) << P_.block_bits) * 4 + 64);
+    // One chain walks through the whole text.  (Chains over spans of blocks, each on rings materialised from the flags of
+    // the round before, were built and measured first: the parse heals from a wrong history within ~100 KB, but every change
+    // of a flag has a small chance to change a search result up to a window further on, and with masked entries and a
+    // 4 MiB window that cascade does not die out -- every span behind the frontier stayed dirty, one span settled per
+    // round.  DESIGN.md section 10.)
+    const size_t K = (size_t)1 << P_.bucket_bits;
+    L_.span_blocks = (uint32_t)std::max<size_t>(1, segments_.size());
+    L_.tables = 1;
+    L_.num = (uint16_t*)dev_alloc_uninit(K * 2 + 64);
+    L_.buckets = (uint32_t*)dev_alloc_uninit((K << P_.block_bits) * 4 + 64);
+    L_.state = (LiveBlockState*)dev_alloc(segments_.size() * sizeof(LiveBlockState) + 64);
+    live_verify_ = getenv("BROTLI_MI355X_LIVE_VERIFY") != nullptr || getenv("BROTLI_MI355X_SELFTEST") != nullptr;
     L_.slot_of = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
     for (int i = 0; i < 2; ++i) {
       L_.rank[i] = (uint32_t*)dev_alloc_uninit((M + 1) * 4 + 64);
       L_.entry[i] = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
     }
-    // every search is logged; the verification repeats them one by one (lz77_live_verify)
-    B_.search_log = (uint32_t*)dev_alloc(M * kSearchLogWords * 4 + 64);
-    B_.recheck_cap = (uint32_t)(M + 4096);  // (every position can be a searched one)
-    B_.recheck_list = (uint32_t*)dev_alloc_uninit((size_t)B_.recheck_cap * 4 + 64);
-    B_.recheck_count = (uint32_t*)dev_alloc(64);
+    if (live_verify_) {
+      // every search is logged; the verification repeats them one by one against the final flags (lz77_live_verify)
+      B_.search_log = (uint32_t*)dev_alloc(M * kSearchLogWords * 4 + 64);
+      B_.recheck_cap = (uint32_t)(M + 4096);  // (every position can be a searched one)
+      B_.recheck_list = (uint32_t*)dev_alloc_uninit((size_t)B_.recheck_cap * 4 + 64);
+      B_.recheck_count = (uint32_t*)dev_alloc(64);
+    }
     L_.changed_key = (uint8_t*)dev_alloc(65536 + 64);
     B_.changed_cap = kChangedCap;
     B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
@@ -483,6 +491,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
   dirty_entry_.assign(nseg, 0);
   entry_reason_.assign(nseg, 0);
   predicted_entry_.assign(nseg, 0);
+  if (use_live_) live_state_.assign(nseg, LiveBlockState{});
   // reason: bit 1 = the distance cache at the entry differs, bit 0 = anything else
   auto mark = [&](uint32_t k, bool same, uint8_t reason = 1) {
     if (!same) {
@@ -557,6 +566,15 @@ bool Lz77Stage::Resolve(bool final_pass) {
       mark(k0, cache_same && u.ext_allowed == E.ext_allowed, (uint8_t)((ext_same ? 0 : 1) | (cache_same ? 0 : 2)));
     }
     next_entries_[k0] = E;
+    if (use_live_) {
+      LiveBlockState& st = live_state_[k0];
+      st.mb_start = last_flush_pos;
+      st.mb_cmds = (uint32_t)num_commands;
+      st.mb_lits = (uint32_t)num_literals;
+      st.last_valid = last_cmd.valid ? 1u : 0u;
+      st.last_dist_code = last_cmd.dist_code;
+      st.last_copy_len = last_cmd.copy_len;
+    }
     // ---- chain through the segments of the block
     uint32_t carry = last_insert_len;  // literals pending when the segment is entered
     int32_t cur_cache[4];              // dist cache at the entry of segment j (as derived in this pass)
@@ -1027,114 +1045,100 @@ void Lz77Stage::InitEntries() {
   exits_.assign(nseg, SegExit{});
 }
 
-// The rounds of live chains (lz77_live.h).  A chain parses a span of input blocks on a private copy of the bucket rings,
-// materialised for the block it starts at from the flags of the round before.  Round 0 has only a guess of those flags: its
-// chains start a few blocks early and run dry up to their span.  After every round the host resolver chains the exits
-// (entry states, as in RunRounds) and the device repeats the logged searches against the rings the new flags imply; a span
-// is parsed again from its first block whose entry or searches do not hold.  The first block that is still wrong has
-// an exact entry and exact rings, so every round settles at least one block; since a parse heals from a wrong history
-// within ~100 KB, it settles almost all of them.
+// Live chains (lz77_live.h): ONE chain walks through all input blocks on a copy of the reference's bucket rings, which is
+// materialised for its first block from the stored / masked flags of the prefix (custom dictionary, or the window of the
+// stream so far).  The chain enters every further block by itself (flush rule and extend_last_command on its own books);
+// the host resolver then replays the exits like after any other round.  Where it derives another entry than the chain
+// used -- a meta-block that is stored uncompressed hands on the distance cache of its start -- everything in front of that
+// block is final: the rings are materialised again for its start and the chain walks on from there.
+// BROTLI_MI355X_LIVE_VERIFY=1: every search is logged and, at the end, repeated on its own against the ring that the final
+// flags imply for its position (a check of the chain against the definition of the rings, all searches in parallel).
 void Lz77Stage::RunLive() {
   const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
   const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
   Timer tm(prof);
   const uint32_t nseg = (uint32_t)segments_.size();
-  const uint32_t span = L_.span_blocks, nspan = L_.tables;
   InitFlags();
   InitEntries();
+  entries_[0].dict_exact = 1;  // (the chain starts with the true counters of the stream and keeps them)
+  if (P_.use_dictionary) {
+    entries_[0].dict_lookups = (carry_ && carry_->valid) ? carry_->dict_lookups : 0u;
+    entries_[0].dict_matches = (carry_ && carry_->valid) ? carry_->dict_matches : 0u;
+    if (carry_ && carry_->valid && carry_->dict_dead) {
+      entries_[0].dict_lookups = DictTracker::kDeadL;
+      entries_[0].dict_matches = DictTracker::kDeadM;
+    }
+  }
   tm.stop(&stats_.ms_init);
-  uint32_t warm = 2;
-  if (const char* w = getenv("BROTLI_MI355X_LIVE_WARM")) warm = (uint32_t)atoi(w);
-  SegGeometry geo{};
-  geo.prefix_bytes = P_.prefix_bytes;
-  geo.first_block_start = segments_[0].blk_start;
-  geo.block_bytes = block_bytes_;
-  geo.num_blocks = nseg;
-  geo.num_segments = nseg;
-  geo.block_size = 1u << P_.block_bits;
-  uint32_t* first_dev = (uint32_t*)dev_alloc((size_t)nspan * 4 + 64);
-  uint32_t* start_dev = (uint32_t*)dev_alloc((size_t)nspan * 4 + 64);
-  uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
-  uint8_t* reparsed_dev = (uint8_t*)dev_alloc(nseg + 64);
-  PinnedArray<uint32_t> first, start;
-  PinnedArray<uint8_t> failed, reparsed;
-  first.resize_discard(nspan);
-  start.resize_discard(nspan);
-  failed.resize_discard(nseg);
-  reparsed.resize_discard(nseg);
-  std::vector<uint32_t> redo_from(nspan);  // per span: first block to parse again (nseg: none)
-  for (uint32_t t = 0; t < nspan; ++t) redo_from[t] = t * span;
+  uint32_t* first_dev = (uint32_t*)dev_alloc(64);
+  uint32_t* start_dev = (uint32_t*)dev_alloc(64);
+  PinnedArray<uint32_t> first_start;
+  PinnedArray<LiveBlockState> books;
+  first_start.resize_discard(2);
+  books.resize_discard(nseg);
+  for (uint32_t k = 0; k < nseg; ++k) books[k] = LiveBlockState{};
+  books[0].mb_start = P_.prefix_bytes + raw_head_bytes_;
   int which = 0;
-  critical_blocks_ = 0;
-  lz77_live_slots(P_, B_, L_);
-  lz77_live_index(P_, B_, L_, which);
+  uint32_t from = 0;
   const uint32_t max_rounds = getenv("BROTLI_MI355X_MAX_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_MAX_ROUNDS")) : nseg + 8;
   bool done = false;
   for (uint32_t round = 0; round < max_rounds && !done; ++round) {
     stats_.rounds++;
-    const uint32_t w = round == 0 ? warm : 0u;
-    uint32_t count = 0, longest = 0;
-    uint64_t blocks = 0;
-    for (uint32_t k = 0; k < nseg; ++k) reparsed[k] = 0;
-    for (uint32_t t = 0; t < nspan; ++t) {
-      const uint32_t f = redo_from[t];
-      if (f >= nseg) continue;
-      const uint32_t last = std::min(nseg, (t + 1) * span);
-      first[count] = f;
-      start[count] = segments_[f > w ? f - w : 0u].blk_start;
-      // (the chain derives the entries of the later blocks by itself and writes them back)
-      if (round != 0) entries_[f] = next_entries_[f];
-      for (uint32_t k = f; k < last; ++k) reparsed[k] = 1;
-      blocks += last - f + std::min(f, w);
-      longest = std::max(longest, last - f + std::min(f, w));
-      ++count;
+    if (round != 0) {
+      entries_[from] = next_entries_[from];
+      books[from] = live_state_[from];
     }
+    first_start[0] = from;
+    first_start[1] = segments_[from].blk_start;
     dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
-    dev_h2d(first_dev, first.data(), (size_t)count * 4);
-    dev_h2d(start_dev, start.data(), (size_t)count * 4);
-    dev_h2d(reparsed_dev, reparsed.data(), nseg);
-    lz77_live_materialise(P_, B_, L_, which, first_dev, start_dev, count);
+    dev_h2d(L_.state, books.data(), (size_t)nseg * sizeof(LiveBlockState));
+    dev_h2d(first_dev, first_start.data(), 4);
+    dev_h2d(start_dev, first_start.data() + 1, 4);
+    lz77_live_index(P_, B_, L_, which);
+    lz77_live_materialise(P_, B_, L_, which, first_dev, start_dev, 1);
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     tm.stop(&stats_.ms_rank);
-    lz77_live_parse(P_, B_, L_, which, first_dev, count, w);
-    stats_.segments_parsed += blocks;
-    critical_blocks_ += longest;
-    tm.stop(&stats_.ms_parse);
-    lz77_live_index(P_, B_, L_, which ^ 1);
-    dev_memset(dirty_dev, 0, nseg);
-    lz77_live_verify(P_, B_, L_, round == 0 ? -1 : which, which ^ 1, geo, reparsed_dev, dirty_dev);
+    lz77_live_parse(P_, B_, L_, which, first_dev, 1);
+    stats_.segments_parsed += nseg - from;
     dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
-    dev_d2h_async(entries_.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));  // (the chains chose the entries inside their spans)
-    dev_d2h_async(failed.data(), dirty_dev, nseg);
+    dev_d2h_async(entries_.data(), B_.entries, (size_t)nseg * sizeof(SegEntry));  // (the chain chose the entries behind its first block)
     dev_sync();
-    tm.stop(&stats_.ms_rank);
+    tm.stop(&stats_.ms_parse);
     which ^= 1;
     const auto host_t0 = std::chrono::steady_clock::now();
     Resolve(false);
     host_resolve_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-    uint32_t n_entry = 0, n_failed = 0, n_redo = 0;
-    for (uint32_t t = 0; t < nspan; ++t) {
-      redo_from[t] = nseg;
-      const uint32_t last = std::min(nseg, (t + 1) * span);
-      for (uint32_t k = t * span; k < last; ++k) {
-        n_entry += dirty_entry_[k];
-        n_failed += failed[k];
-        if ((dirty_entry_[k] || failed[k]) && redo_from[t] == nseg) redo_from[t] = k;
-      }
-      if (redo_from[t] != nseg) n_redo += last - redo_from[t];
-    }
-    if (debug)
-      fprintf(stderr, "live round %u: %u chains over %llu blocks of %u, longest %u (critical path so far %u blocks); blocks with a wrong entry %u, with a search that does not hold %u; to redo %u\n",
-              round, count, (unsigned long long)blocks, nseg, longest, critical_blocks_, n_entry, n_failed, n_redo);
+    uint32_t wrong = nseg;
+    for (uint32_t k = 0; k < nseg && wrong == nseg; ++k)
+      if (dirty_entry_[k]) wrong = k;
+    if (debug) fprintf(stderr, "live chain from block %u of %u: first block entered in another state than the resolver derives: %d\n", from, nseg, wrong == nseg ? -1 : (int)wrong);
+    if (wrong != nseg && wrong <= from && round != 0) throw std::runtime_error("brotli_mi355x: live chain and resolver disagree about an entry the resolver chose");
     tm.stop(&stats_.ms_resolve);
-    done = n_redo == 0;
+    from = wrong;
+    done = wrong == nseg;
   }
   dev_free(first_dev);
   dev_free(start_dev);
-  dev_free(dirty_dev);
-  dev_free(reparsed_dev);
-  if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search (live chains) did not reach a fixed point");
+  if (!done) throw std::runtime_error("brotli_mi355x: backward-reference search (live chain) did not reach a fixed point");
   final_flags_ = which;
+  if (live_verify_) {
+    SegGeometry geo{};
+    geo.prefix_bytes = P_.prefix_bytes;
+    geo.first_block_start = segments_[0].blk_start;
+    geo.block_bytes = block_bytes_;
+    geo.num_blocks = nseg;
+    geo.num_segments = nseg;
+    geo.block_size = 1u << P_.block_bits;
+    uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
+    std::vector<uint8_t> failed(nseg);
+    lz77_live_slots(P_, B_, L_);
+    lz77_live_index(P_, B_, L_, which);
+    lz77_live_verify(P_, B_, L_, -1, which, geo, nullptr, dirty_dev);
+    dev_d2h(failed.data(), dirty_dev, nseg);
+    dev_free(dirty_dev);
+    for (uint32_t k = 0; k < nseg; ++k)
+      if (failed[k]) throw std::runtime_error("brotli_mi355x: live chain verification failed in block " + std::to_string(k));
+  }
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
 }
 

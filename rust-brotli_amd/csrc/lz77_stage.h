@@ -147,7 +147,8 @@ class Lz77Stage {
   Lz77Buffers B_{};
   LiveBuffers L_{};    // live chains (lz77_live.h)
   bool use_live_ = false;
-  uint32_t critical_blocks_ = 0;  // RunLive: sum over the rounds of the longest chain (in blocks) -- what the wall clock sees
+  bool live_verify_ = false;
+  std::vector<LiveBlockState> live_state_;  // Resolve(): the meta-block books at the entry of every block (live chains)
   uint32_t input_bytes_ = 0;
   uint32_t raw_head_bytes_ = 0;
   uint32_t segment_bytes_ = 4096;

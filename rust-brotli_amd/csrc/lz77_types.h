@@ -55,8 +55,20 @@ struct Lz77Params {
   // of every later search (kFlagMasked, lz77_chain.h).  kNeverMasked: not an H5 hasher, or the text ends inside the first
   // ring-buffer revolution of the stream.  Anything else is parsed by live chains (lz77_live.h).
   uint32_t masked_from;
+  // the meta-block flush rule (encode.rs:2454-2477) for chains that walk from block to block by themselves (live chains)
+  uint32_t block_bytes;          // 1 << lgblock
+  uint32_t max_metablock_bytes;  // MaxMetablockSize; the limits on literals and commands are an eighth of it
 };
 static constexpr uint32_t kNeverMasked = 0xffffffffu;
+
+// What a live chain knows about the open meta-block when it enters a block (Lz77Stage::Resolve keeps the same books):
+// where it started, the commands and literals in it so far, and its last command -- extend_last_command (encode.rs:360-400)
+// runs at the start of a block only if there is one, nothing is pending behind it and its distance is the last distance.
+struct LiveBlockState {
+  uint32_t mb_start, mb_cmds, mb_lits;
+  uint32_t last_valid, last_dist_code, last_copy_len;
+  uint32_t pad[2];
+};
 // candidate rows (lz77_chain.h): entries per position, end-of-row marker
 static constexpr uint32_t kRowEntries = 16;
 static constexpr uint32_t kRowEnd = 0xffffffffu;

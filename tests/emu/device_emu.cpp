@@ -467,6 +467,7 @@ static ChainTables emu_chain_tables(const Lz77Params& P, const Lz77Buffers& B, c
   T.keys = B.keys;
   T.live_num = L.num;
   T.live_buckets = L.buckets;
+  T.live_state = L.state;
   return T;
 }
 
@@ -496,14 +497,13 @@ void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const Live
   }
 }
 
-void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first, uint32_t count,
-                     uint32_t warm_blocks) {
+void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first, uint32_t count) {
   const ChainTables T = emu_chain_tables(P, B, L, which ^ 1);
   ChainScratchT<false, false> scratch;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t t = first[i] / L.span_blocks;
     const uint32_t last = std::min<uint32_t>((t + 1) * L.span_blocks, P.num_segments);
-    br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t, warm_blocks);
+    br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t);
   }
 }
 

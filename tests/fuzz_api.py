@@ -2,8 +2,6 @@
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
 oracle."""
 import os, sys, time
-# the product does not model the reference's masked H5 store-range entries yet (tests/orc.py): compare in its view
-os.environ.setdefault("ORC_H5_ABSOLUTE_STORE_RANGE", "1")
 import synth, orc
 import test_cabi
 kind = "emu" if len(sys.argv) > 3 and sys.argv[3] == "emu" else "gpu"

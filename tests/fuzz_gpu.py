@@ -2,8 +2,6 @@
 emulation build (same host driver and chain code, no GPU needed).  Every case = (content, size, quality,
 lgwin, segment size) -> the HIP path's stream must equal the oracle's one-shot stream."""
 import os, sys, time
-# the product does not model the reference's masked H5 store-range entries yet (tests/orc.py): compare in its view
-os.environ.setdefault("ORC_H5_ABSOLUTE_STORE_RANGE", "1")
 import synth, emu, orc
 use_emu = len(sys.argv) > 3 and sys.argv[3] == "emu"
 max_bytes = int(float(sys.argv[4]) * (1 << 20)) if len(sys.argv) > 4 else (3 << 20)

@@ -14,11 +14,19 @@ CASES = {
     "c5_xorshift_1GiB_q5": dict(make=lambda: synth.random_bytes(1 << 30, 0x5EED000000000005), quality=5, lgwin=22),
     # zero fill, 1 GiB (north_star's fifth distribution)
     "zero_1GiB_q5": dict(make=lambda: bytes(1 << 30), quality=5, lgwin=22),
-    # configs[3] at a quarter of its size: Silesia-like mix, BrotliEncoderCompressMulti with 8 shards of 128 MiB.
+    # configs[3] at a quarter of its size: Silesia-like mix, BrotliEncoderCompressMulti with 8 shards of 128 MiB, the caller
+    # stating the size of the input like c/brotli.c does (BROTLI_PARAM_SIZE_HINT; the reference's own multi tests pass it too,
+    # src/ffi/multicompress/test.rs:40): every shard gets an H6 hasher (encode.rs:863-893).
     # `seeds`: the reference encoder FAILS on some shardings of this kind of data (a match cut to one byte at the end of the
     # custom dictionary; the oracle raises ReferencePanics): the first seed it accepts is frozen.
-    "c4_silesia_1GiB_multi8": dict(make=lambda seed: synth.silesia_like(1 << 30, seed), quality=5, lgwin=22, shards=8,
-                                   seeds=[0x5EED000000000004 + i for i in range(16)]),
+    "c4_silesia_1GiB_multi8_hinted": dict(make=lambda seed: synth.silesia_like(1 << 30, seed), quality=5, lgwin=22, shards=8, hint=1 << 30,
+                                          seeds=[0x5EED000000000004 + i for i in range(16)]),
+    # The same call WITHOUT a size hint: the shards' hashers are chosen in set_custom_dictionary before any size is known --
+    # H5, whose StoreRangeOptBatch files masked ring entries once a shard (with its prefix) has passed the 8 MiB ring buffer
+    # (mod.rs:1163-1232).  Such a shard is parsed by one live chain (lz77_live.h), at the speed of one wavefront: 8 shards of
+    # 16 MiB keep the test short.
+    "c4_silesia_128MiB_multi8_h5": dict(make=lambda seed: synth.silesia_like(128 << 20, seed, min_segment=256 << 10, max_segment=8 << 20),
+                                        quality=5, lgwin=22, shards=8, seeds=[0x5EED000000000004 + i for i in range(16)]),
     # (configs[3] itself -- 4 GiB, 8 shards of 512 MiB -- cannot be frozen: the reference FAILS on it, on every one of the
     # 13 seeds tried, also when no shard boundary lies in periodic data.  fix_unbroken_len (mod.rs:42-54) is applied to
     # ring-buffer indices, so the "no match across the custom-dictionary end" rule returns with every revolution of the
@@ -27,16 +35,19 @@ CASES = {
 }
 
 
-# bench.py --gpus N (weak scaling): one stream of N x 64 MiB text, compress_multi with N shards
+# bench.py --gpus N (weak scaling): one stream of N x 64 MiB text, compress_multi with N shards and the size of the stream as
+# BROTLI_PARAM_SIZE_HINT (the N = 1 step is BrotliEncoderCompress, which sets it too)
 for _n in (2, 4, 8):
-    CASES["text_%dx64MiB_multi%d" % (_n, _n)] = dict(make=(lambda n=_n: synth.markov_text(n * (64 << 20))), quality=5, lgwin=22, shards=_n,
-                                                    bench_only=True)
+    CASES["text_%dx64MiB_multi%d_hinted" % (_n, _n)] = dict(make=(lambda n=_n: synth.markov_text(n * (64 << 20))), quality=5, lgwin=22, shards=_n,
+                                                           hint=_n * (64 << 20), bench_only=True)
 
 
-# a single stream longer than the reference's 32-bit position wrap (hasher reset at 3 GiB), fed CompressorWriter style in
-# 4 MiB writes: bounded-memory streaming at full scale (tests/test_streaming.py has the scaled-down versions)
-CASES["stream_4GiB_q5_w22"] = dict(make=lambda: synth.markov_text(4 << 30, 0x5EED00000000000A), quality=5, lgwin=22, writer_chunk=4 << 20,
-                                   bench_only=True)
+# a single stream longer than the reference's 32-bit position wrap (hasher reset at 3 GiB), fed in 4 MiB writes with
+# PROCESS, then FINISH without input (BrotliCompressCustomIo's pattern), BROTLI_PARAM_SIZE_HINT = 1 GiB (H6: without a hint
+# the stream runs under H5 with masked ring entries, i.e. at the speed of one live chain -- tests/test_streaming.py has
+# that case at 40 MiB): bounded-memory streaming at full scale
+CASES["stream_4GiB_q5_w22_hinted"] = dict(make=lambda: synth.markov_text(4 << 30, 0x5EED00000000000A), quality=5, lgwin=22, writer_chunk=4 << 20,
+                                          hint=1 << 30, bench_only=True)
 
 
 def make_input(name, frozen=None):

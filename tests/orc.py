@@ -60,27 +60,7 @@ def lib():
         L.orc_bits_entropy.restype = ctypes.c_float
         L.orc_bits_entropy.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t]
         _lib = L
-        if os.environ.get("ORC_H5_ABSOLUTE_STORE_RANGE"):
-            ctypes.c_int.in_dll(L, H5_SWITCH).value = 1
     return _lib
-
-
-# KNOWN DIVERGENCE of the product: rust-brotli's AdvHasher::StoreRangeOptBatch (H5 family,
-# backward_references/mod.rs:1163-1232) writes MASKED positions into the bucket rings; past the first revolution of the ring
-# buffer FindLongestMatch takes such an entry for "further away than max_backward" and ends its walk there.  The oracle
-# restates that (default).  The device path does not model it yet: it behaves like the C encoder, which stores absolute
-# positions.  Tests that compare the PRODUCT with the oracle therefore run the oracle with this switch on; it changes
-# nothing unless an H5 hasher meets positions beyond the ring buffer (lgwin < 19 or a size hint <= 4 MiB, AND more than
-# 2 << max(lgwin, lgblock) bytes).  tests/conftest.py applies it per test module; ORC_H5_ABSOLUTE_STORE_RANGE=1 applies it
-# at load time (tools/freeze_large_hashes.py, fuzz drivers).
-H5_SWITCH = "orc_test_c109_adv_store_range"
-
-
-def set_h5_absolute_store_range(on):
-    cell = ctypes.c_int.in_dll(lib(), H5_SWITCH)
-    old = cell.value
-    cell.value = 1 if on else 0
-    return old
 
 
 class ReferencePanics(Exception):

@@ -3,6 +3,7 @@ tests/emu (one lane per wave, serial loops instead of kernels), against the orac
 speculative-parse resolver, meta-block planning, stitching and C-ABI state machine without a GPU; the
 `-m gpu` tests repeat the same comparisons through the HIP kernels."""
 import glob
+import ctypes
 import os
 
 import pytest
@@ -171,42 +172,54 @@ def test_incompressible_input_converges_in_a_few_rounds(L):
     assert st["rounds"] <= 8, st  # 29 before
 
 
-@pytest.mark.oracle_as_is
-@pytest.mark.xfail(reason="known divergence: the reference's StoreRangeOptBatch writes masked positions into the H5 rings "
-                          "(mod.rs:1163-1232), which end FindLongestMatch's bucket walk past the first ring revolution; the "
-                          "device path stores absolute positions like the C encoder (DESIGN.md section 6)", strict=False)
-def test_known_divergence_h5_past_the_first_ring_revolution(L):
-    """1 MiB at lgwin 17 (256 KiB ring) with the H5 hasher: against the oracle AS IT IS.  Every other product test runs the
-    oracle with orc_test_c109_adv_store_range on (tests/conftest.py), under which the same input is byte-identical:"""
-    data = synth.markov_text(1 << 20)
-    out, _ = emu.encode_stream(L, data, [(Q, 5), (W, 17), (SH, len(data))])
-    old = orc.set_h5_absolute_store_range(True)
-    try:
-        assert out == orc.compress(data, 5, 17)  # the product's view: identical
-    finally:
-        orc.set_h5_absolute_store_range(bool(old))
-    assert out == orc.compress(data, 5, 17)      # the reference as it is: differs (xfail)
-
-
-@pytest.mark.oracle_as_is
-def test_masked_h5_entries_modelled_on_the_emulation_build(L):
-    """The staged fix for the known divergence above (BROTLI_MI355X_MASKED_H5=1, off by default because the gfx950 row and
-    flag-diff kernels do not take the third flag bit yet): the chains mark the positions the reference's StoreRangeOptBatch
-    files as masked entries (kFlagMasked, FlagWriter::copy_value), the row lookback ends at them (br_collect_row), the bit
-    travels with the stored flags of a stream's window.  Against the oracle AS IT IS: one-shot, shards, trimmed streams."""
+def test_h5_past_the_first_ring_revolution(L):
+    """The reference's StoreRangeOptBatch writes MASKED positions into the H5 rings (mod.rs:1163-1232), which end
+    FindLongestMatch's bucket walk once the stream has passed one ring-buffer size (mod.rs:1763-1775) -- where the C encoder
+    stores absolute positions (the oracle keeps that as a switch for its comparison with libbrotlienc).  Such inputs are
+    parsed by a live chain on the reference's own bucket rings (lz77_live.h): one-shot, shards, qualities 5..8, with the
+    verification pass that repeats every logged search against the rings the final flags imply."""
     import test_cabi
-    os.environ["BROTLI_MI355X_MASKED_H5"] = "1"
+    os.environ["BROTLI_MI355X_LIVE_VERIFY"] = "1"
     try:
-        for data, w in ((synth.markov_text(1 << 20), 17), (synth.mixed(1 << 20), 17), (synth.markov_text(2 << 20)[:1500000], 18)):
+        data = synth.markov_text(1 << 20)
+        out, st = emu.encode_stream(L, data, [(Q, 5), (W, 17), (SH, len(data))])
+        assert out == orc.compress(data, 5, 17)
+        assert st["lz77_rounds"] == 1
+        cell = ctypes.c_int.in_dll(orc.lib(), "orc_test_c109_adv_store_range")
+        cell.value = 1
+        try:
+            assert out != orc.compress(data, 5, 17)  # (the C behaviour is another stream: 871 791 bytes instead of 1 092 273 on 3 MiB)
+        finally:
+            cell.value = 0
+        for data, w in ((synth.mixed(1 << 20), 17), (synth.markov_text(2 << 20)[:1500000], 18), (synth.stretches(1 << 20), 17), (bytes(1 << 20), 17)):
             out, _ = emu.encode_stream(L, data, [(Q, 5), (W, w), (SH, len(data))])
             assert out == orc.compress(data, 5, w)
-        # qualities 6..8 (rank structures: the ring entry is held as position | kMaskedEntry, the probe breaks on it)
+        # incompressible input: a meta-block stored uncompressed hands on the distance cache of its start, which the chain
+        # cannot know -- the resolver sends it back to that block
+        data = synth.random_bytes(2 << 20)
+        out, st = emu.encode_stream(L, data, [(Q, 5), (W, 17), (SH, len(data))])
+        assert out == orc.compress(data, 5, 17)
+        assert st["lz77_rounds"] >= 2
+        # qualities 6..8 (rings of 32..128 entries)
         data = synth.mixed(1 << 20)
-        for q in (6, 8):
+        for q in (6, 7, 8):
             out, _ = emu.encode_stream(L, data, [(Q, q), (W, 17), (SH, len(data))])
             assert out == orc.compress(data, q, 17)
         lib = test_cabi._load("emu")
         t = synth.markov_text(900000, 2)
         assert bytes(lib.BrotliCompress(t, {Q: 5, W: 17}, 3)) == orc.compress_multi(t, [(Q, 5), (W, 17)], 3)
     finally:
-        del os.environ["BROTLI_MI355X_MASKED_H5"]
+        del os.environ["BROTLI_MI355X_LIVE_VERIFY"]
+
+
+def test_live_chain_on_inputs_without_masked_entries(L):
+    """BROTLI_MI355X_LIVE=1 sends any H5 / H6 input through the live chain: the same streams as the speculative parse"""
+    os.environ["BROTLI_MI355X_LIVE"] = "1"
+    os.environ["BROTLI_MI355X_LIVE_VERIFY"] = "1"
+    try:
+        for data, q, w in ((synth.alice(), 5, 22), (synth.markov_text(2 << 20), 5, 22), (synth.mixed(1 << 20), 7, 22), (synth.markov_text(5 << 20)[:4500000], 5, 22)):
+            out, _ = emu.encode_stream(L, data, [(Q, q), (W, w), (SH, len(data))])
+            assert out == orc.compress(data, q, w)
+    finally:
+        del os.environ["BROTLI_MI355X_LIVE"]
+        del os.environ["BROTLI_MI355X_LIVE_VERIFY"]

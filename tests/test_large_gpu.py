@@ -82,16 +82,30 @@ def test_zero_fill_1GiB(L):
     assert orc.decompress(out, len(data)) == data
 
 
-def test_config4_silesia_like_1GiB_multi_8_shards(L):
-    """BASELINE config 4 at a quarter of its size on one GPU: BrotliEncoderCompressMulti with 8 shards of 128 MiB over a
-    Silesia-like mix, byte-identical to the oracle's compress_multi (src/enc/threading/mod.rs:333-453)"""
+def _multi(name):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "rust-brotli_amd"))
     import brotli_mi355x
-    name = "c4_silesia_1GiB_multi8"
+    case = large_cases.CASES[name]
     data = _input(name)
-    got = bytes(brotli_mi355x.default_library().BrotliCompress(data, {1: 5, 2: 22}, 8))
+    params = {1: case["quality"], 2: case["lgwin"]}
+    if case.get("hint"):
+        params[5] = case["hint"]
+    got = bytes(brotli_mi355x.default_library().BrotliCompress(data, params, case["shards"]))
     _check(name, got, data)
+
+
+def test_config4_silesia_like_1GiB_multi_8_shards(L):
+    """BASELINE config 4 at a quarter of its size on one GPU: BrotliEncoderCompressMulti with 8 shards of 128 MiB over a
+    Silesia-like mix and the input size as BROTLI_PARAM_SIZE_HINT (H6 shards), byte-identical to the oracle's compress_multi
+    (src/enc/threading/mod.rs:333-453)"""
+    _multi("c4_silesia_1GiB_multi8_hinted")
+
+
+def test_config4_without_a_size_hint_h5_shards_past_the_ring(L):
+    """the same call without a size hint: H5 shards, masked ring entries from 8 MiB on (mod.rs:1163-1232) -- every shard is
+    parsed by one live chain (lz77_live.h); 8 shards of 16 MiB"""
+    _multi("c4_silesia_128MiB_multi8_h5")
 
 
 def test_silesia_like_64MiB_multi_8_shards_against_live_oracle(L):
@@ -106,17 +120,17 @@ def test_silesia_like_64MiB_multi_8_shards_against_live_oracle(L):
 
 
 def test_stream_4GiB_bounded_memory(L):
-    """A single 4 GiB stream fed CompressorWriter style (4 MiB writes, then FINISH) through BrotliEncoderCompressStream:
+    """A single 4 GiB stream (4 MiB writes with PROCESS, then FINISH; size hint 1 GiB) through BrotliEncoderCompressStream:
     encoded batch by batch with only a window of the stream kept (the encoder's input buffer never exceeds window + batch),
     through the reference's hasher reset at the 3 GiB position wrap (encode.rs:1623-1631, 1705-1710), output handed out
     during PROCESS -- and the same bytes as the oracle's stream encoder fed the same way (frozen: it needs three minutes)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "rust-brotli_amd"))
     import brotli_mi355x
-    name = "stream_4GiB_q5_w22"
+    name = "stream_4GiB_q5_w22_hinted"
     data = _input(name)
     lib = brotli_mi355x.default_library()
-    e = lib.encoder(params=[(Q, 5), (W, 22)])
+    e = lib.encoder(params=[(Q, 5), (W, 22), (SH, large_cases.CASES[name]["hint"])])
     h = hashlib.sha256()
     total = 0
     chunk = large_cases.CASES[name]["writer_chunk"]

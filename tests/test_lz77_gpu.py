@@ -91,10 +91,9 @@ def test_lazy_probe_across_a_segment_boundary(L):
     assert check("lazy probe", d, 5, 22, seg=256, lib=L)
 
 
-@pytest.mark.oracle_as_is
-@pytest.mark.xfail(reason="known divergence: H5 bucket entries written by the reference's StoreRangeOptBatch are masked "
-                          "positions (mod.rs:1163-1232) and end the bucket walk past the first ring revolution; not modelled "
-                          "on the device yet (DESIGN.md section 6)", strict=False)
-def test_known_divergence_h5_past_the_first_ring_revolution(L):
-    # 1 MiB at lgwin 17: the ring buffer (256 KiB) goes round three times under an H5 hasher
+def test_h5_past_the_first_ring_revolution(L):
+    """1 MiB at lgwin 17: the ring buffer (256 KiB) goes round three times under an H5 hasher, whose StoreRangeOptBatch files
+    masked positions (mod.rs:1163-1232) -- parsed by a live chain (lz77_live.h), checked against the oracle as it is"""
     assert check("markov1M-w17", synth.markov_text(1 << 20), 5, 17, lib=L)
+    assert check("mixed1M-w17-q7", synth.mixed(1 << 20), 7, 17, lib=L)
+    assert check("stretches2M-w18", synth.stretches(2 << 20), 5, 18, lib=L)

@@ -49,3 +49,28 @@ def test_device_shard_job_world1():
         assert orc.decompress(got, len(data)) == data
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_shard_job_path_prints_its_line():
+    """bench.py as the driver launches it for N > 1 -- process group on the nccl backend, device-resident shard, gather,
+    stitch, then BASELINE config 4 (cut to 1 GiB, 8 shards dealt to the ranks) -- with a single rank: the code path of the
+    multi-GPU run is executed on every GPU round, and must print its one JSON line with config 4 verified."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BROTLI_MI355X_BENCH_SHARD_JOB="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config4", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["unit"] == "MB/s" and line["value"] > 0
+    assert "compress_multi shard per GPU" in line["config"]["workload"]
+    assert "error" not in line["config4"], line["config4"]
+    assert line["config4"]["identical_to_cpu_oracle"] is True, line["config4"]

@@ -20,9 +20,11 @@ import orc, synth, test_cabi
 lib = test_cabi._load(%(kind)r)
 Q, W = 1, 2
 cases = %(cases)s
-for name, gen, q, w, write in cases:
+for case in cases:
+    name, gen, q, w, write = case[:5]
+    hint = case[5] if len(case) > 5 else 0  # BROTLI_PARAM_SIZE_HINT set by the caller (decides H5 / H6, encode.rs:863-893)
     data = eval(gen)
-    e = lib.encoder(params=[(Q, q), (W, w)])
+    e = lib.encoder(params=[(Q, q), (W, w)] + ([(5, hint)] if hint else []))
     early = 0  # output produced by PROCESS alone
     for i in range(0, len(data), write):
         e.write(data[i:i + write])
@@ -30,7 +32,7 @@ for name, gen, q, w, write in cases:
     mid = early
     got = e.finish()
     e.close()
-    want = orc.writer_compress(data, q, w, chunk=write)
+    want = orc.reader_compress(data, [(Q, q), (W, w), (5, hint)], chunk=write) if hint else orc.writer_compress(data, q, w, chunk=write)
     assert got == want, (name, len(got), len(want))
     assert orc.decompress(got, len(data)) == data
     print("OK %%s: %%d -> %%d bytes, %%d handed out before FINISH" %% (name, len(data), len(got), mid))
@@ -57,14 +59,8 @@ print("OK flush in a trimmed stream")
 '''
 
 
-def _run(kind, cases, batch, wrap_shift=0, masked_h5=False, flush_part=True):
-    # (the child compares the product with the oracle: in the product's view of the masked H5 store-range entries,
-    # tests/orc.py -- the conftest fixture does not reach a subprocess)
-    env = dict(os.environ, BROTLI_MI355X_STREAM_BATCH=str(batch), ORC_H5_ABSOLUTE_STORE_RANGE="1")
-    if masked_h5:
-        # the staged model of the masked H5 ring entries against the oracle as it is
-        env["BROTLI_MI355X_MASKED_H5"] = "1"
-        del env["ORC_H5_ABSOLUTE_STORE_RANGE"]
+def _run(kind, cases, batch, wrap_shift=0, flush_part=True):
+    env = dict(os.environ, BROTLI_MI355X_STREAM_BATCH=str(batch))
     code = _DRIVER % dict(tests=HERE, kind=kind, cases=repr(cases), flush_part=flush_part)
     if wrap_shift:
         # scale the position wrap of the reference (3, 5, 7 ... GiB) down to MiB, in the product and in the oracle
@@ -96,8 +92,10 @@ def test_streaming_pieces_gpu():
 
 @pytest.mark.gpu
 def test_streaming_default_batches_gpu():
-    """the default 64 MiB batches at lgwin 22: a 200 MiB stream fed in 4 MiB writes"""
-    _run("gpu", [("markov 200 MiB q5 w22", "synth.markov_text(200 << 20, 7)", 5, 22, 4 << 20)], 64 << 20)
+    """the default 64 MiB batches at lgwin 22, fed in 4 MiB writes: a 200 MiB stream with a size hint (H6), and a 40 MiB one
+    without (H5: masked ring entries from 8 MiB on, parsed by a live chain)"""
+    _run("gpu", [("markov 200 MiB q5 w22 hinted", "synth.markov_text(200 << 20, 7)", 5, 22, 4 << 20, 1 << 30),
+                 ("markov 40 MiB q5 w22", "synth.markov_text(40 << 20, 7)", 5, 22, 4 << 20)], 64 << 20)
 
 
 WRAP_CASES = [
@@ -108,12 +106,10 @@ WRAP_CASES = [
 ]
 
 
-def test_streaming_pieces_emu_masked_h5():
-    """trimmed windows and carried masked flags (StreamCarry), candidate rows and rank structures -- with
-    BROTLI_MI355X_MASKED_H5=1 the emulation build equals the oracle AS IT IS on H5 streams that pass the ring size"""
-    # (kept small: under the masked model the fixed point takes ~40 rounds per MiB of text, DESIGN.md section 9 item 0)
+def test_streaming_pieces_emu_small_batches():
+    """trimmed windows and carried masked flags (StreamCarry) with batches as small as the ring"""
     _run("emu", [("markov 1.5 MiB q5 w17", "synth.markov_text(1536 << 10, 3)", 5, 17, 65536),
-                 ("mixed 1 MiB q7 w17 odd writes", "synth.mixed(1 << 20, 4)", 7, 17, 100003)], 256 << 10, masked_h5=True, flush_part=False)
+                 ("mixed 1 MiB q7 w17 odd writes", "synth.mixed(1 << 20, 4)", 7, 17, 100003)], 256 << 10, flush_part=False)
 
 
 def test_hasher_reset_at_position_wrap_emu():

@@ -10,8 +10,6 @@ import json
 import os
 import sys
 import time
-# the product does not model the reference's masked H5 store-range entries yet (tests/orc.py): compare in its view
-os.environ.setdefault("ORC_H5_ABSOLUTE_STORE_RANGE", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -32,10 +30,12 @@ def main():
             data = case["make"]() if seed is None else case["make"](seed)
             t1 = time.time()
             try:
+                params = [(1, case["quality"]), (2, case["lgwin"])] + ([(5, case["hint"])] if case.get("hint") else [])
                 if case.get("writer_chunk"):
-                    out = orc.writer_compress(data, case["quality"], case["lgwin"], chunk=case["writer_chunk"])
+                    out = (orc.reader_compress(data, params, chunk=case["writer_chunk"]) if case.get("hint") else
+                           orc.writer_compress(data, case["quality"], case["lgwin"], chunk=case["writer_chunk"]))
                 elif case.get("shards"):
-                    out = orc.compress_multi(data, [(1, case["quality"]), (2, case["lgwin"])], case["shards"])
+                    out = orc.compress_multi(data, params, case["shards"])
                 else:
                     out = orc.compress(data, case["quality"], case["lgwin"])
             except orc.ReferencePanics:
