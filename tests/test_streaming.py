@@ -23,6 +23,7 @@ cases = %(cases)s
 for case in cases:
     name, gen, q, w, write = case[:5]
     hint = case[5] if len(case) > 5 else 0  # BROTLI_PARAM_SIZE_HINT set by the caller (decides H5 / H6, encode.rs:863-893)
+    expect_early = case[6] if len(case) > 6 else True  # (a stream shorter than one batch is encoded by FINISH)
     data = eval(gen)
     e = lib.encoder(params=[(Q, q), (W, w)] + ([(5, hint)] if hint else []))
     early = 0  # output produced by PROCESS alone
@@ -36,7 +37,7 @@ for case in cases:
     assert got == want, (name, len(got), len(want))
     assert orc.decompress(got, len(data)) == data
     print("OK %%s: %%d -> %%d bytes, %%d handed out before FINISH" %% (name, len(data), len(got), mid))
-    assert mid > len(got) // 2, (name, "PROCESS did not produce output mid-stream", mid)
+    assert mid > len(got) // 2 or not expect_early, (name, "PROCESS did not produce output mid-stream", mid)
 # FLUSH in the middle of a stream that has already been trimmed to its window, then more input
 if not %(flush_part)r:
     sys.exit(0)
@@ -95,7 +96,7 @@ def test_streaming_default_batches_gpu():
     """the default 64 MiB batches at lgwin 22, fed in 4 MiB writes: a 200 MiB stream with a size hint (H6), and a 40 MiB one
     without (H5: masked ring entries from 8 MiB on, parsed by a live chain)"""
     _run("gpu", [("markov 200 MiB q5 w22 hinted", "synth.markov_text(200 << 20, 7)", 5, 22, 4 << 20, 1 << 30),
-                 ("markov 40 MiB q5 w22", "synth.markov_text(40 << 20, 7)", 5, 22, 4 << 20)], 64 << 20)
+                 ("markov 40 MiB q5 w22", "synth.markov_text(40 << 20, 7)", 5, 22, 4 << 20, 0, False)], 64 << 20)
 
 
 WRAP_CASES = [
