@@ -32,6 +32,8 @@
 #define BR_ATOMIC_INC(ptr) ((*(ptr))++)
 #define BR_UNIFORM(x) (x)
 #define BR_READLANE(x, lane) (x)
+#define BR_SCALAR 1
+#define BR_UNROLL
 #else
 #include <hip/hip_runtime.h>
 #define BR_DEV __device__ __forceinline__
@@ -44,6 +46,7 @@
 // BR_UNIFORM moves such a value into an SGPR (all lanes hold the same value); BR_READLANE picks one lane's value.
 #define BR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define BR_READLANE(x, lane) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(lane)))
+#define BR_SCALAR 0
 #endif
 
 #include "lz77_live.h"
@@ -393,7 +396,7 @@ struct ProbeMeta {
 extern __device__ unsigned long long g_chain_prof[16];
 #endif
 
-#if defined(BROTLI_HOST_EMU)
+#if BR_SCALAR
 BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t limit, const uint32_t* = nullptr, uint32_t = 0, uint32_t = 0) {
   return br_match_len(a, b, limit);
 }
@@ -443,7 +446,7 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
 }
 #endif
 
-#if !defined(BROTLI_HOST_EMU)
+#if !BR_SCALAR
 // kRows, device: fixed lane layout, results stay in registers.  Half w = lane >> 5 probes position p0 + w; inside a half
 // lane c = lane & 31 holds: c < ndist the distance-cache candidate c, ndist <= c < ndist + 16 ring entry c - ndist of the
 // row, c = ndist + 16 / + 17 the two static-dictionary probes.  One memory round trip per probe: the rows and the
@@ -526,7 +529,7 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
 #endif
 
 
-#if !defined(BROTLI_HOST_EMU)
+#if !BR_SCALAR
 // Live chains, ring depth <= 16: the lane layout of br_probe_pair_rows, the ring entries read from the chain's own table
 // (lz77_live.h).  Two memory round trips per probe: ring counters + bucket rows of both positions, then the candidate
 // text.  The hash keys come from a window of 64 keys held one per lane.  Position p0 is filed when its search is folded
@@ -603,7 +606,7 @@ BR_DEV void br_probe_pair_live16(const Lz77Params& P, const ChainTables& t, cons
 template <bool kH9, bool kRows, bool kLive = false>
 BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, uint32_t p0,
                           const int32_t* cache, uint32_t cache_version, uint32_t pos_end, const LiveRing* live = nullptr) {
-#if !defined(BROTLI_HOST_EMU)
+#if !BR_SCALAR
   if constexpr (kRows && kLive) {
     br_probe_pair_live16<kH9>(P, t, *live, m, p0, cache, cache_version, pos_end);
     return;
@@ -640,7 +643,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     m.nbucket[0] = n0 < block_size ? n0 : block_size;
     m.nbucket[1] = n1 < block_size ? n1 : block_size;
   } else if (kRows) {
-#if defined(BROTLI_HOST_EMU)
+#if BR_SCALAR
     for (int w = 0; w < 2; ++w) {
       uint32_t nb = 0;
       if (p0 + w < P.total_bytes)
@@ -703,7 +706,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
   m.pos = p0;
   m.version = cache_version;
   const uint32_t total = n[0] + n[1];
-#if !defined(BROTLI_HOST_EMU)
+#if !BR_SCALAR
   if constexpr (!kRows) {
     // Deep rings (up to 2 x 274 candidates at quality 9) in three steps instead of one dependent load chain per 64
     // candidates: (1) all ring entries and their tags are requested at once, (2) every candidate gets its `prev`, and
@@ -816,7 +819,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
       if (kLive) {
         q = live_entry(w, c - ndist);
       } else if (kRows) {
-#if defined(BROTLI_HOST_EMU)
+#if BR_SCALAR
         q = t.rows[(size_t)cur * kRowEntries + (c - ndist)];
 #else
         q = s.win[(cur - m.win_base) * kRowEntries + (c - ndist)];
@@ -858,6 +861,60 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
   BR_SYNC();
 }
 
+// The static dictionary stage of FindLongestMatch: SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988
+// (shallow = false), on the two probed hash items; probed(i, &item, &matchlen) hands them over (matchlen: the common
+// prefix of the dictionary word and the text, 0 if the word is longer than max_length).
+template <typename Probed>
+BR_DEV void br_dictionary_stage(const Lz77Params& P, const ChainTables& t, DictState& ds, bool no_dict, uint32_t max_length, uint32_t max_backward,
+                                SearchResult& out, Probed probed) {
+  if (out.found || !P.use_dictionary) return;
+  const bool dead = ds.matches < (ds.lookups >> 7);
+  const uint32_t seen = dead ? 2u : 1u;
+  ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
+  if (no_dict) {
+    // switched off for good under the exact counters of this round: no probes, no virtual bookkeeping.  Should a later
+    // pass of the resolver find the dictionary still alive here (something changed upstream), this parse says
+    // nothing about what a live dictionary would have done: mode 4 = "ran blind", valid only while the dictionary is off.
+    ds.mode = 4;
+    return;
+  }
+  if (dead && ds.vwould) return;
+  if (dead) {
+    if ((int32_t)ds.vlookups > ds.vmaxdef) ds.vmaxdef = (int32_t)ds.vlookups;
+  } else {
+    const int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
+    if (def > ds.maxdef) ds.maxdef = def;
+  }
+  uint32_t threshold = out.score;
+  for (uint32_t i = 0; i < 2; ++i) {
+    uint32_t item, matchlen;
+    probed(i, &item, &matchlen);
+    if (dead) ds.vlookups++; else ds.lookups++;
+    if (item == 0) continue;
+    const uint32_t len = item & 0x1f;
+    const uint32_t dist = item >> 5;
+    if (len > max_length) continue;
+    if (matchlen + 10 <= len || matchlen == 0) continue;
+    const uint32_t cut = len - matchlen;
+    const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
+    const uint32_t backward = max_backward + dist + 1 + (transform_id << BR_UNIFORM(t.dict_size_bits_by_length[len]));
+    if (backward > P.dist_max_distance) continue;
+    const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
+    if (score < threshold) continue;
+    threshold = score;
+    if (dead) {
+      ds.vwould = 1;
+      continue;
+    }
+    out.len = matchlen;
+    out.len_x_code = len ^ matchlen;
+    out.distance = backward;
+    out.score = score;
+    ds.matches++;
+    out.found = true;
+  }
+}
+
 // Phase 2: fold the candidates of probe slot w in the reference's order, then the static dictionary stage.
 template <bool kH9, bool kRows>
 BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const ProbeMeta& m, uint32_t w,
@@ -874,7 +931,7 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   out.score = kMinScore;
   out.found = false;
   out.stored = true;
-#if defined(BROTLI_HOST_EMU)
+#if BR_SCALAR
   uint32_t best_len = 0;
   uint32_t best_score = kMinScore;
   const uint32_t brk = P.dict_break;
@@ -1081,62 +1138,165 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
 #endif
   if (before_dictionary) *before_dictionary = out;
   if (candidates_only) return out;
-  if (!out.found && P.use_dictionary) {
-    // SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988 (shallow = false), on the probed items
-    const bool dead = ds.matches < (ds.lookups >> 7);
-    const uint32_t seen = dead ? 2u : 1u;
-    ds.mode = (ds.mode == 0 || ds.mode == seen) ? seen : 3u;
-    if (m.no_dict) {
-      // switched off for good under the exact counters of this round: no probes, no virtual bookkeeping.  Should a later
-      // pass of the resolver find the dictionary still alive here (something changed upstream), this parse says
-      // nothing about what a live dictionary would have done: mode 4 = "ran blind", valid only while the dictionary is off.
-      ds.mode = 4;
-      return out;
-    }
-    if (dead && ds.vwould) return out;
-    if (dead) {
-      if ((int32_t)ds.vlookups > ds.vmaxdef) ds.vmaxdef = (int32_t)ds.vlookups;
-    } else {
-      const int32_t def = (int32_t)(ds.lookups - ds.lookups0) - 128 * (int32_t)(ds.matches - ds.matches0);
-      if (def > ds.maxdef) ds.maxdef = def;
-    }
-    uint32_t threshold = out.score;
-    for (uint32_t i = 0; i < 2; ++i) {
-#if !defined(BROTLI_HOST_EMU)
-      const uint32_t dict_lane = 32u * w + ndist + kRowDictLane + i;
-      const uint32_t item = kRows ? BR_READLANE(m.r_prev, dict_lane) : BR_UNIFORM(s.cand_prev[w][ncand + i]);
-      const uint32_t matchlen = kRows ? BR_READLANE(m.r_len, dict_lane) : BR_UNIFORM(s.cand_len[w][ncand + i]);
+  br_dictionary_stage(P, t, ds, m.no_dict != 0, max_length, max_backward, out, [&](uint32_t i, uint32_t* item_out, uint32_t* matchlen_out) {
+#if !BR_SCALAR
+    const uint32_t dict_lane = 32u * w + ndist + kRowDictLane + i;
+    *item_out = kRows ? BR_READLANE(m.r_prev, dict_lane) : BR_UNIFORM(s.cand_prev[w][ncand + i]);
+    *matchlen_out = kRows ? BR_READLANE(m.r_len, dict_lane) : BR_UNIFORM(s.cand_len[w][ncand + i]);
 #else
-      const uint32_t item = BR_UNIFORM(s.cand_prev[w][ncand + i]);
-      const uint32_t matchlen = BR_UNIFORM(s.cand_len[w][ncand + i]);
+    *item_out = BR_UNIFORM(s.cand_prev[w][ncand + i]);
+    *matchlen_out = BR_UNIFORM(s.cand_len[w][ncand + i]);
 #endif
-      if (dead) ds.vlookups++; else ds.lookups++;
-      if (item == 0) continue;
-      const uint32_t len = item & 0x1f;
-      const uint32_t dist = item >> 5;
-      if (len > max_length) continue;
-      if (matchlen + 10 <= len || matchlen == 0) continue;
-      const uint32_t cut = len - matchlen;
-      const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
-      const uint32_t backward = max_backward + dist + 1 + (transform_id << BR_UNIFORM(t.dict_size_bits_by_length[len]));
-      if (backward > P.dist_max_distance) continue;
-      const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
-      if (score < threshold) continue;
-      threshold = score;
-      if (dead) {
-        ds.vwould = 1;
-        continue;
+  });
+  return out;
+}
+
+#if BR_SCALAR
+// Common prefix of the text at a_pos and b_pos (a_pos < b_pos), at most `limit`: 8 bytes at a time; with the run table a
+// pair that starts with 32 equal bytes of one value is settled by the lengths of the two runs (see br_match_len_wide).
+BR_DEV uint32_t br_match_len_scalar(const ChainTables& t, uint32_t a_pos, uint32_t b_pos, uint32_t limit) {
+  const uint8_t* a = t.text + a_pos;
+  const uint8_t* b = t.text + b_pos;
+  uint32_t i = 0;
+  if (t.run_end != nullptr && limit > 32) {
+    const uint64_t a0 = br_load64(a), pat = (a0 & 0xffull) * 0x0101010101010101ull;
+    if (a0 == pat && br_load64(b) == pat && br_load64(a + 8) == pat && br_load64(b + 8) == pat && br_load64(a + 16) == pat &&
+        br_load64(b + 16) == pat && br_load64(a + 24) == pat && br_load64(b + 24) == pat) {
+      const uint32_t ra = t.run_end[a_pos] - a_pos, rb = t.run_end[b_pos] - b_pos;
+      if (ra != rb) {
+        const uint32_t r = ra < rb ? ra : rb;
+        return r < limit ? r : limit;
       }
-      out.len = matchlen;
-      out.len_x_code = len ^ matchlen;
+      if (ra >= limit) return limit;
+      i = ra;
+    }
+  }
+  // 64 bytes of either side per memory round trip while the match lasts (a lane has no other lane to wait behind)
+  while (i + 64 <= limit) {
+    uint64_t x[8];
+    BR_UNROLL
+    for (int k = 0; k < 8; ++k) x[k] = br_load64(a + i + 8 * k) ^ br_load64(b + i + 8 * k);
+    uint32_t first = 64;
+    BR_UNROLL
+    for (int k = 7; k >= 0; --k)
+      if (x[k] != 0) first = 8u * (uint32_t)k + (uint32_t)(__builtin_ctzll(x[k]) >> 3);
+    if (first != 64) return i + first;
+    i += 64;
+  }
+  return i + br_match_len(a + i, b + i, limit - i);
+}
+
+// the first 16 bytes at a text position, in registers
+struct Head16 {
+  uint64_t lo, hi;
+};
+BR_DEV Head16 br_load_head(const uint8_t* p) {
+  Head16 h;
+  h.lo = br_load64(p);
+  h.hi = br_load64(p + 8);
+  return h;
+}
+BR_DEV uint32_t br_head_common(const Head16& a, const Head16& b) {  // common prefix, 0..16
+  const uint64_t x = a.lo ^ b.lo;
+  if (x != 0) return (uint32_t)(__builtin_ctzll(x) >> 3);
+  const uint64_t y = a.hi ^ b.hi;
+  if (y != 0) return 8u + (uint32_t)(__builtin_ctzll(y) >> 3);
+  return 16u;
+}
+BR_DEV uint8_t br_head_byte(const Head16& a, uint32_t i) { return (uint8_t)(i < 8 ? a.lo >> (8 * i) : a.hi >> (8 * (i - 8))); }
+
+// AdvHasher::FindLongestMatch (mod.rs:1684-1812) for ONE position, candidate by candidate in the reference's order, the
+// ring entries taken from the candidate row of the position (kRows chains).  The scalar form of br_probe_pair_rows +
+// br_fold_probe, which the host emulation runs.  (It was also compiled for the device with one chain per LANE, 64 chains to a
+// wavefront, for round 0: correct, and 3.5 x slower than one chain per wavefront -- 32 768 chains are half a wavefront per
+// SIMD, and a lone wavefront issues the ~2 000 predicated instructions of an unrolled search at one per ~5 cycles.
+// All loads of a search are issued together for that experiment: the row, then the first 16 bytes of every candidate.)
+BR_DEV SearchResult br_search_rows_scalar(const Lz77Params& P, const ChainTables& t, DictState& ds, bool no_dict, uint32_t cur, const int32_t* cache,
+                                          uint32_t blk_end) {
+  constexpr uint32_t kCache = 4, kCand = kCache + kRowEntries;
+  const uint32_t max_length = blk_end - cur;
+  const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
+  const uint32_t brk = P.dict_break;
+  const uint32_t ndist = P.ndist < kCache ? P.ndist : kCache;  // (rows exist for ring depth 16, i.e. quality 5: four cache candidates)
+  SearchResult out;
+  out.len = 0;
+  out.len_x_code = 0;
+  out.distance = 0;
+  out.score = kMinScore;
+  out.found = false;
+  out.stored = true;
+  uint32_t best_len = 0, best_score = kMinScore;
+  const uint32_t cur_ring = cur & P.ring_mask;
+  // ---- where the candidates are
+  uint32_t prev[kCand];
+BR_UNROLL
+  for (uint32_t c = 0; c < kCache; ++c) {
+    const int64_t b = c < ndist ? (int64_t)cache[c] : 0;
+    prev[c] = (b > 0 && b <= (int64_t)max_backward) ? cur - (uint32_t)b : 0xffffffffu;
+  }
+  {
+    const uint32_t* row = t.rows + (size_t)cur * kRowEntries;
+BR_UNROLL
+    for (uint32_t i = 0; i < kRowEntries; ++i) prev[kCache + i] = row[i];
+  }
+  // ---- their first 16 bytes (one memory round trip for all of them)
+  const Head16 here = br_load_head(t.text + cur);
+  Head16 head[kCand];
+BR_UNROLL
+  for (uint32_t c = 0; c < kCand; ++c) head[c] = br_load_head(t.text + (prev[c] != 0xffffffffu ? prev[c] : cur));
+  // ---- the fold, in the reference's order
+  bool row_open = true;
+BR_UNROLL
+  for (uint32_t c = 0; c < kCand; ++c) {
+    const bool is_cache = c < kCache;
+    const uint32_t q = prev[c];
+    if (q == 0xffffffffu) {
+      if (!is_cache) row_open = false;  // (kRowEnd: the row ends here)
+      continue;
+    }
+    if (!is_cache && !row_open) continue;
+    // quick reject at best_len (mod.rs:1713-1718 / 1765-1773); the byte AT the block end is whatever the ring buffer holds there
+    if (cur_ring + best_len > P.ring_mask || (q & P.ring_mask) + best_len > P.ring_mask) continue;
+    bool same;
+    if (best_len < 16 && cur + best_len < blk_end) {
+      same = br_head_byte(here, best_len) == br_head_byte(head[c], best_len);
+    } else {
+      const uint8_t cb = (cur + best_len < blk_end) ? t.text[cur + best_len] : br_unwritten_byte(P, t, cur + best_len);
+      same = cb == t.text[q + best_len];
+    }
+    if (!same) continue;
+    if (!is_cache && (uint32_t)head[c].lo != (uint32_t)here.lo) continue;  // FindMatchLengthWithLimitMin4 == 0, static_dict.rs:134-147
+    uint32_t unbroken = br_head_common(head[c], here);
+    if (unbroken >= 16 && max_length > 16) unbroken = br_match_len_scalar(t, q, cur, max_length);
+    if (unbroken > max_length) unbroken = max_length;
+    if (is_cache ? !(unbroken >= 3 || (unbroken == 2 && c < 2)) : unbroken < 4) continue;
+    uint32_t len = unbroken;
+    if (brk != 0 && (q & P.ring_mask) < brk && (q & P.ring_mask) + unbroken > brk) len = brk - (q & P.ring_mask);  // fix_unbroken_len, mod.rs:42-54
+    const uint32_t backward = cur - q;
+    const uint32_t score = is_cache ? br_score_cache<false>(P, len, c) : br_score_ring<false>(P, len, backward);
+    if (best_score < score) {
+      best_score = score;
+      best_len = len;
+      out.len = len;
       out.distance = backward;
       out.score = score;
-      ds.matches++;
       out.found = true;
     }
   }
+  const uint32_t first4 = (uint32_t)here.lo;
+  br_dictionary_stage(P, t, ds, no_dict, max_length, max_backward, out, [&](uint32_t i, uint32_t* item_out, uint32_t* matchlen_out) {
+    const uint32_t item = t.dict_hash[(((first4 * 0x1e35a7bdu) >> (32 - 14)) << 1) + i];
+    uint32_t matchlen = 0;
+    if (item != 0) {
+      const uint32_t wlen = item & 0x1f;
+      if (wlen <= max_length) matchlen = br_match_len(t.dict_data + t.dict_offsets_by_length[wlen] + wlen * (item >> 5), t.text + cur, wlen);
+    }
+    *item_out = item;
+    *matchlen_out = matchlen;
+  });
   return out;
 }
+#endif
 
 // one record of ChainTables::search_log
 BR_DEV void br_log_search(uint32_t* rec, const int32_t* cache, const SearchResult& found_before_dictionary) {
@@ -1156,6 +1316,9 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
                               uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end, const LiveRing* live = nullptr) {
 #if defined(BR_CHAIN_PROFILE)
   const unsigned long long t0 = BR_TICK();
+#endif
+#if BR_SCALAR
+  if constexpr (kRows && !kLive && !kH9) return br_search_rows_scalar(P, t, ds, m.no_dict != 0, x, cache, blk_end);
 #endif
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
@@ -1789,7 +1952,7 @@ BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const Li
   const uint32_t max_backward = p < P.max_backward_limit ? p : P.max_backward_limit;
   const uint8_t* cur_data = t.text + p;
   BR_SYNC();
-#if !defined(BROTLI_HOST_EMU)
+#if !BR_SCALAR
   if constexpr (kRows) {
     // the lane layout of br_probe_pair_rows, first half only
     const uint32_t lane = (uint32_t)BR_LANE, c = lane & 31u;

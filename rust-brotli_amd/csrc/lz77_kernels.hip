@@ -18,6 +18,7 @@
 #include "lz77_chain.h"
 #include "lz77_rows.h"
 #include "device_scan.h"
+#include "lz77_parse_args.h"
 
 namespace brotli_mi355x {
 
@@ -1221,20 +1222,6 @@ void lz77_run_table(const Lz77Params& P, const Lz77Buffers& B) {
 }
 
 // ------------------------------------------------------------------------------------------ parse
-struct ParseArgs {
-  Lz77Params P;
-  ChainTables T;
-  const Segment* segments;
-  SegEntry* entries;
-  SegExit* exits;
-  uint32_t first_segment;
-  const uint32_t* list;  // optional explicit segment indices
-  uint8_t* sched;  // list rounds: per segment, 1 if it is in the list (see br_parse_chain)
-  uint32_t count;
-  uint32_t per_xcd;      // 0: identity mapping
-  uint32_t max_continuation;
-};
-
 struct ParseTiming {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<uint32_t> counts;  // chains per launch

@@ -42,7 +42,7 @@ struct LiveRing {
   uint32_t bits;        // block_bits: ring depth = 1 << bits
 };
 
-#if defined(BROTLI_HOST_EMU)
+#if BR_SCALAR
 #define BR_LIVE_LD16(p) (*(p))
 #define BR_LIVE_LD32(p) (*(p))
 #define BR_LIVE_ST16(p, v) (*(p) = (uint16_t)(v))
@@ -72,7 +72,7 @@ BR_DEV void br_live_insert(const LiveRing& lr, uint32_t key, uint32_t n, uint32_
 // form writes (ix & mask) where Store writes ix.
 BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint32_t count, uint32_t masked_lo, uint32_t masked_hi) {
   const uint32_t depth = 1u << lr.bits;
-#if defined(BROTLI_HOST_EMU)
+#if BR_SCALAR
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t q = base + i * step;
     const uint32_t key = lr.keys[q];
