@@ -217,7 +217,7 @@ void CompressChunk(const EncoderParams& user_params, const uint8_t* input, size_
 // LZ77 rounds leave the device idle while the host resolves them, and its late rounds run a handful of wavefronts:
 // two or three chunks side by side fill those gaps.  The helpers live as long as the process (their device memory
 // pools and streams are per thread and are reused from call to call); BROTLI_MI355X_SHARD_WORKERS sets how many
-// chunks run at once (default 4, 1 = one after the other on the calling thread).
+// chunks run at once (default 8, 1 = one after the other on the calling thread).
 class ShardWorkers {
  public:
   static ShardWorkers& Get() {
@@ -270,7 +270,7 @@ class ShardWorkers {
   static size_t WorkerCount() {
     static const size_t n = [] {
       const char* e = getenv("BROTLI_MI355X_SHARD_WORKERS");
-      const long v = e ? atol(e) : 4;
+      const long v = e ? atol(e) : 8;
       return (size_t)std::min<long>(std::max<long>(v, 1), 8);
     }();
     return n;

@@ -50,6 +50,7 @@
 #endif
 
 #include "lz77_live.h"
+#include "entropy_device.h"
 
 namespace brotli_mi355x {
 
@@ -103,6 +104,7 @@ struct ChainTables {
   uint16_t* live_num = nullptr;       // [tables][1 << bucket_bits]
   uint32_t* live_buckets = nullptr;   // [tables][(1 << bucket_bits) << block_bits]
   LiveBlockState* live_state = nullptr;  // [blocks]: the meta-block books at the entry of every block (read for the first one)
+  EntropyTables logs = {nullptr, nullptr};  // should_compress in the live chain (encode.rs:1325-1354)
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -553,7 +555,10 @@ BR_DEV void br_probe_pair_live16(const Lz77Params& P, const ChainTables& t, cons
   const uint32_t w = lane >> 5, c = lane & 31u;
   const uint32_t key = w ? k1 : k0;
   const uint32_t depth = 1u << lr.bits;
+  // ring counter and the 16 slots of the ring are requested together (one round trip); which slot is the newest entry
+  // comes out of the counter afterwards
   const uint32_t raw_n = (uint32_t)BR_LIVE_LD16(lr.num + key);
+  const uint32_t raw_e = (c >= ndist && c < ndist + kRowEntries) ? (uint32_t)BR_LIVE_LD32(lr.buckets + (((size_t)key << lr.bits) | (c - ndist))) : 0u;
   const uint32_t n0 = BR_READLANE(raw_n, 0), n1 = (BR_READLANE(raw_n, 32) + (same ? 1u : 0u)) & 0xffffu;
   const uint32_t n = w ? n1 : n0;
   const uint32_t visible = !(w && !second) ? (n < depth ? n : depth) : 0u;
@@ -565,7 +570,11 @@ BR_DEV void br_probe_pair_live16(const Lz77Params& P, const ChainTables& t, cons
   const uint32_t i = c - ndist;  // ring entry number, newest first
   const bool is_ring = !is_cache && i < visible;
   uint32_t e = kLiveBreak;
-  if (is_ring) e = (w && same && i == 0) ? p0 : BR_LIVE_LD32(lr.buckets + (((size_t)key << lr.bits) | ((n - 1u - i) & (depth - 1u))));
+  {
+    const uint32_t from = (lane & 32u) + ndist + ((n - 1u - i) & (depth - 1u));  // the lane that loaded slot (n - 1 - i) mod depth
+    const uint32_t moved = (uint32_t)__shfl((int)raw_e, (int)(from & 63u), 64);
+    if (is_ring) e = (w && same && i == 0) ? p0 : moved;
+  }
   // the bucket walk ends with the first entry that is masked or out of reach (mod.rs:1763-1775)
   const bool brk = is_ring && (e >= kLiveBreak || cur - e > max_backward);
   const unsigned long long brk_mask = __ballot(brk);
@@ -1322,7 +1331,8 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
 #endif
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
-    BR_SYNC();  // every lane is done reading the previous probe (live chains: and what was filed since is in memory)
+    if constexpr (!(kLive && kRows)) BR_SYNC();  // every lane is done reading the previous probe (live chains with register
+                                                 // probes: nothing shared is read, and what was filed is ordered by address)
     br_probe_pair<kH9, kRows, kLive>(P, t, s, m, x, cache, cache_version, blk_end, live);
     w = 0;
 #if defined(BR_CHAIN_PROFILE)
@@ -1630,7 +1640,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
         fw.one(position + 1, next_probed ? ((!kH9 || next_stored) ? (uint8_t)(kFlagStored | kFlagSearched) : kFlagSearched) : fw.unstored(position + 1));
       if (sr.len > 2) {
         fw.template copy_range<kLive>(position + 2, position + sr.len, store_end, kH9 ? kNeverMasked : P.masked_from);
-        if constexpr (kLive) br_live_store_copy(*live, position + 2, position + sr.len < store_end ? position + sr.len : store_end, P.masked_from);
+        if constexpr (kLive) br_live_store_copy(*live, position + 2, position + sr.len < store_end ? position + sr.len : store_end, P.masked_from, probe.kwin, probe.kwin_base);
       }
       position += sr.len;
     } else {
@@ -1853,7 +1863,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
 // and the stream is parsed again from that block.  The entries used go to entries[], the books to live_state[].
 template <bool kRows>
 BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratchT<false, kRows>& s, const Segment* segments, SegEntry* entries,
-                          SegExit* exits, uint32_t first, uint32_t last, uint32_t table) {
+                          SegExit* exits, uint32_t first, uint32_t last, uint32_t table, uint32_t* histo /* 256 words of scratch */) {
   LiveRing lr;
   const size_t keys_per_table = (size_t)1 << P.bucket_bits;
   lr.num = t.live_num + (size_t)table * keys_per_table;
@@ -1864,6 +1874,8 @@ BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratc
   SegEntry next;
   LiveBlockState st = t.live_state[first];
   uint32_t carry = BR_UNIFORM(entry.insert_len);  // literals pending at the entry of the block
+  int32_t saved_cache[4];  // the distance cache at the start of the open meta-block
+  for (int i = 0; i < 4; ++i) saved_cache[i] = (int32_t)BR_UNIFORM(t.live_state[first].saved_cache[i]);
   const uint32_t max_mb = P.max_metablock_bytes, limit = max_mb / 8;
   for (uint32_t j = first; j < last; ++j) {
     const Segment seg = segments[j];
@@ -1888,6 +1900,25 @@ BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratc
     const uint32_t be = BR_UNIFORM(seg.blk_end);
     const bool next_fits = (uint64_t)(be - st.mb_start) + P.block_bytes <= (uint64_t)max_mb;
     if (!(next_fits && st.mb_lits < limit && st.mb_cmds < limit)) {  // the meta-block is closed here
+      // A meta-block that should_compress (encode.rs:1325-1354) sends out uncompressed hands the distance cache of its START
+      // to the next one (encode.rs:1994): few commands, nearly all literals, and an every-13th-byte histogram whose f32
+      // entropy says "incompressible".  (What the chain cannot know is the size fallback of encode.rs:2141-2163; the host
+      // resolver finds the entry wrong then and sends the chain back.)
+      const uint32_t bytes = be - st.mb_start;
+      const uint32_t cmds_all = st.mb_cmds + (carry != 0 ? 1u : 0u), lits_all = st.mb_lits + carry;  // with the trailing insert-only command
+      bool compress = true;
+      if (cmds_all < (bytes >> 8) + 2 && (float)lits_all > 0.99f * (float)bytes) {
+        BR_SYNC();
+        for (uint32_t i = BR_LANE; i < 256; i += BR_NLANES) histo[i] = 0;
+        BR_SYNC();
+        for (uint32_t q = st.mb_start + 13u * (uint32_t)BR_LANE; q < be; q += 13u * BR_NLANES) BR_ATOMIC_INC(&histo[t.text[q]]);
+        BR_SYNC();
+        const float threshold = (float)bytes * 7.92f / 13.0f;
+        compress = !(br_bits_entropy(t.logs, histo, 256) > threshold);
+      }
+      if (!compress)
+        for (int i = 0; i < 4; ++i) next.cache[i] = saved_cache[i];
+      for (int i = 0; i < 4; ++i) saved_cache[i] = next.cache[i];
       st.mb_start = be;
       st.mb_cmds = st.mb_lits = 0;
       st.last_valid = 0;

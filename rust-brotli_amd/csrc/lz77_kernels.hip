@@ -915,9 +915,11 @@ __global__ __launch_bounds__(256) void k_apply_flips(const uint32_t* __restrict_
     return;
   }
   if (i >= n) return;
-  // many changes: one pass over all rows is cheaper than a walk per change.  (Tried total_slots / 1024 with a walk budget
-  // of n / 64: 64 MiB of random bytes went from 70 to 55 ms, 1 GiB of them from 1.8 to 3.4 s.)
-  if (i == 0 && n > total_slots / 256) atomicMax(&ctl[kCtlNeedFull], 1u);
+  // many changes: one pass over all rows is cheaper than a walk per change.  Measured (profiles/r03_c5_xorshift_1GiB_q5.json): a
+  // walked slot costs 0.45 ns, a slot of the full pass 0.017 ns -- 27 x less; k_update_rows gives up after n / 64 walked
+  // slots (it used to walk n / 16 of them, 30 ms at 1 GiB, before the full pass ran anyway), and every change walks at
+  // least 64.
+  if (i == 0 && n > total_slots / 4096) atomicMax(&ctl[kCtlNeedFull], 1u);
   const uint32_t p = changed_pos[i];
   const uint32_t key = keys[p];
   uint32_t lo = key_first[key], hi = key_last[key];
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
     // A change in front of a long stretch of unstored slots reaches every row of the stretch, and several such changes
     // walk the same stretch again and again: when the walks add up to a good part of all rows, the full rebuild behind
     // this kernel is the cheaper way (what was updated here has been checked and marked already).
-    if (a.walk_counter[kCtlWalked] > a.n / 16 || *(volatile const uint32_t*)&a.ctl[kCtlNeedFull] != 0) {
+    if (a.walk_counter[kCtlWalked] > a.n / 64 || *(volatile const uint32_t*)&a.ctl[kCtlNeedFull] != 0) {
       if (threadIdx.x == 0) atomicMax(&a.walk_counter[kCtlNeedFull], 1u);
       return;
     }
@@ -1728,6 +1730,8 @@ static ChainTables live_chain_tables(const Lz77Params& P, const Lz77Buffers& B, 
   T.live_num = L.num;
   T.live_buckets = L.buckets;
   T.live_state = L.state;
+  T.logs.logs_16 = dt.logs_16;
+  T.logs.logs_8 = dt.logs_8;
   return T;
 }
 
@@ -1807,13 +1811,14 @@ struct LiveParseArgs {
 template <bool kRows>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_parse_live(LiveParseArgs a) {
   __shared__ ChainScratchT<false, kRows> scratch;
+  __shared__ uint32_t histo[256];
   const uint32_t item = blockIdx.x;
   if (item >= a.count) return;
   const uint32_t first = a.first[item];
   const uint32_t table = first / a.span_blocks;
   uint32_t last = (table + 1) * a.span_blocks;
   if (last > a.P.num_segments) last = a.P.num_segments;
-  br_parse_live<kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, first, last, table);
+  br_parse_live<kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, first, last, table, histo);
 }
 
 void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first_dev, uint32_t count) {

@@ -50,7 +50,7 @@ struct LiveRing {
 #define BR_LIVE_ST8(p, v) (*(p) = (uint8_t)(v))
 #else
 // The chain reads back what it wrote a moment ago: device-scope accesses (served by the L2) so that no stale line of
-// the vector L1 gets in between; the s_waitcnt of BR_SYNC() orders a store in front of the loads that follow it.
+// the vector L1 gets in between; a wavefront's accesses to one address arrive there in program order.
 #define BR_LIVE_LD16(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define BR_LIVE_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define BR_LIVE_ST16(p, v) __hip_atomic_store((p), (uint16_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -70,9 +70,12 @@ BR_DEV void br_live_insert(const LiveRing& lr, uint32_t key, uint32_t n, uint32_
 // Store / StoreRange + StoreRangeOptBatch / Store4Vec4 / StoreEvenVec4, mod.rs:1644-1661, 1163-1232, 1581-1643, 1526-1580:
 // all of them are "Store in ascending order" as far as ring counters and slots go (mod.rs test.rs:101-111); the batch
 // form writes (ix & mask) where Store writes ix.
-BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint32_t count, uint32_t masked_lo, uint32_t masked_hi) {
+BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint32_t count, uint32_t masked_lo, uint32_t masked_hi,
+                          uint32_t kwin = 0, uint32_t kwin_base = 0xffffff00u) {
   const uint32_t depth = 1u << lr.bits;
 #if BR_SCALAR
+  (void)kwin;
+  (void)kwin_base;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t q = base + i * step;
     const uint32_t key = lr.keys[q];
@@ -81,12 +84,16 @@ BR_DEV void br_live_store(const LiveRing& lr, uint32_t base, uint32_t step, uint
     lr.num[key] = (uint16_t)(n + 1u);
   }
 #else
+  // (No fence between what was filed before and the loads here: a wavefront's accesses to one address reach the L2 in
+  // program order, and both sides are device-scope accesses that do not stop in the vector L1.)
+  // kwin / kwin_base: the chain's window of 64 hash keys, one per lane (ProbeMeta); positions inside it need no load
   for (uint32_t first = 0; first < count; first += 64) {
-    BR_SYNC();  // what was stored before (the searched positions, the previous 64) is in memory
     const uint32_t i = first + (uint32_t)BR_LANE;
     const bool active = i < count;
     const uint32_t q = base + i * step;
-    const uint32_t key = active ? (uint32_t)lr.keys[q] : 0xffffffffu;
+    const uint32_t off = q - kwin_base;
+    const uint32_t from_window = (uint32_t)__shfl((int)kwin, (int)(off & 63u), 64);
+    const uint32_t key = !active ? 0xffffffffu : (off < 64u ? from_window : (uint32_t)lr.keys[q]);
     const uint32_t n = active ? (uint32_t)BR_LIVE_LD16(lr.num + key) : 0u;
     // lanes with the same key take consecutive slots in lane (= position) order
     unsigned long long todo = __ballot(active);
@@ -122,11 +129,12 @@ BR_DEV void br_live_reset(const LiveRing& lr, uint32_t bucket_bits) {
 
 // What StoreRange(first, last) of a copy files as masked entries (FlagWriter::copy_value says the same per position):
 // the first 4 * floor(n / 4) positions of a range of n >= 8, from masked_from on.
-BR_DEV void br_live_store_copy(const LiveRing& lr, uint32_t first, uint32_t last, uint32_t masked_from) {
+BR_DEV void br_live_store_copy(const LiveRing& lr, uint32_t first, uint32_t last, uint32_t masked_from, uint32_t kwin = 0,
+                               uint32_t kwin_base = 0xffffff00u) {
   if (last <= first) return;
   const uint32_t n = last - first;
   const uint32_t masked_hi = n >= 8 ? first + (n & ~3u) : first;
-  br_live_store(lr, first, 1, n, masked_from, masked_hi);
+  br_live_store(lr, first, 1, n, masked_from, masked_hi, kwin, kwin_base);
 }
 
 // ---- materialisation --------------------------------------------------------------------------------------------------

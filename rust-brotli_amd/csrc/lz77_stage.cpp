@@ -574,6 +574,7 @@ bool Lz77Stage::Resolve(bool final_pass) {
       st.last_valid = last_cmd.valid ? 1u : 0u;
       st.last_dist_code = last_cmd.dist_code;
       st.last_copy_len = last_cmd.copy_len;
+      memcpy(st.saved_cache, saved_cache, sizeof(st.saved_cache));
     }
     // ---- chain through the segments of the block
     uint32_t carry = last_insert_len;  // literals pending when the segment is entered
@@ -1078,6 +1079,7 @@ void Lz77Stage::RunLive() {
   books.resize_discard(nseg);
   for (uint32_t k = 0; k < nseg; ++k) books[k] = LiveBlockState{};
   books[0].mb_start = P_.prefix_bytes + raw_head_bytes_;
+  memcpy(books[0].saved_cache, entries_[0].cache, sizeof(books[0].saved_cache));
   int which = 0;
   uint32_t from = 0;
   const uint32_t max_rounds = getenv("BROTLI_MI355X_MAX_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_MAX_ROUNDS")) : nseg + 8;

@@ -67,6 +67,7 @@ static constexpr uint32_t kNeverMasked = 0xffffffffu;
 struct LiveBlockState {
   uint32_t mb_start, mb_cmds, mb_lits;
   uint32_t last_valid, last_dist_code, last_copy_len;
+  int32_t saved_cache[4];  // the distance cache at its start (a meta-block stored uncompressed hands it on, encode.rs:1994)
   uint32_t pad[2];
 };
 // candidate rows (lz77_chain.h): entries per position, end-of-row marker

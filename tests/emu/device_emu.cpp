@@ -468,6 +468,8 @@ static ChainTables emu_chain_tables(const Lz77Params& P, const Lz77Buffers& B, c
   T.live_num = L.num;
   T.live_buckets = L.buckets;
   T.live_state = L.state;
+  T.logs.logs_16 = dt.logs_16;
+  T.logs.logs_8 = dt.logs_8;
   return T;
 }
 
@@ -503,7 +505,8 @@ void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffer
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t t = first[i] / L.span_blocks;
     const uint32_t last = std::min<uint32_t>((t + 1) * L.span_blocks, P.num_segments);
-    br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t);
+    uint32_t histo[256];
+    br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t, histo);
   }
 }
 

@@ -7,7 +7,6 @@ sys.path.insert(0, os.path.join(ROOT, "rust-brotli_amd"))
 import orc, synth, emu, gpulib
 Q, W, SH = 1, 2, 5
 L = gpulib.lib()
-orc.set_h5_absolute_store_range(False)
 
 def chk(name, data, q, w):
     t = time.time()

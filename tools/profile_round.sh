@@ -2,7 +2,7 @@
 # tools/profile_round.sh <tag> -- run on the GPU box (through gpurun): kernel trace + separate PMC passes of the
 # bench command; raw output under gpurun_out/<tag>_*; tools/summarize_profile.py turns it into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 CMD="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
