@@ -83,6 +83,7 @@ struct Lz77Buffers {
   // candidate rows (ring depth <= 16, i.e. quality 5; null otherwise -- then info / sorted are used instead)
   uint16_t* stag;       // br_tag16 of by_key[i]                           [total_bytes]
   uint32_t* rows;       // per position kRowEntries candidates             [16 * total_bytes]
+  uint32_t* dict_items = nullptr;  // optional: the two static-dictionary hash items of every position (k_compute_keys)  [total_bytes + 64]
   uint32_t* changed_slot;  // slot of every changed position                [changed_cap]
   uint32_t* row_ctl;    // device-side control words of lz77_rows_update    [4]
   uint32_t* reset_counts;      // Lz77Params::reset_pos != 0: per key, stored positions in front of reset_vis  [65536]
@@ -153,6 +154,30 @@ void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_
 // lists the keys of the positions whose stored flag differs between flags[prev] and flags[next] in B.changed_keys /
 // B.changed_count (the count may exceed kChangedCap; only the first kChangedCap entries are kept)
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next);
+// ---- bursts: several list launches in a row without the host resolver in between (candidate rows only).  After a launch
+// the device itself chains the exits of the segments it parsed into the entries of their successors inside the block and
+// schedules the next launch: segments whose candidates changed (lz77_rows_update), whose entry changed, or that were left
+// to a chain that did not get there.  What it cannot judge -- block starts (meta-block books, extend_last_command), the
+// static-dictionary throttle, literal sprees carried by arithmetic -- it leaves alone: the host resolver runs after the
+// burst over everything, exactly as after a single launch, and alone decides when the parse is the fixed point.
+struct BurstBuffers {
+  uint8_t* sched = nullptr;        // [segments] as for lz77_parse_list
+  uint8_t* cand_dirty = nullptr;   // [segments] marks of lz77_rows_update
+  uint8_t* entry_dirty = nullptr;  // [segments] the state handed over by the predecessor differs from the entry last used
+  uint8_t* touched = nullptr;      // [segments] parsed at least once since the host last cleared it
+  SegEntry* new_entries = nullptr; // [segments] valid where entry_dirty
+  uint32_t* list = nullptr;        // [segments] the next launch
+  uint32_t* counters = nullptr;    // [0] length of list, [1] number of touched segments (lz77_gather_touched)
+};
+// after lz77_parse_list(list, sched): marks touched[], entry_dirty[] / new_entries[] (see above)
+void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U);
+// counters[0] = number of segments lz77_burst_schedule would list (nothing is changed)
+void lz77_burst_count(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U);
+// list := segments with cand_dirty | entry_dirty | (sched == 2: left to a chain that stopped short); their sched := 1, all
+// others 0; B.entries := new_entries where entry_dirty; the marks are cleared; counters[0] = length
+void lz77_burst_schedule(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U);
+// index / exits / entries of the touched segments, in any order; counters[1] = their number; touched[] is cleared
+void lz77_gather_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, uint32_t* index_out, SegExit* exits_out, SegEntry* entries_out);
 // marks (dirty[k] = 1) the segments that searched a position whose candidate list differs between the rank
 // structures rbuf_old and rbuf_new
 struct SegGeometry {

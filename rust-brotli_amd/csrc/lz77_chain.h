@@ -79,6 +79,7 @@ struct ChainTables {
   // mostly such entries -- 15 hash bits for four bytes -- and their text gathers were what the parse was waiting for.
   const uint16_t* sorted_tag = nullptr;
   const uint32_t* rows;        // kRows chains: per position kRowEntries candidate positions, newest first, 0xffffffff-terminated
+  const uint32_t* dict_items = nullptr;  // optional, kRows chains: per position the two static-dictionary hash items (Lz77Buffers::dict_items)
   uint8_t* flags_next;         // stored flags produced by this round
   Command* cmds;
   const uint16_t* dict_hash;   // kStaticDictionaryHash (src/enc/dictionary_hash.rs)
@@ -139,6 +140,9 @@ struct ChainScratchT {  // one per wavefront (LDS on the device)
   // !kRows, device: the candidates whose text has to be fetched (slot numbers, see br_probe_pair)
   uint16_t fetch_list[kRows ? 2 : 2 * (kMaxCandidates + 2)];
   uint32_t keep[12];  // br_parse_chain: what the previous parse of the segment being redone left behind
+  // kBrotliDictionaryOffsetsByLength, copied in by br_parse_chain: the dictionary lanes of a probe look up where their word
+  // starts, and a load from the table in global memory was a whole memory round trip in front of the candidate fetch
+  uint32_t dict_off[kRows ? 32 : 1];
 };
 
 struct SearchResult {
@@ -466,9 +470,14 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
     BR_SYNC();
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // dictionary hash items of the window positions (SearchInStaticDictionary, mod.rs:1942-1988): lane = 2 * position + probe
+    // (first4 holds the items themselves where the per-position array exists: one memory round trip instead of two)
+    const bool items_ready = t.dict_items != nullptr;
     uint32_t first4[kRowWindow * 2 / 64];
 #pragma unroll
-    for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j) first4[j] = use_dict ? br_load32(t.text + min(p0 + j * 32 + ((uint32_t)BR_LANE >> 1), P.total_bytes)) : 0u;  // (the text is padded by 64 bytes)
+    for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j) {
+      const uint32_t q = min(p0 + j * 32 + ((uint32_t)BR_LANE >> 1), P.total_bytes);  // (text and items are padded by 64 bytes)
+      first4[j] = !use_dict ? 0u : (items_ready ? t.dict_items[q] : br_load32(t.text + q));
+    }
     u32x4 v[kRowWindow * (kRowEntries / 4) / 64];
 #pragma unroll
     for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) {
@@ -481,7 +490,8 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
     if (use_dict) {
 #pragma unroll
       for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j)
-        s.dictwin[j * 64 + BR_LANE] = t.dict_hash[(((first4[j] * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
+        s.dictwin[j * 64 + BR_LANE] = items_ready ? (uint16_t)(first4[j] >> (16u * (BR_LANE & 1)))
+                                                  : t.dict_hash[(((first4[j] * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
     }
 #pragma unroll
     for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) ((u32x4*)s.win)[j * 64 + BR_LANE] = v[j];
@@ -516,7 +526,7 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
     if (item != 0) {
       const uint32_t wlen = item & 0x1f;
       if (wlen <= max_length) {
-        src = t.dict_data + t.dict_offsets_by_length[wlen] + wlen * (item >> 5);
+        src = t.dict_data + s.dict_off[wlen] + wlen * (item >> 5);
         limit = wlen;
       }
     }
@@ -870,6 +880,14 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
   BR_SYNC();
 }
 
+// kBrotliDictionarySizeBitsByLength (RFC 7932 appendix A; lengths 4..24), four bits per length: in registers instead of a
+// table in memory
+BR_DEV uint32_t br_dict_size_bits(uint32_t len) {
+  const uint64_t lo = 0x899aaaaabbaa0000ull;   // lengths 0..15: 0,0,0,0,10,10,11,11,10,10,10,10,10,9,9,8
+  const uint64_t hi = 0x556677877ull;         // lengths 16..24: 7,7,8,7,7,6,6,5,5
+  return (uint32_t)(((len < 16 ? lo : hi) >> (4u * (len & 15u))) & 0xfu);
+}
+
 // The static dictionary stage of FindLongestMatch: SearchInStaticDictionary + TestStaticDictionaryItem, mod.rs:1891-1988
 // (shallow = false), on the two probed hash items; probed(i, &item, &matchlen) hands them over (matchlen: the common
 // prefix of the dictionary word and the text, 0 if the word is longer than max_length).
@@ -906,7 +924,7 @@ BR_DEV void br_dictionary_stage(const Lz77Params& P, const ChainTables& t, DictS
     if (matchlen + 10 <= len || matchlen == 0) continue;
     const uint32_t cut = len - matchlen;
     const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071b520ada2d3200ull >> (cut * 6)) & 0x3f);
-    const uint32_t backward = max_backward + dist + 1 + (transform_id << BR_UNIFORM(t.dict_size_bits_by_length[len]));
+    const uint32_t backward = max_backward + dist + 1 + (transform_id << br_dict_size_bits(len));
     if (backward > P.dist_max_distance) continue;
     const uint32_t score = 30 * 8 * 8 + P.score_per_byte * matchlen - 30 * br_log2_floor_nonzero(backward);
     if (score < threshold) continue;
@@ -1762,6 +1780,13 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
 template <bool kH9, bool kRows>
 BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment* segments,
                            SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
+  if constexpr (kRows) {
+    if (BR_LANE < 32) s.dict_off[BR_LANE] = BR_LANE < 25 ? t.dict_offsets_by_length[BR_LANE] : 0u;
+#if BR_SCALAR
+    for (uint32_t i = 1; i < 32; ++i) s.dict_off[i] = i < 25 ? t.dict_offsets_by_length[i] : 0u;
+#endif
+    BR_SYNC();
+  }
   SegEntry entry = entries[k];
   // a chain takes on at most max_continuation further segments' worth of searches (one search every other byte is
   // the going rate): what it leaves behind is picked up in the next round by a chain of its own, so that a launch with
@@ -2030,6 +2055,42 @@ BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const Li
   SearchResult now;
   br_fold_probe<false, kRows>(P, t, s, m, 0, ds, blk_end, &now, true);
   return br_same_as_logged(rec, now);
+}
+
+// ---- bursts (device_api.h): what the device decides between two list launches, per segment --------------------------------
+// Segment k was parsed in the launch just finished (own chain: sched 1; walked into: sched 3): does the state its exit hands
+// to segment k + 1 (same input block) equal the entry k + 1 was last parsed with?  The plain chaining rule of
+// Lz77Stage::Resolve -- position, spree countdown, distance cache, the step that reaches into k + 1; the dictionary
+// counters and the books stay what k + 1's entry holds (the host judges those).
+BR_DEV void br_chain_check(const Segment* segments, const SegEntry* entries, const SegExit* exits, uint32_t num_segments, uint32_t k,
+                           const uint8_t* sched, uint8_t* touched, uint8_t* entry_dirty, SegEntry* new_entries) {
+  if (sched[k] != 1 && sched[k] != 3) return;
+  touched[k] = 1;
+  if (k + 1 >= num_segments || (segments[k + 1].flags & kSegFirstInBlock)) return;
+  const SegExit& x = exits[k];
+  const SegEntry& u = entries[k + 1];
+  bool same = u.pos == x.pos && u.apply == x.apply && u.head_kind == x.tail_kind && u.head_base == x.tail_base && u.head_p1 == x.tail_p1;
+  for (int i = 0; i < 4; ++i) same = same && u.cache[i] == x.cache[i];
+  if (same) return;
+  SegEntry n = u;
+  n.pos = x.pos;
+  n.apply = x.apply;
+  for (int i = 0; i < 4; ++i) n.cache[i] = x.cache[i];
+  n.head_kind = x.tail_kind;
+  n.head_base = x.tail_base;
+  n.head_p1 = x.tail_p1;
+  n.ext_allowed = 0;
+  new_entries[k + 1] = n;
+  entry_dirty[k + 1] = 1;
+}
+// Does segment k go into the next launch?  Takes its new entry if it has one and clears its marks.
+BR_DEV bool br_burst_schedule_one(SegEntry* entries, uint32_t k, uint8_t* sched, uint8_t* cand_dirty, uint8_t* entry_dirty, const SegEntry* new_entries) {
+  const bool go = cand_dirty[k] != 0 || entry_dirty[k] != 0 || sched[k] == 2;
+  if (entry_dirty[k]) entries[k] = new_entries[k];
+  cand_dirty[k] = 0;
+  entry_dirty[k] = 0;
+  sched[k] = go ? 1 : 0;
+  return go;
 }
 
 }  // namespace brotli_mi355x

@@ -27,12 +27,20 @@ void hip_check(hipError_t e, const char* what) {
 }
 
 // ------------------------------------------------------------------------------------------ keys
+// dict_items (optional, candidate rows with the static dictionary on): for every position the two hash items
+// SearchInStaticDictionary would probe there (mod.rs:1942-1988: kStaticDictionaryHash[2 * hash14(first four bytes) + i]), low
+// half = probe 0.  A chain refills its window of them with one coalesced load instead of text -> hash -> table.
 __global__ __launch_bounds__(256) void k_compute_keys(const uint8_t* __restrict__ text, uint16_t* __restrict__ keys,
                                                       uint32_t n, uint32_t valid_n, uint32_t kind, uint32_t bucket_bits,
-                                                      uint64_t hash_mask, uint32_t* __restrict__ run_samples) {
+                                                      uint64_t hash_mask, uint32_t* __restrict__ run_samples,
+                                                      const uint16_t* __restrict__ dict_hash, uint32_t* __restrict__ dict_items) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
+    if (dict_items != nullptr) {  // (the text is padded by 64 zero bytes)
+      const uint32_t h = ((br_load32(text + i) * 0x1e35a7bdu) >> (32 - 14)) << 1;
+      dict_items[i] = (uint32_t)dict_hash[h] | ((uint32_t)dict_hash[h + 1] << 16);
+    }
     uint32_t key = 0xffffu;
     if (i < valid_n) {
       // sample (every 64th position): does a run of one byte start here?  Enough of those switch on the run table.
@@ -52,6 +60,10 @@ __global__ __launch_bounds__(256) void k_compute_keys(const uint8_t* __restrict_
     }
     keys[i] = (uint16_t)key;
   }
+  if (dict_items != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // (positions behind the end are looked up as position n)
+    const uint32_t h = ((br_load32(text + n) * 0x1e35a7bdu) >> (32 - 14)) << 1;
+    dict_items[n] = (uint32_t)dict_hash[h] | ((uint32_t)dict_hash[h + 1] << 16);
+  }
 }
 
 void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
@@ -63,7 +75,7 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   if (blocks > 8192) blocks = 8192;
   HIP_CHECK(hipMemsetAsync(B.changed_count + 8, 0, 4, BR_STREAM));
   hipLaunchKernelGGL(k_compute_keys, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, B.keys, n, valid_n, P.hasher_kind, P.bucket_bits,
-                     hash_mask, B.changed_count + 8);
+                     hash_mask, B.changed_count + 8, dev_tables().dict_hash, B.dict_items);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1225,7 +1237,8 @@ void lz77_run_table(const Lz77Params& P, const Lz77Buffers& B) {
 
 // ------------------------------------------------------------------------------------------ parse
 struct ParseTiming {
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // the first `used` are recorded; created once, reused from call to call
+  size_t used = 0;
   std::vector<uint32_t> counts;  // chains per launch
   uint64_t segments = 0;
   unsigned long long* work_dev = nullptr;  // [4] what the chains did since the last lz77_parse_timing (ChainTables::work)
@@ -1240,7 +1253,16 @@ static ParseTiming& parse_timing() {
 #endif
 // (quality 9 walks up to 256 ring entries per search through LDS staging and wants registers more than waves: 6 per SIMD
 // measured 8 % faster than 8, which the fixed-layout quality-5 probe prefers)
-template <bool kH9, bool kRows>
+// kSpec: 0 = every parameter is read from ParseArgs.  4 / 8 = the plain quality-5 configuration with that hash type length
+// (H5 / H6 as BrotliEncoderCompress picks them: four cache candidates, 16-deep rings, the quality < 9 spree window and score,
+// no custom-dictionary break, no hasher reset, no masked entries): the constants are folded into the code, which is a tenth
+// shorter and keeps that many fewer scalars alive across the parse loop.  Same results: plain_q5_config() admits only
+// parameter sets that equal the constants.
+static bool plain_q5_config(const Lz77Params& P) {
+  return P.hasher_kind != 9 && P.ndist == 4 && P.block_bits == 4 && P.spree_window == 64 && P.score_per_byte == 135 && P.dict_break == 0 &&
+         P.reset_pos == 0 && P.masked_from == kNeverMasked && (P.htl == 4 || P.htl == 8);
+}
+template <bool kH9, bool kRows, uint32_t kSpec = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kH9 ? 6 : BR_PARSE_WAVES, kH9 ? 6 : BR_PARSE_WAVES))) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratchT<kH9, kRows> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
@@ -1249,7 +1271,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kH9 ? 6 : BR
   if (a.per_xcd) item = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
   if (item >= a.count) return;
   const uint32_t k = a.list ? a.list[item] : a.first_segment + item;
-  br_parse_chain<kH9, kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+  if constexpr (kSpec != 0) {
+    Lz77Params P = a.P;
+    P.ndist = 4;
+    P.block_bits = 4;
+    P.spree_window = 64;
+    P.score_per_byte = 135;
+    P.dict_break = 0;
+    P.reset_pos = 0;
+    P.masked_from = kNeverMasked;
+    P.htl = kSpec;
+    br_parse_chain<kH9, kRows>(P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+  } else {
+    br_parse_chain<kH9, kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+  }
 }
 
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
@@ -1263,6 +1298,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.T.sorted = B.sorted[rbuf];
   a.T.sorted_tag = (!B.rows && B.stag) ? B.sorted_tag[rbuf] : nullptr;
   a.T.rows = B.rows;
+  a.T.dict_items = B.dict_items;
   a.T.run_end = B.run_end;
   a.T.search_log = B.rows ? nullptr : B.search_log;
   a.T.flags_next = B.flags[flags_out];
@@ -1292,9 +1328,14 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.count = count;
   // HIP events around every launch of the dominant kernel (same stream): bench.py's roofline numbers
   ParseTiming& pt = parse_timing();
-  hipEvent_t e0, e1;
-  HIP_CHECK(hipEventCreate(&e0));
-  HIP_CHECK(hipEventCreate(&e1));
+  if (pt.used == pt.events.size()) {
+    hipEvent_t n0, n1;
+    HIP_CHECK(hipEventCreate(&n0));
+    HIP_CHECK(hipEventCreate(&n1));
+    pt.events.push_back(std::make_pair(n0, n1));
+  }
+  const hipEvent_t e0 = pt.events[pt.used].first, e1 = pt.events[pt.used].second;
+  pt.used++;
   HIP_CHECK(hipEventRecord(e0, BR_STREAM));
   static const bool xcd_aware = getenv("BROTLI_MI355X_NO_XCD_MAP") == nullptr;
   a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
@@ -1303,13 +1344,19 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   if (P.hasher_kind == 9) {
     hipLaunchKernelGGL((k_parse_segments<true, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else if (B.rows) {
-    hipLaunchKernelGGL((k_parse_segments<false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    static const bool spec_off = getenv("BROTLI_MI355X_NO_SPEC") != nullptr;
+    if (!spec_off && plain_q5_config(P) && P.htl == 8) {
+      hipLaunchKernelGGL((k_parse_segments<false, true, 8>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    } else if (!spec_off && plain_q5_config(P) && P.htl == 4) {
+      hipLaunchKernelGGL((k_parse_segments<false, true, 4>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    } else {
+      hipLaunchKernelGGL((k_parse_segments<false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    }
   } else {
     hipLaunchKernelGGL((k_parse_segments<false, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   }
   HIP_CHECK(hipEventRecord(e1, BR_STREAM));
   HIP_CHECK(hipGetLastError());
-  pt.events.push_back(std::make_pair(e0, e1));
   pt.counts.push_back(count);
   pt.segments += count;
 }
@@ -1413,6 +1460,75 @@ void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_
   const uint32_t n = count > num_segments ? count : num_segments;
   hipLaunchKernelGGL(k_gather_results, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.exits, B.entries, list_dev, count, sched_dev, num_segments,
                      exits_out, cont_count, cont_index, cont_exits, cont_entries);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ bursts (device_api.h)
+__global__ __launch_bounds__(256) void k_chain_check(const Segment* __restrict__ segments, const SegEntry* __restrict__ entries,
+                                                      const SegExit* __restrict__ exits, uint32_t num_segments, const uint8_t* __restrict__ sched,
+                                                      uint8_t* __restrict__ touched, uint8_t* __restrict__ entry_dirty, SegEntry* __restrict__ new_entries) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < num_segments) br_chain_check(segments, entries, exits, num_segments, k, sched, touched, entry_dirty, new_entries);
+}
+void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
+  hipLaunchKernelGGL(k_chain_check, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.segments, B.entries, B.exits, P.num_segments,
+                     U.sched, U.touched, U.entry_dirty, U.new_entries);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_burst_count(uint32_t num_segments, const uint8_t* __restrict__ sched, const uint8_t* __restrict__ cand_dirty,
+                                                      const uint8_t* __restrict__ entry_dirty, uint32_t* __restrict__ counters) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool go = k < num_segments && (cand_dirty[k] != 0 || entry_dirty[k] != 0 || sched[k] == 2);
+  const unsigned long long m = __ballot(go);
+  if (m != 0 && (threadIdx.x & 63u) == 0) atomicAdd(&counters[0], (uint32_t)__popcll(m));
+}
+void lz77_burst_count(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
+  HIP_CHECK(hipMemsetAsync(U.counters, 0, 4, BR_STREAM));
+  hipLaunchKernelGGL(k_burst_count, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, P.num_segments, U.sched, U.cand_dirty, U.entry_dirty,
+                     U.counters);
+  HIP_CHECK(hipGetLastError());
+  (void)B;
+}
+
+__global__ __launch_bounds__(256) void k_burst_schedule(SegEntry* __restrict__ entries, uint32_t num_segments, uint8_t* __restrict__ sched,
+                                                         uint8_t* __restrict__ cand_dirty, uint8_t* __restrict__ entry_dirty,
+                                                         const SegEntry* __restrict__ new_entries, uint32_t* __restrict__ list, uint32_t* __restrict__ counters) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool go = k < num_segments && br_burst_schedule_one(entries, k, sched, cand_dirty, entry_dirty, new_entries);
+  // (segments of one wave keep their order in the list, waves land in the order they get here: chains of neighbouring
+  // segments stay neighbours, which is all the launch cares about)
+  const unsigned long long m = __ballot(go);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&counters[0], (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, (int)leader, 64);
+  if (go) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+}
+void lz77_burst_schedule(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
+  HIP_CHECK(hipMemsetAsync(U.counters, 0, 4, BR_STREAM));
+  hipLaunchKernelGGL(k_burst_schedule, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.entries, P.num_segments, U.sched, U.cand_dirty,
+                     U.entry_dirty, U.new_entries, U.list, U.counters);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_gather_touched(const SegExit* __restrict__ exits, const SegEntry* __restrict__ entries, uint32_t num_segments,
+                                                         uint8_t* __restrict__ touched, uint32_t* __restrict__ counters, uint32_t* __restrict__ index_out,
+                                                         SegExit* __restrict__ exits_out, SegEntry* __restrict__ entries_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_segments || !touched[k]) return;
+  touched[k] = 0;
+  const uint32_t j = atomicAdd(&counters[1], 1u);
+  index_out[j] = k;
+  exits_out[j] = exits[k];
+  entries_out[j] = entries[k];
+}
+void lz77_gather_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, uint32_t* index_out, SegExit* exits_out, SegEntry* entries_out) {
+  HIP_CHECK(hipMemsetAsync(U.counters + 1, 0, 4, BR_STREAM));
+  hipLaunchKernelGGL(k_gather_touched, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.exits, B.entries, P.num_segments, U.touched,
+                     U.counters, index_out, exits_out, entries_out);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1564,21 +1680,19 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments,
   double ms = 0;
   static const bool show = getenv("BROTLI_MI355X_DEBUG_LAUNCH") != nullptr;
   size_t idx = 0;
-  for (auto& ev : pt.events) {
+  for (; idx < pt.used; ++idx) {
+    const auto& ev = pt.events[idx];
     float t = 0;
     HIP_CHECK(hipEventSynchronize(ev.second));
     HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
     if (show) fprintf(stderr, "  parse launch %zu: %u chains, %.3f ms\n", idx, pt.counts[idx], t);
-    ++idx;
     ms += t;
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
   }
   *total_ms = ms;
-  *launches = (uint32_t)pt.events.size();
+  *launches = (uint32_t)pt.used;
   pt.counts.clear();
   *segments = pt.segments;
-  pt.events.clear();
+  pt.used = 0;
   pt.segments = 0;
 }
 

@@ -45,6 +45,7 @@ void Lz77Stage::Release() {
     dev_free(B_.key_base);
     dev_free(B_.stag);
     dev_free(B_.rows);
+    dev_free(B_.dict_items);
     dev_free(B_.changed_slot);
     dev_free(B_.row_ctl);
     dev_free(B_.big_tile);
@@ -186,6 +187,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.gprev = (uint32_t*)dev_alloc_uninit((M / 64 + 2) * 4 + 64);
     B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
     B_.rows = (uint32_t*)dev_alloc_uninit(M * kRowEntries * 4 + 64);
+    if (P_.use_dictionary) B_.dict_items = (uint32_t*)dev_alloc_uninit(M * 4 + 256);
   } else {
     B_.changed_cap = kChangedCap;
     B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
@@ -1246,6 +1248,20 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   SegExit* cont_exits_dev = (SegExit*)dev_alloc_uninit((size_t)cont_cap * sizeof(SegExit) + 64);
   SegEntry* cont_entries_dev = (SegEntry*)dev_alloc_uninit((size_t)cont_cap * sizeof(SegEntry) + 64);
   std::vector<uint32_t> also_upload;
+  // bursts (device_api.h): up to burst_max list launches per pass of the host resolver, scheduled on the device in between
+  static const uint32_t burst_env = getenv("BROTLI_MI355X_BURST") ? (uint32_t)atoi(getenv("BROTLI_MI355X_BURST")) : 8u;
+  static const uint32_t burst_shrink = getenv("BROTLI_MI355X_BURST_SHRINK") ? (uint32_t)atoi(getenv("BROTLI_MI355X_BURST_SHRINK")) : 4u;
+  const uint32_t burst_max = use_rows_ ? burst_env : 0u;  // 0: one launch per pass, scheduled by the host (rank-structure chains)
+  BurstBuffers U;
+  if (burst_max != 0) {
+    U.sched = (uint8_t*)dev_alloc(nseg + 64);
+    U.cand_dirty = dirty_dev;
+    U.entry_dirty = (uint8_t*)dev_alloc(nseg + 64);
+    U.touched = (uint8_t*)dev_alloc(nseg + 64);
+    U.new_entries = (SegEntry*)dev_alloc_uninit((size_t)nseg * sizeof(SegEntry) + 64);
+    U.list = (uint32_t*)dev_alloc_uninit((size_t)nseg * 4 + 64);
+    U.counters = (uint32_t*)dev_alloc(64);
+  }
   RoundBuffers& rb = round_buffers_;  // page-locked, kept from call to call
   rb.up_index.resize_discard((size_t)nseg * 2);
   rb.up_entries.resize_discard((size_t)nseg * 2);
@@ -1296,9 +1312,51 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       dev_h2d(list_dev, up_index, (size_t)n_up * 4);
       dev_h2d(up_entries_dev, up_entries, (size_t)n_up * sizeof(SegEntry));
       lz77_scatter_entries(B_, list_dev, up_entries_dev, n_up);
-      dev_h2d(dirty_dev, sched.data(), nseg);
+      dev_h2d(burst_max != 0 ? U.sched : dirty_dev, sched.data(), nseg);
     }
     also_upload.clear();
+    const bool burst = !full_round && burst_max != 0;
+    uint32_t n_touched = 0;
+    if (burst) {
+      // launch, bring the rows up to date, chain the exits on the device, schedule the next launch there; the host only
+      // waits for the length of the next list
+      const uint32_t* launch_list = list_dev;
+      uint32_t launch_count = count;
+      for (uint32_t it = 0;; ++it) {
+        dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+        lz77_parse_list(P_, B_, which, rbuf, launch_list, U.sched, launch_count);
+        stats_.segments_parsed += launch_count;
+        lz77_diff_flags(P_, B_, which, which ^ 1);
+        dev_memset(dirty_dev, 0, nseg);
+        lz77_rows_update(P_, B_, which, which ^ 1, geo, dirty_dev, has_big_keys_);
+        lz77_chain_check(P_, B_, U);
+        which ^= 1;
+        stats_.burst_launches++;
+        if (it + 1 >= burst_max) break;
+        lz77_burst_count(P_, B_, U);
+        dev_d2h((void*)counts, U.counters, 4);
+        const uint32_t next_count = counts[0];
+        if (debug) fprintf(stderr, "  burst launch %u: %u segments next\n", it, next_count);
+        // The device goes on by itself only while the parse is settling fast (text: 2 900 -> 7 -> 0 segments).  Where every
+        // launch leaves about as many segments dirty as it parsed (pieces of a mix that never fall back into step), parsing
+        // all of them again from entries chained out of parses that are themselves about to be redone only adds noise: the
+        // host resolver, which leaves such segments to the chain in front of them, takes over.  (The marks of this launch
+        // are still on the device: nothing was cleared.)
+        if (next_count == 0 || (uint64_t)next_count * burst_shrink > launch_count) break;
+        lz77_burst_schedule(P_, B_, U);
+        launch_list = U.list;
+        launch_count = next_count;
+      }
+      which ^= 1;  // (flags[which ^ 1] holds the newest flags; the common code below flips)
+      lz77_gather_touched(P_, B_, U, cont_index_dev, cont_exits_dev, cont_entries_dev);
+      dev_d2h((void*)counts, U.counters, 8);
+      n_touched = counts[1];
+      dev_d2h_async(cont_index, cont_index_dev, (size_t)n_touched * 4);
+      dev_d2h_async(cont_exits, cont_exits_dev, (size_t)n_touched * sizeof(SegExit));
+      dev_d2h_async(cont_entries, cont_entries_dev, (size_t)n_touched * sizeof(SegEntry));
+      dev_sync();
+      stamp("burst-done");
+    } else {
     dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
     stamp("uploaded");
     if (full_round) {
@@ -1308,6 +1366,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     stats_.segments_parsed += count;
     lz77_diff_flags(P_, B_, which, which ^ 1);
+    }
     if (getenv("BROTLI_MI355X_DEBUG_FLAGS")) {
       std::vector<uint8_t> fa(P_.total_bytes), fb(P_.total_bytes);
       dev_d2h(fa.data(), B_.flags[which], P_.total_bytes);
@@ -1321,6 +1380,17 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     // everything the host needs from this launch in one round trip: exit records, the change list, and -- in list
     // rounds -- the entries and marks of the segments that chains continued into
+    if (burst) {
+      // the exits and entries of every segment parsed during the burst (the device rewrote entries it chained itself)
+      for (uint32_t i = 0; i < n_touched; ++i) {
+        const uint32_t k = cont_index[i];
+        pending[k] = 0;
+        exits_[k] = cont_exits[i];
+        entries_[k] = cont_entries[i];
+      }
+      counts[0] = 1;  // (read the marks of the last lz77_rows_update below)
+      counts[1] = 0;
+    } else {
     counts[0] = counts[1] = 0;
     if (full_round) {
       dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
@@ -1349,8 +1419,9 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     } else {
       dev_sync();
     }
+    }
     const uint32_t n_changed = counts[0], n_cont = counts[1];
-    if (!full_round) {
+    if (!full_round && !burst) {
       for (uint32_t i = 0; i < count; ++i) exits_[list[i]] = got_exits[i];
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
       if (n_cont > kContFirst) {
@@ -1586,6 +1657,12 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   dev_free(cont_index_dev);
   dev_free(cont_exits_dev);
   dev_free(cont_entries_dev);
+  dev_free(U.sched);
+  dev_free(U.entry_dirty);
+  dev_free(U.touched);
+  dev_free(U.new_entries);
+  dev_free(U.list);
+  dev_free(U.counters);
   if (restart) {
     // what the pass so far says about the state at every block start
     saved_block_guess_.clear();

@@ -39,6 +39,7 @@ struct Lz77Stats {
   uint64_t searches = 0;
   uint64_t total_commands = 0;
   uint32_t incremental_ranks = 0, full_ranks = 0, coarse_restarts = 0;
+  uint32_t burst_launches = 0;  // list launches scheduled on the device (device_api.h, bursts)
   // wall-clock milliseconds per phase (device synchronised), filled when profiling is enabled
   uint64_t cache_rechecks = 0;
   double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;

@@ -598,6 +598,34 @@ void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t nu
       out[offsets[k] + i] = br_finish_command(B.cmds[(size_t)B.segments[k].cmd_base + i], P.num_direct_distance_codes, P.dist_postfix_bits);
 }
 
+// ---- bursts (device_api.h)
+void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
+  for (uint32_t k = 0; k < P.num_segments; ++k) br_chain_check(B.segments, B.entries, B.exits, P.num_segments, k, U.sched, U.touched, U.entry_dirty, U.new_entries);
+}
+void lz77_burst_count(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
+  uint32_t n = 0;
+  for (uint32_t k = 0; k < P.num_segments; ++k) n += (U.cand_dirty[k] != 0 || U.entry_dirty[k] != 0 || U.sched[k] == 2) ? 1u : 0u;
+  U.counters[0] = n;
+}
+void lz77_burst_schedule(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
+  uint32_t n = 0;
+  for (uint32_t k = 0; k < P.num_segments; ++k)
+    if (br_burst_schedule_one(B.entries, k, U.sched, U.cand_dirty, U.entry_dirty, U.new_entries)) U.list[n++] = k;
+  U.counters[0] = n;
+}
+void lz77_gather_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, uint32_t* index_out, SegExit* exits_out, SegEntry* entries_out) {
+  uint32_t n = 0;
+  for (uint32_t k = P.num_segments; k-- > 0;) {  // (any order will do: the host must not rely on one)
+    if (!U.touched[k]) continue;
+    U.touched[k] = 0;
+    index_out[n] = k;
+    exits_out[n] = B.exits[k];
+    entries_out[n] = B.entries[k];
+    ++n;
+  }
+  U.counters[1] = n;
+}
+
 void lz77_scatter_entries(const Lz77Buffers& B, const uint32_t* index, const SegEntry* entries, uint32_t count) {
   for (uint32_t i = 0; i < count; ++i) B.entries[index[i]] = entries[i];
 }
