@@ -28,6 +28,11 @@
  * encode.rs:1623-1631, 1705-1710) is reproduced.  Streams with a custom
  * dictionary or in the catable / appendable modes are buffered whole until BROTLI_OPERATION_FINISH (at most 2 GiB) and
  * cannot be flushed.  All input offered to a call is always consumed (*available_in becomes 0).
+ *
+ * BrotliEncoderCompress (one shot) takes inputs of any size: above 1 GiB (BROTLI_MI355X_ONESHOT_STREAM_ABOVE bytes) the
+ * call runs through the same stream state machine in batches -- encoder_compress is a loop over compress_stream with
+ * FINISH (encode.rs:1484-1520) -- so its device memory stays bounded as well and the bytes are the reference's one-shot
+ * stream (tests/test_oneshot_streamed.py, tests/test_large_gpu.py::test_one_shot_above_2GiB).
  */
 #ifndef BROTLI_MI355X_H_
 #define BROTLI_MI355X_H_

@@ -612,6 +612,59 @@ void BrotliEncoderFreeUsize(BrotliEncoderState* s, size_t* data, size_t) {
   }
 }
 
+// Inputs above this size take the one-shot call through the stream state machine in batches (bounded device memory, no 2 GiB
+// limit): encoder_compress IS a loop over compress_stream with BROTLI_OPERATION_FINISH (encode.rs:1484-1520), and the stream
+// does not depend on how the input is cut into calls as long as nothing is flushed -- input blocks fill up to 64 KiB whatever
+// the writes, and the last block is known to be the last because the FINISH call itself hands over the final bytes.
+static size_t OneShotStreamThreshold() {
+  static const size_t v = getenv("BROTLI_MI355X_ONESHOT_STREAM_ABOVE") ? (size_t)strtoull(getenv("BROTLI_MI355X_ONESHOT_STREAM_ABOVE"), nullptr, 10) : ((size_t)1 << 30);
+  return v;
+}
+
+// 1 = done, 0 = failed (message set), -1 = the stream does not fit the output buffer
+static int CompressOneShotStreamed(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size, const uint8_t* input, size_t* encoded_size,
+                                   uint8_t* encoded) {
+  BrotliEncoderState* s = BrotliEncoderCreateInstance(nullptr, nullptr, nullptr);
+  if (!s) return 0;
+  BrotliEncoderSetParameter(s, BROTLI_PARAM_QUALITY, (uint32_t)quality);
+  BrotliEncoderSetParameter(s, BROTLI_PARAM_LGWIN, (uint32_t)lgwin);
+  BrotliEncoderSetParameter(s, BROTLI_PARAM_MODE, (uint32_t)mode);
+  BrotliEncoderSetParameter(s, BROTLI_PARAM_SIZE_HINT, (uint32_t)input_size);  // (a u32 in the reference as well, encode.rs:1474)
+  if (lgwin > 24) BrotliEncoderSetParameter(s, BROTLI_PARAM_LARGE_WINDOW, 1);
+  const size_t batch = StreamBatchBytes();
+  size_t available_out = *encoded_size, done = 0;
+  uint8_t* next_out = encoded;
+  int result = 1;
+  while (result == 1) {
+    const bool last = input_size - done <= batch;
+    size_t available_in = last ? input_size - done : batch;
+    const uint8_t* next_in = input + done;
+    const size_t fed = available_in;
+    if (!BrotliEncoderCompressStream(s, last ? BROTLI_OPERATION_FINISH : BROTLI_OPERATION_PROCESS, &available_in, &next_in, &available_out, &next_out, nullptr)) {
+      result = 0;
+      break;
+    }
+    done += fed - available_in;
+    if (last && available_in == 0) {
+      // drain what the last call could not hand over
+      while (BrotliEncoderHasMoreOutput(s) && available_out != 0) {
+        size_t none = 0;
+        const uint8_t* nothing = nullptr;
+        if (!BrotliEncoderCompressStream(s, BROTLI_OPERATION_FINISH, &none, &nothing, &available_out, &next_out, nullptr)) {
+          result = 0;
+          break;
+        }
+      }
+      if (result == 1 && !BrotliEncoderIsFinished(s)) result = -1;
+      break;
+    }
+    if (BrotliEncoderHasMoreOutput(s) && available_out == 0) result = -1;
+  }
+  if (result == 1) *encoded_size = (size_t)(next_out - encoded);
+  BrotliEncoderDestroyInstance(s);
+  return result;
+}
+
 static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mode, size_t input_size, const uint8_t* input,
                                    bool input_on_device, size_t* encoded_size, uint8_t* encoded, double* stats_out) {
   // encoder_compress, encode.rs:1436-1538
@@ -626,6 +679,21 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
   // encode.rs:1468-1481: the one-shot entry runs quality 10 ("9.5") at quality 9, with an H9 hasher made ahead of time from
   // {q9_5, quality 10} -- the hasher quality 9 selects anyway.  (Quality 10 / 11 through the stream API are Zopfli.)
   if (quality == 10) quality = 9;
+  if (!input_on_device && input_size > OneShotStreamThreshold()) {
+    size_t n = out_size;
+    const int r = CompressOneShotStreamed(quality, lgwin, mode, input_size, input, &n, encoded);
+    if (r == 1 && !(max_out_size != 0 && n > max_out_size)) {
+      *encoded_size = n;
+      return BROTLI_TRUE;
+    }
+    *encoded_size = 0;
+    if (r == 0 || max_out_size == 0) return BROTLI_FALSE;
+    if (out_size >= max_out_size) {  // (compression expanded the input, or the caller's buffer is too small for it: as below)
+      *encoded_size = MakeUncompressedStream(input, input_size, encoded);
+      return BROTLI_TRUE;
+    }
+    return BROTLI_FALSE;
+  }
   bool ok = false;
   std::vector<uint8_t> out;
   try {

@@ -219,7 +219,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
   B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
   B_.sort_tmp_bytes = lz77_sort_tmp_bytes(P_.total_bytes);
-  B_.sort_tmp = dev_alloc(B_.sort_tmp_bytes);
+  B_.sort_tmp = dev_alloc_uninit(B_.sort_tmp_bytes);  // (every user writes what it reads: histograms, tile sums, ping-pong arrays)
   histo_dev_ = (uint32_t*)dev_alloc(256 * 4);
   gather_offsets_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
   gather_counts_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);

@@ -50,6 +50,11 @@ CASES["stream_4GiB_q5_w22_hinted"] = dict(make=lambda: synth.markov_text(4 << 30
                                           hint=1 << 30, bench_only=True)
 
 
+# BrotliEncoderCompress on more than 2 GiB (round 2 refused it): the call goes through the stream state machine in 64 MiB
+# batches (cabi.cpp CompressOneShotStreamed) and must produce the one-shot stream of the reference, size hint = (u32) size
+CASES["oneshot_2304MiB_q5_w22"] = dict(make=lambda: synth.markov_text(9 << 28, 0x5EED00000000000B), quality=5, lgwin=22, bench_only=True)
+
+
 def make_input(name, frozen=None):
     """the input of case `name`; multi-shard cases use the seed recorded in tests/golden/large_hashes.json"""
     case = CASES[name]

@@ -149,3 +149,18 @@ def test_stream_4GiB_bounded_memory(L):
     assert early > total // 2, "PROCESS did not hand out output mid-stream"
     assert total == FROZEN[name]["stream_bytes"]
     assert h.hexdigest() == FROZEN[name]["stream_sha256"]
+
+
+def test_one_shot_above_2GiB(L):
+    """BrotliEncoderCompress on 2.25 GiB (round 2 refused anything from 2 GiB): the call runs through the stream state machine
+    in 64 MiB batches (cabi.cpp CompressOneShotStreamed, bounded device memory) and yields the reference's one-shot stream
+    (size hint = (u32) input size, as encode.rs:1474 sets it)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "rust-brotli_amd"))
+    import brotli_mi355x
+    name = "oneshot_2304MiB_q5_w22"
+    if name not in FROZEN:
+        pytest.skip("no frozen oracle hash (tools/freeze_large_hashes.py %s)" % name)
+    data = _input(name)
+    out = brotli_mi355x.default_library().compress(data, 5, 22)
+    _check(name, out, data)
