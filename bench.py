@@ -128,7 +128,19 @@ def timed_steps(fn, steps, warmup, torch):
     return (time.time() - t0) / steps, out
 
 
-def other_workloads(torch, bm, lib, enc, frozen):
+def parse_roofline(walked, searches, cmds, parse_ms, launches, row_bytes):
+    """roofline block of the parse kernel from what its launches did (same accounting as the headline): bytes = 2 B per
+    position walked + one candidate row per search (64 B at ring depth 16; 4 B x ring depth otherwise) + 16 B per command"""
+    bytes_done = 2.0 * walked + float(row_bytes) * searches + 16.0 * cmds
+    sec = parse_ms * 1e-3
+    achieved = bytes_done / sec / 1e9 if sec > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_parse_segments", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "avg_launch_ms": round(parse_ms / max(1, launches), 3), "launches": int(launches),
+            "alg_bytes_per_launch": int(bytes_done / max(1, launches)), "row_bytes_per_search": row_bytes,
+            "traffic": None, "traffic_source": "profiles/r03_<workload>.json holds the FETCH_SIZE / WRITE_SIZE passes of this workload"}
+
+
+def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
     """BASELINE configs[2], [4], zero fill, and configs[3] cut to 1 GiB, at their stated sizes on this one GPU"""
     import large_cases
     res = []
@@ -163,6 +175,11 @@ def other_workloads(torch, bm, lib, enc, frozen):
             enc._out, enc._out_owner = saved
             entry["residency"] = "input resident in HBM, output to page-locked host memory"
             entry["lz77_rounds"] = enc.stats[0]
+            if work_fn is not None:  # (the last of the timed calls)
+                work = (ctypes.c_double * 4)()
+                work_fn(work)
+                row_bytes = 64 if case["quality"] == 5 else 4 * (1 << {6: 5, 7: 6, 8: 7, 9: 8}[case["quality"]])
+                entry["roofline"] = parse_roofline(work[0], work[1], work[2], enc.stats[26], enc.stats[27], row_bytes)
             del dev, pinned
         entry.update({"value": round(len(data) / sec / 1e6, 1), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 2), "compressed_bytes": len(out),
                       "identical_to_cpu_oracle": hashlib.sha256(out).hexdigest() == frozen[name]["stream_sha256"],
@@ -367,12 +384,13 @@ def main():
     one_pass = (2.0 * per_gpu + 64.0 * S + 16.0 * K) * args.steps  # the useful share: one sequential pass over the input
     whole_step = 9.0 * per_gpu + 64.0 * S + 48.0 * K + 2.0 * Lit + len(comp) / world  # SURVEY 8d, bytes per step and GPU
     traffic, traffic_src = None, None
-    for cand in ("r02_pmc_parse.json",):
+    for cand in ("r03_pmc_parse.json", "r02_pmc_parse.json"):
         pmc = os.path.join(ROOT, "profiles", cand)
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 traffic, traffic_src = j.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 PMC passes of commit %s, not measured in this run)" % (cand, j.get("commit", "?"))
+                break
             except Exception:
                 pass
     line = {
@@ -443,7 +461,7 @@ def main():
         line["config"]["identical_to_cpu_oracle"] = (ref_bytes == comp)
     if not args.no_extras and not shard_job:
         try:
-            line["other_workloads"] = other_workloads(torch, bm, lib, enc, frozen)
+            line["other_workloads"] = other_workloads(torch, bm, lib, enc, frozen, work_fn)
         except Exception as e:  # the headline must not die with an extra
             line["other_workloads"] = {"error": repr(e)}
     if c4 is not None:

@@ -83,6 +83,13 @@ struct Lz77Buffers {
   // candidate rows (ring depth <= 16, i.e. quality 5; null otherwise -- then info / sorted are used instead)
   uint16_t* stag;       // br_tag16 of by_key[i]                           [total_bytes]
   uint32_t* rows;       // per position kRowEntries candidates             [16 * total_bytes]
+  // checkpoints (lz77_chain.h, Checkpoint): one 128-byte record per 512 bytes of text, and per segment the lowest / highest
+  // searched position whose candidate row changed since the segment was parsed last (written by lz77_rows_update, reset by
+  // lz77_chain_check for the segments a launch parsed)
+  void* checkpoints = nullptr;            // Checkpoint[total_bytes / 512 + 2]
+  uint32_t* rows_changed_lo = nullptr;    // [segments]
+  uint32_t* rows_changed_hi = nullptr;    // [segments]
+  uint32_t splice_lists = 1;              // list launches run the chains that restart from / stop at checkpoints (set per launch by the host)
   uint32_t* dict_items = nullptr;  // optional: the two static-dictionary hash items of every position (k_compute_keys)  [total_bytes + 64]
   uint32_t* changed_slot;  // slot of every changed position                [changed_cap]
   uint32_t* row_ctl;    // device-side control words of lz77_rows_update    [4]
@@ -169,8 +176,14 @@ struct BurstBuffers {
   uint32_t* list = nullptr;        // [segments] the next launch
   uint32_t* counters = nullptr;    // [0] length of list, [1] number of touched segments (lz77_gather_touched)
 };
-// after lz77_parse_list(list, sched): marks touched[], entry_dirty[] / new_entries[] (see above)
+// after lz77_parse_list(list, sched): marks touched[], entry_dirty[] / new_entries[] (see above); the rows_changed_lo / _hi
+// marks of the segments the launch parsed are reset -- call it BEFORE the lz77_rows_update that follows the launch
 void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U);
+// rows_changed_lo / _hi of every segment := none (after a launch that parsed all of them)
+void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B);
+// the checkpoints of the listed segments are dropped (their parse now stands for another distance cache at the entry than
+// the records were taken with, Lz77Stage::RecheckCacheOnly)
+void lz77_drop_checkpoints(const Lz77Params& P, const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count);
 // counters[0] = number of segments lz77_burst_schedule would list (nothing is changed)
 void lz77_burst_count(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U);
 // list := segments with cand_dirty | entry_dirty | (sched == 2: left to a chain that stopped short); their sched := 1, all

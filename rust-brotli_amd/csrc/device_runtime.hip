@@ -1,5 +1,6 @@
 // device_runtime.hip -- device memory helpers and the read-only tables of the encoder hot path.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -36,10 +37,53 @@ struct Pool {
   std::unordered_map<void*, size_t> capacity;  // every live block handed out or pooled
   size_t pooled_bytes = 0;
   static constexpr size_t kMaxPooled = (size_t)192 << 30;  // (a 1 GiB piece alone needs ~90 GiB; of 288)
-  ~Pool() {
-    for (auto& kv : free_blocks) (void)hipFree(kv.second);  // (errors at process exit are of no consequence)
+  Pool();
+  ~Pool();
+  // hands every pooled block back to the driver; returns the bytes freed (any thread may call it: hipFree waits for the
+  // device, so nothing queued on the owner's stream can still be using a block that sits in its free list)
+  size_t Trim() {
+    std::vector<void*> drop;
+    size_t bytes;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (auto& kv : free_blocks) {
+        drop.push_back(kv.second);
+        capacity.erase(kv.second);
+      }
+      free_blocks.clear();
+      bytes = pooled_bytes;
+      pooled_bytes = 0;
+    }
+    for (void* d : drop) (void)hipFree(d);
+    return bytes;
   }
 };
+// Every host thread has a pool of its own, but the memory they sit on is one device's: when an allocation fails, the
+// pools of the OTHER threads are emptied as well (the helper threads of BrotliEncoderCompressMulti start with nothing while
+// the calling thread may be sitting on 190 GiB from earlier one-shot calls).
+std::mutex g_pools_mu;
+std::vector<Pool*>& all_pools() {
+  static std::vector<Pool*>* v = new std::vector<Pool*>;  // (never destroyed: threads may outlive static destruction)
+  return *v;
+}
+Pool::Pool() {
+  std::lock_guard<std::mutex> lock(g_pools_mu);
+  all_pools().push_back(this);
+}
+Pool::~Pool() {
+  {
+    std::lock_guard<std::mutex> lock(g_pools_mu);
+    auto& v = all_pools();
+    v.erase(std::remove(v.begin(), v.end(), this), v.end());
+  }
+  for (auto& kv : free_blocks) (void)hipFree(kv.second);  // (errors at process exit are of no consequence)
+}
+size_t TrimAllPools() {
+  std::lock_guard<std::mutex> lock(g_pools_mu);
+  size_t bytes = 0;
+  for (Pool* q : all_pools()) bytes += q->Trim();
+  return bytes;
+}
 // one pool per host thread = per stream: a block is only ever reused by work queued behind its previous use
 Pool& pool() {
   static thread_local Pool p;
@@ -103,21 +147,28 @@ static void* AllocBlock(size_t bytes) {
   }
   if (!p) {
     DriverCallClock clock(0);
+    // Leave the runtime room of its own: kernel scratch, the queues of helper threads, signals.  With every last byte in
+    // the pools, a later launch died inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES, "Available Free mem : 0 MB")
+    // where nothing can be caught.  Idle pooled blocks go back first -- this thread's, then every thread's.
+    {
+      static constexpr size_t kHeadroom = (size_t)6 << 30;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < cap + kHeadroom) {
+        P.Trim();
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < cap + kHeadroom) TrimAllPools();
+      }
+    }
     hipError_t e = hipMalloc(&p, cap);
     if (e != hipSuccess) {
-      // give pooled memory back to the driver and retry once
-      std::vector<void*> drop;
-      {
-        std::lock_guard<std::mutex> lock(P.mu);
-        for (auto& kv : P.free_blocks) {
-          drop.push_back(kv.second);
-          P.capacity.erase(kv.second);
-        }
-        P.free_blocks.clear();
-        P.pooled_bytes = 0;
+      // give pooled memory back to the driver and retry: this thread's pool first, then every thread's
+      (void)hipGetLastError();
+      P.Trim();
+      e = hipMalloc(&p, cap);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        TrimAllPools();
+        HIP_CHECK(hipMalloc(&p, cap));
       }
-      for (void* d : drop) (void)hipFree(d);
-      HIP_CHECK(hipMalloc(&p, cap));
     }
     std::lock_guard<std::mutex> lock(P.mu);
     P.capacity[p] = cap;

@@ -25,6 +25,9 @@
 
 #if defined(BROTLI_HOST_EMU)
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 #define BR_DEV inline
 #define BR_LANE 0
 #define BR_NLANES 1
@@ -106,6 +109,12 @@ struct ChainTables {
   uint32_t* live_buckets = nullptr;   // [tables][(1 << bucket_bits) << block_bits]
   LiveBlockState* live_state = nullptr;  // [blocks]: the meta-block books at the entry of every block (read for the first one)
   EntropyTables logs = {nullptr, nullptr};  // should_compress in the live chain (encode.rs:1325-1354)
+  // checkpoints (candidate-row chains, see Checkpoint): one record per kCheckpointStride bytes of text; and per segment the
+  // lowest / highest searched position whose candidate row changed since the segment was parsed last (lz77_rows_update)
+  Checkpoint* checkpoints = nullptr;
+  const uint32_t* rows_changed_lo = nullptr;
+  const uint32_t* rows_changed_hi = nullptr;
+  uint32_t splice_off = 0;  // bit 0: never restart from a checkpoint, bit 1: never stop at one
 };
 
 static constexpr uint32_t kInfoWindow = 64;
@@ -1510,10 +1519,24 @@ struct BlockTail {
   uint32_t n_cmds, n_lits, insert_len, ext_len, last_dist_code, last_copy_len;
 };
 
-template <bool kH9, bool kRows, bool kLive = false>
+// How a list launch takes a segment (checkpoints, see Checkpoint).
+struct Reparse {
+  uint32_t mode;     // 0: from its entry to its end.  1: from its entry, may stop at a checkpoint (the entry changed, or a chain
+                     // walked into it).  2: the entry is the one it was parsed with last: restart in front of rows_lo, may stop.
+  uint32_t rows_lo;  // lowest / highest searched position of the segment whose candidate row changed since it was parsed
+  uint32_t rows_hi;  // last (0xffffffff / 0: none)
+};
+static constexpr uint32_t kSpliceGap = 32;  // commands of room between a new head and the old tail (br_parse_segment)
+
+// lane 0 writes one checkpoint record
+BR_DEV void br_write_checkpoint(Checkpoint* rec, const Checkpoint& c) {
+  if (BR_LANE == 0) *rec = c;
+}
+
+template <bool kH9, bool kRows, bool kLive = false, bool kSplice = false>
 BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment& seg_in,
                                  const SegEntry& entry, SegExit& exit_out, SegEntry& next, const LiveRing* live = nullptr,
-                                 BlockTail* tail = nullptr) {
+                                 BlockTail* tail = nullptr, const Reparse* rp = nullptr) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
   Segment seg;
   seg.start = BR_UNIFORM(seg_in.start);
@@ -1605,7 +1628,226 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     if (position > seg.start) fw.template head<kH9, kLive>(tail_kind, tail_base, tail_p1, seg.start, position, store_end, kH9 ? kNeverMasked : P.masked_from);
   }
 
+  // ---- checkpoints (see Checkpoint)
+  constexpr bool kCheckpoints = kRows && !kLive && !kH9;
+  const bool cp_on = kCheckpoints && t.checkpoints != nullptr && fw.enabled;
+  uint32_t next_cp = cp_on ? (seg.start / kCheckpointStride + 1u) * kCheckpointStride : 0xffffffffu;  // first boundary behind the start
+  bool spliced = false;
+  uint32_t sp_rec_cmds = 0, sp_rec_lits = 0, sp_rec_searches = 0, sp_rec_pushes = 0, sp_rec_bad = 0, sp_rec_lookups = 0, sp_rec_matches = 0,
+           sp_rec_entry_lookups = 0, sp_rec_entry_matches = 0;  // the old record at the splice point
+  uint32_t splice_room = 0;     // kSplice: how far the old commands were moved up; 0 = this parse cannot be spliced
+  uint32_t old_n_cmds = 0;      // kSplice: commands of the parse being replaced
+  uint32_t walked_from = BR_UNIFORM(entry.pos);
+  if constexpr (kSplice && kCheckpoints) {
+    if (cp_on && rp != nullptr && rp->mode != 0) {
+      old_n_cmds = BR_UNIFORM(exit_out.n_cmds);
+#if defined(BROTLI_HOST_EMU) && defined(BR_DEBUG_SPLICE)
+      for (uint32_t b = (seg.start / kCheckpointStride + 1u) * kCheckpointStride; b < seg.end; b += kCheckpointStride) {
+        const Checkpoint& r = t.checkpoints[b / kCheckpointStride];
+        if (r.valid == kCheckpointValid && r.n_cmds > old_n_cmds) {
+          fprintf(stderr, "inconsistent at entry: seg [%u,%u) mode %u old exit cmds %u pos %u searches %u | cp %u: pos %u cmds %u searches %u\n", seg.start, seg.end, rp->mode, old_n_cmds,
+                  exit_out.pos, exit_out.n_searches, b, r.pos, r.n_cmds, r.n_searches);
+        }
+      }
+#endif
+      uint32_t keep_cmds = 0;  // commands of the old parse that stay where they are (restart)
+      const bool no_restart = (t.splice_off & 1u) != 0, no_stop = (t.splice_off & 2u) != 0;  // (diagnosis: BROTLI_MI355X_SPLICE_OFF)
+      if (rp->mode == 2 && rp->rows_lo != 0xffffffffu && !no_restart) {
+        // same entry, rows changed from rows_lo on: everything the old parse did in front of the last checkpoint that lies
+        // at or in front of rows_lo would come out again
+        uint32_t b = (rp->rows_lo < seg.end ? rp->rows_lo : seg.end - 1u) / kCheckpointStride * kCheckpointStride;
+        for (; b > seg.start; b -= kCheckpointStride) {
+          const Checkpoint* rec = t.checkpoints + b / kCheckpointStride;
+          if (BR_UNIFORM(rec->valid) != kCheckpointValid || BR_UNIFORM(rec->pos) > rp->rows_lo) continue;
+#if defined(BROTLI_HOST_EMU) && defined(BR_DEBUG_SPLICE)
+          {
+            // shadow: a parse from the entry must arrive at the record's position in the record's state
+            ChainTables t2 = t;
+            t2.checkpoints = nullptr;
+            Segment g2 = seg_in;
+            g2.end = rec->pos;
+            g2.flags &= ~(uint32_t)kSegLastInBlock;
+            std::vector<Command> keep(cmds, cmds + exit_out.n_cmds + 40);
+            SegExit sx{};
+            SegEntry sn{};
+            br_parse_segment<kH9, kRows, false, false>(P, t2, s, g2, entry, sx, sn);
+            {
+              // where do the old head and the head parsed now part?
+              uint32_t at = entry.pos;
+              for (uint32_t i = 0; i < sx.n_cmds && i < rec->n_cmds; ++i) {
+                if (memcmp(&keep[i], &cmds[i], sizeof(Command)) != 0) {
+                  fprintf(stderr, "  first differing command %u at text position ~%u (+ insert): old ins %u copy %u dist %u | now ins %u copy %u dist %u; flags there: ", i, at, keep[i].insert_len_,
+                          keep[i].copy_len_ & 0x1ffffff, keep[i].dist_extra_, cmds[i].insert_len_, cmds[i].copy_len_ & 0x1ffffff, cmds[i].dist_extra_);
+                  for (uint32_t q = at; q < at + 24; ++q) fprintf(stderr, "%u ", t.flags_next[q]);
+                  fprintf(stderr, "\n  row of %u now:", at + keep[i].insert_len_);
+                  for (uint32_t e = 0; e < kRowEntries; ++e) fprintf(stderr, " %d", (int)(t.rows[(size_t)(at + keep[i].insert_len_) * kRowEntries + e] == kRowEnd ? -1 : (int)(at + keep[i].insert_len_ - t.rows[(size_t)(at + keep[i].insert_len_) * kRowEntries + e])));
+                  {
+                    const uint32_t q = at + keep[i].insert_len_ - (keep[i].dist_extra_ - 15);
+                    fprintf(stderr, "  | old candidate at %u: flag %u, rows_lo/hi of this segment %u %u\n", q, t.flags_next[q], rp->rows_lo, rp->rows_hi);
+                  }
+                  break;
+                }
+                at += keep[i].insert_len_ + (keep[i].copy_len_ & 0x1ffffff);
+              }
+            }
+            for (size_t i = 0; i < keep.size(); ++i) cmds[i] = keep[i];
+            bool ok = sx.pos == rec->pos && sx.apply == rec->apply && sx.insert_len == rec->insert_len && sx.n_cmds == rec->n_cmds && sx.n_lits == rec->n_lits;
+            for (int i = 0; i < 4; ++i) ok = ok && sx.cache[i] == rec->dc[i];
+            if (!ok)
+              fprintf(stderr, "RESTART RECORD STALE seg [%u,%u) rows %u..%u record at %u: pos %u apply %u ins %u cmds %u lits %u dc %d %d %d %d entryLM %u/%u | parse now: pos %u apply %u ins %u cmds %u lits %u dc %d %d %d %d | entry pos %u apply %u cache %d %d %d %d LM %u/%u exact %u head %u/%u\n",
+                      seg.start, seg.end, rp->rows_lo, rp->rows_hi, b, rec->pos, rec->apply, rec->insert_len, rec->n_cmds, rec->n_lits, rec->dc[0], rec->dc[1], rec->dc[2], rec->dc[3],
+                      rec->entry_lookups, rec->entry_matches, sx.pos, sx.apply, sx.insert_len, sx.n_cmds, sx.n_lits, sx.cache[0], sx.cache[1], sx.cache[2], sx.cache[3], entry.pos, entry.apply,
+                      entry.cache[0], entry.cache[1], entry.cache[2], entry.cache[3], entry.dict_lookups, entry.dict_matches, entry.dict_exact, entry.head_kind, entry.head_base);
+          }
+#endif
+          position = BR_UNIFORM(rec->pos);
+          insert_length = BR_UNIFORM(rec->insert_len);
+          apply = BR_UNIFORM(rec->apply);
+          BR_SYNC();
+          for (int i = 0; i < 4; ++i) dc[i] = (int32_t)BR_UNIFORM(rec->dc[i]);
+          BR_SYNC();
+          br_prepare_distance_cache(dc, P.ndist);
+          n_cmds = BR_UNIFORM(rec->n_cmds);
+          n_lits = BR_UNIFORM(rec->n_lits);
+          n_searches = BR_UNIFORM(rec->n_searches);
+          n_pushes = BR_UNIFORM(rec->n_pushes);
+          n_bad = BR_UNIFORM(rec->n_bad);
+          last_dist_code = BR_UNIFORM(rec->last_dist_code);
+          last_copy_len = BR_UNIFORM(rec->last_copy_len);
+          ext_len = BR_UNIFORM(rec->ext_len);
+          tail_kind = BR_UNIFORM(rec->tail_kind);
+          tail_base = BR_UNIFORM(rec->tail_base);
+          tail_p1 = BR_UNIFORM(rec->tail_p1);
+          // the throttle counters are absolute: they move with the entry (the host has judged the old parse valid under
+          // the entry of now, DictTracker::Consume)
+          if (probe.no_dict) {
+            // off for good under the entry of now (the old parse may have run with a guess and looked things up): nothing is
+            // looked up, the counters stay where the entry has them, and a consult makes the parse one that "ran blind"
+            ds.mode = BR_UNIFORM(rec->d_mode) != 0 ? 4u : 0u;
+          } else {
+            ds.lookups = BR_UNIFORM(rec->d_lookups) + (ds.lookups0 - BR_UNIFORM(rec->entry_lookups));
+            ds.matches = BR_UNIFORM(rec->d_matches) + (ds.matches0 - BR_UNIFORM(rec->entry_matches));
+            ds.mode = BR_UNIFORM(rec->d_mode);
+          }
+          ds.maxdef = (int32_t)BR_UNIFORM(rec->d_maxdef);
+          ds.vlookups = BR_UNIFORM(rec->d_vlookups);
+          ds.vwould = BR_UNIFORM(rec->d_vwould);
+          ds.vmaxdef = (int32_t)BR_UNIFORM(rec->d_vmaxdef);
+          keep_cmds = n_cmds;
+          next_cp = b + kCheckpointStride;
+          walked_from = position;
+          break;
+        }
+      }
+      // Room for the new commands: the old ones from keep_cmds on move up by kSpliceGap, so that a head that comes out a few
+      // commands longer than the old one does not run over the tail it may be spliced with.  (Highest chunk first: a chunk
+      // is read whole before it is written, and lands only on slots that have been moved already.)
+      if (!no_stop && old_n_cmds >= keep_cmds && old_n_cmds + kSpliceGap <= seg.cmd_cap) {
+        Command* slab = cmds;
+        for (uint32_t hi = old_n_cmds; hi > keep_cmds;) {
+          const uint32_t lo = hi - keep_cmds > BR_NLANES ? hi - BR_NLANES : keep_cmds;
+          const uint32_t i = lo + BR_LANE;
+          Command v = slab[i < hi ? i : lo];
+          BR_SYNC();
+          if (i < hi) {
+            // (device-scope stores: the splice below reads these slots back through the L2)
+            uint32_t* dst = (uint32_t*)(slab + i + kSpliceGap);
+            BR_LIVE_ST32(dst, v.insert_len_);
+            BR_LIVE_ST32(dst + 1, v.copy_len_);
+            BR_LIVE_ST32(dst + 2, v.dist_extra_);
+            BR_LIVE_ST32(dst + 3, (uint32_t)v.cmd_prefix_ | ((uint32_t)v.dist_prefix_ << 16));
+          }
+          hi = lo;
+        }
+        BR_SYNC();
+        splice_room = kSpliceGap;
+      }
+    }
+  }
+
   while (position + htl < pos_end && position < seg.end) {
+    if constexpr (kCheckpoints) {
+      // the first loop-top position at or behind a boundary: stop here if this is where the old parse was, in the same state;
+      // otherwise leave the record for the next parse
+      while (next_cp <= position && next_cp < seg.end) {
+        Checkpoint* rec = t.checkpoints + next_cp / kCheckpointStride;
+        if constexpr (kSplice) {
+          if (splice_room != 0 && (rp->rows_hi == 0 || rp->rows_hi < position) && BR_UNIFORM(rec->valid) == kCheckpointValid &&
+              BR_UNIFORM(rec->pos) == position && BR_UNIFORM(rec->insert_len) == insert_length && BR_UNIFORM(rec->apply) == apply &&
+              n_cmds <= BR_UNIFORM(rec->n_cmds) + splice_room) {
+            bool same = true;
+            for (int i = 0; i < 4; ++i) same = same && (int32_t)BR_UNIFORM(rec->dc[i]) == dc[i];
+            // the static dictionary: does the old parse of the rest hold under the throttle state this parse arrives with?
+            const uint32_t old_mode = BR_UNIFORM(exit_out.dict_mode);
+            if (same && P.use_dictionary) {
+              if (probe.no_dict) {
+                // off for good: the old rest must not have used a dictionary match
+                same = old_mode == 0 || old_mode == 2 || old_mode == 4 ||
+                       (old_mode == 1 && BR_UNIFORM(exit_out.dict_matches) == BR_UNIFORM(exit_out.dict_entry_matches));
+              } else if (BR_UNIFORM(entry.dict_exact) && ds.mode <= 1 && old_mode <= 1 && !BR_UNIFORM(rec->no_dict)) {
+                // on, with the true counters: the old rest found it on at every consult; it stays on under the counters of
+                // now if they cover the largest deficit (lookups - 128 matches) the rest can have run up from here
+                if (old_mode == 1) {
+                  const int64_t d_old_here = (int64_t)(BR_UNIFORM(rec->d_lookups) - BR_UNIFORM(rec->entry_lookups)) -
+                                             128ll * (int64_t)(BR_UNIFORM(rec->d_matches) - BR_UNIFORM(rec->entry_matches));
+                  const int64_t need = (int64_t)(int32_t)BR_UNIFORM(exit_out.dict_maxdef) - d_old_here;
+                  same = 128ll * (int64_t)ds.matches - (int64_t)ds.lookups + 127 >= need;
+                }
+              } else {
+                same = false;
+              }
+            }
+            if (same) spliced = true;  // (the record below is still written: same state, but the counts of the head parsed now)
+          }
+        }
+        if (spliced) {
+          // what the splice needs of the old record
+          sp_rec_cmds = BR_UNIFORM(rec->n_cmds);
+          sp_rec_lits = BR_UNIFORM(rec->n_lits);
+          sp_rec_searches = BR_UNIFORM(rec->n_searches);
+          sp_rec_pushes = BR_UNIFORM(rec->n_pushes);
+          sp_rec_bad = BR_UNIFORM(rec->n_bad);
+          sp_rec_lookups = BR_UNIFORM(rec->d_lookups);
+          sp_rec_matches = BR_UNIFORM(rec->d_matches);
+          sp_rec_entry_lookups = BR_UNIFORM(rec->entry_lookups);
+          sp_rec_entry_matches = BR_UNIFORM(rec->entry_matches);
+        }
+        if (cp_on) {
+          Checkpoint c;
+          c.pos = position;
+          c.insert_len = insert_length;
+          c.apply = apply;
+          for (int i = 0; i < 4; ++i) c.dc[i] = dc[i];
+          c.n_cmds = n_cmds;
+          c.n_lits = n_lits;
+          c.n_searches = n_searches;
+          c.n_pushes = n_pushes;
+          c.n_bad = n_bad;
+          c.last_dist_code = last_dist_code;
+          c.last_copy_len = last_copy_len;
+          c.ext_len = ext_len;
+          c.tail_kind = tail_kind;
+          c.tail_base = tail_base;
+          c.tail_p1 = tail_p1;
+          c.d_lookups = ds.lookups;
+          c.d_matches = ds.matches;
+          c.d_mode = ds.mode;
+          c.d_maxdef = ds.maxdef;
+          c.d_vlookups = ds.vlookups;
+          c.d_vwould = ds.vwould;
+          c.d_vmaxdef = ds.vmaxdef;
+          c.entry_lookups = ds.lookups0;
+          c.entry_matches = ds.matches0;
+          c.no_dict = probe.no_dict;
+          c.valid = kCheckpointValid;
+          c.pad[0] = c.pad[1] = c.pad[2] = 0;
+          br_write_checkpoint(rec, c);
+        }
+        if (spliced) break;
+        next_cp += kCheckpointStride;
+      }
+      if (spliced) break;
+    }
     SearchResult sr = br_search<kH9, kRows, kLive>(P, t, s, probe, ds, position, dc, cache_version, pos_end, live);
     n_searches++;
     if (sr.found) {
@@ -1637,7 +1879,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
         dc[2] = dc[1];
         dc[1] = dc[0];
         dc[0] = (int32_t)sr.distance;
-        if (n_pushes < 4) n_pushes++;
+        n_pushes++;
         cache_version++;
         br_prepare_distance_cache(dc, P.ndist);
       }
@@ -1699,6 +1941,107 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
       }
     }
   }
+  const uint32_t walked_to = position;
+  (void)walked_to;
+  bool dict_spliced = false;
+  uint32_t sp_lookups = 0, sp_matches = 0, sp_mode = 0;
+  int32_t sp_maxdef = 0;
+  if constexpr (kCheckpoints) {
+    if (cp_on && !spliced) {
+      // boundaries this parse never reached at a loop top (a copy or a jump carried it past them, or the block ended): whatever
+      // record sits there belongs to an older parse
+      for (; next_cp < seg.end; next_cp += kCheckpointStride)
+        if (BR_LANE == 0) t.checkpoints[next_cp / kCheckpointStride].valid = 0;
+    }
+  }
+  if constexpr (kSplice && kCheckpoints) {
+    if (spliced) {
+      // ---- splice: the head parsed now + the rest of the old parse from the record at next_cp on
+      const uint32_t rec_cmds = sp_rec_cmds;
+      const uint32_t tail_cmds = old_n_cmds - rec_cmds;
+#if defined(BROTLI_HOST_EMU) && defined(BR_DEBUG_SPLICE)
+      if (rec_cmds > old_n_cmds) {
+        fprintf(stderr, "splice: seg [%u,%u) cp at %u: record has %u commands, old exit %u (mode %u rows %u..%u, n_cmds now %u, old pos %u)\n", seg.start, seg.end, next_cp,
+                rec_cmds, old_n_cmds, rp->mode, rp->rows_lo, rp->rows_hi, n_cmds, exit_out.pos);
+        abort();
+      }
+#endif
+      {
+        // the old rest sits at [rec_cmds + room, old_n_cmds + room) and goes to [n_cmds, ...): downwards or nowhere, lowest chunk first
+        Command* slab = cmds;
+        const uint32_t from = rec_cmds + splice_room;
+        if (from != n_cmds) {
+          for (uint32_t done = 0; done < tail_cmds; done += BR_NLANES) {
+            const uint32_t i = done + BR_LANE;
+            // (read from the L2: these slots were written a moment ago, by this chain's move above, and a line of the
+            // vector L1 may still hold what was there before)
+            const uint32_t* src = (const uint32_t*)(slab + from + (i < tail_cmds ? i : 0u));
+            uint32_t w0 = BR_LIVE_LD32(src), w1 = BR_LIVE_LD32(src + 1), w2 = BR_LIVE_LD32(src + 2), w3 = BR_LIVE_LD32(src + 3);
+            BR_SYNC();
+            if (i < tail_cmds) {
+              uint32_t* dst = (uint32_t*)(slab + n_cmds + i);
+              dst[0] = w0;
+              dst[1] = w1;
+              dst[2] = w2;
+              dst[3] = w3;
+            }
+          }
+        }
+      }
+      // records behind the splice point count from the old head: dropped (the next full parse writes them again)
+      for (uint32_t b = next_cp + kCheckpointStride; b < seg.end; b += kCheckpointStride)
+        if (BR_LANE == 0) t.checkpoints[b / kCheckpointStride].valid = 0;
+      const uint32_t old_mode = BR_UNIFORM(exit_out.dict_mode);
+      if (P.use_dictionary) {
+        dict_spliced = true;
+        if (probe.no_dict) {
+          sp_lookups = ds.lookups;
+          sp_matches = ds.matches;
+          sp_mode = (ds.mode == 0 && old_mode == 0) ? 0u : 4u;
+          sp_maxdef = ds.maxdef;
+        } else {
+          const int64_t d_old_here = (int64_t)(sp_rec_lookups - sp_rec_entry_lookups) - 128ll * (int64_t)(sp_rec_matches - sp_rec_entry_matches);
+          const int64_t d_new_here = (int64_t)(ds.lookups - ds.lookups0) - 128ll * (int64_t)(ds.matches - ds.matches0);
+          // (counts relative to the entry each was taken with: the record may stem from an older parse than the exit -- a restart
+          // leaves the records in front of it alone)
+          sp_lookups = ds.lookups + ((BR_UNIFORM(exit_out.dict_lookups) - BR_UNIFORM(exit_out.dict_entry_lookups)) - (sp_rec_lookups - sp_rec_entry_lookups));
+          sp_matches = ds.matches + ((BR_UNIFORM(exit_out.dict_matches) - BR_UNIFORM(exit_out.dict_entry_matches)) - (sp_rec_matches - sp_rec_entry_matches));
+          sp_mode = (ds.mode | old_mode) ? 1u : 0u;
+          int64_t md = ds.mode == 1 ? (int64_t)ds.maxdef : -(1ll << 30);
+          if (old_mode == 1) {
+            const int64_t rest = d_new_here + ((int64_t)(int32_t)BR_UNIFORM(exit_out.dict_maxdef) - d_old_here);  // (an upper bound: the old maximum may lie in the old head)
+            if (rest > md) md = rest;
+          }
+          sp_maxdef = (int32_t)(md < -(1ll << 30) ? -(1ll << 30) : (md > (1ll << 30) ? (1ll << 30) : md));
+          ds.lookups = sp_lookups;
+          ds.matches = sp_matches;
+        }
+      }
+      n_lits += BR_UNIFORM(exit_out.n_lits) - sp_rec_lits;
+      n_searches += BR_UNIFORM(exit_out.n_searches) - sp_rec_searches;
+      n_bad += BR_UNIFORM(exit_out.bad_commands) - sp_rec_bad;
+      n_pushes += BR_UNIFORM(exit_out.n_pushes_all) - sp_rec_pushes;
+      if (tail_cmds != 0) {
+        last_dist_code = BR_UNIFORM(exit_out.last_dist_code);
+        last_copy_len = BR_UNIFORM(exit_out.last_copy_len);
+      }
+      n_cmds += tail_cmds;
+      position = BR_UNIFORM(exit_out.pos);
+      apply = BR_UNIFORM(exit_out.apply);
+      insert_length = BR_UNIFORM(exit_out.insert_len);
+      tail_kind = BR_UNIFORM(exit_out.tail_kind);
+      tail_base = BR_UNIFORM(exit_out.tail_base);
+      tail_p1 = BR_UNIFORM(exit_out.tail_p1);
+      const int32_t c0 = (int32_t)BR_UNIFORM(exit_out.cache[0]), c1 = (int32_t)BR_UNIFORM(exit_out.cache[1]),
+                    c2 = (int32_t)BR_UNIFORM(exit_out.cache[2]), c3 = (int32_t)BR_UNIFORM(exit_out.cache[3]);
+      BR_SYNC();
+      dc[0] = c0;
+      dc[1] = c1;
+      dc[2] = c2;
+      dc[3] = c3;
+      BR_SYNC();
+    }
+  }
   if (seg.flags & kSegLastInBlock) {
     if (position < pos_end) fw.range(position, pos_end, 0);
     insert_length += pos_end - position;
@@ -1706,7 +2049,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   }
 #if !defined(BROTLI_HOST_EMU)
   if (BR_LANE == 0 && t.work) {
-    atomicAdd(t.work + 0, (unsigned long long)(position - BR_UNIFORM(entry.pos)));
+    atomicAdd(t.work + 0, (unsigned long long)((spliced ? walked_to : position) - walked_from));
     atomicAdd(t.work + 1, (unsigned long long)n_searches);
     if (fw.enabled) atomicAdd(t.work + 2, (unsigned long long)n_cmds);
   }
@@ -1728,7 +2071,16 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
     exit_out.last_copy_len = last_copy_len;
     exit_out.dict_mode = ds.mode;
     exit_out.dict_maxdef = ds.mode == 2 ? ds.vmaxdef : ds.maxdef;
-    exit_out.n_pushes = n_pushes;
+    exit_out.n_pushes = n_pushes < 4 ? n_pushes : 4u;
+    exit_out.n_pushes_all = n_pushes;
+    exit_out.dict_entry_lookups = ds.lookups0;
+    exit_out.dict_entry_matches = ds.matches0;
+    if (dict_spliced) {
+      exit_out.dict_lookups = sp_lookups;
+      exit_out.dict_matches = sp_matches;
+      exit_out.dict_mode = sp_mode;
+      exit_out.dict_maxdef = sp_maxdef;
+    }
     exit_out.tail_kind = position > seg.end ? tail_kind : (uint32_t)kHeadNone;
     exit_out.tail_base = position > seg.end ? tail_base : 0u;
     exit_out.tail_p1 = position > seg.end ? tail_p1 : 0u;
@@ -1769,7 +2121,36 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   next.head_base = position > seg.end ? tail_base : 0u;
   next.head_p1 = position > seg.end ? tail_p1 : 0u;
   next.pad = 0;
-  return (n_searches < 0x0fffffffu ? n_searches : 0x0fffffffu) | (n_pushes << 28);  // what the segment cost | distances pushed
+#if defined(BROTLI_HOST_EMU) && defined(BR_DEBUG_SPLICE)
+  if constexpr (kSplice && kCheckpoints) {
+    if (cp_on && rp != nullptr && (spliced || walked_from != entry.pos)) {
+      // shadow: the same segment parsed from its entry to its end must give the same exit and the same commands
+      std::vector<Command> got(cmds, cmds + n_cmds);
+      const SegExit merged = exit_out;
+      ChainTables t2 = t;
+      t2.checkpoints = nullptr;
+      SegExit sx{};
+      SegEntry sn{};
+      br_parse_segment<kH9, kRows, false, false>(P, t2, s, seg_in, entry, sx, sn);
+      bool same = sx.pos == merged.pos && sx.apply == merged.apply && sx.insert_len == merged.insert_len && sx.n_cmds == merged.n_cmds && sx.n_lits == merged.n_lits &&
+                  sx.n_searches == merged.n_searches && sx.last_dist_code == merged.last_dist_code && sx.last_copy_len == merged.last_copy_len &&
+                  sx.n_pushes_all == merged.n_pushes_all && sx.tail_kind == merged.tail_kind && sx.tail_base == merged.tail_base && sx.tail_p1 == merged.tail_p1 &&
+                  sx.ext_len == merged.ext_len && sx.dict_lookups == merged.dict_lookups && sx.dict_matches == merged.dict_matches && sx.dict_mode == merged.dict_mode &&
+                  sx.dict_maxdef <= merged.dict_maxdef;
+      for (int i = 0; i < 4; ++i) same = same && sx.cache[i] == merged.cache[i];
+      bool cmds_same = sx.n_cmds == got.size();
+      for (size_t i = 0; cmds_same && i < got.size(); ++i) cmds_same = memcmp(&got[i], &cmds[i], sizeof(Command)) == 0;
+      if (!same || !cmds_same)
+        fprintf(stderr, "SHADOW MISMATCH seg [%u,%u) mode %u rows %u..%u restart from %u spliced %d at %u: merged pos %u cmds %u lits %u searches %u pushes %u dict %u/%u mode %u | full pos %u cmds %u lits %u searches %u pushes %u dict %u/%u mode %u | cmds same %d\n",
+                seg.start, seg.end, rp->mode, rp->rows_lo, rp->rows_hi, walked_from, (int)spliced, walked_to, merged.pos, merged.n_cmds, merged.n_lits, merged.n_searches,
+                merged.n_pushes_all, merged.dict_lookups, merged.dict_matches, merged.dict_mode, sx.pos, sx.n_cmds, sx.n_lits, sx.n_searches, sx.n_pushes_all, sx.dict_lookups,
+                sx.dict_matches, sx.dict_mode, (int)cmds_same);
+      exit_out = merged;
+      for (size_t i = 0; i < got.size(); ++i) cmds[i] = got[i];
+    }
+  }
+#endif
+  return (n_searches < 0x0fffffffu ? n_searches : 0x0fffffffu) | ((n_pushes < 4 ? n_pushes : 4u) << 28);  // what the segment cost | distances pushed
 }
 
 // Parses segment k and -- in list rounds (sched != nullptr) -- keeps going into the following segments of the
@@ -1777,7 +2158,7 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
 // they are not scheduled themselves: a change that would otherwise creep forward one segment per round (each
 // round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
 // written to entries[] so that the host resolver sees what it was parsed with.
-template <bool kH9, bool kRows>
+template <bool kH9, bool kRows, bool kSplice = false>
 BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment* segments,
                            SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
   if constexpr (kRows) {
@@ -1804,7 +2185,22 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
   for (;;) {
     const Segment seg = segments[k];
     SegEntry next;
-    const uint32_t ret = br_parse_segment<kH9, kRows>(P, t, s, seg, entry, exits[k], next);
+    uint32_t ret;
+    if constexpr (kSplice) {
+      Reparse rp;
+      rp.mode = 0;
+      rp.rows_lo = 0xffffffffu;
+      rp.rows_hi = 0;
+      if (sched != nullptr && t.rows_changed_lo != nullptr) {
+        rp.rows_lo = BR_UNIFORM(t.rows_changed_lo[k]);
+        rp.rows_hi = BR_UNIFORM(t.rows_changed_hi[k]);
+        // (the first segment: as the scheduler marked it; a segment walked into: other entry than last time)
+        rp.mode = (first && BR_UNIFORM(sched[k]) == kSchedOwnRows) ? 2u : 1u;
+      }
+      ret = br_parse_segment<kH9, kRows, false, true>(P, t, s, seg, entry, exits[k], next, nullptr, nullptr, &rp);
+    } else {
+      ret = br_parse_segment<kH9, kRows>(P, t, s, seg, entry, exits[k], next);
+    }
     const uint32_t cost = ret & 0x0fffffffu, np = ret >> 28;
     if (first) {
       const uint32_t per_segment = (seg.end - seg.start) / 2;
@@ -1821,7 +2217,7 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
     }
     if (!sched || (seg.flags & (kSegLastInBlock | kSegWarmup))) break;
     const uint32_t mark = sched[k + 1];
-    if (mark == 1 || mark == 3) break;  // has its own chain in this launch
+    if (mark == kSchedOwn || mark == kSchedOwnRows || mark == kSchedWalked) break;  // has its own chain in this launch
     if (budget == 0) break;
     const bool forced = mark == 2;     // left to this chain, must be redone whatever state we arrive with
     const SegEntry old = entries[k + 1];
@@ -2063,9 +2459,14 @@ BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const Li
 // Lz77Stage::Resolve -- position, spree countdown, distance cache, the step that reaches into k + 1; the dictionary
 // counters and the books stay what k + 1's entry holds (the host judges those).
 BR_DEV void br_chain_check(const Segment* segments, const SegEntry* entries, const SegExit* exits, uint32_t num_segments, uint32_t k,
-                           const uint8_t* sched, uint8_t* touched, uint8_t* entry_dirty, SegEntry* new_entries) {
-  if (sched[k] != 1 && sched[k] != 3) return;
+                           const uint8_t* sched, uint8_t* touched, uint8_t* entry_dirty, SegEntry* new_entries, uint32_t* rows_changed_lo,
+                           uint32_t* rows_changed_hi) {
+  if (sched[k] != kSchedOwn && sched[k] != kSchedOwnRows && sched[k] != kSchedWalked) return;
   touched[k] = 1;
+  if (rows_changed_lo != nullptr) {  // parsed: what is marked from now on happened after this parse
+    rows_changed_lo[k] = 0xffffffffu;
+    rows_changed_hi[k] = 0;
+  }
   if (k + 1 >= num_segments || (segments[k + 1].flags & kSegFirstInBlock)) return;
   const SegExit& x = exits[k];
   const SegEntry& u = entries[k + 1];
@@ -2083,13 +2484,19 @@ BR_DEV void br_chain_check(const Segment* segments, const SegEntry* entries, con
   new_entries[k + 1] = n;
   entry_dirty[k + 1] = 1;
 }
+// drops the checkpoint records of one segment
+BR_DEV void br_drop_checkpoints(Checkpoint* checkpoints, const Segment& seg) {
+  for (uint32_t b = (seg.start / kCheckpointStride + 1u) * kCheckpointStride; b < seg.end; b += kCheckpointStride) checkpoints[b / kCheckpointStride].valid = 0;
+}
 // Does segment k go into the next launch?  Takes its new entry if it has one and clears its marks.
 BR_DEV bool br_burst_schedule_one(SegEntry* entries, uint32_t k, uint8_t* sched, uint8_t* cand_dirty, uint8_t* entry_dirty, const SegEntry* new_entries) {
-  const bool go = cand_dirty[k] != 0 || entry_dirty[k] != 0 || sched[k] == 2;
+  const bool go = cand_dirty[k] != 0 || entry_dirty[k] != 0 || sched[k] == kSchedLeft;
+  // (a segment that only had rows change keeps its entry: its chain may restart from a checkpoint, see Reparse)
+  const uint8_t how = (entry_dirty[k] != 0 || sched[k] == kSchedLeft) ? kSchedOwn : kSchedOwnRows;
   if (entry_dirty[k]) entries[k] = new_entries[k];
   cand_dirty[k] = 0;
   entry_dirty[k] = 0;
-  sched[k] = go ? 1 : 0;
+  sched[k] = go ? how : 0;
   return go;
 }
 

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(64) void k_init_flag_tails(const Segment* __restric
 
 void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_block_start, const uint8_t* prefix_flags_host,
                      uint32_t prefix_flags_bytes) {
-  // (masked H5 ring entries, Lz77Params::masked_from: the row and rank kernels below take kFlagMasked -- written at the end
-  // of round 2 without a GPU to run them on, hence still behind BROTLI_MI355X_MASKED_H5)
+  // (masked H5 ring entries, Lz77Params::masked_from: texts that have them are parsed by live chains, lz77_live.h; the row
+  // and rank kernels below carry kFlagMasked through, which only the live index reads)
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
   HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, BR_STREAM));
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), BR_STREAM));  // StoreLookaheadThenStore, mod.rs:224-229
@@ -437,7 +437,14 @@ void lz77_rank_flags(const Lz77Params& P, const Lz77Buffers& B, int which, int r
 }
 
 // marks the chain(s) that searched position p
-__device__ __forceinline__ void mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* __restrict__ dirty) {
+// rows_lo / rows_hi (optional, candidate rows): lowest / highest such position per segment (Lz77Buffers::rows_changed_lo / _hi)
+__device__ __forceinline__ void note_rows_changed(uint32_t k, uint32_t p, uint32_t* rows_lo, uint32_t* rows_hi) {
+  if (rows_lo == nullptr) return;
+  atomicMin(&rows_lo[k], p);
+  atomicMax(&rows_hi[k], p);
+}
+__device__ __forceinline__ void mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* __restrict__ dirty, uint32_t* rows_lo = nullptr,
+                                           uint32_t* rows_hi = nullptr) {
   const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
   const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
   const uint32_t off = p - bs;
@@ -445,8 +452,12 @@ __device__ __forceinline__ void mark_dirty(uint32_t p, const SegGeometry& geo, u
   uint32_t k = geo.block_first_segment[blk] + off / seg_bytes;
   if (k >= geo.block_first_segment[blk + 1]) k = geo.block_first_segment[blk + 1] - 1;
   dirty[k] = 1;
+  note_rows_changed(k, p, rows_lo, rows_hi);
   // a lazy probe just behind a segment boundary belongs to the previous chain
-  if (k > 0 && (off % seg_bytes) < 8) dirty[k - 1] = 1;
+  if (k > 0 && (off % seg_bytes) < 8) {
+    dirty[k - 1] = 1;
+    note_rows_changed(k - 1, p, rows_lo, rows_hi);
+  }
 }
 
 // A chain evaluates the lazy alternative one position ahead, up to four times in a row (mod.rs:2455-2480), so its last
@@ -636,6 +647,8 @@ struct RowArgs {
   uint32_t validate;     // compare with the row in memory and mark the chains that searched a position whose row changed
   SegGeometry geo;
   uint8_t* dirty;
+  uint32_t* rows_lo;     // optional: Lz77Buffers::rows_changed_lo / _hi
+  uint32_t* rows_hi;
   const uint32_t* ctl;   // conditional launches: run only if ctl[kCtlNeedFull] != 0
   uint32_t* walk_counter;  // == ctl, writable (k_update_rows)
   uint32_t conditional;
@@ -648,10 +661,13 @@ enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtl
 __device__ __forceinline__ void row_changed(const RowArgs& a, uint32_t p) {
   if (p < a.geo.first_block_start) return;
   if (a.flags[p] & kFlagSearched) {
-    mark_dirty(p, a.geo, a.dirty);
+    mark_dirty(p, a.geo, a.dirty, a.rows_lo, a.rows_hi);
   } else {
     const uint32_t k = chain_in_front_if_near_boundary(p, a.geo);
-    if (k != 0xffffffffu) a.dirty[k] = 1;
+    if (k != 0xffffffffu) {
+      a.dirty[k] = 1;
+      note_rows_changed(k, p, a.rows_lo, a.rows_hi);
+    }
   }
 }
 
@@ -1012,6 +1028,8 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.validate = validate ? 1 : 0;
   if (geo) a.geo = *geo;
   a.dirty = dirty_dev;
+  a.rows_lo = validate ? B.rows_changed_lo : nullptr;
+  a.rows_hi = validate ? B.rows_changed_hi : nullptr;
   a.ctl = B.row_ctl;
   a.walk_counter = B.row_ctl;
   a.smask = B.smask;
@@ -1262,7 +1280,9 @@ static bool plain_q5_config(const Lz77Params& P) {
   return P.hasher_kind != 9 && P.ndist == 4 && P.block_bits == 4 && P.spree_window == 64 && P.score_per_byte == 135 && P.dict_break == 0 &&
          P.reset_pos == 0 && P.masked_from == kNeverMasked && (P.htl == 4 || P.htl == 8);
 }
-template <bool kH9, bool kRows, uint32_t kSpec = 0>
+// kSplice: the chains of a list launch, which restart from and stop at checkpoints (lz77_chain.h, Checkpoint / Reparse);
+// round 0 and the warm-up run without that code (round 0 records the checkpoints).
+template <bool kH9, bool kRows, uint32_t kSpec = 0, bool kSplice = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kH9 ? 6 : BR_PARSE_WAVES, kH9 ? 6 : BR_PARSE_WAVES))) void k_parse_segments(ParseArgs a) {
   __shared__ ChainScratchT<kH9, kRows> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
@@ -1281,9 +1301,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kH9 ? 6 : BR
     P.reset_pos = 0;
     P.masked_from = kNeverMasked;
     P.htl = kSpec;
-    br_parse_chain<kH9, kRows>(P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+    br_parse_chain<kH9, kRows, kSplice>(P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
   } else {
-    br_parse_chain<kH9, kRows>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
+    br_parse_chain<kH9, kRows, kSplice>(a.P, a.T, scratch, a.segments, a.entries, a.exits, k, a.sched, a.max_continuation);
   }
 }
 
@@ -1345,12 +1365,27 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
     hipLaunchKernelGGL((k_parse_segments<true, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else if (B.rows) {
     static const bool spec_off = getenv("BROTLI_MI355X_NO_SPEC") != nullptr;
-    if (!spec_off && plain_q5_config(P) && P.htl == 8) {
-      hipLaunchKernelGGL((k_parse_segments<false, true, 8>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
-    } else if (!spec_off && plain_q5_config(P) && P.htl == 4) {
-      hipLaunchKernelGGL((k_parse_segments<false, true, 4>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    static const bool splice_off = getenv("BROTLI_MI355X_NO_SPLICE") != nullptr;
+    const uint32_t spec = (!spec_off && plain_q5_config(P)) ? P.htl : 0u;
+    // checkpoints: recorded by every parse of the real segments (not the warm-up's), used by the list launches
+    const bool own_segments = segments == B.segments;
+    a.T.checkpoints = own_segments ? (Checkpoint*)B.checkpoints : nullptr;
+    a.T.rows_changed_lo = B.rows_changed_lo;
+    a.T.rows_changed_hi = B.rows_changed_hi;
+    // (default 1: chains stop at checkpoints but do not restart from them -- a record was found stale in a way the rows-changed
+  // marks did not show; 0 switches the restart on for experiments)
+  static const uint32_t splice_part_off = getenv("BROTLI_MI355X_SPLICE_OFF") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_OFF")) : 1u;
+    a.T.splice_off = splice_part_off;
+    const bool splice = !splice_off && sched != nullptr && own_segments && B.checkpoints != nullptr && B.splice_lists != 0;
+    if (spec == 8) {
+      if (splice) hipLaunchKernelGGL((k_parse_segments<false, true, 8, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+      else hipLaunchKernelGGL((k_parse_segments<false, true, 8>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+    } else if (spec == 4) {
+      if (splice) hipLaunchKernelGGL((k_parse_segments<false, true, 4, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+      else hipLaunchKernelGGL((k_parse_segments<false, true, 4>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
     } else {
-      hipLaunchKernelGGL((k_parse_segments<false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+      if (splice) hipLaunchKernelGGL((k_parse_segments<false, true, 0, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
+      else hipLaunchKernelGGL((k_parse_segments<false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
     }
   } else {
     hipLaunchKernelGGL((k_parse_segments<false, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
@@ -1466,14 +1501,31 @@ void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_
 // ------------------------------------------------------------------------------------------ bursts (device_api.h)
 __global__ __launch_bounds__(256) void k_chain_check(const Segment* __restrict__ segments, const SegEntry* __restrict__ entries,
                                                       const SegExit* __restrict__ exits, uint32_t num_segments, const uint8_t* __restrict__ sched,
-                                                      uint8_t* __restrict__ touched, uint8_t* __restrict__ entry_dirty, SegEntry* __restrict__ new_entries) {
+                                                      uint8_t* __restrict__ touched, uint8_t* __restrict__ entry_dirty, SegEntry* __restrict__ new_entries,
+                                                      uint32_t* __restrict__ rows_lo, uint32_t* __restrict__ rows_hi) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < num_segments) br_chain_check(segments, entries, exits, num_segments, k, sched, touched, entry_dirty, new_entries);
+  if (k < num_segments) br_chain_check(segments, entries, exits, num_segments, k, sched, touched, entry_dirty, new_entries, rows_lo, rows_hi);
 }
 void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
   hipLaunchKernelGGL(k_chain_check, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.segments, B.entries, B.exits, P.num_segments,
-                     U.sched, U.touched, U.entry_dirty, U.new_entries);
+                     U.sched, U.touched, U.entry_dirty, U.new_entries, B.rows_changed_lo, B.rows_changed_hi);
   HIP_CHECK(hipGetLastError());
+}
+void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B) {
+  if (B.rows_changed_lo == nullptr) return;
+  HIP_CHECK(hipMemsetAsync(B.rows_changed_lo, 0xff, (size_t)P.num_segments * 4, BR_STREAM));
+  HIP_CHECK(hipMemsetAsync(B.rows_changed_hi, 0, (size_t)P.num_segments * 4, BR_STREAM));
+}
+__global__ __launch_bounds__(64) void k_drop_checkpoints(Checkpoint* __restrict__ checkpoints, const Segment* __restrict__ segments,
+                                                          const uint32_t* __restrict__ list, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) br_drop_checkpoints(checkpoints, segments[list[i]]);
+}
+void lz77_drop_checkpoints(const Lz77Params& P, const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count) {
+  if (B.checkpoints == nullptr || count == 0) return;
+  hipLaunchKernelGGL(k_drop_checkpoints, dim3((count + 63) / 64), dim3(64), 0, BR_STREAM, (Checkpoint*)B.checkpoints, B.segments, list_dev, count);
+  HIP_CHECK(hipGetLastError());
+  (void)P;
 }
 
 __global__ __launch_bounds__(256) void k_burst_count(uint32_t num_segments, const uint8_t* __restrict__ sched, const uint8_t* __restrict__ cand_dirty,

@@ -46,6 +46,9 @@ void Lz77Stage::Release() {
     dev_free(B_.stag);
     dev_free(B_.rows);
     dev_free(B_.dict_items);
+    dev_free(B_.checkpoints);
+    dev_free(B_.rows_changed_lo);
+    dev_free(B_.rows_changed_hi);
     dev_free(B_.changed_slot);
     dev_free(B_.row_ctl);
     dev_free(B_.big_tile);
@@ -188,6 +191,11 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
     B_.rows = (uint32_t*)dev_alloc_uninit(M * kRowEntries * 4 + 64);
     if (P_.use_dictionary) B_.dict_items = (uint32_t*)dev_alloc_uninit(M * 4 + 256);
+    if (getenv("BROTLI_MI355X_NO_CHECKPOINTS") == nullptr) {
+      B_.checkpoints = dev_alloc((M / kCheckpointStride + 2) * sizeof(Checkpoint));  // (zero: no record is valid)
+      B_.rows_changed_lo = (uint32_t*)dev_alloc_uninit(segments_.size() * 4 + 64);
+      B_.rows_changed_hi = (uint32_t*)dev_alloc_uninit(segments_.size() * 4 + 64);
+    }
   } else {
     B_.changed_cap = kChangedCap;
     B_.changed_keys = (uint32_t*)dev_alloc((size_t)kChangedCap * 4);
@@ -1028,6 +1036,7 @@ void Lz77Stage::Resegment(uint32_t segment_bytes) {
   segments_upload_.resize_discard(segments_.size());
   memcpy(segments_upload_.data(), segments_.data(), segments_.size() * sizeof(Segment));
   dev_h2d(B_.segments, segments_upload_.data(), segments_.size() * sizeof(Segment));
+  if (B_.checkpoints) dev_memset(B_.checkpoints, 0, ((size_t)P_.total_bytes / kCheckpointStride + 2) * sizeof(Checkpoint));  // (other segments: no record holds)
 }
 
 // first guess of the entries: every chain starts at its segment start with the default cache
@@ -1250,6 +1259,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   std::vector<uint32_t> also_upload;
   // bursts (device_api.h): up to burst_max list launches per pass of the host resolver, scheduled on the device in between
   static const uint32_t burst_env = getenv("BROTLI_MI355X_BURST") ? (uint32_t)atoi(getenv("BROTLI_MI355X_BURST")) : 8u;
+  static const uint32_t splice_max_share = getenv("BROTLI_MI355X_SPLICE_SHARE") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_SHARE")) : 8u;
   static const uint32_t burst_shrink = getenv("BROTLI_MI355X_BURST_SHRINK") ? (uint32_t)atoi(getenv("BROTLI_MI355X_BURST_SHRINK")) : 4u;
   const uint32_t burst_max = use_rows_ ? burst_env : 0u;  // 0: one launch per pass, scheduled by the host (rank-structure chains)
   BurstBuffers U;
@@ -1312,6 +1322,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       dev_h2d(list_dev, up_index, (size_t)n_up * 4);
       dev_h2d(up_entries_dev, up_entries, (size_t)n_up * sizeof(SegEntry));
       lz77_scatter_entries(B_, list_dev, up_entries_dev, n_up);
+      // (segments whose parse was accepted for another distance cache: their checkpoints hold the old one)
+      if (n_up > count) lz77_drop_checkpoints(P_, B_, list_dev + count, n_up - count);
       dev_h2d(burst_max != 0 ? U.sched : dirty_dev, sched.data(), nseg);
     }
     also_upload.clear();
@@ -1323,13 +1335,17 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       const uint32_t* launch_list = list_dev;
       uint32_t launch_count = count;
       for (uint32_t it = 0;; ++it) {
+        // Chains that restart from / stop at checkpoints carry more state (the kernel keeps ~180 more scalars in spill slots):
+        // worth it where most of a re-parse is saved -- launches of a few per cent of the segments, as on text -- and a loss
+        // where a fifth of the input is parsed again every round by chains that never fall back into step (pieces of a mix).
+        B_.splice_lists = (uint64_t)launch_count * splice_max_share <= nseg ? 1u : 0u;
         dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
         lz77_parse_list(P_, B_, which, rbuf, launch_list, U.sched, launch_count);
         stats_.segments_parsed += launch_count;
+        lz77_chain_check(P_, B_, U);  // (also resets the rows-changed marks of what was parsed: before the marks of this launch's flips)
         lz77_diff_flags(P_, B_, which, which ^ 1);
         dev_memset(dirty_dev, 0, nseg);
         lz77_rows_update(P_, B_, which, which ^ 1, geo, dirty_dev, has_big_keys_);
-        lz77_chain_check(P_, B_, U);
         which ^= 1;
         stats_.burst_launches++;
         if (it + 1 >= burst_max) break;
@@ -1412,6 +1428,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       dev_mark();
       dev_memset(dirty_dev, 0, nseg);
       stamp("launched");
+      if (full_round) lz77_reset_rows_changed(P_, B_);  // (everything was parsed)
       lz77_rows_update(P_, B_, which, which ^ 1, geo, dirty_dev, has_big_keys_);
       stamp("rows-queued");
       dev_wait_mark();
@@ -1615,8 +1632,10 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         dirty[k] = 0;
         continue;
       }
+      // (kSchedOwnRows: the entry is the one it was parsed with last and only its candidate rows changed -- its chain may
+      // restart from a checkpoint, lz77_chain.h Reparse)
+      sched[k] = (dirty_entry_[k] || pending[k]) ? kSchedOwn : kSchedOwnRows;
       pending[k] = 0;
-      sched[k] = 1;
       list[count++] = k;
       entries_[k] = next_entries_[k];
       const bool cache_only = dirty_entry_[k] && entry_reason_[k] == 2;

@@ -145,7 +145,46 @@ struct SegExit {
   int32_t dict_maxdef;      // mode 1: max over consults of (local lookups - 128 * local matches)
   uint32_t n_pushes;        // number of dist-cache pushes in this segment, saturated at 4
   uint32_t tail_kind, tail_base, tail_p1;  // the step that carried the parse past the segment end (-> next entry's head_*)
+  uint32_t n_pushes_all;    // the same count, not saturated (splicing two parses at a checkpoint adds and subtracts it)
+  uint32_t dict_entry_lookups, dict_entry_matches;  // the throttle counters this parse was entered with (dict_lookups / _matches count on from them)
 };
+
+// ---- checkpoints: parsing a segment again without parsing all of it --------------------------------------------------------
+// A re-parse launch lasts as long as one chain needs for its segment (plus what it walks into), however few chains there
+// are -- and most segments are parsed again for a reason that touches a fraction of them: a candidate row changed at one
+// searched position, or the entry state changed and the parse falls back into step with the old one after a hundred bytes.
+// So every (candidate-row) parse leaves a record of its complete loop-top state at the first position it reaches at or
+// behind every kCheckpointStride-byte boundary inside its segment.  A later parse of the same segment
+//   * with the same entry, parsed again because rows changed from position p on, RESTARTS from the last record in front
+//     of p (everything up to there -- commands, flags, state -- is what it would produce again), and
+//   * whatever it started from, STOPS at a boundary where it finds itself in exactly the recorded state (position, pending
+//     literals, spree countdown, distance cache, and a static-dictionary regime under which the old parse of the rest holds),
+//     provided no row changed behind that point: the rest of the old parse -- its commands, its flags, its exit -- stands,
+//     and the two halves are spliced (br_parse_segment).
+// Records behind a splice point are dropped (their running counts belong to the old head); the next full parse of the
+// segment writes them afresh.
+static constexpr uint32_t kCheckpointStride = 512;
+static constexpr uint32_t kCheckpointValid = 0x43503031u;  // "CP01"
+struct Checkpoint {  // 128 bytes
+  uint32_t pos, insert_len, apply;
+  int32_t dc[4];
+  uint32_t n_cmds, n_lits, n_searches, n_pushes, n_bad, last_dist_code, last_copy_len, ext_len;
+  uint32_t tail_kind, tail_base, tail_p1;
+  uint32_t d_lookups, d_matches, d_mode;
+  int32_t d_maxdef;
+  uint32_t d_vlookups, d_vwould;
+  int32_t d_vmaxdef;
+  uint32_t entry_lookups, entry_matches, no_dict;
+  uint32_t valid;
+  uint32_t pad[3];
+};
+static_assert(sizeof(Checkpoint) == 128, "one checkpoint = two 64-byte lines");
+
+// marks in the sched[] array of a list launch
+static constexpr uint8_t kSchedOwn = 1;        // has a chain of its own in this launch (its entry changed, or it is owed a full parse)
+static constexpr uint8_t kSchedLeft = 2;       // left to the chain in front of it; must be redone whatever state that chain arrives with
+static constexpr uint8_t kSchedWalked = 3;     // a chain walked into it (set by the chain)
+static constexpr uint8_t kSchedOwnRows = 5;    // has a chain of its own; its entry is the one it was parsed with last, rows changed
 
 // Post-parse fix-ups of the gathered command array.
 struct CmdPatch {

@@ -182,7 +182,8 @@ static uint32_t emu_chain_in_front(uint32_t p, const SegGeometry& geo) {
   return k - 1;
 }
 
-static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
+static void emu_note_rows_changed(const Lz77Buffers& B, uint32_t k, uint32_t p);
+static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty, const Lz77Buffers* B = nullptr) {
   const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;
   const uint32_t bs = blk == 0 ? geo.first_block_start : geo.prefix_bytes + blk * geo.block_bytes;
   const uint32_t off = p - bs;
@@ -190,7 +191,11 @@ static void emu_mark_dirty(uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
   uint32_t k = geo.block_first_segment[blk] + off / seg_bytes;
   if (k >= geo.block_first_segment[blk + 1]) k = geo.block_first_segment[blk + 1] - 1;
   dirty[k] = 1;
-  if (k > 0 && (off % seg_bytes) < 8) dirty[k - 1] = 1;
+  if (B) emu_note_rows_changed(*B, k, p);
+  if (k > 0 && (off % seg_bytes) < 8) {
+    dirty[k - 1] = 1;
+    if (B) emu_note_rows_changed(*B, k - 1, p);
+  }
 }
 
 // a searched position whose candidate list changed (see list_or_mark in lz77_kernels.hip)
@@ -278,13 +283,21 @@ void lz77_rerank_keys(const Lz77Params& P, const Lz77Buffers& B, int which, int 
 }
 
 // ---- candidate rows: the same algorithm as the kernels of lz77_kernels.hip, one slot at a time ----
+static void emu_note_rows_changed(const Lz77Buffers& B, uint32_t k, uint32_t p) {
+  if (B.rows_changed_lo == nullptr) return;
+  B.rows_changed_lo[k] = std::min(B.rows_changed_lo[k], p);
+  B.rows_changed_hi[k] = std::max(B.rows_changed_hi[k], p);
+}
 static void emu_row_changed(const Lz77Buffers& B, int which, uint32_t p, const SegGeometry& geo, uint8_t* dirty) {
   if (p < geo.first_block_start) return;
   if (B.flags[which][p] & kFlagSearched) {
-    emu_mark_dirty(p, geo, dirty);
+    emu_mark_dirty(p, geo, dirty, &B);
   } else {
     const uint32_t k = emu_chain_in_front(p, geo);
-    if (k != 0xffffffffu) dirty[k] = 1;
+    if (k != 0xffffffffu) {
+      dirty[k] = 1;
+      emu_note_rows_changed(B, k, p);
+    }
   }
 }
 
@@ -404,10 +417,23 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   ChainScratchT<false, false> scratch;
   ChainScratchT<false, true> scratch_rows;
   ChainScratchT<true, false> scratch9;
+  // checkpoints: recorded by every parse of the real segments (not the warm-up's), used by the list launches
+  const bool own_segments = segments == B.segments;
+  T.checkpoints = own_segments ? (Checkpoint*)B.checkpoints : nullptr;
+  T.rows_changed_lo = B.rows_changed_lo;
+  T.rows_changed_hi = B.rows_changed_hi;
+  // (default 1: chains stop at checkpoints but do not restart from them -- a record was found stale in a way the rows-changed
+  // marks did not show; 0 switches the restart on for experiments)
+  static const uint32_t splice_part_off = getenv("BROTLI_MI355X_SPLICE_OFF") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_OFF")) : 1u;
+  T.splice_off = splice_part_off;
+  static const bool splice_off = getenv("BROTLI_MI355X_NO_SPLICE") != nullptr;
+  const bool splice = !splice_off && sched != nullptr && own_segments && B.rows != nullptr && B.checkpoints != nullptr && B.splice_lists != 0;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
     if (P.hasher_kind == 9) {
       br_parse_chain<true, false>(P, T, scratch9, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
+    } else if (splice) {
+      br_parse_chain<false, true, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     } else if (B.rows) {
       br_parse_chain<false, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     } else {
@@ -600,7 +626,19 @@ void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t nu
 
 // ---- bursts (device_api.h)
 void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
-  for (uint32_t k = 0; k < P.num_segments; ++k) br_chain_check(B.segments, B.entries, B.exits, P.num_segments, k, U.sched, U.touched, U.entry_dirty, U.new_entries);
+  for (uint32_t k = 0; k < P.num_segments; ++k)
+    br_chain_check(B.segments, B.entries, B.exits, P.num_segments, k, U.sched, U.touched, U.entry_dirty, U.new_entries, B.rows_changed_lo, B.rows_changed_hi);
+}
+void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B) {
+  if (B.rows_changed_lo == nullptr) return;
+  for (uint32_t k = 0; k < P.num_segments; ++k) {
+    B.rows_changed_lo[k] = 0xffffffffu;
+    B.rows_changed_hi[k] = 0;
+  }
+}
+void lz77_drop_checkpoints(const Lz77Params& P, const Lz77Buffers& B, const uint32_t* list, uint32_t count) {
+  if (B.checkpoints == nullptr) return;
+  for (uint32_t i = 0; i < count; ++i) br_drop_checkpoints((Checkpoint*)B.checkpoints, B.segments[list[i]]);
 }
 void lz77_burst_count(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
   uint32_t n = 0;

@@ -97,3 +97,31 @@ def test_h5_past_the_first_ring_revolution(L):
     assert check("markov1M-w17", synth.markov_text(1 << 20), 5, 17, lib=L)
     assert check("mixed1M-w17-q7", synth.mixed(1 << 20), 7, 17, lib=L)
     assert check("stretches2M-w18", synth.stretches(2 << 20), 5, 18, lib=L)
+
+
+def test_round_counts_at_64MiB(L):
+    """How many passes of the host resolver the speculative parse needs (segments cut as EncodeStream cuts them; the device
+    schedules launches in between by itself while the parse settles fast, bursts).  Guards against a scheduling change that
+    silently costs rounds; the streams themselves are checked by test_large_gpu.py.  Measured in round 3: text 2, Silesia-like
+    6, random 10 (synth.mixed: 64 -- the pieces of such a mix are coupled through the hash table)."""
+    import emu
+    limits = [("text", synth.markov_text(64 << 20), 3), ("silesia", synth.silesia_like(64 << 20), 8), ("random", synth.random_bytes(64 << 20), 12)]
+    for name, data, limit in limits:
+        mbs, st = emu.lz77_trace(L, data, 5, 22, len(data), False, b"", 0)
+        assert st["rounds"] <= limit, (name, st["rounds"])
+
+
+def test_checkpoint_and_burst_switches_leave_the_parse_alone(L):
+    """the command list with chains stopping at checkpoints and launches scheduled on the device (the default) equals the
+    oracle's -- and so does the one of a child process with both switched off (they are read once per process)"""
+    import os
+    import subprocess
+    import sys
+    child = ("import sys; sys.path.insert(0, %r); import synth, gpulib; from cmp_lz77 import check; "
+             "assert check('mixed6M', synth.mixed(6 << 20, seed=21), 5, 22, lib=gpulib.lib(), seg=1024); "
+             "assert check('text12M', synth.markov_text(12 << 20, 22), 5, 22, lib=gpulib.lib(), seg=2048); print('ok')") % os.path.dirname(os.path.abspath(__file__))
+    for extra in ({}, {"BROTLI_MI355X_NO_SPLICE": "1", "BROTLI_MI355X_BURST": "0"}, {"BROTLI_MI355X_NO_CHECKPOINTS": "1", "BROTLI_MI355X_NO_SPEC": "1"}):
+        env = dict(os.environ)
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "ok" in out.stdout, (extra, out.stdout[-2000:], out.stderr[-2000:])
