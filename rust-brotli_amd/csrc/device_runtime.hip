@@ -151,7 +151,10 @@ static void* AllocBlock(size_t bytes) {
     // the pools, a later launch died inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES, "Available Free mem : 0 MB")
     // where nothing can be caught.  Idle pooled blocks go back first -- this thread's, then every thread's.
     {
-      static constexpr size_t kHeadroom = (size_t)6 << 30;
+      // (1 GiB: hipFree waits for the whole device, so a trim in the middle of a multi-shard call -- kernels of seconds when
+      // the shards are live chains -- stalls every worker; with 6 GiB the 8-shard H5 case took 44 s instead of 14 right after
+      // the 1 GiB cases had filled the pools)
+      static constexpr size_t kHeadroom = (size_t)1 << 30;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < cap + kHeadroom) {
         P.Trim();

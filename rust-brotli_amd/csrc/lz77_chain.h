@@ -1641,15 +1641,6 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
   if constexpr (kSplice && kCheckpoints) {
     if (cp_on && rp != nullptr && rp->mode != 0) {
       old_n_cmds = BR_UNIFORM(exit_out.n_cmds);
-#if defined(BROTLI_HOST_EMU) && defined(BR_DEBUG_SPLICE)
-      for (uint32_t b = (seg.start / kCheckpointStride + 1u) * kCheckpointStride; b < seg.end; b += kCheckpointStride) {
-        const Checkpoint& r = t.checkpoints[b / kCheckpointStride];
-        if (r.valid == kCheckpointValid && r.n_cmds > old_n_cmds) {
-          fprintf(stderr, "inconsistent at entry: seg [%u,%u) mode %u old exit cmds %u pos %u searches %u | cp %u: pos %u cmds %u searches %u\n", seg.start, seg.end, rp->mode, old_n_cmds,
-                  exit_out.pos, exit_out.n_searches, b, r.pos, r.n_cmds, r.n_searches);
-        }
-      }
-#endif
       uint32_t keep_cmds = 0;  // commands of the old parse that stay where they are (restart)
       const bool no_restart = (t.splice_off & 1u) != 0, no_stop = (t.splice_off & 2u) != 0;  // (diagnosis: BROTLI_MI355X_SPLICE_OFF)
       if (rp->mode == 2 && rp->rows_lo != 0xffffffffu && !no_restart) {
@@ -1671,25 +1662,6 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
             SegExit sx{};
             SegEntry sn{};
             br_parse_segment<kH9, kRows, false, false>(P, t2, s, g2, entry, sx, sn);
-            {
-              // where do the old head and the head parsed now part?
-              uint32_t at = entry.pos;
-              for (uint32_t i = 0; i < sx.n_cmds && i < rec->n_cmds; ++i) {
-                if (memcmp(&keep[i], &cmds[i], sizeof(Command)) != 0) {
-                  fprintf(stderr, "  first differing command %u at text position ~%u (+ insert): old ins %u copy %u dist %u | now ins %u copy %u dist %u; flags there: ", i, at, keep[i].insert_len_,
-                          keep[i].copy_len_ & 0x1ffffff, keep[i].dist_extra_, cmds[i].insert_len_, cmds[i].copy_len_ & 0x1ffffff, cmds[i].dist_extra_);
-                  for (uint32_t q = at; q < at + 24; ++q) fprintf(stderr, "%u ", t.flags_next[q]);
-                  fprintf(stderr, "\n  row of %u now:", at + keep[i].insert_len_);
-                  for (uint32_t e = 0; e < kRowEntries; ++e) fprintf(stderr, " %d", (int)(t.rows[(size_t)(at + keep[i].insert_len_) * kRowEntries + e] == kRowEnd ? -1 : (int)(at + keep[i].insert_len_ - t.rows[(size_t)(at + keep[i].insert_len_) * kRowEntries + e])));
-                  {
-                    const uint32_t q = at + keep[i].insert_len_ - (keep[i].dist_extra_ - 15);
-                    fprintf(stderr, "  | old candidate at %u: flag %u, rows_lo/hi of this segment %u %u\n", q, t.flags_next[q], rp->rows_lo, rp->rows_hi);
-                  }
-                  break;
-                }
-                at += keep[i].insert_len_ + (keep[i].copy_len_ & 0x1ffffff);
-              }
-            }
             for (size_t i = 0; i < keep.size(); ++i) cmds[i] = keep[i];
             bool ok = sx.pos == rec->pos && sx.apply == rec->apply && sx.insert_len == rec->insert_len && sx.n_cmds == rec->n_cmds && sx.n_lits == rec->n_lits;
             for (int i = 0; i < 4; ++i) ok = ok && sx.cache[i] == rec->dc[i];
@@ -1959,13 +1931,6 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
       // ---- splice: the head parsed now + the rest of the old parse from the record at next_cp on
       const uint32_t rec_cmds = sp_rec_cmds;
       const uint32_t tail_cmds = old_n_cmds - rec_cmds;
-#if defined(BROTLI_HOST_EMU) && defined(BR_DEBUG_SPLICE)
-      if (rec_cmds > old_n_cmds) {
-        fprintf(stderr, "splice: seg [%u,%u) cp at %u: record has %u commands, old exit %u (mode %u rows %u..%u, n_cmds now %u, old pos %u)\n", seg.start, seg.end, next_cp,
-                rec_cmds, old_n_cmds, rp->mode, rp->rows_lo, rp->rows_hi, n_cmds, exit_out.pos);
-        abort();
-      }
-#endif
       {
         // the old rest sits at [rec_cmds + room, old_n_cmds + room) and goes to [n_cmds, ...): downwards or nowhere, lowest chunk first
         Command* slab = cmds;

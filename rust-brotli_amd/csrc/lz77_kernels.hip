@@ -1372,9 +1372,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
     a.T.checkpoints = own_segments ? (Checkpoint*)B.checkpoints : nullptr;
     a.T.rows_changed_lo = B.rows_changed_lo;
     a.T.rows_changed_hi = B.rows_changed_hi;
-    // (default 1: chains stop at checkpoints but do not restart from them -- a record was found stale in a way the rows-changed
-  // marks did not show; 0 switches the restart on for experiments)
-  static const uint32_t splice_part_off = getenv("BROTLI_MI355X_SPLICE_OFF") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_OFF")) : 1u;
+    static const uint32_t splice_part_off = getenv("BROTLI_MI355X_SPLICE_OFF") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_OFF")) : 0u;
     a.T.splice_off = splice_part_off;
     const bool splice = !splice_off && sched != nullptr && own_segments && B.checkpoints != nullptr && B.splice_lists != 0;
     if (spec == 8) {

@@ -1261,7 +1261,10 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   static const uint32_t burst_env = getenv("BROTLI_MI355X_BURST") ? (uint32_t)atoi(getenv("BROTLI_MI355X_BURST")) : 8u;
   static const uint32_t splice_max_share = getenv("BROTLI_MI355X_SPLICE_SHARE") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_SHARE")) : 8u;
   static const uint32_t burst_shrink = getenv("BROTLI_MI355X_BURST_SHRINK") ? (uint32_t)atoi(getenv("BROTLI_MI355X_BURST_SHRINK")) : 4u;
-  const uint32_t burst_max = use_rows_ ? burst_env : 0u;  // 0: one launch per pass, scheduled by the host (rank-structure chains)
+  // 0: one launch per pass, scheduled by the host -- rank-structure chains, and inputs with long runs of one byte (zero fill:
+  // every launch there is followed by passes over all rows, and the device's plain scheduling needs more of them: 1 GiB of
+  // zeros 6 rounds / 736 ms with bursts, 4 rounds / 467 ms without)
+  const uint32_t burst_max = (use_rows_ && B_.run_end == nullptr) ? burst_env : 0u;
   BurstBuffers U;
   if (burst_max != 0) {
     U.sched = (uint8_t*)dev_alloc(nseg + 64);
@@ -1647,6 +1650,11 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       last_death_seg = dict_death_seg_;
       if (warmup_bytes_ > 0 && dict_death_seg_ + 2 < nseg) {
         Warmup(dict_death_seg_ + 1, true, which, rbuf, &dirty);
+        // (the dry run rewrote the entries of the scheduled segments behind that point: none of them is parsed "with the
+        // entry it had last time" any more -- a chain that restarted from a checkpoint on that assumption kept the head of a
+        // parse made from another entry; found by the emulation build's shadow parse on 256 MiB of text)
+        for (uint32_t k = dict_death_seg_ + 1; k < nseg; ++k)
+          if (sched[k] == kSchedOwnRows) sched[k] = kSchedOwn;
       }
     }
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u | block-first: cache %u ext %u | head %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dbg_first_[0], dbg_first_[1], dbg_first_[2], dict_death_seg_, predicted_death_, dict_flips_);

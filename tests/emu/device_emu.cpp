@@ -422,9 +422,7 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.checkpoints = own_segments ? (Checkpoint*)B.checkpoints : nullptr;
   T.rows_changed_lo = B.rows_changed_lo;
   T.rows_changed_hi = B.rows_changed_hi;
-  // (default 1: chains stop at checkpoints but do not restart from them -- a record was found stale in a way the rows-changed
-  // marks did not show; 0 switches the restart on for experiments)
-  static const uint32_t splice_part_off = getenv("BROTLI_MI355X_SPLICE_OFF") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_OFF")) : 1u;
+  static const uint32_t splice_part_off = getenv("BROTLI_MI355X_SPLICE_OFF") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SPLICE_OFF")) : 0u;
   T.splice_off = splice_part_off;
   static const bool splice_off = getenv("BROTLI_MI355X_NO_SPLICE") != nullptr;
   const bool splice = !splice_off && sched != nullptr && own_segments && B.rows != nullptr && B.checkpoints != nullptr && B.splice_lists != 0;
