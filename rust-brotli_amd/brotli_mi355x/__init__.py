@@ -13,6 +13,11 @@ import ctypes
 import os
 from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_size_t, c_uint32, c_void_p
 
+# The library asks the HIP runtime for 16 hardware queues (eight shard workers side by side) when it is loaded; the runtime
+# reads the variable when it starts, so a process in which something else starts HIP first (torch) should import this
+# module -- or set the variable -- before that.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BROTLI_MI355X_LIB") or os.path.join(os.path.dirname(_HERE), "libbrotli_mi355x.so")  # (the override is for profiling builds)
 

@@ -1472,7 +1472,9 @@ struct FlagWriter {
     if constexpr (kMasked) {
       const uint32_t last = copy_end < store_end ? copy_end : store_end;
       if (q >= last) return unstored(q);
-      if (q >= masked_from && last >= first + 8 && q < first + ((last - first) & ~3u)) return (uint8_t)(kFlagStored | kFlagMasked);
+      // (a quad is filed as (start & mask) + 0..3: it is the START of the quad that decides -- the one quad that straddles the
+      // end of the first ring-buffer revolution keeps true positions for all four)
+      if (last >= first + 8 && q < first + ((last - first) & ~3u) && first + ((q - first) & ~3u) >= masked_from) return (uint8_t)(kFlagStored | kFlagMasked);
       return kFlagStored;
     } else {
       return q < store_end ? (uint8_t)1 : unstored(q);  // (q < copy_end at every call)

@@ -134,7 +134,10 @@ BR_DEV void br_live_store_copy(const LiveRing& lr, uint32_t first, uint32_t last
   if (last <= first) return;
   const uint32_t n = last - first;
   const uint32_t masked_hi = n >= 8 ? first + (n & ~3u) : first;
-  br_live_store(lr, first, 1, n, masked_from, masked_hi, kwin, kwin_base);
+  // (the batch files a quad as (start & mask) + 0..3: masked from the first quad that STARTS at or behind masked_from; the quad
+  // that straddles it keeps true positions)
+  const uint32_t masked_lo = masked_from <= first ? first : (masked_from - first > 0xfffffff0u - first ? 0xffffffffu : first + ((masked_from - first + 3u) & ~3u));
+  br_live_store(lr, first, 1, n, masked_lo, masked_hi, kwin, kwin_base);
 }
 
 // ---- materialisation --------------------------------------------------------------------------------------------------

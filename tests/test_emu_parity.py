@@ -223,3 +223,19 @@ def test_live_chain_on_inputs_without_masked_entries(L):
     finally:
         del os.environ["BROTLI_MI355X_LIVE"]
         del os.environ["BROTLI_MI355X_LIVE_VERIFY"]
+
+
+def _quad_straddles_ring_end(L):
+    # A compress_multi shard at lgwin 17 (H5, ring buffer of 256 KiB) whose 131 056-byte prefix + 158 925 bytes pass the end of
+    # the first ring-buffer revolution inside a copy: StoreRangeOptBatch files a quad as (start & mask) + 0..3
+    # (mod.rs:1163-1232), so the ONE quad that straddles that point keeps true positions for all four -- the entry 262 144
+    # stays a candidate where "position >= ring size => masked" ended the bucket walk (found by the API sweep, round 3).
+    import os
+    blob = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quad_straddles_ring_end.bin"), "rb").read()
+    pre, data = blob[:131056], blob[131056:]
+    for q in (5, 6, 7, 8):
+        assert check("quad straddles the ring end q%d" % q, data, q, 17, size_hint=0, catable=True, prefix=pre, lib=L)
+
+
+def test_quad_that_straddles_the_end_of_the_first_ring_revolution(L):
+    _quad_straddles_ring_end(L)

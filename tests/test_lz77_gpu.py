@@ -125,3 +125,8 @@ def test_checkpoint_and_burst_switches_leave_the_parse_alone(L):
         env.update(extra)
         out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, (extra, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_quad_that_straddles_the_end_of_the_first_ring_revolution(L):
+    from test_emu_parity import _quad_straddles_ring_end
+    _quad_straddles_ring_end(L)
