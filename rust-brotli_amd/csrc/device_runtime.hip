@@ -151,9 +151,8 @@ static void* AllocBlock(size_t bytes) {
     // the pools, a later launch died inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES, "Available Free mem : 0 MB")
     // where nothing can be caught.  Idle pooled blocks go back first -- this thread's, then every thread's.
     {
-      // (1 GiB: hipFree waits for the whole device, so a trim in the middle of a multi-shard call -- kernels of seconds when
-      // the shards are live chains -- stalls every worker; with 6 GiB the 8-shard H5 case took 44 s instead of 14 right after
-      // the 1 GiB cases had filled the pools)
+      // (1 GiB is plenty for the runtime, and trimming is expensive: hipFree waits for the whole device and handing back
+      // ~150 GiB of pooled blocks takes seconds)
       static constexpr size_t kHeadroom = (size_t)1 << 30;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < cap + kHeadroom) {
@@ -391,17 +390,6 @@ void dev_wait_mark() {
     if (e != hipErrorNotReady) HIP_CHECK(e);
     __builtin_ia32_pause();
   }
-}
-
-// Before a call that spreads its work over helper threads: if less than `min_free_share` percent of the device memory is
-// free, every thread's idle pooled blocks go back to the driver NOW, while nothing runs.  (hipFree waits for the whole
-// device: the same trim forced by a failing allocation in the middle of the call -- kernels of seconds when the shards are
-// live chains -- stalled every worker: 8 H5 shards took 39-44 s instead of 14 right after the 1 GiB cases had filled the
-// calling thread's pool.)
-void dev_make_room(unsigned min_free_share) {
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
-  if (free_b * 100 < total_b * (size_t)min_free_share) TrimAllPools();
 }
 
 // gives the pooled (currently unused) device memory of the calling thread back to the driver
