@@ -343,6 +343,7 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
     } else {
       EncoderParams params;
       if (!ParamsFromLists(num_params, keys, values, &params)) return 0;
+      dev_make_room(10);  // (the helper threads allocate from pools of their own: room for them while the device is idle)
       if (params.favor_cpu_efficiency) {
         // threading/mod.rs:456-542: one hasher is filled with the whole input in front of every shard and handed to its
         // encoder instead of priming it from the shard's prefix.  While a shard starts within the window that is the same

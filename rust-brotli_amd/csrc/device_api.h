@@ -41,6 +41,7 @@ void dev_wait_mark();  // ... and waits until everything queued before the last 
 void* dev_host_alloc(size_t bytes);
 void dev_host_free(void* p);
 void dev_pool_counters(double* out4, bool reset);  // hipMalloc calls / ms, hipFree calls / ms of the calling thread
+void dev_make_room(unsigned min_free_share);  // trims every thread's pool if less than that percentage of the device memory is free
 size_t dev_trim_pool();  // returns the pooled, currently unused device memory of the calling thread to the driver; bytes freed
 int dev_current_device();        // the calling thread's device (helper threads adopt their caller's)
 void dev_use_device(int device);

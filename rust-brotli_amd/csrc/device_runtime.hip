@@ -35,8 +35,12 @@ struct Pool {
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks;  // capacity -> block
   std::unordered_map<void*, size_t> capacity;  // every live block handed out or pooled
+  std::unordered_map<void*, uint64_t> pooled_seq;  // pooled blocks: when they came back (the oldest go first when the pool is over its cap)
+  uint64_t seq = 0;
   size_t pooled_bytes = 0;
-  static constexpr size_t kMaxPooled = (size_t)192 << 30;  // (a 1 GiB piece alone needs ~90 GiB; of 288)
+  // (a 1 GiB piece alone needs ~95 GiB of the 288; with 192 GiB kept by the calling thread, the eight helper threads of a
+  // multi-shard call that followed found 7 GB free and trimmed in the middle of the call)
+  static constexpr size_t kMaxPooled = (size_t)128 << 30;
   Pool();
   ~Pool();
   // hands every pooled block back to the driver; returns the bytes freed (any thread may call it: hipFree waits for the
@@ -51,6 +55,7 @@ struct Pool {
         capacity.erase(kv.second);
       }
       free_blocks.clear();
+      pooled_seq.clear();
       bytes = pooled_bytes;
       pooled_bytes = 0;
     }
@@ -142,6 +147,7 @@ static void* AllocBlock(size_t bytes) {
     if (it != P.free_blocks.end() && it->first <= cap + cap / 4) {
       p = it->second;
       P.pooled_bytes -= it->first;
+      P.pooled_seq.erase(p);
       P.free_blocks.erase(it);
     }
   }
@@ -187,13 +193,27 @@ void dev_free(void* p) {
     (void)hipFree(p);
     return;
   }
-  if (P.pooled_bytes + it->second > Pool::kMaxPooled) {
+  if (it->second > Pool::kMaxPooled) {
     DriverCallClock clock(2);
     P.capacity.erase(it);
     (void)hipFree(p);
     return;
   }
+  // over the cap: the blocks that have sat in the pool longest go (the sizes of the call before this one), not the block
+  // coming back now -- the next call of the same kind wants exactly that one
+  while (P.pooled_bytes + it->second > Pool::kMaxPooled && !P.free_blocks.empty()) {
+    auto oldest = P.free_blocks.begin();
+    for (auto b = P.free_blocks.begin(); b != P.free_blocks.end(); ++b)
+      if (P.pooled_seq[b->second] < P.pooled_seq[oldest->second]) oldest = b;
+    DriverCallClock clock(2);
+    P.pooled_bytes -= oldest->first;
+    P.capacity.erase(oldest->second);
+    P.pooled_seq.erase(oldest->second);
+    (void)hipFree(oldest->second);
+    P.free_blocks.erase(oldest);
+  }
   P.free_blocks.emplace(it->second, p);
+  P.pooled_seq[p] = ++P.seq;
   P.pooled_bytes += it->second;
 }
 // page-locked host blocks are pooled like the device blocks (hipHostMalloc costs a fraction of a millisecond)
@@ -392,6 +412,17 @@ void dev_wait_mark() {
   }
 }
 
+// Before a call that spreads its work over helper threads: if less than `min_free_share` percent of the device memory is
+// free, every thread's idle pooled blocks go back to the driver NOW, while nothing runs.  hipFree waits for the whole
+// device: the same trim forced by allocations in the middle of the call -- kernels of seconds when the shards are live
+// chains -- stalls every worker (8 H5 shards: 42 s instead of 14 with 7 GB free after the 1 GiB cases).  It is not free
+// either -- handing back ~150 GiB takes seconds -- hence only when memory is really short.
+void dev_make_room(unsigned min_free_share) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
+  if (free_b * 100 < total_b * (size_t)min_free_share) TrimAllPools();
+}
+
 // gives the pooled (currently unused) device memory of the calling thread back to the driver
 size_t dev_trim_pool() {
   Pool& P = pool();
@@ -405,6 +436,7 @@ size_t dev_trim_pool() {
       bytes += kv.first;
     }
     P.free_blocks.clear();
+    P.pooled_seq.clear();
     P.pooled_bytes = 0;
   }
   if (!drop.empty()) HIP_CHECK(hipStreamSynchronize(BR_STREAM));
