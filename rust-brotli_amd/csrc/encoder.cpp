@@ -14,6 +14,7 @@
 #include "lz77_stage.h"
 #include "metablock_api.h"
 #include "metablock_device.h"
+#include "metablock_hq.h"
 #include "metablock_items.h"
 
 namespace brotli_mi355x {
@@ -462,6 +463,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     B.signed_lut = dt.signed_context_lookup;
     B.et.logs_16 = dt.logs_16;
     B.et.logs_8 = dt.logs_8;
+    const bool hq = p.quality >= 10;  // the quality >= 10 meta-block builder behind the greedy chains ("9.5"), metablock_hq.h
+    B.header_stride = hq ? kHqHeaderWords : kHeaderWords;
     B.descs = mm.alloc<MbDesc>(n_mb);
     B.results = mm.alloc<MbResult>(n_mb);
     B.cmd_lit_start = mm.alloc<uint32_t>((size_t)K + 1);
@@ -541,75 +544,259 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       }
       B.n_dists = di[n_mb];
     }
-    // literal context modelling decision
-    if (p.disable_literal_context_modeling == 0) {
-      uint32_t* stats_dev = mm.alloc<uint32_t>((size_t)n_mb * kContextStatsWords);
-      mb_context_stats(B, stats_dev);
-      std::vector<uint32_t> cs((size_t)n_mb * kContextStatsWords);
-      dev_d2h(cs.data(), stats_dev, cs.size() * 4);
-      for (uint32_t m = 0; m < n_mb; ++m) {
-        if (descs[m].uncompressed) continue;
-        DecideContexts(cs.data() + (size_t)m * kContextStatsWords, p.quality, p.size_hint, descs[m].end - descs[m].start,
-                       &descs[m].num_contexts, &descs[m].context_map_id);
-      }
-    }
-    // pools
-    uint32_t gran_total[3] = {0, 0, 0}, row_total[3] = {0, 0, 0}, block_total[3] = {0, 0, 0}, histo_total[3] = {0, 0, 0};
-    for (uint32_t m = 0; m < n_mb; ++m) {
-      MbDesc& d = descs[m];
-      d.n_symbols[0] = d.n_lits;
-      d.n_symbols[1] = d.n_cmds;
-      d.n_symbols[2] = d.n_dists;
-      for (uint32_t k = 0; k < 3; ++k) {
-        const uint32_t gl = kGranuleLen[k];
-        const uint32_t nc = k == 0 ? d.num_contexts : 1;
-        d.granule_base[k] = gran_total[k];
-        d.n_granules[k] = d.uncompressed ? 0 : (d.n_symbols[k] + gl - 1) / gl;
-        d.gran_row_base[k] = row_total[k];
-        d.block_base[k] = block_total[k];
-        d.max_blocks[k] = d.n_symbols[k] / gl + 1;
-        const uint32_t max_types = (k == 0 && nc > 1) ? 256 / nc : 256;
-        d.histo_base[k] = histo_total[k];
-        d.max_histos[k] = std::min(d.max_blocks[k], max_types + 1) * nc;
-        gran_total[k] += d.n_granules[k];
-        row_total[k] += d.n_granules[k] * nc;
-        block_total[k] += d.max_blocks[k] + 1;
-        histo_total[k] += d.max_histos[k];
-      }
-    }
-    std::vector<uint32_t> gran_mb_host[3];
-    for (uint32_t k = 0; k < 3; ++k) {
-      gran_mb_host[k].resize(gran_total[k] + 1);
-      for (uint32_t m = 0; m < n_mb; ++m)
-        for (uint32_t g = 0; g < descs[m].n_granules[k]; ++g) gran_mb_host[k][descs[m].granule_base[k] + g] = m;
-      B.n_granules[k] = gran_total[k];
-      B.gran_mb[k] = mm.alloc<uint32_t>(gran_total[k] + 1);
-      dev_h2d(B.gran_mb[k], gran_mb_host[k].data(), (size_t)gran_total[k] * 4);
-      B.gran_hist[k] = mm.alloc<uint16_t>((size_t)row_total[k] * kRowLen[k] + 8);
-      B.gran_block[k] = mm.alloc<uint16_t>(gran_total[k] + 8);
-      B.histo[k] = mm.alloc<uint32_t>((size_t)histo_total[k] * kRowLen[k] + 8);
-      B.depth[k] = mm.alloc<uint8_t>((size_t)histo_total[k] * kRowLen[k] + 8);
-      B.bits[k] = mm.alloc<uint16_t>((size_t)histo_total[k] * kRowLen[k] + 8);
-      B.tree_bits[k] = mm.alloc<uint64_t>((size_t)histo_total[k] * kTreeBitsWords + 8);
-      B.tree_nbits[k] = mm.alloc<uint32_t>(histo_total[k] + 8);
-      B.block_types[k] = mm.alloc<uint8_t>(block_total[k] + 8);
-      B.block_lengths[k] = mm.alloc<uint32_t>(block_total[k] + 8);
-      B.switch_bits[k] = mm.alloc<uint64_t>(block_total[k] + 8);
-      B.switch_nbits[k] = mm.alloc<uint8_t>(block_total[k] + 8);
-    }
-    B.header_words = mm.alloc<uint64_t>((size_t)n_mb * kHeaderWords);
-    B.ctxmap_scratch = mm.alloc<uint32_t>((size_t)n_mb * 2 * 256 * 64);
-    B.mb_out_bit = mm.alloc<uint64_t>(n_mb + 1);
-    dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
-    stats.ms_phase[1] += clk.lap(prof, "mb1");
-    mb_granule_histograms(B);
-    stats.ms_phase[2] += clk.lap(prof, "mb2");
-    bool wide = false;
-    for (uint32_t m = 0; m < n_mb; ++m) wide = wide || (!descs[m].uncompressed && descs[m].num_contexts > 3);
-    mb_split_chains(B, wide);
     std::vector<MbResult> results(n_mb);
-    dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
-    stats.ms_phase[3] += clk.lap(prof, "mb3");
+    if (hq) {
+      // ---- BrotliBuildMetaBlock (metablock.rs:133-307) on the device, metablock_hq.h
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        descs[m].hq = 1;
+        descs[m].hq_no_context = p.disable_literal_context_modeling ? 1 : 0;
+        descs[m].n_symbols[0] = descs[m].n_lits;
+        descs[m].n_symbols[1] = descs[m].n_cmds;
+        descs[m].n_symbols[2] = descs[m].n_dists;
+      }
+      {
+        // the distance-parameter search re-codes the distance prefixes of a meta-block: on a copy, the LZ77 stage keeps its own
+        Command* copy = mm.alloc<Command>((size_t)K + 1);
+        dev_d2d(copy, B.cmds, (size_t)K * sizeof(Command));
+        B.cmds = copy;
+        B.cmds_rw = copy;
+      }
+      dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+      const bool census = !(p.mode == 3 || p.mode == 4 || p.mode == 5 || p.mode == 6);
+      if (census) mb_hq_utf8_census(B);
+      mb_hq_distance_params(B, mm.alloc<uint32_t>((size_t)n_mb * kNumDistanceHistoSymbols));
+      dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        MbDesc& d = descs[m];
+        if (census) d.context_mode = results[m].hq_mostly_utf8 ? 2 : 3;  // ChooseContextMode, encode.rs:1357-1377
+        d.dist_postfix_bits = results[m].hq_postfix;
+        d.num_direct_distance_codes = results[m].hq_ndirect;
+        d.num_distance_symbols = 16 + d.num_direct_distance_codes + (24u << (d.dist_postfix_bits + 1));
+      }
+      B.hq_sym[0] = mm.alloc<uint16_t>((size_t)L + 8);
+      B.hq_sym[1] = mm.alloc<uint16_t>((size_t)K + 8);
+      B.hq_sym[2] = mm.alloc<uint16_t>((size_t)B.n_dists + 8);
+      mb_hq_gather_symbols(B);
+      // BrotliSplitBlock, block_splitter.rs:840-929: one job per (meta-block, kind)
+      static const uint32_t kSymbolsPerHistogram[3] = {544, 530, 544}, kMaxHistograms[3] = {100, 50, 50}, kStride[3] = {70, 40, 40};
+      static const float kSwitchCost[3] = {28.1f, 13.5f, 14.6f};
+      uint8_t* block_ids[3] = {mm.alloc<uint8_t>((size_t)L + 8), mm.alloc<uint8_t>((size_t)K + 8), mm.alloc<uint8_t>((size_t)B.n_dists + 8)};
+      std::vector<HqSplitJob> jobs;
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        const MbDesc& d = descs[m];
+        if (d.uncompressed) continue;
+        const uint32_t base[3] = {d.lit_base, d.cmd_offset, d.dist_base};
+        for (uint32_t k = 0; k < 3; ++k) {
+          HqSplitJob j;
+          memset(&j, 0, sizeof(j));
+          j.m = m;
+          j.kind = k;
+          j.length = d.n_symbols[k];
+          j.alphabet = kRowLen[k];
+          j.num_histograms = std::min(j.length / kSymbolsPerHistogram[k] + 1, kMaxHistograms[k]);
+          j.stride = kStride[k];
+          j.iters = p.quality <= 11 ? 3 : 10;  // block_splitter.rs:794
+          j.block_switch_cost = kSwitchCost[k];
+          j.data = B.hq_sym[k] + base[k];
+          j.block_ids = block_ids[k] + base[k];
+          if (j.length >= 128) {
+            const size_t nh = j.num_histograms, bitmaplen = (nh + 7) >> 3;
+            j.histo_data = mm.alloc<uint32_t>((nh + 1) * j.alphabet);
+            j.histo_total = mm.alloc<uint32_t>(nh + 1);
+            j.insert_cost = mm.alloc<float>((size_t)j.alphabet * nh + nh + 8);
+            j.cost = mm.alloc<float>(bitmaplen * 8 + 8);
+            j.switch_signal = mm.alloc<uint8_t>((size_t)j.length * bitmaplen + 8);
+            j.new_id = mm.alloc<uint16_t>(nh + 8);
+          }
+          jobs.push_back(j);
+        }
+      }
+      HqSplitJob* jobs_dev = mm.alloc<HqSplitJob>(jobs.size() + 1);
+      dev_h2d(jobs_dev, jobs.data(), jobs.size() * sizeof(HqSplitJob));
+      mb_hq_find_blocks(B, jobs_dev, (uint32_t)jobs.size());
+      dev_d2h(jobs.data(), jobs_dev, jobs.size() * sizeof(HqSplitJob));
+      stats.ms_phase[1] += clk.lap(prof, "hq-find-blocks");
+      // pools sized by what FindBlocks found; ClusterBlocks
+      uint32_t block_total[3] = {0, 0, 0}, histo_total[3] = {0, 0, 0};
+      for (uint32_t m = 0; m < n_mb; ++m)
+        for (uint32_t k = 0; k < 3; ++k) {
+          descs[m].histo_base[k] = histo_total[k];
+          descs[m].max_histos[k] = 256;
+          histo_total[k] += 256;
+        }
+      for (HqSplitJob& j : jobs) {
+        MbDesc& d = descs[j.m];
+        const uint32_t nb = j.num_blocks;
+        d.block_base[j.kind] = block_total[j.kind];
+        d.max_blocks[j.kind] = nb + 1;
+        block_total[j.kind] += nb + 2;
+        if (j.length >= 128) {
+          const size_t n = nb;
+          uint64_t max_pairs = std::min<uint64_t>(64ull * n, (uint64_t)(n / 2) * n);
+          max_pairs = std::max<uint64_t>(max_pairs, kHqBatchPairs);
+          j.histogram_symbols = mm.alloc<uint32_t>(n + 8);
+          j.block_lengths = mm.alloc<uint32_t>(n + 8);
+          j.batch_data = mm.alloc<uint32_t>((size_t)(kHqBatch + 2) * j.alphabet);
+          j.batch_total = mm.alloc<uint32_t>(kHqBatch + 2);
+          j.batch_cost = mm.alloc<float>(kHqBatch + 2);
+          j.all_data = mm.alloc<uint32_t>((n + 2) * j.alphabet);
+          j.all_total = mm.alloc<uint32_t>(n + 2);
+          j.all_cost = mm.alloc<float>(n + 2);
+          j.cluster_size = mm.alloc<uint32_t>(n + 8);
+          j.clusters = mm.alloc<uint32_t>(n + 8);
+          j.new_index = mm.alloc<uint32_t>(n + 8);
+          j.pairs = mm.alloc<HqPair>(max_pairs + 2);
+        }
+      }
+      for (uint32_t k = 0; k < 3; ++k) {
+        B.n_granules[k] = 0;
+        B.histo[k] = mm.alloc<uint32_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+        B.depth[k] = mm.alloc<uint8_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+        B.bits[k] = mm.alloc<uint16_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+        B.tree_bits[k] = mm.alloc<uint64_t>((size_t)histo_total[k] * kTreeBitsWords + 8);
+        B.tree_nbits[k] = mm.alloc<uint32_t>(histo_total[k] + 8);
+        B.block_types[k] = mm.alloc<uint8_t>(block_total[k] + 8);
+        B.block_lengths[k] = mm.alloc<uint32_t>(block_total[k] + 8);
+        B.block_start[k] = mm.alloc<uint32_t>(block_total[k] + 8);
+        B.switch_bits[k] = mm.alloc<uint64_t>(block_total[k] + 8);
+        B.switch_nbits[k] = mm.alloc<uint8_t>(block_total[k] + 8);
+      }
+      B.header_words = mm.alloc<uint64_t>((size_t)n_mb * kHqHeaderWords);
+      B.ctxmap_scratch = mm.alloc<uint32_t>((size_t)n_mb * 2 * 256 * 64);
+      B.mb_out_bit = mm.alloc<uint64_t>(n_mb + 1);
+      dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+      dev_h2d(jobs_dev, jobs.data(), jobs.size() * sizeof(HqSplitJob));
+      mb_hq_cluster_blocks(B, jobs_dev, (uint32_t)jobs.size());
+      dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+      stats.ms_phase[2] += clk.lap(prof, "hq-cluster-blocks");
+      // context histograms and the clustered context maps (histogram.rs:465-534, cluster.rs:353-465)
+      uint32_t rows_total[2] = {0, 0}, map_total[2] = {0, 0};
+      std::vector<HqClusterJob> cjobs;
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        MbDesc& d = descs[m];
+        if (d.uncompressed) continue;
+        const uint32_t nt[2] = {results[m].num_types[kSplitLiteral], results[m].num_types[kSplitDistance]};
+        const uint32_t rows[2] = {d.hq_no_context ? nt[0] : nt[0] << 6, nt[1] << 2};
+        const uint32_t maps[2] = {nt[0] << 6, nt[1] << 2};
+        for (uint32_t w = 0; w < 2; ++w) {
+          d.hq_ctx_row_base[w] = rows_total[w];
+          d.hq_ctx_map_base[w] = map_total[w];
+          rows_total[w] += rows[w];
+          map_total[w] += maps[w];
+        }
+      }
+      B.hq_ctx_histo[0] = mm.alloc<uint32_t>((size_t)rows_total[0] * 256 + 8);
+      B.hq_ctx_histo[1] = mm.alloc<uint32_t>((size_t)rows_total[1] * kNumDistanceHistoSymbols + 8);
+      B.hq_ctx_map[0] = mm.alloc<uint32_t>((size_t)map_total[0] + 8);
+      B.hq_ctx_map[1] = mm.alloc<uint32_t>((size_t)map_total[1] + 8);
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        const MbDesc& d = descs[m];
+        if (d.uncompressed) continue;
+        for (uint32_t w = 0; w < 2; ++w) {
+          HqClusterJob j;
+          memset(&j, 0, sizeof(j));
+          j.m = m;
+          j.kind = w == 0 ? kSplitLiteral : kSplitDistance;
+          const uint32_t nt = results[m].num_types[j.kind];
+          j.in_size = w == 0 ? (d.hq_no_context ? nt : nt << 6) : nt << 2;
+          j.len = kRowLen[j.kind];
+          j.expand64 = (w == 0 && d.hq_no_context) ? 1 : 0;
+          j.in_data = B.hq_ctx_histo[w] + (size_t)d.hq_ctx_row_base[w] * j.len;
+          const size_t n = j.in_size, re = std::min<size_t>(n, 256);
+          j.in_total = mm.alloc<uint32_t>(n + 8);
+          j.out_data = mm.alloc<uint32_t>((n + 2) * j.len);
+          j.out_total = mm.alloc<uint32_t>(n + 2);
+          j.out_cost = mm.alloc<float>(n + 2);
+          j.cluster_size = mm.alloc<uint32_t>(n + 8);
+          j.clusters = mm.alloc<uint32_t>(n + 8);
+          j.symbols = mm.alloc<uint32_t>(n + 8);
+          j.new_index = mm.alloc<uint32_t>(n + 8);
+          j.reindex_data = mm.alloc<uint32_t>(re * j.len + 8);
+          j.reindex_total = mm.alloc<uint32_t>(re + 8);
+          j.reindex_cost = mm.alloc<float>(re + 8);
+          j.pairs = mm.alloc<HqPair>(std::max<size_t>(kHqBatchPairs, 64 * n) + 2);
+          cjobs.push_back(j);
+        }
+      }
+      dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+      mb_hq_context_histograms(B);
+      HqClusterJob* cjobs_dev = mm.alloc<HqClusterJob>(cjobs.size() + 1);
+      dev_h2d(cjobs_dev, cjobs.data(), cjobs.size() * sizeof(HqClusterJob));
+      mb_hq_cluster_histograms(B, cjobs_dev, (uint32_t)cjobs.size());
+      dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+      for (uint32_t m = 0; m < n_mb; ++m) results[m].num_histos[kSplitCommand] = results[m].num_types[kSplitCommand];
+      dev_h2d(B.results, results.data(), n_mb * sizeof(MbResult));
+      stats.ms_phase[3] += clk.lap(prof, "hq-context-maps");
+    } else {
+      // literal context modelling decision
+      if (p.disable_literal_context_modeling == 0) {
+        uint32_t* stats_dev = mm.alloc<uint32_t>((size_t)n_mb * kContextStatsWords);
+        mb_context_stats(B, stats_dev);
+        std::vector<uint32_t> cs((size_t)n_mb * kContextStatsWords);
+        dev_d2h(cs.data(), stats_dev, cs.size() * 4);
+        for (uint32_t m = 0; m < n_mb; ++m) {
+          if (descs[m].uncompressed) continue;
+          DecideContexts(cs.data() + (size_t)m * kContextStatsWords, p.quality, p.size_hint, descs[m].end - descs[m].start,
+                         &descs[m].num_contexts, &descs[m].context_map_id);
+        }
+      }
+      // pools
+      uint32_t gran_total[3] = {0, 0, 0}, row_total[3] = {0, 0, 0}, block_total[3] = {0, 0, 0}, histo_total[3] = {0, 0, 0};
+      for (uint32_t m = 0; m < n_mb; ++m) {
+        MbDesc& d = descs[m];
+        d.n_symbols[0] = d.n_lits;
+        d.n_symbols[1] = d.n_cmds;
+        d.n_symbols[2] = d.n_dists;
+        for (uint32_t k = 0; k < 3; ++k) {
+          const uint32_t gl = kGranuleLen[k];
+          const uint32_t nc = k == 0 ? d.num_contexts : 1;
+          d.granule_base[k] = gran_total[k];
+          d.n_granules[k] = d.uncompressed ? 0 : (d.n_symbols[k] + gl - 1) / gl;
+          d.gran_row_base[k] = row_total[k];
+          d.block_base[k] = block_total[k];
+          d.max_blocks[k] = d.n_symbols[k] / gl + 1;
+          const uint32_t max_types = (k == 0 && nc > 1) ? 256 / nc : 256;
+          d.histo_base[k] = histo_total[k];
+          d.max_histos[k] = std::min(d.max_blocks[k], max_types + 1) * nc;
+          gran_total[k] += d.n_granules[k];
+          row_total[k] += d.n_granules[k] * nc;
+          block_total[k] += d.max_blocks[k] + 1;
+          histo_total[k] += d.max_histos[k];
+        }
+      }
+      std::vector<uint32_t> gran_mb_host[3];
+      for (uint32_t k = 0; k < 3; ++k) {
+        gran_mb_host[k].resize(gran_total[k] + 1);
+        for (uint32_t m = 0; m < n_mb; ++m)
+          for (uint32_t g = 0; g < descs[m].n_granules[k]; ++g) gran_mb_host[k][descs[m].granule_base[k] + g] = m;
+        B.n_granules[k] = gran_total[k];
+        B.gran_mb[k] = mm.alloc<uint32_t>(gran_total[k] + 1);
+        dev_h2d(B.gran_mb[k], gran_mb_host[k].data(), (size_t)gran_total[k] * 4);
+        B.gran_hist[k] = mm.alloc<uint16_t>((size_t)row_total[k] * kRowLen[k] + 8);
+        B.gran_block[k] = mm.alloc<uint16_t>(gran_total[k] + 8);
+        B.histo[k] = mm.alloc<uint32_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+        B.depth[k] = mm.alloc<uint8_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+        B.bits[k] = mm.alloc<uint16_t>((size_t)histo_total[k] * kRowLen[k] + 8);
+        B.tree_bits[k] = mm.alloc<uint64_t>((size_t)histo_total[k] * kTreeBitsWords + 8);
+        B.tree_nbits[k] = mm.alloc<uint32_t>(histo_total[k] + 8);
+        B.block_types[k] = mm.alloc<uint8_t>(block_total[k] + 8);
+        B.block_lengths[k] = mm.alloc<uint32_t>(block_total[k] + 8);
+        B.switch_bits[k] = mm.alloc<uint64_t>(block_total[k] + 8);
+        B.switch_nbits[k] = mm.alloc<uint8_t>(block_total[k] + 8);
+      }
+      B.header_words = mm.alloc<uint64_t>((size_t)n_mb * kHeaderWords);
+      B.ctxmap_scratch = mm.alloc<uint32_t>((size_t)n_mb * 2 * 256 * 64);
+      B.mb_out_bit = mm.alloc<uint64_t>(n_mb + 1);
+      dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
+      stats.ms_phase[1] += clk.lap(prof, "mb1");
+      mb_granule_histograms(B);
+      stats.ms_phase[2] += clk.lap(prof, "mb2");
+      bool wide = false;
+      for (uint32_t m = 0; m < n_mb; ++m) wide = wide || (!descs[m].uncompressed && descs[m].num_contexts > 3);
+      mb_split_chains(B, wide);
+      dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
+      stats.ms_phase[3] += clk.lap(prof, "mb3");
+    }
     // Huffman codes: one job per histogram
     std::vector<CodeJob> jobs;
     for (uint32_t m = 0; m < n_mb; ++m) {
@@ -687,7 +874,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     mb_emit(B);
     for (uint32_t m = 0; m < n_mb; ++m) {
       if (descs[m].uncompressed) continue;
-      mb_copy_bits(B.out_words, mb_out_bit[m], B.header_words + (size_t)m * kHeaderWords, results[m].header_bits);
+      mb_copy_bits(B.out_words, mb_out_bit[m], B.header_words + (size_t)m * B.header_stride, results[m].header_bits);
     }
     for (const RawCopy& rc : copies) dev_d2d((uint8_t*)B.out_words + rc.dst_byte, text + rc.src_pos, rc.bytes);
     if (!bits.pieces.empty()) {

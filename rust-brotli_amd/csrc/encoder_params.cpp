@@ -155,8 +155,9 @@ void ChooseHasher(EncoderParams* params) {
 
 bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
-  if (p.quality < 5 || p.quality > 9) {
-    why = "only qualities 5..9 (H5/H5q5/H6/H9 greedy path) are implemented on the device in this build";
+  if (p.quality < 5 || p.quality > 11 || (p.quality > 9 && !p.q9_5)) {
+    why = "only qualities 5..9 and \"9.5\" (BROTLI_PARAM_Q9_5 with quality 10: the greedy H9 path behind the quality >= 10 meta-block "
+          "builder) are implemented on the device in this build";
   } else if (p.hasher.type != 5 && p.hasher.type != 6 && p.hasher.type != 9) {
     why = "hasher type not implemented on the device (lgwin <= 16 at quality 5..8 selects the reference's H6 fallback with 256-deep rings)";
   } else if (p.hasher.block_bits > 8) {

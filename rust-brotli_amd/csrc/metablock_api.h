@@ -10,6 +10,8 @@
 namespace brotli_mi355x {
 
 struct MbBuffers;  // metablock_items.h
+struct HqSplitJob;    // metablock_hq.h
+struct HqClusterJob;
 
 static constexpr uint32_t kContextStatsWords = 512;  // per meta-block: [0..9) bigram prefix histogram
                                                       // (encode.rs:1885-1918), [16..48) combined 5-bit histogram,
@@ -38,6 +40,17 @@ void mb_write_headers(const MbBuffers& B);
 void mb_symbol_bits(const MbBuffers& B, void* scan_scratch);
 void mb_emit(const MbBuffers& B);
 void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits);
+
+// ---- quality >= 10 (metablock_hq.h; row b10).  Order of a call: census + distance parameters (results: hq_*), symbol
+// streams, FindBlocks iterations (jobs[].num_blocks), ClusterBlocks (the splits), context histograms, context-map
+// clustering (histogram rows + maps + num_histos); the code / header / emission kernels above take it from there.
+void mb_hq_utf8_census(const MbBuffers& B);
+void mb_hq_distance_params(const MbBuffers& B, uint32_t* histo_scratch_dev /* n_mb x 544 */);
+void mb_hq_gather_symbols(const MbBuffers& B);
+void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs);
+void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs);
+void mb_hq_context_histograms(const MbBuffers& B);
+void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs);
 
 }  // namespace brotli_mi355x
 #endif

@@ -1,0 +1,917 @@
+// metablock_hq.h -- the quality >= 10 meta-block builder as device work items.
+//
+// What the reference does behind the LZ77 stage at quality 10 / 11 (BrotliBuildMetaBlock, metablock.rs:133-307):
+//   * a search over the distance parameters (npostfix, ndirect) by the cost of the distance symbols (:88-131, 160-230),
+//   * BrotliSplitBlock (block_splitter.rs:840-929): for literals, commands and distances an iterated "assign every symbol
+//     to the cheapest of up to 100 entropy codes with a block-switch penalty" (FindBlocks, a Viterbi pass, :232-350) seeded
+//     from random samples (:139-222), then ClusterBlocks (:402-688),
+//   * context histograms (histogram.rs:465-534) and BrotliClusterHistograms (cluster.rs:353-465) for the literal and
+//     distance context maps, all priced with BrotliPopulationCost (bit_cost.rs:76-211),
+// everything in f32, left to right.  The items below restate that arithmetic operation by operation (tolerance zero: the
+// stream must equal the oracle's byte for byte).  This first device slice runs every sequential algorithm on ONE lane per
+// (meta-block, kind) -- the same code the CPU emulation runs, so that the emulation build is evidence for the device
+// build -- and only the embarrassingly parallel passes (symbol gathering, context histograms) over all lanes.
+// The lane-parallel forms (lane k = entropy code k in FindBlocks, one wave per candidate pair in the clustering) are
+// the next step.
+#ifndef BROTLI_MI355X_METABLOCK_HQ_H_
+#define BROTLI_MI355X_METABLOCK_HQ_H_
+
+#include "metablock_items.h"
+
+namespace brotli_mi355x {
+
+static constexpr uint32_t kHqMaxAlphabet = 704;
+static constexpr uint32_t kHqBatch = 64;            // HISTOGRAMS_PER_BATCH (block_splitter.rs) / max_input_histograms (cluster.rs)
+static constexpr uint32_t kHqBatchPairs = 2048;     // 64 * 64 / 2
+
+// a set of histograms: rows of `len` counters, the total and the cached bit cost of each
+struct HqHistos {
+  uint32_t* data;
+  uint32_t* total;
+  float* cost;
+  uint32_t len;
+  BR_DEV uint32_t* row(uint32_t i) const { return data + (size_t)i * len; }
+};
+
+struct HqPair {  // HistogramPair, cluster.rs:16-31
+  uint32_t idx1, idx2;
+  float cost_combo, cost_diff;
+};
+
+// One (meta-block, kind) splitting job.  Host fills the sizes and the scratch pointers; the device fills num_blocks
+// (after FindBlocks) and, through MbBuffers, the final split.
+struct HqSplitJob {
+  uint32_t m, kind;
+  uint32_t length;          // symbols
+  uint32_t alphabet;        // 256 / 704 / 544
+  uint32_t num_histograms;  // length / symbols_per_histogram + 1, capped (block_splitter.rs:700-708)
+  uint32_t stride;          // sampling stride (70 literals, 40 commands / distances)
+  uint32_t iters;           // 3 below quality 11, else 10
+  float block_switch_cost;
+  const uint16_t* data;
+  uint8_t* block_ids;       // [length]
+  uint32_t* histo_data;     // [num_histograms + 1][alphabet] (the last row is the sample of RefineEntropyCodes)
+  uint32_t* histo_total;    // [num_histograms + 1]
+  float* insert_cost;       // [alphabet][num_histograms]
+  float* cost;              // [bitmaplen * 8]
+  uint8_t* switch_signal;   // [length][bitmaplen]
+  uint16_t* new_id;         // [num_histograms]
+  uint32_t num_blocks;      // out of phase 1
+  uint32_t pad;
+  // ---- phase 2 (ClusterBlocks), sized by num_blocks
+  uint32_t* histogram_symbols;  // [num_blocks]
+  uint32_t* block_lengths;      // [num_blocks]
+  uint32_t* batch_data;         // [64 + 2][alphabet]: the batch, then the two scratch histograms
+  uint32_t* batch_total;        // [64 + 2]
+  float* batch_cost;            // [64 + 2]
+  uint32_t* all_data;           // [num_blocks][alphabet]
+  uint32_t* all_total;          // [num_blocks]
+  float* all_cost;              // [num_blocks]
+  uint32_t* cluster_size;       // [num_blocks]
+  uint32_t* clusters;           // [num_blocks]
+  uint32_t* new_index;          // [num_blocks]
+  HqPair* pairs;                // [max(2048, min(64 n, n / 2 * n)) + 1]
+};
+
+// One context-map clustering job (literal or distance contexts of one meta-block), cluster.rs:353-465
+struct HqClusterJob {
+  uint32_t m, kind;        // kind: kSplitLiteral or kSplitDistance
+  uint32_t in_size;        // num_types << 6 (literal) or << 2 (distance); num_types when context modelling is disabled
+  uint32_t len;            // 256 / 544
+  uint32_t expand64;       // literal context modelling disabled: the map of `num_types` entries is spread over 64 contexts each
+  uint32_t pad;
+  const uint32_t* in_data;  // [in_size][len]
+  uint32_t* in_total;       // [in_size]
+  uint32_t* out_data;       // [in_size + 2][len] (two scratch rows at the end)
+  uint32_t* out_total;      // [in_size + 2]
+  float* out_cost;          // [in_size + 2]
+  uint32_t* cluster_size;   // [in_size]
+  uint32_t* clusters;       // [in_size]
+  uint32_t* symbols;        // [in_size]
+  uint32_t* new_index;      // [in_size]
+  uint32_t* reindex_data;   // [min(in_size, 256)][len]
+  uint32_t* reindex_total;  // [min(in_size, 256)]
+  float* reindex_cost;      // [min(in_size, 256)]
+  HqPair* pairs;            // [max(2048, 64 * in_size) + 1]
+};
+
+// ------------------------------------------------------------------------------------------------ histogram helpers
+BR_DEV void hq_clear(const HqHistos& h, uint32_t i) {  // HistogramClear, histogram.rs:391-399
+  uint32_t* r = h.row(i);
+  for (uint32_t k = 0; k < h.len; ++k) r[k] = 0;
+  h.total[i] = 0;
+  h.cost[i] = 3.402e+38f;
+}
+BR_DEV void hq_copy(const HqHistos& d, uint32_t di, const HqHistos& s, uint32_t si) {
+  uint32_t* dr = d.row(di);
+  const uint32_t* sr = s.row(si);
+  for (uint32_t k = 0; k < d.len; ++k) dr[k] = sr[k];
+  d.total[di] = s.total[si];
+  d.cost[di] = s.cost[si];
+}
+BR_DEV void hq_add(const HqHistos& d, uint32_t di, const HqHistos& s, uint32_t si) {  // HistogramAddHistogram
+  uint32_t* dr = d.row(di);
+  const uint32_t* sr = s.row(si);
+  d.total[di] += s.total[si];
+  for (uint32_t k = 0; k < d.len; ++k) dr[k] += sr[k];
+}
+
+// BrotliPopulationCost, bit_cost.rs:76-211 (the build without "vector_scratch_space")
+BR_DEV float hq_population_cost(const EntropyTables& et, const uint32_t* data, uint32_t data_size, uint32_t total_count) {
+  const float kOneSymbolHistogramCost = 12.0f, kTwoSymbolHistogramCost = 20.0f, kThreeSymbolHistogramCost = 28.0f,
+              kFourSymbolHistogramCost = 37.0f;
+  if (total_count == 0) return kOneSymbolHistogramCost;
+  uint32_t count = 0;
+  uint32_t s[5] = {0, 0, 0, 0, 0};
+  for (uint32_t i = 0; i < data_size; ++i) {
+    if (data[i] > 0) {
+      s[count] = i;
+      count++;
+      if (count > 4) break;
+    }
+  }
+  if (count == 1) return kOneSymbolHistogramCost;
+  if (count == 2) return kTwoSymbolHistogramCost + (float)total_count;
+  if (count == 3) {
+    const uint32_t h0 = data[s[0]], h1 = data[s[1]], h2 = data[s[2]];
+    const uint32_t m01 = h0 > h1 ? h0 : h1;
+    const uint32_t hmax = m01 > h2 ? m01 : h2;
+    return kThreeSymbolHistogramCost + (float)(2u * (h0 + h1 + h2)) - (float)hmax;
+  }
+  if (count == 4) {
+    uint32_t h[4];
+    for (int i = 0; i < 4; ++i) h[i] = data[s[i]];
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j)
+        if (h[j] > h[i]) {
+          const uint32_t t = h[j];
+          h[j] = h[i];
+          h[i] = t;
+        }
+    const uint32_t h23 = h[2] + h[3];
+    const uint32_t hmax = h23 > h[0] ? h23 : h[0];
+    return kFourSymbolHistogramCost + (float)(3u * h23) + (float)(2u * (h[0] + h[1])) - (float)hmax;
+  }
+  float bits = 0.0f;
+  uint32_t max_depth = 1;
+  uint32_t depth_histo[18];
+  for (int i = 0; i < 18; ++i) depth_histo[i] = 0;
+  const float log2total = br_fast_log2(et, total_count);
+  uint32_t reps = 0;
+  for (uint32_t i = 0; i < data_size; ++i) {
+    const uint32_t histo = data[i];
+    if (histo != 0) {
+      if (reps != 0) {
+        if (reps < 3) {
+          depth_histo[0] += reps;
+        } else {
+          reps -= 2;
+          while (reps > 0) {
+            depth_histo[17] += 1;
+            bits += 3.0f;
+            reps >>= 3;
+          }
+        }
+        reps = 0;
+      }
+      const float log2p = log2total - et.logs_16[histo & 0xffffu];
+      const float dd = log2p + 0.5f;
+      uint32_t depth = dd > 0.0f ? (uint32_t)dd : 0u;  // `as usize` saturates at 0
+      bits += (float)histo * log2p;
+      if (depth > 15) depth = 15;
+      if (depth > max_depth) max_depth = depth;
+      depth_histo[depth] += 1;
+    } else {
+      reps += 1;
+    }
+  }
+  bits += (float)(18 + 2 * max_depth);
+  bits += br_bits_entropy(et, depth_histo, 18);
+  return bits;
+}
+BR_DEV float hq_cost_of(const EntropyTables& et, const HqHistos& h, uint32_t i) { return hq_population_cost(et, h.row(i), h.len, h.total[i]); }
+
+// ------------------------------------------------------------------------------------------------ cluster.rs
+BR_DEV float hq_cluster_cost_diff(const EntropyTables& et, uint32_t size_a, uint32_t size_b) {  // :33-39
+  const uint32_t size_c = size_a + size_b;
+  return (float)size_a * br_fast_log2(et, size_a) + (float)size_b * br_fast_log2(et, size_b) - (float)size_c * br_fast_log2(et, size_c);
+}
+BR_DEV bool hq_pair_is_less(const HqPair& p1, const HqPair& p2) {  // :41-48
+  if (p1.cost_diff != p2.cost_diff) return p1.cost_diff > p2.cost_diff;
+  return (uint32_t)(p1.idx2 - p1.idx1) > (uint32_t)(p2.idx2 - p2.idx1);
+}
+
+// BrotliCompareAndPushToQueue, cluster.rs:52-121.  `tmp` = index of a scratch row of `out`.
+BR_DEV void hq_compare_and_push(const EntropyTables& et, const HqHistos& out, const uint32_t* cluster_size, uint32_t idx1, uint32_t idx2,
+                                uint32_t max_num_pairs, HqPair* pairs, uint32_t* num_pairs, uint32_t tmp) {
+  if (idx1 == idx2) return;
+  if (idx2 < idx1) {
+    const uint32_t t = idx2;
+    idx2 = idx1;
+    idx1 = t;
+  }
+  bool is_good_pair = false;
+  HqPair p;
+  p.idx1 = idx1;
+  p.idx2 = idx2;
+  p.cost_combo = 0.0f;
+  p.cost_diff = 0.5f * hq_cluster_cost_diff(et, cluster_size[idx1], cluster_size[idx2]);
+  p.cost_diff -= out.cost[idx1];
+  p.cost_diff -= out.cost[idx2];
+  if (out.total[idx1] == 0) {
+    p.cost_combo = out.cost[idx2];
+    is_good_pair = true;
+  } else if (out.total[idx2] == 0) {
+    p.cost_combo = out.cost[idx1];
+    is_good_pair = true;
+  } else {
+    float threshold = 1e38f;
+    if (*num_pairs != 0) threshold = pairs[0].cost_diff > 0.0f ? pairs[0].cost_diff : 0.0f;
+    hq_copy(out, tmp, out, idx1);
+    hq_add(out, tmp, out, idx2);
+    const float cost_combo = hq_cost_of(et, out, tmp);
+    if (cost_combo < threshold - p.cost_diff) {
+      p.cost_combo = cost_combo;
+      is_good_pair = true;
+    }
+  }
+  if (is_good_pair) {
+    p.cost_diff += p.cost_combo;
+    if (*num_pairs > 0 && hq_pair_is_less(pairs[0], p)) {
+      if (*num_pairs < max_num_pairs) {
+        pairs[*num_pairs] = pairs[0];
+        ++*num_pairs;
+      }
+      pairs[0] = p;
+    } else if (*num_pairs < max_num_pairs) {
+      pairs[*num_pairs] = p;
+      ++*num_pairs;
+    }
+  }
+}
+
+// BrotliHistogramCombine, cluster.rs:123-236
+BR_DEV uint32_t hq_histogram_combine(const EntropyTables& et, const HqHistos& out, uint32_t* cluster_size, uint32_t* symbols, uint32_t* clusters,
+                                     HqPair* pairs, uint32_t num_clusters, uint32_t symbols_size, uint32_t max_clusters,
+                                     uint32_t max_num_pairs, uint32_t tmp) {
+  float cost_diff_threshold = 0.0f;
+  uint32_t min_cluster_size = 1;
+  uint32_t num_pairs = 0;
+  for (uint32_t i1 = 0; i1 < num_clusters; ++i1)
+    for (uint32_t i2 = i1 + 1; i2 < num_clusters; ++i2)
+      hq_compare_and_push(et, out, cluster_size, clusters[i1], clusters[i2], max_num_pairs, pairs, &num_pairs, tmp);
+  while (num_clusters > min_cluster_size) {
+    if (pairs[0].cost_diff >= cost_diff_threshold) {
+      cost_diff_threshold = 1e38f;
+      min_cluster_size = max_clusters;
+      continue;
+    }
+    const uint32_t best_idx1 = pairs[0].idx1, best_idx2 = pairs[0].idx2;
+    hq_add(out, best_idx1, out, best_idx2);
+    out.cost[best_idx1] = pairs[0].cost_combo;
+    cluster_size[best_idx1] += cluster_size[best_idx2];
+    for (uint32_t i = 0; i < symbols_size; ++i)
+      if (symbols[i] == best_idx2) symbols[i] = best_idx1;
+    for (uint32_t i = 0; i < num_clusters; ++i) {
+      if (clusters[i] == best_idx2) {
+        for (uint32_t k = i; k + 1 < num_clusters; ++k) clusters[k] = clusters[k + 1];
+        break;
+      }
+    }
+    --num_clusters;
+    {
+      uint32_t copy_to_idx = 0;
+      for (uint32_t i = 0; i < num_pairs; ++i) {
+        const HqPair p = pairs[i];
+        if (p.idx1 == best_idx1 || p.idx2 == best_idx1 || p.idx1 == best_idx2 || p.idx2 == best_idx2) continue;
+        if (hq_pair_is_less(pairs[0], p)) {
+          const HqPair front = pairs[0];
+          pairs[0] = p;
+          pairs[copy_to_idx] = front;
+        } else {
+          pairs[copy_to_idx] = p;
+        }
+        ++copy_to_idx;
+      }
+      num_pairs = copy_to_idx;
+    }
+    for (uint32_t i = 0; i < num_clusters; ++i)
+      hq_compare_and_push(et, out, cluster_size, best_idx1, clusters[i], max_num_pairs, pairs, &num_pairs, tmp);
+  }
+  return num_clusters;
+}
+
+// BrotliHistogramBitCostDistance, cluster.rs:238-254; `tmp` = scratch row of `cand_set`
+BR_DEV float hq_bit_cost_distance(const EntropyTables& et, const HqHistos& h, uint32_t hi, const HqHistos& cand_set, uint32_t ci, uint32_t tmp) {
+  if (h.total[hi] == 0) return 0.0f;
+  {
+    uint32_t* t = cand_set.row(tmp);
+    const uint32_t* a = h.row(hi);
+    const uint32_t* b = cand_set.row(ci);
+    for (uint32_t k = 0; k < h.len; ++k) t[k] = a[k] + b[k];
+    cand_set.total[tmp] = h.total[hi] + cand_set.total[ci];
+  }
+  return hq_cost_of(et, cand_set, tmp) - cand_set.cost[ci];
+}
+
+// ------------------------------------------------------------------------------------------------ block_splitter.rs
+BR_DEV uint32_t hq_my_rand(uint32_t* seed) {  // :131-137
+  *seed = *seed * 16807u;
+  if (*seed == 0) *seed = 1;
+  return *seed;
+}
+BR_DEV float hq_bit_cost(const EntropyTables& et, uint32_t count) { return count == 0 ? -2.0f : br_fast_log2(et, count); }  // :224-230
+
+// InitialEntropyCodes + RefineEntropyCodes, block_splitter.rs:139-222
+BR_DEV void hq_seed_entropy_codes(const HqSplitJob& J, const HqHistos& H) {
+  const uint16_t* data = J.data;
+  const uint32_t length = J.length, stride = J.stride, nh = J.num_histograms;
+  {
+    uint32_t seed = 7;
+    const uint32_t block_length = length / nh;
+    for (uint32_t i = 0; i < nh; ++i) hq_clear(H, i);
+    for (uint32_t i = 0; i < nh; ++i) {
+      uint32_t pos = (uint32_t)((uint64_t)length * i / nh);
+      if (i != 0) pos += hq_my_rand(&seed) % block_length;
+      if (pos + stride >= length) pos = length - stride - 1;
+      H.total[i] += stride;
+      uint32_t* r = H.row(i);
+      for (uint32_t k = 0; k < stride; ++k) r[data[pos + k]]++;
+    }
+  }
+  {
+    uint32_t iters = (uint32_t)(2ull * length / stride) + 100u;  // kIterMulForRefining, kMinItersForRefining
+    uint32_t seed = 7;
+    iters = (iters + nh - 1) / nh * nh;
+    for (uint32_t iter = 0; iter < iters; ++iter) {
+      // RandomSample (:167-188) straight into the target histogram (sample + add = add)
+      uint32_t pos, n = stride;
+      if (stride >= length) {
+        pos = 0;
+        n = length;
+      } else {
+        pos = hq_my_rand(&seed) % (length - stride + 1);
+      }
+      const uint32_t t = iter % nh;
+      H.total[t] += n;
+      uint32_t* r = H.row(t);
+      for (uint32_t k = 0; k < n; ++k) r[data[pos + k]]++;
+    }
+  }
+}
+
+// FindBlocks, block_splitter.rs:232-350 (with update_cost_and_signal :46-82 over the padded lanes)
+BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, const HqHistos& H, uint32_t num_histograms) {
+  const uint16_t* data = J.data;
+  const uint32_t length = J.length, data_size = J.alphabet;
+  uint8_t* block_id = J.block_ids;
+  const uint32_t bitmaplen = (num_histograms + 7) >> 3;
+  const uint32_t padded = bitmaplen << 3;
+  if (num_histograms == 0) return 0;
+  if (num_histograms <= 1) {
+    for (uint32_t i = 0; i < length; ++i) block_id[i] = 0;
+    return 1;
+  }
+  float* insert_cost = J.insert_cost;
+  float* cost = J.cost;
+  uint8_t* switch_signal = J.switch_signal;
+  for (uint32_t i = 0; i < data_size * num_histograms; ++i) insert_cost[i] = 0.0f;
+  for (uint32_t i = 0; i < num_histograms; ++i) insert_cost[i] = br_fast_log2(et, H.total[i]);
+  for (uint32_t i = data_size; i != 0;) {
+    --i;
+    for (uint32_t j = 0; j < num_histograms; ++j) insert_cost[i * num_histograms + j] = insert_cost[j] - hq_bit_cost(et, H.row(j)[i]);
+  }
+  for (uint32_t i = 0; i < padded; ++i) cost[i] = 0.0f;
+  for (size_t i = 0; i < (size_t)length * bitmaplen; ++i) switch_signal[i] = 0;
+  for (uint32_t byte_ix = 0; byte_ix < length; ++byte_ix) {
+    const size_t ix = (size_t)byte_ix * bitmaplen;
+    const float* ic = insert_cost + (size_t)data[byte_ix] * num_histograms;
+    float min_cost = 1e38f;
+    float block_switch_cost = J.block_switch_cost;
+    uint8_t best = block_id[byte_ix];
+    for (uint32_t k = 0; k < num_histograms; ++k) {
+      const float c = cost[k] + ic[k];
+      cost[k] = c;
+      if (c < min_cost) {
+        min_cost = c;
+        best = (uint8_t)k;
+      }
+    }
+    block_id[byte_ix] = best;
+    if (byte_ix < 2000) block_switch_cost *= (0.77f + 0.07f * (float)byte_ix / 2000.0f);
+    for (uint32_t k = 0; k < padded; ++k) {
+      const float d = cost[k] - min_cost;
+      if (d >= block_switch_cost) switch_signal[ix + (k >> 3)] |= (uint8_t)(1u << (k & 7));
+      cost[k] = d < block_switch_cost ? d : block_switch_cost;
+    }
+  }
+  uint32_t num_blocks = 1;
+  {
+    uint32_t byte_ix = length - 1;
+    size_t ix = (size_t)byte_ix * bitmaplen;
+    uint8_t cur_id = block_id[byte_ix];
+    while (byte_ix > 0) {
+      const uint8_t mask = (uint8_t)(1u << (cur_id & 7));
+      --byte_ix;
+      ix -= bitmaplen;
+      if ((switch_signal[ix + (cur_id >> 3)] & mask) != 0 && cur_id != block_id[byte_ix]) {
+        cur_id = block_id[byte_ix];
+        ++num_blocks;
+      }
+      block_id[byte_ix] = cur_id;
+    }
+  }
+  return num_blocks;
+}
+
+// phase 1 of SplitByteVector (block_splitter.rs:690-838): seeds + the FindBlocks / RemapBlockIds / BuildBlockHistograms
+// iterations.  Leaves block_ids and J.num_blocks; 0 blocks = "no symbols", 1 with length < 128 = "one block, no search".
+BR_DEV void hq_item_find_blocks(const EntropyTables& et, HqSplitJob& J) {
+  if (J.length == 0) {
+    J.num_blocks = 0;
+    return;
+  }
+  if (J.length < 128) {  // kMinLengthForBlockSplitting
+    J.num_blocks = 1;
+    for (uint32_t i = 0; i < J.length; ++i) J.block_ids[i] = 0;
+    return;
+  }
+  HqHistos H;
+  H.data = J.histo_data;
+  H.total = J.histo_total;
+  // (the bit-cost slot is never read for the block histograms: hq_clear gets a harmless target, the front of insert_cost,
+  // which FindBlocks initialises before it reads it)
+  H.cost = J.insert_cost;
+  H.len = J.alphabet;
+  hq_seed_entropy_codes(J, H);
+  uint32_t num_histograms = J.num_histograms;
+  uint32_t num_blocks = 0;
+  for (uint32_t it = 0; it < J.iters; ++it) {
+    num_blocks = hq_find_blocks(et, J, H, num_histograms);
+    // RemapBlockIds, :352-378
+    {
+      const uint16_t kInvalidId = 256;
+      uint16_t next_id = 0;
+      for (uint32_t i = 0; i < num_histograms; ++i) J.new_id[i] = kInvalidId;
+      for (uint32_t i = 0; i < J.length; ++i)
+        if (J.new_id[J.block_ids[i]] == kInvalidId) J.new_id[J.block_ids[i]] = next_id++;
+      for (uint32_t i = 0; i < J.length; ++i) J.block_ids[i] = (uint8_t)J.new_id[J.block_ids[i]];
+      num_histograms = next_id;
+    }
+    // BuildBlockHistograms, :380-400
+    for (uint32_t i = 0; i < num_histograms; ++i) hq_clear(H, i);
+    for (uint32_t i = 0; i < J.length; ++i) {
+      const uint32_t b = J.block_ids[i];
+      H.row(b)[J.data[i]]++;
+      H.total[b]++;
+    }
+  }
+  J.num_blocks = num_blocks;
+}
+
+// phase 2: ClusterBlocks, block_splitter.rs:402-688.  Writes the split of (m, kind): types, lengths, starts, counts.
+BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
+  const EntropyTables& et = B.et;
+  const MbDesc& d = B.descs[J.m];
+  MbResult& r = B.results[J.m];
+  const uint32_t kind = J.kind;
+  uint8_t* types = B.block_types[kind] + d.block_base[kind];
+  uint32_t* lengths = B.block_lengths[kind] + d.block_base[kind];
+  uint32_t* starts = B.block_start[kind] + d.block_base[kind];
+  if (J.num_blocks == 0) {  // no symbols: one type, no blocks
+    r.num_types[kind] = 1;
+    r.num_blocks[kind] = 0;
+    starts[0] = 0;
+    return;
+  }
+  if (J.length < 128) {
+    r.num_types[kind] = 1;
+    r.num_blocks[kind] = 1;
+    types[0] = 0;
+    lengths[0] = J.length;
+    starts[0] = 0;
+    starts[1] = J.length;
+    return;
+  }
+  const uint16_t* data = J.data;
+  const uint32_t length = J.length, num_blocks = J.num_blocks, len = J.alphabet;
+  const uint8_t* block_ids = J.block_ids;
+  uint32_t* histogram_symbols = J.histogram_symbols;
+  uint32_t* block_lengths = J.block_lengths;
+  for (uint32_t i = 0; i < num_blocks; ++i) block_lengths[i] = 0;
+  {
+    uint32_t block_idx = 0;
+    for (uint32_t i = 0; i < length; ++i) {
+      block_lengths[block_idx]++;
+      if (i + 1 == length || block_ids[i] != block_ids[i + 1]) ++block_idx;
+    }
+  }
+  HqHistos batch;  // 64 histograms + scratch rows 64, 65
+  batch.data = J.batch_data;
+  batch.total = J.batch_total;
+  batch.cost = J.batch_cost;
+  batch.len = len;
+  HqHistos all;
+  all.data = J.all_data;
+  all.total = J.all_total;
+  all.cost = J.all_cost;
+  all.len = len;
+  uint32_t* cluster_size = J.cluster_size;
+  uint32_t all_size = 0;
+  uint32_t num_clusters = 0;
+  uint32_t pos = 0;
+  uint32_t sizes[kHqBatch], new_clusters[kHqBatch], symbols[kHqBatch], remap[kHqBatch];
+  for (uint32_t i = 0; i < kHqBatch; ++i) sizes[i] = new_clusters[i] = symbols[i] = remap[i] = 0;
+  for (uint32_t i = 0; i < num_blocks; i += kHqBatch) {
+    const uint32_t num_to_combine = num_blocks - i < kHqBatch ? num_blocks - i : kHqBatch;
+    for (uint32_t j = 0; j < num_to_combine; ++j) {
+      hq_clear(batch, j);
+      uint32_t* row = batch.row(j);
+      for (uint32_t k = 0; k < block_lengths[i + j]; ++k) row[data[pos++]]++;
+      batch.total[j] = block_lengths[i + j];
+      batch.cost[j] = hq_cost_of(et, batch, j);
+      new_clusters[j] = j;
+      symbols[j] = j;
+      sizes[j] = 1;
+    }
+    const uint32_t num_new_clusters =
+        hq_histogram_combine(et, batch, sizes, symbols, new_clusters, J.pairs, num_to_combine, num_to_combine, kHqBatch, kHqBatchPairs, kHqBatch);
+    for (uint32_t j = 0; j < num_new_clusters; ++j) {
+      hq_copy(all, all_size, batch, new_clusters[j]);
+      cluster_size[all_size] = sizes[new_clusters[j]];
+      all_size++;
+      remap[new_clusters[j]] = j;
+    }
+    for (uint32_t j = 0; j < num_to_combine; ++j) histogram_symbols[i + j] = num_clusters + remap[symbols[j]];
+    num_clusters += num_new_clusters;
+  }
+  uint32_t max_num_pairs = 64u * num_clusters;
+  {
+    const uint64_t alt = (uint64_t)(num_clusters / 2) * num_clusters;
+    if (alt < max_num_pairs) max_num_pairs = (uint32_t)alt;
+  }
+  uint32_t* clusters = J.clusters;
+  for (uint32_t i = 0; i < num_clusters; ++i) clusters[i] = i;
+  // the scratch row of `all` for the pair evaluation: one past the used rows would overrun when every block kept its own
+  // cluster, so the two spare rows of the batch set serve -- through a view that shares `all`'s rows up to all_size
+  // (hq_compare_and_push only touches out.row(tmp), out.total[tmp], out.cost[tmp])
+  const uint32_t tmp_all = num_blocks;  // J.all_* are allocated with num_blocks + 2 rows
+  const uint32_t num_final_clusters =
+      hq_histogram_combine(et, all, cluster_size, histogram_symbols, clusters, J.pairs, num_clusters, num_blocks, 256, max_num_pairs, tmp_all);
+  uint32_t* new_index = J.new_index;
+  const uint32_t kInvalidIndex = 0xffffffffu;
+  for (uint32_t i = 0; i < num_clusters; ++i) new_index[i] = kInvalidIndex;
+  pos = 0;
+  {
+    uint32_t next_index = 0;
+    const uint32_t hrow = kHqBatch;  // scratch row of the batch set holds the histogram of the block
+    for (uint32_t i = 0; i < num_blocks; ++i) {
+      hq_clear(batch, hrow);
+      uint32_t* row = batch.row(hrow);
+      for (uint32_t j = 0; j < block_lengths[i]; ++j) row[data[pos++]]++;
+      batch.total[hrow] = block_lengths[i];
+      uint32_t best_out = i == 0 ? histogram_symbols[0] : histogram_symbols[i - 1];
+      float best_bits = hq_bit_cost_distance(et, batch, hrow, all, best_out, tmp_all);
+      for (uint32_t j = 0; j < num_final_clusters; ++j) {
+        const float cur_bits = hq_bit_cost_distance(et, batch, hrow, all, clusters[j], tmp_all);
+        if (cur_bits < best_bits) {
+          best_bits = cur_bits;
+          best_out = clusters[j];
+        }
+      }
+      histogram_symbols[i] = best_out;
+      if (new_index[best_out] == kInvalidIndex) new_index[best_out] = next_index++;
+    }
+  }
+  {
+    uint32_t cur_length = 0, block_idx = 0, start = 0;
+    uint8_t max_type = 0;
+    for (uint32_t i = 0; i < num_blocks; ++i) {
+      cur_length += block_lengths[i];
+      if (i + 1 == num_blocks || histogram_symbols[i] != histogram_symbols[i + 1]) {
+        const uint8_t id = (uint8_t)new_index[histogram_symbols[i]];
+        types[block_idx] = id;
+        lengths[block_idx] = cur_length;
+        starts[block_idx] = start;
+        start += cur_length;
+        if (id > max_type) max_type = id;
+        cur_length = 0;
+        ++block_idx;
+      }
+    }
+    starts[block_idx] = start;
+    r.num_blocks[kind] = block_idx;
+    r.num_types[kind] = (uint32_t)max_type + 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ metablock.rs
+// CommandRestoreDistanceCode, command.rs:84-100
+BR_DEV uint32_t hq_restore_distance_code(const Command& c, uint32_t ndirect, uint32_t npostfix) {
+  const uint32_t dcode = c.dist_prefix_ & 0x3ffu;
+  if (dcode < 16 + ndirect) return dcode;
+  const uint32_t nbits = (uint32_t)(c.dist_prefix_ >> 10);
+  const uint32_t extra = c.dist_extra_;
+  const uint32_t postfix_mask = (1u << npostfix) - 1;
+  const uint32_t hcode = (dcode - ndirect - 16u) >> npostfix;
+  const uint32_t lcode = (dcode - ndirect - 16u) & postfix_mask;
+  const uint32_t offset = ((2u + (hcode & 1)) << nbits) - 4u;
+  return ((offset + extra) << npostfix) + lcode + ndirect + 16u;
+}
+// PrefixEncodeCopyDistance, command.rs:134-173
+BR_DEV void hq_prefix_encode_distance(uint32_t distance_code, uint32_t ndirect, uint32_t npostfix, uint16_t* code, uint32_t* extra_bits) {
+  if (distance_code < 16 + ndirect) {
+    *code = (uint16_t)distance_code;
+    *extra_bits = 0;
+    return;
+  }
+  const uint64_t dist = (1ull << (npostfix + 2)) + ((uint64_t)distance_code - 16 - ndirect);
+  const uint32_t bucket = (63u ^ (uint32_t)__builtin_clzll(dist)) - 1;
+  const uint64_t postfix_mask = (1u << npostfix) - 1;
+  const uint64_t postfix = dist & postfix_mask;
+  const uint64_t prefix = (dist >> bucket) & 1;
+  const uint64_t offset = (2 + prefix) << bucket;
+  const uint64_t nbits = bucket - npostfix;
+  *code = (uint16_t)((nbits << 10) | (16 + ndirect + ((2 * (nbits - 1) + prefix) << npostfix) + postfix));
+  *extra_bits = (uint32_t)((dist - offset) >> npostfix);
+}
+// BrotliInitDistanceParams without large_window, encode.rs:519-553
+BR_DEV uint32_t hq_distance_alphabet_size(uint32_t npostfix, uint32_t ndirect) { return 16 + ndirect + (24u << (npostfix + 1)); }
+BR_DEV uint32_t hq_max_distance(uint32_t npostfix, uint32_t ndirect) { return ndirect + (1u << (24 + npostfix + 2)) - (1u << (npostfix + 2)); }
+
+// ComputeDistanceCost, metablock.rs:88-131.  `histo`: 544 counters of scratch.
+BR_DEV bool hq_distance_cost(const MbBuffers& B, const MbDesc& d, uint32_t new_npostfix, uint32_t new_ndirect, uint32_t* histo, double* cost) {
+  const bool equal_params = d.dist_postfix_bits == new_npostfix && d.num_direct_distance_codes == new_ndirect;
+  const uint32_t new_max_distance = hq_max_distance(new_npostfix, new_ndirect);
+  double extra_bits = 0.0;
+  uint32_t total = 0;
+  for (uint32_t i = 0; i < kNumDistanceHistoSymbols; ++i) histo[i] = 0;
+  for (uint32_t c = d.cmd_offset; c < d.cmd_offset + d.n_cmds; ++c) {
+    const Command cmd = B.cmds[c];
+    if (!br_command_has_distance(cmd)) continue;
+    uint16_t dist_prefix;
+    uint32_t dist_extra;
+    if (equal_params) {
+      dist_prefix = cmd.dist_prefix_;
+    } else {
+      const uint32_t distance = hq_restore_distance_code(cmd, d.num_direct_distance_codes, d.dist_postfix_bits);
+      if (distance > new_max_distance) return false;
+      hq_prefix_encode_distance(distance, new_ndirect, new_npostfix, &dist_prefix, &dist_extra);
+    }
+    histo[dist_prefix & 0x3ffu]++;
+    total++;
+    extra_bits += (double)(dist_prefix >> 10);
+  }
+  *cost = (double)hq_population_cost(B.et, histo, kNumDistanceHistoSymbols, total) + extra_bits;
+  return true;
+}
+
+// the distance-parameter search of BrotliBuildMetaBlock (metablock.rs:160-240) + RecomputeDistancePrefixes (:62-86) on the
+// meta-block's own copy of the commands.  Result in MbResult::hq_postfix / hq_ndirect.
+BR_DEV void hq_item_distance_params(const MbBuffers& B, uint32_t m, uint32_t* histo) {
+  const MbDesc& d = B.descs[m];
+  MbResult& r = B.results[m];
+  uint32_t best_npostfix = d.dist_postfix_bits, best_ndirect = d.num_direct_distance_codes;
+  r.hq_postfix = best_npostfix;
+  r.hq_ndirect = best_ndirect;
+  if (d.uncompressed) return;
+  uint32_t ndirect_msb = 0;
+  bool check_orig = true;
+  double best_dist_cost = 1e99;
+  for (uint32_t npostfix = 0; npostfix <= 3; ++npostfix) {
+    while (ndirect_msb < 16) {
+      const uint32_t ndirect = ndirect_msb << npostfix;
+      double dist_cost = 0.0;
+      if (npostfix == d.dist_postfix_bits && ndirect == d.num_direct_distance_codes) check_orig = false;
+      const bool skip = !hq_distance_cost(B, d, npostfix, ndirect, histo, &dist_cost);
+      if (skip || dist_cost > best_dist_cost) break;
+      best_dist_cost = dist_cost;
+      best_npostfix = npostfix;
+      best_ndirect = ndirect;
+      ndirect_msb += 1;
+    }
+    ndirect_msb = ndirect_msb > 0 ? ndirect_msb - 1 : 0;
+    ndirect_msb /= 2;
+  }
+  if (check_orig) {
+    double dist_cost = 0.0;
+    hq_distance_cost(B, d, d.dist_postfix_bits, d.num_direct_distance_codes, histo, &dist_cost);
+    if (dist_cost < best_dist_cost) {
+      best_npostfix = d.dist_postfix_bits;
+      best_ndirect = d.num_direct_distance_codes;
+    }
+  }
+  r.hq_postfix = best_npostfix;
+  r.hq_ndirect = best_ndirect;
+  if (best_npostfix != d.dist_postfix_bits || best_ndirect != d.num_direct_distance_codes) {
+    for (uint32_t c = d.cmd_offset; c < d.cmd_offset + d.n_cmds; ++c) {
+      Command cmd = B.cmds_rw[c];
+      if (!br_command_has_distance(cmd)) continue;
+      const uint32_t code = hq_restore_distance_code(cmd, d.num_direct_distance_codes, d.dist_postfix_bits);
+      hq_prefix_encode_distance(code, best_ndirect, best_npostfix, &cmd.dist_prefix_, &cmd.dist_extra_);
+      B.cmds_rw[c] = cmd;
+    }
+  }
+}
+
+// BrotliIsMostlyUTF8 (utf8_util.rs:3-62) over the bytes ChooseContextMode really looks at (encode.rs:1357-1377 is handed
+// the ring buffer ALLOCATION, whose data start two bytes in: the census runs over the stream shifted by two; positions in
+// front of the stream read the zeroed slack).  Result: MbResult::hq_mostly_utf8.
+BR_DEV uint32_t hq_census_byte(const MbBuffers& B, const MbDesc& d, uint32_t i) {
+  const uint32_t p = d.start + i;  // the reference reads data_mo[p] = ring[p - 2] (a custom dictionary lies in the ring too)
+  return p >= 2 ? B.text[p - 2] : 0u;
+}
+BR_DEV void hq_item_utf8_census(const MbBuffers& B, uint32_t m) {
+  const MbDesc& d = B.descs[m];
+  const uint32_t length = d.end - d.start;
+  uint32_t size_utf8 = 0;
+  uint32_t i = 0;
+  while (i < length) {
+    const uint32_t size = length - i;
+    const uint32_t b0 = hq_census_byte(B, d, i);
+    // (bytes behind the meta-block's end are read from the buffer as they lie there: they are the stream's next bytes or,
+    // at the very end, whatever follows -- only looked at when size > 1 .. 3, i.e. never past `length`)
+    const uint32_t b1 = size > 1 ? hq_census_byte(B, d, i + 1) : 0u;
+    const uint32_t b2 = size > 2 ? hq_census_byte(B, d, i + 2) : 0u;
+    const uint32_t b3 = size > 3 ? hq_census_byte(B, d, i + 3) : 0u;
+    uint32_t bytes_read = 0;
+    int32_t symbol = 0;
+    if ((b0 & 0x80) == 0 && b0 > 0) {
+      symbol = (int32_t)b0;
+      bytes_read = 1;
+    }
+    if (bytes_read == 0 && size > 1 && (b0 & 0xe0) == 0xc0 && (b1 & 0xc0) == 0x80) {
+      symbol = (int32_t)(((b0 & 0x1f) << 6) | (b1 & 0x3f));
+      if (symbol > 0x7f) bytes_read = 2;
+    }
+    if (bytes_read == 0 && size > 2 && (b0 & 0xf0) == 0xe0 && (b1 & 0xc0) == 0x80 && (b2 & 0xc0) == 0x80) {
+      symbol = (int32_t)(((b0 & 0x0f) << 12) | ((b1 & 0x3f) << 6) | (b2 & 0x3f));
+      if (symbol > 0x7ff) bytes_read = 3;
+    }
+    if (bytes_read == 0 && size > 3 && (b0 & 0xf8) == 0xf0 && (b1 & 0xc0) == 0x80 && (b2 & 0xc0) == 0x80 && (b3 & 0xc0) == 0x80) {
+      symbol = (int32_t)(((b0 & 0x07) << 18) | ((b1 & 0x3f) << 12) | ((b2 & 0x3f) << 6) | (b3 & 0x3f));
+      if (symbol > 0xffff && symbol <= 0x10ffff) bytes_read = 4;
+    }
+    if (bytes_read == 0) {
+      symbol = (int32_t)(0x110000u | b0);
+      bytes_read = 1;
+    }
+    i += bytes_read;
+    if (symbol < 0x110000) size_utf8 += bytes_read;
+  }
+  B.results[m].hq_mostly_utf8 = (float)size_utf8 > 0.75f * (float)length ? 1u : 0u;
+}
+
+// ---- symbol streams of the three splitters (CopyLiteralsToByteArray etc., block_splitter.rs:97-129, 860-927)
+BR_DEV void hq_item_literal_symbol(const MbBuffers& B, uint32_t i) { B.hq_sym[kSplitLiteral][i] = B.text[B.lit_pos[i]]; }
+BR_DEV void hq_item_command_symbols(const MbBuffers& B, uint32_t c) {
+  const Command cmd = B.cmds[c];
+  B.hq_sym[kSplitCommand][c] = cmd.cmd_prefix_;
+  if (br_command_has_distance(cmd)) B.hq_sym[kSplitDistance][B.cmd_dist_index[c]] = cmd.dist_prefix_ & 0x3ffu;
+}
+
+// ---- BrotliBuildHistogramsWithContext (histogram.rs:465-534), one symbol per item, counters by atomic add
+BR_DEV void hq_item_literal_context_count(const MbBuffers& B, uint32_t i) {
+  const uint32_t m = mb_find_by_lit(B, i);
+  const MbDesc& d = B.descs[m];
+  if (d.uncompressed) return;
+  const uint32_t local = i - d.lit_base;
+  const uint32_t blk = hq_block_of(B.block_start[kSplitLiteral] + d.block_base[kSplitLiteral], B.results[m].num_blocks[kSplitLiteral], local);
+  const uint32_t type = B.block_types[kSplitLiteral][d.block_base[kSplitLiteral] + blk];
+  const uint32_t pos = B.lit_pos[i];
+  const uint32_t row = d.hq_no_context ? type : (type << 6) + mb_literal_context(B, d, pos);
+  BR_ATOMIC_ADD_U32(B.hq_ctx_histo[0] + ((size_t)d.hq_ctx_row_base[0] + row) * 256 + B.text[pos], 1u);
+}
+BR_DEV void hq_item_command_context_count(const MbBuffers& B, uint32_t c) {
+  const uint32_t m = mb_find_by_cmd(B, c);
+  const MbDesc& d = B.descs[m];
+  if (d.uncompressed) return;
+  const Command cmd = B.cmds[c];
+  {
+    const uint32_t local = c - d.cmd_offset;
+    const uint32_t blk = hq_block_of(B.block_start[kSplitCommand] + d.block_base[kSplitCommand], B.results[m].num_blocks[kSplitCommand], local);
+    const uint32_t type = B.block_types[kSplitCommand][d.block_base[kSplitCommand] + blk];
+    BR_ATOMIC_ADD_U32(B.histo[kSplitCommand] + ((size_t)d.histo_base[kSplitCommand] + type) * kNumCommandSymbols + cmd.cmd_prefix_, 1u);
+  }
+  if (br_command_has_distance(cmd)) {
+    const uint32_t local = B.cmd_dist_index[c] - d.dist_base;
+    const uint32_t blk = hq_block_of(B.block_start[kSplitDistance] + d.block_base[kSplitDistance], B.results[m].num_blocks[kSplitDistance], local);
+    const uint32_t type = B.block_types[kSplitDistance][d.block_base[kSplitDistance] + blk];
+    const uint32_t row = (type << 2) + br_distance_context(cmd);
+    BR_ATOMIC_ADD_U32(B.hq_ctx_histo[1] + ((size_t)d.hq_ctx_row_base[1] + row) * kNumDistanceHistoSymbols + (cmd.dist_prefix_ & 0x3ffu), 1u);
+  }
+}
+
+// ---- BrotliClusterHistograms, cluster.rs:353-465 (+ HistogramRemap :261-297, HistogramReindex :310-351), and the copy of
+// the result into the meta-block's histogram rows and context map
+BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J) {
+  const EntropyTables& et = B.et;
+  const MbDesc& d = B.descs[J.m];
+  MbResult& r = B.results[J.m];
+  const uint32_t which = J.kind == kSplitLiteral ? 0u : 1u;
+  const uint32_t in_size = J.in_size, len = J.len;
+  uint32_t* map = B.hq_ctx_map[which] + d.hq_ctx_map_base[which];
+  HqHistos inp;
+  inp.data = const_cast<uint32_t*>(J.in_data);
+  inp.total = J.in_total;
+  inp.cost = J.out_cost;  // (not used for the inputs)
+  inp.len = len;
+  HqHistos out;
+  out.data = J.out_data;
+  out.total = J.out_total;
+  out.cost = J.out_cost;
+  out.len = len;
+  const uint32_t tmp = in_size;  // scratch row
+  for (uint32_t i = 0; i < in_size; ++i) {
+    uint32_t t = 0;
+    const uint32_t* row = inp.row(i);
+    for (uint32_t k = 0; k < len; ++k) t += row[k];
+    J.in_total[i] = t;
+  }
+  uint32_t* cluster_size = J.cluster_size;
+  uint32_t* clusters = J.clusters;
+  uint32_t* symbols = J.symbols;
+  uint32_t num_clusters = 0;
+  for (uint32_t i = 0; i < in_size; ++i) cluster_size[i] = 1;
+  for (uint32_t i = 0; i < in_size; ++i) {
+    uint32_t* o = out.row(i);
+    const uint32_t* s = inp.row(i);
+    for (uint32_t k = 0; k < len; ++k) o[k] = s[k];
+    out.total[i] = J.in_total[i];
+    out.cost[i] = hq_population_cost(et, s, len, J.in_total[i]);
+    symbols[i] = i;
+  }
+  for (uint32_t i = 0; i < in_size; i += kHqBatch) {
+    const uint32_t num_to_combine = in_size - i < kHqBatch ? in_size - i : kHqBatch;
+    for (uint32_t j = 0; j < num_to_combine; ++j) clusters[num_clusters + j] = i + j;
+    const uint32_t num_new_clusters = hq_histogram_combine(et, out, cluster_size, symbols + i, clusters + num_clusters, J.pairs, num_to_combine,
+                                                           num_to_combine, 256, kHqBatchPairs, tmp);
+    num_clusters += num_new_clusters;
+  }
+  {
+    uint32_t max_num_pairs = 64u * num_clusters;
+    const uint64_t alt = (uint64_t)(num_clusters / 2) * num_clusters;
+    if (alt < max_num_pairs) max_num_pairs = (uint32_t)alt;
+    num_clusters = hq_histogram_combine(et, out, cluster_size, symbols, clusters, J.pairs, num_clusters, in_size, 256, max_num_pairs, tmp);
+  }
+  // BrotliHistogramRemap
+  for (uint32_t i = 0; i < in_size; ++i) {
+    uint32_t best_out = i == 0 ? symbols[0] : symbols[i - 1];
+    float best_bits = hq_bit_cost_distance(et, inp, i, out, best_out, tmp);
+    for (uint32_t j = 0; j < num_clusters; ++j) {
+      const float cur_bits = hq_bit_cost_distance(et, inp, i, out, clusters[j], tmp);
+      if (cur_bits < best_bits) {
+        best_bits = cur_bits;
+        best_out = clusters[j];
+      }
+    }
+    symbols[i] = best_out;
+  }
+  for (uint32_t i = 0; i < num_clusters; ++i) hq_clear(out, clusters[i]);
+  for (uint32_t i = 0; i < in_size; ++i) hq_add(out, symbols[i], inp, i);
+  // BrotliHistogramReindex
+  uint32_t next_index = 0;
+  {
+    const uint32_t kInvalidIndex = 0xffffffffu;
+    uint32_t* new_index = J.new_index;
+    for (uint32_t i = 0; i < in_size; ++i) new_index[i] = kInvalidIndex;
+    for (uint32_t i = 0; i < in_size; ++i) {
+      if (new_index[symbols[i]] == kInvalidIndex) {
+        new_index[symbols[i]] = next_index;
+        ++next_index;
+      }
+    }
+    HqHistos re;
+    re.data = J.reindex_data;
+    re.total = J.reindex_total;
+    re.cost = J.reindex_cost;
+    re.len = len;
+    next_index = 0;
+    for (uint32_t i = 0; i < in_size; ++i) {
+      if (new_index[symbols[i]] == next_index) {
+        hq_copy(re, next_index, out, symbols[i]);
+        ++next_index;
+      }
+      symbols[i] = new_index[symbols[i]];
+    }
+    // into the meta-block's histogram rows
+    uint32_t* H = B.histo[J.kind] + (size_t)d.histo_base[J.kind] * len;
+    for (uint32_t i = 0; i < next_index; ++i) {
+      const uint32_t* s = re.row(i);
+      for (uint32_t k = 0; k < len; ++k) H[(size_t)i * len + k] = s[k];
+    }
+  }
+  r.num_histos[J.kind] = next_index;
+  if (J.expand64) {
+    for (uint32_t i = in_size; i != 0;) {
+      --i;
+      const uint32_t val = symbols[i];
+      for (uint32_t j = 0; j < 64; ++j) map[(i << 6) + j] = val;
+    }
+  } else {
+    for (uint32_t i = 0; i < in_size; ++i) map[i] = symbols[i];
+  }
+}
+
+}  // namespace brotli_mi355x
+#endif

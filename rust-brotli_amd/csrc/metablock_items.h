@@ -56,6 +56,14 @@ struct MbBuffers {
   const uint8_t* utf8_lut;
   const uint8_t* signed_lut;
   EntropyTables et;
+  uint32_t header_stride;    // words of header scratch per meta-block (kHeaderWords / kHqHeaderWords)
+  uint32_t pad_hq;
+  // ---- quality >= 10 (metablock_hq.h)
+  Command* cmds_rw;          // the stage's own copy of the commands (distance prefixes are re-coded per meta-block)
+  uint16_t* hq_sym[3];       // symbol streams of the three splitters: [L] literals, [K] command prefixes, [D] distance codes
+  uint32_t* block_start[3];  // per block: index of its first symbol inside the meta-block (one extra entry = the total)
+  uint32_t* hq_ctx_histo[2]; // context histograms before clustering: literal rows of 256, distance rows of 544
+  uint32_t* hq_ctx_map[2];   // clustered context maps
 };
 
 static constexpr uint32_t kRowLen[3] = {256, 704, 544};
@@ -477,9 +485,9 @@ BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch*
     r.header_bits = 0;
     return;
   }
-  uint64_t* words = staging ? staging : B.header_words + (size_t)m * kHeaderWords;
+  uint64_t* words = staging ? staging : B.header_words + (size_t)m * B.header_stride;
   if (!staging)
-    for (uint32_t i = 0; i < kHeaderWords; ++i) words[i] = 0;
+    for (uint32_t i = 0; i < B.header_stride; ++i) words[i] = 0;
   BitSink out;
   out.words = words;
   out.pos = 0;
@@ -501,17 +509,24 @@ BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch*
   out.put(2, d.dist_postfix_bits);
   out.put(4, d.num_direct_distance_codes >> d.dist_postfix_bits);
   for (uint32_t i = 0; i < r.num_types[kSplitLiteral]; ++i) out.put(2, d.context_mode);
-  if (d.num_contexts <= 1) {
-    br_store_trivial_context_map(r.num_histos[kSplitLiteral], 6, sc, out);
+  if (d.hq) {
+    // BrotliBuildMetaBlock always hands over full maps (num_types << 6 and << 2 entries): EncodeContextMap for both
+    uint32_t* scratch = B.ctxmap_scratch + (size_t)m * (2 * 256 * 64);
+    br_encode_context_map(B.hq_ctx_map[0] + d.hq_ctx_map_base[0], r.num_types[kSplitLiteral] << 6, r.num_histos[kSplitLiteral], scratch, sc, out);
+    br_encode_context_map(B.hq_ctx_map[1] + d.hq_ctx_map_base[1], r.num_types[kSplitDistance] << 2, r.num_histos[kSplitDistance], scratch, sc, out);
   } else {
-    // MapStaticContexts, metablock.rs:832-857
-    uint32_t* cm = B.ctxmap_scratch + (size_t)m * (2 * 256 * 64);
-    const uint32_t n = r.num_types[kSplitLiteral] << 6;
-    for (uint32_t i = 0; i < r.num_types[kSplitLiteral]; ++i)
-      for (uint32_t j = 0; j < 64; ++j) cm[(i << 6) + j] = i * d.num_contexts + br_static_context_map(d.context_map_id, j);
-    br_encode_context_map(cm, n, r.num_histos[kSplitLiteral], cm + 256 * 64, sc, out);
+    if (d.num_contexts <= 1) {
+      br_store_trivial_context_map(r.num_histos[kSplitLiteral], 6, sc, out);
+    } else {
+      // MapStaticContexts, metablock.rs:832-857
+      uint32_t* cm = B.ctxmap_scratch + (size_t)m * (2 * 256 * 64);
+      const uint32_t n = r.num_types[kSplitLiteral] << 6;
+      for (uint32_t i = 0; i < r.num_types[kSplitLiteral]; ++i)
+        for (uint32_t j = 0; j < 64; ++j) cm[(i << 6) + j] = i * d.num_contexts + br_static_context_map(d.context_map_id, j);
+      br_encode_context_map(cm, n, r.num_histos[kSplitLiteral], cm + 256 * 64, sc, out);
+    }
+    br_store_trivial_context_map(r.num_histos[kSplitDistance], 2, sc, out);
   }
-  br_store_trivial_context_map(r.num_histos[kSplitDistance], 2, sc, out);
   for (uint32_t kind = 0; kind < 3; ++kind) {
     for (uint32_t i = 0; i < r.num_histos[kind]; ++i) {
       const uint32_t row_index = d.histo_base[kind] + i;
@@ -553,6 +568,45 @@ struct SymbolCode {
   uint32_t nbits;
 };
 
+// block (index inside its meta-block's split) of local symbol `local`: last start <= local
+BR_DEV uint32_t hq_block_of(const uint32_t* starts, uint32_t num_blocks, uint32_t local) {
+  uint32_t lo = 0, hi = num_blocks;  // starts[lo] <= local < starts[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (starts[mid] <= local) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
+}
+
+// Block of symbol `local` of (meta-block m, kind), and whether the block-switch command precedes it (the first symbol of
+// every block but the first).  Greedy splits (quality < 10) end on granule boundaries and are looked up through the
+// granule index; the quality >= 10 splits have arbitrary lengths and are searched in block_start.
+BR_DEV uint32_t mb_block_of(const MbBuffers& B, const MbDesc& d, uint32_t m, uint32_t kind, uint32_t local, bool* at_switch) {
+  if (d.hq) {
+    const uint32_t* starts = B.block_start[kind] + d.block_base[kind];
+    const uint32_t blk = hq_block_of(starts, B.results[m].num_blocks[kind], local);
+    *at_switch = blk != 0 && starts[blk] == local;
+    return blk;
+  }
+  const uint32_t gl = kGranuleLen[kind];
+  const uint32_t blk = B.gran_block[kind][d.granule_base[kind] + local / gl];
+  *at_switch = false;
+  if ((local % gl) == 0 && blk != 0) *at_switch = B.gran_block[kind][d.granule_base[kind] + local / gl - 1] != blk;
+  return blk;
+}
+
+// CommandDistanceContext, command.rs:28-36
+BR_DEV uint32_t br_distance_context(const Command& c) {
+  const uint32_t r = (uint32_t)(c.cmd_prefix_ >> 6);
+  const uint32_t cc = (uint32_t)(c.cmd_prefix_ & 7);
+  if ((r == 0 || r == 2 || r == 4 || r == 7) && cc <= 2) return cc;
+  return 3;
+}
+
 // code of literal i (global literal index), store_symbol[_with_context] brotli_bit_stream.rs:1891-1920,1980-2020
 BR_DEV SymbolCode mb_literal_code(const MbBuffers& B, uint32_t i) {
   const uint32_t m = mb_find_by_lit(B, i);
@@ -562,20 +616,22 @@ BR_DEV SymbolCode mb_literal_code(const MbBuffers& B, uint32_t i) {
   sc.nbits = 0;
   if (d.uncompressed) return sc;
   const uint32_t local = i - d.lit_base;
-  const uint32_t blk = B.gran_block[kSplitLiteral][d.granule_base[kSplitLiteral] + local / kLiteralGranule];
+  bool at_switch;
+  const uint32_t blk = mb_block_of(B, d, m, kSplitLiteral, local, &at_switch);
   const uint32_t type = B.block_types[kSplitLiteral][d.block_base[kSplitLiteral] + blk];
   // first symbol of a block (other than the first one) is preceded by the block switch command
-  if ((local % kLiteralGranule) == 0 && blk != 0) {
-    const uint32_t prev_blk = B.gran_block[kSplitLiteral][d.granule_base[kSplitLiteral] + local / kLiteralGranule - 1];
-    if (prev_blk != blk) {
-      sc.bits = B.switch_bits[kSplitLiteral][d.block_base[kSplitLiteral] + blk];
-      sc.nbits = B.switch_nbits[kSplitLiteral][d.block_base[kSplitLiteral] + blk];
-    }
+  if (at_switch) {
+    sc.bits = B.switch_bits[kSplitLiteral][d.block_base[kSplitLiteral] + blk];
+    sc.nbits = B.switch_nbits[kSplitLiteral][d.block_base[kSplitLiteral] + blk];
   }
   const uint32_t pos = B.lit_pos[i];
   const uint32_t lit = B.text[pos];
   uint32_t histo = type;
-  if (d.num_contexts > 1) histo = type * d.num_contexts + br_static_context_map(d.context_map_id, mb_literal_context(B, d, pos));
+  if (d.hq) {
+    histo = B.hq_ctx_map[0][d.hq_ctx_map_base[0] + (type << 6) + mb_literal_context(B, d, pos)];
+  } else if (d.num_contexts > 1) {
+    histo = type * d.num_contexts + br_static_context_map(d.context_map_id, mb_literal_context(B, d, pos));
+  }
   const size_t ix = ((size_t)d.histo_base[kSplitLiteral] + histo) * 256 + lit;
   sc.bits |= (uint64_t)B.bits[kSplitLiteral][ix] << sc.nbits;
   sc.nbits += B.depth[kSplitLiteral][ix];
@@ -583,20 +639,18 @@ BR_DEV SymbolCode mb_literal_code(const MbBuffers& B, uint32_t i) {
 }
 
 // the command's own symbols: [block switch] command code, insert/copy extra bits
-BR_DEV SymbolCode mb_command_code(const MbBuffers& B, uint32_t c, const MbDesc& d) {
+BR_DEV SymbolCode mb_command_code(const MbBuffers& B, uint32_t c, const MbDesc& d, uint32_t m) {
   SymbolCode sc;
   sc.bits = 0;
   sc.nbits = 0;
   const Command cmd = B.cmds[c];
   const uint32_t local = c - d.cmd_offset;
-  const uint32_t blk = B.gran_block[kSplitCommand][d.granule_base[kSplitCommand] + local / kCommandGranule];
+  bool at_switch;
+  const uint32_t blk = mb_block_of(B, d, m, kSplitCommand, local, &at_switch);
   const uint32_t type = B.block_types[kSplitCommand][d.block_base[kSplitCommand] + blk];
-  if ((local % kCommandGranule) == 0 && blk != 0) {
-    const uint32_t prev_blk = B.gran_block[kSplitCommand][d.granule_base[kSplitCommand] + local / kCommandGranule - 1];
-    if (prev_blk != blk) {
-      sc.bits = B.switch_bits[kSplitCommand][d.block_base[kSplitCommand] + blk];
-      sc.nbits = B.switch_nbits[kSplitCommand][d.block_base[kSplitCommand] + blk];
-    }
+  if (at_switch) {
+    sc.bits = B.switch_bits[kSplitCommand][d.block_base[kSplitCommand] + blk];
+    sc.nbits = B.switch_nbits[kSplitCommand][d.block_base[kSplitCommand] + blk];
   }
   const size_t ix = ((size_t)d.histo_base[kSplitCommand] + type) * kNumCommandSymbols + cmd.cmd_prefix_;
   sc.bits |= (uint64_t)B.bits[kSplitCommand][ix] << sc.nbits;
@@ -610,24 +664,23 @@ BR_DEV SymbolCode mb_command_code(const MbBuffers& B, uint32_t c, const MbDesc& 
 }
 
 // distance symbol of command c: [block switch] distance code, extra bits
-BR_DEV SymbolCode mb_distance_code(const MbBuffers& B, uint32_t c, const MbDesc& d) {
+BR_DEV SymbolCode mb_distance_code(const MbBuffers& B, uint32_t c, const MbDesc& d, uint32_t m) {
   SymbolCode sc;
   sc.bits = 0;
   sc.nbits = 0;
   const Command cmd = B.cmds[c];
   if (!br_command_has_distance(cmd)) return sc;
   const uint32_t local = B.cmd_dist_index[c] - d.dist_base;
-  const uint32_t blk = B.gran_block[kSplitDistance][d.granule_base[kSplitDistance] + local / kDistanceGranule];
+  bool at_switch;
+  const uint32_t blk = mb_block_of(B, d, m, kSplitDistance, local, &at_switch);
   const uint32_t type = B.block_types[kSplitDistance][d.block_base[kSplitDistance] + blk];
-  if ((local % kDistanceGranule) == 0 && blk != 0) {
-    const uint32_t prev_blk = B.gran_block[kSplitDistance][d.granule_base[kSplitDistance] + local / kDistanceGranule - 1];
-    if (prev_blk != blk) {
-      sc.bits = B.switch_bits[kSplitDistance][d.block_base[kSplitDistance] + blk];
-      sc.nbits = B.switch_nbits[kSplitDistance][d.block_base[kSplitDistance] + blk];
-    }
+  if (at_switch) {
+    sc.bits = B.switch_bits[kSplitDistance][d.block_base[kSplitDistance] + blk];
+    sc.nbits = B.switch_nbits[kSplitDistance][d.block_base[kSplitDistance] + blk];
   }
   const uint32_t dist_code = cmd.dist_prefix_ & 0x3ffu;
-  const size_t ix = ((size_t)d.histo_base[kSplitDistance] + type) * kNumDistanceHistoSymbols + dist_code;
+  const uint32_t histo = d.hq ? B.hq_ctx_map[1][d.hq_ctx_map_base[1] + (type << 2) + br_distance_context(cmd)] : type;
+  const size_t ix = ((size_t)d.histo_base[kSplitDistance] + histo) * kNumDistanceHistoSymbols + dist_code;
   sc.bits |= (uint64_t)B.bits[kSplitDistance][ix] << sc.nbits;
   sc.nbits += B.depth[kSplitDistance][ix];
   return sc;
@@ -647,8 +700,8 @@ BR_DEV void mb_item_command_nbits(const MbBuffers& B, uint32_t c) {
   }
   // command code + extras can exceed 64 bits together with a block switch: count the pieces separately
   const Command cmd = B.cmds[c];
-  SymbolCode own = mb_command_code(B, c, d);
-  const SymbolCode dist = mb_distance_code(B, c, d);
+  SymbolCode own = mb_command_code(B, c, d, m);
+  const SymbolCode dist = mb_distance_code(B, c, d, m);
   const uint32_t dist_extra_n = br_command_has_distance(cmd) ? (uint32_t)(cmd.dist_prefix_ >> 10) : 0;
   const uint32_t lit_bits = B.lit_nbits[B.cmd_lit_start[c + 1]] - B.lit_nbits[B.cmd_lit_start[c]];  // after the scan
   B.cmd_own_bits[c] = own.nbits;
@@ -676,14 +729,12 @@ BR_DEV void mb_item_emit_command(const MbBuffers& B, uint32_t c) {
     sc.bits = 0;
     sc.nbits = 0;
     const uint32_t local = c - d.cmd_offset;
-    const uint32_t blk = B.gran_block[kSplitCommand][d.granule_base[kSplitCommand] + local / kCommandGranule];
+    bool at_switch;
+    const uint32_t blk = mb_block_of(B, d, m, kSplitCommand, local, &at_switch);
     const uint32_t type = B.block_types[kSplitCommand][d.block_base[kSplitCommand] + blk];
-    if ((local % kCommandGranule) == 0 && blk != 0) {
-      const uint32_t prev_blk = B.gran_block[kSplitCommand][d.granule_base[kSplitCommand] + local / kCommandGranule - 1];
-      if (prev_blk != blk) {
-        sc.bits = B.switch_bits[kSplitCommand][d.block_base[kSplitCommand] + blk];
-        sc.nbits = B.switch_nbits[kSplitCommand][d.block_base[kSplitCommand] + blk];
-      }
+    if (at_switch) {
+      sc.bits = B.switch_bits[kSplitCommand][d.block_base[kSplitCommand] + blk];
+      sc.nbits = B.switch_nbits[kSplitCommand][d.block_base[kSplitCommand] + blk];
     }
     uint64_t pos = base;
     mb_put_bits_atomic(B.out_words, pos, sc.nbits, sc.bits);
@@ -698,7 +749,7 @@ BR_DEV void mb_item_emit_command(const MbBuffers& B, uint32_t c) {
   if (br_command_has_distance(cmd)) {
     const uint32_t lit_bits = B.lit_nbits[B.cmd_lit_start[c + 1]] - B.lit_nbits[B.cmd_lit_start[c]];
     uint64_t pos = base + B.cmd_own_bits[c] + lit_bits;
-    const SymbolCode dc = mb_distance_code(B, c, d);
+    const SymbolCode dc = mb_distance_code(B, c, d, m);
     mb_put_bits_atomic(B.out_words, pos, dc.nbits, dc.bits);
     pos += dc.nbits;
     mb_put_bits_atomic(B.out_words, pos, (uint32_t)(cmd.dist_prefix_ >> 10), cmd.dist_extra_);

@@ -7,7 +7,7 @@
 #include "device_api.h"
 #include "device_scan.h"
 #include "metablock_api.h"
-#include "metablock_items.h"
+#include "metablock_hq.h"
 
 namespace brotli_mi355x {
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
   const uint32_t m = blockIdx.x;
   if (m >= B.n_mb) return;
   const MbDesc d = B.descs[m];
-  uint64_t* global_words = B.header_words + (size_t)m * kHeaderWords;
+  uint64_t* global_words = B.header_words + (size_t)m * B.header_stride;
   if (d.uncompressed) {
     if (threadIdx.x == 0) mb_item_write_header(B, m, B.huff_scratch + m, global_words);
     return;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
   trees = (uint32_t)__shfl((int)trees, 0, 64);
   const bool in_lds = (uint64_t)trees + kOtherBits <= (uint64_t)kLdsWords * 64;
   uint64_t* stage = in_lds ? lw : global_words;
-  const uint32_t clear_words = in_lds ? kLdsWords : kHeaderWords;
+  const uint32_t clear_words = in_lds ? kLdsWords : B.header_stride;
   for (uint32_t i = threadIdx.x; i < clear_words; i += 64) stage[i] = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -251,6 +251,60 @@ void mb_emit(const MbBuffers& B) {
   const MbBuffers b = B;
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_emit_command(b, c); });
   for_each(b.n_lits, [b] __device__(uint32_t i) { mb_item_emit_literal(b, i); });
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- quality >= 10: one lane per sequential job (metablock_hq.h says why), all lanes for the per-symbol passes
+__global__ __launch_bounds__(64) void k_hq_utf8_census(MbBuffers B) {
+  if (threadIdx.x == 0 && !B.descs[blockIdx.x].uncompressed) hq_item_utf8_census(B, blockIdx.x);
+}
+void mb_hq_utf8_census(const MbBuffers& B) {
+  if (B.n_mb == 0) return;
+  hipLaunchKernelGGL(k_hq_utf8_census, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B);
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void k_hq_distance_params(MbBuffers B, uint32_t* histo) {
+  if (threadIdx.x == 0) hq_item_distance_params(B, blockIdx.x, histo + (size_t)blockIdx.x * kNumDistanceHistoSymbols);
+}
+void mb_hq_distance_params(const MbBuffers& B, uint32_t* histo_scratch_dev) {
+  if (B.n_mb == 0) return;
+  hipLaunchKernelGGL(k_hq_distance_params, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B, histo_scratch_dev);
+  HIP_CHECK(hipGetLastError());
+}
+void mb_hq_gather_symbols(const MbBuffers& B) {
+  const MbBuffers b = B;
+  for_each(b.n_lits, [b] __device__(uint32_t i) { hq_item_literal_symbol(b, i); });
+  for_each(b.n_cmds, [b] __device__(uint32_t c) { hq_item_command_symbols(b, c); });
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void k_hq_find_blocks(EntropyTables et, HqSplitJob* jobs) {
+  if (threadIdx.x == 0) hq_item_find_blocks(et, jobs[blockIdx.x]);
+}
+void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs) {
+  if (n_jobs == 0) return;
+  hipLaunchKernelGGL(k_hq_find_blocks, dim3(n_jobs), dim3(64), 0, BR_STREAM, B.et, jobs_dev);
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void k_hq_cluster_blocks(MbBuffers B, const HqSplitJob* jobs) {
+  if (threadIdx.x == 0) hq_item_cluster_blocks(B, jobs[blockIdx.x]);
+}
+void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs) {
+  if (n_jobs == 0) return;
+  hipLaunchKernelGGL(k_hq_cluster_blocks, dim3(n_jobs), dim3(64), 0, BR_STREAM, B, jobs_dev);
+  HIP_CHECK(hipGetLastError());
+}
+void mb_hq_context_histograms(const MbBuffers& B) {
+  const MbBuffers b = B;
+  for_each(b.n_lits, [b] __device__(uint32_t i) { hq_item_literal_context_count(b, i); });
+  for_each(b.n_cmds, [b] __device__(uint32_t c) { hq_item_command_context_count(b, c); });
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void k_hq_cluster_histograms(MbBuffers B, const HqClusterJob* jobs) {
+  if (threadIdx.x == 0) hq_item_cluster_histograms(B, jobs[blockIdx.x]);
+}
+void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs) {
+  if (n_jobs == 0) return;
+  hipLaunchKernelGGL(k_hq_cluster_histograms, dim3(n_jobs), dim3(64), 0, BR_STREAM, B, jobs_dev);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -22,6 +22,7 @@ static constexpr uint32_t kDistanceGranule = 512;
 static constexpr uint32_t kMaxBlockTypes = 256;
 static constexpr uint32_t kTreeBitsWords = 64;     // scratch for one serialised Huffman tree (<= 4096 bits)
 static constexpr uint32_t kHeaderWords = 16384;    // scratch for one meta-block header (<= 1 Mi bits)
+static constexpr uint32_t kHqHeaderWords = 131072; // quality >= 10: up to 3 x 256 trees of <= 4096 bits + two clustered context maps
 
 enum SplitKind : uint32_t { kSplitLiteral = 0, kSplitCommand = 1, kSplitDistance = 2 };
 
@@ -51,7 +52,13 @@ struct MbDesc {
   uint32_t histo_base[3];       // first histogram slot (units of one histogram)
   uint32_t max_histos[3];       // capacity in histograms
   uint32_t header_word_base;    // into header scratch (uint64 words)
-  uint32_t pad;
+  // quality >= 10 (metablock_hq.h): splits with arbitrary block lengths (block_start instead of the granule index) and
+  // clustered context maps instead of the static ones
+  uint32_t hq;
+  uint32_t hq_no_context;       // disable_literal_context_modeling: one literal histogram row per block type
+  uint32_t hq_ctx_row_base[2];  // first row of this meta-block in the context histogram pools (literal, distance)
+  uint32_t hq_ctx_map_base[2];  // first entry in the context map pools (num_types << 6 literal, << 2 distance)
+  uint32_t pad2;
 };
 
 // Results of the greedy splitters and the header pass, one per meta-block.
@@ -61,7 +68,9 @@ struct MbResult {
   uint32_t num_histos[3];      // literal: num_types * num_contexts
   uint32_t header_bits;        // length of the serialised header (incl. the meta-block header bits)
   uint32_t body_bits;          // commands + literals + distances
-  uint32_t pad[5];
+  uint32_t hq_postfix, hq_ndirect;  // distance parameters chosen by the quality >= 10 search
+  uint32_t hq_mostly_utf8;          // BrotliIsMostlyUTF8 of the meta-block's bytes (ChooseContextMode)
+  uint32_t pad[2];
 };
 
 }  // namespace brotli_mi355x

@@ -1,0 +1,127 @@
+"""Quality "9.5" (SURVEY row b10): BROTLI_PARAM_Q9_5 with quality 10 keeps the greedy H9 search of quality 9 and runs the
+quality >= 10 meta-block builder behind it -- the distance-parameter search, BrotliSplitBlock (FindBlocks / ClusterBlocks),
+context histograms, BrotliClusterHistograms, BrotliPopulationCost (metablock.rs:133-307, block_splitter.rs, cluster.rs,
+bit_cost.rs:76-211) -- all on the device (rust-brotli_amd/csrc/metablock_hq.h).
+
+The reference holds one exact size for this path: src/bin/integration_tests.rs:397-428, random_then_unicode through
+roundtrip_helper(.., 10, 28, q9_5) == 130 036 bytes (4096-byte reads, size hint 2 MiB).  Everything else is byte identity
+with the oracle (oracle/orc_hq_metablock.c, itself pinned on that size and on 129 715 / 47 488 / 46 493).
+
+CPU: the emulation build (the same item code compiled for the host).  -m gpu: the product library."""
+import glob
+import os
+
+import pytest
+
+import orc
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+Q, W, MODE, SH, Q9_5, NO_CTX = 1, 2, 0, 5, 150, 4
+P = [(Q, 10), (Q9_5, 1)]
+
+
+def _kat(lib):
+    d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
+    # roundtrip_helper: lgwin 28 without large_window is cut back to 24 by the parameter check (encode.rs:657-676)
+    for w in (28, 24):
+        e = lib.encoder(params=P + [(W, w), (SH, 2048 * 1024)])
+        for i in range(0, len(d), 4096):
+            e.write(d[i:i + 4096])
+        got = e.finish()
+        e.close()
+        assert len(got) == 130036
+        assert got == orc.reader_compress(d, P + [(W, w), (SH, 2048 * 1024)], chunk=4096)
+        assert orc.decompress(got, len(d)) == d
+
+
+def _cases(small):
+    a = synth.alice()
+    yield "alice w22 hint", a, P + [(W, 22), (SH, len(a))], b""
+    yield "alice w16", a, P + [(W, 16), (SH, len(a))], b""
+    yield "alice no hint", a, P + [(W, 22)], b""
+    for mode in (3, 4, 6):  # forced context modes (ChooseContextMode, encode.rs:1357-1377); 0-2 and 5 take the UTF-8 census
+        yield "alice mode %d" % mode, a, P + [(W, 22), (MODE, mode)], b""
+    yield "alice no literal contexts", a, P + [(W, 22), (NO_CTX, 1)], b""
+    h = len(a) // 2
+    yield "alice second half behind the first as dictionary", a[h:], P + [(W, 22), (167, 1), (168, 1)], a[:h]
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))):
+        d = open(f, "rb").read()
+        yield os.path.basename(f), d, P + [(W, 22), (SH, len(d))], b""
+    yield "random 300k (stored raw)", synth.random_bytes(300000), P + [(W, 22)], b""
+    yield "zeros 300k", bytes(300000), P + [(W, 22)], b""
+    yield "stretches 1 MiB", synth.stretches(1 << 20, 9), P + [(W, 22)], b""
+    yield "Silesia-like 2 MiB", synth.silesia_like(2 << 20, min_segment=1 << 18, max_segment=1 << 20), P + [(W, 22)], b""
+    yield "mixed %s" % ("1 MiB" if small else "3 MiB"), synth.mixed((1 if small else 3) << 20), P + [(W, 22)], b""
+    n = (2 if small else 5) << 20  # several meta-blocks, one with the signed context mode if the census says so
+    d = synth.markov_text(n)
+    yield "markov text", d, P + [(W, 22), (SH, n)], b""
+
+
+def _identity(L, small):
+    from cmp_stream import check_bytes
+    bad = [name for name, data, params, prefix in _cases(small) if not check_bytes(L, name, data, params, prefix=prefix)]
+    assert not bad, bad
+
+
+def _flushes(lib):
+    """FLUSH in the middle of a stream: every piece is built by the quality >= 10 builder, the carry goes on"""
+    d = synth.mixed(1 << 20, 7)
+    e = lib.encoder(params=P + [(W, 20)])
+    pieces = []
+    cuts = [300000, 700001]
+    last = 0
+    for c in cuts:
+        pieces.append(e.flush(d[last:c]))
+        last = c
+    e._stream(2, d[last:])
+    pieces.append(bytes(e._out))
+    e.close()
+    want = orc.stream_with_flushes(d, P + [(W, 20)], cuts, write_size=1 << 30)
+    assert [len(p) for p in pieces] == [len(p) for p in want]
+    assert pieces == want
+
+
+def test_reference_kat_130036_emu():
+    import test_cabi
+    _kat(test_cabi._load("emu"))
+
+
+def test_identity_with_the_oracle_emu():
+    import emu
+    _identity(emu.lib(), small=False)
+
+
+def test_flushes_emu():
+    import test_cabi
+    _flushes(test_cabi._load("emu"))
+
+
+def test_what_is_still_refused():
+    """quality 10 / 11 without Q9_5 are the Zopfli path (H10), quality 11 with it asks for 512-deep rings: refused with
+    a message, never routed anywhere else"""
+    import emu
+    L = emu.lib()
+    a = synth.alice()
+    for params in ([(Q, 10), (W, 22)], [(Q, 11), (W, 22)], [(Q, 11), (Q9_5, 1), (W, 22), (SH, 2 << 20)]):
+        with pytest.raises(RuntimeError):
+            emu.encode_stream(L, a, params)
+
+
+@pytest.mark.gpu
+def test_reference_kat_130036_gpu():
+    import test_cabi
+    _kat(test_cabi._load("gpu"))
+
+
+@pytest.mark.gpu
+def test_identity_with_the_oracle_gpu():
+    import gpulib
+    _identity(gpulib.lib(), small=True)
+
+
+@pytest.mark.gpu
+def test_flushes_gpu():
+    import test_cabi
+    _flushes(test_cabi._load("gpu"))
