@@ -322,23 +322,45 @@ BR_DEV uint32_t hq_my_rand(uint32_t* seed) {  // :131-137
 }
 BR_DEV float hq_bit_cost(const EntropyTables& et, uint32_t count) { return count == 0 ? -2.0f : br_fast_log2(et, count); }  // :224-230
 
-// InitialEntropyCodes + RefineEntropyCodes, block_splitter.rs:139-222
+// ---- phase 1 of SplitByteVector, cooperatively: the item is entered by all lanes of a 64-lane workgroup (one lane in the
+// emulation).  Histogram counters are bumped by atomic adds (integers: any order gives the same histogram), the costs of
+// FindBlocks live in registers, two entropy codes per lane.
+#if defined(BROTLI_HOST_EMU)
+#define BR_ATOMIC_MIN_U32(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define HQ_LD32(p) (*(p))
+#else
+#define BR_ATOMIC_MIN_U32(p, v) atomicMin((p), (v))
+// counters that other lanes bump with atomic adds (performed in the L2) are read with device-scope loads: a plain load could
+// be served from a line the vector L1 fetched before the adds
+#define HQ_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+struct HqWaveScratch {  // workgroup shared memory
+  uint32_t first_pos[256];
+  uint32_t ctl[4];
+};
+
+// InitialEntropyCodes + RefineEntropyCodes, block_splitter.rs:139-222.  The sample positions come from a 32-bit
+// multiplicative generator that every lane steps for itself (uniform); a sample of `stride` symbols is one atomic add per lane.
 BR_DEV void hq_seed_entropy_codes(const HqSplitJob& J, const HqHistos& H) {
   const uint16_t* data = J.data;
   const uint32_t length = J.length, stride = J.stride, nh = J.num_histograms;
+  for (uint32_t i = BR_TID; i < nh * H.len; i += BR_NT) H.data[i] = 0;
+  for (uint32_t i = BR_TID; i < nh; i += BR_NT) H.total[i] = 0;
+  BR_SYNC();
   {
     uint32_t seed = 7;
     const uint32_t block_length = length / nh;
-    for (uint32_t i = 0; i < nh; ++i) hq_clear(H, i);
     for (uint32_t i = 0; i < nh; ++i) {
       uint32_t pos = (uint32_t)((uint64_t)length * i / nh);
       if (i != 0) pos += hq_my_rand(&seed) % block_length;
       if (pos + stride >= length) pos = length - stride - 1;
-      H.total[i] += stride;
+      if (BR_TID == 0) H.total[i] += stride;
       uint32_t* r = H.row(i);
-      for (uint32_t k = 0; k < stride; ++k) r[data[pos + k]]++;
+      for (uint32_t k = BR_TID; k < stride; k += BR_NT) BR_ATOMIC_ADD_U32(&r[data[pos + k]], 1u);
     }
   }
+  BR_SYNC();
   {
     uint32_t iters = (uint32_t)(2ull * length / stride) + 100u;  // kIterMulForRefining, kMinItersForRefining
     uint32_t seed = 7;
@@ -353,36 +375,41 @@ BR_DEV void hq_seed_entropy_codes(const HqSplitJob& J, const HqHistos& H) {
         pos = hq_my_rand(&seed) % (length - stride + 1);
       }
       const uint32_t t = iter % nh;
-      H.total[t] += n;
+      if (BR_TID == 0) H.total[t] += n;
       uint32_t* r = H.row(t);
-      for (uint32_t k = 0; k < n; ++k) r[data[pos + k]]++;
+      for (uint32_t k = BR_TID; k < n; k += BR_NT) BR_ATOMIC_ADD_U32(&r[data[pos + k]], 1u);
     }
   }
+  BR_SYNC();
 }
 
-// FindBlocks, block_splitter.rs:232-350 (with update_cost_and_signal :46-82 over the padded lanes)
+// FindBlocks, block_splitter.rs:232-350 (with update_cost_and_signal :46-82).  Per symbol: cost[k] += insert_cost[sym][k];
+// the minimum over k (ties to the lowest k); cost[k] = min(cost[k] - min, switch cost), and one "would switch" bit per k.
+// The reference also steps the lanes that pad the cost vector to a multiple of eight; they feed neither the minimum nor
+// the trace-back (which reads bit cur_id < num_histograms only) and are left out here.
 BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, const HqHistos& H, uint32_t num_histograms) {
   const uint16_t* data = J.data;
   const uint32_t length = J.length, data_size = J.alphabet;
   uint8_t* block_id = J.block_ids;
   const uint32_t bitmaplen = (num_histograms + 7) >> 3;
-  const uint32_t padded = bitmaplen << 3;
   if (num_histograms == 0) return 0;
   if (num_histograms <= 1) {
-    for (uint32_t i = 0; i < length; ++i) block_id[i] = 0;
+    for (uint32_t i = BR_TID; i < length; i += BR_NT) block_id[i] = 0;
+    BR_SYNC();
     return 1;
   }
   float* insert_cost = J.insert_cost;
-  float* cost = J.cost;
   uint8_t* switch_signal = J.switch_signal;
-  for (uint32_t i = 0; i < data_size * num_histograms; ++i) insert_cost[i] = 0.0f;
-  for (uint32_t i = 0; i < num_histograms; ++i) insert_cost[i] = br_fast_log2(et, H.total[i]);
-  for (uint32_t i = data_size; i != 0;) {
-    --i;
-    for (uint32_t j = 0; j < num_histograms; ++j) insert_cost[i * num_histograms + j] = insert_cost[j] - hq_bit_cost(et, H.row(j)[i]);
+  // insert_cost[i][j] = log2(total_j) - bit_cost(histogram_j[i])  (the reference keeps log2(total_j) in row 0 until that row
+  // is overwritten last, :262-283)
+  for (uint32_t idx = BR_TID; idx < data_size * num_histograms; idx += BR_NT) {
+    const uint32_t i = idx / num_histograms, j = idx - i * num_histograms;
+    insert_cost[idx] = br_fast_log2(et, HQ_LD32(&H.total[j])) - hq_bit_cost(et, HQ_LD32(&H.row(j)[i]));
   }
-  for (uint32_t i = 0; i < padded; ++i) cost[i] = 0.0f;
-  for (size_t i = 0; i < (size_t)length * bitmaplen; ++i) switch_signal[i] = 0;
+  BR_SYNC();
+#if defined(BROTLI_HOST_EMU)
+  float* cost = J.cost;
+  for (uint32_t i = 0; i < num_histograms; ++i) cost[i] = 0.0f;
   for (uint32_t byte_ix = 0; byte_ix < length; ++byte_ix) {
     const size_t ix = (size_t)byte_ix * bitmaplen;
     const float* ic = insert_cost + (size_t)data[byte_ix] * num_histograms;
@@ -399,14 +426,63 @@ BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, con
     }
     block_id[byte_ix] = best;
     if (byte_ix < 2000) block_switch_cost *= (0.77f + 0.07f * (float)byte_ix / 2000.0f);
-    for (uint32_t k = 0; k < padded; ++k) {
+    for (uint32_t j = 0; j < bitmaplen; ++j) switch_signal[ix + j] = 0;
+    for (uint32_t k = 0; k < num_histograms; ++k) {
       const float d = cost[k] - min_cost;
       if (d >= block_switch_cost) switch_signal[ix + (k >> 3)] |= (uint8_t)(1u << (k & 7));
       cost[k] = d < block_switch_cost ? d : block_switch_cost;
     }
   }
-  uint32_t num_blocks = 1;
+#else
   {
+    const uint32_t lane = threadIdx.x;
+    const bool has0 = lane < num_histograms, has1 = lane + 64 < num_histograms;
+    const uint32_t k0 = has0 ? lane : 0u, k1 = has1 ? lane + 64 : 0u;
+    float c0 = 0.0f, c1 = 0.0f;
+    constexpr uint32_t kAhead = 8;  // symbols whose insert-cost rows are fetched together, ahead of the dependent chain
+    for (uint32_t base = 0; base < length; base += kAhead) {
+      float a0[kAhead], a1[kAhead];
+#pragma unroll
+      for (uint32_t u = 0; u < kAhead; ++u) {
+        const uint32_t bx = base + u < length ? base + u : length - 1;
+        const float* ic = insert_cost + (size_t)data[bx] * num_histograms;
+        a0[u] = ic[k0];
+        a1[u] = ic[k1];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kAhead; ++u) {
+        const uint32_t byte_ix = base + u;
+        if (byte_ix < length) {  // (uniform)
+          c0 += a0[u];
+          c1 += a1[u];
+          // every cost is >= 0 (insert costs are, and the carried part lies in [0, switch cost]): absent lanes hold a huge value
+          float v = has0 ? c0 : 3.0e38f;
+          if (has1 && c1 < v) v = c1;
+          for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_xor(v, off, 64);
+            v = o < v ? o : v;
+          }
+          const float min_cost = v;
+          const unsigned long long e0 = __ballot(has0 && c0 == min_cost), e1 = __ballot(has1 && c1 == min_cost);
+          const uint32_t best = e0 != 0 ? (uint32_t)__ffsll((long long)e0) - 1u : 64u + (uint32_t)__ffsll((long long)e1) - 1u;
+          float block_switch_cost = J.block_switch_cost;
+          if (byte_ix < 2000) block_switch_cost *= (0.77f + 0.07f * (float)byte_ix / 2000.0f);
+          const float d0 = c0 - min_cost, d1 = c1 - min_cost;
+          const unsigned long long m0 = __ballot(has0 && d0 >= block_switch_cost), m1 = __ballot(has1 && d1 >= block_switch_cost);
+          c0 = d0 < block_switch_cost ? d0 : block_switch_cost;
+          c1 = d1 < block_switch_cost ? d1 : block_switch_cost;
+          if (lane < bitmaplen)
+            switch_signal[(size_t)byte_ix * bitmaplen + lane] = (uint8_t)(lane < 8 ? (m0 >> (8 * lane)) : (m1 >> (8 * (lane - 8))));
+          if (lane == 0) block_id[byte_ix] = (uint8_t)best;
+        }
+      }
+    }
+  }
+#endif
+  BR_SYNC();
+  // trace back (:318-348): sequential, one lane
+  if (BR_TID == 0) {
+    uint32_t num_blocks = 1;
     uint32_t byte_ix = length - 1;
     size_t ix = (size_t)byte_ix * bitmaplen;
     uint8_t cur_id = block_id[byte_ix];
@@ -420,53 +496,73 @@ BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, con
       }
       block_id[byte_ix] = cur_id;
     }
+    const_cast<HqSplitJob&>(J).num_blocks = num_blocks;
   }
-  return num_blocks;
+  BR_SYNC();
+  return 0;
 }
 
 // phase 1 of SplitByteVector (block_splitter.rs:690-838): seeds + the FindBlocks / RemapBlockIds / BuildBlockHistograms
 // iterations.  Leaves block_ids and J.num_blocks; 0 blocks = "no symbols", 1 with length < 128 = "one block, no search".
-BR_DEV void hq_item_find_blocks(const EntropyTables& et, HqSplitJob& J) {
+BR_DEV void hq_item_find_blocks(const EntropyTables& et, HqSplitJob& J, HqWaveScratch& S) {
   if (J.length == 0) {
-    J.num_blocks = 0;
+    if (BR_TID == 0) J.num_blocks = 0;
     return;
   }
   if (J.length < 128) {  // kMinLengthForBlockSplitting
-    J.num_blocks = 1;
-    for (uint32_t i = 0; i < J.length; ++i) J.block_ids[i] = 0;
+    if (BR_TID == 0) J.num_blocks = 1;
+    for (uint32_t i = BR_TID; i < J.length; i += BR_NT) J.block_ids[i] = 0;
     return;
   }
   HqHistos H;
   H.data = J.histo_data;
   H.total = J.histo_total;
-  // (the bit-cost slot is never read for the block histograms: hq_clear gets a harmless target, the front of insert_cost,
-  // which FindBlocks initialises before it reads it)
-  H.cost = J.insert_cost;
+  H.cost = J.insert_cost;  // (the bit-cost slot is never used for the block histograms)
   H.len = J.alphabet;
   hq_seed_entropy_codes(J, H);
   uint32_t num_histograms = J.num_histograms;
-  uint32_t num_blocks = 0;
   for (uint32_t it = 0; it < J.iters; ++it) {
-    num_blocks = hq_find_blocks(et, J, H, num_histograms);
-    // RemapBlockIds, :352-378
-    {
-      const uint16_t kInvalidId = 256;
-      uint16_t next_id = 0;
-      for (uint32_t i = 0; i < num_histograms; ++i) J.new_id[i] = kInvalidId;
-      for (uint32_t i = 0; i < J.length; ++i)
-        if (J.new_id[J.block_ids[i]] == kInvalidId) J.new_id[J.block_ids[i]] = next_id++;
-      for (uint32_t i = 0; i < J.length; ++i) J.block_ids[i] = (uint8_t)J.new_id[J.block_ids[i]];
-      num_histograms = next_id;
+    if (num_histograms <= 1) {
+      for (uint32_t i = BR_TID; i < J.length; i += BR_NT) J.block_ids[i] = 0;
+      if (BR_TID == 0) J.num_blocks = 1;
+      BR_SYNC();
+    } else {
+      hq_find_blocks(et, J, H, num_histograms);
     }
-    // BuildBlockHistograms, :380-400
-    for (uint32_t i = 0; i < num_histograms; ++i) hq_clear(H, i);
-    for (uint32_t i = 0; i < J.length; ++i) {
-      const uint32_t b = J.block_ids[i];
-      H.row(b)[J.data[i]]++;
-      H.total[b]++;
+    // RemapBlockIds (:352-378): new ids in the order of first appearance
+    for (uint32_t i = BR_TID; i < 256; i += BR_NT) S.first_pos[i] = 0xffffffffu;
+    BR_SYNC();
+    for (uint32_t i = BR_TID; i < J.length; i += BR_NT) BR_ATOMIC_MIN_U32(&S.first_pos[J.block_ids[i]], i);
+    BR_SYNC();
+    if (BR_TID == 0) {
+      uint32_t next_id = 0;
+      for (;;) {  // (at most 100 ids: selection by smallest first position)
+        uint32_t best = 0xffffffffu, best_id = 0;
+        for (uint32_t id = 0; id < num_histograms; ++id)
+          if (S.first_pos[id] < best) {
+            best = S.first_pos[id];
+            best_id = id;
+          }
+        if (best == 0xffffffffu) break;
+        J.new_id[best_id] = (uint16_t)next_id++;
+        S.first_pos[best_id] = 0xffffffffu;
+      }
+      S.ctl[0] = next_id;
     }
+    BR_SYNC();
+    num_histograms = S.ctl[0];
+    // BuildBlockHistograms (:380-400)
+    for (uint32_t i = BR_TID; i < num_histograms * H.len; i += BR_NT) H.data[i] = 0;
+    for (uint32_t i = BR_TID; i < num_histograms; i += BR_NT) H.total[i] = 0;
+    BR_SYNC();
+    for (uint32_t i = BR_TID; i < J.length; i += BR_NT) {
+      const uint32_t b = J.new_id[J.block_ids[i]];
+      J.block_ids[i] = (uint8_t)b;
+      BR_ATOMIC_ADD_U32(&H.row(b)[J.data[i]], 1u);
+      BR_ATOMIC_ADD_U32(&H.total[b], 1u);
+    }
+    BR_SYNC();
   }
-  J.num_blocks = num_blocks;
 }
 
 // phase 2: ClusterBlocks, block_splitter.rs:402-688.  Writes the split of (m, kind): types, lengths, starts, counts.

@@ -278,7 +278,8 @@ void mb_hq_gather_symbols(const MbBuffers& B) {
   HIP_CHECK(hipGetLastError());
 }
 __global__ __launch_bounds__(64) void k_hq_find_blocks(EntropyTables et, HqSplitJob* jobs) {
-  if (threadIdx.x == 0) hq_item_find_blocks(et, jobs[blockIdx.x]);
+  __shared__ HqWaveScratch S;
+  hq_item_find_blocks(et, jobs[blockIdx.x], S);
 }
 void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs) {
   if (n_jobs == 0) return;

@@ -122,7 +122,8 @@ void mb_hq_gather_symbols(const MbBuffers& B) {
   for (uint32_t c = 0; c < B.n_cmds; ++c) hq_item_command_symbols(B, c);
 }
 void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs, uint32_t n_jobs) {
-  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_find_blocks(B.et, jobs[i]);
+  HqWaveScratch S;
+  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_find_blocks(B.et, jobs[i], S);
 }
 void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs, uint32_t n_jobs) {
   for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_blocks(B, jobs[i]);
