@@ -564,7 +564,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
       const bool census = !(p.mode == 3 || p.mode == 4 || p.mode == 5 || p.mode == 6);
       if (census) mb_hq_utf8_census(B);
-      mb_hq_distance_params(B, mm.alloc<uint32_t>((size_t)n_mb * kNumDistanceHistoSymbols));
+      mb_hq_distance_params(B);
       dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
       for (uint32_t m = 0; m < n_mb; ++m) {
         MbDesc& d = descs[m];
@@ -643,8 +643,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
           j.all_total = mm.alloc<uint32_t>(n + 2);
           j.all_cost = mm.alloc<float>(n + 2);
           j.cluster_size = mm.alloc<uint32_t>(n + 8);
-          j.clusters = mm.alloc<uint32_t>(n + 8);
-          j.new_index = mm.alloc<uint32_t>(n + 8);
+          j.clusters = mm.alloc<uint32_t>(n + 2 * kHqBatch + 8);  // (also the per-batch sizes / cluster lists)
+          j.new_index = mm.alloc<uint32_t>(n + 2 * kHqBatch + 8);
           j.pairs = mm.alloc<HqPair>(max_pairs + 2);
         }
       }

@@ -45,7 +45,7 @@ void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t
 // streams, FindBlocks iterations (jobs[].num_blocks), ClusterBlocks (the splits), context histograms, context-map
 // clustering (histogram rows + maps + num_histos); the code / header / emission kernels above take it from there.
 void mb_hq_utf8_census(const MbBuffers& B);
-void mb_hq_distance_params(const MbBuffers& B, uint32_t* histo_scratch_dev /* n_mb x 544 */);
+void mb_hq_distance_params(const MbBuffers& B);
 void mb_hq_gather_symbols(const MbBuffers& B);
 void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs);
 void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs);

@@ -95,28 +95,64 @@ struct HqClusterJob {
   HqPair* pairs;            // [max(2048, 64 * in_size) + 1]
 };
 
+// ------------------------------------------------------------------------------------------------ execution model
+// Every item below that works on one (meta-block, kind) job is entered by ALL lanes of a 64-lane workgroup (one lane in
+// the emulation, where BR_TID == 0, BR_NT == 1 and BR_SYNC() is nothing).  The control flow is uniform: every lane keeps
+// the job's scalar state in its own registers and redoes the scalar steps (stores of identical values to one address are
+// harmless on SIMT hardware); loops over a histogram row or over the symbols are strided across the lanes and end with a
+// barrier; f32 sums whose order matters are made by lane 0 from workgroup memory and broadcast.
+#if defined(BROTLI_HOST_EMU)
+#define BR_ATOMIC_MIN_U32(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
+#define HQ_LD32(p) (*(p))
+#else
+#define BR_ATOMIC_MIN_U32(p, v) atomicMin((p), (v))
+// counters that other lanes bump with atomic adds (performed in the L2) are read with device-scope loads: a plain load could
+// be served from a line the vector L1 fetched before the adds
+#define HQ_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+struct HqWaveScratch {  // workgroup shared memory
+  uint32_t first_pos[256];
+  uint32_t ctl[8];
+  float f[4];
+  uint32_t tmp[kHqMaxAlphabet];  // the histogram being priced (sum of two rows, or one block's)
+  uint32_t blk[kHqMaxAlphabet];  // the histogram of the block / input that is compared with the candidates
+  // BrotliPopulationCost across the lanes: the non-zero bins compacted in index order
+  uint32_t cval[kHqMaxAlphabet];
+  float cterm[kHqMaxAlphabet];
+  uint32_t cn3[kHqMaxAlphabet];
+  uint32_t depth[18];
+};
+
 // ------------------------------------------------------------------------------------------------ histogram helpers
 BR_DEV void hq_clear(const HqHistos& h, uint32_t i) {  // HistogramClear, histogram.rs:391-399
   uint32_t* r = h.row(i);
-  for (uint32_t k = 0; k < h.len; ++k) r[k] = 0;
-  h.total[i] = 0;
-  h.cost[i] = 3.402e+38f;
+  for (uint32_t k = BR_TID; k < h.len; k += BR_NT) r[k] = 0;
+  if (BR_TID == 0) {
+    h.total[i] = 0;
+    h.cost[i] = 3.402e+38f;
+  }
+  BR_SYNC();
 }
 BR_DEV void hq_copy(const HqHistos& d, uint32_t di, const HqHistos& s, uint32_t si) {
   uint32_t* dr = d.row(di);
   const uint32_t* sr = s.row(si);
-  for (uint32_t k = 0; k < d.len; ++k) dr[k] = sr[k];
-  d.total[di] = s.total[si];
-  d.cost[di] = s.cost[si];
+  for (uint32_t k = BR_TID; k < d.len; k += BR_NT) dr[k] = sr[k];
+  if (BR_TID == 0) {
+    d.total[di] = s.total[si];
+    d.cost[di] = s.cost[si];
+  }
+  BR_SYNC();
 }
 BR_DEV void hq_add(const HqHistos& d, uint32_t di, const HqHistos& s, uint32_t si) {  // HistogramAddHistogram
   uint32_t* dr = d.row(di);
   const uint32_t* sr = s.row(si);
-  d.total[di] += s.total[si];
-  for (uint32_t k = 0; k < d.len; ++k) dr[k] += sr[k];
+  for (uint32_t k = BR_TID; k < d.len; k += BR_NT) dr[k] += sr[k];
+  if (BR_TID == 0) d.total[di] += s.total[si];
+  BR_SYNC();
 }
 
-// BrotliPopulationCost, bit_cost.rs:76-211 (the build without "vector_scratch_space")
+// BrotliPopulationCost, bit_cost.rs:76-211 (the build without "vector_scratch_space").  Sequential: called by one lane.
 BR_DEV float hq_population_cost(const EntropyTables& et, const uint32_t* data, uint32_t data_size, uint32_t total_count) {
   const float kOneSymbolHistogramCost = 12.0f, kTwoSymbolHistogramCost = 20.0f, kThreeSymbolHistogramCost = 28.0f,
               kFourSymbolHistogramCost = 37.0f;
@@ -189,7 +225,115 @@ BR_DEV float hq_population_cost(const EntropyTables& et, const uint32_t* data, u
   bits += br_bits_entropy(et, depth_histo, 18);
   return bits;
 }
-BR_DEV float hq_cost_of(const EntropyTables& et, const HqHistos& h, uint32_t i) { return hq_population_cost(et, h.row(i), h.len, h.total[i]); }
+
+#if !defined(BROTLI_HOST_EMU)
+// BrotliPopulationCost of the histogram in S.tmp, by all 64 lanes.  The f32 sum of the reference runs over the bins in
+// index order -- for every non-zero bin first one 3.0 per code-length-17 symbol that the run of zeros in front of it
+// costs, then count * log2(total / count) -- so its ORDER is kept and only its LENGTH is cut: the lanes compute the terms
+// of their bins, find the zero run in front of each (ballot masks, the last non-zero bin of the earlier 64-bin groups
+// carried along) and compact the non-zero bins in index order; lane 0 adds up that list (a few dozen entries instead of
+// 256 / 544 / 704 dependent steps); the depth histogram and the maximal depth are integers (atomics, any order).
+BR_DEV float hq_population_cost_wave(const EntropyTables& et, HqWaveScratch& S, uint32_t len, uint32_t total) {
+  const uint32_t lane = threadIdx.x;
+  if (total == 0) return 12.0f;
+  if (lane < 18) S.depth[lane] = 0;
+  if (lane == 0) S.ctl[4] = 1;  // max_depth
+  __syncthreads();
+  const float log2total = br_fast_log2(et, total);
+  uint32_t base = 0;   // non-zero bins so far
+  int32_t carry = -1;  // index of the last non-zero bin of the groups in front
+  for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+    const uint32_t i = c0 + lane;
+    const uint32_t histo = i < len ? S.tmp[i] : 0u;
+    const bool nz = histo != 0;
+    const unsigned long long mask = __ballot(nz);
+    if (nz) {
+      const unsigned long long below = mask & ((1ull << lane) - 1ull);
+      const int32_t prev = below != 0 ? (int32_t)(c0 + 63u - (uint32_t)__clzll((long long)below)) : carry;
+      uint32_t reps = (uint32_t)((int32_t)i - prev - 1);
+      uint32_t n3 = 0;
+      if (reps != 0) {
+        if (reps < 3) {
+          atomicAdd(&S.depth[0], reps);
+        } else {
+          reps -= 2;
+          while (reps > 0) {
+            n3++;
+            reps >>= 3;
+          }
+          atomicAdd(&S.depth[17], n3);
+        }
+      }
+      const float log2p = log2total - et.logs_16[histo & 0xffffu];
+      const float dd = log2p + 0.5f;
+      uint32_t depth = dd > 0.0f ? (uint32_t)dd : 0u;
+      if (depth > 15) depth = 15;
+      atomicMax(&S.ctl[4], depth);
+      atomicAdd(&S.depth[depth], 1u);
+      const uint32_t k = base + (uint32_t)__popcll(below);
+      S.cval[k] = histo;
+      S.cterm[k] = (float)histo * log2p;
+      S.cn3[k] = n3;
+    }
+    if (mask != 0) carry = (int32_t)(c0 + 63u - (uint32_t)__clzll((long long)mask));
+    base += (uint32_t)__popcll(mask);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    const uint32_t count = base;
+    float bits = 0.0f;
+    if (count == 1) {
+      bits = 12.0f;
+    } else if (count == 2) {
+      bits = 20.0f + (float)total;
+    } else if (count == 3) {
+      const uint32_t h0 = S.cval[0], h1 = S.cval[1], h2 = S.cval[2];
+      const uint32_t m01 = h0 > h1 ? h0 : h1;
+      const uint32_t hmax = m01 > h2 ? m01 : h2;
+      bits = 28.0f + (float)(2u * (h0 + h1 + h2)) - (float)hmax;
+    } else if (count == 4) {
+      uint32_t h[4];
+      for (int i = 0; i < 4; ++i) h[i] = S.cval[i];
+      for (int i = 0; i < 4; ++i)
+        for (int j = i + 1; j < 4; ++j)
+          if (h[j] > h[i]) {
+            const uint32_t t = h[j];
+            h[j] = h[i];
+            h[i] = t;
+          }
+      const uint32_t h23 = h[2] + h[3];
+      const uint32_t hmax = h23 > h[0] ? h23 : h[0];
+      bits = 37.0f + (float)(3u * h23) + (float)(2u * (h[0] + h[1])) - (float)hmax;
+    } else {
+      for (uint32_t k = 0; k < count; ++k) {
+        for (uint32_t t = S.cn3[k]; t != 0; --t) bits += 3.0f;
+        bits += S.cterm[k];
+      }
+      bits += (float)(18 + 2 * S.ctl[4]);
+      bits += br_bits_entropy(et, S.depth, 18);
+    }
+    S.f[0] = bits;
+  }
+  __syncthreads();
+  return S.f[0];
+}
+#endif
+
+// cost of the histogram in S.tmp (complete and visible: the caller has passed a barrier); all lanes call, all get the value
+BR_DEV float hq_cost_in_tmp(const EntropyTables& et, HqWaveScratch& S, uint32_t len, uint32_t total) {
+#if defined(BROTLI_HOST_EMU)
+  return hq_population_cost(et, S.tmp, len, total);
+#else
+  return hq_population_cost_wave(et, S, len, total);
+#endif
+}
+
+// cost of the histogram a (+ b): the sum is formed in workgroup memory by all lanes
+BR_DEV float hq_cost_of_sum(const EntropyTables& et, HqWaveScratch& S, const uint32_t* a, const uint32_t* b, uint32_t len, uint32_t total) {
+  for (uint32_t k = BR_TID; k < len; k += BR_NT) S.tmp[k] = a[k] + (b != nullptr ? b[k] : 0u);
+  BR_SYNC();
+  return hq_cost_in_tmp(et, S, len, total);
+}
 
 // ------------------------------------------------------------------------------------------------ cluster.rs
 BR_DEV float hq_cluster_cost_diff(const EntropyTables& et, uint32_t size_a, uint32_t size_b) {  // :33-39
@@ -201,9 +345,9 @@ BR_DEV bool hq_pair_is_less(const HqPair& p1, const HqPair& p2) {  // :41-48
   return (uint32_t)(p1.idx2 - p1.idx1) > (uint32_t)(p2.idx2 - p2.idx1);
 }
 
-// BrotliCompareAndPushToQueue, cluster.rs:52-121.  `tmp` = index of a scratch row of `out`.
-BR_DEV void hq_compare_and_push(const EntropyTables& et, const HqHistos& out, const uint32_t* cluster_size, uint32_t idx1, uint32_t idx2,
-                                uint32_t max_num_pairs, HqPair* pairs, uint32_t* num_pairs, uint32_t tmp) {
+// BrotliCompareAndPushToQueue, cluster.rs:52-121
+BR_DEV void hq_compare_and_push(const EntropyTables& et, HqWaveScratch& S, const HqHistos& out, const uint32_t* cluster_size, uint32_t idx1,
+                                uint32_t idx2, uint32_t max_num_pairs, HqPair* pairs, uint32_t* num_pairs) {
   if (idx1 == idx2) return;
   if (idx2 < idx1) {
     const uint32_t t = idx2;
@@ -227,9 +371,7 @@ BR_DEV void hq_compare_and_push(const EntropyTables& et, const HqHistos& out, co
   } else {
     float threshold = 1e38f;
     if (*num_pairs != 0) threshold = pairs[0].cost_diff > 0.0f ? pairs[0].cost_diff : 0.0f;
-    hq_copy(out, tmp, out, idx1);
-    hq_add(out, tmp, out, idx2);
-    const float cost_combo = hq_cost_of(et, out, tmp);
+    const float cost_combo = hq_cost_of_sum(et, S, out.row(idx1), out.row(idx2), out.len, out.total[idx1] + out.total[idx2]);
     if (cost_combo < threshold - p.cost_diff) {
       p.cost_combo = cost_combo;
       is_good_pair = true;
@@ -251,15 +393,15 @@ BR_DEV void hq_compare_and_push(const EntropyTables& et, const HqHistos& out, co
 }
 
 // BrotliHistogramCombine, cluster.rs:123-236
-BR_DEV uint32_t hq_histogram_combine(const EntropyTables& et, const HqHistos& out, uint32_t* cluster_size, uint32_t* symbols, uint32_t* clusters,
-                                     HqPair* pairs, uint32_t num_clusters, uint32_t symbols_size, uint32_t max_clusters,
-                                     uint32_t max_num_pairs, uint32_t tmp) {
+BR_DEV uint32_t hq_histogram_combine(const EntropyTables& et, HqWaveScratch& S, const HqHistos& out, uint32_t* cluster_size, uint32_t* symbols,
+                                     uint32_t* clusters, HqPair* pairs, uint32_t num_clusters, uint32_t symbols_size, uint32_t max_clusters,
+                                     uint32_t max_num_pairs) {
   float cost_diff_threshold = 0.0f;
   uint32_t min_cluster_size = 1;
   uint32_t num_pairs = 0;
   for (uint32_t i1 = 0; i1 < num_clusters; ++i1)
     for (uint32_t i2 = i1 + 1; i2 < num_clusters; ++i2)
-      hq_compare_and_push(et, out, cluster_size, clusters[i1], clusters[i2], max_num_pairs, pairs, &num_pairs, tmp);
+      hq_compare_and_push(et, S, out, cluster_size, clusters[i1], clusters[i2], max_num_pairs, pairs, &num_pairs);
   while (num_clusters > min_cluster_size) {
     if (pairs[0].cost_diff >= cost_diff_threshold) {
       cost_diff_threshold = 1e38f;
@@ -267,11 +409,14 @@ BR_DEV uint32_t hq_histogram_combine(const EntropyTables& et, const HqHistos& ou
       continue;
     }
     const uint32_t best_idx1 = pairs[0].idx1, best_idx2 = pairs[0].idx2;
+    const float best_combo = pairs[0].cost_combo;
     hq_add(out, best_idx1, out, best_idx2);
-    out.cost[best_idx1] = pairs[0].cost_combo;
+    out.cost[best_idx1] = best_combo;
     cluster_size[best_idx1] += cluster_size[best_idx2];
-    for (uint32_t i = 0; i < symbols_size; ++i)
+    BR_SYNC();  // (every lane has read the old cluster size before any lane's store can land ... and reads the new one below)
+    for (uint32_t i = BR_TID; i < symbols_size; i += BR_NT)
       if (symbols[i] == best_idx2) symbols[i] = best_idx1;
+    BR_SYNC();
     for (uint32_t i = 0; i < num_clusters; ++i) {
       if (clusters[i] == best_idx2) {
         for (uint32_t k = i; k + 1 < num_clusters; ++k) clusters[k] = clusters[k + 1];
@@ -296,24 +441,18 @@ BR_DEV uint32_t hq_histogram_combine(const EntropyTables& et, const HqHistos& ou
       num_pairs = copy_to_idx;
     }
     for (uint32_t i = 0; i < num_clusters; ++i)
-      hq_compare_and_push(et, out, cluster_size, best_idx1, clusters[i], max_num_pairs, pairs, &num_pairs, tmp);
+      hq_compare_and_push(et, S, out, cluster_size, best_idx1, clusters[i], max_num_pairs, pairs, &num_pairs);
   }
   return num_clusters;
 }
 
-// BrotliHistogramBitCostDistance, cluster.rs:238-254; `tmp` = scratch row of `cand_set`
-BR_DEV float hq_bit_cost_distance(const EntropyTables& et, const HqHistos& h, uint32_t hi, const HqHistos& cand_set, uint32_t ci, uint32_t tmp) {
-  if (h.total[hi] == 0) return 0.0f;
-  {
-    uint32_t* t = cand_set.row(tmp);
-    const uint32_t* a = h.row(hi);
-    const uint32_t* b = cand_set.row(ci);
-    for (uint32_t k = 0; k < h.len; ++k) t[k] = a[k] + b[k];
-    cand_set.total[tmp] = h.total[hi] + cand_set.total[ci];
-  }
-  return hq_cost_of(et, cand_set, tmp) - cand_set.cost[ci];
+// BrotliHistogramBitCostDistance, cluster.rs:238-254, of the histogram in S.blk (total `blk_total`) to candidate ci
+BR_DEV float hq_bit_cost_distance(const EntropyTables& et, HqWaveScratch& S, uint32_t blk_total, const HqHistos& cand_set, uint32_t ci) {
+  if (blk_total == 0) return 0.0f;
+  return hq_cost_of_sum(et, S, S.blk, cand_set.row(ci), cand_set.len, blk_total + cand_set.total[ci]) - cand_set.cost[ci];
 }
 
+// ------------------------------------------------------------------------------------------------ block_splitter.rs
 // ------------------------------------------------------------------------------------------------ block_splitter.rs
 BR_DEV uint32_t hq_my_rand(uint32_t* seed) {  // :131-137
   *seed = *seed * 16807u;
@@ -322,24 +461,10 @@ BR_DEV uint32_t hq_my_rand(uint32_t* seed) {  // :131-137
 }
 BR_DEV float hq_bit_cost(const EntropyTables& et, uint32_t count) { return count == 0 ? -2.0f : br_fast_log2(et, count); }  // :224-230
 
+
 // ---- phase 1 of SplitByteVector, cooperatively: the item is entered by all lanes of a 64-lane workgroup (one lane in the
 // emulation).  Histogram counters are bumped by atomic adds (integers: any order gives the same histogram), the costs of
 // FindBlocks live in registers, two entropy codes per lane.
-#if defined(BROTLI_HOST_EMU)
-#define BR_ATOMIC_MIN_U32(p, v) (*(p) = *(p) < (v) ? *(p) : (v))
-#define HQ_LD32(p) (*(p))
-#else
-#define BR_ATOMIC_MIN_U32(p, v) atomicMin((p), (v))
-// counters that other lanes bump with atomic adds (performed in the L2) are read with device-scope loads: a plain load could
-// be served from a line the vector L1 fetched before the adds
-#define HQ_LD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#endif
-
-struct HqWaveScratch {  // workgroup shared memory
-  uint32_t first_pos[256];
-  uint32_t ctl[4];
-};
-
 // InitialEntropyCodes + RefineEntropyCodes, block_splitter.rs:139-222.  The sample positions come from a 32-bit
 // multiplicative generator that every lane steps for itself (uniform); a sample of `stride` symbols is one atomic add per lane.
 BR_DEV void hq_seed_entropy_codes(const HqSplitJob& J, const HqHistos& H) {
@@ -565,8 +690,16 @@ BR_DEV void hq_item_find_blocks(const EntropyTables& et, HqSplitJob& J, HqWaveSc
   }
 }
 
+// histogram of `n` symbols into workgroup memory (S.tmp or S.blk), by atomic adds
+BR_DEV void hq_block_histogram(uint32_t* dst, uint32_t len, const uint16_t* data, uint32_t n) {
+  for (uint32_t k = BR_TID; k < len; k += BR_NT) dst[k] = 0;
+  BR_SYNC();
+  for (uint32_t k = BR_TID; k < n; k += BR_NT) BR_ATOMIC_ADD_U32(&dst[data[k]], 1u);
+  BR_SYNC();
+}
+
 // phase 2: ClusterBlocks, block_splitter.rs:402-688.  Writes the split of (m, kind): types, lengths, starts, counts.
-BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
+BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J, HqWaveScratch& S) {
   const EntropyTables& et = B.et;
   const MbDesc& d = B.descs[J.m];
   MbResult& r = B.results[J.m];
@@ -575,18 +708,22 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
   uint32_t* lengths = B.block_lengths[kind] + d.block_base[kind];
   uint32_t* starts = B.block_start[kind] + d.block_base[kind];
   if (J.num_blocks == 0) {  // no symbols: one type, no blocks
-    r.num_types[kind] = 1;
-    r.num_blocks[kind] = 0;
-    starts[0] = 0;
+    if (BR_TID == 0) {
+      r.num_types[kind] = 1;
+      r.num_blocks[kind] = 0;
+      starts[0] = 0;
+    }
     return;
   }
   if (J.length < 128) {
-    r.num_types[kind] = 1;
-    r.num_blocks[kind] = 1;
-    types[0] = 0;
-    lengths[0] = J.length;
-    starts[0] = 0;
-    starts[1] = J.length;
+    if (BR_TID == 0) {
+      r.num_types[kind] = 1;
+      r.num_blocks[kind] = 1;
+      types[0] = 0;
+      lengths[0] = J.length;
+      starts[0] = 0;
+      starts[1] = J.length;
+    }
     return;
   }
   const uint16_t* data = J.data;
@@ -594,15 +731,19 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
   const uint8_t* block_ids = J.block_ids;
   uint32_t* histogram_symbols = J.histogram_symbols;
   uint32_t* block_lengths = J.block_lengths;
-  for (uint32_t i = 0; i < num_blocks; ++i) block_lengths[i] = 0;
-  {
-    uint32_t block_idx = 0;
+  // lengths of the runs of equal ids: position of every run end, then differences (J.new_index serves as the list of ends)
+  if (BR_TID == 0) {
+    uint32_t block_idx = 0, run = 0;
     for (uint32_t i = 0; i < length; ++i) {
-      block_lengths[block_idx]++;
-      if (i + 1 == length || block_ids[i] != block_ids[i + 1]) ++block_idx;
+      run++;
+      if (i + 1 == length || block_ids[i] != block_ids[i + 1]) {
+        block_lengths[block_idx++] = run;
+        run = 0;
+      }
     }
   }
-  HqHistos batch;  // 64 histograms + scratch rows 64, 65
+  BR_SYNC();
+  HqHistos batch;  // 64 histograms
   batch.data = J.batch_data;
   batch.total = J.batch_total;
   batch.cost = J.batch_cost;
@@ -616,30 +757,41 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
   uint32_t all_size = 0;
   uint32_t num_clusters = 0;
   uint32_t pos = 0;
-  uint32_t sizes[kHqBatch], new_clusters[kHqBatch], symbols[kHqBatch], remap[kHqBatch];
-  for (uint32_t i = 0; i < kHqBatch; ++i) sizes[i] = new_clusters[i] = symbols[i] = remap[i] = 0;
+  // per-batch arrays of BrotliHistogramCombine: in the job's scratch (clusters / new_index are free until the final pass)
+  uint32_t* sizes = J.clusters;
+  uint32_t* new_clusters = J.clusters + kHqBatch;
+  uint32_t* symbols = J.new_index;
+  uint32_t* remap = J.new_index + kHqBatch;
   for (uint32_t i = 0; i < num_blocks; i += kHqBatch) {
     const uint32_t num_to_combine = num_blocks - i < kHqBatch ? num_blocks - i : kHqBatch;
     for (uint32_t j = 0; j < num_to_combine; ++j) {
-      hq_clear(batch, j);
+      const uint32_t n = block_lengths[i + j];
+      hq_block_histogram(S.tmp, len, data + pos, n);
+      pos += n;
       uint32_t* row = batch.row(j);
-      for (uint32_t k = 0; k < block_lengths[i + j]; ++k) row[data[pos++]]++;
-      batch.total[j] = block_lengths[i + j];
-      batch.cost[j] = hq_cost_of(et, batch, j);
-      new_clusters[j] = j;
-      symbols[j] = j;
-      sizes[j] = 1;
+      for (uint32_t k = BR_TID; k < len; k += BR_NT) row[k] = S.tmp[k];
+      const float cost_j = hq_cost_in_tmp(et, S, len, n);
+      if (BR_TID == 0) {
+        batch.total[j] = n;
+        batch.cost[j] = cost_j;
+        new_clusters[j] = j;
+        symbols[j] = j;
+        sizes[j] = 1;
+      }
+      BR_SYNC();
     }
     const uint32_t num_new_clusters =
-        hq_histogram_combine(et, batch, sizes, symbols, new_clusters, J.pairs, num_to_combine, num_to_combine, kHqBatch, kHqBatchPairs, kHqBatch);
+        hq_histogram_combine(et, S, batch, sizes, symbols, new_clusters, J.pairs, num_to_combine, num_to_combine, kHqBatch, kHqBatchPairs);
     for (uint32_t j = 0; j < num_new_clusters; ++j) {
       hq_copy(all, all_size, batch, new_clusters[j]);
       cluster_size[all_size] = sizes[new_clusters[j]];
       all_size++;
       remap[new_clusters[j]] = j;
     }
+    BR_SYNC();
     for (uint32_t j = 0; j < num_to_combine; ++j) histogram_symbols[i + j] = num_clusters + remap[symbols[j]];
     num_clusters += num_new_clusters;
+    BR_SYNC();
   }
   uint32_t max_num_pairs = 64u * num_clusters;
   {
@@ -648,28 +800,24 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
   }
   uint32_t* clusters = J.clusters;
   for (uint32_t i = 0; i < num_clusters; ++i) clusters[i] = i;
-  // the scratch row of `all` for the pair evaluation: one past the used rows would overrun when every block kept its own
-  // cluster, so the two spare rows of the batch set serve -- through a view that shares `all`'s rows up to all_size
-  // (hq_compare_and_push only touches out.row(tmp), out.total[tmp], out.cost[tmp])
-  const uint32_t tmp_all = num_blocks;  // J.all_* are allocated with num_blocks + 2 rows
+  BR_SYNC();
   const uint32_t num_final_clusters =
-      hq_histogram_combine(et, all, cluster_size, histogram_symbols, clusters, J.pairs, num_clusters, num_blocks, 256, max_num_pairs, tmp_all);
+      hq_histogram_combine(et, S, all, cluster_size, histogram_symbols, clusters, J.pairs, num_clusters, num_blocks, 256, max_num_pairs);
   uint32_t* new_index = J.new_index;
   const uint32_t kInvalidIndex = 0xffffffffu;
   for (uint32_t i = 0; i < num_clusters; ++i) new_index[i] = kInvalidIndex;
+  BR_SYNC();
   pos = 0;
   {
     uint32_t next_index = 0;
-    const uint32_t hrow = kHqBatch;  // scratch row of the batch set holds the histogram of the block
     for (uint32_t i = 0; i < num_blocks; ++i) {
-      hq_clear(batch, hrow);
-      uint32_t* row = batch.row(hrow);
-      for (uint32_t j = 0; j < block_lengths[i]; ++j) row[data[pos++]]++;
-      batch.total[hrow] = block_lengths[i];
+      const uint32_t n = block_lengths[i];
+      hq_block_histogram(S.blk, len, data + pos, n);
+      pos += n;
       uint32_t best_out = i == 0 ? histogram_symbols[0] : histogram_symbols[i - 1];
-      float best_bits = hq_bit_cost_distance(et, batch, hrow, all, best_out, tmp_all);
+      float best_bits = hq_bit_cost_distance(et, S, n, all, best_out);
       for (uint32_t j = 0; j < num_final_clusters; ++j) {
-        const float cur_bits = hq_bit_cost_distance(et, batch, hrow, all, clusters[j], tmp_all);
+        const float cur_bits = hq_bit_cost_distance(et, S, n, all, clusters[j]);
         if (cur_bits < best_bits) {
           best_bits = cur_bits;
           best_out = clusters[j];
@@ -679,7 +827,8 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J) {
       if (new_index[best_out] == kInvalidIndex) new_index[best_out] = next_index++;
     }
   }
-  {
+  BR_SYNC();
+  if (BR_TID == 0) {
     uint32_t cur_length = 0, block_idx = 0, start = 0;
     uint8_t max_type = 0;
     for (uint32_t i = 0; i < num_blocks; ++i) {
@@ -735,14 +884,16 @@ BR_DEV void hq_prefix_encode_distance(uint32_t distance_code, uint32_t ndirect, 
 BR_DEV uint32_t hq_distance_alphabet_size(uint32_t npostfix, uint32_t ndirect) { return 16 + ndirect + (24u << (npostfix + 1)); }
 BR_DEV uint32_t hq_max_distance(uint32_t npostfix, uint32_t ndirect) { return ndirect + (1u << (24 + npostfix + 2)) - (1u << (npostfix + 2)); }
 
-// ComputeDistanceCost, metablock.rs:88-131.  `histo`: 544 counters of scratch.
-BR_DEV bool hq_distance_cost(const MbBuffers& B, const MbDesc& d, uint32_t new_npostfix, uint32_t new_ndirect, uint32_t* histo, double* cost) {
+
+// ComputeDistanceCost, metablock.rs:88-131: the histogram of the re-coded distance symbols in workgroup memory (atomic
+// adds), their extra bits as an integer sum (the reference adds them up in f64: small integers, exact in any order).
+BR_DEV bool hq_distance_cost(const MbBuffers& B, const MbDesc& d, HqWaveScratch& S, uint32_t new_npostfix, uint32_t new_ndirect, double* cost) {
   const bool equal_params = d.dist_postfix_bits == new_npostfix && d.num_direct_distance_codes == new_ndirect;
   const uint32_t new_max_distance = hq_max_distance(new_npostfix, new_ndirect);
-  double extra_bits = 0.0;
-  uint32_t total = 0;
-  for (uint32_t i = 0; i < kNumDistanceHistoSymbols; ++i) histo[i] = 0;
-  for (uint32_t c = d.cmd_offset; c < d.cmd_offset + d.n_cmds; ++c) {
+  for (uint32_t i = BR_TID; i < kNumDistanceHistoSymbols; i += BR_NT) S.tmp[i] = 0;
+  if (BR_TID == 0) S.ctl[0] = S.ctl[1] = S.ctl[2] = 0;  // too far, symbols, extra bits
+  BR_SYNC();
+  for (uint32_t c = d.cmd_offset + BR_TID; c < d.cmd_offset + d.n_cmds; c += BR_NT) {
     const Command cmd = B.cmds[c];
     if (!br_command_has_distance(cmd)) continue;
     uint16_t dist_prefix;
@@ -751,26 +902,39 @@ BR_DEV bool hq_distance_cost(const MbBuffers& B, const MbDesc& d, uint32_t new_n
       dist_prefix = cmd.dist_prefix_;
     } else {
       const uint32_t distance = hq_restore_distance_code(cmd, d.num_direct_distance_codes, d.dist_postfix_bits);
-      if (distance > new_max_distance) return false;
+      if (distance > new_max_distance) {
+        BR_ATOMIC_ADD_U32(&S.ctl[0], 1u);
+        continue;
+      }
       hq_prefix_encode_distance(distance, new_ndirect, new_npostfix, &dist_prefix, &dist_extra);
     }
-    histo[dist_prefix & 0x3ffu]++;
-    total++;
-    extra_bits += (double)(dist_prefix >> 10);
+    BR_ATOMIC_ADD_U32(&S.tmp[dist_prefix & 0x3ffu], 1u);
+    BR_ATOMIC_ADD_U32(&S.ctl[1], 1u);
+    BR_ATOMIC_ADD_U32(&S.ctl[2], (uint32_t)(dist_prefix >> 10));
   }
-  *cost = (double)hq_population_cost(B.et, histo, kNumDistanceHistoSymbols, total) + extra_bits;
+  BR_SYNC();
+  const bool too_far = S.ctl[0] != 0;
+  const uint32_t total = S.ctl[1];
+  const double extra_bits = (double)S.ctl[2];
+  BR_SYNC();  // (every lane has read S.ctl)
+  if (too_far) return false;
+  *cost = (double)hq_cost_in_tmp(B.et, S, kNumDistanceHistoSymbols, total) + extra_bits;
   return true;
 }
 
 // the distance-parameter search of BrotliBuildMetaBlock (metablock.rs:160-240) + RecomputeDistancePrefixes (:62-86) on the
 // meta-block's own copy of the commands.  Result in MbResult::hq_postfix / hq_ndirect.
-BR_DEV void hq_item_distance_params(const MbBuffers& B, uint32_t m, uint32_t* histo) {
+BR_DEV void hq_item_distance_params(const MbBuffers& B, uint32_t m, HqWaveScratch& S) {
   const MbDesc& d = B.descs[m];
   MbResult& r = B.results[m];
   uint32_t best_npostfix = d.dist_postfix_bits, best_ndirect = d.num_direct_distance_codes;
-  r.hq_postfix = best_npostfix;
-  r.hq_ndirect = best_ndirect;
-  if (d.uncompressed) return;
+  if (d.uncompressed) {
+    if (BR_TID == 0) {
+      r.hq_postfix = best_npostfix;
+      r.hq_ndirect = best_ndirect;
+    }
+    return;
+  }
   uint32_t ndirect_msb = 0;
   bool check_orig = true;
   double best_dist_cost = 1e99;
@@ -779,7 +943,7 @@ BR_DEV void hq_item_distance_params(const MbBuffers& B, uint32_t m, uint32_t* hi
       const uint32_t ndirect = ndirect_msb << npostfix;
       double dist_cost = 0.0;
       if (npostfix == d.dist_postfix_bits && ndirect == d.num_direct_distance_codes) check_orig = false;
-      const bool skip = !hq_distance_cost(B, d, npostfix, ndirect, histo, &dist_cost);
+      const bool skip = !hq_distance_cost(B, d, S, npostfix, ndirect, &dist_cost);
       if (skip || dist_cost > best_dist_cost) break;
       best_dist_cost = dist_cost;
       best_npostfix = npostfix;
@@ -791,16 +955,18 @@ BR_DEV void hq_item_distance_params(const MbBuffers& B, uint32_t m, uint32_t* hi
   }
   if (check_orig) {
     double dist_cost = 0.0;
-    hq_distance_cost(B, d, d.dist_postfix_bits, d.num_direct_distance_codes, histo, &dist_cost);
+    hq_distance_cost(B, d, S, d.dist_postfix_bits, d.num_direct_distance_codes, &dist_cost);
     if (dist_cost < best_dist_cost) {
       best_npostfix = d.dist_postfix_bits;
       best_ndirect = d.num_direct_distance_codes;
     }
   }
-  r.hq_postfix = best_npostfix;
-  r.hq_ndirect = best_ndirect;
+  if (BR_TID == 0) {
+    r.hq_postfix = best_npostfix;
+    r.hq_ndirect = best_ndirect;
+  }
   if (best_npostfix != d.dist_postfix_bits || best_ndirect != d.num_direct_distance_codes) {
-    for (uint32_t c = d.cmd_offset; c < d.cmd_offset + d.n_cmds; ++c) {
+    for (uint32_t c = d.cmd_offset + BR_TID; c < d.cmd_offset + d.n_cmds; c += BR_NT) {
       Command cmd = B.cmds_rw[c];
       if (!br_command_has_distance(cmd)) continue;
       const uint32_t code = hq_restore_distance_code(cmd, d.num_direct_distance_codes, d.dist_postfix_bits);
@@ -900,7 +1066,7 @@ BR_DEV void hq_item_command_context_count(const MbBuffers& B, uint32_t c) {
 
 // ---- BrotliClusterHistograms, cluster.rs:353-465 (+ HistogramRemap :261-297, HistogramReindex :310-351), and the copy of
 // the result into the meta-block's histogram rows and context map
-BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J) {
+BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J, HqWaveScratch& S) {
   const EntropyTables& et = B.et;
   const MbDesc& d = B.descs[J.m];
   MbResult& r = B.results[J.m];
@@ -917,51 +1083,67 @@ BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J
   out.total = J.out_total;
   out.cost = J.out_cost;
   out.len = len;
-  const uint32_t tmp = in_size;  // scratch row
-  for (uint32_t i = 0; i < in_size; ++i) {
-    uint32_t t = 0;
-    const uint32_t* row = inp.row(i);
-    for (uint32_t k = 0; k < len; ++k) t += row[k];
-    J.in_total[i] = t;
-  }
   uint32_t* cluster_size = J.cluster_size;
   uint32_t* clusters = J.clusters;
   uint32_t* symbols = J.symbols;
   uint32_t num_clusters = 0;
-  for (uint32_t i = 0; i < in_size; ++i) cluster_size[i] = 1;
   for (uint32_t i = 0; i < in_size; ++i) {
-    uint32_t* o = out.row(i);
+    // copy + total (an integer sum: order-free) + cost
     const uint32_t* s = inp.row(i);
-    for (uint32_t k = 0; k < len; ++k) o[k] = s[k];
-    out.total[i] = J.in_total[i];
-    out.cost[i] = hq_population_cost(et, s, len, J.in_total[i]);
-    symbols[i] = i;
+    uint32_t* o = out.row(i);
+    uint32_t part = 0;
+    for (uint32_t k = BR_TID; k < len; k += BR_NT) {
+      const uint32_t v = s[k];
+      o[k] = v;
+      S.tmp[k] = v;
+      part += v;
+    }
+    if (BR_TID == 0) S.ctl[0] = 0;
+    BR_SYNC();
+    BR_ATOMIC_ADD_U32(&S.ctl[0], part);
+    BR_SYNC();
+    const uint32_t t = S.ctl[0];
+    const float cost_i = hq_cost_in_tmp(et, S, len, t);
+    if (BR_TID == 0) {
+      J.in_total[i] = t;
+      out.total[i] = t;
+      out.cost[i] = cost_i;
+      cluster_size[i] = 1;
+      symbols[i] = i;
+    }
+    BR_SYNC();
   }
   for (uint32_t i = 0; i < in_size; i += kHqBatch) {
     const uint32_t num_to_combine = in_size - i < kHqBatch ? in_size - i : kHqBatch;
     for (uint32_t j = 0; j < num_to_combine; ++j) clusters[num_clusters + j] = i + j;
-    const uint32_t num_new_clusters = hq_histogram_combine(et, out, cluster_size, symbols + i, clusters + num_clusters, J.pairs, num_to_combine,
-                                                           num_to_combine, 256, kHqBatchPairs, tmp);
+    BR_SYNC();
+    const uint32_t num_new_clusters = hq_histogram_combine(et, S, out, cluster_size, symbols + i, clusters + num_clusters, J.pairs, num_to_combine,
+                                                           num_to_combine, 256, kHqBatchPairs);
     num_clusters += num_new_clusters;
   }
   {
     uint32_t max_num_pairs = 64u * num_clusters;
     const uint64_t alt = (uint64_t)(num_clusters / 2) * num_clusters;
     if (alt < max_num_pairs) max_num_pairs = (uint32_t)alt;
-    num_clusters = hq_histogram_combine(et, out, cluster_size, symbols, clusters, J.pairs, num_clusters, in_size, 256, max_num_pairs, tmp);
+    num_clusters = hq_histogram_combine(et, S, out, cluster_size, symbols, clusters, J.pairs, num_clusters, in_size, 256, max_num_pairs);
   }
   // BrotliHistogramRemap
   for (uint32_t i = 0; i < in_size; ++i) {
+    const uint32_t* s = inp.row(i);
+    for (uint32_t k = BR_TID; k < len; k += BR_NT) S.blk[k] = s[k];
+    BR_SYNC();
+    const uint32_t t = J.in_total[i];
     uint32_t best_out = i == 0 ? symbols[0] : symbols[i - 1];
-    float best_bits = hq_bit_cost_distance(et, inp, i, out, best_out, tmp);
+    float best_bits = hq_bit_cost_distance(et, S, t, out, best_out);
     for (uint32_t j = 0; j < num_clusters; ++j) {
-      const float cur_bits = hq_bit_cost_distance(et, inp, i, out, clusters[j], tmp);
+      const float cur_bits = hq_bit_cost_distance(et, S, t, out, clusters[j]);
       if (cur_bits < best_bits) {
         best_bits = cur_bits;
         best_out = clusters[j];
       }
     }
     symbols[i] = best_out;
+    BR_SYNC();
   }
   for (uint32_t i = 0; i < num_clusters; ++i) hq_clear(out, clusters[i]);
   for (uint32_t i = 0; i < in_size; ++i) hq_add(out, symbols[i], inp, i);
@@ -977,6 +1159,7 @@ BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J
         ++next_index;
       }
     }
+    BR_SYNC();
     HqHistos re;
     re.data = J.reindex_data;
     re.total = J.reindex_total;
@@ -984,28 +1167,24 @@ BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J
     re.len = len;
     next_index = 0;
     for (uint32_t i = 0; i < in_size; ++i) {
-      if (new_index[symbols[i]] == next_index) {
-        hq_copy(re, next_index, out, symbols[i]);
+      const uint32_t sym = symbols[i];
+      if (new_index[sym] == next_index) {
+        hq_copy(re, next_index, out, sym);
         ++next_index;
       }
-      symbols[i] = new_index[symbols[i]];
+      BR_SYNC();  // (every lane has read symbols[i] before it is rewritten)
+      symbols[i] = new_index[sym];
     }
+    BR_SYNC();
     // into the meta-block's histogram rows
     uint32_t* H = B.histo[J.kind] + (size_t)d.histo_base[J.kind] * len;
-    for (uint32_t i = 0; i < next_index; ++i) {
-      const uint32_t* s = re.row(i);
-      for (uint32_t k = 0; k < len; ++k) H[(size_t)i * len + k] = s[k];
-    }
+    for (uint32_t i = BR_TID; i < next_index * len; i += BR_NT) H[i] = re.data[i];
   }
-  r.num_histos[J.kind] = next_index;
+  if (BR_TID == 0) r.num_histos[J.kind] = next_index;
   if (J.expand64) {
-    for (uint32_t i = in_size; i != 0;) {
-      --i;
-      const uint32_t val = symbols[i];
-      for (uint32_t j = 0; j < 64; ++j) map[(i << 6) + j] = val;
-    }
+    for (uint32_t i = BR_TID; i < in_size * 64; i += BR_NT) map[i] = symbols[i >> 6];
   } else {
-    for (uint32_t i = 0; i < in_size; ++i) map[i] = symbols[i];
+    for (uint32_t i = BR_TID; i < in_size; i += BR_NT) map[i] = symbols[i];
   }
 }
 

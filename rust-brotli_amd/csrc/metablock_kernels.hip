@@ -263,12 +263,13 @@ void mb_hq_utf8_census(const MbBuffers& B) {
   hipLaunchKernelGGL(k_hq_utf8_census, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B);
   HIP_CHECK(hipGetLastError());
 }
-__global__ __launch_bounds__(64) void k_hq_distance_params(MbBuffers B, uint32_t* histo) {
-  if (threadIdx.x == 0) hq_item_distance_params(B, blockIdx.x, histo + (size_t)blockIdx.x * kNumDistanceHistoSymbols);
+__global__ __launch_bounds__(64) void k_hq_distance_params(MbBuffers B) {
+  __shared__ HqWaveScratch S;
+  hq_item_distance_params(B, blockIdx.x, S);
 }
-void mb_hq_distance_params(const MbBuffers& B, uint32_t* histo_scratch_dev) {
+void mb_hq_distance_params(const MbBuffers& B) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_hq_distance_params, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B, histo_scratch_dev);
+  hipLaunchKernelGGL(k_hq_distance_params, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B);
   HIP_CHECK(hipGetLastError());
 }
 void mb_hq_gather_symbols(const MbBuffers& B) {
@@ -287,7 +288,8 @@ void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs
   HIP_CHECK(hipGetLastError());
 }
 __global__ __launch_bounds__(64) void k_hq_cluster_blocks(MbBuffers B, const HqSplitJob* jobs) {
-  if (threadIdx.x == 0) hq_item_cluster_blocks(B, jobs[blockIdx.x]);
+  __shared__ HqWaveScratch S;
+  hq_item_cluster_blocks(B, jobs[blockIdx.x], S);
 }
 void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs) {
   if (n_jobs == 0) return;
@@ -301,7 +303,8 @@ void mb_hq_context_histograms(const MbBuffers& B) {
   HIP_CHECK(hipGetLastError());
 }
 __global__ __launch_bounds__(64) void k_hq_cluster_histograms(MbBuffers B, const HqClusterJob* jobs) {
-  if (threadIdx.x == 0) hq_item_cluster_histograms(B, jobs[blockIdx.x]);
+  __shared__ HqWaveScratch S;
+  hq_item_cluster_histograms(B, jobs[blockIdx.x], S);
 }
 void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs) {
   if (n_jobs == 0) return;

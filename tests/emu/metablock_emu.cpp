@@ -114,8 +114,9 @@ void mb_hq_utf8_census(const MbBuffers& B) {
   for (uint32_t m = 0; m < B.n_mb; ++m)
     if (!B.descs[m].uncompressed) hq_item_utf8_census(B, m);
 }
-void mb_hq_distance_params(const MbBuffers& B, uint32_t* histo) {
-  for (uint32_t m = 0; m < B.n_mb; ++m) hq_item_distance_params(B, m, histo + (size_t)m * kNumDistanceHistoSymbols);
+void mb_hq_distance_params(const MbBuffers& B) {
+  HqWaveScratch S;
+  for (uint32_t m = 0; m < B.n_mb; ++m) hq_item_distance_params(B, m, S);
 }
 void mb_hq_gather_symbols(const MbBuffers& B) {
   for (uint32_t i = 0; i < B.n_lits; ++i) hq_item_literal_symbol(B, i);
@@ -126,14 +127,16 @@ void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs, uint32_t n_jobs) {
   for (uint32_t i = 0; i < n_jobs; ++i) hq_item_find_blocks(B.et, jobs[i], S);
 }
 void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs, uint32_t n_jobs) {
-  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_blocks(B, jobs[i]);
+  HqWaveScratch S;
+  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_blocks(B, jobs[i], S);
 }
 void mb_hq_context_histograms(const MbBuffers& B) {
   for (uint32_t i = 0; i < B.n_lits; ++i) hq_item_literal_context_count(B, i);
   for (uint32_t c = 0; c < B.n_cmds; ++c) hq_item_command_context_count(B, c);
 }
 void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs, uint32_t n_jobs) {
-  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_histograms(B, jobs[i]);
+  HqWaveScratch S;
+  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_histograms(B, jobs[i], S);
 }
 
 void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits) {
