@@ -18,6 +18,11 @@
 
 #include "metablock_items.h"
 
+#if !defined(BROTLI_HOST_EMU)
+// wavefront-wide minimum of the device library (DPP row operations; the result is returned to every lane)
+extern "C" __device__ __attribute__((const)) float __ockl_wfred_min_f32(float);
+#endif
+
 namespace brotli_mi355x {
 
 static constexpr uint32_t kHqMaxAlphabet = 704;
@@ -583,11 +588,7 @@ BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, con
           // every cost is >= 0 (insert costs are, and the carried part lies in [0, switch cost]): absent lanes hold a huge value
           float v = has0 ? c0 : 3.0e38f;
           if (has1 && c1 < v) v = c1;
-          for (int off = 32; off > 0; off >>= 1) {
-            const float o = __shfl_xor(v, off, 64);
-            v = o < v ? o : v;
-          }
-          const float min_cost = v;
+          const float min_cost = __ockl_wfred_min_f32(v);
           const unsigned long long e0 = __ballot(has0 && c0 == min_cost), e1 = __ballot(has1 && c1 == min_cost);
           const uint32_t best = e0 != 0 ? (uint32_t)__ffsll((long long)e0) - 1u : 64u + (uint32_t)__ffsll((long long)e1) - 1u;
           float block_switch_cost = J.block_switch_cost;
@@ -983,45 +984,68 @@ BR_DEV uint32_t hq_census_byte(const MbBuffers& B, const MbDesc& d, uint32_t i) 
   const uint32_t p = d.start + i;  // the reference reads data_mo[p] = ring[p - 2] (a custom dictionary lies in the ring too)
   return p >= 2 ? B.text[p - 2] : 0u;
 }
-BR_DEV void hq_item_utf8_census(const MbBuffers& B, uint32_t m) {
+// BrotliParseAsUTF8 (utf8_util.rs:3-43) at offset i of a census of `length` bytes: bytes consumed, and whether they count
+// as UTF-8 (symbol < 0x110000).  Returns bytes | valid << 3.
+BR_DEV uint32_t hq_parse_utf8(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t size) {
+  uint32_t bytes_read = 0;
+  int32_t symbol = 0;
+  if ((b0 & 0x80) == 0 && b0 > 0) {
+    symbol = (int32_t)b0;
+    bytes_read = 1;
+  }
+  if (bytes_read == 0 && size > 1 && (b0 & 0xe0) == 0xc0 && (b1 & 0xc0) == 0x80) {
+    symbol = (int32_t)(((b0 & 0x1f) << 6) | (b1 & 0x3f));
+    if (symbol > 0x7f) bytes_read = 2;
+  }
+  if (bytes_read == 0 && size > 2 && (b0 & 0xf0) == 0xe0 && (b1 & 0xc0) == 0x80 && (b2 & 0xc0) == 0x80) {
+    symbol = (int32_t)(((b0 & 0x0f) << 12) | ((b1 & 0x3f) << 6) | (b2 & 0x3f));
+    if (symbol > 0x7ff) bytes_read = 3;
+  }
+  if (bytes_read == 0 && size > 3 && (b0 & 0xf8) == 0xf0 && (b1 & 0xc0) == 0x80 && (b2 & 0xc0) == 0x80 && (b3 & 0xc0) == 0x80) {
+    symbol = (int32_t)(((b0 & 0x07) << 18) | ((b1 & 0x3f) << 12) | ((b2 & 0x3f) << 6) | (b3 & 0x3f));
+    if (symbol > 0xffff && symbol <= 0x10ffff) bytes_read = 4;
+  }
+  if (bytes_read == 0) {
+    symbol = (int32_t)(0x110000u | b0);
+    bytes_read = 1;
+  }
+  return bytes_read | (symbol < 0x110000 ? 8u : 0u);
+}
+
+// What a parse that starts at offset i consumes depends on the four bytes there only: every lane classifies its offsets of a
+// tile (bytes consumed + "counts as UTF-8" per offset, in workgroup memory), and one lane then walks the chain of offsets the
+// parse really visits -- one short read per symbol instead of four dependent trips to memory.
+struct HqCensusScratch {
+  static constexpr uint32_t kTile = 4096;
+  uint8_t step[kTile];
+  uint32_t ctl[4];
+};
+BR_DEV void hq_item_utf8_census(const MbBuffers& B, uint32_t m, HqCensusScratch& S) {
   const MbDesc& d = B.descs[m];
   const uint32_t length = d.end - d.start;
-  uint32_t size_utf8 = 0;
-  uint32_t i = 0;
-  while (i < length) {
-    const uint32_t size = length - i;
-    const uint32_t b0 = hq_census_byte(B, d, i);
-    // (bytes behind the meta-block's end are read from the buffer as they lie there: they are the stream's next bytes or,
-    // at the very end, whatever follows -- only looked at when size > 1 .. 3, i.e. never past `length`)
-    const uint32_t b1 = size > 1 ? hq_census_byte(B, d, i + 1) : 0u;
-    const uint32_t b2 = size > 2 ? hq_census_byte(B, d, i + 2) : 0u;
-    const uint32_t b3 = size > 3 ? hq_census_byte(B, d, i + 3) : 0u;
-    uint32_t bytes_read = 0;
-    int32_t symbol = 0;
-    if ((b0 & 0x80) == 0 && b0 > 0) {
-      symbol = (int32_t)b0;
-      bytes_read = 1;
+  uint32_t size_utf8 = 0;  // (lane 0's)
+  uint32_t i = 0;          // next offset of the parse (lane 0's; it may lie up to three bytes inside the next tile)
+  for (uint32_t base = 0; base < length; base += HqCensusScratch::kTile) {
+    const uint32_t n = length - base < HqCensusScratch::kTile ? length - base : HqCensusScratch::kTile;
+    for (uint32_t k = BR_TID; k < n; k += BR_NT) {
+      const uint32_t o = base + k, size = length - o;
+      const uint32_t b0 = hq_census_byte(B, d, o);
+      const uint32_t b1 = size > 1 ? hq_census_byte(B, d, o + 1) : 0u;
+      const uint32_t b2 = size > 2 ? hq_census_byte(B, d, o + 2) : 0u;
+      const uint32_t b3 = size > 3 ? hq_census_byte(B, d, o + 3) : 0u;
+      S.step[k] = (uint8_t)hq_parse_utf8(b0, b1, b2, b3, size);
     }
-    if (bytes_read == 0 && size > 1 && (b0 & 0xe0) == 0xc0 && (b1 & 0xc0) == 0x80) {
-      symbol = (int32_t)(((b0 & 0x1f) << 6) | (b1 & 0x3f));
-      if (symbol > 0x7f) bytes_read = 2;
+    BR_SYNC();
+    if (BR_TID == 0) {
+      while (i < base + n) {
+        const uint32_t s = S.step[i - base];
+        if (s & 8u) size_utf8 += s & 7u;
+        i += s & 7u;
+      }
     }
-    if (bytes_read == 0 && size > 2 && (b0 & 0xf0) == 0xe0 && (b1 & 0xc0) == 0x80 && (b2 & 0xc0) == 0x80) {
-      symbol = (int32_t)(((b0 & 0x0f) << 12) | ((b1 & 0x3f) << 6) | (b2 & 0x3f));
-      if (symbol > 0x7ff) bytes_read = 3;
-    }
-    if (bytes_read == 0 && size > 3 && (b0 & 0xf8) == 0xf0 && (b1 & 0xc0) == 0x80 && (b2 & 0xc0) == 0x80 && (b3 & 0xc0) == 0x80) {
-      symbol = (int32_t)(((b0 & 0x07) << 18) | ((b1 & 0x3f) << 12) | ((b2 & 0x3f) << 6) | (b3 & 0x3f));
-      if (symbol > 0xffff && symbol <= 0x10ffff) bytes_read = 4;
-    }
-    if (bytes_read == 0) {
-      symbol = (int32_t)(0x110000u | b0);
-      bytes_read = 1;
-    }
-    i += bytes_read;
-    if (symbol < 0x110000) size_utf8 += bytes_read;
+    BR_SYNC();
   }
-  B.results[m].hq_mostly_utf8 = (float)size_utf8 > 0.75f * (float)length ? 1u : 0u;
+  if (BR_TID == 0) B.results[m].hq_mostly_utf8 = (float)size_utf8 > 0.75f * (float)length ? 1u : 0u;
 }
 
 // ---- symbol streams of the three splitters (CopyLiteralsToByteArray etc., block_splitter.rs:97-129, 860-927)

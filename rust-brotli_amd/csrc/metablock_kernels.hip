@@ -255,12 +255,13 @@ void mb_emit(const MbBuffers& B) {
 }
 
 // ---- quality >= 10: one lane per sequential job (metablock_hq.h says why), all lanes for the per-symbol passes
-__global__ __launch_bounds__(64) void k_hq_utf8_census(MbBuffers B) {
-  if (threadIdx.x == 0 && !B.descs[blockIdx.x].uncompressed) hq_item_utf8_census(B, blockIdx.x);
+__global__ __launch_bounds__(256) void k_hq_utf8_census(MbBuffers B) {
+  __shared__ HqCensusScratch S;
+  if (!B.descs[blockIdx.x].uncompressed) hq_item_utf8_census(B, blockIdx.x, S);
 }
 void mb_hq_utf8_census(const MbBuffers& B) {
   if (B.n_mb == 0) return;
-  hipLaunchKernelGGL(k_hq_utf8_census, dim3(B.n_mb), dim3(64), 0, BR_STREAM, B);
+  hipLaunchKernelGGL(k_hq_utf8_census, dim3(B.n_mb), dim3(256), 0, BR_STREAM, B);
   HIP_CHECK(hipGetLastError());
 }
 __global__ __launch_bounds__(64) void k_hq_distance_params(MbBuffers B) {

@@ -111,8 +111,9 @@ void mb_emit(const MbBuffers& B) {
 }
 
 void mb_hq_utf8_census(const MbBuffers& B) {
+  HqCensusScratch S;
   for (uint32_t m = 0; m < B.n_mb; ++m)
-    if (!B.descs[m].uncompressed) hq_item_utf8_census(B, m);
+    if (!B.descs[m].uncompressed) hq_item_utf8_census(B, m, S);
 }
 void mb_hq_distance_params(const MbBuffers& B) {
   HqWaveScratch S;
