@@ -636,9 +636,14 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
           max_pairs = std::max<uint64_t>(max_pairs, kHqBatchPairs);
           j.histogram_symbols = mm.alloc<uint32_t>(n + 8);
           j.block_lengths = mm.alloc<uint32_t>(n + 8);
-          j.batch_data = mm.alloc<uint32_t>((size_t)(kHqBatch + 2) * j.alphabet);
-          j.batch_total = mm.alloc<uint32_t>(kHqBatch + 2);
-          j.batch_cost = mm.alloc<float>(kHqBatch + 2);
+          j.block_pos = mm.alloc<uint32_t>(n + 8);
+          j.batch_data = mm.alloc<uint32_t>((n + 2) * j.alphabet);
+          j.batch_total = mm.alloc<uint32_t>(n + 8);
+          j.batch_cost = mm.alloc<float>(n + 8);
+          j.batch_sizes = mm.alloc<uint32_t>(n + 8);
+          j.batch_clusters = mm.alloc<uint32_t>(n + 8);
+          j.batch_symbols = mm.alloc<uint32_t>(n + 8);
+          j.batch_count = mm.alloc<uint32_t>(n / kHqBatch + 8);
           j.all_data = mm.alloc<uint32_t>((n + 2) * j.alphabet);
           j.all_total = mm.alloc<uint32_t>(n + 2);
           j.all_cost = mm.alloc<float>(n + 2);
@@ -666,7 +671,13 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       B.mb_out_bit = mm.alloc<uint64_t>(n_mb + 1);
       dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
       dev_h2d(jobs_dev, jobs.data(), jobs.size() * sizeof(HqSplitJob));
-      mb_hq_cluster_blocks(B, jobs_dev, (uint32_t)jobs.size());
+      std::vector<HqBatchRef> batch_refs;
+      for (uint32_t ji = 0; ji < jobs.size(); ++ji)
+        if (jobs[ji].length >= 128)
+          for (uint32_t b = 0; b * kHqBatch < jobs[ji].num_blocks; ++b) batch_refs.push_back({ji, b});
+      HqBatchRef* batch_refs_dev = mm.alloc<HqBatchRef>(batch_refs.size() + 1);
+      dev_h2d(batch_refs_dev, batch_refs.data(), batch_refs.size() * sizeof(HqBatchRef));
+      mb_hq_cluster_blocks(B, jobs_dev, (uint32_t)jobs.size(), batch_refs_dev, (uint32_t)batch_refs.size());
       dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
       stats.ms_phase[2] += clk.lap(prof, "hq-cluster-blocks");
       // context histograms and the clustered context maps (histogram.rs:465-534, cluster.rs:353-465)
@@ -711,6 +722,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
           j.clusters = mm.alloc<uint32_t>(n + 8);
           j.symbols = mm.alloc<uint32_t>(n + 8);
           j.new_index = mm.alloc<uint32_t>(n + 8);
+          j.batch_count = mm.alloc<uint32_t>(n / kHqBatch + 8);
           j.reindex_data = mm.alloc<uint32_t>(re * j.len + 8);
           j.reindex_total = mm.alloc<uint32_t>(re + 8);
           j.reindex_cost = mm.alloc<float>(re + 8);
@@ -722,7 +734,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       mb_hq_context_histograms(B);
       HqClusterJob* cjobs_dev = mm.alloc<HqClusterJob>(cjobs.size() + 1);
       dev_h2d(cjobs_dev, cjobs.data(), cjobs.size() * sizeof(HqClusterJob));
-      mb_hq_cluster_histograms(B, cjobs_dev, (uint32_t)cjobs.size());
+      std::vector<HqBatchRef> cbatch_refs;
+      for (uint32_t ji = 0; ji < cjobs.size(); ++ji)
+        for (uint32_t b = 0; b * kHqBatch < cjobs[ji].in_size; ++b) cbatch_refs.push_back({ji, b});
+      HqBatchRef* cbatch_refs_dev = mm.alloc<HqBatchRef>(cbatch_refs.size() + 1);
+      dev_h2d(cbatch_refs_dev, cbatch_refs.data(), cbatch_refs.size() * sizeof(HqBatchRef));
+      mb_hq_cluster_histograms(B, cjobs_dev, (uint32_t)cjobs.size(), cbatch_refs_dev, (uint32_t)cbatch_refs.size());
       dev_d2h(results.data(), B.results, n_mb * sizeof(MbResult));
       for (uint32_t m = 0; m < n_mb; ++m) results[m].num_histos[kSplitCommand] = results[m].num_types[kSplitCommand];
       dev_h2d(B.results, results.data(), n_mb * sizeof(MbResult));

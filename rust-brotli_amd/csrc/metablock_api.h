@@ -12,6 +12,7 @@ namespace brotli_mi355x {
 struct MbBuffers;  // metablock_items.h
 struct HqSplitJob;    // metablock_hq.h
 struct HqClusterJob;
+struct HqBatchRef;
 
 static constexpr uint32_t kContextStatsWords = 512;  // per meta-block: [0..9) bigram prefix histogram
                                                       // (encode.rs:1885-1918), [16..48) combined 5-bit histogram,
@@ -48,9 +49,10 @@ void mb_hq_utf8_census(const MbBuffers& B);
 void mb_hq_distance_params(const MbBuffers& B);
 void mb_hq_gather_symbols(const MbBuffers& B);
 void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs);
-void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs);
+void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs, const HqBatchRef* batches_dev, uint32_t n_batches);
 void mb_hq_context_histograms(const MbBuffers& B);
-void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs);
+void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs, const HqBatchRef* batches_dev,
+                              uint32_t n_batches);
 
 }  // namespace brotli_mi355x
 #endif

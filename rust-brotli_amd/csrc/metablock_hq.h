@@ -42,6 +42,12 @@ struct HqPair {  // HistogramPair, cluster.rs:16-31
   uint32_t idx1, idx2;
   float cost_combo, cost_diff;
 };
+struct HqBatchRef {  // one batch of 64 histograms of one job
+  uint32_t job, batch;
+};
+struct HqBatchPairs {  // the pair queue of a batch: workgroup memory
+  HqPair pairs[2048 + 1];
+};
 
 // One (meta-block, kind) splitting job.  Host fills the sizes and the scratch pointers; the device fills num_blocks
 // (after FindBlocks) and, through MbBuffers, the final split.
@@ -66,9 +72,15 @@ struct HqSplitJob {
   // ---- phase 2 (ClusterBlocks), sized by num_blocks
   uint32_t* histogram_symbols;  // [num_blocks]
   uint32_t* block_lengths;      // [num_blocks]
-  uint32_t* batch_data;         // [64 + 2][alphabet]: the batch, then the two scratch histograms
-  uint32_t* batch_total;        // [64 + 2]
-  float* batch_cost;            // [64 + 2]
+  uint32_t* block_pos;          // [num_blocks + 1] first symbol of every block
+  // the batches of 64 blocks are clustered side by side (one workgroup each), every batch in its own rows / slots:
+  uint32_t* batch_data;         // [num_blocks][alphabet]
+  uint32_t* batch_total;        // [num_blocks]
+  float* batch_cost;            // [num_blocks]
+  uint32_t* batch_sizes;        // [num_blocks] cluster sizes inside the batch
+  uint32_t* batch_clusters;     // [num_blocks] surviving clusters of the batch (indices 0..63), batch_count[b] of them
+  uint32_t* batch_symbols;      // [num_blocks] cluster (0..63) of every block inside its batch
+  uint32_t* batch_count;        // [ceil(num_blocks / 64)]
   uint32_t* all_data;           // [num_blocks][alphabet]
   uint32_t* all_total;          // [num_blocks]
   float* all_cost;              // [num_blocks]
@@ -94,6 +106,7 @@ struct HqClusterJob {
   uint32_t* clusters;       // [in_size]
   uint32_t* symbols;        // [in_size]
   uint32_t* new_index;      // [in_size]
+  uint32_t* batch_count;    // [ceil(in_size / 64)] clusters left of every batch of 64 inputs (clustered side by side)
   uint32_t* reindex_data;   // [min(in_size, 256)][len]
   uint32_t* reindex_total;  // [min(in_size, 256)]
   float* reindex_cost;      // [min(in_size, 256)]
@@ -699,7 +712,60 @@ BR_DEV void hq_block_histogram(uint32_t* dst, uint32_t len, const uint16_t* data
   BR_SYNC();
 }
 
-// phase 2: ClusterBlocks, block_splitter.rs:402-688.  Writes the split of (m, kind): types, lengths, starts, counts.
+// phase 2: ClusterBlocks, block_splitter.rs:402-688, in three launches: the block lengths (one pass over the ids), the
+// batches of 64 blocks side by side (their clusterings do not depend on each other), then the rest -- the clusters of all
+// batches against each other, every block to its closest cluster, the split of (m, kind): types, lengths, starts, counts.
+BR_DEV void hq_item_blocks_prep(const HqSplitJob& J) {
+  if (J.num_blocks == 0 || J.length < 128) return;
+  if (BR_TID == 0) {
+    uint32_t block_idx = 0, run = 0, start = 0;
+    for (uint32_t i = 0; i < J.length; ++i) {
+      run++;
+      if (i + 1 == J.length || J.block_ids[i] != J.block_ids[i + 1]) {
+        J.block_lengths[block_idx] = run;
+        J.block_pos[block_idx] = start;
+        start += run;
+        block_idx++;
+        run = 0;
+      }
+    }
+    J.block_pos[block_idx] = start;
+  }
+}
+
+BR_DEV void hq_item_cluster_blocks_batch(const EntropyTables& et, const HqSplitJob& J, uint32_t b, HqWaveScratch& S, HqPair* pairs) {
+  if (J.num_blocks == 0 || J.length < 128) return;
+  const uint32_t len = J.alphabet;
+  const uint32_t i0 = b * kHqBatch;
+  const uint32_t num_to_combine = J.num_blocks - i0 < kHqBatch ? J.num_blocks - i0 : kHqBatch;
+  HqHistos batch;  // the batch's own 64 rows
+  batch.data = J.batch_data + (size_t)i0 * len;
+  batch.total = J.batch_total + i0;
+  batch.cost = J.batch_cost + i0;
+  batch.len = len;
+  uint32_t* sizes = J.batch_sizes + i0;
+  uint32_t* new_clusters = J.batch_clusters + i0;
+  uint32_t* symbols = J.batch_symbols + i0;
+  for (uint32_t j = 0; j < num_to_combine; ++j) {
+    const uint32_t n = J.block_lengths[i0 + j];
+    hq_block_histogram(S.tmp, len, J.data + J.block_pos[i0 + j], n);
+    uint32_t* row = batch.row(j);
+    for (uint32_t k = BR_TID; k < len; k += BR_NT) row[k] = S.tmp[k];
+    const float cost_j = hq_cost_in_tmp(et, S, len, n);
+    if (BR_TID == 0) {
+      batch.total[j] = n;
+      batch.cost[j] = cost_j;
+      new_clusters[j] = j;
+      symbols[j] = j;
+      sizes[j] = 1;
+    }
+    BR_SYNC();
+  }
+  const uint32_t num_new_clusters =
+      hq_histogram_combine(et, S, batch, sizes, symbols, new_clusters, pairs, num_to_combine, num_to_combine, kHqBatch, kHqBatchPairs);
+  if (BR_TID == 0) J.batch_count[b] = num_new_clusters;
+}
+
 BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J, HqWaveScratch& S) {
   const EntropyTables& et = B.et;
   const MbDesc& d = B.descs[J.m];
@@ -728,27 +794,9 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J, HqWa
     return;
   }
   const uint16_t* data = J.data;
-  const uint32_t length = J.length, num_blocks = J.num_blocks, len = J.alphabet;
-  const uint8_t* block_ids = J.block_ids;
+  const uint32_t num_blocks = J.num_blocks, len = J.alphabet;
   uint32_t* histogram_symbols = J.histogram_symbols;
-  uint32_t* block_lengths = J.block_lengths;
-  // lengths of the runs of equal ids: position of every run end, then differences (J.new_index serves as the list of ends)
-  if (BR_TID == 0) {
-    uint32_t block_idx = 0, run = 0;
-    for (uint32_t i = 0; i < length; ++i) {
-      run++;
-      if (i + 1 == length || block_ids[i] != block_ids[i + 1]) {
-        block_lengths[block_idx++] = run;
-        run = 0;
-      }
-    }
-  }
-  BR_SYNC();
-  HqHistos batch;  // 64 histograms
-  batch.data = J.batch_data;
-  batch.total = J.batch_total;
-  batch.cost = J.batch_cost;
-  batch.len = len;
+  const uint32_t* block_lengths = J.block_lengths;
   HqHistos all;
   all.data = J.all_data;
   all.total = J.all_total;
@@ -757,40 +805,24 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J, HqWa
   uint32_t* cluster_size = J.cluster_size;
   uint32_t all_size = 0;
   uint32_t num_clusters = 0;
-  uint32_t pos = 0;
-  // per-batch arrays of BrotliHistogramCombine: in the job's scratch (clusters / new_index are free until the final pass)
-  uint32_t* sizes = J.clusters;
-  uint32_t* new_clusters = J.clusters + kHqBatch;
-  uint32_t* symbols = J.new_index;
-  uint32_t* remap = J.new_index + kHqBatch;
-  for (uint32_t i = 0; i < num_blocks; i += kHqBatch) {
+  uint32_t* remap = J.new_index;  // (free until the last pass)
+  for (uint32_t i = 0; i < num_blocks; i += kHqBatch) {  // the clusters of the batches, in batch order (:480-560)
     const uint32_t num_to_combine = num_blocks - i < kHqBatch ? num_blocks - i : kHqBatch;
-    for (uint32_t j = 0; j < num_to_combine; ++j) {
-      const uint32_t n = block_lengths[i + j];
-      hq_block_histogram(S.tmp, len, data + pos, n);
-      pos += n;
-      uint32_t* row = batch.row(j);
-      for (uint32_t k = BR_TID; k < len; k += BR_NT) row[k] = S.tmp[k];
-      const float cost_j = hq_cost_in_tmp(et, S, len, n);
-      if (BR_TID == 0) {
-        batch.total[j] = n;
-        batch.cost[j] = cost_j;
-        new_clusters[j] = j;
-        symbols[j] = j;
-        sizes[j] = 1;
-      }
-      BR_SYNC();
-    }
-    const uint32_t num_new_clusters =
-        hq_histogram_combine(et, S, batch, sizes, symbols, new_clusters, J.pairs, num_to_combine, num_to_combine, kHqBatch, kHqBatchPairs);
+    const uint32_t num_new_clusters = J.batch_count[i / kHqBatch];
+    HqHistos batch;
+    batch.data = J.batch_data + (size_t)i * len;
+    batch.total = J.batch_total + i;
+    batch.cost = J.batch_cost + i;
+    batch.len = len;
+    const uint32_t* new_clusters = J.batch_clusters + i;
     for (uint32_t j = 0; j < num_new_clusters; ++j) {
       hq_copy(all, all_size, batch, new_clusters[j]);
-      cluster_size[all_size] = sizes[new_clusters[j]];
+      cluster_size[all_size] = J.batch_sizes[i + new_clusters[j]];
       all_size++;
       remap[new_clusters[j]] = j;
     }
     BR_SYNC();
-    for (uint32_t j = 0; j < num_to_combine; ++j) histogram_symbols[i + j] = num_clusters + remap[symbols[j]];
+    for (uint32_t j = 0; j < num_to_combine; ++j) histogram_symbols[i + j] = num_clusters + remap[J.batch_symbols[i + j]];
     num_clusters += num_new_clusters;
     BR_SYNC();
   }
@@ -808,13 +840,11 @@ BR_DEV void hq_item_cluster_blocks(const MbBuffers& B, const HqSplitJob& J, HqWa
   const uint32_t kInvalidIndex = 0xffffffffu;
   for (uint32_t i = 0; i < num_clusters; ++i) new_index[i] = kInvalidIndex;
   BR_SYNC();
-  pos = 0;
   {
     uint32_t next_index = 0;
     for (uint32_t i = 0; i < num_blocks; ++i) {
       const uint32_t n = block_lengths[i];
-      hq_block_histogram(S.blk, len, data + pos, n);
-      pos += n;
+      hq_block_histogram(S.blk, len, data + J.block_pos[i], n);
       uint32_t best_out = i == 0 ? histogram_symbols[0] : histogram_symbols[i - 1];
       float best_bits = hq_bit_cost_distance(et, S, n, all, best_out);
       for (uint32_t j = 0; j < num_final_clusters; ++j) {
@@ -1089,7 +1119,54 @@ BR_DEV void hq_item_command_context_count(const MbBuffers& B, uint32_t c) {
 }
 
 // ---- BrotliClusterHistograms, cluster.rs:353-465 (+ HistogramRemap :261-297, HistogramReindex :310-351), and the copy of
-// the result into the meta-block's histogram rows and context map
+// the result into the meta-block's histogram rows and context map.  Two launches: the batches of 64 input histograms side by
+// side (one workgroup each, the pair queue in workgroup memory), then the rest per job.
+BR_DEV void hq_item_cluster_histograms_batch(const EntropyTables& et, const HqClusterJob& J, uint32_t b, HqWaveScratch& S, HqPair* pairs) {
+  const uint32_t in_size = J.in_size, len = J.len;
+  const uint32_t i0 = b * kHqBatch;
+  const uint32_t num_to_combine = in_size - i0 < kHqBatch ? in_size - i0 : kHqBatch;
+  HqHistos inp;
+  inp.data = const_cast<uint32_t*>(J.in_data);
+  inp.total = J.in_total;
+  inp.cost = J.out_cost;  // (not used for the inputs)
+  inp.len = len;
+  HqHistos out;
+  out.data = J.out_data;
+  out.total = J.out_total;
+  out.cost = J.out_cost;
+  out.len = len;
+  for (uint32_t i = i0; i < i0 + num_to_combine; ++i) {
+    // copy + total (an integer sum: order-free) + cost
+    const uint32_t* s = inp.row(i);
+    uint32_t* o = out.row(i);
+    uint32_t part = 0;
+    for (uint32_t k = BR_TID; k < len; k += BR_NT) {
+      const uint32_t v = s[k];
+      o[k] = v;
+      S.tmp[k] = v;
+      part += v;
+    }
+    if (BR_TID == 0) S.ctl[0] = 0;
+    BR_SYNC();
+    BR_ATOMIC_ADD_U32(&S.ctl[0], part);
+    BR_SYNC();
+    const uint32_t t = S.ctl[0];
+    const float cost_i = hq_cost_in_tmp(et, S, len, t);
+    if (BR_TID == 0) {
+      J.in_total[i] = t;
+      out.total[i] = t;
+      out.cost[i] = cost_i;
+      J.cluster_size[i] = 1;
+      J.symbols[i] = i;
+      J.clusters[i] = i;  // the batch's cluster list lives in its own stretch of the array until the batches are gathered
+    }
+    BR_SYNC();
+  }
+  const uint32_t num_new_clusters = hq_histogram_combine(et, S, out, J.cluster_size, J.symbols + i0, J.clusters + i0, pairs, num_to_combine,
+                                                         num_to_combine, 256, kHqBatchPairs);
+  if (BR_TID == 0) J.batch_count[b] = num_new_clusters;
+}
+
 BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J, HqWaveScratch& S) {
   const EntropyTables& et = B.et;
   const MbDesc& d = B.descs[J.m];
@@ -1111,40 +1188,12 @@ BR_DEV void hq_item_cluster_histograms(const MbBuffers& B, const HqClusterJob& J
   uint32_t* clusters = J.clusters;
   uint32_t* symbols = J.symbols;
   uint32_t num_clusters = 0;
-  for (uint32_t i = 0; i < in_size; ++i) {
-    // copy + total (an integer sum: order-free) + cost
-    const uint32_t* s = inp.row(i);
-    uint32_t* o = out.row(i);
-    uint32_t part = 0;
-    for (uint32_t k = BR_TID; k < len; k += BR_NT) {
-      const uint32_t v = s[k];
-      o[k] = v;
-      S.tmp[k] = v;
-      part += v;
-    }
-    if (BR_TID == 0) S.ctl[0] = 0;
-    BR_SYNC();
-    BR_ATOMIC_ADD_U32(&S.ctl[0], part);
-    BR_SYNC();
-    const uint32_t t = S.ctl[0];
-    const float cost_i = hq_cost_in_tmp(et, S, len, t);
-    if (BR_TID == 0) {
-      J.in_total[i] = t;
-      out.total[i] = t;
-      out.cost[i] = cost_i;
-      cluster_size[i] = 1;
-      symbols[i] = i;
-    }
-    BR_SYNC();
+  for (uint32_t i = 0; i < in_size; i += kHqBatch) {  // gather the batches' cluster lists (compact, in batch order)
+    const uint32_t cnt = J.batch_count[i / kHqBatch];
+    for (uint32_t j = 0; j < cnt; ++j) clusters[num_clusters + j] = clusters[i + j];
+    num_clusters += cnt;
   }
-  for (uint32_t i = 0; i < in_size; i += kHqBatch) {
-    const uint32_t num_to_combine = in_size - i < kHqBatch ? in_size - i : kHqBatch;
-    for (uint32_t j = 0; j < num_to_combine; ++j) clusters[num_clusters + j] = i + j;
-    BR_SYNC();
-    const uint32_t num_new_clusters = hq_histogram_combine(et, S, out, cluster_size, symbols + i, clusters + num_clusters, J.pairs, num_to_combine,
-                                                           num_to_combine, 256, kHqBatchPairs);
-    num_clusters += num_new_clusters;
-  }
+  BR_SYNC();
   {
     uint32_t max_num_pairs = 64u * num_clusters;
     const uint64_t alt = (uint64_t)(num_clusters / 2) * num_clusters;

@@ -288,12 +288,21 @@ void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs_dev, uint32_t n_jobs
   hipLaunchKernelGGL(k_hq_find_blocks, dim3(n_jobs), dim3(64), 0, BR_STREAM, B.et, jobs_dev);
   HIP_CHECK(hipGetLastError());
 }
+__global__ __launch_bounds__(64) void k_hq_blocks_prep(const HqSplitJob* jobs) { hq_item_blocks_prep(jobs[blockIdx.x]); }
+__global__ __launch_bounds__(64) void k_hq_cluster_blocks_batch(EntropyTables et, const HqSplitJob* jobs, const HqBatchRef* batches) {
+  __shared__ HqWaveScratch S;
+  __shared__ HqBatchPairs P;
+  const HqBatchRef ref = batches[blockIdx.x];
+  hq_item_cluster_blocks_batch(et, jobs[ref.job], ref.batch, S, P.pairs);
+}
 __global__ __launch_bounds__(64) void k_hq_cluster_blocks(MbBuffers B, const HqSplitJob* jobs) {
   __shared__ HqWaveScratch S;
   hq_item_cluster_blocks(B, jobs[blockIdx.x], S);
 }
-void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs) {
+void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs_dev, uint32_t n_jobs, const HqBatchRef* batches_dev, uint32_t n_batches) {
   if (n_jobs == 0) return;
+  hipLaunchKernelGGL(k_hq_blocks_prep, dim3(n_jobs), dim3(64), 0, BR_STREAM, jobs_dev);
+  if (n_batches) hipLaunchKernelGGL(k_hq_cluster_blocks_batch, dim3(n_batches), dim3(64), 0, BR_STREAM, B.et, jobs_dev, batches_dev);
   hipLaunchKernelGGL(k_hq_cluster_blocks, dim3(n_jobs), dim3(64), 0, BR_STREAM, B, jobs_dev);
   HIP_CHECK(hipGetLastError());
 }
@@ -303,12 +312,20 @@ void mb_hq_context_histograms(const MbBuffers& B) {
   for_each(b.n_cmds, [b] __device__(uint32_t c) { hq_item_command_context_count(b, c); });
   HIP_CHECK(hipGetLastError());
 }
+__global__ __launch_bounds__(64) void k_hq_cluster_histograms_batch(EntropyTables et, const HqClusterJob* jobs, const HqBatchRef* batches) {
+  __shared__ HqWaveScratch S;
+  __shared__ HqBatchPairs P;
+  const HqBatchRef ref = batches[blockIdx.x];
+  hq_item_cluster_histograms_batch(et, jobs[ref.job], ref.batch, S, P.pairs);
+}
 __global__ __launch_bounds__(64) void k_hq_cluster_histograms(MbBuffers B, const HqClusterJob* jobs) {
   __shared__ HqWaveScratch S;
   hq_item_cluster_histograms(B, jobs[blockIdx.x], S);
 }
-void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs) {
+void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, uint32_t n_jobs, const HqBatchRef* batches_dev,
+                              uint32_t n_batches) {
   if (n_jobs == 0) return;
+  if (n_batches) hipLaunchKernelGGL(k_hq_cluster_histograms_batch, dim3(n_batches), dim3(64), 0, BR_STREAM, B.et, jobs_dev, batches_dev);
   hipLaunchKernelGGL(k_hq_cluster_histograms, dim3(n_jobs), dim3(64), 0, BR_STREAM, B, jobs_dev);
   HIP_CHECK(hipGetLastError());
 }

@@ -127,16 +127,21 @@ void mb_hq_find_blocks(const MbBuffers& B, HqSplitJob* jobs, uint32_t n_jobs) {
   HqWaveScratch S;
   for (uint32_t i = 0; i < n_jobs; ++i) hq_item_find_blocks(B.et, jobs[i], S);
 }
-void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs, uint32_t n_jobs) {
-  HqWaveScratch S;
+void mb_hq_cluster_blocks(const MbBuffers& B, const HqSplitJob* jobs, uint32_t n_jobs, const HqBatchRef* batches, uint32_t n_batches) {
+  static thread_local HqWaveScratch S;
+  static thread_local HqBatchPairs P;
+  for (uint32_t i = 0; i < n_jobs; ++i) hq_item_blocks_prep(jobs[i]);
+  for (uint32_t i = 0; i < n_batches; ++i) hq_item_cluster_blocks_batch(B.et, jobs[batches[i].job], batches[i].batch, S, P.pairs);
   for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_blocks(B, jobs[i], S);
 }
 void mb_hq_context_histograms(const MbBuffers& B) {
   for (uint32_t i = 0; i < B.n_lits; ++i) hq_item_literal_context_count(B, i);
   for (uint32_t c = 0; c < B.n_cmds; ++c) hq_item_command_context_count(B, c);
 }
-void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs, uint32_t n_jobs) {
-  HqWaveScratch S;
+void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs, uint32_t n_jobs, const HqBatchRef* batches, uint32_t n_batches) {
+  static thread_local HqWaveScratch S;
+  static thread_local HqBatchPairs P;
+  for (uint32_t i = 0; i < n_batches; ++i) hq_item_cluster_histograms_batch(B.et, jobs[batches[i].job], batches[i].batch, S, P.pairs);
   for (uint32_t i = 0; i < n_jobs; ++i) hq_item_cluster_histograms(B, jobs[i], S);
 }
 
