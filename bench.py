@@ -190,6 +190,37 @@ def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
                       "input_generated_in_s": round(gen_s, 1)})
         res.append(entry)
         del data
+    res.extend(quality_9_5_workloads(torch, bm, enc))
+    return res
+
+
+def quality_9_5_workloads(torch, bm, enc):
+    """quality 10 + BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder behind the H9 search), 8 MiB of
+    the text generator; compared with the oracle run here (one core), which is also the CPU figure beside it"""
+    import orc
+    import synth
+    res = []
+    try:
+        data = synth.markov_text(8 << 20)
+        dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    except Exception as e:
+        return [{"workload": "q9_5_text_8MiB", "error": repr(e)}]
+    for lgwin in (22, 18):
+        params = [(bm.BROTLI_PARAM_QUALITY, 10), (150, 1), (bm.BROTLI_PARAM_LGWIN, lgwin), (bm.BROTLI_PARAM_SIZE_HINT, len(data))]
+        entry = {"workload": "q9_5_text_8MiB_w%d" % lgwin, "input_bytes": len(data), "quality": "10 + Q9_5", "lgwin": lgwin,
+                 "residency": "input resident in HBM, output to host memory"}
+        try:
+            sec, out = timed_steps(lambda: enc.encode(params, b"", dev.data_ptr(), len(data), True, copy=True), 1, 1, torch)
+            out = bytes(out)
+            t0 = time.time()
+            want, _ = orc.stream_compress(data, params)
+            cpu_s = time.time() - t0
+            entry.update({"value": round(len(data) / sec / 1e6, 2), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out),
+                          "identical_to_cpu_oracle": out == want,
+                          "cpu_oracle": {"value": round(len(data) / cpu_s / 1e6, 2), "unit": "MB/s", "cores": 1, "sample": "the same 8 MiB, one run"}})
+        except Exception as e:
+            entry["error"] = repr(e)
+        res.append(entry)
     return res
 
 

@@ -619,8 +619,9 @@ BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, con
   }
 #endif
   BR_SYNC();
-  // trace back (:318-348): sequential, one lane
-  if (BR_TID == 0) {
+  // trace back (:318-348): the id in force changes only where a switch was signalled for it
+#if defined(BROTLI_HOST_EMU)
+  {
     uint32_t num_blocks = 1;
     uint32_t byte_ix = length - 1;
     size_t ix = (size_t)byte_ix * bitmaplen;
@@ -637,6 +638,34 @@ BR_DEV uint32_t hq_find_blocks(const EntropyTables& et, const HqSplitJob& J, con
     }
     const_cast<HqSplitJob&>(J).num_blocks = num_blocks;
   }
+#else
+  {
+    // 64 positions per step: every lane tests "a switch to my own id was signalled here" for the id in force; the nearest hit
+    // (ballot) ends the stretch, everything in front of it takes the id in force
+    const uint32_t lane = threadIdx.x;
+    uint32_t num_blocks = 1;
+    uint32_t p = length - 1;  // positions below p are still to do
+    uint32_t cur = block_id[p];
+    while (p > 0) {
+      const bool valid = lane < p;
+      const uint32_t q = valid ? p - 1u - lane : 0u;
+      const uint32_t bid = valid ? (uint32_t)block_id[q] : cur;
+      const uint32_t sig = valid ? ((uint32_t)switch_signal[(size_t)q * bitmaplen + (cur >> 3)] >> (cur & 7u)) & 1u : 0u;
+      const unsigned long long m = __ballot(valid && sig != 0 && bid != cur);
+      if (m == 0) {
+        if (valid) block_id[q] = (uint8_t)cur;
+        p = p > 64u ? p - 64u : 0u;
+      } else {
+        const uint32_t f = (uint32_t)__ffsll((long long)m) - 1u;
+        if (valid && lane < f) block_id[q] = (uint8_t)cur;
+        cur = (uint32_t)__shfl((int)bid, (int)f, 64);
+        ++num_blocks;
+        p = p - 1u - f;  // the position of the hit: it keeps its own id, which is the id in force from here on
+      }
+    }
+    if (lane == 0) const_cast<HqSplitJob&>(J).num_blocks = num_blocks;
+  }
+#endif
   BR_SYNC();
   return 0;
 }
@@ -717,7 +746,8 @@ BR_DEV void hq_block_histogram(uint32_t* dst, uint32_t len, const uint16_t* data
 // batches against each other, every block to its closest cluster, the split of (m, kind): types, lengths, starts, counts.
 BR_DEV void hq_item_blocks_prep(const HqSplitJob& J) {
   if (J.num_blocks == 0 || J.length < 128) return;
-  if (BR_TID == 0) {
+#if defined(BROTLI_HOST_EMU)
+  {
     uint32_t block_idx = 0, run = 0, start = 0;
     for (uint32_t i = 0; i < J.length; ++i) {
       run++;
@@ -731,6 +761,23 @@ BR_DEV void hq_item_blocks_prep(const HqSplitJob& J) {
     }
     J.block_pos[block_idx] = start;
   }
+#else
+  {
+    // the ends of the runs of equal ids, 64 positions per step (ballot + rank among the ends), then the lengths as differences
+    const uint32_t lane = threadIdx.x;
+    uint32_t base = 0;
+    if (lane == 0) J.block_pos[0] = 0;
+    for (uint32_t i0 = 0; i0 < J.length; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool end = i < J.length && (i + 1 == J.length || J.block_ids[i] != J.block_ids[i + 1]);
+      const unsigned long long m = __ballot(end);
+      if (end) J.block_pos[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) + 1u] = i + 1u;
+      base += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    for (uint32_t b = lane; b < base; b += 64) J.block_lengths[b] = J.block_pos[b + 1] - J.block_pos[b];
+  }
+#endif
 }
 
 BR_DEV void hq_item_cluster_blocks_batch(const EntropyTables& et, const HqSplitJob& J, uint32_t b, HqWaveScratch& S, HqPair* pairs) {
