@@ -624,6 +624,17 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
           descs[m].max_histos[k] = 256;
           histo_total[k] += 256;
         }
+      {
+        // ClusterBlocks keeps one histogram per block FindBlocks found, twice (the batches' rows and the gathered clusters);
+        // a pathological input (a switch every few symbols over a 16 MiB meta-block) would ask for more than the device
+        // has.  Refuse with a message instead of dying in an allocation half-way through.
+        uint64_t need = 0;
+        for (const HqSplitJob& j : jobs)
+          if (j.length >= 128) need += (uint64_t)(j.num_blocks + 2) * (2ull * j.alphabet * 4 + 64ull * sizeof(HqPair) + 64);
+        if (need > (96ull << 30))
+          throw std::runtime_error("brotli_mi355x: quality 9.5: clustering " + std::to_string(need >> 30) +
+                                   " GiB of block histograms is more than this build sets aside; feed the stream in smaller pieces");
+      }
       for (HqSplitJob& j : jobs) {
         MbDesc& d = descs[j.m];
         const uint32_t nb = j.num_blocks;

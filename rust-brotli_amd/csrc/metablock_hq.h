@@ -8,11 +8,13 @@
 //   * context histograms (histogram.rs:465-534) and BrotliClusterHistograms (cluster.rs:353-465) for the literal and
 //     distance context maps, all priced with BrotliPopulationCost (bit_cost.rs:76-211),
 // everything in f32, left to right.  The items below restate that arithmetic operation by operation (tolerance zero: the
-// stream must equal the oracle's byte for byte).  This first device slice runs every sequential algorithm on ONE lane per
-// (meta-block, kind) -- the same code the CPU emulation runs, so that the emulation build is evidence for the device
-// build -- and only the embarrassingly parallel passes (symbol gathering, context histograms) over all lanes.
-// The lane-parallel forms (lane k = entropy code k in FindBlocks, one wave per candidate pair in the clustering) are
-// the next step.
+// stream must equal the oracle's byte for byte).  How the work is spread: one 64-lane workgroup per
+// (meta-block, kind) job for the sequential algorithms, with the lanes sharing what is order-free or element-wise (integer
+// histograms by atomics, rows strided, the costs of FindBlocks two entropy codes per lane, BrotliPopulationCost with its
+// non-zero terms compacted in index order); the batches of 64 histograms of the two clustering passes side by side, one
+// workgroup each; one thread per symbol for the gather / count passes.  The CPU emulation (tests/emu) compiles the same
+// items for one lane; where the device form differs in shape (the wave minimum, ballots) the scalar twin sits beside it
+// under BROTLI_HOST_EMU, and the GPU tests (tests/test_quality_9_5.py) are what vouches for the device form.
 #ifndef BROTLI_MI355X_METABLOCK_HQ_H_
 #define BROTLI_MI355X_METABLOCK_HQ_H_
 

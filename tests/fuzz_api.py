@@ -1,6 +1,6 @@
 """Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
-oracle."""
+oracle.  FUZZ_Q9_5=1: every case at quality 10 with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10)."""
 import os, sys, time
 import synth, orc
 import test_cabi
@@ -22,8 +22,14 @@ for c in range(cases):
     o = rng.next() % (len(pool) - n)
     d = pool[o:o + n]
     q = 5 + rng.next() % 5
+    q95 = bool(os.environ.get("FUZZ_Q9_5"))
+    if q95:
+        q = 10
     w = [17, 18, 20, 22, 24][rng.next() % 5]
     mode = rng.next() % 6
+    if q95 and mode == 5:
+        mode = 4  # (orc.writer_compress takes quality and window only)
+    base = [(Q, q), (W, w)] + ([(150, 1)] if q95 else [])
     extra = []
     for pid in (167, 168, 169, 172):  # catable, appendable, magic number, byte align
         if rng.next() % 4 == 0:
@@ -34,7 +40,7 @@ for c in range(cases):
         print("case %d n %d q %d w %d mode %d" % (c, n, q, w, mode), flush=True)
         open(os.environ["FUZZ_TRACE"], "wb").write(d)
     def flushed(ops):
-        e = lib.encoder(params=[(Q, q), (W, w)])
+        e = lib.encoder(params=base)
         pieces, pos = [], 0
         for item in ops:
             if isinstance(item, tuple):
@@ -54,8 +60,8 @@ for c in range(cases):
     if mode == 0:
         nt = 1 + rng.next() % 9
         what = "multi nt=%d" % nt
-        product = lambda: bytes(lib.BrotliCompress(d, {Q: q, W: w}, nt))
-        oracle = lambda: orc.compress_multi(d, [(Q, q), (W, w)], nt) if nt > 1 else orc.stream_compress(d, [(Q, q), (W, w)])[0]
+        product = lambda: bytes(lib.BrotliCompress(d, dict(base), nt))
+        oracle = lambda: orc.compress_multi(d, base, nt) if nt > 1 else orc.stream_compress(d, base)[0]
     elif mode == 3:
         # custom LZ77 dictionary (BrotliEncoderSetCustomDictionary)
         m = 1 + rng.next() % 400000
@@ -64,12 +70,12 @@ for c in range(cases):
         what = "dictionary %d B" % m
 
         def product():
-            e = lib.encoder(params=[(Q, q), (W, w)], dictionary=dic)
+            e = lib.encoder(params=base, dictionary=dic)
             e.write(d)
             got = e.finish()
             e.close()
             return got
-        oracle = lambda: orc.stream_compress(d, [(Q, q), (W, w)], prefix=dic, continuation=False)[0]
+        oracle = lambda: orc.stream_compress(d, base, prefix=dic, continuation=False)[0]
     elif mode == 5:
         # CompressorWriter feeding pattern (src/enc/writer.rs:183-313): PROCESS calls of one buffer each, then FINISH
         chunk = [1000, 4096, 65536, 100000, 1 << 20][rng.next() % 5]
@@ -88,12 +94,12 @@ for c in range(cases):
         what = "params %r" % (extra,)
 
         def product():
-            e = lib.encoder(params=[(Q, q), (W, w)] + extra)
+            e = lib.encoder(params=base + extra)
             e.write(d)
             got = e.finish()
             e.close()
             return got
-        oracle = lambda: orc.stream_compress(d, [(Q, q), (W, w)] + extra)[0]
+        oracle = lambda: orc.stream_compress(d, base + extra)[0]
     else:
         ncut = 1 + rng.next() % 4
         cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))
@@ -105,7 +111,7 @@ for c in range(cases):
                 ops.append(cut)
         what = "ops %r" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops],)
         product = lambda: flushed(ops)
-        oracle = lambda: orc.stream_with_flushes(d, [(Q, q), (W, w)], ops)
+        oracle = lambda: orc.stream_with_flushes(d, base, ops)
     if os.environ.get("FUZZ_ONLY") and c != int(os.environ["FUZZ_ONLY"]):
         continue
     # an input on which the reference itself fails (it panics on a copy of length 1, see orc.ReferencePanics) must make

@@ -9,9 +9,9 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(script, *args):
+def _run(script, *args, **env):
     r = subprocess.run([sys.executable, os.path.join(HERE, script)] + [str(a) for a in args], cwd=HERE, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=1500)
+                       stderr=subprocess.STDOUT, timeout=1500, env=dict(os.environ, **env))
     tail = r.stdout.decode(errors="replace")[-2000:]
     assert r.returncode == 0, tail
     return tail
@@ -27,6 +27,18 @@ def test_api_sweep_emulation():
     import emu
     emu.build()
     assert " 0 failures" in _run("fuzz_api.py", 60, 5, "emu")
+
+
+def test_api_sweep_quality_9_5_emulation():
+    """the same stream operations at quality 10 + BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10)"""
+    import emu
+    emu.build()
+    assert " 0 failures" in _run("fuzz_api.py", 40, 9, "emu", FUZZ_Q9_5="1")
+
+
+@pytest.mark.gpu
+def test_api_sweep_quality_9_5_device():
+    assert " 0 failures" in _run("fuzz_api.py", 40, 9, FUZZ_Q9_5="1")
 
 
 @pytest.mark.gpu

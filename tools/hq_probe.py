@@ -1,3 +1,8 @@
+"""Quality 9.5 probe (GPU): three inputs through the product library's flat entry point, compared with the oracle, with the
+stage times of the call (BROTLI_MI355X_PROFILE=1 adds the LZ77 stage's own split on stderr).  phases[1..3] = census +
+distance parameters + FindBlocks, ClusterBlocks, context maps (encoder.cpp).  Used for profiles/r03_q9_5_probe_*.log:
+    BROTLI_MI355X_PROFILE=1 python tools/hq_probe.py
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_hq -o hq -- python tools/hq_probe.py"""
 import sys, time, os
 sys.path.insert(0, 'tests')
 import gpulib, emu, orc, synth
