@@ -1,10 +1,10 @@
 // broccoli_api.cpp -- the BroCatli streaming C API of the reference (c/brotli/broccoli.h, src/ffi/broccoli.rs:55-175):
 // concatenation of brotli streams that were encoded `catable` / `appendable`, fed and drained piecewise.
 //
-// The stitching rules are those of csrc/concat.cpp (ChunkStitcher = src/concat/mod.rs:274-608 restated for whole
-// files).  This front end collects the bytes of the file that is being fed and runs the stitcher whenever a file is
-// complete (BroccoliNewBrotliFile / BroccoliConcatFinish), so its memory grows with the largest input file instead of
-// staying constant like the reference's byte-at-a-time state machine; the bytes that come out are the same.
+// The stitching rules are those of csrc/concat.cpp (ChunkStitcher = src/concat/mod.rs:274-608 restated).  Like the
+// reference's state machine this front end keeps nothing of a file but the bytes of its header until they can be judged and
+// its last two bytes: input is taken in slices of at most 64 KiB, and only while the stitched bytes of the slice before
+// have been handed out -- memory stays constant whatever the sizes of the files and of the caller's buffers.
 // Host-only code: concatenation touches two bytes per junction, there is nothing in it for a GPU.
 #include <stdint.h>
 #include <stdlib.h>
@@ -19,11 +19,10 @@
 using namespace brotli_mi355x;
 
 namespace {
+constexpr size_t kSlice = 64 << 10;
 struct Broccoli {
   ChunkStitcher stitcher;
-  std::vector<uint8_t> file;     // bytes of the file being fed
-  bool file_open = false;
-  std::vector<uint8_t> pending;  // stitched output not yet handed out
+  std::vector<uint8_t> pending;  // stitched output not yet handed out (at most one slice + the junction bytes)
   size_t pending_pos = 0;
   int error = 0;                 // sticky BroccoliResult (>= 124)
   bool finished = false;
@@ -39,13 +38,6 @@ BroccoliState Wrap(Broccoli* b) {
   memset(&s, 0, sizeof(s));
   memcpy(s.data, &b, sizeof(b));
   return s;
-}
-void CloseFile(Broccoli* b) {
-  if (!b->file_open) return;
-  b->file_open = false;
-  if (!b->stitcher.Append(b->file.data(), b->file.size(), &b->pending) && b->error == 0)
-    b->error = BroccoliBrotliFileNotCraftedForConcatenation;
-  b->file.clear();
 }
 BroccoliResult Drain(Broccoli* b, size_t* available_out, uint8_t** out, BroccoliResult when_empty) {
   const size_t have = b->pending.size() - b->pending_pos;
@@ -81,22 +73,25 @@ void BroccoliDestroyInstance(BroccoliState state) { delete Get(&state); }
 void BroccoliNewBrotliFile(BroccoliState* state) {
   Broccoli* b = Get(state);
   if (!b) return;
-  CloseFile(b);
-  b->file_open = true;
+  b->stitcher.BeginFile();
 }
 
 BroccoliResult BroccoliConcatStream(BroccoliState* state, size_t* available_in, const uint8_t** input_buf_ptr, size_t* available_out,
                                     uint8_t** output_buf_ptr) {
   Broccoli* b = Get(state);
   if (!b) return BroccoliBrotliFileNotCraftedForConcatenation;
-  if (b->error) return (BroccoliResult)b->error;
-  if (*available_in) {
-    if (!b->file_open) b->file_open = true;  // (the reference panics without new_brotli_file; be lenient)
-    b->file.insert(b->file.end(), *input_buf_ptr, *input_buf_ptr + *available_in);
-    *input_buf_ptr += *available_in;
-    *available_in = 0;
+  for (;;) {
+    if (b->error) return (BroccoliResult)b->error;
+    // what the slice before produced goes out first; no new input while the caller has not taken it
+    const BroccoliResult r = Drain(b, available_out, output_buf_ptr, BroccoliNeedsMoreInput);
+    if (r != BroccoliNeedsMoreInput) return r;
+    if (*available_in == 0) return BroccoliNeedsMoreInput;
+    const size_t n = *available_in < kSlice ? *available_in : kSlice;
+    ByteSink sink(&b->pending);
+    if (!b->stitcher.Feed(*input_buf_ptr, n, &sink)) b->error = BroccoliBrotliFileNotCraftedForConcatenation;
+    *input_buf_ptr += n;
+    *available_in -= n;
   }
-  return Drain(b, available_out, output_buf_ptr, BroccoliNeedsMoreInput);
 }
 
 BroccoliResult BroccoliConcatStreaming(BroccoliState* state, size_t* available_in, const uint8_t* input_buf, size_t* available_out,
@@ -108,7 +103,6 @@ BroccoliResult BroccoliConcatFinish(BroccoliState* state, size_t* available_out,
   Broccoli* b = Get(state);
   if (!b) return BroccoliBrotliFileNotCraftedForConcatenation;
   if (!b->finished) {
-    CloseFile(b);
     if (b->error == 0 && !b->stitcher.Finish(&b->pending)) b->error = BroccoliBrotliFileNotCraftedForAppend;
     b->finished = true;
   }

@@ -127,24 +127,7 @@ bool ChunkStitcher::FlushPreviousStream(ByteSink* out) {
   return true;
 }
 
-bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, ByteSink* out) {
-  ChunkView view;
-  view.full = in;
-  view.size = in_len;
-  return Append(view, out, nullptr);
-}
-
-bool ChunkStitcher::Append(const ChunkView& in, ByteSink* out, BodyCopy* body) {
-  const size_t in_len = in.size;
-  if (body) *body = BodyCopy{0, 0, 0};
-  // new_brotli_file() + stream(), concat/mod.rs:274-276, 450-566
-  if (!FlushPreviousStream(out)) return false;
-  uint8_t header[5] = {0, 0, 0, 0, 0};
-  size_t num_read = in_len < 5 ? in_len : 5;
-  for (size_t i = 0; i < num_read; ++i) header[i] = in.at(i);
-  size_t in_offset = num_read;
-  const bool sufficient = (num_read == 4 && (127 & header[0]) != 17) || num_read == 5;
-  if (!sufficient) return true;  // the reference waits for more input that never comes: the chunk is dropped
+bool ChunkStitcher::EmitNewStreamHeader(const uint8_t* header, size_t num_read, ByteSink* out) {
   // shift_and_check_new_stream_header, concat/mod.rs:332-449
   uint8_t pending[6];
   size_t pending_len;
@@ -188,6 +171,62 @@ bool ChunkStitcher::Append(const ChunkView& in, ByteSink* out, BodyCopy* body) {
   last_bytes_[1] = 0;
   last_bytes_len_ = 1;
   out->pop_back();
+  return true;
+}
+
+void ChunkStitcher::BeginFile() {
+  new_file_pending_ = true;  // (a header that never became long enough to judge is dropped with its file)
+  in_header_ = false;
+  header_len_ = 0;
+}
+
+bool ChunkStitcher::Feed(const uint8_t* p, size_t n, ByteSink* out) {
+  size_t i = 0;
+  if (new_file_pending_) {
+    if (n == 0) return true;
+    if (!FlushPreviousStream(out)) return false;
+    new_file_pending_ = false;
+    in_header_ = true;
+    header_len_ = 0;
+  }
+  if (in_header_) {
+    while (i < n && header_len_ < 5) header_[header_len_++] = p[i++];  // (as much of the five as this piece has)
+    const bool sufficient = (header_len_ == 4 && (127 & header_[0]) != 17) || header_len_ == 5;
+    if (!sufficient) return true;
+    if (!EmitNewStreamHeader(header_, header_len_, out)) return false;
+    in_header_ = false;
+  }
+  for (; i < n; ++i) {  // the body, two bytes behind
+    if (last_bytes_len_ < 2) {
+      last_bytes_[last_bytes_len_++] = p[i];
+    } else {
+      out->push_back(last_bytes_[0]);
+      last_bytes_[0] = last_bytes_[1];
+      last_bytes_[1] = p[i];
+    }
+  }
+  return !out->overflow();
+}
+
+bool ChunkStitcher::Append(const uint8_t* in, size_t in_len, ByteSink* out) {
+  ChunkView view;
+  view.full = in;
+  view.size = in_len;
+  return Append(view, out, nullptr);
+}
+
+bool ChunkStitcher::Append(const ChunkView& in, ByteSink* out, BodyCopy* body) {
+  const size_t in_len = in.size;
+  if (body) *body = BodyCopy{0, 0, 0};
+  // new_brotli_file() + stream(), concat/mod.rs:274-276, 450-566
+  if (!FlushPreviousStream(out)) return false;
+  uint8_t header[5] = {0, 0, 0, 0, 0};
+  size_t num_read = in_len < 5 ? in_len : 5;
+  for (size_t i = 0; i < num_read; ++i) header[i] = in.at(i);
+  size_t in_offset = num_read;
+  const bool sufficient = (num_read == 4 && (127 & header[0]) != 17) || num_read == 5;
+  if (!sufficient) return true;  // the reference waits for more input that never comes: the chunk is dropped
+  if (!EmitNewStreamHeader(header, num_read, out)) return false;
   // body: keep the last two bytes back
   while (last_bytes_len_ != 2) {
     if (in_offset == in_len) return true;

@@ -1,6 +1,7 @@
 // concat.h -- stitching of independently compressed chunks into one brotli stream.
-// Restates BroCatli (reference src/concat/mod.rs:39-123, 274-608) for whole chunks and an unbounded output,
-// the way CompressMulti drives it (src/enc/threading/mod.rs:565-660): new_brotli_file(); stream(chunk); ...; finish().
+// Restates BroCatli (reference src/concat/mod.rs:39-123, 274-608): for whole chunks and an unbounded output, the way
+// CompressMulti drives it (src/enc/threading/mod.rs:565-660): new_brotli_file(); stream(chunk); ...; finish() -- and, for
+// the BroCatli C API, fed in pieces of any size with two bytes of state per junction (BeginFile / Feed).
 #ifndef BROTLI_MI355X_CONCAT_H_
 #define BROTLI_MI355X_CONCAT_H_
 #include <stddef.h>
@@ -65,6 +66,10 @@ class ChunkStitcher {
   // returns false when the chunk cannot be concatenated (not appendable / not catable / window too large)
   bool Append(const uint8_t* chunk, size_t size, ByteSink* out);
   bool Finish(ByteSink* out);
+  // The same file by file, piece by piece (BroCatli::new_brotli_file / stream, concat/mod.rs:274-276, 450-566): nothing of
+  // a file is kept but the (at most five) bytes of its header until they can be judged and the last two bytes handed over.
+  void BeginFile();
+  bool Feed(const uint8_t* piece, size_t size, ByteSink* out);
   bool Append(const uint8_t* chunk, size_t size, std::vector<uint8_t>* out) {
     ByteSink sink(out);
     return Append(chunk, size, &sink);
@@ -76,6 +81,12 @@ class ChunkStitcher {
 
  private:
   bool FlushPreviousStream(ByteSink* out);
+  // shift_and_check_new_stream_header (concat/mod.rs:332-449) + the take-back of the last byte written
+  bool EmitNewStreamHeader(const uint8_t* header, size_t num_read, ByteSink* out);
+  bool new_file_pending_ = false;  // BeginFile seen, nothing of the file yet
+  bool in_header_ = false;
+  uint8_t header_[5] = {0, 0, 0, 0, 0};
+  uint8_t header_len_ = 0;
   uint8_t last_bytes_[2] = {0, 0};
   uint8_t last_bytes_len_ = 0;
   bool last_byte_sanitized_ = false;

@@ -40,7 +40,9 @@ def _concat(L, files, in_piece, out_piece, window=None):
             avail_in = ctypes.c_size_t(len(piece))
             while True:
                 avail_out = ctypes.c_size_t(out_piece)
-                r = L.BroccoliConcatStreaming(ctypes.byref(st), ctypes.byref(avail_in), piece, ctypes.byref(avail_out), buf)
+                # (the pointer is passed by value, src/ffi/broccoli.rs:109-128: the caller moves on by what was consumed)
+                rest = piece[len(piece) - avail_in.value:]
+                r = L.BroccoliConcatStreaming(ctypes.byref(st), ctypes.byref(avail_in), rest, ctypes.byref(avail_out), buf)
                 out += buf.raw[:out_piece - avail_out.value]
                 assert r in (1, 2), r
                 if r == 1:  # BroccoliNeedsMoreInput
@@ -84,3 +86,21 @@ def test_streaming_concat_equals_whole_chunk_stitcher():
     r = L.BroccoliConcatFinished(ctypes.byref(st), ctypes.byref(avail_out), buf)
     assert r >= 124, r
     L.BroccoliDestroyInstance(st)
+
+
+def test_streaming_concat_in_constant_memory_slices():
+    """files larger than the 64 KiB slice the front end takes in at a time (broccoli_api.cpp), fed and drained in sizes that
+    do not divide anything; a file whose header arrives one byte at a time; an empty file between two real ones"""
+    import test_cabi
+    lib = test_cabi._load("emu")
+    L = _bind()
+    a, b = synth.random_bytes(300000, 5), synth.markov_text(1 << 20, 9)
+    files = [orc.stream_compress(x, [(Q, 5), (W, 22), (CAT, 1), (APP, 1)])[0] for x in (a, b, a[:1000])]
+    assert len(files[0]) > 4 * 65536 and len(files[1]) > 2 * 65536
+    want = lib.concat_chunks(files)
+    for in_piece, out_piece in ((100003, 3001), (1, 1 << 16), (1 << 22, 7), (65536, 65536), (65537, 65535)):
+        assert _concat(L, files, in_piece, out_piece) == want, (in_piece, out_piece)
+    assert orc.decompress(want, len(a) + len(b) + 1000) == a + b + a[:1000]
+    # BroccoliNewBrotliFile without any bytes (a file that turned out empty) leaves the stream as it is
+    with_gap = [files[0], b"", files[1], files[2]]
+    assert _concat(L, with_gap, 4096, 4096) == want
