@@ -50,6 +50,7 @@ struct BrotliEncoderStateStruct {
   std::vector<uint8_t> input;
   std::vector<uint8_t> dictionary;
   bool has_dictionary;
+  bool dictionary_in_window;  // the custom dictionary has been put in front of `input` as the first piece's window
   size_t size_hint_at_dictionary;  // params.size_hint when BrotliEncoderSetCustomDictionary ran
   std::vector<uint8_t> output;
   size_t output_pos;
@@ -89,10 +90,6 @@ size_t StreamBatchBytes() {
   return v;
 }
 
-// Streams that can be encoded piece by piece without a flush: no custom dictionary, not catable / appendable (their
-// pieces would need the dictionary-end rule and the raw head carried along; such streams are buffered until FINISH).
-bool Streamable(const BrotliEncoderState* s) { return !s->has_dictionary && !s->params.catable && !s->params.appendable; }
-
 // Runs the device encoder over the input buffered since the last piece.  FLUSH: finish = false, FINISH: finish = true;
 // partial (PROCESS): only the meta-blocks that close by themselves within the whole input blocks buffered so far.
 bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = false, size_t metadata_size = 0, bool partial = false,
@@ -101,6 +98,22 @@ bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = fal
     EncodeRequest req;
     req.params = s->params;
     req.last_block_processed_early = last_block_processed_early;
+    const bool flushed_stream = !finish || s->carry.valid;
+    const bool first_piece = !s->carry.valid;
+    size_t dict_use = 0;
+    if (s->has_dictionary && first_piece) {
+      // set_custom_dictionary (encode.rs:1196-1270): last (1 << lgwin) - 16 bytes
+      EncoderParams p = s->params;
+      FinalizeParams(&p);
+      const size_t max_dict = ((size_t)1 << p.lgwin) - 16;
+      dict_use = std::min(s->dictionary.size(), max_dict);
+      if (flushed_stream && !s->dictionary_in_window) {
+        // a stream that goes on after this piece: the dictionary is the first stretch of its window
+        s->input.insert(s->input.begin(), s->dictionary.end() - (ptrdiff_t)dict_use, s->dictionary.end());
+        s->encoded_upto += dict_use;
+        s->dictionary_in_window = true;
+      }
+    }
     req.input = s->input.data() + s->encoded_upto;
     req.input_size = s->input.size() - s->encoded_upto;
     if (partial) {
@@ -115,27 +128,20 @@ bool EncodeBuffered(BrotliEncoderState* s, bool finish, bool emit_metadata = fal
     size_t consumed = req.input_size, keep_from = 0;
     req.consumed_out = &consumed;
     req.keep_from_out = &keep_from;
-    const bool flushed_stream = !finish || s->carry.valid;
     if (flushed_stream) {
-      if (s->has_dictionary || s->params.catable || s->params.appendable)
-        throw std::runtime_error("BROTLI_OPERATION_FLUSH is not supported together with a custom dictionary or catable / appendable streams");
       req.prefix = s->encoded_upto ? s->input.data() : nullptr;
       req.prefix_size = s->encoded_upto;
-      req.prefix_is_file_continuation = true;
+      req.prefix_is_file_continuation = !(s->has_dictionary && first_piece);
       req.carry_in = &s->carry;
       req.carry_out = &s->carry;
     }
-    if (s->has_dictionary) {
-      // set_custom_dictionary (encode.rs:1196-1270): last (1 << lgwin) - 16 bytes, no static dictionary,
-      // hasher chosen before any size hint, prev bytes stay 0
-      EncoderParams p = s->params;
-      FinalizeParams(&p);
-      const size_t max_dict = ((size_t)1 << p.lgwin) - 16;
-      const size_t n = s->dictionary.size();
-      const size_t use = std::min(n, max_dict);
-      req.prefix = s->dictionary.data() + (n - use);
-      req.prefix_size = use;
-      req.prefix_is_file_continuation = false;
+    if (s->has_dictionary && first_piece) {
+      // no static dictionary, hasher chosen before any size hint, prev bytes stay 0 (encode.rs:1196-1270)
+      if (!flushed_stream) {
+        req.prefix = s->dictionary.data() + (s->dictionary.size() - dict_use);
+        req.prefix_size = dict_use;
+        req.prefix_is_file_continuation = false;
+      }
       req.hasher_chosen_before_size_hint = true;
       req.has_hasher_size_hint = true;
       req.hasher_size_hint = s->size_hint_at_dictionary;
@@ -435,6 +441,7 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func alloc_func, br
   s->failed = false;
   s->stream_state = kProcessing;
   s->has_dictionary = false;
+  s->dictionary_in_window = false;
   s->size_hint_at_dictionary = 0;
   s->output_pos = 0;
   s->total_out = 0;
@@ -526,7 +533,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
       // (repeated FLUSH calls that only drain output must not encode again)
       // (a partial piece leaves the output on a bit boundary: the flush padding is still owed then)
       if (!(s->carry.valid && s->encoded_upto == s->input.size() && s->carry.tail_nbits == 0) && !EncodeBuffered(s, false)) return BROTLI_FALSE;
-    } else if (Streamable(s) && s->first_encode_seen) {
+    } else if (s->first_encode_seen) {
       // PROCESS: once a batch worth of input has piled up, the meta-blocks that are complete within it are encoded and
       // their output becomes available (BrotliEncoderHasMoreOutput); the bytes of the still open meta-block stay
       // buffered, together with the window the next piece needs -- memory stays bounded however long the stream is

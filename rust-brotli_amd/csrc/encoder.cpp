@@ -277,6 +277,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     if (p.size_hint == 0) p.size_hint = std::min<size_t>(n, (size_t)1 << 30);  // update_size_hint with everything offered at once
     if (!req.hasher_chosen_before_size_hint) ChooseHasher(&p);
   }
+  if (continuing && !req.carry_in->use_dictionary) p.use_dictionary = false;  // (turned off by the stream's first piece)
   const char* why = nullptr;
   if (!IsAccelerated(p, &why)) throw std::runtime_error(std::string("brotli_mi355x: ") + why);
   bool catable = p.catable;
@@ -336,7 +337,10 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   };
   std::vector<RawCopy> raw_copies;
   uint32_t raw_head = 0;
-  if (p.catable && n != 0) {
+  // is_first_mb of the reference (encode.rs:2283-2333): nothing / one / both of the raw first bytes are out.  Every encode_data
+  // before "both" stores min(2, bytes) raw -- a flush behind the very first byte makes it three raw bytes in all.
+  const uint32_t raw_state = continuing ? req.carry_in->catable_raw_bytes : 0u;
+  if (p.catable && n != 0 && raw_state < 2) {
     raw_head = (uint32_t)std::min<size_t>(2, n);
     WriteUncompressedHeader(raw_head, &hb);
     raw_copies.push_back({hb.pos >> 3, prefix_bytes, raw_head});
@@ -355,14 +359,19 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       WriteOpenTail(req, &hb);
     }
     if (req.carry_out) {
+      if (!continuing && prefix_bytes != 0)
+        throw std::runtime_error("brotli_mi355x: a flush with nothing to search yet on a stream with a custom dictionary is not supported");
       StreamCarry& co = *req.carry_out;
       if (continuing) co = *req.carry_in;
       co.tail_bits = co.tail_nbits = 0;  // (this piece ends byte aligned: flush padding or the end of the stream)
+      co.catable_raw_bytes = raw_head >= 2 ? 2u : (raw_head == 1 ? (raw_state == 1 ? 2u : 1u) : raw_state);
+      co.use_dictionary = p.use_dictionary;
       if (!co.valid) {
         co.valid = true;
         co.hasher = p.hasher;
         co.size_hint = p.size_hint;
-        const int32_t d0[4] = {4, 11, 15, 16};
+        const int32_t far_away = 0x7ffffff0;  // a catable stream starts without usable last distances (encode.rs:693-703)
+        const int32_t d0[4] = {p.catable ? far_away : 4, p.catable ? far_away : 11, p.catable ? far_away : 15, p.catable ? far_away : 16};
         memcpy(co.dist_cache, d0, sizeof(d0));
       }
     }
@@ -941,6 +950,9 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       co.valid = true;
       co.hasher = p.hasher;
       co.size_hint = p.size_hint;
+      co.dict_break = continuing ? req.carry_in->dict_break : prefix_bytes;
+      co.use_dictionary = p.use_dictionary;
+      co.catable_raw_bytes = raw_head >= 2 ? 2u : (raw_head == 1 ? (raw_state == 1 ? 2u : 1u) : raw_state);
       memcpy(co.dist_cache, plans.back().dist_cache_after, sizeof(co.dist_cache));
       if (partial) {
         co.dict_lookups = plans.back().dict_lookups_after;

@@ -96,7 +96,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   memset(&P_, 0, sizeof(P_));
   P_.total_bytes = prefix_bytes + input_bytes;
   P_.prefix_bytes = prefix_bytes;
-  P_.dict_break = (carry_ && carry_->valid) ? 0u : prefix_bytes;
+  P_.dict_break = (carry_ && carry_->valid) ? carry_->dict_break : prefix_bytes;
   P_.ring_mask = (1u << ComputeRbBits(params)) - 1u;
   P_.max_backward_limit = (1u << params.lgwin) - 16u;
   P_.hasher_kind = params.hasher.type == 5 ? 5 : (params.hasher.type == 9 ? 9 : 6);

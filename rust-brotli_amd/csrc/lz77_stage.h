@@ -63,6 +63,11 @@ struct StreamCarry {
                                      // reference's u16 ring counter num[key] counts from the start of the stream)
   uint32_t tail_bits = 0, tail_nbits = 0;  // last, incomplete byte of the output so far (a piece that ends on a
                                            // meta-block boundary without a flush is not byte aligned)
+  // ---- what the first piece of a stream with a custom dictionary / a catable stream fixes for all that follow
+  uint32_t dict_break = 0;         // ring_buffer_break: the reference keeps cutting matches at this RING index for the whole
+                                   // stream, also after the dictionary has been overwritten (mod.rs:42-54 on masked indices)
+  bool use_dictionary = true;      // static dictionary still in use (a custom dictionary / catable turn it off for good)
+  uint32_t catable_raw_bytes = 0;  // is_first_mb: 0 nothing, 1 one, 2 both raw first bytes of a catable stream are out (encode.rs:2283-2333)
 };
 
 class Lz77Stage {

@@ -39,8 +39,17 @@ for c in range(cases):
     if os.environ.get("FUZZ_TRACE"):
         print("case %d n %d q %d w %d mode %d" % (c, n, q, w, mode), flush=True)
         open(os.environ["FUZZ_TRACE"], "wb").write(d)
+    # flushes on catable / appendable streams and streams with a custom dictionary (row f4): a third of the flush cases
+    fparams, fdic = base, None
+    if mode in (1, 2) and rng.next() % 3 == 0:
+        fparams = base + [x for x in extra if x[0] != 5]
+        if rng.next() % 2:
+            mdic = 2 + rng.next() % 300000
+            odic = rng.next() % (len(pool) - mdic)
+            fdic = pool[odic:odic + mdic]
+
     def flushed(ops):
-        e = lib.encoder(params=base)
+        e = lib.encoder(params=fparams, dictionary=fdic)
         pieces, pos = [], 0
         for item in ops:
             if isinstance(item, tuple):
@@ -109,9 +118,12 @@ for c in range(cases):
                 ops.append((cut, bytes([65 + (rng.next() % 26)]) * (2 + rng.next() % 300)))
             else:
                 ops.append(cut)
-        what = "ops %r" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops],)
+        if fdic is not None and any((x[0] if isinstance(x, tuple) else x) <= 2 for x in ops):
+            fdic = None  # (a flush with nothing to search yet on a stream with a custom dictionary is refused: INTEGRATION.md)
+        what = "ops %r params %r dictionary %s" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops], fparams[2:],
+                                                   len(fdic) if fdic else None)
         product = lambda: flushed(ops)
-        oracle = lambda: orc.stream_with_flushes(d, base, ops)
+        oracle = lambda: orc.stream_with_flushes(d, fparams, ops, dictionary=fdic)
     if os.environ.get("FUZZ_ONLY") and c != int(os.environ["FUZZ_ONLY"]):
         continue
     # an input on which the reference itself fails (it panics on a copy of length 1, see orc.ReferencePanics) must make
@@ -127,7 +139,7 @@ for c in range(cases):
     ok = got == want
     if want == "reference fails":
         panics += 1
-    elif ok and mode != 3:  # (a stream that refers to a custom dictionary needs that dictionary to decode)
+    elif ok and mode != 3 and fdic is None:  # (a stream that refers to a custom dictionary needs that dictionary to decode)
         try:
             ok = orc.decompress(got if isinstance(got, bytes) else b"".join(got), len(d)) == d
         except RuntimeError as ex:

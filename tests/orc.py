@@ -209,7 +209,7 @@ def stream_compress(data, params, prefix=None, collect_trace=False, continuation
     return out.raw[:cap - avail_out.value], trace
 
 
-def stream_with_flushes(data, params, cuts, write_size=0):
+def stream_with_flushes(data, params, cuts, write_size=0, dictionary=None):
     """Oracle stream API with BROTLI_OPERATION_FLUSH after the bytes up to each offset in `cuts` (ascending) and FINISH
     at the end; between flushes the input is handed over with PROCESS in pieces of `write_size` bytes (0: all at once).
     Returns the list of output pieces (one per flush + the final one)."""
@@ -225,6 +225,9 @@ def stream_with_flushes(data, params, cuts, write_size=0):
     s = L.orc_encoder_create()
     for k, v in params:
         L.orc_encoder_set_parameter(s, k, v)
+    if dictionary is not None:  # BrotliEncoderSetCustomDictionary (encode.rs:1196-1270)
+        L.orc_encoder_set_custom_dictionary.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int]
+        L.orc_encoder_set_custom_dictionary(s, len(dictionary), dictionary, 0)
     cap = L.orc_max_compressed_size(len(data)) + 1024 + 16 * len(cuts)
     out = ctypes.create_string_buffer(cap)
     inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)

@@ -164,10 +164,18 @@ def _suite(lib):
     got = e.finish()
     e.close()
     assert got == orc.writer_compress(x, 8, 17, chunk=100000)
-    # not supported: flushing a stream with a custom dictionary
+    # flushing a stream with a custom dictionary (round 3; tests/test_streaming_dictionary.py has the sweep) ...
+    e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
+    pieces = [e.flush(a[1000:2000])]
+    e._stream(2, a[2000:9000])
+    pieces.append(bytes(e._out))
+    e.close()
+    assert pieces == orc.stream_with_flushes(a[1000:9000], [(Q, 5)], [1000], dictionary=a[:1000])
+    # ... except a flush with nothing to search yet, which is refused (the state of the bare dictionary's hash table is
+    # something only the search stage produces)
     e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
     with pytest.raises(Exception):
-        e.flush(a[1000:2000])
+        e.flush(b"")
     e.close()
     # unsupported parameters fail loudly instead of silently doing something else
     import brotli_mi355x as _m  # noqa: F401
