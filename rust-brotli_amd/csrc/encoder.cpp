@@ -291,6 +291,9 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   p.appendable = appendable;
   const uint32_t prefix_bytes = (continuing || req.prefix_size > 1) ? (uint32_t)req.prefix_size : 0;
 
+  // context bytes in front of a meta-block read as 0 below this text position: a custom dictionary does not count as stream
+  // until the first meta-block has been written (the reference sets prev_byte only behind a written meta-block)
+  const uint32_t prev_floor = continuing ? req.carry_in->prev_floor : ((prefix_bytes && !req.prefix_is_file_continuation) ? prefix_bytes : 0u);
   HostBits hb;
   // stream header: window bits (EncodeWindowBits, encode.rs:603-625)
   if (!continuing && !(req.params.catable && p.bare_stream)) {
@@ -359,13 +362,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       WriteOpenTail(req, &hb);
     }
     if (req.carry_out) {
-      if (!continuing && prefix_bytes != 0)
-        throw std::runtime_error("brotli_mi355x: a flush with nothing to search yet on a stream with a custom dictionary is not supported");
       StreamCarry& co = *req.carry_out;
       if (continuing) co = *req.carry_in;
       co.tail_bits = co.tail_nbits = 0;  // (this piece ends byte aligned: flush padding or the end of the stream)
       co.catable_raw_bytes = raw_head >= 2 ? 2u : (raw_head == 1 ? (raw_state == 1 ? 2u : 1u) : raw_state);
       co.use_dictionary = p.use_dictionary;
+      co.prev_floor = prev_floor;  // (no meta-block written by this piece)
       if (!co.valid) {
         co.valid = true;
         co.hasher = p.hasher;
@@ -373,6 +375,14 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         const int32_t far_away = 0x7ffffff0;  // a catable stream starts without usable last distances (encode.rs:693-703)
         const int32_t d0[4] = {p.catable ? far_away : 4, p.catable ? far_away : 11, p.catable ? far_away : 15, p.catable ? far_away : 16};
         memcpy(co.dist_cache, d0, sizeof(d0));
+        co.dict_break = prefix_bytes;
+        if (prefix_bytes != 0) {
+          // nothing searched yet behind a custom dictionary: the hash table holds what HasherPrependCustomDictionary put there,
+          // every dictionary position but the last StoreLookahead - 1 (encode.rs:1196-1270, mod.rs:224-229)
+          const uint32_t htl = p.hasher.type == 6 ? 8u : 4u;
+          co.stored.assign(prefix_bytes, 0);
+          if (prefix_bytes > htl - 1) std::fill(co.stored.begin(), co.stored.begin() + (prefix_bytes - (htl - 1)), (uint8_t)1);
+        }
       }
     }
     const size_t total_bytes = (size_t)((hb.pos + 7) >> 3);
@@ -516,7 +526,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       std::vector<uint32_t> where((size_t)n_mb * 2, 0xffffffffu);
       for (uint32_t m = 0; m < n_mb; ++m) {
         const uint32_t s = descs[m].start;
-        const uint32_t lo = (prefix_bytes && !req.prefix_is_file_continuation) ? prefix_bytes : 0;
+        const uint32_t lo = prev_floor;
         if (s >= lo + 2) where[2 * m] = s - 2;
         if (s >= lo + 1) where[2 * m + 1] = s - 1;
       }
@@ -951,6 +961,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       co.hasher = p.hasher;
       co.size_hint = p.size_hint;
       co.dict_break = continuing ? req.carry_in->dict_break : prefix_bytes;
+      co.prev_floor = 0;
       co.use_dictionary = p.use_dictionary;
       co.catable_raw_bytes = raw_head >= 2 ? 2u : (raw_head == 1 ? (raw_state == 1 ? 2u : 1u) : raw_state);
       memcpy(co.dist_cache, plans.back().dist_cache_after, sizeof(co.dist_cache));

@@ -67,6 +67,8 @@ struct StreamCarry {
   uint32_t dict_break = 0;         // ring_buffer_break: the reference keeps cutting matches at this RING index for the whole
                                    // stream, also after the dictionary has been overwritten (mod.rs:42-54 on masked indices)
   bool use_dictionary = true;      // static dictionary still in use (a custom dictionary / catable turn it off for good)
+  uint32_t prev_floor = 0;         // text position below which the context bytes of the next meta-block read as 0: the end of a
+                                   // custom dictionary until the first meta-block has been written (encode.rs:2526-2534 runs only then)
   uint32_t catable_raw_bytes = 0;  // is_first_mb: 0 nothing, 1 one, 2 both raw first bytes of a catable stream are out (encode.rs:2283-2333)
 };
 

@@ -118,8 +118,6 @@ for c in range(cases):
                 ops.append((cut, bytes([65 + (rng.next() % 26)]) * (2 + rng.next() % 300)))
             else:
                 ops.append(cut)
-        if fdic is not None and any((x[0] if isinstance(x, tuple) else x) <= 2 for x in ops):
-            fdic = None  # (a flush with nothing to search yet on a stream with a custom dictionary is refused: INTEGRATION.md)
         what = "ops %r params %r dictionary %s" % ([x if not isinstance(x, tuple) else (x[0], len(x[1])) for x in ops], fparams[2:],
                                                    len(fdic) if fdic else None)
         product = lambda: flushed(ops)

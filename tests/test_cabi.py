@@ -171,12 +171,14 @@ def _suite(lib):
     pieces.append(bytes(e._out))
     e.close()
     assert pieces == orc.stream_with_flushes(a[1000:9000], [(Q, 5)], [1000], dictionary=a[:1000])
-    # ... except a flush with nothing to search yet, which is refused (the state of the bare dictionary's hash table is
-    # something only the search stage produces)
-    e = lib.encoder(params=[(Q, 5)], dictionary=a[:1000])
-    with pytest.raises(Exception):
-        e.flush(b"")
+    # ... also with nothing to search yet (the hash table then holds the bare dictionary, and the context bytes of the first
+    # meta-block still read as 0)
+    e = lib.encoder(params=[(Q, 6), (SH, 5 << 20)], dictionary=a[:1000])
+    pieces = [e.flush(b"")]
+    e._stream(2, a[1000:60000])
+    pieces.append(bytes(e._out))
     e.close()
+    assert pieces == orc.stream_with_flushes(a[1000:60000], [(Q, 6), (SH, 5 << 20)], [0], dictionary=a[:1000])
     # unsupported parameters fail loudly instead of silently doing something else
     import brotli_mi355x as _m  # noqa: F401
     with pytest.raises(Exception):

@@ -62,6 +62,12 @@ run("catable + magic number", a, [(Q, 6), (W, 18), (CAT, 1), (MAGIC, 1)], [1, 40
 run("appendable", mix, [(Q, 5), (W, 20), (APP, 1)], [100, 1 << 20])
 run("appendable + byte align, flush twice at one point", a, [(Q, 5), (W, 22), (APP, 1), (ALIGN, 1)], [70000, 70000])
 run("dictionary + catable", a[1000:], [(Q, 5), (W, 22), (CAT, 1)], [40000], dic=a[:1000])
+# a flush with nothing to search yet behind a dictionary: the table holds the bare dictionary, and the context bytes of the
+# first meta-block still read as 0 (13 literal contexts with this size hint, so they matter)
+for q in (5, 6, 9):
+    run("dictionary q%%d, flush before any input" %% q, m[300000:400000], [(Q, q), (W, 22), (5, 5 << 20)], [0, 0, 50000], dic=m[:300000])
+run("dictionary + catable, flushes at 0, 1, 2, 3", a[5000:], [(Q, 5), (W, 22), (CAT, 1)], [0, 1, 2, 3, 40000], dic=a[:5000])
+run("dictionary of three bytes, flush at 0", a[3:], [(Q, 5), (W, 22)], [0, 40000], dic=a[:3])
 # PROCESS in bounded memory: the window is trimmed behind the dictionary, the dictionary-end rule stays
 run("dictionary, 64 KiB writes, lgwin 17", m[100000:], [(Q, 5), (W, 17)], [1 << 20, 2 << 20], dic=m[:100000], write=65536, expect_early=True)
 run("dictionary, odd writes, no flush", m[100000:], [(Q, 5), (W, 17)], [], dic=m[:100000], write=100003, expect_early=True)
