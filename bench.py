@@ -20,7 +20,9 @@ The same line carries
                 libbrotlienc 1.0.9 at the same settings as an independent column
   e2e           the same step with the host->device copy of the input inside the timed region
   other_workloads (N = 1)  BASELINE configs[2], [4], zero fill and a 1 GiB cut of configs[3] at their stated sizes, each
-                verified against the oracle hash frozen in tests/golden/large_hashes.json
+                verified against the oracle hash frozen in tests/golden/large_hashes.json; and two quality-9.5 entries
+                (quality 10 + BROTLI_PARAM_Q9_5, SURVEY row b10: 8 MiB of text at lgwin 22 = one meta-block, and at lgwin 18
+                = sixteen in flight), each compared with the oracle run here, whose single-core rate stands beside it
   config4       (N > 1, or --config4) BASELINE configs[3], cut to 1 GiB: Silesia-like mix, BrotliEncoderCompressMulti with
                 8 shards dealt to the N GPUs -- strong scaling, same stream for every N, verified against the frozen hash.
                 (At the full 4 GiB -- 512 MiB per shard -- the REFERENCE fails on every seed that was tried: a match cut to
