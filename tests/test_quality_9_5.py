@@ -83,6 +83,47 @@ def _flushes(lib):
     assert pieces == want
 
 
+_STREAMED = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+import orc, synth, test_cabi
+lib = test_cabi._load(%(kind)r)
+Q, W, SH = 1, 2, 5
+for name, d, w, chunk in (("markov 6 MiB, lgwin 18", synth.markov_text(6 << 20, 11), 18, 65536),
+                          ("mixed 4 MiB, lgwin 20", synth.mixed(4 << 20, 12), 20, 100003)):
+    params = [(Q, 10), (150, 1), (W, w), (SH, 2 << 20)]
+    e = lib.encoder(params=params)
+    early = 0
+    for i in range(0, len(d), chunk):
+        e.write(d[i:i + chunk])
+        early = max(early, len(e._out))
+    got = e.finish()
+    e.close()
+    assert got == orc.reader_compress(d, params, chunk=chunk), name
+    assert early > len(got) // 2, (name, "PROCESS handed nothing out", early)
+    print("OK", name, len(got), early)
+"""
+
+
+def _streamed(kind):
+    """bounded-memory streaming (BROTLI_OPERATION_PROCESS hands out the meta-blocks that are complete, the window is trimmed):
+    every piece is built by the quality >= 10 builder; the batch is turned down so that a few MiB go through several pieces"""
+    import subprocess
+    import sys
+    env = dict(os.environ, BROTLI_MI355X_STREAM_BATCH=str(1 << 20))
+    r = subprocess.run([sys.executable, "-c", _STREAMED % dict(tests=HERE, kind=kind)], env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_streamed_in_pieces_emu():
+    _streamed("emu")
+
+
+@pytest.mark.gpu
+def test_streamed_in_pieces_gpu():
+    _streamed("gpu")
+
+
 def test_reference_kat_130036_emu():
     import test_cabi
     _kat(test_cabi._load("emu"))
