@@ -160,7 +160,11 @@ bool IsAccelerated(const EncoderParams& p, const char** why_not) {
           "builder) are implemented on the device in this build";
   } else if (p.hasher.type != 5 && p.hasher.type != 6 && p.hasher.type != 9) {
     why = "hasher type not implemented on the device (lgwin <= 16 at quality 5..8 selects the reference's H6 fallback with 256-deep rings)";
+#if defined(BROTLI_HOST_EMU) || defined(BR_DEEP_RINGS)
+  } else if (p.hasher.block_bits > 9) {
+#else
   } else if (p.hasher.block_bits > 8) {
+#endif
     why = "ring depth above 256 not implemented on the device";
   } else if (p.large_window) {
     why = "large_window not implemented on the device";

@@ -58,7 +58,15 @@
 namespace brotli_mi355x {
 
 static constexpr int kMaxCandidatesH9 = 16 + 256;  // ndist <= 16, ring depth <= 256 (H9, quality 9)
+#if defined(BROTLI_HOST_EMU) || defined(BR_DEEP_RINGS)
+// (the emulation build also takes the 512-deep H5 / H6 rings of quality 11 + Q9_5, so that the host logic and the scalar chain
+// code can be checked against the reference's 129 715-byte known answer; the device build refuses them until its kernels have
+// been run at that depth on the hardware, encoder_params.cpp.  `make variant NAME=deep EXTRA=-DBR_DEEP_RINGS=1` builds the
+// device library with the deep scratch for that run.)
+static constexpr int kMaxCandidatesAdv = 16 + 512;
+#else
 static constexpr int kMaxCandidatesAdv = 16 + 128;  // ring depth <= 128 (quality <= 8)
+#endif
 // per-position flag byte: bit 0 = the position is in the hash table, bit 1 = FindLongestMatch ran on it
 static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 // the position went into its bucket ring as a MASKED position (StoreRangeOptBatch past the first ring-buffer revolution,

@@ -140,14 +140,40 @@ def test_flushes_emu():
 
 
 def test_what_is_still_refused():
-    """quality 10 / 11 without Q9_5 are the Zopfli path (H10), quality 11 with it asks for 512-deep rings: refused with
-    a message, never routed anywhere else"""
+    """quality 10 / 11 without Q9_5 are the Zopfli path (H10): refused with a message, never routed anywhere else"""
     import emu
     L = emu.lib()
     a = synth.alice()
-    for params in ([(Q, 10), (W, 22)], [(Q, 11), (W, 22)], [(Q, 11), (Q9_5, 1), (W, 22), (SH, 2 << 20)]):
+    for params in ([(Q, 10), (W, 22)], [(Q, 11), (W, 22)]):
         with pytest.raises(RuntimeError):
             emu.encode_stream(L, a, params)
+
+
+def test_quality_11_with_q9_5_emulation_only():
+    """Quality 11 + Q9_5 selects H5 / H6 with 512-deep rings and 16 cache candidates (encode.rs:863-893).  The EMULATION build
+    takes that depth (kMaxCandidatesAdv in lz77_chain.h), the device build refuses it until its kernels have been run at that
+    depth on the hardware -- so this is evidence for the host logic, the scalar chain code and the meta-block builder at
+    quality 11, not for the device.  The reference's second known answer for the path: random_then_unicode through
+    roundtrip_helper(.., 11, 22, q9_5) == 129 715 bytes (src/bin/integration_tests.rs:397-428)."""
+    import emu
+    import test_cabi
+    from cmp_stream import check_bytes
+    d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
+    params = [(Q, 11), (Q9_5, 1), (W, 22), (SH, 2048 * 1024)]
+    e = test_cabi._load("emu").encoder(params=params)
+    for i in range(0, len(d), 4096):
+        e.write(d[i:i + 4096])
+    got = e.finish()
+    e.close()
+    assert len(got) == 129715
+    assert got == orc.reader_compress(d, params, chunk=4096)
+    L = emu.lib()
+    a = synth.alice()
+    assert check_bytes(L, "alice q11 + Q9_5", a, [(Q, 11), (Q9_5, 1), (W, 22)])
+    assert check_bytes(L, "alice q11 + Q9_5, lgwin 18", a, [(Q, 11), (Q9_5, 1), (W, 18), (SH, len(a))])
+    assert check_bytes(L, "mixed 2 MiB q11 + Q9_5", synth.mixed(2 << 20), [(Q, 11), (Q9_5, 1), (W, 20)])
+    m = synth.markov_text(6 << 20)
+    assert check_bytes(L, "markov 6 MiB q11 + Q9_5 (H6)", m, [(Q, 11), (Q9_5, 1), (W, 22), (SH, len(m))])
 
 
 @pytest.mark.gpu
