@@ -1,6 +1,8 @@
 // encoder_params.cpp -- see encoder_params.h
 #include "encoder_params.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace brotli_mi355x {
@@ -153,6 +155,17 @@ void ChooseHasher(EncoderParams* params) {
   }
 }
 
+// The emulation build takes the 512-deep rings (tests/test_quality_9_5.py checks the reference's 129 715-byte known answer
+// through it); on the device they stay behind a switch until their kernels have been validated there.
+static bool DeepRingsAllowed() {
+#if defined(BROTLI_HOST_EMU)
+  return true;
+#else
+  static const bool on = getenv("BROTLI_MI355X_DEEP_RINGS") != nullptr;
+  return on;
+#endif
+}
+
 bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
   if (p.quality < 5 || p.quality > 11 || (p.quality > 9 && !p.q9_5)) {
@@ -160,12 +173,11 @@ bool IsAccelerated(const EncoderParams& p, const char** why_not) {
           "builder) are implemented on the device in this build";
   } else if (p.hasher.type != 5 && p.hasher.type != 6 && p.hasher.type != 9) {
     why = "hasher type not implemented on the device (lgwin <= 16 at quality 5..8 selects the reference's H6 fallback with 256-deep rings)";
-#if defined(BROTLI_HOST_EMU) || defined(BR_DEEP_RINGS)
   } else if (p.hasher.block_bits > 9) {
-#else
-  } else if (p.hasher.block_bits > 8) {
-#endif
-    why = "ring depth above 256 not implemented on the device";
+    why = "ring depth above 512 does not occur in the reference";
+  } else if (p.hasher.block_bits > 8 && !DeepRingsAllowed()) {
+    why = "the 512-deep rings of quality 11 + Q9_5 have kernels of their own (ChainScratchT<.., kDeep>) that have not been run on "
+          "the hardware yet: BROTLI_MI355X_DEEP_RINGS=1 switches them on for that run";
   } else if (p.large_window) {
     why = "large_window not implemented on the device";
   }

@@ -58,15 +58,8 @@
 namespace brotli_mi355x {
 
 static constexpr int kMaxCandidatesH9 = 16 + 256;  // ndist <= 16, ring depth <= 256 (H9, quality 9)
-#if defined(BROTLI_HOST_EMU) || defined(BR_DEEP_RINGS)
-// (the emulation build also takes the 512-deep H5 / H6 rings of quality 11 + Q9_5, so that the host logic and the scalar chain
-// code can be checked against the reference's 129 715-byte known answer; the device build refuses them until its kernels have
-// been run at that depth on the hardware, encoder_params.cpp.  `make variant NAME=deep EXTRA=-DBR_DEEP_RINGS=1` builds the
-// device library with the deep scratch for that run.)
-static constexpr int kMaxCandidatesAdv = 16 + 512;
-#else
-static constexpr int kMaxCandidatesAdv = 16 + 128;  // ring depth <= 128 (quality <= 8)
-#endif
+static constexpr int kMaxCandidatesAdv = 16 + 128;   // ring depth <= 128 (quality <= 8)
+static constexpr int kMaxCandidatesDeep = 16 + 512;  // the 512-deep H5 / H6 rings of quality 11 + Q9_5 (ChainScratchT<.., kDeep>)
 // per-position flag byte: bit 0 = the position is in the hash table, bit 1 = FindLongestMatch ran on it
 static constexpr uint8_t kFlagStored = 1, kFlagSearched = 2;
 // the position went into its bucket ring as a MASKED position (StoreRangeOptBatch past the first ring-buffer revolution,
@@ -144,9 +137,11 @@ static constexpr uint32_t kMaxContinuation = 4;
 static constexpr uint32_t kRowWindow = BR_ROW_WINDOW;  // positions held in LDS
 BR_DEV uint32_t br_tag16(uint32_t first_four_bytes) { return (first_four_bytes * 0x9E3779B1u) >> 16; }
 
-template <bool kH9, bool kRows = false>
+// kDeep: the candidate scratch of the 512-deep rings, an instantiation of its own so that the kernels of quality 6-8 keep
+// their registers and LDS (with the deep scratch they would run at half the occupancy)
+template <bool kH9, bool kRows = false, bool kDeep = false>
 struct ChainScratchT {  // one per wavefront (LDS on the device)
-  static constexpr int kMaxCandidates = kRows ? 16 + (int)kRowEntries : (kH9 ? kMaxCandidatesH9 : kMaxCandidatesAdv);
+  static constexpr int kMaxCandidates = kRows ? 16 + (int)kRowEntries : (kH9 ? kMaxCandidatesH9 : (kDeep ? kMaxCandidatesDeep : kMaxCandidatesAdv));
   // !kRows: rank records (info) of positions [win_base, win_base + kInfoWindow), two words each
   //  kRows: candidate rows of positions [win_base, win_base + kRowWindow)
   alignas(16) uint32_t win[kRows ? kRowWindow * kRowEntries : kInfoWindow * 2];
@@ -639,8 +634,8 @@ BR_DEV void br_probe_pair_live16(const Lz77Params& P, const ChainTables& t, cons
 }
 #endif
 
-template <bool kH9, bool kRows, bool kLive = false>
-BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, uint32_t p0,
+template <bool kH9, bool kRows, bool kLive = false, bool kDeep = false>
+BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows, kDeep>& s, ProbeMeta& m, uint32_t p0,
                           const int32_t* cache, uint32_t cache_version, uint32_t pos_end, const LiveRing* live = nullptr) {
 #if !BR_SCALAR
   if constexpr (kRows && kLive) {
@@ -749,7 +744,7 @@ BR_DEV void br_probe_pair(const Lz77Params& P, const ChainTables& t, ChainScratc
     // those whose text must be looked at -- valid cache distances, ring entries in reach whose tag equals that of the
     // searched position, dictionary items -- are compacted into a list, (3) the list is worked off 64 entries at a time
     // (typically two trips).  Same results as the loop below, slot for slot.
-    constexpr uint32_t kMaxTrips = (2u * (uint32_t)(ChainScratchT<kH9, kRows>::kMaxCandidates + 2) + 63u) / 64u;
+    constexpr uint32_t kMaxTrips = (2u * (uint32_t)(ChainScratchT<kH9, kRows, kDeep>::kMaxCandidates + 2) + 63u) / 64u;
     const uint32_t lane = (uint32_t)BR_LANE;
     const uint32_t tag_of[2] = {br_tag16(br_load32(t.text + p0)), br_tag16(br_load32(t.text + p0 + 1))};
     uint32_t ring_q[kMaxTrips], ring_tag[kMaxTrips];
@@ -960,8 +955,8 @@ BR_DEV void br_dictionary_stage(const Lz77Params& P, const ChainTables& t, DictS
 }
 
 // Phase 2: fold the candidates of probe slot w in the reference's order, then the static dictionary stage.
-template <bool kH9, bool kRows>
-BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const ProbeMeta& m, uint32_t w,
+template <bool kH9, bool kRows, bool kDeep = false>
+BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows, kDeep>& s, const ProbeMeta& m, uint32_t w,
                                   DictState& ds, uint32_t blk_end, SearchResult* before_dictionary = nullptr, bool candidates_only = false) {
   const uint32_t cur = m.pos + w;
   const uint32_t max_length = blk_end - cur;
@@ -1355,8 +1350,8 @@ BR_DEV bool br_same_as_logged(const uint32_t* rec, const SearchResult& r) {
 }
 
 // search(x) for the parse loop: reuses the speculative second slot when it is still valid
-template <bool kH9, bool kRows, bool kLive = false>
-BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, ProbeMeta& m, DictState& ds,
+template <bool kH9, bool kRows, bool kLive = false, bool kDeep = false>
+BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows, kDeep>& s, ProbeMeta& m, DictState& ds,
                               uint32_t x, const int32_t* cache, uint32_t cache_version, uint32_t blk_end, const LiveRing* live = nullptr) {
 #if defined(BR_CHAIN_PROFILE)
   const unsigned long long t0 = BR_TICK();
@@ -1421,8 +1416,8 @@ BR_DEV void br_prepare_distance_cache(int32_t* dc, uint32_t ndist) {
 // (ChainTables::search_log) and the candidate lists of NOW -- and says whether they find what they found then.  Used by
 // the validation after a flag change (lz77_recheck_searches): a segment is parsed again only if one of its searches
 // comes out differently, not whenever one of its candidate lists was touched.
-template <bool kH9>
-BR_DEV bool br_recheck_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, false>& s, uint32_t p, uint32_t blk_end) {
+template <bool kH9, bool kDeep = false>
+BR_DEV bool br_recheck_search(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, false, kDeep>& s, uint32_t p, uint32_t blk_end) {
   const uint32_t* rec = t.search_log + (size_t)p * kSearchLogWords;
   BR_SYNC();
   int32_t* dc = s.dc;
@@ -1543,8 +1538,8 @@ BR_DEV void br_write_checkpoint(Checkpoint* rec, const Checkpoint& c) {
   if (BR_LANE == 0) *rec = c;
 }
 
-template <bool kH9, bool kRows, bool kLive = false, bool kSplice = false>
-BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment& seg_in,
+template <bool kH9, bool kRows, bool kLive = false, bool kSplice = false, bool kDeep = false>
+BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows, kDeep>& s, const Segment& seg_in,
                                  const SegEntry& entry, SegExit& exit_out, SegEntry& next, const LiveRing* live = nullptr,
                                  BlockTail* tail = nullptr, const Reparse* rp = nullptr) {
   const uint32_t pos_end = BR_UNIFORM(seg_in.blk_end);
@@ -2133,8 +2128,8 @@ BR_DEV uint32_t br_parse_segment(const Lz77Params& P, const ChainTables& t, Chai
 // they are not scheduled themselves: a change that would otherwise creep forward one segment per round (each
 // round costing a full chain latency) is absorbed in one launch.  A continued segment gets its new entry
 // written to entries[] so that the host resolver sees what it was parsed with.
-template <bool kH9, bool kRows, bool kSplice = false>
-BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows>& s, const Segment* segments,
+template <bool kH9, bool kRows, bool kSplice = false, bool kDeep = false>
+BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, kRows, kDeep>& s, const Segment* segments,
                            SegEntry* entries, SegExit* exits, uint32_t k, uint8_t* sched, uint32_t max_continuation) {
   if constexpr (kRows) {
     if (BR_LANE < 32) s.dict_off[BR_LANE] = BR_LANE < 25 ? t.dict_offsets_by_length[BR_LANE] : 0u;
@@ -2257,8 +2252,8 @@ BR_DEV void br_parse_chain(const Lz77Params& P, const ChainTables& t, ChainScrat
 // (LiveBlockState).  What it cannot know -- a meta-block that ends up stored uncompressed hands the distance cache of
 // its start to the next one (encode.rs:1994, 2142) -- shows as a wrong entry when the host resolver replays the exits,
 // and the stream is parsed again from that block.  The entries used go to entries[], the books to live_state[].
-template <bool kRows>
-BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratchT<false, kRows>& s, const Segment* segments, SegEntry* entries,
+template <bool kRows, bool kDeep = false>
+BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratchT<false, kRows, kDeep>& s, const Segment* segments, SegEntry* entries,
                           SegExit* exits, uint32_t first, uint32_t last, uint32_t table, uint32_t* histo /* 256 words of scratch */) {
   LiveRing lr;
   const size_t keys_per_table = (size_t)1 << P.bucket_bits;
@@ -2348,8 +2343,8 @@ BR_DEV void br_parse_live(const Lz77Params& P, const ChainTables& t, ChainScratc
 // Repeats the cache and ring stages of the search a live chain ran at position p -- with the distance cache it had then
 // (ChainTables::search_log) and the ring that the flags behind `ix` imply for that position -- and says whether they find
 // what they found then (lz77_live_verify).
-template <bool kRows>
-BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const LiveIndex& ix, ChainScratchT<false, kRows>& s, uint32_t p,
+template <bool kRows, bool kDeep = false>
+BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const LiveIndex& ix, ChainScratchT<false, kRows, kDeep>& s, uint32_t p,
                              uint32_t blk_end) {
   const uint32_t* rec = t.search_log + (size_t)p * kSearchLogWords;
   BR_SYNC();

@@ -1282,9 +1282,11 @@ static bool plain_q5_config(const Lz77Params& P) {
 }
 // kSplice: the chains of a list launch, which restart from and stop at checkpoints (lz77_chain.h, Checkpoint / Reparse);
 // round 0 and the warm-up run without that code (round 0 records the checkpoints).
-template <bool kH9, bool kRows, uint32_t kSpec = 0, bool kSplice = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kH9 ? 6 : BR_PARSE_WAVES, kH9 ? 6 : BR_PARSE_WAVES))) void k_parse_segments(ParseArgs a) {
-  __shared__ ChainScratchT<kH9, kRows> scratch;
+// kDeep: the 512-deep rings of quality 11 + Q9_5 (ChainScratchT<.., kDeep>): twice the candidates per search of quality 9 and 17
+// trips of candidate bookkeeping in registers (120 VGPRs): four waves per SIMD is what fits
+template <bool kH9, bool kRows, uint32_t kSpec = 0, bool kSplice = false, bool kDeep = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kDeep ? 4 : (kH9 ? 6 : BR_PARSE_WAVES), kDeep ? 4 : (kH9 ? 6 : BR_PARSE_WAVES)))) void k_parse_segments(ParseArgs a) {
+  __shared__ ChainScratchT<kH9, kRows, kDeep> scratch;
   // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of segments so that the text
   // window and the rank rows its chains touch stay in that XCD's L2
   uint32_t item = blockIdx.x;
@@ -1385,6 +1387,8 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
       if (splice) hipLaunchKernelGGL((k_parse_segments<false, true, 0, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
       else hipLaunchKernelGGL((k_parse_segments<false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
     }
+  } else if (P.block_bits > 7) {
+    hipLaunchKernelGGL((k_parse_segments<false, false, 0, false, true>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else {
     hipLaunchKernelGGL((k_parse_segments<false, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   }
@@ -1650,9 +1654,9 @@ struct RecheckArgs {
   SegGeometry geo;
   uint8_t* dirty;
 };
-template <bool kH9>
+template <bool kH9, bool kDeep = false>
 __global__ __launch_bounds__(64) void k_recheck_searches(RecheckArgs a) {
-  __shared__ ChainScratchT<kH9, false> scratch;
+  __shared__ ChainScratchT<kH9, false, kDeep> scratch;
   uint32_t n = *a.count;
   if (n > a.cap) n = a.cap;
   for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
@@ -1694,6 +1698,8 @@ void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, 
   const uint32_t grid = B.recheck_cap < 16384u ? B.recheck_cap : 16384u;
   if (P.hasher_kind == 9) {
     hipLaunchKernelGGL((k_recheck_searches<true>), dim3(grid), dim3(64), 0, BR_STREAM, a);
+  } else if (P.block_bits > 7) {
+    hipLaunchKernelGGL((k_recheck_searches<false, true>), dim3(grid), dim3(64), 0, BR_STREAM, a);
   } else {
     hipLaunchKernelGGL((k_recheck_searches<false>), dim3(grid), dim3(64), 0, BR_STREAM, a);
   }
@@ -1972,9 +1978,9 @@ struct LiveParseArgs {
 };
 // (a launch has at most a few thousand of these chains, each of them bound by the latency of its own dependent loads:
 // registers matter more than waves per SIMD)
-template <bool kRows>
+template <bool kRows, bool kDeep = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_parse_live(LiveParseArgs a) {
-  __shared__ ChainScratchT<false, kRows> scratch;
+  __shared__ ChainScratchT<false, kRows, kDeep> scratch;
   __shared__ uint32_t histo[256];
   const uint32_t item = blockIdx.x;
   if (item >= a.count) return;
@@ -1998,6 +2004,8 @@ void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffer
   a.span_blocks = L.span_blocks;
   if ((1u << P.block_bits) <= kRowEntries) {
     hipLaunchKernelGGL((k_parse_live<true>), dim3(count), dim3(64), 0, BR_STREAM, a);
+  } else if (P.block_bits > 7) {
+    hipLaunchKernelGGL((k_parse_live<false, true>), dim3(count), dim3(64), 0, BR_STREAM, a);
   } else {
     hipLaunchKernelGGL((k_parse_live<false>), dim3(count), dim3(64), 0, BR_STREAM, a);
   }
@@ -2038,9 +2046,9 @@ struct LiveVerifyArgs {
   uint32_t prefix_bytes, block_bytes;
   uint8_t* dirty;
 };
-template <bool kRows>
+template <bool kRows, bool kDeep = false>
 __global__ __launch_bounds__(64) void k_live_verify(LiveVerifyArgs a) {
-  __shared__ ChainScratchT<false, kRows> scratch;
+  __shared__ ChainScratchT<false, kRows, kDeep> scratch;
   uint32_t n = *a.count;
   if (n > a.cap) n = a.cap;
   for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
@@ -2081,6 +2089,8 @@ void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffe
   const uint32_t grid = B.recheck_cap < 32768u ? B.recheck_cap : 32768u;
   if ((1u << P.block_bits) <= kRowEntries) {
     hipLaunchKernelGGL((k_live_verify<true>), dim3(grid), dim3(64), 0, BR_STREAM, a);
+  } else if (P.block_bits > 7) {
+    hipLaunchKernelGGL((k_live_verify<false, true>), dim3(grid), dim3(64), 0, BR_STREAM, a);
   } else {
     hipLaunchKernelGGL((k_live_verify<false>), dim3(grid), dim3(64), 0, BR_STREAM, a);
   }

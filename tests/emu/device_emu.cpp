@@ -231,6 +231,7 @@ void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, 
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
   ChainScratchT<false, false> scratch;
+  ChainScratchT<false, false, true> scratch_deep;  // (512-deep rings: the same dispatch as lz77_kernels.hip)
   ChainScratchT<true, false> scratch9;
   const uint32_t n = *B.recheck_count < B.recheck_cap ? *B.recheck_count : B.recheck_cap;
   for (uint32_t i = 0; i < n; ++i) {
@@ -238,7 +239,9 @@ void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, 
     const uint32_t blk = (p - geo.first_block_start) / geo.block_bytes;
     const uint64_t end64 = (uint64_t)geo.first_block_start + (uint64_t)(blk + 1) * geo.block_bytes;
     const uint32_t blk_end = end64 < P.total_bytes ? (uint32_t)end64 : P.total_bytes;
-    const bool same = P.hasher_kind == 9 ? br_recheck_search<true>(P, T, scratch9, p, blk_end) : br_recheck_search<false>(P, T, scratch, p, blk_end);
+    const bool same = P.hasher_kind == 9 ? br_recheck_search<true>(P, T, scratch9, p, blk_end)
+                      : P.block_bits > 7 ? br_recheck_search<false>(P, T, scratch_deep, p, blk_end)
+                                         : br_recheck_search<false>(P, T, scratch, p, blk_end);
     if (!same) emu_mark_dirty(p, geo, dirty);
   }
 }
@@ -416,6 +419,7 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.dist_postfix_bits = P.dist_postfix_bits;
   T.num_direct_distance_codes = P.num_direct_distance_codes;
   ChainScratchT<false, false> scratch;
+  ChainScratchT<false, false, true> scratch_deep;
   ChainScratchT<false, true> scratch_rows;
   ChainScratchT<true, false> scratch9;
   // checkpoints: recorded by every parse of the real segments (not the warm-up's), used by the list launches
@@ -435,6 +439,8 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
       br_parse_chain<false, true, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     } else if (B.rows) {
       br_parse_chain<false, true>(P, T, scratch_rows, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
+    } else if (P.block_bits > 7) {
+      br_parse_chain<false, false>(P, T, scratch_deep, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     } else {
       br_parse_chain<false, false>(P, T, scratch, segments, entries, exits, k, sched, count <= 256 ? 1024u : emu_continuation());
     }
@@ -527,11 +533,16 @@ void lz77_live_materialise(const Lz77Params& P, const Lz77Buffers& B, const Live
 void lz77_live_parse(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffers& L, int which, const uint32_t* first, uint32_t count) {
   const ChainTables T = emu_chain_tables(P, B, L, which ^ 1);
   ChainScratchT<false, false> scratch;
+  ChainScratchT<false, false, true> scratch_deep;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t t = first[i] / L.span_blocks;
     const uint32_t last = std::min<uint32_t>((t + 1) * L.span_blocks, P.num_segments);
     uint32_t histo[256];
-    br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t, histo);
+    if (P.block_bits > 7) {
+      br_parse_live<false>(P, T, scratch_deep, B.segments, B.entries, B.exits, first[i], last, t, histo);
+    } else {
+      br_parse_live<false>(P, T, scratch, B.segments, B.entries, B.exits, first[i], last, t, histo);
+    }
   }
 }
 
@@ -545,13 +556,15 @@ void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffe
   const LiveIndex ix = emu_live_index(P, B, L, next);
   const ChainTables T = emu_chain_tables(P, B, L, next);
   ChainScratchT<false, false> scratch;
+  ChainScratchT<false, false, true> scratch_deep;
   for (uint32_t p = geo.first_block_start; p < P.total_bytes; ++p) {
     if (!(B.flags[next][p] & kFlagSearched)) continue;
     const uint32_t block = (p - geo.prefix_bytes) / geo.block_bytes;
     if (dirty[block]) continue;
     if (prev >= 0 && !reparsed[block] && !L.changed_key[B.keys[p]]) continue;
     const uint32_t blk_end = std::min<uint64_t>(P.total_bytes, (uint64_t)geo.prefix_bytes + ((uint64_t)block + 1) * geo.block_bytes);
-    if (!br_verify_search<false>(P, T, ix, scratch, p, blk_end)) dirty[block] = 1;
+    const bool same = P.block_bits > 7 ? br_verify_search<false>(P, T, ix, scratch_deep, p, blk_end) : br_verify_search<false>(P, T, ix, scratch, p, blk_end);
+    if (!same) dirty[block] = 1;
   }
 }
 

@@ -149,31 +149,44 @@ def test_what_is_still_refused():
             emu.encode_stream(L, a, params)
 
 
-def test_quality_11_with_q9_5_emulation_only():
-    """Quality 11 + Q9_5 selects H5 / H6 with 512-deep rings and 16 cache candidates (encode.rs:863-893).  The EMULATION build
-    takes that depth (kMaxCandidatesAdv in lz77_chain.h), the device build refuses it until its kernels have been run at that
-    depth on the hardware -- so this is evidence for the host logic, the scalar chain code and the meta-block builder at
-    quality 11, not for the device.  The reference's second known answer for the path: random_then_unicode through
-    roundtrip_helper(.., 11, 22, q9_5) == 129 715 bytes (src/bin/integration_tests.rs:397-428)."""
-    import emu
-    import test_cabi
+def _quality_11(lib, L):
+    """Quality 11 + Q9_5 selects H5 / H6 with 512-deep rings and 16 cache candidates (encode.rs:863-893): the chain kernels
+    instantiated with the deep candidate scratch (ChainScratchT<.., kDeep>, lz77_chain.h).  The reference's second known answer
+    for the path: random_then_unicode through roundtrip_helper(.., 11, 22, q9_5) == 129 715 bytes
+    (src/bin/integration_tests.rs:397-428)."""
     from cmp_stream import check_bytes
     d = open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read()
     params = [(Q, 11), (Q9_5, 1), (W, 22), (SH, 2048 * 1024)]
-    e = test_cabi._load("emu").encoder(params=params)
+    e = lib.encoder(params=params)
     for i in range(0, len(d), 4096):
         e.write(d[i:i + 4096])
     got = e.finish()
     e.close()
     assert len(got) == 129715
     assert got == orc.reader_compress(d, params, chunk=4096)
-    L = emu.lib()
     a = synth.alice()
     assert check_bytes(L, "alice q11 + Q9_5", a, [(Q, 11), (Q9_5, 1), (W, 22)])
     assert check_bytes(L, "alice q11 + Q9_5, lgwin 18", a, [(Q, 11), (Q9_5, 1), (W, 18), (SH, len(a))])
     assert check_bytes(L, "mixed 2 MiB q11 + Q9_5", synth.mixed(2 << 20), [(Q, 11), (Q9_5, 1), (W, 20)])
     m = synth.markov_text(6 << 20)
     assert check_bytes(L, "markov 6 MiB q11 + Q9_5 (H6)", m, [(Q, 11), (Q9_5, 1), (W, 22), (SH, len(m))])
+
+
+def test_quality_11_with_q9_5_emu():
+    """on the emulation build: the host logic, the scalar chain code at depth 512 and the meta-block builder at quality 11 --
+    not the device kernels, which wait behind BROTLI_MI355X_DEEP_RINGS=1 for their first run on the hardware (next test)"""
+    import emu
+    import test_cabi
+    _quality_11(test_cabi._load("emu"), emu.lib())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("BROTLI_MI355X_DEEP_RINGS"), reason="the deep-ring kernels have not been run on the hardware "
+                    "yet: BROTLI_MI355X_DEEP_RINGS=1 switches them on (and this test with them)")
+def test_quality_11_with_q9_5_gpu():
+    import gpulib
+    import test_cabi
+    _quality_11(test_cabi._load("gpu"), gpulib.lib())
 
 
 @pytest.mark.gpu
