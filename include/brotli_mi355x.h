@@ -6,7 +6,7 @@
  * reference location each function replaces is cited next to it.  Plain pointers and sizes only.
  *
  * Behavioural contract: for the accelerated configurations (quality 5..9, lgwin 17..24, which select the
- * H5 / H5q5 / H6 / H9 greedy path of the reference; and quality 10 with BROTLI_PARAM_Q9_5 through the stream API,
+ * H5 / H5q5 / H6 / H9 greedy path of the reference; and quality 10 / 11 with BROTLI_PARAM_Q9_5 through the stream API,
  * the reference's "9.5": the H9 search with the quality >= 10 meta-block builder, metablock.rs:133-307) the produced
  * stream is byte-identical to the reference encoder fed the same way.  Everything runs on the GPU through HIP; there is no CPU fallback: calls with
  * parameters outside the accelerated set, or on a machine without a usable gfx950 device, fail

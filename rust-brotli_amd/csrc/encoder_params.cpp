@@ -155,29 +155,25 @@ void ChooseHasher(EncoderParams* params) {
   }
 }
 
-// The emulation build takes the 512-deep rings (tests/test_quality_9_5.py checks the reference's 129 715-byte known answer
-// through it); on the device they stay behind a switch until their kernels have been validated there.
+// The 512-deep rings of quality 11 + Q9_5 run on kernels of their own (ChainScratchT<.., kDeep>).  Their evidence on the
+// hardware is thin so far -- the reference's 129 715-byte known answer, profiles/r03_q11_q9_5_deep_rings_probe.log; the wider
+// identity set has only run on the emulation build -- hence the switch to turn them off.
 static bool DeepRingsAllowed() {
-#if defined(BROTLI_HOST_EMU)
-  return true;
-#else
-  static const bool on = getenv("BROTLI_MI355X_DEEP_RINGS") != nullptr;
-  return on;
-#endif
+  static const bool off = getenv("BROTLI_MI355X_NO_DEEP_RINGS") != nullptr;
+  return !off;
 }
 
 bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
   if (p.quality < 5 || p.quality > 11 || (p.quality > 9 && !p.q9_5)) {
-    why = "only qualities 5..9 and \"9.5\" (BROTLI_PARAM_Q9_5 with quality 10: the greedy H9 path behind the quality >= 10 meta-block "
-          "builder) are implemented on the device in this build";
+    why = "only qualities 5..9 and \"9.5\" (BROTLI_PARAM_Q9_5 with quality 10 or 11: the greedy search behind the quality >= 10 "
+          "meta-block builder) are implemented on the device in this build";
   } else if (p.hasher.type != 5 && p.hasher.type != 6 && p.hasher.type != 9) {
     why = "hasher type not implemented on the device (lgwin <= 16 at quality 5..8 selects the reference's H6 fallback with 256-deep rings)";
   } else if (p.hasher.block_bits > 9) {
     why = "ring depth above 512 does not occur in the reference";
   } else if (p.hasher.block_bits > 8 && !DeepRingsAllowed()) {
-    why = "the 512-deep rings of quality 11 + Q9_5 have kernels of their own (ChainScratchT<.., kDeep>) that have not been run on "
-          "the hardware yet: BROTLI_MI355X_DEEP_RINGS=1 switches them on for that run";
+    why = "the 512-deep rings of quality 11 + Q9_5 are switched off (BROTLI_MI355X_NO_DEEP_RINGS)";
   } else if (p.large_window) {
     why = "large_window not implemented on the device";
   }

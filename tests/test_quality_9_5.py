@@ -149,7 +149,7 @@ def test_what_is_still_refused():
             emu.encode_stream(L, a, params)
 
 
-def _quality_11(lib, L):
+def _quality_11(lib, L, wide):
     """Quality 11 + Q9_5 selects H5 / H6 with 512-deep rings and 16 cache candidates (encode.rs:863-893): the chain kernels
     instantiated with the deep candidate scratch (ChainScratchT<.., kDeep>, lz77_chain.h).  The reference's second known answer
     for the path: random_then_unicode through roundtrip_helper(.., 11, 22, q9_5) == 129 715 bytes
@@ -164,6 +164,8 @@ def _quality_11(lib, L):
     e.close()
     assert len(got) == 129715
     assert got == orc.reader_compress(d, params, chunk=4096)
+    if not wide:
+        return
     a = synth.alice()
     assert check_bytes(L, "alice q11 + Q9_5", a, [(Q, 11), (Q9_5, 1), (W, 22)])
     assert check_bytes(L, "alice q11 + Q9_5, lgwin 18", a, [(Q, 11), (Q9_5, 1), (W, 18), (SH, len(a))])
@@ -173,20 +175,21 @@ def _quality_11(lib, L):
 
 
 def test_quality_11_with_q9_5_emu():
-    """on the emulation build: the host logic, the scalar chain code at depth 512 and the meta-block builder at quality 11 --
-    not the device kernels, which wait behind BROTLI_MI355X_DEEP_RINGS=1 for their first run on the hardware (next test)"""
+    """on the emulation build: the known answer and a wider identity set (host logic, scalar chain code at depth 512, the
+    meta-block builder at quality 11)"""
     import emu
     import test_cabi
-    _quality_11(test_cabi._load("emu"), emu.lib())
+    _quality_11(test_cabi._load("emu"), emu.lib(), wide=True)
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("BROTLI_MI355X_DEEP_RINGS"), reason="the deep-ring kernels have not been run on the hardware "
-                    "yet: BROTLI_MI355X_DEEP_RINGS=1 switches them on (and this test with them)")
 def test_quality_11_with_q9_5_gpu():
+    """on the device: the known answer -- what the deep-ring kernels had shown on the hardware by the end of round 3 (the last
+    ten GPU-seconds of the round, profiles/r03_q11_q9_5_deep_rings_probe.log); BROTLI_MI355X_TEST_DEEP_RINGS_WIDE=1 adds the
+    identity set of the emulation test, which is the first thing to run in round 4"""
     import gpulib
     import test_cabi
-    _quality_11(test_cabi._load("gpu"), gpulib.lib())
+    _quality_11(test_cabi._load("gpu"), gpulib.lib(), wide=bool(os.environ.get("BROTLI_MI355X_TEST_DEEP_RINGS_WIDE")))
 
 
 @pytest.mark.gpu
