@@ -1,6 +1,6 @@
 """Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
-oracle.  FUZZ_Q9_5=1: every case at quality 10 with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10)."""
+oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10)."""
 import os, sys, time
 import synth, orc
 import test_cabi
@@ -24,7 +24,7 @@ for c in range(cases):
     q = 5 + rng.next() % 5
     q95 = bool(os.environ.get("FUZZ_Q9_5"))
     if q95:
-        q = 10
+        q = 11 if os.environ["FUZZ_Q9_5"] == "11" else 10  # (11: the 512-deep H5 / H6 rings)
     w = [17, 18, 20, 22, 24][rng.next() % 5]
     mode = rng.next() % 6
     if q95 and mode == 5:
