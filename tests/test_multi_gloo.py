@@ -101,3 +101,18 @@ def test_empty_shards_and_magic_number(tmp_path):
         mp.spawn(_worker, args=(2, _free_port(), data, 22, out, nshards, extra), nprocs=2, join=True)
         got = open(out, "rb").read()
         assert got == orc.compress_multi(data, [(Q, 5), (W, 22)] + list(extra), nshards)
+
+
+def test_two_ranks_quality_9_5(tmp_path):
+    """the shards of a quality-9.5 job (quality 10 + BROTLI_PARAM_Q9_5: every shard's meta-blocks built by the quality >= 10
+    builder) across two ranks, stitched on rank 0"""
+    import torch.multiprocessing as mp
+    import emu
+    emu.build()
+    data = synth.mixed(700000, seed=31)
+    out = str(tmp_path / "stream.br")
+    extra = ((Q, 10), (150, 1))  # (later settings of a parameter win)
+    mp.spawn(_worker, args=(2, _free_port(), data, 22, out, 3, extra), nprocs=2, join=True)
+    got = open(out, "rb").read()
+    assert got == orc.compress_multi(data, [(Q, 10), (150, 1), (W, 22)], 3)
+    assert orc.decompress(got, len(data)) == data
