@@ -39,6 +39,7 @@ def test_api_sweep_quality_9_5_emulation():
 @pytest.mark.gpu
 def test_api_sweep_quality_9_5_device():
     assert " 0 failures" in _run("fuzz_api.py", 40, 9, FUZZ_Q9_5="1")
+    assert " 0 failures" in _run("fuzz_api.py", 25, 10, FUZZ_Q9_5="11")  # quality 11: the 512-deep H5 / H6 rings
 
 
 @pytest.mark.gpu

@@ -118,12 +118,13 @@ def _streamed(kind, quality=10):
 
 def test_streamed_in_pieces_emu():
     _streamed("emu")
-    _streamed("emu", 11)  # (512-deep rings; on the device only the known answer has run at that depth so far)
+    _streamed("emu", 11)  # 512-deep rings
 
 
 @pytest.mark.gpu
 def test_streamed_in_pieces_gpu():
     _streamed("gpu")
+    _streamed("gpu", 11)  # 512-deep rings (the deep chain kernels)
 
 
 def test_reference_kat_130036_emu():
@@ -186,12 +187,11 @@ def test_quality_11_with_q9_5_emu():
 
 @pytest.mark.gpu
 def test_quality_11_with_q9_5_gpu():
-    """on the device: the known answer -- what the deep-ring kernels had shown on the hardware by the end of round 3 (the last
-    ten GPU-seconds of the round, profiles/r03_q11_q9_5_deep_rings_probe.log); BROTLI_MI355X_TEST_DEEP_RINGS_WIDE=1 adds the
-    identity set of the emulation test, which is the first thing to run in round 4"""
+    """on the device: the known answer and the same identity set as the emulation test -- H5 and H6 at ring depth 512,
+    lgwin 18 / 20 / 22 (the deep chain kernels: k_parse_segments<.., deep>, k_recheck_searches, k_parse_live, k_live_verify)"""
     import gpulib
     import test_cabi
-    _quality_11(test_cabi._load("gpu"), gpulib.lib(), wide=bool(os.environ.get("BROTLI_MI355X_TEST_DEEP_RINGS_WIDE")))
+    _quality_11(test_cabi._load("gpu"), gpulib.lib(), wide=True)
 
 
 @pytest.mark.gpu
