@@ -379,7 +379,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         if (prefix_bytes != 0) {
           // nothing searched yet behind a custom dictionary: the hash table holds what HasherPrependCustomDictionary put there,
           // every dictionary position but the last StoreLookahead - 1 (encode.rs:1196-1270, mod.rs:224-229)
-          const uint32_t htl = p.hasher.type == 6 ? 8u : 4u;
+          const uint32_t htl = IsH6Family(p.hasher.type) ? 8u : 4u;
           co.stored.assign(prefix_bytes, 0);
           if (prefix_bytes > htl - 1) std::fill(co.stored.begin(), co.stored.begin() + (prefix_bytes - (htl - 1)), (uint8_t)1);
         }

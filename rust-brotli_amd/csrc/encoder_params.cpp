@@ -168,8 +168,8 @@ bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   if (p.quality < 5 || p.quality > 11 || (p.quality > 9 && !p.q9_5)) {
     why = "only qualities 5..9 and \"9.5\" (BROTLI_PARAM_Q9_5 with quality 10 or 11: the greedy search behind the quality >= 10 "
           "meta-block builder) are implemented on the device in this build";
-  } else if (p.hasher.type != 5 && p.hasher.type != 6 && p.hasher.type != 9) {
-    why = "hasher type not implemented on the device (lgwin <= 16 at quality 5..8 selects the reference's H6 fallback with 256-deep rings)";
+  } else if (p.hasher.type != 5 && !IsH6Family(p.hasher.type) && p.hasher.type != 9) {
+    why = "hasher type not implemented on the device";
   } else if (p.hasher.block_bits > 9) {
     why = "ring depth above 512 does not occur in the reference";
   } else if (p.hasher.block_bits > 8 && !DeepRingsAllowed()) {

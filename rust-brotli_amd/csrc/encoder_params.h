@@ -89,6 +89,10 @@ bool SetParameter(EncoderParams* params, int id, uint32_t value);
 void FinalizeParams(EncoderParams* params);
 // encode.rs:834-893
 void ChooseHasher(EncoderParams* params);
+// Hasher types 40 / 41 / 42 (lgwin <= 16 at quality 5..8, encode.rs:855-862) have no implementation of their own in the
+// reference: BrotliMakeHasher falls through to InitializeH6 (encode.rs:1096-1114) with the hasher parameters nobody has
+// touched -- bucket_bits 15, block_bits 8 (256-deep rings), hash_len 5, 16 last distances (encode.rs:348-355).
+inline bool IsH6Family(int type) { return type == 6 || type == 40 || type == 41 || type == 42; }
 // true when (quality, hasher) is covered by the gfx950 kernels of this build
 bool IsAccelerated(const EncoderParams& params, const char** why_not);
 
