@@ -27,8 +27,8 @@
  * (encode.rs:2579-2685) flushes pending input the same way and writes the payload (<= 16 MiB) as a metadata block.
  * A stream may be of any length: the hasher reset of the reference at its position wraps (3, 5, 7 ... GiB,
  * encode.rs:1623-1631, 1705-1710) is reproduced.  Streams with a custom
- * dictionary or in the catable / appendable modes are buffered whole until BROTLI_OPERATION_FINISH (at most 2 GiB) and
- * cannot be flushed.  All input offered to a call is always consumed (*available_in becomes 0).
+ * dictionary or in the catable / appendable modes stream and flush the same way, piece by piece in bounded memory
+ * (tests/test_streaming_dictionary.py).  All input offered to a call is always consumed (*available_in becomes 0).
  *
  * BrotliEncoderCompress (one shot) takes inputs of any size: above 1 GiB (BROTLI_MI355X_ONESHOT_STREAM_ABOVE bytes) the
  * call runs through the same stream state machine in batches -- encoder_compress is a loop over compress_stream with

@@ -364,3 +364,93 @@ int orc_compress_multi(const int* keys, const uint32_t* vals, size_t nparams, si
   *encoded_size = out_file_size;
   return 1;
 }
+
+/* BroCatli::new_with_window_size, concat/mod.rs:232-271; returns 0 or CAT_INVALID_WINDOW_SIZE */
+static int brocatli_init_with_window(BroCatli* c, uint8_t lg) {
+  memset(c, 0, sizeof(*c));
+  if (lg > 24) {
+    c->last_bytes[0] = 17;
+    c->last_bytes[1] = (uint8_t)(lg | 64 | 128);
+    c->last_bytes_len = 2;
+  } else if (lg == 16) {
+    c->last_bytes[0] = 1 | 2 | 4;
+    c->last_bytes_len = 1;
+  } else if (lg > 17) {
+    c->last_bytes[0] = (uint8_t)((3 + (lg - 18) * 2) | (16 | 32));
+    c->last_bytes_len = 1;
+  } else {
+    switch (lg) {
+      case 15: c->last_bytes[0] = 0x71 | 0x80; break;
+      case 14: c->last_bytes[0] = 0x61 | 0x80; break;
+      case 13: c->last_bytes[0] = 0x51 | 0x80; break;
+      case 12: c->last_bytes[0] = 0x41 | 0x80; break;
+      case 11: c->last_bytes[0] = 0x31 | 0x80; break;
+      case 10: c->last_bytes[0] = 0x21 | 0x80; break;
+      case 17: c->last_bytes[0] = 0x1 | 0x80; break;
+      default: return CAT_INVALID_WINDOW_SIZE;
+    }
+    c->last_bytes[1] = 1;
+    c->last_bytes_len = 2;
+  }
+  c->window_size = lg;
+  return CAT_SUCCESS;
+}
+
+/* Test entry: concatenates `nfiles` brotli files the way src/bin/test_broccoli.rs:28-132 (`concat`) drives BroCatli -- reads
+ * of `bs` bytes per file, an output buffer of `bs` bytes flushed on NeedsMoreOutput.  window < 0: BroCatli::new().
+ * Returns CAT_SUCCESS (0) or the failure code (>= 124); *out_size = bytes written (<= out_cap). */
+int orc_concat(size_t nfiles, const uint8_t* const* files, const size_t* sizes, int window, size_t bs, uint8_t* out, size_t out_cap,
+               size_t* out_size) {
+  BroCatli cat;
+  uint8_t* obuf = (uint8_t*)malloc(bs ? bs : 1);
+  size_t ooffset = 0, written = 0;
+  int result = CAT_SUCCESS;
+  memset(&cat, 0, sizeof(cat));
+  if (window >= 0) {
+    /* (broccoli.rs:60-65: an invalid size falls back to the plain constructor) */
+    if (brocatli_init_with_window(&cat, (uint8_t)window) != CAT_SUCCESS) memset(&cat, 0, sizeof(cat));
+  }
+#define ORC_CONCAT_WRITE()                                        \
+  do {                                                            \
+    if (written + ooffset > out_cap) { result = -1; goto done; }  \
+    memcpy(out + written, obuf, ooffset);                         \
+    written += ooffset;                                           \
+    ooffset = 0;                                                  \
+  } while (0)
+  for (size_t f = 0; f < nfiles; ++f) {
+    memset(&cat.pending, 0, sizeof(cat.pending)); /* new_brotli_file() */
+    cat.has_pending = 1;
+    for (size_t pos = 0; pos < sizes[f];) {
+      const size_t cur_read = ORC_MIN(bs, sizes[f] - pos);
+      size_t ioffset = 0;
+      for (;;) {
+        const int r = brocatli_stream(&cat, files[f] + pos, cur_read, &ioffset, obuf, bs, &ooffset);
+        if (r == CAT_NEEDS_MORE_OUTPUT) {
+          ORC_CONCAT_WRITE();
+        } else if (r == CAT_NEEDS_MORE_INPUT) {
+          break;
+        } else {
+          result = r == CAT_SUCCESS ? -2 : r;
+          goto done;
+        }
+      }
+      pos += cur_read;
+    }
+  }
+  for (;;) {
+    const int r = brocatli_finish(&cat, obuf, bs, &ooffset);
+    if (r == CAT_NEEDS_MORE_OUTPUT) {
+      ORC_CONCAT_WRITE();
+    } else if (r == CAT_SUCCESS) {
+      ORC_CONCAT_WRITE();
+      break;
+    } else {
+      result = r;
+      goto done;
+    }
+  }
+done:
+  free(obuf);
+  *out_size = written;
+  return result;
+}

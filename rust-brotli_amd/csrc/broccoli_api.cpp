@@ -26,6 +26,7 @@ struct Broccoli {
   size_t pending_pos = 0;
   int error = 0;                 // sticky BroccoliResult (>= 124)
   bool finished = false;
+  bool file_open = false;        // BroccoliNewBrotliFile has been called at least once
 };
 
 Broccoli* Get(BroccoliState* s) {
@@ -73,6 +74,7 @@ void BroccoliDestroyInstance(BroccoliState state) { delete Get(&state); }
 void BroccoliNewBrotliFile(BroccoliState* state) {
   Broccoli* b = Get(state);
   if (!b) return;
+  b->file_open = true;
   b->stitcher.BeginFile();
 }
 
@@ -86,6 +88,13 @@ BroccoliResult BroccoliConcatStream(BroccoliState* state, size_t* available_in, 
     const BroccoliResult r = Drain(b, available_out, output_buf_ptr, BroccoliNeedsMoreInput);
     if (r != BroccoliNeedsMoreInput) return r;
     if (*available_in == 0) return BroccoliNeedsMoreInput;
+    if (!b->file_open) {
+      // Bytes without a BroccoliNewBrotliFile in front of them: the reference's state machine has no file to put them in
+      // (concat/mod.rs:450-468 runs into its unwrap).  They are taken for the start of a first file -- header, window and
+      // catable checks included -- never forwarded unjudged.
+      b->file_open = true;
+      b->stitcher.BeginFile();
+    }
     const size_t n = *available_in < kSlice ? *available_in : kSlice;
     ByteSink sink(&b->pending);
     if (!b->stitcher.Feed(*input_buf_ptr, n, &sink)) b->error = BroccoliBrotliFileNotCraftedForConcatenation;

@@ -14,12 +14,11 @@
 #include "device_api.h"
 #include "../../tables/brotli_tables.h"
 
-namespace {
-// Every host thread of the library works on its own stream, and a live chain (lz77_live.h) is one kernel that runs for
-// seconds: with the runtime's default of four hardware queues the streams of eight shard workers share queues, and the
-// short kernels of one shard wait behind the long kernel of another.  Takes effect if the runtime has not started yet.
-const int g_more_hw_queues = (setenv("GPU_MAX_HW_QUEUES", "16", 0), 0);
-}  // namespace
+// Hardware queues: every host thread of the library works on its own stream, and a live chain (lz77_live.h) is one kernel
+// that runs for seconds; with the runtime's default of four hardware queues the streams of eight shard workers share
+// queues and the short kernels of one shard wait behind the long kernel of another.  The library does NOT touch the
+// process environment: the host application asks for more queues itself (GPU_MAX_HW_QUEUES=16 before the HIP runtime
+// starts) -- the Python binding and bench.py do.
 
 namespace brotli_mi355x {
 

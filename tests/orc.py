@@ -287,3 +287,22 @@ def stream_with_flushes(data, params, cuts, write_size=0, dictionary=None):
         raise RuntimeError("oracle stream did not finish")
     _check_panic()
     return pieces
+
+
+def concat(files, window=None, bs=4096):
+    """The oracle's BroCatli (oracle/orc_multi.c: concat/mod.rs:274-608 restated) driven like the reference's own test helper
+    (src/bin/test_broccoli.rs:28-132): reads and writes of `bs` bytes.  Returns (result code, bytes): 0 = success, >= 124 = the
+    BroCatliResult failure the reference would report."""
+    L = lib()
+    n = len(files)
+    bufs = [ctypes.create_string_buffer(f, len(f) if len(f) else 1) for f in files]
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(b) for b in bufs])
+    sizes = (ctypes.c_size_t * max(n, 1))(*[len(f) for f in files])
+    cap = sum(len(f) for f in files) + 16 * n + 64
+    out = ctypes.create_string_buffer(cap)
+    got = ctypes.c_size_t(0)
+    L.orc_concat.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_char_p,
+                             ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    r = L.orc_concat(n, ptrs, sizes, -1 if window is None else window, bs, out, cap, ctypes.byref(got))
+    assert r >= 0, "oracle concat: output buffer too small / unexpected state (%d)" % r
+    return r, out.raw[:got.value]
