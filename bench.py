@@ -39,8 +39,8 @@ import sys
 import time
 
 
-# (the library asks for 16 hardware queues -- eight shard workers side by side -- but the HIP runtime reads the variable when
-# it starts, and here torch starts it first: without this the 8-shard H5 case ran 39 s instead of 14)
+# 16 hardware queues -- eight shard workers side by side -- instead of the runtime's four: the HIP runtime reads the variable when
+# it starts (torch starts it here), and the library never touches the environment itself
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -51,6 +51,17 @@ WORKLOAD_BYTES = 64 << 20
 QUALITY, LGWIN = 5, 22
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s peak
 TEXT_SEED = 0x5EED000000000002
+
+
+def source_fingerprint():
+    """sha256 over the library's sources (rust-brotli_amd/csrc/*, sorted): what a PMC summary under profiles/ was measured on.
+    (There is no .git on the GPU box, so the commit hash itself cannot be checked there.)"""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "rust-brotli_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        h.update(name.encode())
+        h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def frozen_hashes():
@@ -190,6 +201,12 @@ def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
         entry.update({"value": round(len(data) / sec / 1e6, 1), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 2), "compressed_bytes": len(out),
                       "identical_to_cpu_oracle": hashlib.sha256(out).hexdigest() == frozen[name]["stream_sha256"],
                       "input_generated_in_s": round(gen_s, 1)})
+        if frozen[name].get("oracle_seconds"):
+            # the CPU column: the oracle's time for the same call when the hash was frozen (tools/freeze_large_hashes.py: -O3 build,
+            # one core of the builder's container, 8 vCPU Xeon @ 2.1 GHz; multi-shard calls run their shards one after the other)
+            entry["cpu_oracle"] = {"value": round(len(data) / frozen[name]["oracle_seconds"] / 1e6, 1), "unit": "MB/s", "cores": 1,
+                                   "sample": "the whole workload, timed once when tests/golden/large_hashes.json was frozen (not on this host)"}
+            entry["vs_cpu_oracle"] = round((len(data) / sec) / (len(data) / frozen[name]["oracle_seconds"]), 2)
         res.append(entry)
         del data
     res.extend(quality_9_5_workloads(torch, bm, enc))
@@ -420,16 +437,24 @@ def main():
     achieved = bytes_done / parse_s / 1e9 if parse_s > 0 else 0.0
     one_pass = (2.0 * per_gpu + 64.0 * S + 16.0 * K) * args.steps  # the useful share: one sequential pass over the input
     whole_step = 9.0 * per_gpu + 64.0 * S + 48.0 * K + 2.0 * Lit + len(comp) / world  # SURVEY 8d, bytes per step and GPU
+    # PMC counters cannot be collected inside this run: the figure is quoted from the newest profiles/r*_pmc_parse.json -- but only
+    # if that summary was measured on THIS source tree (fingerprint of rust-brotli_amd/csrc/*); otherwise traffic is null
     traffic, traffic_src = None, None
-    for cand in ("r03_pmc_parse.json", "r02_pmc_parse.json"):
-        pmc = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                traffic, traffic_src = j.get("hbm_bytes_per_launch"), "profiles/%s (rocprofv3 PMC passes of commit %s, not measured in this run)" % (cand, j.get("commit", "?"))
-                break
-            except Exception:
-                pass
+    here = source_fingerprint()
+    import glob as _glob
+    for pmc in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_parse.json")), reverse=True):
+        try:
+            j = json.load(open(pmc))
+        except Exception:
+            continue
+        rel = os.path.relpath(pmc, ROOT)
+        if j.get("source_fingerprint") == here:
+            traffic = j.get("hbm_bytes_per_launch")
+            traffic_src = "%s (rocprofv3 PMC passes of commit %s, same library sources as this run: fingerprint %s; not measured inside this run)" % (rel, j.get("commit", "?"), here)
+        else:
+            traffic_src = "null: %s was measured on other library sources (fingerprint %s, commit %s; this run: %s) -- re-take with tools/profile_round.sh" % (
+                rel, j.get("source_fingerprint", "none recorded"), j.get("commit", "?"), here)
+        break
     line = {
         "metric": "compress MB/s at q5 lgwin22", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
