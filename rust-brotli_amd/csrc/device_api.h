@@ -100,6 +100,12 @@ struct Lz77Buffers {
   unsigned long long* smask;  // stored bits of the slots, one word per 64 slots      [total_bytes / 64 + 2]
   uint32_t* gprev;      // per 64 slots: 1 + last stored slot in front of them           [total_bytes / 64 + 2]
   uint8_t* big_tile;    // per 1024 slots: holds slots of a key with >= 65 536 slots  [total_bytes / 1024 + 64]
+  // "potential" mask, one bit per slot: some slot of the same key in front of it, within max_backward, carries the same tag.
+  // A slot without the bit has an EMPTY candidate row whatever the stored flags are (a row only ever holds tag-equal
+  // predecessors), so the validation passes skip it.  Parse-independent; computed on the device the first time a full
+  // validation pass is due (pot_state[0] != 0: the mask is there) -- inputs that never need one (text) never pay for it.
+  unsigned long long* pot = nullptr;  // [total_bytes / 64 + 2]
+  uint32_t* pot_state = nullptr;      // [16], zero at the start of a call
   uint32_t changed_cap; // entries in changed_keys / changed_slot
   // rank-structure chains (qualities 6-9): log of every search (ChainTables::search_log, kSearchLogWords words per
   // position) and the list of searched positions whose candidate list changed in this round (lz77_recheck_searches)

@@ -567,7 +567,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     if (hq) {
       // ---- BrotliBuildMetaBlock (metablock.rs:133-307) on the device, metablock_hq.h
       for (uint32_t m = 0; m < n_mb; ++m) {
-        descs[m].hq = 1;
+        descs[m].hq = 1u | (p.large_window ? 2u : 0u);
         descs[m].hq_no_context = p.disable_literal_context_modeling ? 1 : 0;
         descs[m].n_symbols[0] = descs[m].n_lits;
         descs[m].n_symbols[1] = descs[m].n_cmds;
@@ -590,7 +590,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         if (census) d.context_mode = results[m].hq_mostly_utf8 ? 2 : 3;  // ChooseContextMode, encode.rs:1357-1377
         d.dist_postfix_bits = results[m].hq_postfix;
         d.num_direct_distance_codes = results[m].hq_ndirect;
-        d.num_distance_symbols = 16 + d.num_direct_distance_codes + (24u << (d.dist_postfix_bits + 1));
+        d.num_distance_symbols = 16 + d.num_direct_distance_codes + ((p.large_window ? 62u : 24u) << (d.dist_postfix_bits + 1));
       }
       B.hq_sym[0] = mm.alloc<uint16_t>((size_t)L + 8);
       B.hq_sym[1] = mm.alloc<uint16_t>((size_t)K + 8);

@@ -174,8 +174,6 @@ bool IsAccelerated(const EncoderParams& p, const char** why_not) {
     why = "ring depth above 512 does not occur in the reference";
   } else if (p.hasher.block_bits > 8 && !DeepRingsAllowed()) {
     why = "the 512-deep rings of quality 11 + Q9_5 are switched off (BROTLI_MI355X_NO_DEEP_RINGS)";
-  } else if (p.large_window) {
-    why = "large_window not implemented on the device";
   }
   if (why_not) *why_not = why;
   return why == nullptr;

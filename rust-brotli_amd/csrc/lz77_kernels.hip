@@ -652,6 +652,8 @@ struct RowArgs {
   const uint32_t* ctl;   // conditional launches: run only if ctl[kCtlNeedFull] != 0
   uint32_t* walk_counter;  // == ctl, writable (k_update_rows)
   uint32_t conditional;
+  const unsigned long long* pot;  // Lz77Buffers::pot / pot_state (null: no mask)
+  const uint32_t* pot_state;
 };
 // device-side control words of lz77_rows_update
 enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtlWrapKeyFlip = 3, kCtlWords = 4 };
@@ -734,9 +736,17 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
   __syncthreads();
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   SlotsInMemory sl{a.by_key, a.fbits, a.stag, a.smask, a.gprev};
+  // validation passes look only at the slots that can have a candidate at all (Lz77Buffers::pot): the others hold an empty
+  // row and keep it whatever the flags do
+  const bool use_pot = a.validate && a.pot != nullptr && a.pot_state[0] != 0;
   for (uint32_t r = 0; r < kRowTile / 256; ++r) {
     const uint32_t e = (base - lo) + w * 256 + r * 64 + lane;
-    const bool valid = lo + e < hi;
+    bool valid = lo + e < hi;
+    if (use_pot) {
+      const unsigned long long pw = a.pot[(base + w * 256 + r * 64) >> 6];  // (wave-uniform: the tile starts at a multiple of 64)
+      if (pw == 0) continue;
+      valid = valid && ((pw >> lane) & 1ull) != 0;
+    }
     bool slow = false;
     if (valid) {
       const uint32_t p = s_pos[e], tk = s_tk[e];
@@ -980,9 +990,11 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
     const uint32_t key = keys[a.by_key[s]];
     const uint32_t kf = a.key_first[key], kl = a.key_last[key];
     uint32_t stable = 0;
+    const bool use_pot = a.pot != nullptr && a.pot_state[0] != 0;
+    const uint32_t max_walk = use_pot ? 32u * kMaxRowWalk : kMaxRowWalk;  // (a walked slot without a row to rebuild costs one ballot)
     // (slot s itself is rebuilt as well: its own row changes when its wrap mark does)
     for (uint32_t base = s; base < kl && stable < a.depth; base += 64) {
-      if (base - s >= kMaxRowWalk) {
+      if (base - s >= max_walk) {
         // a stretch of unstored slots (e.g. an extended copy through zero fill): every row of it changes, and every
         // change in front of it would walk it again -- leave it to the full rebuild
         if (threadIdx.x == 0) atomicMax(&a.walk_counter[kCtlNeedFull], 1u);
@@ -993,11 +1005,14 @@ __global__ __launch_bounds__(64) void k_update_rows(RowArgs a, const uint32_t* _
       const bool st = in && i != s && (a.fbits[i] & (kSlotStored | kSlotChanged)) == kSlotStored;
       const unsigned long long m = __ballot(st);
       const uint32_t before = (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
-      if (in && stable + before < a.depth) {
+      bool build = in && stable + before < a.depth;
+      if (use_pot && build) build = ((a.pot[i >> 6] >> (i & 63u)) & 1ull) != 0;  // (no candidate possible: the row is empty and stays so)
+      if (build) {
         if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true, a.reset_pos, a.reset_vis)) row_changed(a, a.by_key[i]);
       }
       stable += (uint32_t)__popcll(m);
-      if (threadIdx.x == 0) atomicAdd(&a.walk_counter[kCtlWalked], 64u);
+      const uint32_t cost = use_pot ? (__ballot(build) != 0 ? 64u : 4u) : 64u;
+      if (threadIdx.x == 0) atomicAdd(&a.walk_counter[kCtlWalked], cost);
     }
   }
 }
@@ -1034,7 +1049,77 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.walk_counter = B.row_ctl;
   a.smask = B.smask;
   a.gprev = B.gprev;
+  a.pot = B.pot;
+  a.pot_state = B.pot_state;
   return a;
+}
+
+// ---- the potential mask (Lz77Buffers::pot): one bit per slot, set when some slot of the same key in front of it, at most
+// max_backward_limit bytes back, carries the same tag -- the only slots whose candidate row can ever hold an entry
+// (br_collect_row keeps tag-equal predecessors only).  Conservative where the scan is cut short.  Runs once per call, and
+// only when a full validation pass is due (ctl[kCtlNeedFull]) and the mask is not there yet.
+// One workgroup per tile of kPotTile slots with kPotHalo slots in front of it, staged in LDS.  A slot gets the bit when an
+// EARLIER slot of the staged span carries the same (key, tag) -- found through a hash table of first occurrences in LDS, a
+// backward scan only where two values collide in it -- whatever the distance between the two (a superset: the span is a few
+// windows of a sparse key long), or when its key's slots reach back beyond the staged span inside the window (dense keys,
+// i.e. text: nearly every slot, but such input never asks for the mask).
+static constexpr uint32_t kPotTile = 1024, kPotHalo = 512, kPotSpan = kPotTile + kPotHalo, kPotTable = 16384;
+__global__ __launch_bounds__(256) void k_row_potential(const uint32_t* __restrict__ by_key, const uint16_t* __restrict__ sorted_keys,
+                                                        const uint16_t* __restrict__ stag, const uint32_t* __restrict__ key_first, uint32_t n,
+                                                        uint32_t max_backward_limit, const uint32_t* __restrict__ ctl,
+                                                        const uint32_t* __restrict__ pot_state, unsigned long long* __restrict__ pot) {
+  if (ctl[kCtlNeedFull] == 0 || pot_state[0] != 0) return;
+  (void)key_first;
+  __shared__ uint32_t s_val[kPotSpan];  // tag | key << 16
+  __shared__ uint32_t s_pos[kPotSpan];
+  __shared__ uint32_t tab[kPotTable];   // first span entry whose value hashes here
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * kPotTile; base < n; base += gridDim.x * kPotTile) {
+    const uint32_t lo = base >= kPotHalo ? base - kPotHalo : 0u;
+    const uint32_t hi = min(base + kPotTile, n);
+    const uint32_t span = hi - lo;
+    __syncthreads();  // (the previous tile is done with the arrays)
+    for (uint32_t h = threadIdx.x; h < kPotTable; h += 256) tab[h] = 0xffffffffu;
+    for (uint32_t e = threadIdx.x; e < span; e += 256) {
+      s_val[e] = (uint32_t)stag[lo + e] | ((uint32_t)sorted_keys[lo + e] << 16);
+      s_pos[e] = by_key[lo + e];
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < span; e += 256) atomicMin(&tab[(s_val[e] * 0x9E3779B1u) >> 18], e);
+    __syncthreads();
+    for (uint32_t r = 0; r < kPotTile / 256; ++r) {
+      const uint32_t e = (base - lo) + r * 256 + threadIdx.x;
+      bool bit = false;
+      if (lo + e < hi) {
+        const uint32_t val = s_val[e], p = s_pos[e];
+        const uint32_t f = tab[(val * 0x9E3779B1u) >> 18];
+        bool known = false;
+        if (s_val[f] == val) {  // f is the first occurrence of this value in the span
+          bit = f < e;
+          known = true;
+        }
+        if (!known) {  // another value owns the table entry: look for an earlier equal the slow way
+          for (uint32_t j = e; j > 0;) {
+            --j;
+            const uint32_t v = s_val[j];
+            if ((v >> 16) != (val >> 16) || p - s_pos[j] > max_backward_limit) break;
+            if (v == val) {
+              bit = true;
+              break;
+            }
+          }
+        }
+        // the key's slots go on in front of the span, still inside the window: anything may be there
+        if (!bit && lo > 0 && (s_val[0] >> 16) == (val >> 16) && p - s_pos[0] <= max_backward_limit) bit = true;
+      }
+      const unsigned long long m = __ballot(bit);
+      const uint32_t i = lo + e;
+      if (lane == 0 && (i >> 6) <= ((n - 1) >> 6)) pot[i >> 6] = m;
+    }
+  }
+}
+__global__ void k_row_potential_ready(const uint32_t* __restrict__ ctl, uint32_t* __restrict__ pot_state) {
+  if (ctl[kCtlNeedFull] != 0 && threadIdx.x == 0 && blockIdx.x == 0) pot_state[0] = 1;
 }
 
 // ---- stored-bit masks and skip pointers (SlotsInMemory::prev_stored) from the per-slot bytes ----
@@ -1187,6 +1272,13 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   RowArgs a = row_args(P, B, next, true, &geo, dirty_dev);
   hipLaunchKernelGGL(k_update_rows, dim3(cap < 65536u ? cap : 65536u), dim3(64), 0, BR_STREAM, a, B.changed_slot, B.changed_count, B.keys);
   a.conditional = 1;
+  if (B.pot) {
+    uint32_t pot_blocks = (n + kPotTile - 1) / kPotTile;
+    if (pot_blocks > 8192u) pot_blocks = 8192u;
+    hipLaunchKernelGGL(k_row_potential, dim3(pot_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.stag, B.key_first, n,
+                       P.max_backward_limit, B.row_ctl, B.pot_state, B.pot);
+    hipLaunchKernelGGL(k_row_potential_ready, dim3(1), dim3(64), 0, BR_STREAM, B.row_ctl, B.pot_state);
+  }
   hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
   hipLaunchKernelGGL(k_clear_flip_marks, dim3(flip_blocks < 1024u ? flip_blocks : 1024u), dim3(256), 0, BR_STREAM, B.changed_slot, B.changed_count,
                      cap, B.fbits);

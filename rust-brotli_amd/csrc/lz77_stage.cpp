@@ -68,6 +68,8 @@ void Lz77Stage::Release() {
     dev_free(B_.reset_counts);
     dev_free(B_.smask);
     dev_free(B_.gprev);
+    dev_free(B_.pot);
+    dev_free(B_.pot_state);
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
     dev_free(B_.cmds);
@@ -188,6 +190,10 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.big_tile = (uint8_t*)dev_alloc(M / 1024 + 128);
     B_.smask = (unsigned long long*)dev_alloc_uninit((M / 64 + 2) * 8 + 64);
     B_.gprev = (uint32_t*)dev_alloc_uninit((M / 64 + 2) * 4 + 64);
+    if (getenv("BROTLI_MI355X_NO_POTENTIAL_MASK") == nullptr) {
+      B_.pot = (unsigned long long*)dev_alloc_uninit((M / 64 + 2) * 8 + 64);
+      B_.pot_state = (uint32_t*)dev_alloc(64);
+    }
     B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
     B_.rows = (uint32_t*)dev_alloc_uninit(M * kRowEntries * 4 + 64);
     if (P_.use_dictionary) B_.dict_items = (uint32_t*)dev_alloc_uninit(M * 4 + 256);

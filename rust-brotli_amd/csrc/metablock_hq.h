@@ -960,16 +960,28 @@ BR_DEV void hq_prefix_encode_distance(uint32_t distance_code, uint32_t ndirect, 
   *code = (uint16_t)((nbits << 10) | (16 + ndirect + ((2 * (nbits - 1) + prefix) << npostfix) + postfix));
   *extra_bits = (uint32_t)((dist - offset) >> npostfix);
 }
-// BrotliInitDistanceParams without large_window, encode.rs:519-553
-BR_DEV uint32_t hq_distance_alphabet_size(uint32_t npostfix, uint32_t ndirect) { return 16 + ndirect + (24u << (npostfix + 1)); }
-BR_DEV uint32_t hq_max_distance(uint32_t npostfix, uint32_t ndirect) { return ndirect + (1u << (24 + npostfix + 2)) - (1u << (npostfix + 2)); }
+// BrotliInitDistanceParams, metablock.rs:28-60 (large_window: MbDesc::hq bit 1)
+BR_DEV uint32_t hq_distance_alphabet_size(uint32_t npostfix, uint32_t ndirect, bool large_window = false) {
+  return 16 + ndirect + ((large_window ? 62u : 24u) << (npostfix + 1));
+}
+BR_DEV uint32_t hq_max_distance(uint32_t npostfix, uint32_t ndirect, bool large_window = false) {
+  if (large_window) {
+    // (no distance symbol in use may encode more than BROTLI_MAX_ALLOWED_DISTANCE with all its extra bits set)
+    const uint32_t bound = npostfix == 0 ? 0u : (npostfix == 1 ? 4u : (npostfix == 2 ? 12u : 28u));
+    const uint32_t postfix = 1u << npostfix;
+    if (ndirect < bound) return 0x07fffffcu - (bound - ndirect);
+    if (ndirect >= bound + postfix) return (3u << 29) - 4u + (ndirect - bound);
+    return 0x07fffffcu;
+  }
+  return ndirect + (1u << (24 + npostfix + 2)) - (1u << (npostfix + 2));
+}
 
 
 // ComputeDistanceCost, metablock.rs:88-131: the histogram of the re-coded distance symbols in workgroup memory (atomic
 // adds), their extra bits as an integer sum (the reference adds them up in f64: small integers, exact in any order).
 BR_DEV bool hq_distance_cost(const MbBuffers& B, const MbDesc& d, HqWaveScratch& S, uint32_t new_npostfix, uint32_t new_ndirect, double* cost) {
   const bool equal_params = d.dist_postfix_bits == new_npostfix && d.num_direct_distance_codes == new_ndirect;
-  const uint32_t new_max_distance = hq_max_distance(new_npostfix, new_ndirect);
+  const uint32_t new_max_distance = hq_max_distance(new_npostfix, new_ndirect, (d.hq & 2u) != 0);
   for (uint32_t i = BR_TID; i < kNumDistanceHistoSymbols; i += BR_NT) S.tmp[i] = 0;
   if (BR_TID == 0) S.ctl[0] = S.ctl[1] = S.ctl[2] = 0;  // too far, symbols, extra bits
   BR_SYNC();
