@@ -105,7 +105,9 @@ struct Lz77Buffers {
   // predecessors), so the validation passes skip it.  Parse-independent; computed on the device the first time a full
   // validation pass is due (pot_state[0] != 0: the mask is there) -- inputs that never need one (text) never pay for it.
   unsigned long long* pot = nullptr;  // [total_bytes / 64 + 2]
-  uint32_t* pot_state = nullptr;      // [16], zero at the start of a call
+  uint32_t* pot_state = nullptr;      // [16], zero at the start of a call: [0] mask there, [1] listed slots, [2] list overflowed
+  uint32_t* pot_list = nullptr;       // the slots with the bit, any order  [pot_list_cap]
+  uint32_t pot_list_cap = 0;
   uint32_t changed_cap; // entries in changed_keys / changed_slot
   // rank-structure chains (qualities 6-9): log of every search (ChainTables::search_log, kSearchLogWords words per
   // position) and the list of searched positions whose candidate list changed in this round (lz77_recheck_searches)

@@ -683,6 +683,7 @@ static_assert(kRowSpan == 256 * 5, "five span entries per thread");
 
 __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
   if (a.conditional && a.ctl[kCtlNeedFull] == 0) return;
+  if (a.conditional && a.validate && a.pot != nullptr && a.pot_state[0] != 0 && a.pot_state[2] == 0) return;  // (k_validate_listed_rows has been over the rows that can change)
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   __shared__ uint32_t s_pos[kRowSpan];
   __shared__ uint32_t s_tk[kRowSpan];  // tag | key << 16
@@ -1059,63 +1060,142 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
 // (br_collect_row keeps tag-equal predecessors only).  Conservative where the scan is cut short.  Runs once per call, and
 // only when a full validation pass is due (ctl[kCtlNeedFull]) and the mask is not there yet.
 // One workgroup per tile of kPotTile slots with kPotHalo slots in front of it, staged in LDS.  A slot gets the bit when an
-// EARLIER slot of the staged span carries the same (key, tag) -- found through a hash table of first occurrences in LDS, a
-// backward scan only where two values collide in it -- whatever the distance between the two (a superset: the span is a few
-// windows of a sparse key long), or when its key's slots reach back beyond the staged span inside the window (dense keys,
-// i.e. text: nearly every slot, but such input never asks for the mask).
-static constexpr uint32_t kPotTile = 1024, kPotHalo = 512, kPotSpan = kPotTile + kPotHalo, kPotTable = 16384;
+// earlier slot of the staged span carries the same (key, tag) at most max_backward_limit bytes back -- the first occurrence of
+// every value in the span comes out of two hash tables in LDS (entries carry the number of the tile they were written for,
+// so the tables are cleared once per workgroup, not once per tile); where a value collides in both, or its first occurrence
+// lies outside the window, the wave scans the slots in front of it 64 at a time -- or when its key's slots reach back beyond
+// the staged span inside the window (dense keys, i.e. text: nearly every slot, but such input never asks for the mask).
+// The slots with the bit are also LISTED (pot_list; pot_state[1] = their number, pot_state[2] = the list overflowed): the
+// validation pass of sparse input is a pass over that list (k_validate_listed_rows), not over all slots.
+static constexpr uint32_t kPotTile = 1024, kPotHalo = 512, kPotSpan = kPotTile + kPotHalo, kPotTable = 8192;
 __global__ __launch_bounds__(256) void k_row_potential(const uint32_t* __restrict__ by_key, const uint16_t* __restrict__ sorted_keys,
-                                                        const uint16_t* __restrict__ stag, const uint32_t* __restrict__ key_first, uint32_t n,
-                                                        uint32_t max_backward_limit, const uint32_t* __restrict__ ctl,
-                                                        const uint32_t* __restrict__ pot_state, unsigned long long* __restrict__ pot) {
+                                                        const uint16_t* __restrict__ stag, uint32_t n, uint32_t max_backward_limit,
+                                                        const uint32_t* __restrict__ ctl, uint32_t* __restrict__ pot_state,
+                                                        unsigned long long* __restrict__ pot, uint32_t* __restrict__ pot_list, uint32_t list_cap) {
   if (ctl[kCtlNeedFull] == 0 || pot_state[0] != 0) return;
-  (void)key_first;
   __shared__ uint32_t s_val[kPotSpan];  // tag | key << 16
   __shared__ uint32_t s_pos[kPotSpan];
-  __shared__ uint32_t tab[kPotTable];   // first span entry whose value hashes here
+  // two tables under two hash functions; an entry = generation << 16 | (0xffff - first span entry whose value hashes here), atomicMax
+  __shared__ uint32_t tab[kPotTable], tab2[kPotTable];
+  __shared__ uint32_t s_count, s_base;
   const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t h = threadIdx.x; h < kPotTable; h += 256) tab[h] = tab2[h] = 0;
+  uint32_t gen = 0;
   for (uint32_t base = blockIdx.x * kPotTile; base < n; base += gridDim.x * kPotTile) {
+    ++gen;  // (at most n / kPotTile / gridDim.x + 1 tiles per workgroup: far below 65 536)
     const uint32_t lo = base >= kPotHalo ? base - kPotHalo : 0u;
     const uint32_t hi = min(base + kPotTile, n);
     const uint32_t span = hi - lo;
     __syncthreads();  // (the previous tile is done with the arrays)
-    for (uint32_t h = threadIdx.x; h < kPotTable; h += 256) tab[h] = 0xffffffffu;
     for (uint32_t e = threadIdx.x; e < span; e += 256) {
       s_val[e] = (uint32_t)stag[lo + e] | ((uint32_t)sorted_keys[lo + e] << 16);
       s_pos[e] = by_key[lo + e];
     }
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < span; e += 256) atomicMin(&tab[(s_val[e] * 0x9E3779B1u) >> 18], e);
+    for (uint32_t e = threadIdx.x; e < span; e += 256) {
+      // (an entry that repeats the value in front of it is not a first occurrence: runs of one value -- zero fill -- would
+      // all hit one table word)
+      if (e != 0 && s_val[e - 1] == s_val[e]) continue;
+      atomicMax(&tab[(s_val[e] * 0x9E3779B1u) >> 19], (gen << 16) | (0xffffu - e));
+      atomicMax(&tab2[(s_val[e] * 0x85EBCA6Bu) >> 19], (gen << 16) | (0xffffu - e));
+    }
+    if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
+    unsigned long long masks[kPotTile / 256];
     for (uint32_t r = 0; r < kPotTile / 256; ++r) {
       const uint32_t e = (base - lo) + r * 256 + threadIdx.x;
-      bool bit = false;
-      if (lo + e < hi) {
-        const uint32_t val = s_val[e], p = s_pos[e];
-        const uint32_t f = tab[(val * 0x9E3779B1u) >> 18];
-        bool known = false;
+      const bool in = lo + e < hi;
+      bool bit = false, scan = false;
+      uint32_t val = 0, p = 0;
+      if (in) {
+        val = s_val[e];
+        p = s_pos[e];
+        uint32_t f = 0xffffu - (tab[(val * 0x9E3779B1u) >> 19] & 0xffffu);  // (this tile's: e or the head of its run was entered)
+        if (f >= span || s_val[f] != val) f = 0xffffu - (tab2[(val * 0x85EBCA6Bu) >> 19] & 0xffffu);
+        if (f >= span) f = e;  // (cannot happen: both words hold an entry of this tile)
+        scan = true;
         if (s_val[f] == val) {  // f is the first occurrence of this value in the span
-          bit = f < e;
-          known = true;
+          if (f == e) scan = false;                                  // nothing in front of it
+          else if (p - s_pos[f] <= max_backward_limit) bit = true;   // (f < e) and within reach
         }
-        if (!known) {  // another value owns the table entry: look for an earlier equal the slow way
-          for (uint32_t j = e; j > 0;) {
-            --j;
-            const uint32_t v = s_val[j];
-            if ((v >> 16) != (val >> 16) || p - s_pos[j] > max_backward_limit) break;
-            if (v == val) {
-              bit = true;
-              break;
-            }
-          }
-        }
-        // the key's slots go on in front of the span, still inside the window: anything may be there
-        if (!bit && lo > 0 && (s_val[0] >> 16) == (val >> 16) && p - s_pos[0] <= max_backward_limit) bit = true;
+        scan = scan && !bit;
       }
+      // the slow way, one slot at a time with the whole wave: the slots in front of it, 64 per step, nearest first
+      unsigned long long todo = __ballot(scan);
+      if (__popcll(todo) > 4) {  // dense values (text): not worth looking closer, such slots simply count as possible
+        if (scan) bit = true;
+        todo = 0;
+      }
+      while (todo != 0) {
+        const uint32_t l = (uint32_t)__ffsll((long long)todo) - 1u;
+        todo &= todo - 1ull;
+        const uint32_t ee = (uint32_t)__shfl((int)e, (int)l, 64), vv = (uint32_t)__shfl((int)val, (int)l, 64), pp = (uint32_t)__shfl((int)p, (int)l, 64);
+        bool found = false;
+        for (uint32_t top = ee; top > 0;) {
+          const bool have = top > lane;
+          const uint32_t j = have ? top - 1u - lane : 0u;
+          const uint32_t v = s_val[j];
+          const bool reach = have && (v >> 16) == (vv >> 16) && pp - s_pos[j] <= max_backward_limit;
+          const unsigned long long reach_m = __ballot(reach), hit_m = __ballot(reach && v == vv);
+          // (slots of a key are in position order: the ones within reach are the nearest, a prefix of the lanes)
+          if (hit_m != 0) {
+            found = true;
+            break;
+          }
+          if (reach_m != ~0ull) break;  // the walk ends inside this step
+          top = top > 64u ? top - 64u : 0u;
+        }
+        if (lane == l) bit = found;
+      }
+      // the key's slots go on in front of the span, still inside the window: anything may be there
+      if (in && !bit && lo > 0 && (s_val[0] >> 16) == (val >> 16) && p - s_pos[0] <= max_backward_limit) bit = true;
       const unsigned long long m = __ballot(bit);
       const uint32_t i = lo + e;
       if (lane == 0 && (i >> 6) <= ((n - 1) >> 6)) pot[i >> 6] = m;
+      masks[r] = m;
     }
+    // the list: one reservation per tile (and none once the list has overflowed: dense input)
+    uint32_t mine = 0, wave_at = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kPotTile / 256; ++r) mine += (uint32_t)__popcll(masks[r]);
+    if (lane == 0 && mine != 0) wave_at = atomicAdd(&s_count, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t total = s_count;
+      uint32_t at = 0xffffffffu;
+      if (total != 0) {
+        if (*(volatile uint32_t*)&pot_state[2] == 0) {
+          at = atomicAdd(&pot_state[1], total);
+          if (at + total > list_cap) {
+            pot_state[2] = 1;
+            at = 0xffffffffu;
+          }
+        }
+      }
+      s_base = at;
+    }
+    __syncthreads();
+    if (s_base != 0xffffffffu) {
+      uint32_t at = s_base + (uint32_t)__shfl((int)wave_at, 0, 64);
+#pragma unroll
+      for (uint32_t r = 0; r < kPotTile / 256; ++r) {
+        const unsigned long long m = masks[r];
+        if ((m >> lane) & 1ull) pot_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + r * 256 + threadIdx.x;
+        at += (uint32_t)__popcll(m);
+      }
+    }
+  }
+}
+// The validation pass over the listed slots: every row that can hold a candidate is built afresh from the slots in memory and
+// compared with the row in memory (br_build_row); the chains that searched a changed row are marked.
+__global__ __launch_bounds__(256) void k_validate_listed_rows(RowArgs a, const uint32_t* __restrict__ pot_list) {
+  if (a.ctl[kCtlNeedFull] == 0 || a.pot_state[0] == 0 || a.pot_state[2] != 0) return;
+  const uint32_t count = a.pot_state[1];
+  SlotsInMemory sl{a.by_key, a.fbits, a.stag, a.smask, a.gprev};
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
+    const uint32_t i = pot_list[t];
+    const uint32_t kf = a.key_first[a.sorted_keys[i]];
+    if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true, a.reset_pos, a.reset_vis)) row_changed(a, a.by_key[i]);
   }
 }
 __global__ void k_row_potential_ready(const uint32_t* __restrict__ ctl, uint32_t* __restrict__ pot_state) {
@@ -1275,9 +1355,10 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   if (B.pot) {
     uint32_t pot_blocks = (n + kPotTile - 1) / kPotTile;
     if (pot_blocks > 8192u) pot_blocks = 8192u;
-    hipLaunchKernelGGL(k_row_potential, dim3(pot_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.stag, B.key_first, n,
-                       P.max_backward_limit, B.row_ctl, B.pot_state, B.pot);
+    hipLaunchKernelGGL(k_row_potential, dim3(pot_blocks), dim3(256), 0, BR_STREAM, B.by_key, B.sorted_keys, B.stag, n, P.max_backward_limit,
+                       B.row_ctl, B.pot_state, B.pot, B.pot_list, B.pot_list_cap);
     hipLaunchKernelGGL(k_row_potential_ready, dim3(1), dim3(64), 0, BR_STREAM, B.row_ctl, B.pot_state);
+    hipLaunchKernelGGL(k_validate_listed_rows, dim3(2048), dim3(256), 0, BR_STREAM, a, B.pot_list);
   }
   hipLaunchKernelGGL(k_build_rows, dim3((n + kRowTile - 1) / kRowTile), dim3(256), 0, BR_STREAM, a);
   hipLaunchKernelGGL(k_clear_flip_marks, dim3(flip_blocks < 1024u ? flip_blocks : 1024u), dim3(256), 0, BR_STREAM, B.changed_slot, B.changed_count,

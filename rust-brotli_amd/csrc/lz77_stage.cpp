@@ -70,6 +70,7 @@ void Lz77Stage::Release() {
     dev_free(B_.gprev);
     dev_free(B_.pot);
     dev_free(B_.pot_state);
+    dev_free(B_.pot_list);
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
     dev_free(B_.cmds);
@@ -193,6 +194,8 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     if (getenv("BROTLI_MI355X_NO_POTENTIAL_MASK") == nullptr) {
       B_.pot = (unsigned long long*)dev_alloc_uninit((M / 64 + 2) * 8 + 64);
       B_.pot_state = (uint32_t*)dev_alloc(64);
+      B_.pot_list_cap = (uint32_t)(M / 16 + 1024);  // (denser than that: the pass over all rows is the cheaper one)
+      B_.pot_list = (uint32_t*)dev_alloc_uninit((size_t)B_.pot_list_cap * 4 + 64);
     }
     B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
     B_.rows = (uint32_t*)dev_alloc_uninit(M * kRowEntries * 4 + 64);
