@@ -57,6 +57,8 @@ struct DeviceTables {
   const float* logs_8;
   const uint8_t* utf8_context_lookup;   // 512
   const uint8_t* signed_context_lookup; // 256
+  const uint16_t* dict_lut_buckets;     // kStaticDictionaryBuckets [32768] (BrotliFindAllStaticDictionaryMatches, qualities 10 / 11)
+  const uint32_t* dict_lut_words;       // kStaticDictionaryWords [31705]
 };
 const DeviceTables& dev_tables();
 
@@ -253,6 +255,32 @@ void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, 
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]
 void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t num_segments, const uint32_t* offsets_dev,
                           const uint32_t* counts_dev, Command* out);
+
+// ---- qualities 10 / 11 (zopfli_device.h): the H10 binary-tree hasher and the Zopfli shortest-path parse, block by block ----
+struct ZopfliJob {
+  uint32_t quality = 10, lgwin = 22;
+  uint32_t use_dictionary = 1;
+  uint32_t dist_alphabet_size = 0;
+  uint32_t block_bytes = 0;      // 1 << lgblock: bound of everything that is sized per block
+  // device memory (Lz77Stage owns it)
+  uint32_t* buckets = nullptr;   // [1 << 17]
+  uint32_t* forest = nullptr;    // [2 << lgwin]
+  void* nodes = nullptr;         // ZNode[block_bytes + 1]
+  float* literal_costs = nullptr;  // [block_bytes + 2]
+  float* cost_dist = nullptr;    // [dist_alphabet_size + 64]
+  float* cost_cmd = nullptr;     // [704]
+  unsigned long long* matches = nullptr;  // quality 10: [128]; quality 11: [128 * block_bytes]
+  uint32_t* num_matches = nullptr;        // quality 11: [block_bytes]
+  Command* tmp_cmds = nullptr;   // quality 11: [block_bytes / 2 + 8]
+  uint32_t* histo = nullptr;     // [2048]
+};
+// empties the hasher: buckets = invalid position, forest = 0 (InitializeH10, hash_to_binary_tree.rs:149-190)
+void lz77_zopfli_init(const ZopfliJob& J);
+// HasherPrependCustomDictionary (encode.rs:1163-1194): the positions [0, dict_bytes - 127) of the text go into the trees
+void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes);
+// input block `block` (= segment `block`: one segment per block) with the entry B.entries[block]: commands into its slab, exit into
+// B.exits[block].  The blocks of a stream go through here in order.
+void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block);
 
 // ---- live chains (lz77_live.h): chains that parse a span of input blocks on a private copy of the reference's bucket rings ----
 struct LiveBuffers {

@@ -13,6 +13,7 @@
 
 #include "device_api.h"
 #include "../../tables/brotli_tables.h"
+#include "../../tables/brotli_static_dict_lut.h"
 
 // Hardware queues: every host thread of the library works on its own stream, and a live chain (lz77_live.h) is one kernel
 // that runs for seconds; with the runtime's default of four hardware queues the streams of eight shard workers share
@@ -494,6 +495,8 @@ const DeviceTables& dev_tables() {
   h.t.logs_8 = (const float*)upload(kBrotliLog2Table8_bits, sizeof(kBrotliLog2Table8_bits));
   h.t.utf8_context_lookup = (const uint8_t*)upload(kBrotliUTF8ContextLookup, sizeof(kBrotliUTF8ContextLookup));
   h.t.signed_context_lookup = (const uint8_t*)upload(kBrotliSigned3BitContextLookup, sizeof(kBrotliSigned3BitContextLookup));
+  h.t.dict_lut_buckets = (const uint16_t*)upload(kStaticDictionaryBuckets, sizeof(kStaticDictionaryBuckets));
+  h.t.dict_lut_words = (const uint32_t*)upload(kStaticDictionaryWords, sizeof(kStaticDictionaryWords));
   h.device = dev;
   return h.t;
 }

@@ -165,10 +165,9 @@ static bool DeepRingsAllowed() {
 
 bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
-  if (p.quality < 5 || p.quality > 11 || (p.quality > 9 && !p.q9_5)) {
-    why = "only qualities 5..9 and \"9.5\" (BROTLI_PARAM_Q9_5 with quality 10 or 11: the greedy search behind the quality >= 10 "
-          "meta-block builder) are implemented on the device in this build";
-  } else if (p.hasher.type != 5 && !IsH6Family(p.hasher.type) && p.hasher.type != 9) {
+  if (p.quality < 5 || p.quality > 11) {
+    why = "only qualities 5..11 are implemented on the device in this build (0..4: the fragment compressors and the BasicHasher family)";
+  } else if (p.hasher.type != 5 && !IsH6Family(p.hasher.type) && p.hasher.type != 9 && p.hasher.type != 10) {
     why = "hasher type not implemented on the device";
   } else if (p.hasher.block_bits > 9) {
     why = "ring depth above 512 does not occur in the reference";

@@ -19,6 +19,7 @@
 #include "lz77_rows.h"
 #include "device_scan.h"
 #include "lz77_parse_args.h"
+#include "zopfli_device.h"
 
 namespace brotli_mi355x {
 
@@ -2267,6 +2268,86 @@ void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffe
   } else {
     hipLaunchKernelGGL((k_live_verify<false>), dim3(grid), dim3(64), 0, BR_STREAM, a);
   }
+  HIP_CHECK(hipGetLastError());
+}
+
+
+// ------------------------------------------------------------------------------------------ qualities 10 / 11 (zopfli_device.h)
+static ZopfliParams zopfli_params_of(const Lz77Params& P, const ZopfliJob& J) {
+  ZopfliParams Z;
+  Z.quality = J.quality;
+  Z.lgwin = J.lgwin;
+  Z.max_backward_limit = P.max_backward_limit;
+  Z.ring_mask = P.ring_mask;
+  Z.dict_break = P.dict_break;
+  Z.use_dictionary = J.use_dictionary;
+  Z.dist_max_distance = P.dist_max_distance;
+  Z.dist_alphabet_size = J.dist_alphabet_size;
+  Z.ndirect = P.num_direct_distance_codes;
+  Z.npostfix = P.dist_postfix_bits;
+  return Z;
+}
+static ZopfliBuffers zopfli_buffers_of(const ZopfliJob& J) {
+  ZopfliBuffers Z;
+  Z.buckets = J.buckets;
+  Z.forest = J.forest;
+  Z.nodes = (ZNode*)J.nodes;
+  Z.literal_costs = J.literal_costs;
+  Z.cost_dist = J.cost_dist;
+  Z.cost_cmd = J.cost_cmd;
+  Z.matches = J.matches;
+  Z.num_matches = J.num_matches;
+  Z.tmp_cmds = J.tmp_cmds;
+  Z.histo = J.histo;
+  return Z;
+}
+static ZopfliTables zopfli_tables() {
+  const DeviceTables& dt = dev_tables();
+  ZopfliTables T;
+  T.lut_buckets = dt.dict_lut_buckets;
+  T.lut_words = dt.dict_lut_words;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.logs.logs_16 = dt.logs_16;
+  T.logs.logs_8 = dt.logs_8;
+  return T;
+}
+__global__ __launch_bounds__(256) void k_zopfli_fill(uint32_t* __restrict__ p, size_t n, uint32_t value) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = value;
+}
+void lz77_zopfli_init(const ZopfliJob& J) {
+  const uint32_t window_mask = (1u << J.lgwin) - 1u;
+  hipLaunchKernelGGL(k_zopfli_fill, dim3(256), dim3(256), 0, BR_STREAM, J.buckets, (size_t)1 << kZBucketBits, 0u - window_mask);
+  hipLaunchKernelGGL(k_zopfli_fill, dim3(4096), dim3(256), 0, BR_STREAM, J.forest, (size_t)2 << J.lgwin, 0u);
+  HIP_CHECK(hipGetLastError());
+}
+// (first device slice: one lane per stream, see the header of zopfli_device.h)
+__global__ __launch_bounds__(64) void k_zopfli_prepend(ZopfliParams Z, ZopfliBuffers ZB, const uint8_t* __restrict__ text, uint32_t dict_bytes) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ZH10 h;
+  h.buckets = ZB.buckets;
+  h.forest = ZB.forest;
+  h.window_mask = (1u << Z.lgwin) - 1u;
+  h.invalid_pos = 0u - h.window_mask;
+  const uint32_t overlap = kZMaxTreeCompLength - 1;  // StoreLookahead() - 1
+  for (uint32_t i = 0; i + overlap < dict_bytes; ++i) z_h10_store(h, Z, text, i);
+}
+void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes) {
+  hipLaunchKernelGGL(k_zopfli_prepend, dim3(1), dim3(64), 0, BR_STREAM, zopfli_params_of(P, J), zopfli_buffers_of(J), (const uint8_t*)B.text, dict_bytes);
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void k_zopfli_block(ZopfliParams Z, ZopfliTables T, ZopfliBuffers ZB, const uint8_t* __restrict__ text,
+                                                     const Segment* __restrict__ segments, const SegEntry* __restrict__ entries, Command* __restrict__ cmds,
+                                                     SegExit* __restrict__ exits, uint32_t block) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const Segment seg = segments[block];
+  const SegEntry entry = entries[block];
+  br_zopfli_block(Z, T, ZB, text, seg, entry, cmds + seg.cmd_base, exits + block);
+}
+void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
+  hipLaunchKernelGGL(k_zopfli_block, dim3(1), dim3(64), 0, BR_STREAM, zopfli_params_of(P, J), zopfli_tables(), zopfli_buffers_of(J), (const uint8_t*)B.text,
+                     (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds, B.exits, block);
   HIP_CHECK(hipGetLastError());
 }
 

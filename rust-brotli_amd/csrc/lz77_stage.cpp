@@ -71,6 +71,17 @@ void Lz77Stage::Release() {
     dev_free(B_.pot);
     dev_free(B_.pot_state);
     dev_free(B_.pot_list);
+    dev_free(Z_.buckets);
+    dev_free(Z_.forest);
+    dev_free(Z_.nodes);
+    dev_free(Z_.literal_costs);
+    dev_free(Z_.cost_dist);
+    dev_free(Z_.cost_cmd);
+    dev_free(Z_.matches);
+    dev_free(Z_.num_matches);
+    dev_free(Z_.tmp_cmds);
+    dev_free(Z_.histo);
+    Z_ = ZopfliJob{};
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
     dev_free(B_.cmds);
@@ -125,6 +136,53 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   const size_t M = P_.total_bytes;
   B_ = Lz77Buffers{};
   B_.text = text_dev;
+  use_zopfli_ = params.hasher.type == 10;
+  if (use_zopfli_) {
+    // Qualities 10 / 11 (zopfli_device.h): the H10 trees and the shortest-path parse go block by block, one segment per input
+    // block; none of the sort / row / rank structures of the greedy path exist.
+    use_live_ = use_rows_ = false;
+    if (segment_bytes_ != block_bytes_) {
+      segment_bytes_ = block_bytes_;
+      P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
+      BuildSegments();
+      P_.num_segments = (uint32_t)segments_.size();
+    }
+    P_.use_dictionary = 0;  // (no throttle books for the resolver to keep: H10 consults the dictionary at every position)
+    Z_ = ZopfliJob{};
+    Z_.quality = (uint32_t)params.quality;
+    Z_.lgwin = (uint32_t)params.lgwin;
+    Z_.use_dictionary = params.use_dictionary ? 1 : 0;
+    Z_.dist_alphabet_size = params.dist.alphabet_size;
+    Z_.block_bytes = block_bytes_;
+    Z_.buckets = (uint32_t*)dev_alloc_uninit(((size_t)1 << 17) * 4 + 64);
+    Z_.forest = (uint32_t*)dev_alloc_uninit(((size_t)2 << params.lgwin) * 4 + 64);
+    Z_.nodes = dev_alloc_uninit(((size_t)block_bytes_ + 2) * 20 + 64);
+    Z_.literal_costs = (float*)dev_alloc_uninit(((size_t)block_bytes_ + 4) * 4 + 64);
+    Z_.cost_dist = (float*)dev_alloc((size_t)(params.dist.alphabet_size + 64) * 4 + 64);
+    Z_.cost_cmd = (float*)dev_alloc(704 * 4 + 64);
+    Z_.histo = (uint32_t*)dev_alloc(2048 * 4 + 64);
+    if (params.quality >= 11) {
+      Z_.matches = (unsigned long long*)dev_alloc_uninit((size_t)128 * block_bytes_ * 8 + 64);
+      Z_.num_matches = (uint32_t*)dev_alloc_uninit((size_t)block_bytes_ * 4 + 64);
+      Z_.tmp_cmds = (Command*)dev_alloc_uninit(((size_t)block_bytes_ / 2 + 8) * sizeof(Command) + 64);
+    } else {
+      Z_.matches = (unsigned long long*)dev_alloc_uninit(128 * 8 + 64);
+    }
+    cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
+    B_.cmds = (Command*)dev_alloc_uninit(cmds_bytes_);
+    B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
+    B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
+    B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
+    histo_dev_ = (uint32_t*)dev_alloc(256 * 4);
+    gather_offsets_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+    gather_counts_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+    owns_buffers_ = true;
+    segments_upload_.resize_discard(segments_.size());
+    memcpy(segments_upload_.data(), segments_.data(), segments_.size() * sizeof(Segment));
+    dev_h2d(B_.segments, segments_upload_.data(), segments_.size() * sizeof(Segment));
+    exits_.assign((uint32_t)segments_.size(), SegExit{});
+    return;
+  }
   B_.keys = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
   B_.by_key = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
   B_.sorted_keys = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
@@ -967,6 +1025,14 @@ void Lz77Stage::Run() {
     total_cmds_ = 0;
     return;
   }
+  if (use_zopfli_) {
+    RunZopfli();
+    tm.stop(&stats_.ms_parse);
+    Gather();
+    tm.stop(&stats_.ms_gather);
+    total.stop(&stats_.ms_total);
+    return;
+  }
   lz77_compute_keys(P_, B_);
   tm.stop(&stats_.ms_keys);
   lz77_sort_by_key(P_, B_);
@@ -1161,6 +1227,45 @@ void Lz77Stage::RunLive() {
     for (uint32_t k = 0; k < nseg; ++k)
       if (failed[k]) throw std::runtime_error("brotli_mi355x: live chain verification failed in block " + std::to_string(k));
   }
+  for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
+}
+
+// Qualities 10 / 11: the blocks go through the device one after the other (the H10 trees and the dynamic programme are a
+// function of everything in front); between two of them the host resolver replays the exits -- flush rule, should_compress,
+// extend_last_command -- exactly as behind a round of the greedy path, and hands the next block its entry.
+void Lz77Stage::RunZopfli() {
+  const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
+  const uint32_t nseg = (uint32_t)segments_.size();
+  if (carry_ && carry_->valid) throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece (no flush, no continuation) in this build");
+  if (partial_) throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece in this build");
+  InitEntries();
+  lz77_zopfli_init(Z_);
+  // a custom dictionary (the prefix of a compress_multi shard) goes into the trees first (encode.rs:1163-1194)
+  if (P_.prefix_bytes > 1) lz77_zopfli_prepend(P_, B_, Z_, P_.prefix_bytes);
+  uint32_t from = 0;
+  bool done = false;
+  for (uint32_t round = 0; round < nseg + 8 && !done; ++round) {
+    stats_.rounds++;
+    if (round != 0) entries_[from] = next_entries_[from];
+    dev_h2d(B_.entries + from, entries_.data() + from, sizeof(SegEntry));
+    lz77_zopfli_block(P_, B_, Z_, from);
+    stats_.segments_parsed++;
+    dev_d2h(exits_.data() + from, B_.exits + from, sizeof(SegExit));
+    if (exits_[from].bad_commands != 0)
+      throw std::runtime_error("brotli_mi355x: the reference encoder fails on this input at quality 10 / 11 (it indexes past the end of an array)");
+    Resolve(false);
+    // Everything up to `from` is final: its entries came out of exits that were final already (the trees do not hang on the
+    // parse, and what a meta-block in front decides -- stored uncompressed: it hands on the distance cache of its start,
+    // encode.rs:1994 -- was decided from the same exits).  The blocks behind are unparsed, whatever their empty exit records
+    // make the resolver think of them.
+    for (uint32_t k = 0; k <= from; ++k)
+      if (dirty_entry_[k]) throw std::runtime_error("brotli_mi355x: resolver and Zopfli parse disagree about the entry of a finished block");
+    if (debug) fprintf(stderr, "zopfli block %u of %u done: %u commands, %u bytes pending\n", from, nseg, exits_[from].n_cmds, exits_[from].insert_len);
+    ++from;
+    done = from == nseg;
+  }
+  if (!done) throw std::runtime_error("brotli_mi355x: quality 10 / 11 parse did not finish");
+  final_flags_ = 0;
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
 }
 

@@ -139,6 +139,7 @@ class Lz77Stage {
   void Resegment(uint32_t segment_bytes);
   void RunRounds(bool allow_restart);
   void RunLive();
+  void RunZopfli();
   void InitEntries();
   void InitFlags();
   bool Resolve(bool final_pass);
@@ -155,6 +156,8 @@ class Lz77Stage {
   Lz77Buffers B_{};
   LiveBuffers L_{};    // live chains (lz77_live.h)
   bool use_live_ = false;
+  bool use_zopfli_ = false;  // qualities 10 / 11 (zopfli_device.h)
+  ZopfliJob Z_{};
   bool live_verify_ = false;
   std::vector<LiveBlockState> live_state_;  // Resolve(): the meta-block books at the entry of every block (live chains)
   uint32_t input_bytes_ = 0;

@@ -15,7 +15,9 @@
 #include "../../rust-brotli_amd/csrc/device_api.h"
 #include "../../rust-brotli_amd/csrc/lz77_chain.h"
 #include "../../rust-brotli_amd/csrc/lz77_rows.h"
+#include "../../rust-brotli_amd/csrc/zopfli_device.h"
 #include "../../tables/brotli_tables.h"
+#include "../../tables/brotli_static_dict_lut.h"
 
 namespace brotli_mi355x {
 
@@ -63,6 +65,8 @@ const DeviceTables& dev_tables() {
   t.logs_8 = (const float*)(const void*)kBrotliLog2Table8_bits;
   t.utf8_context_lookup = kBrotliUTF8ContextLookup;
   t.signed_context_lookup = kBrotliSigned3BitContextLookup;
+  t.dict_lut_buckets = kStaticDictionaryBuckets;
+  t.dict_lut_words = kStaticDictionaryWords;
   return t;
 }
 
@@ -707,6 +711,64 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
 
 void lz77_patch_commands(Command* cmds, const CmdPatch* patches, uint32_t n) {
   for (uint32_t i = 0; i < n; ++i) br_apply_patch(cmds, patches[i]);
+}
+
+
+// ---- qualities 10 / 11 (zopfli_device.h): the same item code, called directly
+static ZopfliParams emu_zopfli_params(const Lz77Params& P, const ZopfliJob& J) {
+  ZopfliParams Z;
+  Z.quality = J.quality;
+  Z.lgwin = J.lgwin;
+  Z.max_backward_limit = P.max_backward_limit;
+  Z.ring_mask = P.ring_mask;
+  Z.dict_break = P.dict_break;
+  Z.use_dictionary = J.use_dictionary;
+  Z.dist_max_distance = P.dist_max_distance;
+  Z.dist_alphabet_size = J.dist_alphabet_size;
+  Z.ndirect = P.num_direct_distance_codes;
+  Z.npostfix = P.dist_postfix_bits;
+  return Z;
+}
+static ZopfliBuffers emu_zopfli_buffers(const ZopfliJob& J) {
+  ZopfliBuffers Z;
+  Z.buckets = J.buckets;
+  Z.forest = J.forest;
+  Z.nodes = (ZNode*)J.nodes;
+  Z.literal_costs = J.literal_costs;
+  Z.cost_dist = J.cost_dist;
+  Z.cost_cmd = J.cost_cmd;
+  Z.matches = J.matches;
+  Z.num_matches = J.num_matches;
+  Z.tmp_cmds = J.tmp_cmds;
+  Z.histo = J.histo;
+  return Z;
+}
+void lz77_zopfli_init(const ZopfliJob& J) {
+  const uint32_t window_mask = (1u << J.lgwin) - 1u;
+  for (size_t i = 0; i < ((size_t)1 << kZBucketBits); ++i) J.buckets[i] = 0u - window_mask;
+  memset(J.forest, 0, ((size_t)2 << J.lgwin) * 4);
+}
+void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes) {
+  const ZopfliParams Z = emu_zopfli_params(P, J);
+  ZH10 h;
+  h.buckets = J.buckets;
+  h.forest = J.forest;
+  h.window_mask = (1u << J.lgwin) - 1u;
+  h.invalid_pos = 0u - h.window_mask;
+  for (uint32_t i = 0; i + (kZMaxTreeCompLength - 1) < dict_bytes; ++i) z_h10_store(h, Z, B.text, i);
+}
+void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
+  const DeviceTables& dt = dev_tables();
+  ZopfliTables T;
+  T.lut_buckets = dt.dict_lut_buckets;
+  T.lut_words = dt.dict_lut_words;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
+  T.logs.logs_16 = dt.logs_16;
+  T.logs.logs_8 = dt.logs_8;
+  const Segment seg = B.segments[block];
+  br_zopfli_block(emu_zopfli_params(P, J), T, emu_zopfli_buffers(J), B.text, seg, B.entries[block], B.cmds + seg.cmd_base, B.exits + block);
 }
 
 }  // namespace brotli_mi355x
