@@ -415,6 +415,11 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   const uint32_t segment_bytes = req.segment_bytes ? req.segment_bytes : ChooseSegmentBytes(n);
   {
     Clock c;
+    // Qualities 10 / 11 (first device slice, zopfli_device.h): the state of the H10 trees is not carried from piece to piece yet.
+    // A stream that is flushed, or that is longer than one batch, is refused -- never answered with other bytes.
+    if (p.hasher.type == 10 && (continuing || !req.finish))
+      throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece in this build (no BROTLI_OPERATION_FLUSH / EMIT_METADATA in the "
+                               "middle, at most one batch of input -- BROTLI_MI355X_STREAM_BATCH, 64 MiB)");
     lz.SetStreamState(continuing ? req.carry_in : nullptr, req.finish, req.partial && !req.finish, req.last_block_processed_early);
     lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, segment_bytes);
     {

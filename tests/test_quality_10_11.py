@@ -1,0 +1,121 @@
+"""Qualities 10 and 11 proper: the H10 binary-tree hasher (hash_to_binary_tree.rs), FindAllMatchesH10 with
+BrotliFindAllStaticDictionaryMatches, the literal cost model (literal_cost.rs) and the Zopfli shortest-path parse
+(backward_references/hq.rs: one pass at quality 10, two at 11) as device code (rust-brotli_amd/csrc/zopfli_device.h), behind the
+quality >= 10 meta-block builder.
+
+The reference holds two exact sizes for the path: alice29 at quality 10 -> 47 488 bytes and at quality 11 -> 46 493 bytes
+(src/bin/integration_tests.rs:401-449, 4096-byte reads through roundtrip_helper).  Everything else is byte identity with the
+oracle (oracle/orc_zopfli.c, pinned on the same two sizes).  CPU: the emulation build; -m gpu: the product library."""
+import glob
+import os
+
+import pytest
+
+import orc
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+Q, W, SH, LARGE = 1, 2, 5, 6
+
+
+def _kat(lib):
+    a = synth.alice()
+    for quality, size in ((10, 47488), (11, 46493)):
+        params = [(Q, quality), (W, 22)]
+        e = lib.encoder(params=params)
+        for i in range(0, len(a), 4096):
+            e.write(a[i:i + 4096])
+        got = e.finish()
+        e.close()
+        assert len(got) == size, (quality, len(got))
+        assert got == orc.reader_compress(a, params, chunk=4096)
+        assert orc.decompress(got, len(a)) == a
+
+
+def _cases(small):
+    a = synth.alice()
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))):
+        d = open(f, "rb").read()
+        if small and len(d) > 70000:
+            continue
+        for q in (10, 11):
+            yield "%s q%d" % (os.path.basename(f), q), d, [(Q, q), (W, 22), (SH, len(d))], b""
+    h = len(a) // 2
+    for q in (10, 11):
+        yield "alice w16 q%d" % q, a, [(Q, q), (W, 16)], b""
+        yield "alice w18 hint q%d" % q, a, [(Q, q), (W, 18), (SH, len(a))], b""
+        yield "alice catable q%d" % q, a, [(Q, q), (W, 22), (167, 1)], b""
+        yield "alice appendable + magic q%d" % q, a, [(Q, q), (W, 22), (168, 1), (169, 1)], b""
+        yield "alice large window q%d" % q, a, [(Q, q), (LARGE, 1), (W, 26)], b""
+        yield "alice second half behind the first as dictionary q%d" % q, a[h:], [(Q, q), (W, 22), (167, 1), (168, 1)], a[:h]
+        yield "random 300k (stored raw) q%d" % q, synth.random_bytes(300000), [(Q, q), (W, 22)], b""
+        yield "zeros 700k (copies past the quick step) q%d" % q, bytes(700000), [(Q, q), (W, 22)], b""
+        if not small:
+            yield "mixed 1 MiB q%d" % q, synth.mixed(1 << 20), [(Q, q), (W, 22)], b""
+            yield "stretches 1 MiB q%d" % q, synth.stretches(1 << 20, 9), [(Q, q), (W, 20)], b""
+            yield "markov 1.5 MiB (six blocks) q%d" % q, synth.markov_text(3 << 19), [(Q, q), (W, 22), (SH, 3 << 19)], b""
+            yield "random_then_unicode q%d" % q, open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read(), [(Q, q), (W, 22)], b""
+
+
+def _identity(L, small):
+    from cmp_stream import check_bytes
+    bad = [name for name, data, params, prefix in _cases(small) if not check_bytes(L, name, data, params, prefix=prefix)]
+    assert not bad, bad
+
+
+def _multi(lib):
+    """BrotliEncoderCompressMulti at quality 10: every shard behind the first is primed with its prefix as a custom dictionary
+    (HasherPrependCustomDictionary stores it into the H10 trees, encode.rs:1163-1194)"""
+    d = synth.markov_text(700000, 21)
+    for q, nt in ((10, 3), (11, 2)):
+        got = bytes(lib.BrotliCompress(d, {Q: q, W: 20}, nt))
+        assert got == orc.compress_multi(d, [(Q, q), (W, 20)], nt), (q, nt)
+        assert orc.decompress(got, len(d)) == d
+
+
+def test_reference_kats_47488_46493_emu():
+    import test_cabi
+    _kat(test_cabi._load("emu"))
+
+
+def test_identity_with_the_oracle_emu():
+    import emu
+    _identity(emu.lib(), small=False)
+
+
+def test_multi_shard_emu():
+    import test_cabi
+    _multi(test_cabi._load("emu"))
+
+
+def test_streams_in_pieces_are_refused_with_a_message():
+    """first device slice: a quality 10 / 11 stream is encoded in one piece; a flush in the middle is refused, never answered with
+    other bytes"""
+    import test_cabi
+    lib = test_cabi._load("emu")
+    e = lib.encoder(params=[(Q, 10), (W, 22)])
+    with pytest.raises(Exception) as err:
+        e.flush(synth.alice()[:50000])
+        e.write(synth.alice()[50000:])
+        e.finish()
+    assert "one piece" in str(err.value)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_reference_kats_47488_46493_gpu():
+    import test_cabi
+    _kat(test_cabi._load("gpu"))
+
+
+@pytest.mark.gpu
+def test_identity_with_the_oracle_gpu():
+    import gpulib
+    _identity(gpulib.lib(), small=True)
+
+
+@pytest.mark.gpu
+def test_multi_shard_gpu():
+    import test_cabi
+    _multi(test_cabi._load("gpu"))

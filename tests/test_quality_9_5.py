@@ -142,16 +142,6 @@ def test_flushes_emu():
     _flushes(test_cabi._load("emu"))
 
 
-def test_what_is_still_refused():
-    """quality 10 / 11 without Q9_5 are the Zopfli path (H10): refused with a message, never routed anywhere else"""
-    import emu
-    L = emu.lib()
-    a = synth.alice()
-    for params in ([(Q, 10), (W, 22)], [(Q, 11), (W, 22)]):
-        with pytest.raises(RuntimeError):
-            emu.encode_stream(L, a, params)
-
-
 def _quality_11(lib, L, wide):
     """Quality 11 + Q9_5 selects H5 / H6 with 512-deep rings and 16 cache candidates (encode.rs:863-893): the chain kernels
     instantiated with the deep candidate scratch (ChainScratchT<.., kDeep>, lz77_chain.h).  The reference's second known answer
