@@ -273,14 +273,23 @@ struct ZopfliJob {
   uint32_t* num_matches = nullptr;        // quality 11: [block_bytes]
   Command* tmp_cmds = nullptr;   // quality 11: [block_bytes / 2 + 8]
   uint32_t* histo = nullptr;     // [2048]
+  // the trees of different hash keys side by side (br_zopfli_matches_of_group): nodes of the block's own positions, what the
+  // hasher looked like in front of the block (a block whose matches do not hold is parsed again the sequential way), which
+  // positions got a node, and the control words of the block (ZBlockCtl)
+  uint32_t* forest_new = nullptr;   // [2 << lgwin]
+  uint32_t* forest_bak = nullptr;   // [2 << lgwin]
+  uint32_t* buckets_bak = nullptr;  // [1 << 17]
+  uint8_t* rerooted = nullptr;      // [block_bytes]
+  uint32_t* ctl = nullptr;          // [16]
 };
 // empties the hasher: buckets = invalid position, forest = 0 (InitializeH10, hash_to_binary_tree.rs:149-190)
 void lz77_zopfli_init(const ZopfliJob& J);
 // HasherPrependCustomDictionary (encode.rs:1163-1194): the positions [0, dict_bytes - 127) of the text go into the trees
 void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes);
 // input block `block` (= segment `block`: one segment per block) with the entry B.entries[block]: commands into its slab, exit into
-// B.exits[block].  The blocks of a stream go through here in order.
-void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block);
+// B.exits[block].  The blocks of a stream go through here in order.  Needs the positions sorted by 16-bit hash key (lz77_compute_keys
+// with bucket_bits 16 + lz77_sort_by_key: two H10 keys per group).  Returns true if the block had to be parsed the sequential way.
+bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block);
 
 // ---- live chains (lz77_live.h): chains that parse a span of input blocks on a private copy of the reference's bucket rings ----
 struct LiveBuffers {

@@ -2337,18 +2337,66 @@ void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const Zopfli
   hipLaunchKernelGGL(k_zopfli_prepend, dim3(1), dim3(64), 0, BR_STREAM, zopfli_params_of(P, J), zopfli_buffers_of(J), (const uint8_t*)B.text, dict_bytes);
   HIP_CHECK(hipGetLastError());
 }
-__global__ __launch_bounds__(64) void k_zopfli_block(ZopfliParams Z, ZopfliTables T, ZopfliBuffers ZB, const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(64) void k_zopfli_begin(ZopfliParams Z, ZopfliBuffers ZB, const uint8_t* __restrict__ text, const Segment* __restrict__ segments,
+                                                     const SegEntry* __restrict__ entries, uint32_t block, ZBlockCtl* __restrict__ ctl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  br_zopfli_begin(Z, ZB, text, segments[block], entries[block], ctl);
+}
+// one lane per group of hash keys (the positions of a 16-bit key of the sort = two H10 keys): the groups' trees grow side by side
+__global__ __launch_bounds__(64) void k_zopfli_matches(ZopfliParams Z, ZopfliTables T, ZopfliBuffers ZB, uint32_t* __restrict__ forest_new,
+                                                       uint8_t* __restrict__ rerooted, const uint8_t* __restrict__ text, const uint32_t* __restrict__ by_key,
+                                                       const uint32_t* __restrict__ key_first, const uint32_t* __restrict__ key_last, ZBlockCtl* ctl) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 65536u) return;
+  const uint32_t lo = key_first[g], hi = key_last[g];
+  if (lo >= hi) return;
+  br_zopfli_matches_of_group(Z, T, ZB, forest_new, rerooted, text, by_key, lo, hi, ctl);
+}
+__global__ __launch_bounds__(256) void k_zopfli_merge(ZopfliParams Z, ZopfliBuffers ZB, const uint32_t* __restrict__ forest_new, const uint8_t* __restrict__ rerooted,
+                                                      const ZBlockCtl* __restrict__ ctl, uint32_t block_bytes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < block_bytes) br_zopfli_merge_node(Z, ZB, forest_new, rerooted, ctl, i);
+}
+// (first device slice of the parse itself: one lane per stream, see the header of zopfli_device.h)
+__global__ __launch_bounds__(64) void k_zopfli_parse(ZopfliParams Z, ZopfliTables T, ZopfliBuffers ZB, const uint8_t* __restrict__ text,
                                                      const Segment* __restrict__ segments, const SegEntry* __restrict__ entries, Command* __restrict__ cmds,
-                                                     SegExit* __restrict__ exits, uint32_t block) {
+                                                     SegExit* __restrict__ exits, uint32_t block, ZBlockCtl* ctl, uint32_t precomputed) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const Segment seg = segments[block];
-  const SegEntry entry = entries[block];
-  br_zopfli_block(Z, T, ZB, text, seg, entry, cmds + seg.cmd_base, exits + block);
+  ctl->pad[0] = br_zopfli_parse(Z, T, ZB, text, seg, entries[block], ctl, precomputed != 0, cmds + seg.cmd_base, exits + block);
 }
-void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
-  hipLaunchKernelGGL(k_zopfli_block, dim3(1), dim3(64), 0, BR_STREAM, zopfli_params_of(P, J), zopfli_tables(), zopfli_buffers_of(J), (const uint8_t*)B.text,
-                     (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds, B.exits, block);
+bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
+  static const bool sequential_only = getenv("BROTLI_MI355X_ZOPFLI_SEQUENTIAL") != nullptr;
+  const ZopfliParams Z = zopfli_params_of(P, J);
+  const ZopfliBuffers ZB = zopfli_buffers_of(J);
+  const ZopfliTables T = zopfli_tables();
+  ZBlockCtl* ctl = (ZBlockCtl*)J.ctl;
+  const size_t forest_bytes = ((size_t)2 << J.lgwin) * 4, bucket_bytes = ((size_t)1 << kZBucketBits) * 4;
+  hipLaunchKernelGGL(k_zopfli_begin, dim3(1), dim3(64), 0, BR_STREAM, Z, ZB, (const uint8_t*)B.text, (const Segment*)B.segments, (const SegEntry*)B.entries, block, ctl);
+  bool redo = sequential_only;
+  if (!sequential_only) {
+    HIP_CHECK(hipMemcpyAsync(J.forest_bak, J.forest, forest_bytes, hipMemcpyDeviceToDevice, BR_STREAM));
+    HIP_CHECK(hipMemcpyAsync(J.buckets_bak, J.buckets, bucket_bytes, hipMemcpyDeviceToDevice, BR_STREAM));
+    hipLaunchKernelGGL(k_zopfli_matches, dim3(65536 / 64), dim3(64), 0, BR_STREAM, Z, T, ZB, J.forest_new, J.rerooted, (const uint8_t*)B.text, (const uint32_t*)B.by_key,
+                       (const uint32_t*)B.key_first, (const uint32_t*)B.key_last, ctl);
+    hipLaunchKernelGGL(k_zopfli_merge, dim3((J.block_bytes + 255) / 256), dim3(256), 0, BR_STREAM, Z, ZB, (const uint32_t*)J.forest_new, (const uint8_t*)J.rerooted,
+                       (const ZBlockCtl*)ctl, J.block_bytes);
+    hipLaunchKernelGGL(k_zopfli_parse, dim3(1), dim3(64), 0, BR_STREAM, Z, T, ZB, (const uint8_t*)B.text, (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds,
+                       B.exits, block, ctl, 1u);
+    HIP_CHECK(hipGetLastError());
+    ZBlockCtl host;
+    dev_d2h(&host, ctl, sizeof(host));
+    redo = host.pad[0] == kZopfliRedo;
+    if (redo) {  // a match beyond the Zopfli length: positions are skipped there, the trees differ -- back to the block's start
+      HIP_CHECK(hipMemcpyAsync(J.forest, J.forest_bak, forest_bytes, hipMemcpyDeviceToDevice, BR_STREAM));
+      HIP_CHECK(hipMemcpyAsync(J.buckets, J.buckets_bak, bucket_bytes, hipMemcpyDeviceToDevice, BR_STREAM));
+    }
+  }
+  if (redo)
+    hipLaunchKernelGGL(k_zopfli_parse, dim3(1), dim3(64), 0, BR_STREAM, Z, T, ZB, (const uint8_t*)B.text, (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds,
+                       B.exits, block, ctl, 0u);
   HIP_CHECK(hipGetLastError());
+  return redo;
 }
 
 }  // namespace brotli_mi355x

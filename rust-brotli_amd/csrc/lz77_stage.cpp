@@ -81,6 +81,11 @@ void Lz77Stage::Release() {
     dev_free(Z_.num_matches);
     dev_free(Z_.tmp_cmds);
     dev_free(Z_.histo);
+    dev_free(Z_.forest_new);
+    dev_free(Z_.forest_bak);
+    dev_free(Z_.buckets_bak);
+    dev_free(Z_.rerooted);
+    dev_free(Z_.ctl);
     Z_ = ZopfliJob{};
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
@@ -148,6 +153,19 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
       P_.num_segments = (uint32_t)segments_.size();
     }
     P_.use_dictionary = 0;  // (no throttle books for the resolver to keep: H10 consults the dictionary at every position)
+    // the positions sorted by a 16-bit hash key (two H10 keys -- 17 bits of the same product -- per group): the groups of a block
+    // find their matches side by side (br_zopfli_matches_of_group)
+    P_.hasher_kind = 5;
+    P_.bucket_bits = 16;
+    P_.htl = 4;
+    B_.keys = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
+    B_.by_key = (uint32_t*)dev_alloc_uninit(M * 4 + 64);
+    B_.sorted_keys = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
+    B_.key_first = (uint32_t*)dev_alloc((65536 + 1) * 4);
+    B_.key_last = (uint32_t*)dev_alloc((65536 + 1) * 4);
+    B_.changed_count = (uint32_t*)dev_alloc(64);
+    B_.sort_tmp_bytes = lz77_sort_tmp_bytes(P_.total_bytes);
+    B_.sort_tmp = dev_alloc_uninit(B_.sort_tmp_bytes);
     Z_ = ZopfliJob{};
     Z_.quality = (uint32_t)params.quality;
     Z_.lgwin = (uint32_t)params.lgwin;
@@ -161,13 +179,14 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     Z_.cost_dist = (float*)dev_alloc((size_t)(params.dist.alphabet_size + 64) * 4 + 64);
     Z_.cost_cmd = (float*)dev_alloc(704 * 4 + 64);
     Z_.histo = (uint32_t*)dev_alloc(2048 * 4 + 64);
-    if (params.quality >= 11) {
-      Z_.matches = (unsigned long long*)dev_alloc_uninit((size_t)128 * block_bytes_ * 8 + 64);
-      Z_.num_matches = (uint32_t*)dev_alloc_uninit((size_t)block_bytes_ * 4 + 64);
-      Z_.tmp_cmds = (Command*)dev_alloc_uninit(((size_t)block_bytes_ / 2 + 8) * sizeof(Command) + 64);
-    } else {
-      Z_.matches = (unsigned long long*)dev_alloc_uninit(128 * 8 + 64);
-    }
+    Z_.matches = (unsigned long long*)dev_alloc_uninit((size_t)128 * block_bytes_ * 8 + 64);
+    Z_.num_matches = (uint32_t*)dev_alloc((size_t)block_bytes_ * 4 + 64);
+    Z_.tmp_cmds = (Command*)dev_alloc_uninit(((size_t)block_bytes_ / 2 + 8) * sizeof(Command) + 64);
+    Z_.forest_new = (uint32_t*)dev_alloc_uninit(((size_t)2 << params.lgwin) * 4 + 64);
+    Z_.forest_bak = (uint32_t*)dev_alloc_uninit(((size_t)2 << params.lgwin) * 4 + 64);
+    Z_.buckets_bak = (uint32_t*)dev_alloc_uninit(((size_t)1 << 17) * 4 + 64);
+    Z_.rerooted = (uint8_t*)dev_alloc((size_t)block_bytes_ + 64);
+    Z_.ctl = (uint32_t*)dev_alloc(64);
     cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
     B_.cmds = (Command*)dev_alloc_uninit(cmds_bytes_);
     B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
@@ -1239,6 +1258,8 @@ void Lz77Stage::RunZopfli() {
   if (carry_ && carry_->valid) throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece (no flush, no continuation) in this build");
   if (partial_) throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece in this build");
   InitEntries();
+  lz77_compute_keys(P_, B_);
+  lz77_sort_by_key(P_, B_);
   lz77_zopfli_init(Z_);
   // a custom dictionary (the prefix of a compress_multi shard) goes into the trees first (encode.rs:1163-1194)
   if (P_.prefix_bytes > 1) lz77_zopfli_prepend(P_, B_, Z_, P_.prefix_bytes);
@@ -1248,7 +1269,7 @@ void Lz77Stage::RunZopfli() {
     stats_.rounds++;
     if (round != 0) entries_[from] = next_entries_[from];
     dev_h2d(B_.entries + from, entries_.data() + from, sizeof(SegEntry));
-    lz77_zopfli_block(P_, B_, Z_, from);
+    if (lz77_zopfli_block(P_, B_, Z_, from)) stats_.coarse_restarts++;  // (parsed the sequential way)
     stats_.segments_parsed++;
     dev_d2h(exits_.data() + from, B_.exits + from, sizeof(SegExit));
     if (exits_[from].bad_commands != 0)

@@ -140,7 +140,14 @@ struct ZH10 {
   uint32_t* forest;
   uint32_t window_mask;
   uint32_t invalid_pos;  // 0 - window_mask
+  // Where the trees of different hash keys grow side by side (br_zopfli_matches_of_group) the nodes of the positions from
+  // new_from on live in an array of their own: node storage is indexed by position mod window size, so the node of an in-block
+  // position p shares its slot with the node of p - window, which a search at a position in front of p may still visit --
+  // sequentially p comes later, side by side it may come first.  forest_new == forest, new_from = 0: one array (sequential use).
+  uint32_t* forest_new;
+  uint32_t new_from;
 };
+ZDEV uint32_t* z_h10_children(const ZH10& h, uint32_t pos) { return (pos >= h.new_from ? h.forest_new : h.forest) + 2 * (size_t)(pos & h.window_mask); }
 ZDEV unsigned long long z_match(uint32_t distance, uint32_t length_and_code) { return (unsigned long long)distance | ((unsigned long long)length_and_code << 32); }
 ZDEV uint32_t z_match_distance(unsigned long long m) { return (uint32_t)m; }
 ZDEV uint32_t z_match_length(unsigned long long m) { return (uint32_t)(m >> 32) >> 5; }
@@ -157,18 +164,17 @@ ZDEV uint32_t z_h10_store_and_find(const ZH10& h, const ZopfliParams& P, const u
   const uint32_t max_comp_len = max_length < kZMaxTreeCompLength ? max_length : kZMaxTreeCompLength;
   const bool reroot = max_length >= kZMaxTreeCompLength;
   const uint32_t key = (br_load32(data + cur_ix) * 0x1e35a7bdu) >> (32 - kZBucketBits);
-  uint32_t* forest = h.forest;
   uint64_t prev_ix = h.buckets[key];
-  size_t node_left = 2 * (size_t)(cur_ix & h.window_mask);
-  size_t node_right = node_left + 1;
+  uint32_t* node_left = z_h10_children(h, cur_ix);
+  uint32_t* node_right = node_left + 1;
   uint32_t best_left = 0, best_right = 0;
   if (reroot) h.buckets[key] = cur_ix;
   for (uint32_t depth = kZMaxTreeSearchDepth;; --depth) {
     const uint64_t backward = (uint64_t)cur_ix - prev_ix;  // (usize arithmetic of the reference: wraps for the invalid position)
     if (backward == 0 || backward > max_backward || depth == 0) {
       if (reroot) {
-        forest[node_left] = h.invalid_pos;
-        forest[node_right] = h.invalid_pos;
+        *node_left = h.invalid_pos;
+        *node_right = h.invalid_pos;
       }
       break;
     }
@@ -180,24 +186,24 @@ ZDEV uint32_t z_h10_store_and_find(const ZH10& h, const ZopfliParams& P, const u
       *best_len = len;
       matches[found++] = z_match((uint32_t)backward, len << 5);
     }
-    const size_t prev_left = 2 * (size_t)(prev & h.window_mask);
+    uint32_t* prev_children = z_h10_children(h, prev);
     if (len >= max_comp_len) {
       if (reroot) {
-        forest[node_left] = forest[prev_left];
-        forest[node_right] = forest[prev_left + 1];
+        *node_left = prev_children[0];
+        *node_right = prev_children[1];
       }
       break;
     }
     if (data[cur_ix + len] > data[prev + len]) {
       best_left = len;
-      if (reroot) forest[node_left] = prev;
-      node_left = prev_left + 1;
-      prev_ix = forest[node_left];
+      if (reroot) *node_left = prev;
+      node_left = prev_children + 1;
+      prev_ix = *node_left;
     } else {
       best_right = len;
-      if (reroot) forest[node_right] = prev;
-      node_right = prev_left;
-      prev_ix = forest[node_right];
+      if (reroot) *node_right = prev;
+      node_right = prev_children;
+      prev_ix = *node_right;
     }
   }
   return found;
@@ -386,7 +392,7 @@ ZDEV bool z_find_all_dictionary_matches(const ZopfliTables& T, const uint8_t* da
 
 // FindAllMatchesH10, hq.rs:301-412: short distances by direct comparison, then the tree, then the static dictionary
 ZDEV uint32_t z_find_all_matches(const ZH10& h, const ZopfliParams& P, const ZopfliTables& T, const uint8_t* data, uint32_t cur_ix,
-                                 uint32_t max_length, uint32_t max_backward, unsigned long long* matches) {
+                                 uint32_t max_length, uint32_t max_backward, unsigned long long* matches, bool* went_into_tree = nullptr) {
   uint32_t found = 0;
   uint32_t best_len = 1;
   const uint32_t short_reach = P.quality != 11 ? 16u : 64u;
@@ -402,6 +408,7 @@ ZDEV uint32_t z_find_all_matches(const ZH10& h, const ZopfliParams& P, const Zop
       }
     }
   }
+  if (went_into_tree) *went_into_tree = best_len < max_length;
   if (best_len < max_length) found += z_h10_store_and_find(h, P, data, cur_ix, max_length, max_backward, &best_len, matches + found, kZMaxMatches - found);
   if (P.use_dictionary) {
     uint32_t dict_matches[38];
@@ -917,11 +924,15 @@ ZDEV void z_shortest_path_q10(const ZH10& h, const ZopfliParams& P, const Zopfli
     }
   }
 }
-// ZopfliIterate, hq.rs:1162-1244 (quality 11): the node updates over the matches collected beforehand
-ZDEV void z_iterate_q11(const ZopfliParams& P, const ZopfliBuffers& B, const uint8_t* text, uint32_t num_bytes, uint32_t position,
-                        const int32_t* dist_cache, const ZCostModel& model) {
+// ZopfliIterate, hq.rs:1162-1244: the node updates over matches collected beforehand.  Quality 11 as the reference runs it
+// (matches packed one behind the other, stride 0); with stride = 128 the matches of position i sit at matches + 128 * i
+// (br_zopfli_matches_of_group) -- then also quality 10, whose reference interleaves matching and node updates
+// (BrotliZopfliComputeShortestPath, hq.rs:873-988): the same sequence of UpdateNodes calls as long as no position is skipped;
+// returns false where one would be (a copy beyond the quick step: the reference stores the skipped positions differently).
+ZDEV bool z_iterate(const ZopfliParams& P, const ZopfliBuffers& B, const uint8_t* text, uint32_t num_bytes, uint32_t position,
+                    const int32_t* dist_cache, const ZCostModel& model, uint32_t stride) {
   ZNode* nodes = B.nodes;
-  const uint32_t max_zlen = 325;
+  const uint32_t max_zlen = P.quality <= 10 ? 150u : 325u;
   nodes[0].length = 0;
   z_set_cost(nodes[0], 0.0f);
   ZQueue queue;
@@ -933,14 +944,14 @@ ZDEV void z_iterate_q11(const ZopfliParams& P, const ZopfliBuffers& B, const uin
   }
   size_t cur_match_pos = 0;
   for (uint32_t i = 0; i + 3 < num_bytes; ++i) {
-    uint32_t skip = z_update_nodes(P, text, num_bytes, position, i, dist_cache, B.num_matches[i], B.matches + cur_match_pos, model, queue, nodes);
+    const unsigned long long* m = stride ? B.matches + (size_t)stride * i : B.matches + cur_match_pos;
+    const uint32_t nm = B.num_matches[i];
+    uint32_t skip = z_update_nodes(P, text, num_bytes, position, i, dist_cache, nm, m, model, queue, nodes);
     if (skip < kZLongCopyQuickStep) skip = 0;
-    cur_match_pos += B.num_matches[i];
-    if (B.num_matches[i] == 1 && z_match_length(B.matches[cur_match_pos - 1]) > max_zlen) {
-      const uint32_t ml = z_match_length(B.matches[cur_match_pos - 1]);
-      skip = ml > skip ? ml : skip;
-    }
+    cur_match_pos += nm;
+    if (nm == 1 && z_match_length(m[0]) > max_zlen) skip = z_match_length(m[0]) > skip ? z_match_length(m[0]) : skip;
     if (skip > 1) {
+      if (P.quality <= 10) return false;
       --skip;
       while (skip != 0) {
         ++i;
@@ -951,28 +962,46 @@ ZDEV void z_iterate_q11(const ZopfliParams& P, const ZopfliBuffers& B, const uin
       }
     }
   }
+  return true;
 }
 
-// What the kernel reports besides the SegExit record
-static constexpr uint32_t kZopfliOk = 0, kZopfliReferencePanics = 1;
-
-// One input block [seg.start, seg.end) of a stream whose hasher state is in B (all earlier blocks went through here in order):
-// stitch, extend_last_command, the parse of quality 10 or 11, commands into the block's slab (raw: the gather pass finishes
-// them), the exit record for the host resolver (Lz77Stage::Resolve).  `first` = nothing of the stream has been stored yet.
-ZDEV uint32_t br_zopfli_block(const ZopfliParams& P, const ZopfliTables& T, const ZopfliBuffers& B, const uint8_t* text, const Segment& seg,
-                              const SegEntry& entry, Command* slab, SegExit* exit_out) {
+// ---- one input block ---------------------------------------------------------------------------------------------------------
+static constexpr uint32_t kZopfliOk = 0, kZopfliReferencePanics = 1, kZopfliRedo = 2;
+// what travels between the kernels of a block (device memory)
+struct ZBlockCtl {
+  uint32_t position, num_bytes;  // what is left of the block behind extend_last_command
+  uint32_t ext_len;
+  uint32_t event;                // some position found a match beyond the Zopfli length: the reference skips positions there
+  uint32_t pad[4];
+};
+ZDEV ZH10 z_hasher_of(const ZopfliParams& P, const ZopfliBuffers& B) {
   ZH10 h;
   h.buckets = B.buckets;
   h.forest = B.forest;
   h.window_mask = (1u << P.lgwin) - 1u;
   h.invalid_pos = 0u - h.window_mask;
-  uint32_t status = kZopfliOk;
+  h.forest_new = B.forest;
+  h.new_from = 0;
+  return h;
+}
+ZDEV ZCostModel z_model_of(const ZopfliParams& P, const ZopfliBuffers& B, uint32_t num_bytes) {
+  ZCostModel model;
+  model.cost_cmd = B.cost_cmd;
+  model.cost_dist = B.cost_dist;
+  model.literal_costs = B.literal_costs;
+  model.distance_histogram_size = P.dist_alphabet_size < 544 ? P.dist_alphabet_size : 544;
+  model.min_cost_cmd = 0.0f;
+  model.num_bytes = num_bytes;
+  return model;
+}
+// StitchToPreviousBlockH10 + extend_last_command (encode.rs:2417-2437): what comes in front of the parse of a block
+ZDEV void br_zopfli_begin(const ZopfliParams& P, const ZopfliBuffers& B, const uint8_t* text, const Segment& seg, const SegEntry& entry, ZBlockCtl* ctl) {
+  const ZH10 h = z_hasher_of(P, B);
   uint32_t position = seg.blk_start;
   uint32_t num_bytes = seg.blk_end - seg.blk_start;
   z_h10_stitch(h, P, text, num_bytes, position);
-  // extend_last_command, encode.rs:360-400 (the resolver has checked everything but the bytes)
   uint32_t ext_len = 0;
-  if (entry.ext_allowed) {
+  if (entry.ext_allowed) {  // (the resolver has checked everything but the bytes, encode.rs:360-400)
     const uint32_t d = (uint32_t)entry.cache[0];
     while (num_bytes != 0 && text[position] == text[position - d]) {
       ++ext_len;
@@ -980,51 +1009,112 @@ ZDEV uint32_t br_zopfli_block(const ZopfliParams& P, const ZopfliTables& T, cons
       --num_bytes;
     }
   }
+  ctl->position = position;
+  ctl->num_bytes = num_bytes;
+  ctl->ext_len = ext_len;
+  ctl->event = 0;
+}
+// The matches of the positions of one group of hash keys -- the positions by_key[lo .. hi) of the block, in ascending order --
+// as FindAllMatchesH10 finds them when every position of the block goes through it in turn: B.matches + 128 * i, B.num_matches[i],
+// i = position in the block.  The trees of different keys do not touch (node storage apart, see ZH10), so the groups of a block
+// run side by side; what hangs on the order ACROSS keys -- positions skipped behind a match beyond the Zopfli length, stored
+// through StoreRange instead -- is reported (ctl->event) and the block is parsed again sequentially.
+ZDEV void br_zopfli_matches_of_group(const ZopfliParams& P, const ZopfliTables& T, const ZopfliBuffers& B, uint32_t* forest_new, uint8_t* rerooted,
+                                     const uint8_t* text, const uint32_t* by_key, uint32_t lo, uint32_t hi, ZBlockCtl* ctl) {
+  ZH10 h = z_hasher_of(P, B);
+  const uint32_t position = ctl->position, num_bytes = ctl->num_bytes;
+  h.forest_new = forest_new;
+  h.new_from = position;
+  const uint32_t max_zlen = P.quality <= 10 ? 150u : 325u;
+  // first slot of the group whose position is >= position
+  uint32_t a = lo, b = hi;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (by_key[mid] < position) a = mid + 1; else b = mid;
+  }
+  for (uint32_t idx = a; idx < hi; ++idx) {
+    const uint32_t pos = by_key[idx];
+    const uint32_t i = pos - position;
+    if (i + 3 >= num_bytes) break;
+    const uint32_t max_distance = pos < P.max_backward_limit ? pos : P.max_backward_limit;
+    const uint32_t max_length = num_bytes - i;
+    unsigned long long* m = B.matches + (size_t)128 * i;
+    bool tree = false;
+    const uint32_t found = z_find_all_matches(h, P, T, text, pos, max_length, max_distance, m, &tree);
+    B.num_matches[i] = found;
+    rerooted[i] = (tree && max_length >= kZMaxTreeCompLength) ? 1 : 0;
+    if (found > 0 && z_match_length(m[found - 1]) > max_zlen) ctl->event = 1;
+  }
+}
+// the nodes that the positions of the block got in forest_new move to their slots of the one array (after all groups are through)
+ZDEV void br_zopfli_merge_node(const ZopfliParams& P, const ZopfliBuffers& B, const uint32_t* forest_new, const uint8_t* rerooted, const ZBlockCtl* ctl, uint32_t i) {
+  if (i >= ctl->num_bytes || !rerooted[i]) return;
+  const size_t slot = 2 * (size_t)((ctl->position + i) & ((1u << P.lgwin) - 1u));
+  B.forest[slot] = forest_new[slot];
+  B.forest[slot + 1] = forest_new[slot + 1];
+}
+
+// The parse of the block behind br_zopfli_begin: commands into the block's slab (raw: the gather pass finishes them) and the exit
+// record for the host resolver (Lz77Stage::Resolve).  precomputed: the matches are there (br_zopfli_matches_of_group); otherwise
+// the block is walked the reference's way, matching and tree updates position by position.  Returns kZopfliRedo when the
+// precomputed matches do not hold (nothing has been written then; the caller restores the trees and comes again).
+ZDEV uint32_t br_zopfli_parse(const ZopfliParams& P, const ZopfliTables& T, const ZopfliBuffers& B, const uint8_t* text, const Segment& seg,
+                              const SegEntry& entry, const ZBlockCtl* ctl, bool precomputed, Command* slab, SegExit* exit_out) {
+  const ZH10 h = z_hasher_of(P, B);
+  uint32_t status = kZopfliOk;
+  const uint32_t position = ctl->position, num_bytes = ctl->num_bytes;
+  if (precomputed && ctl->event) return kZopfliRedo;
   int32_t dist_cache[4];
   for (int i = 0; i < 4; ++i) dist_cache[i] = entry.cache[i];
   uint32_t n_cmds = 0, n_lits = 0, pending = num_bytes, last_dist_code = 0xffffffffu, last_copy_len = 0;
   if (num_bytes != 0) {
     if (P.quality <= 10) {
       z_init_nodes(B.nodes, num_bytes + 1);
-      z_shortest_path_q10(h, P, T, B, text, num_bytes, position, dist_cache);
+      if (precomputed) {
+        ZCostModel model = z_model_of(P, B, num_bytes);
+        z_model_from_literal_costs(model, T, text + position, B.histo);
+        for (uint32_t i = num_bytes >= 3 ? num_bytes - 3 : 0; i < num_bytes; ++i) B.num_matches[i] = 0;
+        if (!z_iterate(P, B, text, num_bytes, position, dist_cache, model, 128)) return kZopfliRedo;
+      } else {
+        z_shortest_path_q10(h, P, T, B, text, num_bytes, position, dist_cache);
+      }
       z_shortest_path_from_nodes(num_bytes, B.nodes);
       n_cmds = z_create_commands(P, num_bytes, position, B.nodes, dist_cache, entry.insert_len, nullptr, slab, &n_lits, &pending, &last_dist_code, &last_copy_len);
     } else {
       // BrotliCreateHqZopfliBackwardReferences, hq.rs:1246-1448: all matches first ...
-      const uint32_t store_end = num_bytes >= kZMaxTreeCompLength ? position + num_bytes - kZMaxTreeCompLength + 1 : position;
-      size_t cur_match_pos = 0;
-      for (uint32_t i = 0; i < num_bytes; ++i) B.num_matches[i] = 0;
-      for (uint32_t i = 0; i + 3 < num_bytes; ++i) {
-        const uint32_t pos = position + i;
-        const uint32_t max_distance = pos < P.max_backward_limit ? pos : P.max_backward_limit;
-        const uint32_t found = z_find_all_matches(h, P, T, text, pos, num_bytes - i, max_distance, B.matches + cur_match_pos);
-        const size_t cur_match_end = cur_match_pos + found;
-        B.num_matches[i] = found;
-        if (found > 0) {
-          const uint32_t mlen = z_match_length(B.matches[cur_match_end - 1]);
-          if (mlen > 325) {
-            uint32_t skip = mlen - 1;
-            B.matches[cur_match_pos++] = B.matches[cur_match_end - 1];
-            B.num_matches[i] = 1;
-            z_h10_store_range(h, P, text, pos + 1, pos + mlen < store_end ? pos + mlen : store_end);
-            if ((uint64_t)i + 1 + skip > num_bytes) {  // the reference clears num_matches[i + 1 .. i + 1 + skip) and panics past the end
-              status = kZopfliReferencePanics;
-              skip = num_bytes - i - 1;
+      if (!precomputed) {
+        const uint32_t store_end = num_bytes >= kZMaxTreeCompLength ? position + num_bytes - kZMaxTreeCompLength + 1 : position;
+        size_t cur_match_pos = 0;
+        for (uint32_t i = 0; i < num_bytes; ++i) B.num_matches[i] = 0;
+        for (uint32_t i = 0; i + 3 < num_bytes; ++i) {
+          const uint32_t pos = position + i;
+          const uint32_t max_distance = pos < P.max_backward_limit ? pos : P.max_backward_limit;
+          const uint32_t found = z_find_all_matches(h, P, T, text, pos, num_bytes - i, max_distance, B.matches + cur_match_pos);
+          const size_t cur_match_end = cur_match_pos + found;
+          B.num_matches[i] = found;
+          if (found > 0) {
+            const uint32_t mlen = z_match_length(B.matches[cur_match_end - 1]);
+            if (mlen > 325) {
+              uint32_t skip = mlen - 1;
+              B.matches[cur_match_pos++] = B.matches[cur_match_end - 1];
+              B.num_matches[i] = 1;
+              z_h10_store_range(h, P, text, pos + 1, pos + mlen < store_end ? pos + mlen : store_end);
+              if ((uint64_t)i + 1 + skip > num_bytes) {  // the reference clears num_matches[i + 1 .. i + 1 + skip) and panics past the end
+                status = kZopfliReferencePanics;
+                skip = num_bytes - i - 1;
+              }
+              for (uint32_t k = 0; k < skip; ++k) B.num_matches[i + 1 + k] = 0;
+              i += skip;
+            } else {
+              cur_match_pos = cur_match_end;
             }
-            for (uint32_t k = 0; k < skip; ++k) B.num_matches[i + 1 + k] = 0;
-            i += skip;
-          } else {
-            cur_match_pos = cur_match_end;
           }
         }
+      } else {
+        for (uint32_t i = num_bytes >= 3 ? num_bytes - 3 : 0; i < num_bytes; ++i) B.num_matches[i] = 0;
       }
       // ... then two passes of the dynamic programme: literal-cost model, then the model of the first pass's commands
-      ZCostModel model;
-      model.cost_cmd = B.cost_cmd;
-      model.cost_dist = B.cost_dist;
-      model.literal_costs = B.literal_costs;
-      model.distance_histogram_size = P.dist_alphabet_size < 544 ? P.dist_alphabet_size : 544;
-      model.num_bytes = num_bytes;
+      ZCostModel model = z_model_of(P, B, num_bytes);
       int32_t orig_cache[4];
       for (int i = 0; i < 4; ++i) orig_cache[i] = dist_cache[i];
       for (uint32_t pass = 0; pass < 2; ++pass) {
@@ -1036,7 +1126,7 @@ ZDEV uint32_t br_zopfli_block(const ZopfliParams& P, const ZopfliTables& T, cons
         }
         for (int i = 0; i < 4; ++i) dist_cache[i] = orig_cache[i];
         n_lits = 0;
-        z_iterate_q11(P, B, text, num_bytes, position, dist_cache, model);
+        z_iterate(P, B, text, num_bytes, position, dist_cache, model, precomputed ? 128u : 0u);
         z_shortest_path_from_nodes(num_bytes, B.nodes);
         n_cmds = z_create_commands(P, num_bytes, position, B.nodes, dist_cache, entry.insert_len, B.tmp_cmds, slab, &n_lits, &pending, &last_dist_code, &last_copy_len);
       }
@@ -1050,7 +1140,7 @@ ZDEV uint32_t br_zopfli_block(const ZopfliParams& P, const ZopfliTables& T, cons
   x.insert_len = pending;
   x.n_cmds = n_cmds;
   x.n_lits = n_lits;
-  x.ext_len = ext_len;
+  x.ext_len = ctl->ext_len;
   x.dict_lookups = x.dict_matches = 0;
   x.last_dist_code = last_dist_code;
   x.bad_commands = status;  // (where the reference panics the product refuses, like for the copies it cannot encode)

@@ -757,7 +757,8 @@ void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const Zopfli
   h.invalid_pos = 0u - h.window_mask;
   for (uint32_t i = 0; i + (kZMaxTreeCompLength - 1) < dict_bytes; ++i) z_h10_store(h, Z, B.text, i);
 }
-void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
+bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
+  static const bool sequential_only = getenv("BROTLI_MI355X_ZOPFLI_SEQUENTIAL") != nullptr;
   const DeviceTables& dt = dev_tables();
   ZopfliTables T;
   T.lut_buckets = dt.dict_lut_buckets;
@@ -767,8 +768,30 @@ void lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJo
   T.dict_size_bits_by_length = dt.dict_size_bits_by_length;
   T.logs.logs_16 = dt.logs_16;
   T.logs.logs_8 = dt.logs_8;
+  const ZopfliParams Z = emu_zopfli_params(P, J);
+  const ZopfliBuffers ZB = emu_zopfli_buffers(J);
   const Segment seg = B.segments[block];
-  br_zopfli_block(emu_zopfli_params(P, J), T, emu_zopfli_buffers(J), B.text, seg, B.entries[block], B.cmds + seg.cmd_base, B.exits + block);
+  ZBlockCtl* ctl = (ZBlockCtl*)J.ctl;
+  const size_t forest_bytes = ((size_t)2 << J.lgwin) * 4, bucket_bytes = ((size_t)1 << kZBucketBits) * 4;
+  br_zopfli_begin(Z, ZB, B.text, seg, B.entries[block], ctl);
+  bool redo = sequential_only;
+  if (!sequential_only) {
+    memcpy(J.forest_bak, J.forest, forest_bytes);
+    memcpy(J.buckets_bak, J.buckets, bucket_bytes);
+    // (the groups in an order of their own: what one of them leaves in the node arrays must not matter to another)
+    for (uint32_t n = 0; n < 65536; ++n) {
+      const uint32_t g = (n * 40503u + 12345u) & 0xffffu;
+      if (B.key_first[g] < B.key_last[g]) br_zopfli_matches_of_group(Z, T, ZB, J.forest_new, J.rerooted, B.text, B.by_key, B.key_first[g], B.key_last[g], ctl);
+    }
+    for (uint32_t i = 0; i < J.block_bytes; ++i) br_zopfli_merge_node(Z, ZB, J.forest_new, J.rerooted, ctl, i);
+    redo = br_zopfli_parse(Z, T, ZB, B.text, seg, B.entries[block], ctl, true, B.cmds + seg.cmd_base, B.exits + block) == kZopfliRedo;
+    if (redo) {
+      memcpy(J.forest, J.forest_bak, forest_bytes);
+      memcpy(J.buckets, J.buckets_bak, bucket_bytes);
+    }
+  }
+  if (redo) br_zopfli_parse(Z, T, ZB, B.text, seg, B.entries[block], ctl, false, B.cmds + seg.cmd_base, B.exits + block);
+  return redo;
 }
 
 }  // namespace brotli_mi355x
