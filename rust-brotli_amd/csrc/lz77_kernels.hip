@@ -2357,13 +2357,24 @@ __global__ __launch_bounds__(256) void k_zopfli_merge(ZopfliParams Z, ZopfliBuff
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < block_bytes) br_zopfli_merge_node(Z, ZB, forest_new, rerooted, ctl, i);
 }
-// (first device slice of the parse itself: one lane per stream, see the header of zopfli_device.h)
+// The parse itself: one wavefront per stream.  All lanes run the (sequential) dynamic programme with identical scalar state; the
+// lanes differ where a position's candidates and the lengths of a copy are spread over them (z_update_nodes).
 __global__ __launch_bounds__(64) void k_zopfli_parse(ZopfliParams Z, ZopfliTables T, ZopfliBuffers ZB, const uint8_t* __restrict__ text,
                                                      const Segment* __restrict__ segments, const SegEntry* __restrict__ entries, Command* __restrict__ cmds,
                                                      SegExit* __restrict__ exits, uint32_t block, ZBlockCtl* ctl, uint32_t precomputed) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0) return;
+  __shared__ ZNode window[kZWin];   // (ZNodeView)
+  __shared__ float lc_window[kZWin];
+  __shared__ float cost_cmd[704], cost_dist[1200];  // (ZCostModel: every length of every candidate looks one of each up)
+  __shared__ ZQueue queue;          // (indexed dynamically: in registers it would live in scratch memory)
+  ZFast fast;
+  fast.window = window;
+  fast.lc_window = lc_window;
+  fast.cost_cmd = cost_cmd;
+  fast.cost_dist = Z.dist_alphabet_size <= 1136 ? cost_dist : (float*)nullptr;
+  fast.queue = &queue;
   const Segment seg = segments[block];
-  ctl->pad[0] = br_zopfli_parse(Z, T, ZB, text, seg, entries[block], ctl, precomputed != 0, cmds + seg.cmd_base, exits + block);
+  ctl->pad[0] = br_zopfli_parse(Z, T, ZB, text, seg, entries[block], ctl, precomputed != 0, cmds + seg.cmd_base, exits + block, fast);
 }
 bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
   static const bool sequential_only = getenv("BROTLI_MI355X_ZOPFLI_SEQUENTIAL") != nullptr;
@@ -2396,6 +2407,12 @@ bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJo
     hipLaunchKernelGGL(k_zopfli_parse, dim3(1), dim3(64), 0, BR_STREAM, Z, T, ZB, (const uint8_t*)B.text, (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds,
                        B.exits, block, ctl, 0u);
   HIP_CHECK(hipGetLastError());
+  if (getenv("BROTLI_MI355X_DEBUG")) {  // (s_memtime counts at 100 MHz on gfx950)
+    ZBlockCtl host;
+    dev_d2h(&host, ctl, sizeof(host));
+    fprintf(stderr, "zopfli block %u (%s): cost model %.1f ms, programme %.1f ms, commands %.1f ms, sequential matching %.1f ms\n", block, redo ? "sequential" : "matches side by side",
+            host.ticks[0] / 1e5, host.ticks[1] / 1e5, host.ticks[2] / 1e5, host.ticks[3] / 1e5);
+  }
   return redo;
 }
 

@@ -30,9 +30,11 @@
 namespace brotli_mi355x {
 
 #if defined(BROTLI_HOST_EMU)
+#define ZTICK() 0ull
 #define ZDEV inline
 #define ZCONST static const
 #else
+#define ZTICK() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #define ZDEV __device__
 #define ZCONST __device__ const
 #endif
@@ -114,6 +116,44 @@ ZDEV uint32_t z_distance_code(const ZNode& n) {
   const uint32_t short_code = n.dcode_insert_length >> 27;
   return short_code == 0 ? n.distance + 16u - 1u : short_code - 1u;
 }
+
+// The nodes as the dynamic programme sees them: the array in device memory, and on the device a window of it in workgroup
+// memory (the programme reads a few dozen node fields per position, one dependent round trip to memory each otherwise).
+// Writes go to both, reads inside the window come from it; the window follows the position (keep()).
+static constexpr uint32_t kZWin = 4096, kZWinBack = 1024, kZWinMinAhead = 1024;
+struct ZNodeView {
+  ZNode* g;
+  ZNode* w;     // [kZWin], nullptr: no window (host emulation)
+  uint32_t lo;  // the window holds the nodes [lo, lo + kZWin)
+  const float* lc_g;  // the prefix sums of the literal costs (ZCostModel::literal_costs) ride along: read at the position and at
+  float* lc_w;        // the start positions in the queue, a little way back
+  ZDEV float lc(uint32_t i) const {
+    const uint32_t o = i - lo;
+    return (lc_w != nullptr && o < kZWin) ? lc_w[o] : lc_g[i];
+  }
+  ZDEV ZNode get(uint32_t i) const {
+    const uint32_t o = i - lo;
+    return (w != nullptr && o < kZWin) ? w[o] : g[i];
+  }
+  ZDEV void put(uint32_t i, const ZNode& n) {
+    g[i] = n;
+    const uint32_t o = i - lo;
+    if (w != nullptr && o < kZWin) w[o] = n;
+  }
+  // called with the position the programme is at (uniform): moves the window when less than kZWinMinAhead nodes of it lie ahead
+  ZDEV void keep(uint32_t pos, uint32_t count) {
+    if (w == nullptr) return;
+    if (pos >= lo && lo + kZWin - pos >= kZWinMinAhead) return;
+    BR_SYNC();  // (everything written so far has reached the array)
+    lo = pos > kZWinBack ? pos - kZWinBack : 0u;
+    for (uint32_t o = (uint32_t)BR_LANE; o < kZWin; o += BR_NLANES)
+      if (lo + o < count) {
+        w[o] = g[lo + o];
+        if (lc_w) lc_w[o] = lc_g[lo + o];
+      }
+    BR_SYNC();
+  }
+};
 
 // FindMatchLengthWithLimit, static_dict.rs:125-132
 ZDEV uint32_t z_match_len(const uint8_t* a, const uint8_t* b, uint32_t limit) {
@@ -562,6 +602,8 @@ struct ZCostModel {
   uint32_t num_bytes;
 };
 ZDEV float z_literal_cost_between(const ZCostModel& m, uint32_t from, uint32_t to) { return m.literal_costs[to] - m.literal_costs[from]; }
+struct ZNodeView;
+ZDEV float z_literal_cost_between(const ZNodeView& v, uint32_t from, uint32_t to);
 // set_from_literal_costs, hq.rs:199-240 (the running sum carries its rounding error along, Kahan style, in this order)
 ZDEV void z_model_from_literal_costs(ZCostModel& m, const ZopfliTables& T, const uint8_t* data, uint32_t* histo) {
   float* lc = m.literal_costs;
@@ -639,6 +681,8 @@ ZDEV bool z_model_from_commands(ZCostModel& m, const ZopfliTables& T, const uint
   return ok;
 }
 
+ZDEV float z_literal_cost_between(const ZNodeView& v, uint32_t from, uint32_t to) { return v.lc(to) - v.lc(from); }
+
 // ---- StartPosQueue, EvaluateNode, UpdateNodes (hq.rs:414-855) ------------------------------------------------------------------
 struct ZPosData {
   uint32_t pos;
@@ -668,47 +712,51 @@ ZDEV void z_queue_push(ZQueue& q, const ZPosData& d) {  // keeps the entries ord
 ZDEV const ZPosData& z_queue_at(const ZQueue& q, uint32_t k) { return q.q[(k - q.idx) & 7u]; }
 
 // ComputeDistanceShortcut, hq.rs:427-452
-ZDEV uint32_t z_distance_shortcut(uint32_t block_start, uint32_t pos, uint32_t max_backward, const ZNode* nodes) {
-  const uint32_t clen = z_copy_length(nodes[pos]);
-  const uint32_t ilen = z_insert_length(nodes[pos]);
-  const uint32_t dist = nodes[pos].distance;
+ZDEV uint32_t z_distance_shortcut(uint32_t block_start, uint32_t pos, uint32_t max_backward, const ZNodeView& nodes) {
+  const ZNode n = nodes.get(pos);
+  const uint32_t clen = z_copy_length(n);
+  const uint32_t ilen = z_insert_length(n);
+  const uint32_t dist = n.distance;
   if (pos == 0) return 0;
-  if ((uint64_t)dist + clen <= (uint64_t)block_start + pos && dist <= max_backward && z_distance_code(nodes[pos]) > 0) return pos;
-  return z_node_shortcut(nodes[pos - clen - ilen]);
+  if ((uint64_t)dist + clen <= (uint64_t)block_start + pos && dist <= max_backward && z_distance_code(n) > 0) return pos;
+  return z_node_shortcut(nodes.get(pos - clen - ilen));
 }
 // ComputeDistanceCache, hq.rs:461-499
-ZDEV void z_distance_cache_at(uint32_t pos, const int32_t* starting, const ZNode* nodes, int32_t* out) {
+ZDEV void z_distance_cache_at(uint32_t pos, const int32_t* starting, const ZNodeView& nodes, int32_t* out) {
   int idx = 0;
-  uint32_t p = z_node_shortcut(nodes[pos]);
+  uint32_t p = z_node_shortcut(nodes.get(pos));
   while (idx < 4 && p > 0) {
-    const uint32_t ilen = z_insert_length(nodes[p]);
-    const uint32_t clen = z_copy_length(nodes[p]);
-    out[idx++] = (int32_t)nodes[p].distance;
-    p = z_node_shortcut(nodes[p - clen - ilen]);
+    const ZNode n = nodes.get(p);
+    const uint32_t ilen = z_insert_length(n);
+    const uint32_t clen = z_copy_length(n);
+    out[idx++] = (int32_t)n.distance;
+    p = z_node_shortcut(nodes.get(p - clen - ilen));
   }
   for (; idx < 4; ++idx) out[idx] = *starting++;
 }
 // EvaluateNode, hq.rs:524-560
 ZDEV void z_evaluate_node(uint32_t block_start, uint32_t pos, uint32_t max_backward_limit, const int32_t* starting_dist_cache,
-                          const ZCostModel& model, ZQueue& queue, ZNode* nodes) {
-  const float cost = z_node_cost(nodes[pos]);
+                          const ZCostModel& model, ZQueue& queue, ZNodeView& nodes) {
+  ZNode here = nodes.get(pos);
+  const float cost = z_node_cost(here);
   const uint32_t shortcut = z_distance_shortcut(block_start, pos, max_backward_limit, nodes);
-  nodes[pos].tag = 2;
-  nodes[pos].u = shortcut;
-  if (cost <= z_literal_cost_between(model, 0, pos)) {
+  here.tag = 2;
+  here.u = shortcut;
+  nodes.put(pos, here);
+  if (cost <= z_literal_cost_between(nodes, 0, pos)) {
     ZPosData d;
     d.pos = pos;
     d.cost = cost;
-    d.costdiff = cost - z_literal_cost_between(model, 0, pos);
+    d.costdiff = cost - z_literal_cost_between(nodes, 0, pos);
     z_distance_cache_at(pos, starting_dist_cache, nodes, d.distance_cache);
     z_queue_push(queue, d);
   }
 }
 // ComputeMinimumCopyLength, hq.rs:577-602
-ZDEV uint32_t z_minimum_copy_length(float start_cost, const ZNode* nodes, uint32_t num_bytes, uint32_t pos) {
+ZDEV uint32_t z_minimum_copy_length(float start_cost, const ZNodeView& nodes, uint32_t num_bytes, uint32_t pos) {
   float min_cost = start_cost;
   uint32_t len = 2, next_len_bucket = 4, next_len_offset = 10;
-  while (pos + len <= num_bytes && z_node_cost(nodes[pos + len]) <= min_cost) {
+  while (pos + len <= num_bytes && z_node_cost(nodes.get(pos + len)) <= min_cost) {
     ++len;
     if (len == next_len_offset) {
       min_cost += 1.0f;
@@ -734,18 +782,19 @@ ZDEV uint32_t z_distance_symbol(uint32_t distance_code, uint32_t ndirect, uint32
   const uint64_t nbits = bucket - npostfix;
   return (uint32_t)((nbits << 10) | (16 + ndirect + ((2 * (nbits - 1) + prefix) << npostfix) + postfix));
 }
-ZDEV void z_update_node(ZNode* nodes, uint32_t pos, uint32_t start_pos, uint32_t len, uint32_t len_code, uint32_t dist, uint32_t short_code, float cost) {
-  ZNode& next = nodes[pos + len];
+ZDEV void z_update_node(ZNodeView& nodes, uint32_t pos, uint32_t start_pos, uint32_t len, uint32_t len_code, uint32_t dist, uint32_t short_code, float cost) {
+  ZNode next;
   next.length = len | ((len + 9u - len_code) << 25);
   next.distance = dist;
   next.dcode_insert_length = (pos - start_pos) | (short_code << 27);
   z_set_cost(next, cost);
+  nodes.put(pos + len, next);
 }
 // UpdateNodes, hq.rs:644-829: the paths that reach `pos` are extended by every copy that starts there -- the 16 distance-cache
 // codes of up to five start positions, then the matches of the position for the two best of them
 ZDEV uint32_t z_update_nodes(const ZopfliParams& P, const uint8_t* text, uint32_t num_bytes, uint32_t block_start, uint32_t pos,
                              const int32_t* starting_dist_cache, uint32_t num_matches, const unsigned long long* matches, const ZCostModel& model,
-                             ZQueue& queue, ZNode* nodes) {
+                             ZQueue& queue, ZNodeView& nodes) {
   const uint32_t cur_ix = block_start + pos;
   const uint32_t max_distance = cur_ix < P.max_backward_limit ? cur_ix : P.max_backward_limit;
   const uint32_t max_len = num_bytes - pos;
@@ -755,18 +804,48 @@ ZDEV uint32_t z_update_nodes(const ZopfliParams& P, const uint8_t* text, uint32_
   uint32_t min_len;
   {
     const ZPosData& d = z_queue_at(queue, 0);
-    const float min_cost = d.cost + model.min_cost_cmd + z_literal_cost_between(model, d.pos, pos);
+    const float min_cost = d.cost + model.min_cost_cmd + z_literal_cost_between(nodes, d.pos, pos);
     min_len = z_minimum_copy_length(min_cost, nodes, num_bytes, pos);
   }
   const uint32_t max_candidates = P.quality <= 10 ? 1u : 5u;
   const uint32_t kmax = max_candidates < z_queue_size(queue) ? max_candidates : z_queue_size(queue);
+#if !BR_SCALAR
+  // The wave's turn (the whole wave runs this function with identical scalar state).  First the match lengths of ALL distance-
+  // cache candidates of the position -- sixteen codes for each of the (up to five) start positions -- in two goes: lanes
+  // 16 * k + j for the first four start positions, lanes j for the fifth.  One wait for the text instead of one per start position.
+  uint32_t cand_len[2] = {0, 0}, cand_back[2] = {0, 0};
+  {
+    const uint32_t lane = (uint32_t)BR_LANE;
+    for (uint32_t go = 0; go < 2; ++go) {
+      const uint32_t k = go == 0 ? lane >> 4 : 4u;
+      const uint32_t j = lane & 15u;
+      if (k < kmax && (go == 0 || lane < 16)) {
+        const ZPosData& dk = z_queue_at(queue, k);
+        const uint32_t idx = j < 4 ? j : (j < 10 ? 0u : 1u);
+        const int32_t off = j < 4 ? 0 : (int32_t)(((j - 4) % 6) / 2 + 1) * (((j - 4) & 1) ? 1 : -1);
+        const uint64_t backward = (uint64_t)(int64_t)(dk.distance_cache[idx] + off);
+        const uint64_t prev64 = (uint64_t)cur_ix - backward;
+        if (backward <= max_distance && prev64 < cur_ix) {
+          const uint32_t prev_ix = (uint32_t)prev64;
+          cand_len[go] = z_fix_unbroken(z_match_len(text + prev_ix, text + cur_ix, max_len), prev_ix & P.ring_mask, P.dict_break);
+          cand_back[go] = (uint32_t)backward;
+        }
+      }
+      if (kmax <= 4) break;
+    }
+  }
+  // ... and the matches of the position, one per lane
+  unsigned long long my_match = 0;
+  if ((uint32_t)BR_LANE < num_matches) my_match = matches[BR_LANE];
+#endif
   for (uint32_t k = 0; k < kmax; ++k) {
     const ZPosData& d = z_queue_at(queue, k);
     const uint32_t start = d.pos;
     const uint32_t inscode = br_insert_length_code(pos - start);
     const float start_costdiff = d.costdiff;
-    const float base_cost = start_costdiff + (float)z_ins_extra(inscode) + z_literal_cost_between(model, 0, pos);
+    const float base_cost = start_costdiff + (float)z_ins_extra(inscode) + z_literal_cost_between(nodes, 0, pos);
     uint32_t best_len = min_len - 1;
+#if BR_SCALAR
     for (uint32_t j = 0; j < 16; ++j) {
       if (best_len >= max_len) break;
       // kDistanceCacheIndex / kDistanceCacheOffset (mod.rs:653-655)
@@ -784,33 +863,104 @@ ZDEV uint32_t z_update_nodes(const ZopfliParams& P, const uint8_t* text, uint32_
         const uint32_t copycode = br_copy_length_code(l);
         const uint32_t cmdcode = br_combine_length_codes(inscode, copycode, j == 0);
         const float cost = (cmdcode < 128 ? base_cost : dist_cost) + (float)z_copy_extra(copycode) + model.cost_cmd[cmdcode];
-        if (cost < z_node_cost(nodes[pos + l])) {
+        if (cost < z_node_cost(nodes.get(pos + l))) {
           z_update_node(nodes, pos, start, l, l, (uint32_t)backward, j + 1, cost);
           result = result > l ? result : l;
         }
         best_len = l;
       }
     }
+#else
+    {
+      // candidate by candidate in the reference's order (only those that reach beyond min_len - 1 at all), the lengths it adds
+      // beyond best_len on as many lanes -- different lengths are different nodes.  (The reference's look at the byte behind
+      // best_len only saves it a comparison: a candidate that fails it has no length beyond best_len to offer.)
+      const uint32_t lane = (uint32_t)BR_LANE;
+      const uint32_t my_len = k < 4 ? cand_len[0] : cand_len[1], my_backward = k < 4 ? cand_back[0] : cand_back[1];
+      const uint32_t group = k < 4 ? 16u * k : 0u;  // first lane of this start position's candidates
+      unsigned long long todo = (__ballot(my_len > best_len) >> group) & 0xffffull;
+      while (todo != 0) {
+        if (best_len >= max_len) break;
+        const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+        todo &= todo - 1ull;
+        const uint32_t len = (uint32_t)__shfl((int)my_len, (int)(group + j), 64);
+        if (len <= best_len) continue;
+        const uint32_t backward = (uint32_t)__shfl((int)my_backward, (int)(group + j), 64);
+        const float dist_cost = base_cost + model.cost_dist[j];
+        for (uint32_t first = best_len + 1; first <= len; first += 64) {
+          const uint32_t l = first + lane;
+          bool updated = false;
+          if (l <= len) {
+            const uint32_t copycode = br_copy_length_code(l);
+            const uint32_t cmdcode = br_combine_length_codes(inscode, copycode, j == 0);
+            const float cost = (cmdcode < 128 ? base_cost : dist_cost) + (float)z_copy_extra(copycode) + model.cost_cmd[cmdcode];
+            if (cost < z_node_cost(nodes.get(pos + l))) {
+              z_update_node(nodes, pos, start, l, l, backward, j + 1, cost);
+              updated = true;
+            }
+          }
+          const unsigned long long um = __ballot(updated);
+          if (um != 0) {
+            const uint32_t top = first + 63u - (uint32_t)__builtin_clzll(um);
+            result = result > top ? result : top;
+          }
+        }
+        best_len = len;
+      }
+      BR_SYNC();  // (the nodes written by single lanes are read by the others from here on)
+    }
+#endif
     if (k >= 2) continue;
     uint32_t len = min_len;
     for (uint32_t j = 0; j < num_matches; ++j) {
+#if BR_SCALAR
       const unsigned long long match = matches[j];
+#else
+      const unsigned long long match = j < 64 ? (unsigned long long)__shfl((long long)my_match, (int)j, 64) : matches[j];
+#endif
       const uint32_t dist = z_match_distance(match);
       const bool is_dictionary_match = dist > max_distance;
       const uint32_t dist_symbol = z_distance_symbol(dist + 16 - 1, P.ndirect, P.npostfix);
       const float dist_cost = base_cost + (float)(dist_symbol >> 10) + model.cost_dist[dist_symbol & 0x03ffu];
       const uint32_t max_match_len = z_match_length(match);
       if (len < max_match_len && (is_dictionary_match || max_match_len > max_zlen)) len = max_match_len;
+#if BR_SCALAR
       for (; len <= max_match_len; ++len) {
         const uint32_t len_code = is_dictionary_match ? z_match_length_code(match) : len;
         const uint32_t copycode = br_copy_length_code(len_code);
         const uint32_t cmdcode = br_combine_length_codes(inscode, copycode, false);
         const float cost = dist_cost + (float)z_copy_extra(copycode) + model.cost_cmd[cmdcode];
-        if (nodes[pos + len].tag == 0 && cost < z_from_bits(nodes[pos + len].u)) {
+        const ZNode there = nodes.get(pos + len);
+        if (there.tag == 0 && cost < z_from_bits(there.u)) {
           z_update_node(nodes, pos, start, len, len_code, dist, 0, cost);
           result = result > len ? result : len;
         }
       }
+#else
+      // the lengths len .. max_match_len of this match, one per lane
+      for (uint32_t first = len; first <= max_match_len; first += 64) {
+        const uint32_t l = first + (uint32_t)BR_LANE;
+        bool updated = false;
+        if (l <= max_match_len) {
+          const uint32_t len_code = is_dictionary_match ? z_match_length_code(match) : l;
+          const uint32_t copycode = br_copy_length_code(len_code);
+          const uint32_t cmdcode = br_combine_length_codes(inscode, copycode, false);
+          const float cost = dist_cost + (float)z_copy_extra(copycode) + model.cost_cmd[cmdcode];
+          const ZNode there = nodes.get(pos + l);
+          if (there.tag == 0 && cost < z_from_bits(there.u)) {
+            z_update_node(nodes, pos, start, l, len_code, dist, 0, cost);
+            updated = true;
+          }
+        }
+        const unsigned long long um = __ballot(updated);
+        if (um != 0) {
+          const uint32_t top = first + 63u - (uint32_t)__builtin_clzll(um);
+          result = result > top ? result : top;
+        }
+      }
+      if (len <= max_match_len) len = max_match_len + 1;
+      BR_SYNC();
+#endif
     }
   }
   return result;
@@ -830,13 +980,14 @@ ZDEV uint32_t z_shortest_path_from_nodes(uint32_t num_bytes, ZNode* nodes) {
   }
   return num_commands;
 }
-ZDEV void z_init_nodes(ZNode* nodes, uint32_t count) {
-  for (uint32_t i = 0; i < count; ++i) {
+ZDEV void z_init_nodes(ZNode* nodes, uint32_t count) {  // (spread over the lanes of the wave)
+  for (uint32_t i = (uint32_t)BR_LANE; i < count; i += BR_NLANES) {
     nodes[i].length = 1;
     nodes[i].distance = 0;
     nodes[i].dcode_insert_length = 0;
     z_set_cost(nodes[i], kZInfinity);
   }
+  BR_SYNC();
 }
 // BrotliZopfliCreateCommands, hq.rs:97-148.  The commands come out complete (prefix codes included): the cost model of the
 // second quality-11 pass reads them.  Returns the number of commands; *pending = bytes behind the last copy.
@@ -877,14 +1028,33 @@ ZDEV uint32_t z_create_commands(const ZopfliParams& P, uint32_t num_bytes, uint3
   return count;
 }
 
+// workgroup memory of the parse kernel (all null in the host emulation)
+struct ZFast {
+  ZNode* window = nullptr;      // [kZWin]
+  float* lc_window = nullptr;   // [kZWin]
+  float* cost_cmd = nullptr;    // [704]
+  float* cost_dist = nullptr;   // [>= distance alphabet]
+  struct ZQueue* queue = nullptr;
+};
+
 // ---- one input block -------------------------------------------------------------------------------------------------------------
 // BrotliZopfliComputeShortestPath, hq.rs:873-988 (quality 10): matches and node updates position by position
 ZDEV void z_shortest_path_q10(const ZH10& h, const ZopfliParams& P, const ZopfliTables& T, const ZopfliBuffers& B, const uint8_t* text,
-                              uint32_t num_bytes, uint32_t position, const int32_t* dist_cache) {
-  ZNode* nodes = B.nodes;
+                              uint32_t num_bytes, uint32_t position, const int32_t* dist_cache, const ZFast& fast) {
+  ZNodeView nodes;
+  nodes.g = B.nodes;
+  nodes.w = fast.window;
+  nodes.lo = 0;
+  nodes.lc_g = B.literal_costs;
+  nodes.lc_w = fast.lc_window;
   const uint32_t store_end = num_bytes >= kZMaxTreeCompLength ? position + num_bytes - kZMaxTreeCompLength + 1 : position;
-  nodes[0].length = 0;
-  z_set_cost(nodes[0], 0.0f);
+  {
+    ZNode first = B.nodes[0];
+    first.length = 0;
+    z_set_cost(first, 0.0f);
+    B.nodes[0] = first;
+  }
+  BR_SYNC();
   ZCostModel model;
   model.cost_cmd = B.cost_cmd;
   model.cost_dist = B.cost_dist;
@@ -892,7 +1062,11 @@ ZDEV void z_shortest_path_q10(const ZH10& h, const ZopfliParams& P, const Zopfli
   model.distance_histogram_size = P.dist_alphabet_size < 544 ? P.dist_alphabet_size : 544;
   model.num_bytes = num_bytes;
   z_model_from_literal_costs(model, T, text + position, B.histo);
-  ZQueue queue;
+  BR_SYNC();
+  nodes.lo = 0xffffffffu;  // (nothing in the window yet)
+  nodes.keep(0, num_bytes + 1);
+  ZQueue local_queue;
+  ZQueue& queue = fast.queue ? *fast.queue : local_queue;
   queue.idx = 0;
   for (uint32_t k = 0; k < 8; ++k) {
     queue.q[k].pos = 0;
@@ -901,6 +1075,7 @@ ZDEV void z_shortest_path_q10(const ZH10& h, const ZopfliParams& P, const Zopfli
   }
   unsigned long long* matches = B.matches;
   for (uint32_t i = 0; i + 3 < num_bytes; ++i) {
+    nodes.keep(i, num_bytes + 1);
     const uint32_t pos = position + i;
     const uint32_t max_distance = pos < P.max_backward_limit ? pos : P.max_backward_limit;
     uint32_t num_matches = z_find_all_matches(h, P, T, text, pos, num_bytes - i, max_distance, matches);
@@ -918,11 +1093,13 @@ ZDEV void z_shortest_path_q10(const ZH10& h, const ZopfliParams& P, const Zopfli
       while (skip != 0) {
         ++i;
         if (i + 3 >= num_bytes) break;
+        nodes.keep(i, num_bytes + 1);
         z_evaluate_node(position, i, P.max_backward_limit, dist_cache, model, queue, nodes);
         --skip;
       }
     }
   }
+  BR_SYNC();
 }
 // ZopfliIterate, hq.rs:1162-1244: the node updates over matches collected beforehand.  Quality 11 as the reference runs it
 // (matches packed one behind the other, stride 0); with stride = 128 the matches of position i sit at matches + 128 * i
@@ -930,12 +1107,24 @@ ZDEV void z_shortest_path_q10(const ZH10& h, const ZopfliParams& P, const Zopfli
 // (BrotliZopfliComputeShortestPath, hq.rs:873-988): the same sequence of UpdateNodes calls as long as no position is skipped;
 // returns false where one would be (a copy beyond the quick step: the reference stores the skipped positions differently).
 ZDEV bool z_iterate(const ZopfliParams& P, const ZopfliBuffers& B, const uint8_t* text, uint32_t num_bytes, uint32_t position,
-                    const int32_t* dist_cache, const ZCostModel& model, uint32_t stride) {
-  ZNode* nodes = B.nodes;
+                    const int32_t* dist_cache, const ZCostModel& model, uint32_t stride, const ZFast& fast) {
+  ZNodeView nodes;
+  nodes.g = B.nodes;
+  nodes.w = fast.window;
+  nodes.lo = 0xffffffffu;  // (nothing in the window yet)
+  nodes.lc_g = model.literal_costs;
+  nodes.lc_w = fast.lc_window;
   const uint32_t max_zlen = P.quality <= 10 ? 150u : 325u;
-  nodes[0].length = 0;
-  z_set_cost(nodes[0], 0.0f);
-  ZQueue queue;
+  {
+    ZNode first = B.nodes[0];
+    first.length = 0;
+    z_set_cost(first, 0.0f);
+    B.nodes[0] = first;
+  }
+  BR_SYNC();
+  nodes.keep(0, num_bytes + 1);
+  ZQueue local_queue;
+  ZQueue& queue = fast.queue ? *fast.queue : local_queue;
   queue.idx = 0;
   for (uint32_t k = 0; k < 8; ++k) {
     queue.q[k].pos = 0;
@@ -944,6 +1133,7 @@ ZDEV bool z_iterate(const ZopfliParams& P, const ZopfliBuffers& B, const uint8_t
   }
   size_t cur_match_pos = 0;
   for (uint32_t i = 0; i + 3 < num_bytes; ++i) {
+    nodes.keep(i, num_bytes + 1);
     const unsigned long long* m = stride ? B.matches + (size_t)stride * i : B.matches + cur_match_pos;
     const uint32_t nm = B.num_matches[i];
     uint32_t skip = z_update_nodes(P, text, num_bytes, position, i, dist_cache, nm, m, model, queue, nodes);
@@ -951,17 +1141,22 @@ ZDEV bool z_iterate(const ZopfliParams& P, const ZopfliBuffers& B, const uint8_t
     cur_match_pos += nm;
     if (nm == 1 && z_match_length(m[0]) > max_zlen) skip = z_match_length(m[0]) > skip ? z_match_length(m[0]) : skip;
     if (skip > 1) {
-      if (P.quality <= 10) return false;
+      if (P.quality <= 10) {
+        BR_SYNC();
+        return false;
+      }
       --skip;
       while (skip != 0) {
         ++i;
         if (i + 3 >= num_bytes) break;
+        nodes.keep(i, num_bytes + 1);
         z_evaluate_node(position, i, P.max_backward_limit, dist_cache, model, queue, nodes);
         cur_match_pos += B.num_matches[i];
         --skip;
       }
     }
   }
+  BR_SYNC();
   return true;
 }
 
@@ -973,6 +1168,7 @@ struct ZBlockCtl {
   uint32_t ext_len;
   uint32_t event;                // some position found a match beyond the Zopfli length: the reference skips positions there
   uint32_t pad[4];
+  unsigned long long ticks[4];   // cycles of the parse kernel by phase (BROTLI_MI355X_DEBUG): cost model, programme, commands, matches (sequential)
 };
 ZDEV ZH10 z_hasher_of(const ZopfliParams& P, const ZopfliBuffers& B) {
   ZH10 h;
@@ -1059,8 +1255,12 @@ ZDEV void br_zopfli_merge_node(const ZopfliParams& P, const ZopfliBuffers& B, co
 // the block is walked the reference's way, matching and tree updates position by position.  Returns kZopfliRedo when the
 // precomputed matches do not hold (nothing has been written then; the caller restores the trees and comes again).
 ZDEV uint32_t br_zopfli_parse(const ZopfliParams& P, const ZopfliTables& T, const ZopfliBuffers& B, const uint8_t* text, const Segment& seg,
-                              const SegEntry& entry, const ZBlockCtl* ctl, bool precomputed, Command* slab, SegExit* exit_out) {
+                              const SegEntry& entry, ZBlockCtl* ctl, bool precomputed, Command* slab, SegExit* exit_out, const ZFast& fast = ZFast()) {
   const ZH10 h = z_hasher_of(P, B);
+  ZopfliBuffers Bf = B;  // (the cost tables of the model in workgroup memory where there is some)
+  if (fast.cost_cmd) Bf.cost_cmd = fast.cost_cmd;
+  if (fast.cost_dist) Bf.cost_dist = fast.cost_dist;
+  unsigned long long t_model = 0, t_dp = 0, t_cmd = 0, t_match = 0, t0;
   uint32_t status = kZopfliOk;
   const uint32_t position = ctl->position, num_bytes = ctl->num_bytes;
   if (precomputed && ctl->event) return kZopfliRedo;
@@ -1071,18 +1271,27 @@ ZDEV uint32_t br_zopfli_parse(const ZopfliParams& P, const ZopfliTables& T, cons
     if (P.quality <= 10) {
       z_init_nodes(B.nodes, num_bytes + 1);
       if (precomputed) {
-        ZCostModel model = z_model_of(P, B, num_bytes);
+        ZCostModel model = z_model_of(P, Bf, num_bytes);
+        t0 = ZTICK();
         z_model_from_literal_costs(model, T, text + position, B.histo);
+        t_model += ZTICK() - t0;
         for (uint32_t i = num_bytes >= 3 ? num_bytes - 3 : 0; i < num_bytes; ++i) B.num_matches[i] = 0;
-        if (!z_iterate(P, B, text, num_bytes, position, dist_cache, model, 128)) return kZopfliRedo;
+        t0 = ZTICK();
+        if (!z_iterate(P, B, text, num_bytes, position, dist_cache, model, 128, fast)) return kZopfliRedo;
+        t_dp += ZTICK() - t0;
       } else {
-        z_shortest_path_q10(h, P, T, B, text, num_bytes, position, dist_cache);
+        t0 = ZTICK();
+        z_shortest_path_q10(h, P, T, Bf, text, num_bytes, position, dist_cache, fast);
+        t_dp += ZTICK() - t0;
       }
+      t0 = ZTICK();
       z_shortest_path_from_nodes(num_bytes, B.nodes);
       n_cmds = z_create_commands(P, num_bytes, position, B.nodes, dist_cache, entry.insert_len, nullptr, slab, &n_lits, &pending, &last_dist_code, &last_copy_len);
+      t_cmd += ZTICK() - t0;
     } else {
       // BrotliCreateHqZopfliBackwardReferences, hq.rs:1246-1448: all matches first ...
       if (!precomputed) {
+        t0 = ZTICK();
         const uint32_t store_end = num_bytes >= kZMaxTreeCompLength ? position + num_bytes - kZMaxTreeCompLength + 1 : position;
         size_t cur_match_pos = 0;
         for (uint32_t i = 0; i < num_bytes; ++i) B.num_matches[i] = 0;
@@ -1110,25 +1319,32 @@ ZDEV uint32_t br_zopfli_parse(const ZopfliParams& P, const ZopfliTables& T, cons
             }
           }
         }
+        t_match += ZTICK() - t0;
       } else {
         for (uint32_t i = num_bytes >= 3 ? num_bytes - 3 : 0; i < num_bytes; ++i) B.num_matches[i] = 0;
       }
       // ... then two passes of the dynamic programme: literal-cost model, then the model of the first pass's commands
-      ZCostModel model = z_model_of(P, B, num_bytes);
+      ZCostModel model = z_model_of(P, Bf, num_bytes);
       int32_t orig_cache[4];
       for (int i = 0; i < 4; ++i) orig_cache[i] = dist_cache[i];
       for (uint32_t pass = 0; pass < 2; ++pass) {
         z_init_nodes(B.nodes, num_bytes + 1);
+        t0 = ZTICK();
         if (pass == 0) {
           z_model_from_literal_costs(model, T, text + position, B.histo);
         } else {
           if (!z_model_from_commands(model, T, text, position, B.tmp_cmds, n_cmds, entry.insert_len, B.histo)) status = kZopfliReferencePanics;
         }
+        t_model += ZTICK() - t0;
         for (int i = 0; i < 4; ++i) dist_cache[i] = orig_cache[i];
         n_lits = 0;
-        z_iterate(P, B, text, num_bytes, position, dist_cache, model, precomputed ? 128u : 0u);
+        t0 = ZTICK();
+        z_iterate(P, B, text, num_bytes, position, dist_cache, model, precomputed ? 128u : 0u, fast);
+        t_dp += ZTICK() - t0;
+        t0 = ZTICK();
         z_shortest_path_from_nodes(num_bytes, B.nodes);
         n_cmds = z_create_commands(P, num_bytes, position, B.nodes, dist_cache, entry.insert_len, B.tmp_cmds, slab, &n_lits, &pending, &last_dist_code, &last_copy_len);
+        t_cmd += ZTICK() - t0;
       }
     }
   }
@@ -1154,6 +1370,10 @@ ZDEV uint32_t br_zopfli_parse(const ZopfliParams& P, const ZopfliTables& T, cons
   x.n_pushes_all = 4;
   x.dict_entry_lookups = x.dict_entry_matches = 0;
   *exit_out = x;
+  ctl->ticks[0] = t_model;
+  ctl->ticks[1] = t_dp;
+  ctl->ticks[2] = t_cmd;
+  ctl->ticks[3] = t_match;
   return status;
 }
 
