@@ -210,6 +210,43 @@ def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
         res.append(entry)
         del data
     res.extend(quality_9_5_workloads(torch, bm, enc))
+    res.extend(quality_10_11_workloads(torch, bm, enc))
+    return res
+
+
+def quality_10_11_workloads(torch, bm, enc):
+    """qualities 10 and 11 proper (H10 trees + the Zopfli shortest-path parse on the device, zopfli_device.h) on the
+    input the reference holds its known answers for -- alice29, 47 488 / 46 493 bytes (src/bin/integration_tests.rs:401-449) -- and on
+    1 MiB of the text generator; each compared with the oracle run here (one core), whose rate stands beside it"""
+    import orc
+    import synth
+    res = []
+    for name, data in (("alice29", synth.alice()), ("text_1MiB", synth.markov_text(1 << 20))):
+        try:
+            dev = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        except Exception as e:
+            return res + [{"workload": "q10_11_" + name, "error": repr(e)}]
+        for quality in (10, 11):
+            params = [(bm.BROTLI_PARAM_QUALITY, quality), (bm.BROTLI_PARAM_LGWIN, 22), (bm.BROTLI_PARAM_SIZE_HINT, len(data))]
+            entry = {"workload": "q%d_%s" % (quality, name), "input_bytes": len(data), "quality": quality, "lgwin": 22,
+                     "residency": "input resident in HBM, output to host memory",
+                     "path": "first device slice: matches of a block side by side (one lane per group of hash keys), the shortest-path "
+                             "programme on one wavefront per stream (DESIGN.md section 3.9)"}
+            try:
+                sec, out = timed_steps(lambda: enc.encode(params, b"", dev.data_ptr(), len(data), True, copy=True), 1, 0, torch)
+                out = bytes(out)
+                t0 = time.time()
+                want, _ = orc.stream_compress(data, params)
+                cpu_s = time.time() - t0
+                entry.update({"value": round(len(data) / sec / 1e6, 3), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out),
+                              "identical_to_cpu_oracle": out == want,
+                              "cpu_oracle": {"value": round(len(data) / cpu_s / 1e6, 3), "unit": "MB/s", "cores": 1, "sample": "the same input, one run"}})
+                if name == "alice29":
+                    entry["reference_known_answer_bytes"] = {10: 47488, 11: 46493}[quality]
+            except Exception as e:
+                entry["error"] = repr(e)
+            res.append(entry)
+        del dev
     return res
 
 
