@@ -157,6 +157,32 @@ def parse_roofline(walked, searches, cmds, parse_ms, launches, row_bytes):
             "traffic": None, "traffic_source": "profiles/r03_<workload>.json holds the FETCH_SIZE / WRITE_SIZE passes of this workload"}
 
 
+def dominant_kernel_from_profile(name):
+    """what the newest rocprofv3 summary of this workload under profiles/ (tools/profile_workloads.sh) says about where its GPU time
+    goes -- quoted only if it was measured on the same library sources as this run (fingerprint), like the PMC figure of the headline"""
+    import glob as _glob
+    for path in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % name)), reverse=True):
+        try:
+            j = json.load(open(path))
+        except Exception:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if j.get("source_fingerprint") != source_fingerprint():
+            return {"kernel": None, "source": "null: %s was measured on other library sources" % rel}
+        kernels = j.get("kernels", {})
+        if not kernels:
+            return None
+        top = max(kernels.items(), key=lambda kv: kv[1].get("total_ms", 0.0))
+        traffic = None
+        c = j.get("hbm_counters_kib_raw", {}).get(top[0])
+        if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            calls = max(1, c["FETCH_SIZE"].get("launches", 1))
+            traffic = int((c["FETCH_SIZE"]["kib_total_both_calls"] + c["WRITE_SIZE"]["kib_total_both_calls"]) * 1024 / calls)
+        return {"kernel": top[0], "share_of_gpu_time_pct": top[1].get("pct"), "avg_launch_ms": top[1].get("avg_ms"), "launches_both_calls": top[1].get("calls"),
+                "traffic_bytes_per_launch": traffic, "source": "%s (rocprofv3 --kernel-trace --stats + FETCH_SIZE / WRITE_SIZE passes, same library sources as this run)" % rel}
+    return None
+
+
 def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
     """BASELINE configs[2], [4], zero fill, and configs[3] cut to 1 GiB, at their stated sizes on this one GPU"""
     import large_cases
@@ -201,6 +227,9 @@ def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
         entry.update({"value": round(len(data) / sec / 1e6, 1), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 2), "compressed_bytes": len(out),
                       "identical_to_cpu_oracle": hashlib.sha256(out).hexdigest() == frozen[name]["stream_sha256"],
                       "input_generated_in_s": round(gen_s, 1)})
+        dk = dominant_kernel_from_profile(name)
+        if dk:
+            entry["dominant_kernel"] = dk
         if frozen[name].get("oracle_seconds"):
             # the CPU column: the oracle's time for the same call when the hash was frozen (tools/freeze_large_hashes.py: -O3 build,
             # one core of the builder's container, 8 vCPU Xeon @ 2.1 GHz; multi-shard calls run their shards one after the other)

@@ -1,6 +1,8 @@
 """Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
-oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10)."""
+oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10).
+FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB, and no
+flushes in the middle of a stream (first device slice: one stream = one piece)."""
 import os, sys, time
 import synth, orc
 import test_cabi
@@ -25,8 +27,16 @@ for c in range(cases):
     q95 = bool(os.environ.get("FUZZ_Q9_5"))
     if q95:
         q = 11 if os.environ["FUZZ_Q9_5"] == "11" else 10  # (11: the 512-deep H5 / H6 rings)
+    zopfli = os.environ.get("FUZZ_ZOPFLI")
+    if zopfli:
+        q = int(zopfli)
+        if n > 300000:
+            n = 1 + n % 300000
+            d = pool[o:o + n]
     w = [17, 18, 20, 22, 24][rng.next() % 5]
     mode = rng.next() % 6
+    if zopfli and mode in (1, 2):
+        mode = [0, 3, 4, 5][rng.next() % 4]
     if q95 and mode == 5:
         mode = 4  # (orc.writer_compress takes quality and window only)
     base = [(Q, q), (W, w)] + ([(150, 1)] if q95 else [])

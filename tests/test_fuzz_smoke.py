@@ -36,6 +36,21 @@ def test_api_sweep_quality_9_5_emulation():
     assert " 0 failures" in _run("fuzz_api.py", 30, 9, "emu", FUZZ_Q9_5="1")
 
 
+def test_api_sweep_quality_10_11_emulation():
+    """the stream operations that do not cut a stream into pieces, the multi-shard entry and custom dictionaries at qualities 10 and 11
+    proper (row f1: H10 + Zopfli, zopfli_device.h)"""
+    import emu
+    emu.build()
+    assert " 0 failures" in _run("fuzz_api.py", 25, 12, "emu", FUZZ_ZOPFLI="10")
+    assert " 0 failures" in _run("fuzz_api.py", 25, 13, "emu", FUZZ_ZOPFLI="11")
+
+
+@pytest.mark.gpu
+def test_api_sweep_quality_10_11_device():
+    assert " 0 failures" in _run("fuzz_api.py", 8, 12, FUZZ_ZOPFLI="10", FUZZ_TINY="1")
+    assert " 0 failures" in _run("fuzz_api.py", 6, 14, FUZZ_ZOPFLI="11")
+
+
 @pytest.mark.gpu
 def test_api_sweep_quality_9_5_device():
     assert " 0 failures" in _run("fuzz_api.py", 40, 9, FUZZ_Q9_5="1")

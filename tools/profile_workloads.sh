@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE passes (one counter per run, nothing traced alongside) of `python tools/prof_workload.py <name>`.
 # Leaves gpurun_out/<tag>_<name>_kernel_stats.csv and gpurun_out/<tag>_<name>.json (library counters + per-kernel HBM traffic).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift
 NAMES=${@:-"c3_enwik_256MiB_q9 silesia_256MiB_q5 c5_xorshift_1GiB_q5"}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,7 +20,9 @@ for NAME in $NAMES; do
   python3 - "$OUT" "$TAG" "$NAME" <<'PY'
 import csv, glob, json, os, sys, collections
 out, tag, name = sys.argv[1:4]
-res = {"workload": name}
+sys.path.insert(0, os.path.dirname(out.rstrip("/")))
+import bench
+res = {"workload": name, "source_fingerprint": bench.source_fingerprint()}
 for line in open(os.path.join(out, "%s_%s_kt.log" % (tag, name))):
     if line.startswith("{"):
         res["library"] = json.loads(line)
