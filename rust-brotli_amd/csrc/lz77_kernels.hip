@@ -2325,11 +2325,7 @@ void lz77_zopfli_init(const ZopfliJob& J) {
 // (first device slice: one lane per stream, see the header of zopfli_device.h)
 __global__ __launch_bounds__(64) void k_zopfli_prepend(ZopfliParams Z, ZopfliBuffers ZB, const uint8_t* __restrict__ text, uint32_t dict_bytes) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  ZH10 h;
-  h.buckets = ZB.buckets;
-  h.forest = ZB.forest;
-  h.window_mask = (1u << Z.lgwin) - 1u;
-  h.invalid_pos = 0u - h.window_mask;
+  const ZH10 h = z_hasher_of(Z, ZB);
   const uint32_t overlap = kZMaxTreeCompLength - 1;  // StoreLookahead() - 1
   for (uint32_t i = 0; i + overlap < dict_bytes; ++i) z_h10_store(h, Z, text, i);
 }

@@ -750,11 +750,7 @@ void lz77_zopfli_init(const ZopfliJob& J) {
 }
 void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes) {
   const ZopfliParams Z = emu_zopfli_params(P, J);
-  ZH10 h;
-  h.buckets = J.buckets;
-  h.forest = J.forest;
-  h.window_mask = (1u << J.lgwin) - 1u;
-  h.invalid_pos = 0u - h.window_mask;
+  const ZH10 h = z_hasher_of(Z, emu_zopfli_buffers(J));
   for (uint32_t i = 0; i + (kZMaxTreeCompLength - 1) < dict_bytes; ++i) z_h10_store(h, Z, B.text, i);
 }
 bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t block) {
