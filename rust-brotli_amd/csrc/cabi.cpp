@@ -494,10 +494,10 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     if (s->metadata_draining) {
       if (*available_in != 0) return BROTLI_FALSE;  // (the reference insists on the rest of the same payload)
     } else {
-    if (!s->first_encode_seen) {
-      s->first_encode_seen = true;
-      if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
-    }
+    // (update_size_hint(0), encode.rs:2904: a hint that comes out 0 -- nothing received yet -- stays "unset" and is tried again
+    // at the next encode_data)
+    s->first_encode_seen = true;
+    if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
     const size_t n_meta = *available_in;
     if (!EncodeBuffered(s, false, true, n_meta)) return BROTLI_FALSE;
     s->output.insert(s->output.end(), *next_in, *next_in + n_meta);
@@ -519,7 +519,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     }
     // size_hint as update_size_hint would see it at the first encode_data (encode.rs:1604-1620, 2970):
     // everything received up to the end of the call in which the first input block fills up
-    if (!s->first_encode_seen && (s->total_in >= BlockSize(s->params) || op != BROTLI_OPERATION_PROCESS)) {
+    if ((!s->first_encode_seen || s->params.size_hint == 0) && (s->total_in >= BlockSize(s->params) || op != BROTLI_OPERATION_PROCESS)) {
       s->first_encode_seen = true;
       if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
     }

@@ -284,6 +284,10 @@ struct ZopfliJob {
 };
 // empties the hasher: buckets = invalid position, forest = 0 (InitializeH10, hash_to_binary_tree.rs:149-190)
 void lz77_zopfli_init(const ZopfliJob& J);
+// the trees of the piece in front (buckets_src / forest_src, as ZopfliJob's) become this job's: copied, and every position in them
+// moved down by `delta` -- the text of this piece starts `delta` bytes further into the stream (a multiple of the window size:
+// node slots stay what they were); positions in front of the new text lie beyond every window and become the invalid position
+void lz77_zopfli_import(const ZopfliJob& J, const uint32_t* buckets_src, const uint32_t* forest_src, uint32_t delta);
 // HasherPrependCustomDictionary (encode.rs:1163-1194): the positions [0, dict_bytes - 127) of the text go into the trees
 void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes);
 // input block `block` (= segment `block`: one segment per block) with the entry B.entries[block]: commands into its slab, exit into

@@ -263,7 +263,9 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   if (req.prefix_size && !continuing) p.use_dictionary = false;  // set_custom_dictionary, encode.rs:1213
   FinalizeParams(&p);
   if (continuing) {
-    p.size_hint = req.carry_in->size_hint;  // both were fixed by the first encode_data of the stream
+    // both were fixed by the first encode_data of the stream (a size hint that came out 0 there -- a flush or a metadata block
+    // before any input -- stays unset and is filled in by the next one, encode.rs:1604-1620)
+    p.size_hint = req.carry_in->size_hint != 0 ? req.carry_in->size_hint : req.params.size_hint;
     p.hasher = req.carry_in->hasher;
   } else {
     if (req.hasher_chosen_before_size_hint) {
@@ -311,7 +313,12 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     }
   }
   if (continuing && req.carry_in->tail_nbits) hb.put(req.carry_in->tail_nbits, req.carry_in->tail_bits);  // the open last byte of the piece in front
-  if (p.magic_number && !continuing) WriteMetadataMetaBlock(p, &hb);
+  // The magic-number block is written by the first encode_data of the stream (encode.rs:2261-2282).  A metadata block asked for
+  // before any input has arrived does not go through encode_data (process_metadata writes its header straight away,
+  // encode.rs:2630-2640): the magic number then comes BEHIND it, with the first piece that does (StreamCarry::magic_owed).
+  const bool metadata_before_anything = req.emit_metadata && !req.finish && n == 0;
+  const bool magic_due = p.magic_number && (!continuing || req.carry_in->magic_owed);
+  if (magic_due && !metadata_before_anything) WriteMetadataMetaBlock(p, &hb);
   if (!continuing && req.finish && n == 0 && p.byte_align && p.appendable && !p.catable && (hb.pos & 7) != 0) {
     hb.put(6, 6);
     hb.jump_to_byte_boundary();
@@ -365,6 +372,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       StreamCarry& co = *req.carry_out;
       if (continuing) co = *req.carry_in;
       co.tail_bits = co.tail_nbits = 0;  // (this piece ends byte aligned: flush padding or the end of the stream)
+      co.magic_owed = magic_due && metadata_before_anything;
       co.catable_raw_bytes = raw_head >= 2 ? 2u : (raw_head == 1 ? (raw_state == 1 ? 2u : 1u) : raw_state);
       co.use_dictionary = p.use_dictionary;
       co.prev_floor = prev_floor;  // (no meta-block written by this piece)
@@ -415,11 +423,6 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
   const uint32_t segment_bytes = req.segment_bytes ? req.segment_bytes : ChooseSegmentBytes(n);
   {
     Clock c;
-    // Qualities 10 / 11 (first device slice, zopfli_device.h): the state of the H10 trees is not carried from piece to piece yet.
-    // A stream that is flushed, or that is longer than one batch, is refused -- never answered with other bytes.
-    if (p.hasher.type == 10 && (continuing || !req.finish))
-      throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece in this build (no BROTLI_OPERATION_FLUSH / EMIT_METADATA in the "
-                               "middle, at most one batch of input -- BROTLI_MI355X_STREAM_BATCH, 64 MiB)");
     lz.SetStreamState(continuing ? req.carry_in : nullptr, req.finish, req.partial && !req.finish, req.last_block_processed_early);
     lz.Setup(p, text, prefix_bytes, (uint32_t)n, raw_head, segment_bytes);
     {
@@ -963,6 +966,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       // the end of a block), starting at a multiple of the ring size, so that ring-buffer indices stay what they were.
       StreamCarry co;
       co.valid = true;
+      co.magic_owed = false;
       co.hasher = p.hasher;
       co.size_hint = p.size_hint;
       co.dict_break = continuing ? req.carry_in->dict_break : prefix_bytes;
@@ -984,6 +988,11 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       if (abs_resume >= 2 * ring && !getenv("BROTLI_MI355X_KEEP_WHOLE_STREAM")) new_base = (abs_resume - ring) / ring * ring;
       const uint32_t keep_from = (uint32_t)(new_base - old_base);
       co.stream_base = new_base;
+      if (lz.is_zopfli()) {
+        // qualities 10 / 11: the hasher travels as it is -- the H10 trees at the resume point (zopfli_device.h) -- instead of
+        // as the set of stored positions
+        lz.ExportZopfli(&co, partial);
+      } else {
       std::vector<uint8_t> all(M);
       lz.DumpFlags(all.data(), M);
       // a hasher reset at or in front of the resume point wipes what lies before it (minus the three stitched positions)
@@ -1001,6 +1010,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       }
       co.stored.assign(all.begin() + keep_from, all.begin() + resume);
       for (uint8_t& f : co.stored) f &= 5;  // stored, and "stored as a masked position" (kFlagMasked; never set unless modelled)
+      }
       if (tail_nbits) {
         uint8_t last = 0;
         dev_d2h(&last, (const uint8_t*)B.out_words + total_bytes, 1);

@@ -2322,6 +2322,18 @@ void lz77_zopfli_init(const ZopfliJob& J) {
   hipLaunchKernelGGL(k_zopfli_fill, dim3(4096), dim3(256), 0, BR_STREAM, J.forest, (size_t)2 << J.lgwin, 0u);
   HIP_CHECK(hipGetLastError());
 }
+__global__ __launch_bounds__(256) void k_zopfli_import(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n, uint32_t delta, uint32_t invalid) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t e = src[i];
+    dst[i] = (e != invalid && e >= delta) ? e - delta : invalid;
+  }
+}
+void lz77_zopfli_import(const ZopfliJob& J, const uint32_t* buckets_src, const uint32_t* forest_src, uint32_t delta) {
+  const uint32_t invalid = 0u - ((1u << J.lgwin) - 1u);
+  hipLaunchKernelGGL(k_zopfli_import, dim3(256), dim3(256), 0, BR_STREAM, J.buckets, buckets_src, (size_t)1 << kZBucketBits, delta, invalid);
+  hipLaunchKernelGGL(k_zopfli_import, dim3(4096), dim3(256), 0, BR_STREAM, J.forest, forest_src, (size_t)2 << J.lgwin, delta, invalid);
+  HIP_CHECK(hipGetLastError());
+}
 // (first device slice: one lane per stream, see the header of zopfli_device.h)
 __global__ __launch_bounds__(64) void k_zopfli_prepend(ZopfliParams Z, ZopfliBuffers ZB, const uint8_t* __restrict__ text, uint32_t dict_bytes) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;

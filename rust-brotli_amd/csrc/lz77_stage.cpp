@@ -87,6 +87,9 @@ void Lz77Stage::Release() {
     dev_free(Z_.rerooted);
     dev_free(Z_.ctl);
     Z_ = ZopfliJob{};
+    dev_free(zsnap_buckets_);
+    dev_free(zsnap_forest_);
+    zsnap_buckets_ = zsnap_forest_ = nullptr;
     dev_free(B_.flags[0]);
     dev_free(B_.flags[1]);
     dev_free(B_.cmds);
@@ -1249,25 +1252,66 @@ void Lz77Stage::RunLive() {
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
 }
 
+ZopfliCarry::~ZopfliCarry() {
+  dev_free(buckets);
+  dev_free(forest);
+}
+
+void Lz77Stage::ExportZopfli(StreamCarry* co, bool partial) {
+  auto zc = std::make_shared<ZopfliCarry>();
+  zc->lgwin = Z_.lgwin;
+  zc->text_base = (carry_ && carry_->valid) ? carry_->stream_base : 0;
+  if (partial) {
+    if (!zsnap_buckets_) throw std::runtime_error("brotli_mi355x: quality 10 / 11: no snapshot of the trees at the resume point");
+    zc->buckets = zsnap_buckets_;
+    zc->forest = zsnap_forest_;
+    zsnap_buckets_ = zsnap_forest_ = nullptr;
+  } else {
+    zc->buckets = Z_.buckets;
+    zc->forest = Z_.forest;
+    Z_.buckets = Z_.forest = nullptr;
+  }
+  co->zopfli = std::move(zc);
+}
+
 // Qualities 10 / 11: the blocks go through the device one after the other (the H10 trees and the dynamic programme are a
 // function of everything in front); between two of them the host resolver replays the exits -- flush rule, should_compress,
 // extend_last_command -- exactly as behind a round of the greedy path, and hands the next block its entry.
 void Lz77Stage::RunZopfli() {
   const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
   const uint32_t nseg = (uint32_t)segments_.size();
-  if (carry_ && carry_->valid) throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece (no flush, no continuation) in this build");
-  if (partial_) throw std::runtime_error("brotli_mi355x: quality 10 / 11 streams are encoded in one piece in this build");
+  if (P_.reset_pos != 0) throw std::runtime_error("brotli_mi355x: quality 10 / 11 across the reference's 32-bit position wrap is not supported");
   InitEntries();
   lz77_compute_keys(P_, B_);
   lz77_sort_by_key(P_, B_);
-  lz77_zopfli_init(Z_);
-  // a custom dictionary (the prefix of a compress_multi shard) goes into the trees first (encode.rs:1163-1194)
-  if (P_.prefix_bytes > 1) lz77_zopfli_prepend(P_, B_, Z_, P_.prefix_bytes);
+  const size_t forest_bytes = ((size_t)2 << Z_.lgwin) * 4, bucket_bytes = ((size_t)1 << 17) * 4;
+  if (carry_ && carry_->valid && carry_->zopfli) {
+    // a later piece of a stream: the trees of the piece in front, moved to this piece's text positions
+    const ZopfliCarry& zc = *carry_->zopfli;
+    if (zc.lgwin != Z_.lgwin || carry_->stream_base < zc.text_base) throw std::runtime_error("brotli_mi355x: quality 10 / 11: the carried trees do not fit this piece");
+    lz77_zopfli_import(Z_, zc.buckets, zc.forest, (uint32_t)(carry_->stream_base - zc.text_base));
+  } else {
+    lz77_zopfli_init(Z_);
+    // a custom dictionary (the prefix of a compress_multi shard) goes into the trees first (encode.rs:1163-1194); nothing of the
+    // stream itself can lie in front of a piece that brings no trees
+    if (P_.prefix_bytes > 1) lz77_zopfli_prepend(P_, B_, Z_, P_.prefix_bytes);
+  }
+  bool starts_metablock = true;  // (the block about to be parsed is the first of its meta-block)
   uint32_t from = 0;
   bool done = false;
   for (uint32_t round = 0; round < nseg + 8 && !done; ++round) {
     stats_.rounds++;
     if (round != 0) entries_[from] = next_entries_[from];
+    if (partial_ && starts_metablock) {
+      // the next piece starts again at the first block of the meta-block that is still open when this one ends: the trees as
+      // they are in front of every block that opens a meta-block (the last such copy is the one that travels)
+      if (!zsnap_buckets_) {
+        zsnap_buckets_ = (uint32_t*)dev_alloc_uninit(bucket_bytes + 64);
+        zsnap_forest_ = (uint32_t*)dev_alloc_uninit(forest_bytes + 64);
+      }
+      dev_d2d(zsnap_buckets_, Z_.buckets, bucket_bytes);
+      dev_d2d(zsnap_forest_, Z_.forest, forest_bytes);
+    }
     dev_h2d(B_.entries + from, entries_.data() + from, sizeof(SegEntry));
     if (lz77_zopfli_block(P_, B_, Z_, from)) stats_.coarse_restarts++;  // (parsed the sequential way)
     stats_.segments_parsed++;
@@ -1282,10 +1326,21 @@ void Lz77Stage::RunZopfli() {
     for (uint32_t k = 0; k <= from; ++k)
       if (dirty_entry_[k]) throw std::runtime_error("brotli_mi355x: resolver and Zopfli parse disagree about the entry of a finished block");
     if (debug) fprintf(stderr, "zopfli block %u of %u done: %u commands, %u bytes pending\n", from, nseg, exits_[from].n_cmds, exits_[from].insert_len);
+    starts_metablock = false;
+    for (const MetaBlockPlan& mb : metablocks_)
+      if (mb.end == segments_[from].blk_end) starts_metablock = true;  // (the flush rule closed a meta-block behind this block)
     ++from;
     done = from == nseg;
   }
   if (!done) throw std::runtime_error("brotli_mi355x: quality 10 / 11 parse did not finish");
+  if (partial_ && starts_metablock) {  // (the flush rule closed a meta-block with the last block: the next piece starts behind it)
+    if (!zsnap_buckets_) {
+      zsnap_buckets_ = (uint32_t*)dev_alloc_uninit(bucket_bytes + 64);
+      zsnap_forest_ = (uint32_t*)dev_alloc_uninit(forest_bytes + 64);
+    }
+    dev_d2d(zsnap_buckets_, Z_.buckets, bucket_bytes);
+    dev_d2d(zsnap_forest_, Z_.forest, forest_bytes);
+  }
   final_flags_ = 0;
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
 }

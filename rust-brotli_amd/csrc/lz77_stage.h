@@ -10,6 +10,7 @@
 
 #include <stdint.h>
 #include <map>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -45,6 +46,18 @@ struct Lz77Stats {
   double ms_keys = 0, ms_sort = 0, ms_init = 0, ms_warmup = 0, ms_rank = 0, ms_parse = 0, ms_resolve = 0, ms_gather = 0, ms_total = 0;
 };
 
+// Qualities 10 / 11: the H10 trees as a piece of a stream leaves them for the next one (device memory, owned here)
+struct ZopfliCarry {
+  uint32_t* buckets = nullptr;  // [1 << 17]
+  uint32_t* forest = nullptr;   // [2 << lgwin]
+  uint32_t lgwin = 0;
+  uint64_t text_base = 0;       // stream position of text position 0 of the piece that left them
+  ZopfliCarry() = default;
+  ZopfliCarry(const ZopfliCarry&) = delete;
+  ZopfliCarry& operator=(const ZopfliCarry&) = delete;
+  ~ZopfliCarry();
+};
+
 // What an encoder keeps between two encode_data calls of one stream (BROTLI_OPERATION_FLUSH): the reference's hasher
 // contents, distance cache and dictionary-throttle counters.  The hasher is represented by which positions of the
 // stream so far are stored in it.
@@ -70,6 +83,9 @@ struct StreamCarry {
   uint32_t prev_floor = 0;         // text position below which the context bytes of the next meta-block read as 0: the end of a
                                    // custom dictionary until the first meta-block has been written (encode.rs:2526-2534 runs only then)
   uint32_t catable_raw_bytes = 0;  // is_first_mb: 0 nothing, 1 one, 2 both raw first bytes of a catable stream are out (encode.rs:2283-2333)
+  std::shared_ptr<ZopfliCarry> zopfli;  // qualities 10 / 11: the trees at the resume point (null: nothing searched yet)
+  bool magic_owed = false;  // the magic-number block (BROTLI_PARAM_MAGIC_NUMBER) has not been written yet: so far only metadata
+                            // blocks asked for before any input went out, and those do not pass through encode_data
 };
 
 class Lz77Stage {
@@ -117,6 +133,10 @@ class Lz77Stage {
   // the next piece when it keeps text[upto ..) as its prefix
   void KeyCountsBefore(uint32_t upto, std::vector<uint32_t>* out);
   // state after Run() for the next continuation (dist cache comes from metablocks().back())
+  // qualities 10 / 11: hands the H10 trees over to the carry of the next piece -- as they are at the end of the text, or
+  // (partial piece) as they were in front of the block that starts the meta-block still open
+  void ExportZopfli(StreamCarry* co, bool partial);
+  bool is_zopfli() const { return use_zopfli_; }
   void FinalDictState(uint32_t* lookups, uint32_t* matches, bool* dead) const {
     *lookups = final_dict_lookups_;
     *matches = final_dict_matches_;
@@ -158,6 +178,8 @@ class Lz77Stage {
   bool use_live_ = false;
   bool use_zopfli_ = false;  // qualities 10 / 11 (zopfli_device.h)
   ZopfliJob Z_{};
+  uint32_t* zsnap_buckets_ = nullptr;  // partial pieces: the trees in front of the block that starts the open meta-block
+  uint32_t* zsnap_forest_ = nullptr;
   bool live_verify_ = false;
   std::vector<LiveBlockState> live_state_;  // Resolve(): the meta-block books at the entry of every block (live chains)
   uint32_t input_bytes_ = 0;

@@ -852,10 +852,13 @@ ZDEV uint32_t z_update_nodes(const ZopfliParams& P, const uint8_t* text, uint32_
       const uint32_t idx = j < 4 ? j : (j < 10 ? 0u : 1u);
       const int32_t off = j < 4 ? 0 : (int32_t)(((j - 4) % 6) / 2 + 1) * (((j - 4) & 1) ? 1 : -1);
       const uint64_t backward = (uint64_t)(int64_t)(d.distance_cache[idx] + off);
+      // (the reference's ring buffer: no candidate is looked at across its end, hq.rs:721-736)
+      if ((cur_ix & P.ring_mask) + best_len > P.ring_mask) break;
       if (backward > max_distance) continue;
       const uint64_t prev64 = (uint64_t)cur_ix - backward;
       if (prev64 >= cur_ix) continue;
       const uint32_t prev_ix = (uint32_t)prev64;
+      if ((prev_ix & P.ring_mask) + best_len > P.ring_mask) continue;
       if (text[cur_ix + best_len] != text[prev_ix + best_len]) continue;
       const uint32_t len = z_fix_unbroken(z_match_len(text + prev_ix, text + cur_ix, max_len), prev_ix & P.ring_mask, P.dict_break);
       const float dist_cost = base_cost + model.cost_dist[j];
@@ -884,8 +887,12 @@ ZDEV uint32_t z_update_nodes(const ZopfliParams& P, const uint8_t* text, uint32_
         const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
         todo &= todo - 1ull;
         const uint32_t len = (uint32_t)__shfl((int)my_len, (int)(group + j), 64);
-        if (len <= best_len) continue;
         const uint32_t backward = (uint32_t)__shfl((int)my_backward, (int)(group + j), 64);
+        // (the reference's ring buffer: no candidate is looked at across its end, hq.rs:721-736; these two hang on best_len as
+        // it stands when the candidate's turn comes)
+        if ((cur_ix & P.ring_mask) + best_len > P.ring_mask) break;
+        if (((cur_ix - backward) & P.ring_mask) + best_len > P.ring_mask) continue;
+        if (len <= best_len) continue;
         const float dist_cost = base_cost + model.cost_dist[j];
         for (uint32_t first = best_len + 1; first <= len; first += 64) {
           const uint32_t l = first + lane;

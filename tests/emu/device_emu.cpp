@@ -748,6 +748,11 @@ void lz77_zopfli_init(const ZopfliJob& J) {
   for (size_t i = 0; i < ((size_t)1 << kZBucketBits); ++i) J.buckets[i] = 0u - window_mask;
   memset(J.forest, 0, ((size_t)2 << J.lgwin) * 4);
 }
+void lz77_zopfli_import(const ZopfliJob& J, const uint32_t* buckets_src, const uint32_t* forest_src, uint32_t delta) {
+  const uint32_t invalid = 0u - ((1u << J.lgwin) - 1u);
+  for (size_t i = 0; i < ((size_t)1 << kZBucketBits); ++i) J.buckets[i] = (buckets_src[i] != invalid && buckets_src[i] >= delta) ? buckets_src[i] - delta : invalid;
+  for (size_t i = 0; i < ((size_t)2 << J.lgwin); ++i) J.forest[i] = (forest_src[i] != invalid && forest_src[i] >= delta) ? forest_src[i] - delta : invalid;
+}
 void lz77_zopfli_prepend(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJob& J, uint32_t dict_bytes) {
   const ZopfliParams Z = emu_zopfli_params(P, J);
   const ZH10 h = z_hasher_of(Z, emu_zopfli_buffers(J));

@@ -1,8 +1,7 @@
 """Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
 oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10).
-FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB, and no
-flushes in the middle of a stream (first device slice: one stream = one piece)."""
+FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB."""
 import os, sys, time
 import synth, orc
 import test_cabi
@@ -35,8 +34,6 @@ for c in range(cases):
             d = pool[o:o + n]
     w = [17, 18, 20, 22, 24][rng.next() % 5]
     mode = rng.next() % 6
-    if zopfli and mode in (1, 2):
-        mode = [0, 3, 4, 5][rng.next() % 4]
     if q95 and mode == 5:
         mode = 4  # (orc.writer_compress takes quality and window only)
     base = [(Q, q), (W, w)] + ([(150, 1)] if q95 else [])
@@ -87,6 +84,8 @@ for c in range(cases):
         o2 = rng.next() % (len(pool) - m)
         dic = pool[o2:o2 + m]
         what = "dictionary %d B" % m
+        if os.environ.get("FUZZ_TRACE"):
+            open(os.environ["FUZZ_TRACE"] + ".dict", "wb").write(dic)
 
         def product():
             e = lib.encoder(params=base, dictionary=dic)

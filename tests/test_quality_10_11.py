@@ -89,18 +89,66 @@ def test_multi_shard_emu():
     _multi(test_cabi._load("emu"))
 
 
-def test_streams_in_pieces_are_refused_with_a_message():
-    """first device slice: a quality 10 / 11 stream is encoded in one piece; a flush in the middle is refused, never answered with
-    other bytes"""
-    import test_cabi
-    lib = test_cabi._load("emu")
-    e = lib.encoder(params=[(Q, 10), (W, 22)])
-    with pytest.raises(Exception) as err:
-        e.flush(synth.alice()[:50000])
-        e.write(synth.alice()[50000:])
-        e.finish()
-    assert "one piece" in str(err.value)
+def _flushes(lib):
+    """FLUSH in the middle of a stream: the H10 trees travel from piece to piece (ZopfliCarry), moved to the next piece's text
+    positions; a flush in front of any input; a custom dictionary in front of a flushed stream"""
+    d = synth.mixed(600000, 7)
+    a = synth.alice()
+    for q, w, cuts, data, dic in ((10, 20, [200000, 400001], d, None), (11, 18, [0, 70000, 70001, 300000], d[:380000], None),
+                                  (10, 22, [50000], a, None), (11, 22, [1000], a[20000:90000], a[:20000])):
+        params = [(Q, q), (W, w)]
+        e = lib.encoder(params=params, dictionary=dic)
+        pieces, last = [], 0
+        for c in cuts:
+            pieces.append(e.flush(data[last:c]))
+            last = c
+        e._stream(2, data[last:])
+        pieces.append(bytes(e._out))
+        e.close()
+        want = orc.stream_with_flushes(data, params, cuts, write_size=1 << 30, dictionary=dic)
+        assert [len(x) for x in pieces] == [len(x) for x in want], (q, w, cuts)
+        assert pieces == want, (q, w, cuts)
+
+
+_STREAMED = r"""
+import sys
+sys.path.insert(0, %(tests)r)
+import orc, synth, test_cabi
+lib = test_cabi._load(%(kind)r)
+Q, W, SH = 1, 2, 5
+for name, d, q, w, chunk in (("markov 2.5 MiB, quality 10, lgwin 18", synth.markov_text(5 << 19, 11), 10, 18, 65536),
+                             ("mixed 1.5 MiB, quality 11, lgwin 20", synth.mixed(3 << 19, 12), 11, 20, 100003)):
+    params = [(Q, q), (W, w)]
+    e = lib.encoder(params=params)
+    early = 0
+    for i in range(0, len(d), chunk):
+        e.write(d[i:i + chunk])
+        early = max(early, len(e._out))
+    got = e.finish()
     e.close()
+    assert got == orc.reader_compress(d, params, chunk=chunk), name
+    assert early > len(got) // 3, (name, "PROCESS handed nothing out", early)
+    print("OK", name, len(got), early)
+"""
+
+
+def _streamed(kind):
+    """bounded-memory streaming at qualities 10 / 11: the batch is turned down so that a few MiB go through several pieces -- every
+    piece starts again at the first block of the meta-block the one in front left open, on the trees as they were there"""
+    import subprocess
+    import sys
+    env = dict(os.environ, BROTLI_MI355X_STREAM_BATCH=str(1 << 19))
+    r = subprocess.run([sys.executable, "-c", _STREAMED % dict(tests=HERE, kind=kind)], env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_flushes_emu():
+    import test_cabi
+    _flushes(test_cabi._load("emu"))
+
+
+def test_streamed_in_pieces_emu():
+    _streamed("emu")
 
 
 @pytest.mark.gpu
@@ -119,3 +167,9 @@ def test_identity_with_the_oracle_gpu():
 def test_multi_shard_gpu():
     import test_cabi
     _multi(test_cabi._load("gpu"))
+
+
+@pytest.mark.gpu
+def test_flushes_gpu():
+    import test_cabi
+    _flushes(test_cabi._load("gpu"))
