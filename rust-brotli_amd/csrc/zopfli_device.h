@@ -18,9 +18,9 @@
 // All f32 arithmetic keeps the reference's operation order (floatX = f32; tolerance zero: byte identity of the stream is the
 // test, pinned by the reference's own sizes 47 488 / 46 493 for alice29, src/bin/integration_tests.rs:401-449).
 //
-// First device slice: ONE lane walks a block (the tree insertions, the dynamic programme over the positions and the f32
-// running sums are sequential in the reference; what is parallel in it -- match lengths, the candidates of a position, the
-// trees of different hash keys -- is the next step).  The text is flat (prefix + input); ring-buffer
+// How it runs: the matches of a block side by side, one lane per group of hash keys (the trees of
+// different keys do not touch); the dynamic programme on one wavefront per stream with a position's candidates and copy lengths
+// spread over the lanes; the f32 running sums and the sliding-window histograms in the reference's order on the way.  The text is flat (prefix + input); ring-buffer
 // indices appear only where the reference's behaviour hangs on them (the custom-dictionary end, mod.rs:42-54).
 #ifndef BROTLI_MI355X_ZOPFLI_DEVICE_H_
 #define BROTLI_MI355X_ZOPFLI_DEVICE_H_
