@@ -37,15 +37,18 @@ def _cases(small):
     a = synth.alice()
     for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))):
         d = open(f, "rb").read()
-        if small and len(d) > 70000:
+        if small and len(d) > 20000:
             continue
         for q in (10, 11):
             yield "%s q%d" % (os.path.basename(f), q), d, [(Q, q), (W, 22), (SH, len(d))], b""
+    if small:
+        a = a[:60000]  # (the device slice runs at a few hundredths of a MB/s: the GPU suite keeps its inputs short)
     h = len(a) // 2
     for q in (10, 11):
         yield "alice w16 q%d" % q, a, [(Q, q), (W, 16)], b""
-        yield "alice w18 hint q%d" % q, a, [(Q, q), (W, 18), (SH, len(a))], b""
-        yield "alice catable q%d" % q, a, [(Q, q), (W, 22), (167, 1)], b""
+        if not small:
+            yield "alice w18 hint q%d" % q, a, [(Q, q), (W, 18), (SH, len(a))], b""
+            yield "alice catable q%d" % q, a, [(Q, q), (W, 22), (167, 1)], b""
         yield "alice appendable + magic q%d" % q, a, [(Q, q), (W, 22), (168, 1), (169, 1)], b""
         yield "alice large window q%d" % q, a, [(Q, q), (LARGE, 1), (W, 26)], b""
         yield "alice second half behind the first as dictionary q%d" % q, a[h:], [(Q, q), (W, 22), (167, 1), (168, 1)], a[:h]
@@ -91,13 +94,16 @@ def test_multi_shard_emu():
     _multi(test_cabi._load("emu"))
 
 
-def _flushes(lib):
+def _flushes(lib, small=False):
     """FLUSH in the middle of a stream: the H10 trees travel from piece to piece (ZopfliCarry), moved to the next piece's text
     positions; a flush in front of any input; a custom dictionary in front of a flushed stream"""
     d = synth.mixed(600000, 7)
     a = synth.alice()
-    for q, w, cuts, data, dic in ((10, 20, [200000, 400001], d, None), (11, 18, [0, 70000, 70001, 300000], d[:380000], None),
-                                  (10, 22, [50000], a, None), (11, 22, [1000], a[20000:90000], a[:20000])):
+    cases = ((10, 20, [200000, 400001], d, None), (11, 18, [0, 70000, 70001, 300000], d[:380000], None),
+             (10, 22, [50000], a, None), (11, 22, [1000], a[20000:90000], a[:20000]))
+    if small:  # (the GPU suite: short inputs, see _cases)
+        cases = ((10, 18, [30000, 60001], d[:90000], None), (11, 17, [0, 20000, 20001], a[:50000], None), (11, 22, [1000], a[20000:50000], a[:20000]))
+    for q, w, cuts, data, dic in cases:
         params = [(Q, q), (W, w)]
         e = lib.encoder(params=params, dictionary=dic)
         pieces, last = [], 0
@@ -174,4 +180,4 @@ def test_multi_shard_gpu():
 @pytest.mark.gpu
 def test_flushes_gpu():
     import test_cabi
-    _flushes(test_cabi._load("gpu"))
+    _flushes(test_cabi._load("gpu"), small=True)
