@@ -525,6 +525,9 @@ def main():
         "metric": "compress MB/s at q5 lgwin22", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        # (what `value` times: version 3 = rounds 3+, input AND compressed stream resident in HBM, SURVEY 8d's device-resident time;
+        # version 2 = round 2, the stream delivered into page-locked host memory -- still reported as output_to_pinned_host)
+        "metric_version": 3,
         "config": {"workload": "%d MiB synthetic English-like text per GPU (word-bigram Markov over alice29 tokens), quality=5, lgwin=22, "
                                "%s" % (args.mib, "one-shot BrotliEncoderCompress semantics (H6 hasher)" if not shard_job else
                                        "one stream of %d MiB, size hint = stream size, compress_multi shard per GPU + RCCL gather + BroCatli stitch" % (total >> 20)),
