@@ -528,6 +528,9 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       d.dist_postfix_bits = p.dist.distance_postfix_bits;
       d.num_direct_distance_codes = p.dist.num_direct_distance_codes;
       d.num_contexts = 1;
+      // qualities 2 and 3 (store_meta_block_fast / _trivial, metablock_fast.h): one block type per kind, context mode bits 0
+      d.simple = p.quality <= 2 ? kMbFast : (p.quality < 4 ? kMbTrivial : kMbGreedy);
+      if (d.simple != kMbGreedy) d.context_mode = 0;
     }
     // prev bytes (encode.rs:2526-2534): bytes preceding the meta-block in the stream, 0 at the very start
     {
@@ -784,7 +787,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       stats.ms_phase[3] += clk.lap(prof, "hq-context-maps");
     } else {
       // literal context modelling decision
-      if (p.disable_literal_context_modeling == 0) {
+      if (p.disable_literal_context_modeling == 0 && p.quality >= 5) {  // (DecideOverLiteralContextModeling leaves lower qualities alone)
         uint32_t* stats_dev = mm.alloc<uint32_t>((size_t)n_mb * kContextStatsWords);
         mb_context_stats(B, stats_dev);
         std::vector<uint32_t> cs((size_t)n_mb * kContextStatsWords);
@@ -856,8 +859,13 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     std::vector<CodeJob> jobs;
     for (uint32_t m = 0; m < n_mb; ++m) {
       if (descs[m].uncompressed) continue;
-      for (uint32_t k = 0; k < 3; ++k)
-        for (uint32_t i = 0; i < results[m].num_histos[k]; ++i) jobs.push_back({k, descs[m].histo_base[k] + i, descs[m].num_distance_symbols, 0});
+      for (uint32_t k = 0; k < 3; ++k) {
+        uint32_t mode = kCodeOptimized;
+        if (descs[m].simple == kMbTrivial) mode = kCodePlain;
+        // (quality 2: up to 128 commands are written with the static command and distance codes, brotli_bit_stream.rs:2619-2687)
+        if (descs[m].simple == kMbFast) mode = (descs[m].n_cmds <= 128 && k != kSplitLiteral) ? kCodeStatic : kCodeFast;
+        for (uint32_t i = 0; i < results[m].num_histos[k]; ++i) jobs.push_back({k, descs[m].histo_base[k] + i, descs[m].num_distance_symbols, mode});
+      }
     }
     B.huff_scratch = mm.alloc<HuffmanScratch>(std::max<size_t>(jobs.size(), n_mb) + 1);
     CodeJob* jobs_dev = mm.alloc<CodeJob>(jobs.size() + 1);
@@ -992,6 +1000,8 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         // qualities 10 / 11: the hasher travels as it is -- the H10 trees at the resume point (zopfli_device.h) -- instead of
         // as the set of stored positions
         lz.ExportZopfli(&co, partial);
+      } else if (lz.is_quick()) {
+        lz.ExportQuick(&co, partial);  // qualities 2 .. 4: likewise the BasicHasher table (quick_device.h)
       } else {
       std::vector<uint8_t> all(M);
       lz.DumpFlags(all.data(), M);

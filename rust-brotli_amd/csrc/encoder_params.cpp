@@ -165,8 +165,13 @@ static bool DeepRingsAllowed() {
 
 bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
-  if (p.quality < 5 || p.quality > 11) {
-    why = "only qualities 5..11 are implemented on the device in this build (0..4: the fragment compressors and the BasicHasher family)";
+  const bool basic = p.hasher.type == 2 || p.hasher.type == 3 || p.hasher.type == 4 || p.hasher.type == 54;
+  if (p.quality < 2 || p.quality > 11) {
+    why = "only qualities 2..11 are implemented on the device in this build (0 and 1: the fragment compressors)";
+  } else if (basic != (p.quality < 5)) {
+    why = "hasher type and quality do not go together";
+  } else if (basic) {
+    // BasicHasher family under the greedy / lazy parse (quick_device.h)
   } else if (p.hasher.type != 5 && !IsH6Family(p.hasher.type) && p.hasher.type != 9 && p.hasher.type != 10) {
     why = "hasher type not implemented on the device";
   } else if (p.hasher.block_bits > 9) {

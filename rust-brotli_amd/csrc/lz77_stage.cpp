@@ -87,6 +87,10 @@ void Lz77Stage::Release() {
     dev_free(Z_.rerooted);
     dev_free(Z_.ctl);
     Z_ = ZopfliJob{};
+    dev_free(Q_.table);
+    Q_ = QuickJob{};
+    dev_free(qsnap_table_);
+    qsnap_table_ = nullptr;
     dev_free(zsnap_buckets_);
     dev_free(zsnap_forest_);
     zsnap_buckets_ = zsnap_forest_ = nullptr;
@@ -145,6 +149,39 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
   B_ = Lz77Buffers{};
   B_.text = text_dev;
   use_zopfli_ = params.hasher.type == 10;
+  use_quick_ = params.hasher.type == 2 || params.hasher.type == 3 || params.hasher.type == 4 || params.hasher.type == 54;
+  if (use_quick_) {
+    // Qualities 2 .. 4 (quick_device.h): one chain per stream on the reference's own BasicHasher table, block by block, one
+    // segment per input block; none of the sort / row / rank structures of the speculative path exist.
+    use_live_ = use_rows_ = false;
+    P_.htl = 8;
+    if (segment_bytes_ != block_bytes_) segment_bytes_ = block_bytes_;
+    P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
+    BuildSegments();
+    P_.num_segments = (uint32_t)segments_.size();
+    P_.use_dictionary = 0;  // (the throttle books travel with the table, not with the resolver)
+    Q_ = QuickJob{};
+    Q_.kind = (uint32_t)params.hasher.type;
+    Q_.bucket_bits = Q_.kind == 54 ? 20 : (Q_.kind == 4 ? 17 : 16);
+    Q_.sweep = Q_.kind == 2 ? 1 : (Q_.kind == 3 ? 2 : 4);
+    Q_.hash_len = Q_.kind == 54 ? 7 : 5;
+    Q_.use_dictionary = (params.use_dictionary && (Q_.kind == 2 || Q_.kind == 4)) ? 1 : 0;
+    Q_.table = (uint32_t*)dev_alloc_uninit((size_t)quick_table_words(Q_) * 4 + 64);
+    cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
+    B_.cmds = (Command*)dev_alloc_uninit(cmds_bytes_);
+    B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
+    B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
+    B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
+    histo_dev_ = (uint32_t*)dev_alloc(256 * 4);
+    gather_offsets_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+    gather_counts_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+    owns_buffers_ = true;
+    segments_upload_.resize_discard(segments_.size());
+    memcpy(segments_upload_.data(), segments_.data(), segments_.size() * sizeof(Segment));
+    dev_h2d(B_.segments, segments_upload_.data(), segments_.size() * sizeof(Segment));
+    exits_.assign((uint32_t)segments_.size(), SegExit{});
+    return;
+  }
   if (use_zopfli_) {
     // Qualities 10 / 11 (zopfli_device.h): the H10 trees and the shortest-path parse go block by block, one segment per input
     // block; none of the sort / row / rank structures of the greedy path exist.
@@ -788,7 +825,9 @@ bool Lz77Stage::Resolve(bool final_pass) {
     const bool batch_end = (k1 + 1 == nseg);
     bool is_last = batch_end && !partial_;
     const size_t processed_bytes = be - last_flush_pos;
-    const bool next_fits = processed_bytes + block_bytes_ <= max_mb;
+    // (below MIN_QUALITY_FOR_BLOCK_SPLIT a meta-block is also closed once it holds 0x2fff literals + commands, encode.rs:2458-2459)
+    const bool should_flush = params_.quality < 4 && num_literals + num_commands >= 0x2fff;
+    const bool next_fits = processed_bytes + block_bytes_ <= max_mb && !should_flush;
     if (is_last && early_last_ && !(next_fits && num_literals < max_literals && num_commands < max_commands)) {
       // the flush rule had closed this meta-block before anybody knew that the stream ends here
       is_last = false;
@@ -1047,8 +1086,8 @@ void Lz77Stage::Run() {
     total_cmds_ = 0;
     return;
   }
-  if (use_zopfli_) {
-    RunZopfli();
+  if (use_zopfli_ || use_quick_) {
+    if (use_quick_) RunQuick(); else RunZopfli();
     tm.stop(&stats_.ms_parse);
     Gather();
     tm.stop(&stats_.ms_gather);
@@ -1272,6 +1311,65 @@ void Lz77Stage::ExportZopfli(StreamCarry* co, bool partial) {
     Z_.buckets = Z_.forest = nullptr;
   }
   co->zopfli = std::move(zc);
+}
+
+QuickCarry::~QuickCarry() { dev_free(table); }
+
+void Lz77Stage::ExportQuick(StreamCarry* co, bool partial) {
+  auto qc = std::make_shared<QuickCarry>();
+  qc->text_base = (carry_ && carry_->valid) ? carry_->stream_base : 0;
+  if (partial) {
+    if (!qsnap_table_) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4: no snapshot of the hash table at the resume point");
+    qc->table = qsnap_table_;
+    qsnap_table_ = nullptr;
+  } else {
+    qc->table = Q_.table;
+    Q_.table = nullptr;
+  }
+  co->quick = std::move(qc);
+}
+
+// Qualities 2 .. 4: like RunZopfli -- the blocks go through the device one after the other on the stream's BasicHasher table, the
+// host resolver replays the exits in between (flush rule incl. the 0x2fff rule of these qualities, should_compress,
+// extend_last_command) and hands the next block its entry.
+void Lz77Stage::RunQuick() {
+  const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
+  const uint32_t nseg = (uint32_t)segments_.size();
+  if (P_.reset_pos != 0) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4 across the reference's 32-bit position wrap are not supported");
+  InitEntries();
+  const size_t table_bytes = (size_t)quick_table_words(Q_) * 4;
+  if (carry_ && carry_->valid && carry_->quick) {
+    const QuickCarry& qc = *carry_->quick;
+    if (carry_->stream_base < qc.text_base) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4: the carried hash table does not fit this piece");
+    lz77_quick_import(Q_, qc.table, (uint32_t)(carry_->stream_base - qc.text_base));
+  } else {
+    lz77_quick_init(Q_);
+    if (P_.prefix_bytes > 1) lz77_quick_prepend(P_, B_, Q_, P_.prefix_bytes);  // custom dictionary, encode.rs:1163-1194
+  }
+  auto snapshot = [&]() {
+    if (!qsnap_table_) qsnap_table_ = (uint32_t*)dev_alloc_uninit(table_bytes + 64);
+    dev_d2d(qsnap_table_, Q_.table, table_bytes);
+  };
+  bool starts_metablock = true;
+  for (uint32_t from = 0; from < nseg; ++from) {
+    stats_.rounds++;
+    if (from != 0) entries_[from] = next_entries_[from];
+    if (partial_ && starts_metablock) snapshot();  // (the next piece starts again at the first block of the meta-block still open)
+    dev_h2d(B_.entries + from, entries_.data() + from, sizeof(SegEntry));
+    lz77_quick_block(P_, B_, Q_, from);
+    stats_.segments_parsed++;
+    dev_d2h(exits_.data() + from, B_.exits + from, sizeof(SegExit));
+    Resolve(false);
+    for (uint32_t k = 0; k <= from; ++k)
+      if (dirty_entry_[k]) throw std::runtime_error("brotli_mi355x: resolver and quick parse disagree about the entry of a finished block");
+    if (debug) fprintf(stderr, "quick block %u of %u done: %u commands, %u bytes pending\n", from, nseg, exits_[from].n_cmds, exits_[from].insert_len);
+    starts_metablock = false;
+    for (const MetaBlockPlan& mb : metablocks_)
+      if (mb.end == segments_[from].blk_end) starts_metablock = true;
+  }
+  if (partial_ && starts_metablock) snapshot();
+  final_flags_ = 0;
+  for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
 }
 
 // Qualities 10 / 11: the blocks go through the device one after the other (the H10 trees and the dynamic programme are a

@@ -16,6 +16,7 @@
 
 #include "device_api.h"
 #include "encoder_params.h"
+#include "quick_api.h"
 
 namespace brotli_mi355x {
 
@@ -58,6 +59,16 @@ struct ZopfliCarry {
   ~ZopfliCarry();
 };
 
+// Qualities 2 .. 4: the BasicHasher table (slots + dictionary-throttle counters, quick_api.h) as a piece of a stream leaves it
+struct QuickCarry {
+  uint32_t* table = nullptr;  // [quick_table_words()]
+  uint64_t text_base = 0;     // stream position of text position 0 of the piece that left it
+  QuickCarry() = default;
+  QuickCarry(const QuickCarry&) = delete;
+  QuickCarry& operator=(const QuickCarry&) = delete;
+  ~QuickCarry();
+};
+
 // What an encoder keeps between two encode_data calls of one stream (BROTLI_OPERATION_FLUSH): the reference's hasher
 // contents, distance cache and dictionary-throttle counters.  The hasher is represented by which positions of the
 // stream so far are stored in it.
@@ -84,6 +95,7 @@ struct StreamCarry {
                                    // custom dictionary until the first meta-block has been written (encode.rs:2526-2534 runs only then)
   uint32_t catable_raw_bytes = 0;  // is_first_mb: 0 nothing, 1 one, 2 both raw first bytes of a catable stream are out (encode.rs:2283-2333)
   std::shared_ptr<ZopfliCarry> zopfli;  // qualities 10 / 11: the trees at the resume point (null: nothing searched yet)
+  std::shared_ptr<QuickCarry> quick;    // qualities 2 .. 4: the hash table at the resume point (null: nothing searched yet)
   bool magic_owed = false;  // the magic-number block (BROTLI_PARAM_MAGIC_NUMBER) has not been written yet: so far only metadata
                             // blocks asked for before any input went out, and those do not pass through encode_data
 };
@@ -137,6 +149,9 @@ class Lz77Stage {
   // (partial piece) as they were in front of the block that starts the meta-block still open
   void ExportZopfli(StreamCarry* co, bool partial);
   bool is_zopfli() const { return use_zopfli_; }
+  // qualities 2 .. 4: the same for the BasicHasher table
+  void ExportQuick(StreamCarry* co, bool partial);
+  bool is_quick() const { return use_quick_; }
   void FinalDictState(uint32_t* lookups, uint32_t* matches, bool* dead) const {
     *lookups = final_dict_lookups_;
     *matches = final_dict_matches_;
@@ -160,6 +175,7 @@ class Lz77Stage {
   void RunRounds(bool allow_restart);
   void RunLive();
   void RunZopfli();
+  void RunQuick();
   void InitEntries();
   void InitFlags();
   bool Resolve(bool final_pass);
@@ -180,6 +196,9 @@ class Lz77Stage {
   ZopfliJob Z_{};
   uint32_t* zsnap_buckets_ = nullptr;  // partial pieces: the trees in front of the block that starts the open meta-block
   uint32_t* zsnap_forest_ = nullptr;
+  bool use_quick_ = false;   // qualities 2 .. 4 (quick_device.h)
+  QuickJob Q_{};
+  uint32_t* qsnap_table_ = nullptr;    // partial pieces: the table in front of the block that starts the open meta-block
   bool live_verify_ = false;
   std::vector<LiveBlockState> live_state_;  // Resolve(): the meta-block books at the entry of every block (live chains)
   uint32_t input_bytes_ = 0;

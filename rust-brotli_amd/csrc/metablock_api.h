@@ -22,7 +22,7 @@ struct CodeJob {
   uint32_t kind;
   uint32_t row_index;
   uint32_t num_distance_symbols;
-  uint32_t pad;
+  uint32_t mode;  // kCodeOptimized / kCodePlain / kCodeFast / kCodeStatic (metablock_fast.h)
 };
 
 size_t mb_scan_scratch_bytes(size_t n);

@@ -4,7 +4,7 @@
 #ifndef BROTLI_MI355X_METABLOCK_ITEMS_H_
 #define BROTLI_MI355X_METABLOCK_ITEMS_H_
 
-#include "metablock_device.h"
+#include "metablock_fast.h"
 
 #if defined(BROTLI_HOST_EMU)
 #define BR_TID 0
@@ -235,6 +235,25 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
   uint16_t* gran_block = B.gran_block[kind] + d.granule_base[kind];
   const uint32_t max_histos = d.max_histos[kind];
   const uint32_t W = nc * row;
+  if (d.simple != 0) {
+    // qualities 2 / 3: one block type per kind, its histogram is that of the whole meta-block (BuildHistograms,
+    // brotli_bit_stream.rs:2263-2290)
+    for (uint32_t j = BR_TID; j < row; j += BR_NT) {
+      uint32_t acc = 0;
+      for (uint32_t q = 0; q < n_gran; ++q) acc += G[(size_t)q * row + j];
+      H[j] = acc;
+    }
+    for (uint32_t q = BR_TID; q < n_gran; q += BR_NT) gran_block[q] = 0;
+    if (BR_TID == 0) {
+      types[0] = 0;
+      lengths[0] = n_symbols;
+      MbResult& r = B.results[m];
+      r.num_types[kind] = 1;
+      r.num_blocks[kind] = 1;
+      r.num_histos[kind] = 1;
+    }
+    return;
+  }
 
   // uniform control state (every thread keeps a copy)
   uint32_t num_blocks = 0, num_types = 0, block_size = 0, target = min_block, curr_ix = 0, merge_count = 0;
@@ -429,13 +448,33 @@ BR_DEV void mb_item_split_chain(const MbBuffers& B, uint32_t m, uint32_t kind, S
 // same scalar work (stores of identical values, ORs of identical bits), which costs nothing extra on SIMT hardware and
 // lets the O(n^2 / 64) sort inside use all lanes.
 BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols, uint32_t* h, uint8_t* depth, uint16_t* bits,
-                                   uint64_t* words, HuffmanScratch* sc, bool coop = false) {
+                                   uint64_t* words, HuffmanScratch* sc, bool coop = false, uint32_t mode = kCodeOptimized) {
   const uint32_t row = kRowLen[kind];
+  if (mode == kCodeFast || mode == kCodeStatic) {
+    // quality 2 (metablock_fast.h)
+    for (uint32_t i = 0; i < row; ++i) {
+      depth[i] = 0;
+      bits[i] = 0;
+    }
+    for (uint32_t i = 0; i < kTreeBitsWords; ++i) words[i] = 0;
+    BitSink sink;
+    sink.words = words;
+    sink.pos = 0;
+    if (mode == kCodeStatic) {
+      br_store_static_code(kind, depth, bits, sink);
+    } else {
+      uint32_t total = 0;
+      for (uint32_t i = 0; i < row; ++i) total += h[i];
+      const uint32_t max_bits = kind == kSplitLiteral ? 8u : (kind == kSplitCommand ? 10u : br_log2_floor_nonzero(num_distance_symbols - 1u) + 1u);
+      br_build_and_store_huffman_tree_fast(h, total, max_bits, sc, depth, bits, sink);
+    }
+    return (uint32_t)sink.pos;
+  }
   // BrotliOptimizeHistograms (metablock.rs:1076-1108): literal 256, command 704, distance min(alphabet, 544)
   uint32_t opt_len = row;
   if (kind == kSplitDistance) opt_len = num_distance_symbols < kNumDistanceHistoSymbols ? num_distance_symbols : kNumDistanceHistoSymbols;
   BR_PHASE_CLOCK();
-  br_optimize_huffman_counts_for_rle(opt_len, h, sc->good_for_rle, coop);
+  if (mode == kCodeOptimized) br_optimize_huffman_counts_for_rle(opt_len, h, sc->good_for_rle, coop);
   BR_PHASE(9);
   // build_and_store_entropy_codes (brotli_bit_stream.rs:1860-1889): histogram_length = row (distance:
   // num_effective_distance_symbols), alphabet_size = 256 / 704 / num_distance_symbols
@@ -459,11 +498,11 @@ BR_DEV uint32_t mb_build_code_core(uint32_t kind, uint32_t num_distance_symbols,
 }
 
 BR_DEV void mb_item_build_code(const MbBuffers& B, uint32_t kind, uint32_t row_index, uint32_t num_distance_symbols,
-                               HuffmanScratch* sc) {
+                               HuffmanScratch* sc, uint32_t mode = kCodeOptimized) {
   const uint32_t row = kRowLen[kind];
   B.tree_nbits[kind][row_index] =
       mb_build_code_core(kind, num_distance_symbols, B.histo[kind] + (size_t)row_index * row, B.depth[kind] + (size_t)row_index * row,
-                         B.bits[kind] + (size_t)row_index * row, B.tree_bits[kind] + (size_t)row_index * kTreeBitsWords, sc);
+                         B.bits[kind] + (size_t)row_index * row, B.tree_bits[kind] + (size_t)row_index * kTreeBitsWords, sc, false, mode);
 }
 
 BR_DEV void mb_append_bits(BitSink& out, const uint64_t* words, uint32_t nbits) {

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void k_build_codes(MbBuffers B, const CodeJob* 
   for (uint32_t k = threadIdx.x; k < row; k += 64) h[k] = gh[k];
   __syncthreads();
   {
-    const uint32_t nb = mb_build_code_core(j.kind, j.num_distance_symbols, h, depth, bits, words, &sc, true);
+    const uint32_t nb = mb_build_code_core(j.kind, j.num_distance_symbols, h, depth, bits, words, &sc, true, j.mode);
     if (threadIdx.x == 0) nbits = nb;
   }
   __syncthreads();

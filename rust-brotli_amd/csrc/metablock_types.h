@@ -58,7 +58,7 @@ struct MbDesc {
   uint32_t hq_no_context;       // disable_literal_context_modeling: one literal histogram row per block type
   uint32_t hq_ctx_row_base[2];  // first row of this meta-block in the context histogram pools (literal, distance)
   uint32_t hq_ctx_map_base[2];  // first entry in the context map pools (num_types << 6 literal, << 2 distance)
-  uint32_t pad2;
+  uint32_t simple;              // 0: greedy splitter (quality >= 4); 1 / 2: the one-block-type writers of quality 3 / 2 (metablock_fast.h)
 };
 
 // Results of the greedy splitters and the header pass, one per meta-block.

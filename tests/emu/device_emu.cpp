@@ -16,6 +16,7 @@
 #include "../../rust-brotli_amd/csrc/lz77_chain.h"
 #include "../../rust-brotli_amd/csrc/lz77_rows.h"
 #include "../../rust-brotli_amd/csrc/zopfli_device.h"
+#include "../../rust-brotli_amd/csrc/quick_device.h"
 #include "../../tables/brotli_tables.h"
 #include "../../tables/brotli_static_dict_lut.h"
 
@@ -793,6 +794,23 @@ bool lz77_zopfli_block(const Lz77Params& P, const Lz77Buffers& B, const ZopfliJo
   }
   if (redo) br_zopfli_parse(Z, T, ZB, B.text, seg, B.entries[block], ctl, false, B.cmds + seg.cmd_base, B.exits + block);
   return redo;
+}
+
+// ---- qualities 2 .. 4 (quick_device.h): the same item code, called directly
+void lz77_quick_init(const QuickJob& J) { memset(J.table, 0, (size_t)quick_table_words(J) * 4); }
+void lz77_quick_import(const QuickJob& J, const uint32_t* table_src, uint32_t delta) {
+  const uint32_t slots = quick_slots(J), words = quick_table_words(J);
+  for (uint32_t i = 0; i < words; ++i) J.table[i] = i < slots ? (table_src[i] >= delta ? table_src[i] - delta : 0u) : table_src[i];
+}
+void lz77_quick_prepend(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, uint32_t dict_bytes) { br_quick_prepend(J, B.text, dict_bytes); }
+void lz77_quick_block(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, uint32_t block) {
+  const DeviceTables& dt = dev_tables();
+  QuickTables T;
+  T.dict_hash = dt.dict_hash;
+  T.dict_data = dt.dict_data;
+  T.dict_offsets_by_length = dt.dict_offsets_by_length;
+  const Segment seg = B.segments[block];
+  br_quick_block(J, P, T, B.text, seg, B.entries[block], B.cmds + seg.cmd_base, B.exits + block);
 }
 
 }  // namespace brotli_mi355x

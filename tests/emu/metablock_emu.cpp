@@ -89,7 +89,7 @@ void mb_split_chains(const MbBuffers& B, bool /*wide*/) {
 }
 
 void mb_build_codes(const MbBuffers& B, const CodeJob* jobs, uint32_t n_jobs) {
-  for (uint32_t i = 0; i < n_jobs; ++i) mb_item_build_code(B, jobs[i].kind, jobs[i].row_index, jobs[i].num_distance_symbols, B.huff_scratch);
+  for (uint32_t i = 0; i < n_jobs; ++i) mb_item_build_code(B, jobs[i].kind, jobs[i].row_index, jobs[i].num_distance_symbols, B.huff_scratch, jobs[i].mode);
 }
 
 void mb_write_headers(const MbBuffers& B) {

@@ -1,7 +1,8 @@
 """Randomised sweep over the stream operations and the multi-shard entry point (not a test): fuzz_api.py <cases> <seed>
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
 oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10).
-FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB."""
+FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB.
+FUZZ_QUICK=1: every case at quality 2, 3 or 4 (row f3: the BasicHasher family, quick_device.h), windows down to lgwin 10."""
 import os, sys, time
 import synth, orc
 import test_cabi
@@ -20,6 +21,8 @@ for c in range(cases):
     n = 1 + rng.next() % (1200000 if rng.next() % 3 else 5000)
     if os.environ.get("FUZZ_TINY"):
         n = rng.next() % 300
+    if os.environ.get("FUZZ_MAXN"):
+        n = 1 + n % int(os.environ["FUZZ_MAXN"])
     o = rng.next() % (len(pool) - n)
     d = pool[o:o + n]
     q = 5 + rng.next() % 5
@@ -33,6 +36,9 @@ for c in range(cases):
             n = 1 + n % 300000
             d = pool[o:o + n]
     w = [17, 18, 20, 22, 24][rng.next() % 5]
+    if os.environ.get("FUZZ_QUICK"):
+        q = 2 + rng.next() % 3
+        w = [10, 13, 16, 17, 18, 20, 22, 24][rng.next() % 8]
     mode = rng.next() % 6
     if q95 and mode == 5:
         mode = 4  # (orc.writer_compress takes quality and window only)

@@ -45,6 +45,21 @@ def test_api_sweep_quality_10_11_emulation():
     assert " 0 failures" in _run("fuzz_api.py", 25, 13, "emu", FUZZ_ZOPFLI="11")
 
 
+def test_api_sweep_quality_2_4_emulation():
+    """every stream operation, the multi-shard entry and custom dictionaries at qualities 2 .. 4 (row f3: the BasicHasher family,
+    quick_device.h), windows from lgwin 10"""
+    import emu
+    emu.build()
+    assert " 0 failures" in _run("fuzz_api.py", 150, 21, "emu", FUZZ_QUICK="1")
+    assert " 0 failures" in _run("fuzz_api.py", 100, 22, "emu", FUZZ_QUICK="1", FUZZ_TINY="1")
+
+
+@pytest.mark.gpu
+def test_api_sweep_quality_2_4_device():
+    assert " 0 failures" in _run("fuzz_api.py", 16, 21, FUZZ_QUICK="1", FUZZ_MAXN="150000")
+    assert " 0 failures" in _run("fuzz_api.py", 20, 22, FUZZ_QUICK="1", FUZZ_TINY="1")
+
+
 @pytest.mark.gpu
 def test_api_sweep_quality_10_11_device():
     assert " 0 failures" in _run("fuzz_api.py", 8, 12, FUZZ_ZOPFLI="10", FUZZ_TINY="1")
