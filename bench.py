@@ -64,6 +64,39 @@ def source_fingerprint():
     return h.hexdigest()[:12]
 
 
+def kernel_fingerprint(unit="lz77_kernels.hip"):
+    """sha256 over one translation unit of the library: `unit` and every file of rust-brotli_amd/csrc it includes, directly or not.
+    What a per-kernel measurement (PMC traffic, kernel shares) hangs on when other files of the library change: the code of the
+    kernels in that unit is compiled from exactly these files."""
+    import re
+    src = os.path.join(ROOT, "rust-brotli_amd", "csrc")
+    seen, todo = set(), [unit]
+    while todo:
+        name = todo.pop()
+        if name in seen or not os.path.exists(os.path.join(src, name)):
+            continue
+        seen.add(name)
+        todo += re.findall(r'^\s*#\s*include\s+"([^"/]+)"', open(os.path.join(src, name)).read(), re.M)
+    h = hashlib.sha256()
+    for name in sorted(seen):
+        h.update(name.encode())
+        h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def measured_on_these_sources(j):
+    """(usable, words) for a summary under profiles/: measured on this very source tree, or at least on the same sources of the
+    LZ77 kernels' translation unit (the rest of the library has changed since)"""
+    here, unit = source_fingerprint(), kernel_fingerprint()
+    if j.get("source_fingerprint") == here:
+        return True, "same library sources as this run: fingerprint %s" % here
+    if j.get("kernel_fingerprint") == unit:
+        return True, ("same sources of the kernels' translation unit as this run (lz77_kernels.hip and the headers it includes: fingerprint %s); "
+                      "other files of the library have changed since (whole-library fingerprint then %s, now %s)" % (unit, j.get("source_fingerprint"), here))
+    return False, "measured on other library sources (fingerprint %s / kernels %s; this run: %s / %s)" % (
+        j.get("source_fingerprint", "none recorded"), j.get("kernel_fingerprint", "none recorded"), here, unit)
+
+
 def frozen_hashes():
     p = os.path.join(ROOT, "tests", "golden", "large_hashes.json")
     return json.load(open(p)) if os.path.exists(p) else {}
@@ -167,8 +200,9 @@ def dominant_kernel_from_profile(name):
         except Exception:
             continue
         rel = os.path.relpath(path, ROOT)
-        if j.get("source_fingerprint") != source_fingerprint():
-            return {"kernel": None, "source": "null: %s was measured on other library sources" % rel}
+        usable, words = measured_on_these_sources(j)
+        if not usable:
+            return {"kernel": None, "source": "null: %s was %s" % (rel, words)}
         kernels = j.get("kernels", {})
         if not kernels:
             return None
@@ -179,7 +213,7 @@ def dominant_kernel_from_profile(name):
             calls = max(1, c["FETCH_SIZE"].get("launches", 1))
             traffic = int((c["FETCH_SIZE"]["kib_total_both_calls"] + c["WRITE_SIZE"]["kib_total_both_calls"]) * 1024 / calls)
         return {"kernel": top[0], "share_of_gpu_time_pct": top[1].get("pct"), "avg_launch_ms": top[1].get("avg_ms"), "launches_both_calls": top[1].get("calls"),
-                "traffic_bytes_per_launch": traffic, "source": "%s (rocprofv3 --kernel-trace --stats + FETCH_SIZE / WRITE_SIZE passes, same library sources as this run)" % rel}
+                "traffic_bytes_per_launch": traffic, "source": "%s (rocprofv3 --kernel-trace --stats + FETCH_SIZE / WRITE_SIZE passes; %s)" % (rel, words)}
     return None
 
 
@@ -506,7 +540,6 @@ def main():
     # PMC counters cannot be collected inside this run: the figure is quoted from the newest profiles/r*_pmc_parse.json -- but only
     # if that summary was measured on THIS source tree (fingerprint of rust-brotli_amd/csrc/*); otherwise traffic is null
     traffic, traffic_src = None, None
-    here = source_fingerprint()
     import glob as _glob
     for pmc in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_parse.json")), reverse=True):
         try:
@@ -514,12 +547,12 @@ def main():
         except Exception:
             continue
         rel = os.path.relpath(pmc, ROOT)
-        if j.get("source_fingerprint") == here:
+        usable, words = measured_on_these_sources(j)
+        if usable:
             traffic = j.get("hbm_bytes_per_launch")
-            traffic_src = "%s (rocprofv3 PMC passes of commit %s, same library sources as this run: fingerprint %s; not measured inside this run)" % (rel, j.get("commit", "?"), here)
+            traffic_src = "%s (rocprofv3 PMC passes of commit %s; %s; not measured inside this run)" % (rel, j.get("commit", "?"), words)
         else:
-            traffic_src = "null: %s was measured on other library sources (fingerprint %s, commit %s; this run: %s) -- re-take with tools/profile_round.sh" % (
-                rel, j.get("source_fingerprint", "none recorded"), j.get("commit", "?"), here)
+            traffic_src = "null: %s (commit %s) was %s -- re-take with tools/profile_round.sh" % (rel, j.get("commit", "?"), words)
         break
     line = {
         "metric": "compress MB/s at q5 lgwin22", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,

@@ -22,7 +22,7 @@ import csv, glob, json, os, sys, collections
 out, tag, name = sys.argv[1:4]
 sys.path.insert(0, os.path.dirname(out.rstrip("/")))
 import bench
-res = {"workload": name, "source_fingerprint": bench.source_fingerprint()}
+res = {"workload": name, "source_fingerprint": bench.source_fingerprint(), "kernel_fingerprint": bench.kernel_fingerprint()}
 for line in open(os.path.join(out, "%s_%s_kt.log" % (tag, name))):
     if line.startswith("{"):
         res["library"] = json.loads(line)

@@ -59,7 +59,7 @@ def main():
             return c.get(name, {}).get("avg_per_launch")
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
-        pm = {"kernel": "k_parse_segments", "commit": sys.argv[3] if len(sys.argv) > 3 else "?", "source_fingerprint": bench.source_fingerprint(),
+        pm = {"kernel": "k_parse_segments", "commit": sys.argv[3] if len(sys.argv) > 3 else "?", "source_fingerprint": bench.source_fingerprint(), "kernel_fingerprint": bench.kernel_fingerprint(),
               "source": "rocprofv3 --pmc passes (one counter group per run) of `python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras`, tools/profile_round.sh " + tag,
               "launches": c["FETCH_SIZE"]["launches"], "fetch_kib_per_launch": avg("FETCH_SIZE"), "write_kib_per_launch": avg("WRITE_SIZE"),
               "hbm_bytes_per_launch": res["k_parse_segments_hbm"]["hbm_bytes_per_launch"],
