@@ -22,6 +22,7 @@
 #include "device_api.h"
 #include "encoder.h"
 #include "encoder_params.h"
+#include "fragment_stream.h"
 
 using namespace brotli_mi355x;
 
@@ -60,6 +61,7 @@ struct BrotliEncoderStateStruct {
   // the output) followed by the input that has not been encoded yet.  Older bytes are dropped (bounded memory).
   size_t encoded_upto;
   StreamCarry carry;
+  FragmentStream fragments;  // qualities 0 and 1: the stream never enters the ring-buffer path (fragment_stream.h)
   bool metadata_draining;  // an EMIT_METADATA operation whose output has not been fully taken yet
   size_t next_batch_try;   // PROCESS: do not try another partial piece before this much input is pending
 };
@@ -499,7 +501,20 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     s->first_encode_seen = true;
     if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
     const size_t n_meta = *available_in;
-    if (!EncodeBuffered(s, false, true, n_meta)) return BROTLI_FALSE;
+    if (IsFragmentStream(s->params)) {
+      // (qualities 0 / 1: nothing is ever pending in a ring buffer; the header goes behind the open byte, encode.rs:2630-2640)
+      try {
+        if (s->output_pos != 0) {
+          s->output.erase(s->output.begin(), s->output.begin() + (ptrdiff_t)s->output_pos);
+          s->output_pos = 0;
+        }
+        FragmentStreamMetadataHeader(s->params, &s->fragments, n_meta, &s->output);
+      } catch (const std::exception& e) {
+        SetError("BrotliEncoderCompressStream", e.what());
+        s->failed = true;
+        return BROTLI_FALSE;
+      }
+    } else if (!EncodeBuffered(s, false, true, n_meta)) return BROTLI_FALSE;
     s->output.insert(s->output.end(), *next_in, *next_in + n_meta);
     *next_in += n_meta;
     *available_in = 0;
@@ -507,7 +522,26 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     }
   }
   if (s->stream_state != kProcessing && *available_in != 0) return BROTLI_FALSE;  // encode.rs:2918-2922
-  if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA) {
+  if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA && IsFragmentStream(s->params)) {
+    // BrotliEncoderCompressStreamFast, encode.rs:2706-2861: the input of THIS call, cut into fragments of at most 1 << lgwin bytes,
+    // is compressed right away (fragment_stream.h); nothing is buffered
+    try {
+      if (s->output_pos != 0) {
+        s->output.erase(s->output.begin(), s->output.begin() + (ptrdiff_t)s->output_pos);
+        s->output_pos = 0;
+      }
+      const size_t n = *available_in;
+      FragmentStreamCompress(s->params, &s->fragments, *next_in, n, op == BROTLI_OPERATION_FINISH, op == BROTLI_OPERATION_FLUSH, &s->output);
+      s->total_in += n;
+      *next_in += n;
+      *available_in = 0;
+      if (op == BROTLI_OPERATION_FINISH) s->stream_state = kFinished;
+    } catch (const std::exception& e) {
+      SetError("BrotliEncoderCompressStream", e.what());
+      s->failed = true;
+      return BROTLI_FALSE;
+    }
+  } else if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA) {
     // FINISH without input right behind a full input block: the reference has run that block through encode_data already
     // (it does so as soon as a block is full, encode.rs:2959-2964), not knowing it was the last one
     const bool early_last = op == BROTLI_OPERATION_FINISH && *available_in == 0 && s->total_in != 0 && (s->total_in % BlockSize(s->params)) == 0;
@@ -587,7 +621,9 @@ void BrotliEncoderSetCustomDictionary(BrotliEncoderState* s, size_t size, const 
   if (!s) return;
   EnsureInitialized(s);
   s->params.use_dictionary = false;
-  if (size == 0 || size <= 1) {
+  EncoderParams fin = s->params;
+  FinalizeParams(&fin);
+  if (size == 0 || size <= 1 || fin.quality == 0 || fin.quality == 1) {  // (qualities 0 / 1 take no dictionary, encode.rs:1237-1241)
     // too short: the reference only turns on catable + appendable (encode.rs:1237-1241)
     s->params.catable = true;
     s->params.appendable = true;
@@ -687,7 +723,7 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
   // encode.rs:1468-1481: the one-shot entry runs quality 10 ("9.5") at quality 9, with an H9 hasher made ahead of time from
   // {q9_5, quality 10} -- the hasher quality 9 selects anyway.  (Quality 10 / 11 through the stream API are Zopfli.)
   if (quality == 10) quality = 9;
-  if (!input_on_device && input_size > OneShotStreamThreshold()) {
+  if (!input_on_device && quality > 1 && input_size > OneShotStreamThreshold()) {
     size_t n = out_size;
     const int r = CompressOneShotStreamed(quality, lgwin, mode, input_size, input, &n, encoded);
     if (r == 1 && !(max_out_size != 0 && n > max_out_size)) {
@@ -715,7 +751,14 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
     req.input_size = input_size;
     req.input_on_device = input_on_device;
     EncodeStats st;
-    EncodeStream(req, &out, &st);
+    if (IsFragmentStream(req.params)) {
+      // qualities 0 and 1: compress_stream(FINISH) takes the fragment path (encode.rs:2929-2937)
+      if (input_on_device) throw std::runtime_error("qualities 0 and 1 take their input from host memory");
+      FragmentStream fs;
+      FragmentStreamCompress(req.params, &fs, input, input_size, true, false, &out);
+    } else {
+      EncodeStream(req, &out, &st);
+    }
     if (stats_out) {
       stats_out[0] = st.lz77_rounds;
       stats_out[1] = (double)st.searches;

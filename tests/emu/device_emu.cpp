@@ -17,6 +17,7 @@
 #include "../../rust-brotli_amd/csrc/lz77_rows.h"
 #include "../../rust-brotli_amd/csrc/zopfli_device.h"
 #include "../../rust-brotli_amd/csrc/quick_device.h"
+#include "../../rust-brotli_amd/csrc/fragment_device.h"
 #include "../../tables/brotli_tables.h"
 #include "../../tables/brotli_static_dict_lut.h"
 
@@ -811,6 +812,18 @@ void lz77_quick_block(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
   T.dict_offsets_by_length = dt.dict_offsets_by_length;
   const Segment seg = B.segments[block];
   br_quick_block(J, P, T, B.text, seg, B.entries[block], B.cmds + seg.cmd_base, B.exits + block);
+}
+
+// ---- qualities 0 and 1 (fragment_device.h): the same item code, called directly
+void frag_compress(int quality, const uint8_t* input, uint32_t input_size, bool is_last, uint32_t table_bits, const FragmentBuffers& B, uint8_t* out) {
+  const DeviceTables& dt = dev_tables();
+  EntropyTables et;
+  et.logs_16 = dt.logs_16;
+  et.logs_8 = dt.logs_8;
+  memset(B.table, 0, ((size_t)1 << table_bits) * 4);
+  static thread_local FragmentScratch S;
+  static thread_local uint64_t cmd_code_words[kTreeBitsWords];
+  br_fragment(quality, et, input, input_size, is_last, table_bits, B, out, S, cmd_code_words);
 }
 
 }  // namespace brotli_mi355x

@@ -2,6 +2,8 @@
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
 oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10).
 FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB.
+FUZZ_FRAGMENT=1: every case at quality 0 or 1 (row f3: the fragment compressors, fragment_device.h) -- the stream operations, extra
+parameters and the writer pattern; no catable streams, dictionaries or shards (the ring-buffer path at these qualities is not implemented).
 FUZZ_QUICK=1: every case at quality 2, 3 or 4 (row f3: the BasicHasher family, quick_device.h), windows down to lgwin 10."""
 import os, sys, time
 import synth, orc
@@ -40,12 +42,17 @@ for c in range(cases):
         q = 2 + rng.next() % 3
         w = [10, 13, 16, 17, 18, 20, 22, 24][rng.next() % 8]
     mode = rng.next() % 6
+    fragment = bool(os.environ.get("FUZZ_FRAGMENT"))
+    if fragment:
+        q = rng.next() % 2
+        w = [10, 13, 16, 17, 18, 20, 22, 24][rng.next() % 8]
+        mode = [1, 2, 4, 5][rng.next() % 4]
     if q95 and mode == 5:
         mode = 4  # (orc.writer_compress takes quality and window only)
     base = [(Q, q), (W, w)] + ([(150, 1)] if q95 else [])
     extra = []
     for pid in (167, 168, 169, 172):  # catable, appendable, magic number, byte align
-        if rng.next() % 4 == 0:
+        if rng.next() % 4 == 0 and not (fragment and pid == 167):
             extra.append((pid, 1))
     if rng.next() % 3 == 0:
         extra.append((5, [1, 1000, 1 << 20, (1 << 20) + 1, 5 << 20][rng.next() % 5]))  # size hint
@@ -54,7 +61,7 @@ for c in range(cases):
         open(os.environ["FUZZ_TRACE"], "wb").write(d)
     # flushes on catable / appendable streams and streams with a custom dictionary (row f4): a third of the flush cases
     fparams, fdic = base, None
-    if mode in (1, 2) and rng.next() % 3 == 0:
+    if mode in (1, 2) and rng.next() % 3 == 0 and not fragment:
         fparams = base + [x for x in extra if x[0] != 5]
         if rng.next() % 2:
             mdic = 2 + rng.next() % 300000

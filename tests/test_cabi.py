@@ -182,9 +182,10 @@ def _suite(lib):
     # unsupported parameters fail loudly instead of silently doing something else
     import brotli_mi355x as _m  # noqa: F401
     with pytest.raises(Exception):
-        lib.compress(a, 1, 22)  # (qualities 0 and 1 are not on the device: refused with a message, never routed elsewhere)
-    # qualities 2 .. 4 through the one-shot entry (round 4: the BasicHasher family is on the device): the oracle's bytes
-    for q in (2, 3, 4):
+        lib.BrotliCompress(a, {Q: 1}, 2)  # (shards at quality 0 / 1 would be catable streams: refused with a message, never routed elsewhere)
+    # qualities 0 .. 4 through the one-shot entry (round 4: the fragment compressors and the BasicHasher family are on the device):
+    # the oracle's bytes
+    for q in (0, 1, 2, 3, 4):
         assert lib.compress(a[:60000], q, 22) == orc.compress(a[:60000], q, 22), q
     # quality 11 through the one-shot entry (round 4: the Zopfli path is on the device): the oracle's bytes
     assert lib.compress(a[:40000], 11, 22) == orc.compress(a[:40000], 11, 22)

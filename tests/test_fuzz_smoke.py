@@ -54,6 +54,21 @@ def test_api_sweep_quality_2_4_emulation():
     assert " 0 failures" in _run("fuzz_api.py", 100, 22, "emu", FUZZ_QUICK="1", FUZZ_TINY="1")
 
 
+def test_api_sweep_quality_0_1_emulation():
+    """the stream operations, extra parameters and the writer pattern at qualities 0 and 1 (row f3: the fragment compressors,
+    fragment_device.h), windows from lgwin 10"""
+    import emu
+    emu.build()
+    assert " 0 failures" in _run("fuzz_api.py", 200, 31, "emu", FUZZ_FRAGMENT="1")
+    assert " 0 failures" in _run("fuzz_api.py", 150, 32, "emu", FUZZ_FRAGMENT="1", FUZZ_TINY="1")
+
+
+@pytest.mark.gpu
+def test_api_sweep_quality_0_1_device():
+    assert " 0 failures" in _run("fuzz_api.py", 16, 31, FUZZ_FRAGMENT="1", FUZZ_MAXN="150000")
+    assert " 0 failures" in _run("fuzz_api.py", 20, 32, FUZZ_FRAGMENT="1", FUZZ_TINY="1")
+
+
 @pytest.mark.gpu
 def test_api_sweep_quality_2_4_device():
     assert " 0 failures" in _run("fuzz_api.py", 16, 21, FUZZ_QUICK="1", FUZZ_MAXN="150000")

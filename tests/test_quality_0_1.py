@@ -1,0 +1,129 @@
+"""Qualities 0 and 1: compress_fragment (one pass) and compress_fragment_two_pass as device code
+(rust-brotli_amd/csrc/fragment_device.h: one wavefront per fragment), behind what BrotliEncoderCompressStream does instead of the
+ring-buffer path at these qualities (BrotliEncoderCompressStreamFast, encode.rs:2706-2861; fragment_stream.cpp): every call's input
+is cut into fragments of at most 1 << lgwin bytes, each on a fresh hash table; the stream carries the open byte and, at quality 0,
+the command prefix code.
+
+The reference holds no exact size for these qualities; everything is byte identity with the oracle (oracle/orc_fragment.c), which
+tests/test_oracle_vs_libbrotlienc.py holds against libbrotlienc 1.0.9 for the same qualities.  Not implemented, like in the
+oracle: what the reference sends through the ring-buffer path at these qualities (catable streams, and with them custom
+dictionaries and BrotliEncoderCompressMulti shards) -- refused with a message.  CPU: the emulation build; -m gpu: the product library."""
+import glob
+import os
+
+import pytest
+
+import orc
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+Q, W, SH, LARGE = 1, 2, 5, 6
+
+
+def _one_shot(lib, small):
+    """BrotliEncoderCompress: one FINISH with everything -> fragments of 1 << lgwin bytes"""
+    a = synth.alice()
+    cases = [("alice", a, 22), ("alice w16 (three fragments)", a, 16), ("alice w10 (149 fragments)", a, 10), ("alice w24", a, 24),
+             ("zeros", bytes(300000), 22), ("random (stored raw)", synth.random_bytes(200000), 22), ("3 bytes", b"abc", 22),
+             ("15 bytes (below the input margin)", a[:15], 22), ("16 bytes", a[:16], 22), ("empty", b"", 22),
+             ("markov 1.5 MiB w20 (two fragments)", synth.markov_text(3 << 19, 5), 20), ("mixed 1 MiB w18", synth.mixed(1 << 20, 3), 18)]
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))):
+        cases.append((os.path.basename(f), open(f, "rb").read(), 22))
+    if not small:
+        cases += [("silesia-like 3 MiB", synth.silesia_like(3 << 20, 4), 22), ("stretches 2 MiB w17", synth.stretches(2 << 20, 9), 17),
+                  ("random_then_unicode", open(os.path.join(GOLDEN, "random_then_unicode"), "rb").read(), 22),
+                  ("text 5 MiB w22 (a block past the 1 MiB merge limit)", synth.markov_text(5 << 20, 6), 22)]
+    bad = []
+    for name, d, w in cases:
+        for q in (0, 1):
+            got = lib.compress(d, q, w)
+            if got != orc.compress(d, q, w) or orc.decompress(got, len(d)) != d:
+                bad.append((name, q, w))
+    assert not bad, bad
+
+
+def _streams(lib, small):
+    """the stream operations: every PROCESS / FLUSH / FINISH call is compressed on the spot, fragment boundaries are call boundaries;
+    FLUSH seals the open byte with an empty metadata block; EMIT_METADATA writes its header behind the open byte"""
+    d = synth.mixed(300000 if small else 900000, 7)
+    n = len(d)
+    for q, w, cuts in ((0, 22, [n // 3, 2 * n // 3 + 1]), (1, 16, [0, 70000, 70001, n // 2]), (0, 18, [5]), (1, 22, [n // 5, n // 2]), (0, 10, [1000, 1001, 3000])):
+        params = [(Q, q), (W, w)]
+        e = lib.encoder(params=params)
+        pieces, last = [], 0
+        for c in cuts:
+            pieces.append(e.flush(d[last:c]))
+            last = c
+        e.write(d[last:])
+        pieces.append(e.finish())
+        e.close()
+        assert pieces == orc.stream_with_flushes(d, params, cuts), (q, w, cuts)
+    # metadata blocks between pieces, extra parameters (none of them changes the fragment path), the writer pattern
+    for q in (0, 1):
+        params = [(Q, q), (W, 20), (168, 1), (169, 1), (172, 1), (SH, 12345)]
+        ops = [(0, b"first"), n // 4, (n // 2, b"M" * 300), n // 2 + 10]
+        e = lib.encoder(params=params)
+        pieces, pos = [], 0
+        for item in ops:
+            if isinstance(item, tuple):
+                if item[0] > pos:
+                    e.write(d[pos:item[0]])
+                pieces.append(e.emit_metadata(item[1]))
+                pos = item[0]
+            else:
+                pieces.append(e.flush(d[pos:item]))
+                pos = item
+        e.write(d[pos:])
+        pieces.append(e.finish())
+        e.close()
+        assert pieces == orc.stream_with_flushes(d, params, ops), q
+        for chunk in (1000, 65536, 100000):
+            e = lib.encoder(params=[(Q, q), (W, 22)])
+            for i in range(0, n, chunk):
+                e.write(d[i:i + chunk])
+            got = e.finish()
+            e.close()
+            assert got == orc.writer_compress(d, q, 22, chunk=chunk), (q, chunk)
+            assert orc.decompress(got, n) == d
+
+
+def _refusals(lib):
+    a = synth.alice()
+    for q in (0, 1):
+        with pytest.raises(Exception, match="catable|ring-buffer|not implemented"):
+            e = lib.encoder(params=[(Q, q), (W, 22), (167, 1)])
+            try:
+                e.write(a)
+                e.finish()
+            finally:
+                e.close()
+        with pytest.raises(Exception):
+            lib.BrotliCompress(a, {Q: q, W: 22}, 2)  # shards are catable streams
+
+
+def test_one_shot_emu():
+    import test_cabi
+    _one_shot(test_cabi._load("emu"), small=False)
+
+
+def test_streams_emu():
+    import test_cabi
+    _streams(test_cabi._load("emu"), small=False)
+
+
+def test_what_is_refused_emu():
+    import test_cabi
+    _refusals(test_cabi._load("emu"))
+
+
+@pytest.mark.gpu
+def test_one_shot_gpu():
+    import test_cabi
+    _one_shot(test_cabi._load("gpu"), small=True)
+
+
+@pytest.mark.gpu
+def test_streams_gpu():
+    import test_cabi
+    _streams(test_cabi._load("gpu"), small=True)
