@@ -99,7 +99,8 @@ Q, W, SH = 1, 2, 5
 small = %(small)r
 for name, d, q, w, chunk in (("markov, quality 2, lgwin 18", synth.markov_text((3 << 19) if small else (5 << 19), 11), 2, 18, 65536),
                              ("mixed, quality 3, lgwin 16", synth.mixed((2 << 19) if small else (3 << 19), 12), 3, 16, 100003),
-                             ("silesia-like, quality 4, lgwin 20", synth.silesia_like((2 << 19) if small else (4 << 19), 13), 4, 20, 4096)):
+                             # (a meta-block holds up to 1 << min(lgwin + 1, 24) bytes: the window is chosen so that several close inside the input)
+                             ("silesia-like, quality 4", synth.silesia_like((2 << 19) if small else (4 << 19), 13), 4, 17 if small else 20, 4096)):
     params = [(Q, q), (W, w)]
     e = lib.encoder(params=params)
     early = 0
