@@ -274,6 +274,52 @@ def other_workloads(torch, bm, lib, enc, frozen, work_fn=None):
         del data
     res.extend(quality_9_5_workloads(torch, bm, enc))
     res.extend(quality_10_11_workloads(torch, bm, enc))
+    res.extend(quality_0_4_workloads(bm, lib))
+    return res
+
+
+def quality_0_4_workloads(bm, lib):
+    """qualities 0..4 on the device -- the fragment compressors (fragment_device.h) and the BasicHasher family under
+    the greedy / lazy parse (quick_device.h), one wavefront per stream -- on 2 MiB of the text generator through BrotliEncoderCompress
+    (host buffers in and out), and the stream-level parallelism such a path has: 16 MiB through BrotliEncoderCompressMulti as 16
+    shards at quality 2.  Each compared with the oracle run here (one core), whose rate stands beside it."""
+    import orc
+    import synth
+    res = []
+    data = synth.markov_text(2 << 20)
+    for quality in (0, 1, 2, 3, 4):
+        entry = {"workload": "q%d_text_2MiB" % quality, "input_bytes": len(data), "quality": quality, "lgwin": 22,
+                 "residency": "host buffers in and out (BrotliEncoderCompress)",
+                 "path": "one wavefront per stream on the reference's own hash table (DESIGN.md section 3.10)"}
+        try:
+            lib.compress(data[:65536], quality, 22)
+            t0 = time.time()
+            out = lib.compress(data, quality, 22)
+            sec = time.time() - t0
+            t0 = time.time()
+            want = orc.compress(data, quality, 22)
+            cpu_s = time.time() - t0
+            entry.update({"value": round(len(data) / sec / 1e6, 3), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out),
+                          "identical_to_cpu_oracle": out == want,
+                          "cpu_oracle": {"value": round(len(data) / cpu_s / 1e6, 2), "unit": "MB/s", "cores": 1, "sample": "the same input, one run"}})
+        except Exception as e:
+            entry["error"] = repr(e)
+        res.append(entry)
+    try:
+        big = synth.markov_text(16 << 20, 77)
+        params = {bm.BROTLI_PARAM_QUALITY: 2, bm.BROTLI_PARAM_LGWIN: 22}
+        t0 = time.time()
+        out = bytes(lib.BrotliCompress(big, params, 16))
+        sec = time.time() - t0
+        t0 = time.time()
+        want = orc.compress_multi(big, [(bm.BROTLI_PARAM_QUALITY, 2), (bm.BROTLI_PARAM_LGWIN, 22)], 16)
+        cpu_s = time.time() - t0
+        res.append({"workload": "q2_text_16MiB_multi16", "input_bytes": len(big), "quality": 2, "lgwin": 22, "shards": 16,
+                    "residency": "host buffers in and out (BrotliEncoderCompressMulti)", "value": round(len(big) / sec / 1e6, 3), "unit": "MB/s",
+                    "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out), "identical_to_cpu_oracle": out == want,
+                    "cpu_oracle": {"value": round(len(big) / cpu_s / 1e6, 2), "unit": "MB/s", "cores": 1, "sample": "the same call, shards one after the other"}})
+    except Exception as e:
+        res.append({"workload": "q2_text_16MiB_multi16", "error": repr(e)})
     return res
 
 

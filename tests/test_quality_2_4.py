@@ -23,10 +23,9 @@ def _cases(small):
     a = synth.alice()
     for f in sorted(glob.glob(os.path.join(GOLDEN, "small", "*"))):
         d = open(f, "rb").read()
-        if small and len(d) > 20000:
-            continue
-        for q in (2, 3, 4):
-            yield "%s q%d" % (os.path.basename(f), q), d, [(Q, q), (W, 22), (SH, len(d))], b""
+        for q in (2, 3, 4):  # (the 13 fixtures of the reference's testdata at every quality, lgwin 18 and 22 -- on the device too)
+            for w in (18, 22):
+                yield "%s q%d w%d" % (os.path.basename(f), q, w), d, [(Q, q), (W, w), (SH, len(d))], b""
     h = len(a) // 2
     text = synth.markov_text(3 << 19 if not small else 300000, 5)
     for q in (2, 3, 4):
