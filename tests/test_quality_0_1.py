@@ -102,6 +102,26 @@ def _refusals(lib):
             lib.BrotliCompress(a, {Q: q, W: 22}, 2)  # shards are catable streams
 
 
+def _several_fragments(lib):
+    """12 MiB at lgwin 22: three fragments of one call, each on a fresh table, the command code of quality 0 handed on"""
+    d = synth.markov_text(12 << 20, 33)
+    for q in (0, 1):
+        got = lib.compress(d, q, 22)
+        assert got == orc.compress(d, q, 22), q
+        assert orc.decompress(got, len(d)) == d
+
+
+def test_several_fragments_emu():
+    import test_cabi
+    _several_fragments(test_cabi._load("emu"))
+
+
+@pytest.mark.gpu
+def test_several_fragments_gpu():
+    import test_cabi
+    _several_fragments(test_cabi._load("gpu"))
+
+
 def test_one_shot_emu():
     import test_cabi
     _one_shot(test_cabi._load("emu"), small=False)

@@ -124,6 +124,30 @@ def _streamed(kind, small):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def _past_the_ring_and_shards(lib, small):
+    """the default window on one stream past its first ring-buffer lap (8 MiB at lgwin 22: from there on the quads a copy files are
+    ring-buffer indices no search can reach, mod.rs:299-321), and the parallelism this path has: sixteen shards side by side"""
+    d = synth.markov_text(9 << 20, 31)
+    for q, w in ((3, 22),) if small else ((2, 22), (3, 22), (4, 21)):
+        got = lib.compress(d, q, w)
+        assert got == orc.compress(d, q, w), (q, w)
+    big = synth.markov_text((16 if small else 32) << 20, 32)
+    got = bytes(lib.BrotliCompress(big, {Q: 2, W: 22}, 16))
+    assert got == orc.compress_multi(big, [(Q, 2), (W, 22)], 16)
+    assert orc.decompress(got, len(big)) == big
+
+
+def test_past_the_ring_and_shards_emu():
+    import test_cabi
+    _past_the_ring_and_shards(test_cabi._load("emu"), small=False)
+
+
+@pytest.mark.gpu
+def test_past_the_ring_and_shards_gpu():
+    import test_cabi
+    _past_the_ring_and_shards(test_cabi._load("gpu"), small=True)
+
+
 def test_identity_with_the_oracle_emu():
     import emu
     _identity(emu.lib(), small=False)
