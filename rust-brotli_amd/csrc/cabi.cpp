@@ -235,8 +235,9 @@ class ShardWorkers {
     return *w;
   }
   // runs job(0) ... job(count - 1), each exactly once, on the calling thread and the helpers; rethrows the first exception
-  void Run(size_t count, const std::function<void(size_t)>& job) {
-    const size_t workers = std::min(count, WorkerCount());
+  // light: every job is one wavefront on a table of its own (qualities 2 .. 4, quick_device.h) -- all of them side by side
+  void Run(size_t count, const std::function<void(size_t)>& job, bool light = false) {
+    const size_t workers = std::min(count, light && WorkerCount() > 1 ? (size_t)16 : WorkerCount());
     if (workers <= 1) {
       for (size_t i = 0; i < count; ++i) job(i);
       return;
@@ -367,7 +368,10 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
       // the chunks are independent streams (compress_multi hands them to a worker pool, threading/mod.rs:333-453):
       // a few of them are in flight on the device at a time, each on the stream of its host thread
       std::vector<std::vector<uint8_t>> chunks(num_threads);
-      ShardWorkers::Get().Run(num_threads, [&](size_t t) { CompressChunk(params, input, input_size, false, t, num_threads, &chunks[t], nullptr); });
+      EncoderParams fin = params;
+      FinalizeParams(&fin);
+      ShardWorkers::Get().Run(num_threads, [&](size_t t) { CompressChunk(params, input, input_size, false, t, num_threads, &chunks[t], nullptr); },
+                              fin.quality < 5);
       // stitched straight into the caller's buffer
       ChunkStitcher stitcher;
       ByteSink sink(encoded, *encoded_size);

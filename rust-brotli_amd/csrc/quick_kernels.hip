@@ -36,12 +36,22 @@ void lz77_quick_import(const QuickJob& J, const uint32_t* table_src, uint32_t de
   HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(64) void k_quick_prepend(QuickJob J, const uint8_t* __restrict__ text, uint32_t dict_bytes) {
-  if (blockIdx.x != 0) return;
-  br_quick_prepend(J, text, dict_bytes);
+// HasherPrependCustomDictionary files the dictionary positions in ascending order into a table that holds nothing else yet
+// (lz77_quick_init comes first): what a slot ends up with is the LARGEST position filed under it -- one thread per position and
+// an atomic maximum give the table of the sequential loop (br_quick_prepend, which the emulation runs).  A shard of
+// BrotliEncoderCompressMulti is primed with up to a window of text in front of it, several times its own size.
+__global__ __launch_bounds__(256) void k_quick_prepend(QuickJob J, const uint8_t* __restrict__ text, uint32_t count) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const uint64_t v = (br_load64(text + i) << (64u - 8u * J.hash_len)) * kQuickHashMul64;
+    const uint32_t key = (uint32_t)(v >> (64u - J.bucket_bits));
+    atomicMax(J.table + key + ((i >> 3) & (J.sweep - 1u)), i);
+  }
 }
 void lz77_quick_prepend(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, uint32_t dict_bytes) {
-  hipLaunchKernelGGL(k_quick_prepend, dim3(1), dim3(64), 0, BR_STREAM, J, (const uint8_t*)B.text, dict_bytes);
+  if (dict_bytes <= kQuickHtl - 1u) return;
+  const uint32_t count = dict_bytes - (kQuickHtl - 1u);
+  const uint32_t blocks = (count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096;
+  hipLaunchKernelGGL(k_quick_prepend, dim3(blocks), dim3(256), 0, BR_STREAM, J, (const uint8_t*)B.text, count);
   HIP_CHECK(hipGetLastError());
 }
 
