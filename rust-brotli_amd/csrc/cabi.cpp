@@ -727,7 +727,10 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
   // encode.rs:1468-1481: the one-shot entry runs quality 10 ("9.5") at quality 9, with an H9 hasher made ahead of time from
   // {q9_5, quality 10} -- the hasher quality 9 selects anyway.  (Quality 10 / 11 through the stream API are Zopfli.)
   if (quality == 10) quality = 9;
-  if (!input_on_device && quality > 1 && input_size > OneShotStreamThreshold()) {
+  // (qualities 2 .. 4 walk their blocks one launch at a time with the host resolver replaying the stream so far in between: the
+  // pieces of the stream machine keep that replay short -- 16 KiB blocks, quadratic otherwise)
+  const size_t stream_above = (quality >= 2 && quality <= 4) ? std::min(OneShotStreamThreshold(), (size_t)64 << 20) : OneShotStreamThreshold();
+  if (!input_on_device && quality > 1 && input_size > stream_above) {
     size_t n = out_size;
     const int r = CompressOneShotStreamed(quality, lgwin, mode, input_size, input, &n, encoded);
     if (r == 1 && !(max_out_size != 0 && n > max_out_size)) {

@@ -29,7 +29,9 @@ else:
     import brotli_mi355x
     lib = brotli_mi355x.default_library()
 cases = [(synth.markov_text(5 << 20, 3), 5, 22), (synth.mixed(3 << 20, seed=4), 5, 18), (synth.markov_text((2 << 20) + 65536, 5), 7, 20),
-         (synth.random_bytes(1 << 21, 6) + synth.markov_text(1 << 20, 7), 5, 22), (synth.markov_text(1 << 21, 8), 9, 22)]
+         (synth.random_bytes(1 << 21, 6) + synth.markov_text(1 << 20, 7), 5, 22), (synth.markov_text(1 << 21, 8), 9, 22),
+         # qualities 2 .. 4 take the stream machine from 64 MiB on (here: from the scaled-down threshold): the table travels
+         (synth.markov_text(3 << 20, 9), 2, 22), (synth.mixed(3 << 20, seed=10), 3, 18), (synth.markov_text((2 << 20) + 12345, 11), 4, 20)]
 for data, q, w in cases:
     got = lib.compress(data, q, w)
     ref = orc.compress(data, q, w)
