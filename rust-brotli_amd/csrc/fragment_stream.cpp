@@ -1,6 +1,7 @@
 // fragment_stream.cpp -- see fragment_stream.h
 #include "fragment_stream.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -98,45 +99,56 @@ void FragmentStreamCompress(const EncoderParams& user_params, FragmentStream* fs
   EncoderParams p = user_params;
   FinalizeParams(&p);
   Start(p, fs);
-  if (size >= ((size_t)1 << 31)) throw std::runtime_error("brotli_mi355x: 2 GiB or more in one call are not supported at qualities 0 and 1, hand the input over in pieces");
   const size_t block_size_limit = (size_t)1 << p.lgwin;
   bool flush_requested = false;
   if (size != 0 || finish) {
-    // the fragments of this call, one after the other on the device; their bits land in one buffer
-    const size_t n_frag = std::max<size_t>(1, (size + block_size_limit - 1) / block_size_limit);
-    const size_t cap = 2 * size + 503 * n_frag + 64;
-    DevBuf in(size + 64, true), outb(cap + 64, true), table(((size_t)1 << 17) * 4 + 64), commands(((size_t)1 << 17) * 4 + 64), literals(((size_t)1 << 17) + 64),
+    // The fragments of this call, one after the other on the device.  They go in batches of whole fragments (about 64 MiB of input,
+    // at least one fragment) whose bits land in one buffer each: device memory stays bounded however much one call hands over.
+    static const size_t batch_target = getenv("BROTLI_MI355X_FRAGMENT_BATCH") ? (size_t)strtoull(getenv("BROTLI_MI355X_FRAGMENT_BATCH"), nullptr, 10) : ((size_t)64 << 20);
+    const size_t per_batch = std::max<size_t>(1, batch_target / block_size_limit);
+    const size_t batch_bytes = per_batch * block_size_limit;
+    const size_t in_cap = std::min(size, batch_bytes), cap = 2 * in_cap + 503 * per_batch + 64;
+    DevBuf in(in_cap + 64, true), outb(cap + 64, true), table(((size_t)1 << 17) * 4 + 64), commands(((size_t)1 << 17) * 4 + 64), literals(((size_t)1 << 17) + 64),
         state(sizeof(FragmentState) + 64);
-    if (size) dev_h2d_bulk(in.p, input, size);
-    uint8_t head[2] = {(uint8_t)fs->last_bytes, (uint8_t)(fs->last_bytes >> 8)};
-    dev_h2d(outb.p, head, 2);
-    fs->state.storage_ix = fs->last_bytes_bits;
-    fs->state.bad = 0;
-    dev_h2d(state.p, &fs->state, sizeof(FragmentState));
     FragmentBuffers B;
     B.table = (uint32_t*)table.p;
     B.commands = (uint32_t*)commands.p;
     B.literals = (uint8_t*)literals.p;
     B.state = (FragmentState*)state.p;
     size_t done = 0;
-    for (;;) {
-      const size_t block_size = std::min(block_size_limit, size - done);
-      const bool is_last = (size - done == block_size) && finish;
-      if (block_size == 0 && !is_last) break;
-      frag_compress(p.quality, (const uint8_t*)in.p + done, (uint32_t)block_size, is_last, TableBits(p.quality, block_size), B, (uint8_t*)outb.p);
-      done += block_size;
-      if (is_last || done == size) break;
+    bool more = true;
+    std::vector<uint8_t> bytes;
+    while (more) {
+      const size_t here = std::min(size - done, batch_bytes);
+      if (here) dev_h2d_bulk(in.p, input + done, here);
+      uint8_t head[2] = {(uint8_t)fs->last_bytes, (uint8_t)(fs->last_bytes >> 8)};
+      dev_h2d(outb.p, head, 2);
+      fs->state.storage_ix = fs->last_bytes_bits;
+      fs->state.bad = 0;
+      dev_h2d(state.p, &fs->state, sizeof(FragmentState));
+      size_t at = 0;
+      for (;;) {
+        const size_t block_size = std::min(block_size_limit, here - at);
+        const bool is_last = (size - done - at == block_size) && finish;
+        if (block_size == 0 && !is_last) break;
+        frag_compress(p.quality, (const uint8_t*)in.p + at, (uint32_t)block_size, is_last, TableBits(p.quality, block_size), B, (uint8_t*)outb.p);
+        at += block_size;
+        if (is_last || at == here) break;
+      }
+      done += here;
+      more = done < size;
+      dev_d2h(&fs->state, state.p, sizeof(FragmentState));
+      if (fs->state.bad) throw std::runtime_error("brotli_mi355x: fragment compressor failed");
+      const uint64_t ix = fs->state.storage_ix;
+      if ((ix >> 3) + 2 > cap) throw std::runtime_error("brotli_mi355x: fragment output ran over its bound");
+      bytes.resize((size_t)(ix >> 3) + 2);
+      dev_d2h_bulk(bytes.data(), outb.p, bytes.size());
+      out->insert(out->end(), bytes.begin(), bytes.begin() + (ptrdiff_t)(ix >> 3));
+      fs->last_bytes = (uint16_t)(bytes[(size_t)(ix >> 3)] | (bytes[(size_t)(ix >> 3) + 1] << 8));
+      fs->last_bytes_bits = (uint8_t)(ix & 7);
+      if (fs->last_bytes_bits != 0) fs->last_bytes &= (uint16_t)((1u << fs->last_bytes_bits) - 1u); else fs->last_bytes = 0;
+      if (more) dev_memset(outb.p, 0, (size_t)(ix >> 3) + 16);  // (the bit writer ORs nothing, but the open byte is read back: a clean start)
     }
-    dev_d2h(&fs->state, state.p, sizeof(FragmentState));
-    if (fs->state.bad) throw std::runtime_error("brotli_mi355x: fragment compressor failed");
-    const uint64_t ix = fs->state.storage_ix;
-    if ((ix >> 3) + 2 > cap) throw std::runtime_error("brotli_mi355x: fragment output ran over its bound");
-    std::vector<uint8_t> bytes((size_t)(ix >> 3) + 2);
-    dev_d2h_bulk(bytes.data(), outb.p, bytes.size());
-    out->insert(out->end(), bytes.begin(), bytes.begin() + (ptrdiff_t)(ix >> 3));
-    fs->last_bytes = (uint16_t)(bytes[(size_t)(ix >> 3)] | (bytes[(size_t)(ix >> 3) + 1] << 8));
-    fs->last_bytes_bits = (uint8_t)(ix & 7);
-    if (fs->last_bytes_bits != 0) fs->last_bytes &= (uint16_t)((1u << fs->last_bytes_bits) - 1u); else fs->last_bytes = 0;
     if (flush) flush_requested = true;
   } else if (flush) {
     flush_requested = true;

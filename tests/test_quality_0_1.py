@@ -111,6 +111,16 @@ def _several_fragments(lib):
         assert orc.decompress(got, len(d)) == d
 
 
+def test_calls_larger_than_a_batch_emu():
+    """one call's fragments go through the device in batches (64 MiB of input; here turned down to 200 KB): same stream"""
+    import subprocess
+    import sys
+    child = ("import sys; sys.path.insert(0, %r); import orc, synth, test_cabi; lib = test_cabi._load('emu'); d = synth.mixed(1500000, 5)\n"
+             "for q, w in ((0, 16), (1, 16), (0, 10), (1, 22)):\n    assert lib.compress(d, q, w) == orc.compress(d, q, w), (q, w)\nprint('ok')" % HERE)
+    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, BROTLI_MI355X_FRAGMENT_BATCH="200000"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_several_fragments_emu():
     import test_cabi
     _several_fragments(test_cabi._load("emu"))
