@@ -37,8 +37,12 @@ void* dev_alloc_uninit(size_t bytes) {
 }
 void dev_free(void* p) { free(p); }
 void dev_memset(void* p, int value, size_t bytes) { memset(p, value, bytes); }
-void dev_h2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
-void dev_d2h(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+void dev_h2d(void* dst, const void* src, size_t bytes) {
+  if (bytes) memcpy(dst, src, bytes);  // (an empty vector hands over a null pointer)
+}
+void dev_d2h(void* dst, const void* src, size_t bytes) {
+  if (bytes) memcpy(dst, src, bytes);
+}
 void dev_d2h_async(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 void dev_d2d(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
 void dev_sync() {}
