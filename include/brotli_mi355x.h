@@ -8,8 +8,8 @@
  * Behavioural contract: for the accelerated configurations -- every quality 0..11 at every window the reference takes: the
  * H5 / H5q5 / H6 / H9 greedy path of qualities 5..9; quality 10 / 11 with BROTLI_PARAM_Q9_5 through the stream API (the
  * reference's "9.5": the H9 search with the quality >= 10 meta-block builder, metablock.rs:133-307) and without it (H10 + Zopfli);
- * qualities 2..4 (BasicHasher family) and 0 / 1 (the fragment compressors; not their catable / custom-dictionary /
- * multi-shard forms, which the reference runs through the ring-buffer path) -- the produced
+ * qualities 2..4 (BasicHasher family) and 0 / 1 (the fragment compressors, on the fragment path and, for catable streams / custom
+ * dictionaries / shards, block by block like the reference's ring-buffer path) -- the produced
  * stream is byte-identical to the reference encoder fed the same way.  Everything runs on the GPU through HIP; there is no CPU fallback: calls with
  * parameters outside the accelerated set, or on a machine without a usable gfx950 device, fail
  * (BROTLI_FALSE / 0 / NULL) and print the reason on stderr.

@@ -17,7 +17,8 @@
  * block splitter + clustering), orc_encode.c (stream state machine), orc_multi.c (compress_multi + BroCatli).
  * Qualities 2..4 (BasicHasher H2/H3/H4/H54, store_meta_block_fast / _trivial) are byte-identical to libbrotlienc 1.0.9
  * modulo two more documented source differences, qualities 0 and 1 (orc_fragment.c: compress_fragment,
- * compress_fragment_two_pass) modulo one each.  Not restated: catable streams at quality 0 / 1.
+ * compress_fragment_two_pass) modulo one each; their catable forms (the quality 0 / 1 branch of encode_data, encode.rs:2335-2389) exist in
+ * the Rust sources only.
  */
 #ifndef BROTLI_ORACLE_H_
 #define BROTLI_ORACLE_H_

@@ -601,6 +601,7 @@ static void write_meta_block_internal(OrcEncoder* s, const uint8_t* data, size_t
   if (s->trace) s->trace(s->trace_opaque, kind, last_flush_pos, bytes, s->commands_, s->num_commands_, s->dist_cache_);
 }
 
+static int32_t* get_hash_table(int quality, size_t input_size, size_t* table_size);
 static size_t input_block_size(OrcEncoder* s) {
   if (!ensure_initialized(s)) return 0;
   return (size_t)1 << s->params.lgblock;
@@ -752,8 +753,37 @@ static int encode_data(OrcEncoder* s, int is_last, int force_flush, size_t* out_
   }
   uint32_t wrapped_last_processed_pos = wrap_position(s->last_processed_pos_);
   if (s->params.quality < 2) {
-    fprintf(stderr, "oracle: qualities 0 and 1 (compress_fragment*) are not restated\n");
-    abort();
+    /* encode.rs:2335-2389: the fragment compressors on what the ring buffer holds of this block -- the way a CATABLE stream goes
+       at qualities 0 / 1 (and with it one that was given a custom dictionary, :1237-1241, and the shards of compress_multi);
+       everything else takes compress_stream_fast and never gets here */
+    if (delta == 0 && !is_last) {
+      *out_size = catable_header_size;
+      return 1;
+    }
+    {
+      const uint8_t* data = s->ringbuffer_.data_mo + s->ringbuffer_.buffer_index;
+      size_t table_size = 0;
+      int32_t* table = get_hash_table(s->params.quality, bytes, &table_size);
+      if (s->params.quality == 0) {
+        orc_compress_fragment_fast(data + (wrapped_last_processed_pos & mask), bytes, is_last, table, table_size, s->cmd_depths_,
+                                   s->cmd_bits_, &s->cmd_code_numbits_, s->cmd_code_, &storage_ix, s->storage_);
+      } else {
+        uint32_t* command_buf = (uint32_t*)calloc((size_t)1 << 17, sizeof(uint32_t)); /* kCompressFragmentTwoPassBlockSize */
+        uint8_t* literal_buf = (uint8_t*)calloc((size_t)1 << 17, 1);
+        orc_compress_fragment_two_pass(data + (wrapped_last_processed_pos & mask), bytes, is_last, command_buf, literal_buf, table,
+                                       table_size, &storage_ix, s->storage_);
+        free(command_buf);
+        free(literal_buf);
+      }
+      free(table);
+      s->last_bytes_ = (uint16_t)(s->storage_[storage_ix >> 3] | (s->storage_[1 + (storage_ix >> 3)] << 8));
+      s->last_bytes_bits_ = (uint8_t)(storage_ix & 7);
+    }
+    update_last_processed_pos(s);
+    s->next_out_kind = NEXT_OUT_STORAGE;
+    s->next_out_off = 0;
+    *out_size = storage_ix >> 3;
+    return 1;
   }
   {
     size_t newsize = s->num_commands_ + bytes / 2 + 1;
@@ -1083,7 +1113,6 @@ int orc_encoder_compress_stream(OrcEncoder* s, int op, size_t* available_in, con
   if (s->stream_state_ != STREAM_PROCESSING && *available_in != 0) return 0;
   if ((s->params.quality == 0 || s->params.quality == 1) && !s->params.catable)
     return compress_stream_fast(s, op, available_in, next_in, available_out, next_out, total_out);
-  if (s->params.quality < 2) return 0; /* catable streams at quality 0 / 1 take the ring-buffer path: not restated */
   for (;;) {
     size_t remaining_block_size;
     {

@@ -218,6 +218,19 @@ void CompressChunk(const EncoderParams& user_params, const uint8_t* input, size_
     req.hasher_chosen_before_size_hint = start > 1;  // a too-short dictionary returns before hasher_setup
   }
   (void)host_copy;
+  if (IsFragmentStream(req.params) || IsFragmentRing(req.params)) {
+    // qualities 0 / 1: a shard is one FINISH call on a stream of its own -- the first one on the fragment path, the others catable
+    // (set_custom_dictionary leaves them without a dictionary at these qualities, encode.rs:1237-1241) and so on the ring-buffer path
+    if (input_on_device) throw std::runtime_error("brotli_mi355x: qualities 0 and 1 take their input from host memory");
+    FragmentStream fs;
+    if (IsFragmentRing(req.params)) FragmentRingCompress(req.params, &fs, req.input, req.input_size, true, false, out);
+    else FragmentStreamCompress(req.params, &fs, req.input, req.input_size, true, false, out);
+    // compress_part gives a shard BrotliEncoderMaxCompressedSize(its length) of room and fails the call when the stream does not fit
+    // (threading/mod.rs:337-411): small fragments of these qualities on incompressible input do not
+    if (out->size() > MaxCompressedSize(req.input_size))
+      throw std::runtime_error("brotli_mi355x: the reference encoder fails on this input: a shard of quality 0 / 1 outgrows BrotliEncoderMaxCompressedSize of its length");
+    return;
+  }
   EncodeStream(req, out, nullptr);
 }
 
@@ -348,7 +361,13 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
       for (size_t i = 0; i < num_params; ++i) SetParameter(&req.params, (int)keys[i], values[i]);
       req.input = input;
       req.input_size = input_size;
-      EncodeStream(req, &out, nullptr);
+      if (IsFragmentStream(req.params) || IsFragmentRing(req.params)) {
+        FragmentStream fs;
+        if (IsFragmentRing(req.params)) FragmentRingCompress(req.params, &fs, input, input_size, true, false, &out);
+        else FragmentStreamCompress(req.params, &fs, input, input_size, true, false, &out);
+      } else {
+        EncodeStream(req, &out, nullptr);
+      }
     } else {
       EncoderParams params;
       if (!ParamsFromLists(num_params, keys, values, &params)) return 0;
@@ -505,9 +524,14 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     s->first_encode_seen = true;
     if (s->params.size_hint == 0) s->params.size_hint = (size_t)std::min<uint64_t>(s->total_in, (uint64_t)1 << 30);
     const size_t n_meta = *available_in;
-    if (IsFragmentStream(s->params)) {
+    if (IsFragmentStream(s->params) || IsFragmentRing(s->params)) {
       // (qualities 0 / 1: nothing is ever pending in a ring buffer; the header goes behind the open byte, encode.rs:2630-2640)
       try {
+        // A catable stream at these qualities that has seen input: the reference's process_metadata asks encode_data to flush
+        // "pending" input for ever -- its quality 0 / 1 branch never moves last_flush_pos_ (encode.rs:2335-2389, 2621-2629) -- and
+        // does not return.  Nothing to reproduce.
+        if (IsFragmentRing(s->params) && s->fragments.saw_input)
+          throw std::runtime_error("a metadata block behind input on a catable stream of quality 0 / 1: the reference encoder does not return from this call");
         if (s->output_pos != 0) {
           s->output.erase(s->output.begin(), s->output.begin() + (ptrdiff_t)s->output_pos);
           s->output_pos = 0;
@@ -526,7 +550,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
     }
   }
   if (s->stream_state != kProcessing && *available_in != 0) return BROTLI_FALSE;  // encode.rs:2918-2922
-  if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA && IsFragmentStream(s->params)) {
+  if (s->stream_state == kProcessing && op != BROTLI_OPERATION_EMIT_METADATA && (IsFragmentStream(s->params) || IsFragmentRing(s->params))) {
     // BrotliEncoderCompressStreamFast, encode.rs:2706-2861: the input of THIS call, cut into fragments of at most 1 << lgwin bytes,
     // is compressed right away (fragment_stream.h); nothing is buffered
     try {
@@ -535,7 +559,12 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
         s->output_pos = 0;
       }
       const size_t n = *available_in;
-      FragmentStreamCompress(s->params, &s->fragments, *next_in, n, op == BROTLI_OPERATION_FINISH, op == BROTLI_OPERATION_FLUSH, &s->output);
+      if (IsFragmentRing(s->params)) {
+        // catable (also: after BrotliEncoderSetCustomDictionary): the ring-buffer path, block by block (encode.rs:2335-2389)
+        FragmentRingCompress(s->params, &s->fragments, *next_in, n, op == BROTLI_OPERATION_FINISH, op == BROTLI_OPERATION_FLUSH, &s->output);
+      } else {
+        FragmentStreamCompress(s->params, &s->fragments, *next_in, n, op == BROTLI_OPERATION_FINISH, op == BROTLI_OPERATION_FLUSH, &s->output);
+      }
       s->total_in += n;
       *next_in += n;
       *available_in = 0;

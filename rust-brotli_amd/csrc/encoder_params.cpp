@@ -167,9 +167,7 @@ bool IsAccelerated(const EncoderParams& p, const char** why_not) {
   const char* why = nullptr;
   const bool basic = p.hasher.type == 2 || p.hasher.type == 3 || p.hasher.type == 4 || p.hasher.type == 54;
   if (p.quality < 2 || p.quality > 11) {
-    why = "qualities 0 and 1 run on the device as fragment streams (BrotliEncoderCompress / BrotliEncoderCompressStream, fragment_stream.h); what the "
-          "reference sends through the ring-buffer path at these qualities -- catable streams, and with them custom dictionaries and "
-          "BrotliEncoderCompressMulti shards -- is not implemented";
+    why = "qualities 0 and 1 run through fragment_stream.h (BrotliEncoderCompress, BrotliEncoderCompressStream, BrotliEncoderCompressMulti), not through this entry";
   } else if (basic != (p.quality < 5)) {
     why = "hasher type and quality do not go together";
   } else if (basic) {

@@ -20,10 +20,22 @@ struct FragmentStream {
   uint16_t last_bytes = 0;      // the open byte(s) of the output: window bits at first, then what the last piece left
   uint8_t last_bytes_bits = 0;
   FragmentState state{};        // host copy between calls (storage_ix is per call)
+  // catable streams only (FragmentRingCompress): what the reference keeps in its ring buffer and books
+  std::vector<uint8_t> pending;  // input copied in, not yet compressed (less than a block, or the block that has just filled up)
+  uint32_t first_mb = 0;         // is_first_mb, encode.rs:2261-2333: 0 nothing written, 1 magic-number block, 2 one raw byte, 3 both
+  size_t size_hint = 0;          // update_size_hint at the first encode_data (the magic-number block carries it)
+  bool saw_input = false;
 };
 
 // true for the parameter sets that take this path in the reference: quality 0 / 1 and not catable (encode.rs:2929-2937)
 bool IsFragmentStream(const EncoderParams& user_params);
+// quality 0 / 1 AND catable (which a custom dictionary and the shards of compress_multi turn on at these qualities): the stream goes
+// through the reference's ring-buffer path after all, where encode_data hands every input block of 1 << lgwin bytes to the same
+// fragment compressors (encode.rs:2335-2389) -- behind the two raw first bytes of a catable stream and the magic-number block
+bool IsFragmentRing(const EncoderParams& user_params);
+// One BrotliEncoderCompressStream call on such a stream (the generic loop of compress_stream, encode.rs:2938-2995).
+void FragmentRingCompress(const EncoderParams& user_params, FragmentStream* fs, const uint8_t* input, size_t size, bool finish, bool flush,
+                          std::vector<uint8_t>* out);
 // One BrotliEncoderCompressStream call with `size` bytes of input: finish = BROTLI_OPERATION_FINISH, flush = BROTLI_OPERATION_FLUSH
 // (the byte-alignment block behind the data, encode.rs:1541-1566), neither = PROCESS.  Whole bytes of output are appended to *out.
 void FragmentStreamCompress(const EncoderParams& user_params, FragmentStream* fs, const uint8_t* input, size_t size, bool finish, bool flush,

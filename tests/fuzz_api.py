@@ -2,8 +2,9 @@
 [emu].  FLUSH at random cut points, EMIT_METADATA, BrotliEncoderCompressMulti with 1..9 shards; expected bytes from the
 oracle.  FUZZ_Q9_5=1 (or =11): every case at quality 10 (11) with BROTLI_PARAM_Q9_5 (the quality >= 10 meta-block builder, row b10).
 FUZZ_ZOPFLI=10 (or =11): every case at quality 10 (11) proper (row f1: H10 + Zopfli, zopfli_device.h); inputs up to 300 KB.
-FUZZ_FRAGMENT=1: every case at quality 0 or 1 (row f3: the fragment compressors, fragment_device.h) -- the stream operations, extra
-parameters and the writer pattern; no catable streams, dictionaries or shards (the ring-buffer path at these qualities is not implemented).
+FUZZ_FRAGMENT=1: every case at quality 0 or 1 (row f3: the fragment compressors, fragment_device.h), catable streams, custom
+dictionaries and shards (the ring-buffer path of these qualities) included; no metadata block behind input on a catable stream (the
+reference does not return from that call).
 FUZZ_QUICK=1: every case at quality 2, 3 or 4 (row f3: the BasicHasher family, quick_device.h), windows down to lgwin 10."""
 import os, sys, time
 import synth, orc
@@ -46,13 +47,13 @@ for c in range(cases):
     if fragment:
         q = rng.next() % 2
         w = [10, 13, 16, 17, 18, 20, 22, 24][rng.next() % 8]
-        mode = [1, 2, 4, 5][rng.next() % 4]
+        mode = rng.next() % 6
     if q95 and mode == 5:
         mode = 4  # (orc.writer_compress takes quality and window only)
     base = [(Q, q), (W, w)] + ([(150, 1)] if q95 else [])
     extra = []
     for pid in (167, 168, 169, 172):  # catable, appendable, magic number, byte align
-        if rng.next() % 4 == 0 and not (fragment and pid == 167):
+        if rng.next() % 4 == 0:
             extra.append((pid, 1))
     if rng.next() % 3 == 0:
         extra.append((5, [1, 1000, 1 << 20, (1 << 20) + 1, 5 << 20][rng.next() % 5]))  # size hint
@@ -61,7 +62,7 @@ for c in range(cases):
         open(os.environ["FUZZ_TRACE"], "wb").write(d)
     # flushes on catable / appendable streams and streams with a custom dictionary (row f4): a third of the flush cases
     fparams, fdic = base, None
-    if mode in (1, 2) and rng.next() % 3 == 0 and not fragment:
+    if mode in (1, 2) and rng.next() % 3 == 0:
         fparams = base + [x for x in extra if x[0] != 5]
         if rng.next() % 2:
             mdic = 2 + rng.next() % 300000
@@ -135,8 +136,11 @@ for c in range(cases):
         ncut = 1 + rng.next() % 4
         cuts = sorted(rng.next() % (n + 1) for _ in range(ncut))
         ops = []
+        # (quality 0 / 1: a metadata block behind input on a catable stream -- also one with a custom dictionary -- never returns in
+        # the reference, encode.rs:2621-2629 with :2335-2389)
+        no_meta = fragment and (fdic is not None or any(k == 167 for k, _ in fparams))
         for cut in cuts:
-            if mode == 2 and rng.next() % 2:
+            if mode == 2 and rng.next() % 2 and not no_meta:
                 ops.append((cut, bytes([65 + (rng.next() % 26)]) * (2 + rng.next() % 300)))
             else:
                 ops.append(cut)
@@ -155,7 +159,8 @@ for c in range(cases):
     try:
         got = product()
     except Exception as ex:
-        got = "reference fails" if "reference encoder fails" in str(ex) else "EXCEPTION %r" % (ex,)
+        # (BrotliEncoderCompressMulti with the output bound of the binding: a stream that outgrows it fails the call on both sides)
+        got = "reference fails" if ("reference encoder fails" in str(ex) or "insufficient output space" in str(ex)) else "EXCEPTION %r" % (ex,)
     ok = got == want
     if want == "reference fails":
         panics += 1

@@ -92,7 +92,7 @@ def compress(data, quality=5, lgwin=22, mode=0, with_stats=False):
 def writer_compress(data, quality=5, lgwin=22, chunk=0, with_stats=False, trace=None):
     """CompressorWriter feeding pattern (size_hint derived from the first write)"""
     L = lib()
-    cap = L.orc_max_compressed_size(len(data)) + 64
+    cap = L.orc_max_compressed_size(len(data)) + len(data) // 16 + 4096  # (room: tiny fragments of quality 0 / 1 outgrow the bound)
     out = ctypes.create_string_buffer(cap)
     n = ctypes.c_size_t(cap)
     st = OrcStats()
@@ -116,7 +116,7 @@ def reader_compress(data, params, chunk=4096, with_stats=False):
                                       ctypes.c_void_p, ctypes.c_void_p]
     keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
     vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
-    cap = L.orc_max_compressed_size(len(data)) + 1024
+    cap = L.orc_max_compressed_size(len(data)) + len(data) // 16 + 4096
     out = ctypes.create_string_buffer(cap)
     n = ctypes.c_size_t(cap)
     st = OrcStats()
@@ -133,13 +133,15 @@ def compress_multi(data, params, num_threads):
     L = lib()
     keys = (ctypes.c_int * len(params))(*[k for k, _ in params])
     vals = (ctypes.c_uint32 * len(params))(*[v for _, v in params])
-    cap = L.orc_max_compressed_size_multi(len(data), num_threads) + 64
+    cap = L.orc_max_compressed_size_multi(len(data), num_threads)  # (what the reference's own binding hands over, c/py/brotli.py)
     out = ctypes.create_string_buffer(cap)
     n = ctypes.c_size_t(cap)
     ok = L.orc_compress_multi(keys, vals, len(params), len(data), data, ctypes.byref(n), out, num_threads)
     _check_panic()
     if not ok:
-        raise RuntimeError("oracle compress_multi failed")
+        # compress_part gives every shard BrotliEncoderMaxCompressedSize(its length) of room and fails the call when the shard does not
+        # fit (threading/mod.rs:337-411) -- which tiny fragments of quality 0 / 1 on incompressible input do not
+        raise ReferencePanics("the reference's compress_multi reports an error")
     return out.raw[:n.value]
 
 
@@ -191,7 +193,7 @@ def stream_compress(data, params, prefix=None, collect_trace=False, continuation
         L.orc_encoder_set_trace(s, ctypes.cast(cbo, ctypes.c_void_p), None)
     if prefix is not None:
         L.orc_encoder_set_custom_dictionary(s, len(prefix), prefix, 1 if continuation else 0)
-    cap = L.orc_max_compressed_size(len(data)) + 64
+    cap = L.orc_max_compressed_size(len(data)) + len(data) // 16 + 4096
     out = ctypes.create_string_buffer(cap)
     inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)
     avail_in = ctypes.c_size_t(len(data))
@@ -228,7 +230,7 @@ def stream_with_flushes(data, params, cuts, write_size=0, dictionary=None):
     if dictionary is not None:  # BrotliEncoderSetCustomDictionary (encode.rs:1196-1270)
         L.orc_encoder_set_custom_dictionary.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int]
         L.orc_encoder_set_custom_dictionary(s, len(dictionary), dictionary, 0)
-    cap = L.orc_max_compressed_size(len(data)) + 1024 + 16 * len(cuts)
+    cap = L.orc_max_compressed_size(len(data)) + len(data) // 16 + 4096 + 16 * len(cuts)
     out = ctypes.create_string_buffer(cap)
     inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)
     base = ctypes.addressof(inbuf)

@@ -182,7 +182,7 @@ def _suite(lib):
     # unsupported parameters fail loudly instead of silently doing something else
     import brotli_mi355x as _m  # noqa: F401
     with pytest.raises(Exception):
-        lib.BrotliCompress(a, {Q: 1}, 2)  # (shards at quality 0 / 1 would be catable streams: refused with a message, never routed elsewhere)
+        lib.BrotliCompress(a, {Q: 5, W: 17, 171: 1}, 9)  # (favor_cpu_efficiency with shards beyond the window: refused with a message, never routed elsewhere)
     # qualities 0 .. 4 through the one-shot entry (round 4: the fragment compressors and the BasicHasher family are on the device):
     # the oracle's bytes
     for q in (0, 1, 2, 3, 4):

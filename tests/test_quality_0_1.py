@@ -4,10 +4,15 @@ ring-buffer path at these qualities (BrotliEncoderCompressStreamFast, encode.rs:
 is cut into fragments of at most 1 << lgwin bytes, each on a fresh hash table; the stream carries the open byte and, at quality 0,
 the command prefix code.
 
-The reference holds no exact size for these qualities; everything is byte identity with the oracle (oracle/orc_fragment.c), which
-tests/test_oracle_vs_libbrotlienc.py holds against libbrotlienc 1.0.9 for the same qualities.  Not implemented, like in the
-oracle: what the reference sends through the ring-buffer path at these qualities (catable streams, and with them custom
-dictionaries and BrotliEncoderCompressMulti shards) -- refused with a message.  CPU: the emulation build; -m gpu: the product library."""
+Catable streams -- and with them streams that were given a custom dictionary and the shards of BrotliEncoderCompressMulti, which
+are catable at these qualities (encode.rs:1237-1241) -- go through the reference's ring-buffer path after all: encode_data hands
+every input block of 1 << lgwin bytes to the same fragment compressors (encode.rs:2335-2389), behind the two raw first bytes of
+a catable stream and the magic-number block (FragmentRingCompress).
+
+The reference holds no exact size for these qualities; everything is byte identity with the oracle (oracle/orc_fragment.c, the
+quality 0 / 1 branch of encode_data in orc_encode.c), which tests/test_oracle_vs_libbrotlienc.py holds against libbrotlienc 1.0.9
+for the same qualities (the catable forms exist in the Rust sources only).  One call is refused: a metadata block behind input
+on a catable stream -- the reference does not return from it.  CPU: the emulation build; -m gpu: the product library."""
 import glob
 import os
 
@@ -88,18 +93,64 @@ def _streams(lib, small):
             assert orc.decompress(got, n) == d
 
 
+def _catable(lib, small):
+    """the ring-buffer path of qualities 0 / 1: catable streams (two raw first bytes, magic-number block, blocks of 1 << lgwin bytes),
+    streams with a custom dictionary (ignored at these qualities but for turning catable on), shards, flushes"""
+    a = synth.alice()
+    d = synth.mixed(300000 if small else 700000, 3)
+    for q in (0, 1):
+        for data, params in ((a, [(Q, q), (W, 22), (167, 1)]), (a, [(Q, q), (W, 16), (167, 1), (169, 1)]), (d, [(Q, q), (W, 18), (167, 1)]),
+                             (b"x", [(Q, q), (167, 1)]), (b"", [(Q, q), (167, 1)]), (b"ab", [(Q, q), (167, 1)]),
+                             (a, [(Q, q), (W, 18), (167, 1), (173, 1)]), (a, [(Q, q), (LARGE, 1), (W, 26), (167, 1), (169, 1)])):
+            e = lib.encoder(params=params)
+            e.write(data)
+            got = e.finish()
+            e.close()
+            assert got == orc.stream_compress(data, params)[0], (q, params)
+        cuts = [1, 100000, 100001, len(d) * 2 // 3]
+        params = [(Q, q), (W, 17), (167, 1)]
+        e = lib.encoder(params=params)
+        pieces, last = [], 0
+        for c in cuts:
+            pieces.append(e.flush(d[last:c]))
+            last = c
+        e.write(d[last:])
+        pieces.append(e.finish())
+        e.close()
+        assert pieces == orc.stream_with_flushes(d, params, cuts), q
+        assert orc.decompress(b"".join(pieces), len(d)) == d
+        for nt in (2, 4, 7):
+            got = bytes(lib.BrotliCompress(d, {Q: q, W: 20}, nt))
+            assert got == orc.compress_multi(d, [(Q, q), (W, 20)], nt), (q, nt)
+            assert orc.decompress(got, len(d)) == d
+        e = lib.encoder(params=[(Q, q), (W, 22)], dictionary=a[:5000])
+        e.write(a[5000:])
+        got = e.finish()
+        e.close()
+        assert got == orc.stream_compress(a[5000:], [(Q, q), (W, 22)], prefix=a[:5000], continuation=False)[0], q
+
+
 def _refusals(lib):
     a = synth.alice()
     for q in (0, 1):
-        with pytest.raises(Exception, match="catable|ring-buffer|not implemented"):
-            e = lib.encoder(params=[(Q, q), (W, 22), (167, 1)])
-            try:
-                e.write(a)
-                e.finish()
-            finally:
-                e.close()
-        with pytest.raises(Exception):
-            lib.BrotliCompress(a, {Q: q, W: 22}, 2)  # shards are catable streams
+        e = lib.encoder(params=[(Q, q), (W, 22), (167, 1)])
+        try:
+            e.write(a)
+            with pytest.raises(Exception):
+                e.emit_metadata(b"never returns in the reference")
+        finally:
+            e.close()
+
+
+def test_catable_streams_dictionaries_and_shards_emu():
+    import test_cabi
+    _catable(test_cabi._load("emu"), small=False)
+
+
+@pytest.mark.gpu
+def test_catable_streams_dictionaries_and_shards_gpu():
+    import test_cabi
+    _catable(test_cabi._load("gpu"), small=True)
 
 
 def _several_fragments(lib):
