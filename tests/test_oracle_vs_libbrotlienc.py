@@ -174,3 +174,105 @@ def test_low_qualities_identical_to_libbrotlienc_modulo_the_source_differences(g
     # without the switches: rust-brotli's own behaviour, which must at least decode
     for name, data in inputs[:4]:
         assert orc.decompress(orc.compress(data, quality, 22), len(data)) == data
+
+
+def _genc_stream(data, params, cuts, write_size=0):
+    """libbrotlienc's stream API driven like orc.stream_with_flushes: FLUSH after the bytes up to each offset in `cuts` (or
+    EMIT_METADATA for an (offset, bytes) entry), PROCESS in pieces of write_size in between, FINISH at the end"""
+    lib = ctypes.CDLL("libbrotlienc.so.1")
+    lib.BrotliEncoderCreateInstance.restype = ctypes.c_void_p
+    lib.BrotliEncoderCreateInstance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.BrotliEncoderSetParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
+    lib.BrotliEncoderDestroyInstance.argtypes = [ctypes.c_void_p]
+    lib.BrotliEncoderHasMoreOutput.argtypes = [ctypes.c_void_p]
+    lib.BrotliEncoderIsFinished.argtypes = [ctypes.c_void_p]
+    lib.BrotliEncoderCompressStream.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p),
+                                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    s = lib.BrotliEncoderCreateInstance(None, None, None)
+    for k, v in params:
+        assert lib.BrotliEncoderSetParameter(s, k, v)
+    cap = len(data) + len(data) // 4 + 65536
+    out = ctypes.create_string_buffer(cap)
+    inbuf = ctypes.create_string_buffer(data, len(data) if len(data) else 1)
+    base = ctypes.addressof(inbuf)
+    avail_out = ctypes.c_size_t(cap)
+    next_out = ctypes.c_void_p(ctypes.addressof(out))
+    total = ctypes.c_size_t(0)
+
+    def call(op, address, count):
+        avail_in = ctypes.c_size_t(count)
+        next_in = ctypes.c_void_p(address)
+        while True:
+            assert lib.BrotliEncoderCompressStream(s, op, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                                   ctypes.byref(next_out), ctypes.byref(total))
+            if avail_in.value == 0 and not lib.BrotliEncoderHasMoreOutput(s):
+                break
+
+    pieces, pos, done_out = [], 0, 0
+    for item in list(cuts) + [len(data)]:
+        cut, meta = (item if isinstance(item, tuple) else (item, None))
+        final = meta is None and cut == len(data) and len(pieces) == len(cuts)
+        if write_size:
+            while cut - pos > write_size:
+                call(0, base + pos, write_size)
+                pos += write_size
+        if meta is None:
+            call(2 if final else 1, base + pos, cut - pos)
+        else:
+            if cut > pos:
+                call(0, base + pos, cut - pos)
+            mbuf = ctypes.create_string_buffer(bytes(meta), max(1, len(meta)))
+            call(3, ctypes.addressof(mbuf), len(meta))
+        pos = cut
+        produced = cap - avail_out.value
+        pieces.append(out.raw[done_out:produced])
+        done_out = produced
+    assert lib.BrotliEncoderIsFinished(s)
+    lib.BrotliEncoderDestroyInstance(s)
+    return pieces
+
+
+@pytest.mark.parametrize("quality", [0, 1, 2, 3, 4, 5, 6, 8])
+def test_stream_operations_identical_to_libbrotlienc(genc, quality):
+    """The stream state machine -- PROCESS in pieces, FLUSH (the byte-alignment block), EMIT_METADATA, FINISH, the size hint taken
+    from the first call, at qualities 0 / 1 the fragments cut at call boundaries -- against libbrotlienc's, driven with the same
+    calls (the source differences switched to the C behaviour as above)."""
+    Q, W = 1, 2
+    text = synth.markov_text(900000, 41)
+    mixed = synth.mixed(700000, 42)
+    cases = [
+        (text, 22, [300000, 600001], 0),
+        (text, 18, [1, 65536, 65537], 4096),
+        (mixed, 20, [0, 250000], 100003),
+        # (a ONE-byte metadata block is written with MSKIPBYTES = 0 by both encoders -- write_metadata_header, encode.rs:2545-2575, like
+        # C 1.0.9 -- and no decoder takes the stream; the lengths here are 40, 0 and 2)
+        (mixed, 17, [(100000, b"metadata" * 5), 400000, (400000, b""), (650000, b"xy")], 65536),
+        (synth.alice(), 22, [], 1000),
+        # (lgwin <= 16 at qualities 5 .. 8: C has the H40 / H41 / H42 hashers, rust-brotli falls back to H6 -- not comparable)
+        (synth.alice(), 16 if quality < 5 else 17, [(0, b"before anything"), 70000], 0),
+    ]
+    with c109_behaviour(*LOW_QUALITY_SWITCHES):
+        for data, lgwin, cuts, write_size in cases:
+            params = [(Q, quality), (W, lgwin)]
+            mine = orc.stream_with_flushes(data, params, cuts, write_size=write_size)
+            theirs = _genc_stream(data, params, cuts, write_size=write_size)
+            assert [len(x) for x in mine] == [len(x) for x in theirs], (quality, lgwin, cuts, write_size)
+            assert mine == theirs, (quality, lgwin, cuts, write_size)
+            assert orc.decompress(b"".join(mine), len(data)) == data
+        # a small sweep of random call sequences on top
+        rng = synth.XorShift(1000 + quality)
+        pools = (text, mixed, synth.alice())
+        for _ in range(30):
+            pool = pools[rng.next() % 3]
+            n = 1 + rng.next() % min(len(pool) - 1, 300000)
+            o = rng.next() % (len(pool) - n)
+            data = pool[o:o + n]
+            lgwin = ((16, 18, 20, 22) if quality < 5 else (17, 18, 20, 22))[rng.next() % 4]
+            cuts = []
+            for c in sorted(rng.next() % (n + 1) for _ in range(rng.next() % 4)):
+                cuts.append((c, b"m" * (2 + rng.next() % 50)) if rng.next() % 3 == 0 else c)
+            write_size = (0, 1000, 4096, 65536, 100003)[rng.next() % 5]
+            params = [(Q, quality), (W, lgwin)]
+            mine = orc.stream_with_flushes(data, params, cuts, write_size=write_size)
+            theirs = _genc_stream(data, params, cuts, write_size=write_size)
+            assert mine == theirs, (quality, lgwin, n, o, cuts, write_size)
