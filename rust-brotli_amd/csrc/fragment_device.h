@@ -49,6 +49,9 @@ struct FragmentOut {
   uint64_t pos;   // storage_ix
   uint64_t acc;   // the open byte (low `nacc` bits valid)
   uint32_t nacc;  // == pos & 7
+  // position of the first jump to a byte boundary that still stands (~0: none).  Fragments of a batch are compressed from bit 0 of a
+  // slot of their own; what comes behind this point lands on whole bytes whatever phase the stream really has (frag_join).
+  uint64_t first_align;
 
   BR_DEV void put(uint32_t n_bits, uint64_t bits) {
     if (n_bits == 0) return;
@@ -85,6 +88,7 @@ struct FragmentOut {
   }
   // RewindBitPosition, compress_fragment_two_pass.rs:741-750
   BR_DEV void rewind(uint64_t new_pos) {
+    if (first_align != ~0ull && first_align >= new_pos) first_align = ~0ull;  // (that jump is taken back)
     const uint32_t keep = (uint32_t)(new_pos & 7u);
     const uint32_t v = byte_at(new_pos >> 3) & ((1u << keep) - 1u);
     pos = new_pos;
@@ -108,6 +112,7 @@ struct FragmentOut {
     }
   }
   BR_DEV void align() {
+    if (first_align == ~0ull) first_align = pos;
     if (nacc != 0) {
       if (BR_LANE == 0) BR_LIVE_ST8(out + (pos >> 3), (uint8_t)acc);
       pos += 8u - nacc;
@@ -500,9 +505,15 @@ BR_DEV void fr2_store_commands(const uint8_t* literals, uint32_t num_literals, c
   }
 }
 
+// the one decision of a fragment that counts OUTPUT bits (and so sees the padding of an alignment in front of it)
+struct FragmentDecision {
+  uint64_t bits, align;
+  uint32_t fell_back;
+};
+
 // compress_fragment_two_pass, :646-703 + 752-905
 BR_DEV void fr2_compress(const EntropyTables& et, const uint8_t* input, uint32_t input_size, bool is_last, uint32_t table_bits, const FragmentBuffers& B,
-                         FragmentScratch& S, FragmentOut& o) {
+                         FragmentScratch& S, FragmentOut& o, FragmentDecision& dec) {
   const uint64_t initial = o.pos;
   if (table_bits >= 8 && table_bits <= 17) {
     const uint32_t min_match = table_bits < 15 ? 4 : 6;
@@ -526,7 +537,11 @@ BR_DEV void fr2_compress(const EntropyTables& et, const uint8_t* input, uint32_t
       remaining -= block_size;
     }
   }
+  dec.bits = o.pos - initial;
+  dec.align = o.first_align;
+  dec.fell_back = 0;
   if (o.pos - initial > 31 + ((uint64_t)input_size << 3)) {
+    dec.fell_back = 1;
     o.rewind(initial);
     fr_emit_uncompressed(input, input_size, o);
   }
@@ -903,8 +918,11 @@ BR_DEV void fr0_compress_impl(const EntropyTables& et, const uint8_t* input_ptr,
 
 // compress_fragment_fast, :1089-1179
 BR_DEV void fr0_compress(const EntropyTables& et, const uint8_t* input, uint32_t input_size, bool is_last, uint32_t table_bits, const FragmentBuffers& B,
-                         FragmentScratch& S, uint64_t* cmd_code, uint32_t* cmd_code_numbits, FragmentOut& o) {
+                         FragmentScratch& S, uint64_t* cmd_code, uint32_t* cmd_code_numbits, FragmentOut& o, FragmentDecision& dec) {
   const uint64_t initial = o.pos;
+  dec.bits = 0;
+  dec.align = ~0ull;
+  dec.fell_back = 0;
   if (input_size == 0) {
     o.put(1, 1);
     o.put(1, 1);
@@ -913,7 +931,12 @@ BR_DEV void fr0_compress(const EntropyTables& et, const uint8_t* input, uint32_t
   }
   if (table_bits == 9 || table_bits == 11 || table_bits == 13 || table_bits == 15)
     fr0_compress_impl(et, input, input_size, is_last, B.table, table_bits, S, cmd_code, cmd_code_numbits, o);
-  if (o.pos - initial > 31 + ((uint64_t)input_size << 3)) fr0_emit_uncompressed(input, input_size, initial, o);
+  dec.bits = o.pos - initial;
+  dec.align = o.first_align;
+  if (o.pos - initial > 31 + ((uint64_t)input_size << 3)) {
+    dec.fell_back = 1;
+    fr0_emit_uncompressed(input, input_size, initial, o);
+  }
   if (is_last) {
     o.put(1, 1);
     o.put(1, 1);
@@ -921,19 +944,31 @@ BR_DEV void fr0_compress(const EntropyTables& et, const uint8_t* input, uint32_t
   }
 }
 
-// One fragment of a stream (the seam's frag_compress): the state comes from and goes back to B.state.
+// One fragment of a batch (the seam's frag_compress_batch): job j on slab j of B, bits into its own slot of `out`.
 // cmd_code_words: kTreeBitsWords words of workgroup memory.
-BR_DEV void br_fragment(int quality, const EntropyTables& et, const uint8_t* input, uint32_t input_size, bool is_last, uint32_t table_bits,
-                        const FragmentBuffers& B, uint8_t* out, FragmentScratch& S, uint64_t* cmd_code_words) {
-  FragmentState* st = B.state;
+BR_DEV void br_fragment_job(int quality, const EntropyTables& et, const uint8_t* input_base, const FragmentJob& job, uint32_t j, const FragmentBuffers& slabs,
+                            const FragmentState* states_in, FragmentState* states_out, FragmentResult* results, uint8_t* out_base, FragmentScratch& S,
+                            uint64_t* cmd_code_words) {
+  FragmentBuffers B;
+  B.table = slabs.table + (size_t)j * slabs.table_stride;
+  B.commands = slabs.commands ? slabs.commands + (size_t)j * slabs.cmd_stride : nullptr;
+  B.literals = slabs.literals ? slabs.literals + (size_t)j * slabs.lit_stride : nullptr;
+  const uint8_t* input = input_base + job.in_offset;
+  uint8_t* out = out_base + job.out_offset;
   FragmentOut o;
   o.out = out;
-  o.pos = st->storage_ix;
-  o.nacc = (uint32_t)(o.pos & 7u);
-  o.acc = 0;
-  if (o.nacc != 0) o.acc = (uint64_t)(out[o.pos >> 3] & ((1u << o.nacc) - 1u));
-  uint32_t numbits = st->cmd_code_numbits;
+  o.pos = job.start_bits;
+  o.nacc = job.start_bits & 7u;
+  o.acc = 0;  // (the slot starts with a zero byte: the bits in front of start_bits belong to whoever joins the slots)
+  o.first_align = ~0ull;
+  FragmentDecision dec;
+  dec.bits = 0;
+  dec.align = ~0ull;
+  dec.fell_back = 0;
+  uint32_t numbits = 0;
   if (quality == 0) {
+    const FragmentState* st = states_in + job.state_in;
+    numbits = st->cmd_code_numbits;
     for (uint32_t i = 0; i < 128; ++i) {
       S.cmd_depth[i] = st->cmd_depths[i];
       S.cmd_bits[i] = st->cmd_bits[i];
@@ -943,16 +978,25 @@ BR_DEV void br_fragment(int quality, const EntropyTables& et, const uint8_t* inp
       for (uint32_t b = 0; b < 8; ++b) w |= (uint64_t)st->cmd_code[8 * i + b] << (8 * b);
       cmd_code_words[i] = w;
     }
-    fr0_compress(et, input, input_size, is_last, table_bits, B, S, cmd_code_words, &numbits, o);
+    fr0_compress(et, input, job.in_size, job.is_last != 0, job.table_bits, B, S, cmd_code_words, &numbits, o, dec);
   } else {
-    fr2_compress(et, input, input_size, is_last, table_bits, B, S, o);
+    fr2_compress(et, input, job.in_size, job.is_last != 0, job.table_bits, B, S, o, dec);
   }
   o.park();
   FR_FENCE();
   if (BR_LANE == 0) {
-    st->storage_ix = o.pos;
-    if (quality == 0) {
+    FragmentResult r;
+    r.end_bits = o.pos;
+    r.first_align = o.first_align;
+    r.decision_bits = dec.bits;
+    r.decision_align = dec.align;
+    r.fell_back = dec.fell_back;
+    r.bad = 0;
+    results[j] = r;
+    if (quality == 0 && states_out != nullptr) {
+      FragmentState* st = states_out + j;
       st->cmd_code_numbits = numbits;
+      st->pad = 0;
       for (uint32_t i = 0; i < 128; ++i) {
         st->cmd_depths[i] = S.cmd_depth[i];
         st->cmd_bits[i] = S.cmd_bits[i];

@@ -1,6 +1,7 @@
 // fragment_stream.cpp -- see fragment_stream.h
 #include "fragment_stream.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -98,55 +99,161 @@ bool IsFragmentStream(const EncoderParams& user_params) {
 namespace {
 
 // The fragments of `size` bytes (cut at 1 << lgwin, as compress_stream_fast cuts one call's input; one block of the ring-buffer path
-// is a single fragment), one after the other on the device; `finish`: the last one carries is_last.  They go in batches of whole
-// fragments (about 64 MiB of input, at least one fragment) whose bits land in one buffer each: device memory stays bounded however
-// much one call hands over.  Whole bytes are appended to *out, the open byte stays in *fs.
+// is a single fragment), all fragments of a batch side by side on the device (fragment_api.h); `finish`: the last one carries
+// is_last.  They go in batches of whole fragments (about 256 MiB of input, at least one fragment): device memory stays bounded
+// however much one call hands over.  Whole bytes are appended to *out, the open byte stays in *fs.
 void RunFragments(const EncoderParams& p, FragmentStream* fs, const uint8_t* input, size_t size, bool finish, std::vector<uint8_t>* out) {
   const size_t block_size_limit = (size_t)1 << p.lgwin;
-  static const size_t batch_target = getenv("BROTLI_MI355X_FRAGMENT_BATCH") ? (size_t)strtoull(getenv("BROTLI_MI355X_FRAGMENT_BATCH"), nullptr, 10) : ((size_t)64 << 20);
-  const size_t per_batch = std::max<size_t>(1, batch_target / block_size_limit);
+  static const size_t batch_target = getenv("BROTLI_MI355X_FRAGMENT_BATCH") ? (size_t)strtoull(getenv("BROTLI_MI355X_FRAGMENT_BATCH"), nullptr, 10) : ((size_t)256 << 20);
+  static const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
+  static const bool test_again = getenv("BROTLI_MI355X_TEST_FRAGMENT_AGAIN") != nullptr;  // every fragment off phase 0 takes the one-by-one path
+  // (at most 4096 fragments side by side: slabs and grid dimensions stay bounded when the fragments are tiny)
+  const size_t per_batch = std::min<size_t>(4096, std::max<size_t>(1, batch_target / block_size_limit));
   const size_t batch_bytes = per_batch * block_size_limit;
-  const size_t in_cap = std::min(size, batch_bytes), cap = 2 * in_cap + 503 * per_batch + 64;
-  DevBuf in(in_cap + 64, true), outb(cap + 64, true), table(((size_t)1 << 17) * 4 + 64), commands(((size_t)1 << 17) * 4 + 64), literals(((size_t)1 << 17) + 64),
-      state(sizeof(FragmentState) + 64);
+  const size_t in_cap = std::min(size, batch_bytes);
+  const size_t max_jobs = in_cap == 0 ? 1 : (in_cap + block_size_limit - 1) / block_size_limit;
+  auto slot_bytes = [](size_t in_size) { return (2 * in_size + 520 + 63) & ~(size_t)63; };
+  const size_t slots_cap = 2 * in_cap + (520 + 64) * max_jobs + 64;
+  const bool q0 = p.quality == 0;
+  const size_t largest = std::min(in_cap, block_size_limit);  // (the largest fragment of the call)
   FragmentBuffers B;
+  B.table_stride = (size_t)1 << TableBits(p.quality, largest);
+  B.cmd_stride = std::min<size_t>(largest, (size_t)1 << 17) + 16;
+  B.lit_stride = std::min<size_t>(largest, (size_t)1 << 17) + 64;
+  DevBuf in(in_cap + 64, true), slots(slots_cap + 64), table(max_jobs * B.table_stride * 4 + 64),
+      commands(q0 ? 64 : max_jobs * B.cmd_stride * 4 + 64), literals(q0 ? 64 : max_jobs * B.lit_stride + 64),
+      states_a((max_jobs + 1) * sizeof(FragmentState) + 64), states_b(max_jobs * sizeof(FragmentState) + 64),
+      jobs_dev(max_jobs * sizeof(FragmentJob) + 64), results_dev(max_jobs * sizeof(FragmentResult) + 64),
+      pieces_dev(2 * max_jobs * sizeof(FragmentPiece) + 64);
   B.table = (uint32_t*)table.p;
-  B.commands = (uint32_t*)commands.p;
-  B.literals = (uint8_t*)literals.p;
-  B.state = (FragmentState*)state.p;
+  B.commands = q0 ? nullptr : (uint32_t*)commands.p;
+  B.literals = q0 ? nullptr : (uint8_t*)literals.p;
+  FragmentState* const sa = (FragmentState*)states_a.p;  // [0] the code the batch comes in with, [j + 1] what fragment j leaves behind (pass A)
+  FragmentState* const sb = (FragmentState*)states_b.p;  // what fragment j leaves behind (pass B)
   size_t done = 0;
   bool more = true;
+  std::vector<FragmentJob> jobs;
+  std::vector<FragmentResult> results;
+  std::vector<FragmentPiece> pieces;
   std::vector<uint8_t> bytes;
   while (more) {
     const size_t here = std::min(size - done, batch_bytes);
     if (here) dev_h2d_bulk(in.p, input + done, here);
-    uint8_t head[2] = {(uint8_t)fs->last_bytes, (uint8_t)(fs->last_bytes >> 8)};
-    dev_h2d(outb.p, head, 2);
-    fs->state.storage_ix = fs->last_bytes_bits;
-    fs->state.bad = 0;
-    dev_h2d(state.p, &fs->state, sizeof(FragmentState));
-    size_t at = 0;
+    // ---- the fragments of this batch
+    jobs.clear();
+    size_t at = 0, slot_at = 0;
     for (;;) {
       const size_t block_size = std::min(block_size_limit, here - at);
       const bool is_last = (size - done - at == block_size) && finish;
       if (block_size == 0 && !is_last) break;
-      frag_compress(p.quality, (const uint8_t*)in.p + at, (uint32_t)block_size, is_last, TableBits(p.quality, block_size), B, (uint8_t*)outb.p);
+      FragmentJob job;
+      job.in_offset = (uint32_t)at;
+      job.in_size = (uint32_t)block_size;
+      job.is_last = is_last ? 1u : 0u;
+      job.table_bits = TableBits(p.quality, block_size);
+      job.out_offset = slot_at;
+      job.start_bits = 0;
+      job.state_in = 0;
+      jobs.push_back(job);
+      slot_at += slot_bytes(block_size);
       at += block_size;
       if (is_last || at == here) break;
     }
     done += here;
     more = done < size;
-    dev_d2h(&fs->state, state.p, sizeof(FragmentState));
-    if (fs->state.bad) throw std::runtime_error("brotli_mi355x: fragment compressor failed");
-    const uint64_t ix = fs->state.storage_ix;
-    if ((ix >> 3) + 2 > cap) throw std::runtime_error("brotli_mi355x: fragment output ran over its bound");
-    bytes.resize((size_t)(ix >> 3) + 2);
-    dev_d2h_bulk(bytes.data(), outb.p, bytes.size());
+    const uint32_t n = (uint32_t)jobs.size();
+    if (n == 0) break;
+    if (slot_at > slots_cap) throw std::runtime_error("brotli_mi355x: fragment output ran over its bound");
+    // ---- side by side, each into its own slot from bit 0 on
+    if (q0) {
+      // the command code a fragment leaves behind is built from the commands of its own last block, whatever code it came in
+      // with (compress_fragment.rs:1033-1044): pass A runs every fragment but the last with the batch's incoming code to learn
+      // what each leaves behind, pass B runs them all with the right incoming codes
+      dev_h2d(sa, &fs->state, sizeof(FragmentState));
+      if (n > 1) {
+        dev_h2d(jobs_dev.p, jobs.data(), (size_t)(n - 1) * sizeof(FragmentJob));
+        frag_compress_batch(0, (const uint8_t*)in.p, (const FragmentJob*)jobs_dev.p, n - 1, B, sa, sa + 1, (FragmentResult*)results_dev.p, (uint8_t*)slots.p);
+      }
+      for (uint32_t j = 0; j < n; ++j) jobs[j].state_in = j;
+    }
+    dev_h2d(jobs_dev.p, jobs.data(), (size_t)n * sizeof(FragmentJob));
+    frag_compress_batch(p.quality, (const uint8_t*)in.p, (const FragmentJob*)jobs_dev.p, n, B, sa, q0 ? sb : nullptr, (FragmentResult*)results_dev.p, (uint8_t*)slots.p);
+    results.resize(n);
+    dev_d2h(results.data(), results_dev.p, (size_t)n * sizeof(FragmentResult));
+    if (q0 && selftest && n > 1) {
+      std::vector<FragmentState> a(n + 1), b(n);
+      dev_d2h(a.data(), sa, (size_t)(n + 1) * sizeof(FragmentState));
+      dev_d2h(b.data(), sb, (size_t)n * sizeof(FragmentState));
+      for (uint32_t j = 0; j + 1 < n; ++j)
+        if (memcmp(&a[j + 1], &b[j], sizeof(FragmentState)) != 0) throw std::runtime_error("brotli_mi355x selftest: the command code a quality 0 fragment leaves behind depends on the code it came in with");
+    }
+    // ---- where the slots go in the stream.  A fragment's bits move with the phase up to its first jump to a byte boundary; what
+    // comes behind lands on whole bytes.  The padding of that jump is the one thing of a fragment that depends on the phase, and it
+    // reaches one decision -- "larger than stored raw?", which counts output bits: where the true phase turns that decision around,
+    // the fragment is compressed again by itself at its true phase.
+    pieces.clear();
+    uint64_t cur = fs->last_bytes_bits;
+    for (uint32_t j = 0; j < n; ++j) {
+      FragmentResult r = results[j];
+      if (r.bad) throw std::runtime_error("brotli_mi355x: fragment compressor failed");
+      const uint32_t phase = (uint32_t)(cur & 7u);
+      const uint64_t slot_bit = jobs[j].out_offset * 8;
+      bool again = false;
+      if (phase != 0 && r.decision_align != ~0ull) {
+        const uint64_t a = r.decision_align;
+        const uint64_t pad0 = (8 - (a & 7)) & 7, padt = (8 - ((phase + a) & 7)) & 7;
+        const uint64_t total = r.decision_bits - pad0 + padt;
+        const bool fall_back = total > 31 + ((uint64_t)jobs[j].in_size << 3);
+        again = fall_back != (r.fell_back != 0);
+      }
+      if (test_again && phase != 0) again = true;
+      if (again) {
+        if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "fragment %u of %u: compressed again at phase %u (the raw fall-back hangs on the padding)\n", j, n, phase);
+        // (as fragment 0 of a batch of one that sits where fragment j sat: its table slab, its incoming code, its result slot)
+        FragmentJob one = jobs[j];
+        one.start_bits = phase;
+        one.state_in = 0;
+        dev_h2d((FragmentJob*)jobs_dev.p + j, &one, sizeof(FragmentJob));
+        FragmentBuffers Bj = B;
+        Bj.table += (size_t)j * B.table_stride;
+        if (Bj.commands) Bj.commands += (size_t)j * B.cmd_stride;
+        if (Bj.literals) Bj.literals += (size_t)j * B.lit_stride;
+        frag_compress_batch(p.quality, (const uint8_t*)in.p, (const FragmentJob*)jobs_dev.p + j, 1, Bj, sa + j, q0 ? sb + j : nullptr, (FragmentResult*)results_dev.p + j,
+                            (uint8_t*)slots.p);
+        dev_d2h(&r, (FragmentResult*)results_dev.p + j, sizeof(FragmentResult));
+        if (r.bad) throw std::runtime_error("brotli_mi355x: fragment compressor failed");
+        pieces.push_back({slot_bit + phase, cur, r.end_bits - phase});
+        cur += r.end_bits - phase;
+        continue;
+      }
+      if (r.first_align == ~0ull) {
+        pieces.push_back({slot_bit, cur, r.end_bits});
+        cur += r.end_bits;
+      } else {
+        const uint64_t a = r.first_align, a8 = (a + 7) & ~(uint64_t)7;
+        if (a) pieces.push_back({slot_bit, cur, a});
+        const uint64_t aligned = (cur + a + 7) & ~(uint64_t)7;
+        if (r.end_bits > a8) pieces.push_back({slot_bit + a8, aligned, r.end_bits - a8});
+        cur = aligned + (r.end_bits - a8);
+      }
+    }
+    if (q0) dev_d2h(&fs->state, sb + (n - 1), sizeof(FragmentState));
+    // ---- the join
+    const uint64_t ix = cur;
+    const size_t joined_bytes = (size_t)(ix >> 3) + 2;
+    DevBuf joined(((joined_bytes + 7) & ~(size_t)7) + 64, true);
+    uint8_t head[2] = {(uint8_t)fs->last_bytes, (uint8_t)(fs->last_bytes >> 8)};
+    dev_h2d(joined.p, head, 2);
+    if (!pieces.empty()) {
+      dev_h2d(pieces_dev.p, pieces.data(), pieces.size() * sizeof(FragmentPiece));
+      frag_join((const uint8_t*)slots.p, (const FragmentPiece*)pieces_dev.p, (uint32_t)pieces.size(), (uint8_t*)joined.p);
+    }
+    bytes.resize(joined_bytes);
+    dev_d2h_bulk(bytes.data(), joined.p, bytes.size());
     out->insert(out->end(), bytes.begin(), bytes.begin() + (ptrdiff_t)(ix >> 3));
     fs->last_bytes = (uint16_t)(bytes[(size_t)(ix >> 3)] | (bytes[(size_t)(ix >> 3) + 1] << 8));
     fs->last_bytes_bits = (uint8_t)(ix & 7);
     if (fs->last_bytes_bits != 0) fs->last_bytes &= (uint16_t)((1u << fs->last_bytes_bits) - 1u); else fs->last_bytes = 0;
-    if (more) dev_memset(outb.p, 0, (size_t)(ix >> 3) + 16);  // (the bit writer ORs nothing, but the open byte is read back: a clean start)
   }
 }
 

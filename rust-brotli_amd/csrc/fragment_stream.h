@@ -19,7 +19,7 @@ struct FragmentStream {
   bool started = false;
   uint16_t last_bytes = 0;      // the open byte(s) of the output: window bits at first, then what the last piece left
   uint8_t last_bytes_bits = 0;
-  FragmentState state{};        // host copy between calls (storage_ix is per call)
+  FragmentState state{};        // quality 0: the command prefix code, host copy between calls
   // catable streams only (FragmentRingCompress): what the reference keeps in its ring buffer and books
   std::vector<uint8_t> pending;  // input copied in, not yet compressed (less than a block, or the block that has just filled up)
   uint32_t first_mb = 0;         // is_first_mb, encode.rs:2261-2333: 0 nothing written, 1 magic-number block, 2 one raw byte, 3 both

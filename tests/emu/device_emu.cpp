@@ -818,16 +818,26 @@ void lz77_quick_block(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
   br_quick_block(J, P, T, B.text, seg, B.entries[block], B.cmds + seg.cmd_base, B.exits + block);
 }
 
-// ---- qualities 0 and 1 (fragment_device.h): the same item code, called directly
-void frag_compress(int quality, const uint8_t* input, uint32_t input_size, bool is_last, uint32_t table_bits, const FragmentBuffers& B, uint8_t* out) {
+// ---- qualities 0 and 1 (fragment_device.h): the same item code, called directly, one fragment after the other
+void frag_compress_batch(int quality, const uint8_t* input, const FragmentJob* jobs, uint32_t n, const FragmentBuffers& B, const FragmentState* states_in,
+                         FragmentState* states_out, FragmentResult* results, uint8_t* out) {
   const DeviceTables& dt = dev_tables();
   EntropyTables et;
   et.logs_16 = dt.logs_16;
   et.logs_8 = dt.logs_8;
-  memset(B.table, 0, ((size_t)1 << table_bits) * 4);
   static thread_local FragmentScratch S;
   static thread_local uint64_t cmd_code_words[kTreeBitsWords];
-  br_fragment(quality, et, input, input_size, is_last, table_bits, B, out, S, cmd_code_words);
+  for (uint32_t j = 0; j < n; ++j) {
+    memset(B.table + (size_t)j * B.table_stride, 0, ((size_t)1 << jobs[j].table_bits) * 4);
+    br_fragment_job(quality, et, input, jobs[j], j, B, states_in, states_out, results, out, S, cmd_code_words);
+  }
+}
+void frag_join(const uint8_t* src, const FragmentPiece* pieces, uint32_t n, uint8_t* dst) {
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint64_t b = 0; b < pieces[i].nbits; ++b) {
+      const uint64_t s = pieces[i].src_bit + b, d = pieces[i].dst_bit + b;
+      if ((src[s >> 3] >> (s & 7)) & 1) dst[d >> 3] |= (uint8_t)(1u << (d & 7));
+    }
 }
 
 }  // namespace brotli_mi355x

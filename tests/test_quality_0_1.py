@@ -163,13 +163,61 @@ def _several_fragments(lib):
 
 
 def test_calls_larger_than_a_batch_emu():
-    """one call's fragments go through the device in batches (64 MiB of input; here turned down to 200 KB): same stream"""
+    """one call's fragments go through the device in batches (256 MiB of input; here turned down to 200 KB): same stream"""
     import subprocess
     import sys
     child = ("import sys; sys.path.insert(0, %r); import orc, synth, test_cabi; lib = test_cabi._load('emu'); d = synth.mixed(1500000, 5)\n"
              "for q, w in ((0, 16), (1, 16), (0, 10), (1, 22)):\n    assert lib.compress(d, q, w) == orc.compress(d, q, w), (q, w)\nprint('ok')" % HERE)
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, BROTLI_MI355X_FRAGMENT_BATCH="200000"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+_SIDE_BY_SIDE_CHILD = """
+import random, sys
+sys.path.insert(0, %r)
+import orc, synth, test_cabi
+lib = test_cabi._load(%r)
+rng = random.Random(%d)
+text, rnd = synth.markov_text(1 << 20, 3), synth.random_bytes(1 << 20)
+for it in range(%d):
+    # text, random bytes and zeros in pieces of all sizes: stored and compressed meta-blocks alternate inside and across fragments,
+    # so that fragments start at every bit phase and end byte aligned or not
+    parts, total = [], rng.choice([3000, 20000, 100000, 400000])
+    while sum(map(len, parts)) < total:
+        k, ln = rng.choice([0, 0, 1, 1, 2]), rng.choice([1, 7, 100, 900, 1024, 1500, 5000, 40000, 140000])
+        off = rng.randrange(0, (1 << 20) - ln)
+        parts.append(text[off:off + ln] if k == 0 else (rnd[off:off + ln] if k == 1 else bytes(ln)))
+    d = b"".join(parts)[:total + rng.randrange(0, 50)]
+    w = rng.choice([10, 10, 11, 12, 14, 16, 17, 18])
+    for q in (0, 1):
+        assert lib.compress(d, q, w) == orc.compress(d, q, w), (it, q, w, len(d))
+print("ok")
+"""
+
+
+def _side_by_side(which, seed, cases, force_again):
+    """Round 5: the fragments of a call are compressed side by side, each from bit 0 of a slot of its own, quality 0 in two passes
+    (the command code a fragment leaves behind does not depend on the one it came in with -- checked by BROTLI_MI355X_SELFTEST),
+    and joined afterwards; BROTLI_MI355X_TEST_FRAGMENT_AGAIN sends every fragment off phase 0 through the one-by-one path that
+    the join falls back to where the raw fall-back hangs on the padding of an alignment."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BROTLI_MI355X_SELFTEST="1")
+    if force_again:
+        env["BROTLI_MI355X_TEST_FRAGMENT_AGAIN"] = "1"
+    r = subprocess.run([sys.executable, "-c", _SIDE_BY_SIDE_CHILD % (HERE, which, seed, cases)], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_fragments_side_by_side_emu():
+    _side_by_side("emu", 1, 40, False)
+    _side_by_side("emu", 2, 25, True)
+
+
+@pytest.mark.gpu
+def test_fragments_side_by_side_gpu():
+    _side_by_side("gpu", 11, 40, False)
+    _side_by_side("gpu", 12, 20, True)
 
 
 def test_several_fragments_emu():
