@@ -17,7 +17,6 @@
 #include "device_api.h"
 #include "lz77_chain.h"
 #include "lz77_rows.h"
-#include "lz77_lanes.h"
 #include "device_scan.h"
 #include "lz77_parse_args.h"
 #include "zopfli_device.h"
@@ -1484,32 +1483,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kDeep ? 4 : 
   }
 }
 
-// One chain per LANE (lz77_lanes.h): round 0 and the warm-up of the plain quality-5 configuration, where there are enough chains to
-// fill wavefronts with them.  One wave per SIMD is the plan (512 waves for 64 MiB), so the register file is the chain's: the
-// 20 candidates of a search keep their text in registers.
-template <uint32_t kHtl>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_parse_lanes(ParseArgs a) {
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  if (i >= a.count) return;
-  const uint32_t k = a.first_segment + i;
-  Lz77Params P = a.P;
-  P.ndist = 4;
-  P.block_bits = 4;
-  P.spree_window = 64;
-  P.score_per_byte = 135;
-  P.dict_break = 0;
-  P.reset_pos = 0;
-  P.masked_from = kNeverMasked;
-  P.htl = kHtl;
-  uint32_t walked, searches, commands;
-  br_lane_parse<kHtl>(P, a.T, a.segments[k], a.entries[k], a.exits[k], &walked, &searches, &commands);
-  if (a.T.work) {
-    atomicAdd(a.T.work + 0, (unsigned long long)walked);
-    atomicAdd(a.T.work + 1, (unsigned long long)searches);
-    atomicAdd(a.T.work + 2, (unsigned long long)commands);
-  }
-}
-
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
                          SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, uint8_t* sched,
                          uint32_t count) {
@@ -1564,18 +1537,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
   const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
   static const uint32_t lds_pad = getenv("BROTLI_MI355X_LDS_PAD") ? (uint32_t)atoi(getenv("BROTLI_MI355X_LDS_PAD")) : 0u;  // occupancy experiments
-  // one chain per lane where a launch holds every segment of a large input (round 0, the warm-up): see lz77_lanes.h
-  static const uint32_t lanes_min = getenv("BROTLI_MI355X_LANES_MIN") ? (uint32_t)atoi(getenv("BROTLI_MI355X_LANES_MIN")) : 12288u;
-  const bool lanes = B.rows && list == nullptr && sched == nullptr && B.run_end == nullptr && count >= lanes_min && plain_q5_config(P) &&
-                     getenv("BROTLI_MI355X_NO_SPEC") == nullptr;
-  if (lanes) {
-    const bool own = segments == B.segments;
-    a.T.checkpoints = own ? (Checkpoint*)B.checkpoints : nullptr;
-    a.per_xcd = 0;
-    const uint32_t waves = (count + 63u) / 64u;
-    if (P.htl == 8) hipLaunchKernelGGL((k_parse_lanes<8>), dim3(waves), dim3(64), 0, BR_STREAM, a);
-    else hipLaunchKernelGGL((k_parse_lanes<4>), dim3(waves), dim3(64), 0, BR_STREAM, a);
-  } else if (P.hasher_kind == 9) {
+  if (P.hasher_kind == 9) {
     hipLaunchKernelGGL((k_parse_segments<true, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else if (B.rows) {
     static const bool spec_off = getenv("BROTLI_MI355X_NO_SPEC") != nullptr;

@@ -15,7 +15,6 @@
 #include "../../rust-brotli_amd/csrc/device_api.h"
 #include "../../rust-brotli_amd/csrc/lz77_chain.h"
 #include "../../rust-brotli_amd/csrc/lz77_rows.h"
-#include "../../rust-brotli_amd/csrc/lz77_lanes.h"
 #include "../../rust-brotli_amd/csrc/zopfli_device.h"
 #include "../../rust-brotli_amd/csrc/quick_device.h"
 #include "../../rust-brotli_amd/csrc/fragment_device.h"
@@ -442,22 +441,6 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.splice_off = splice_part_off;
   static const bool splice_off = getenv("BROTLI_MI355X_NO_SPLICE") != nullptr;
   const bool splice = !splice_off && sched != nullptr && own_segments && B.rows != nullptr && B.checkpoints != nullptr && B.splice_lists != 0;
-  // one chain per lane (lz77_lanes.h): the device takes round 0 and the warm-up of large inputs this way; here every launch that
-  // qualifies by its configuration does, whatever its size, so that the CPU suite runs the lane code wherever it can
-  static const uint32_t lanes_min = getenv("BROTLI_MI355X_LANES_MIN") ? (uint32_t)atoi(getenv("BROTLI_MI355X_LANES_MIN")) : 0u;
-  const bool lanes = B.rows && list == nullptr && sched == nullptr && count >= lanes_min && P.hasher_kind != 9 && P.ndist == 4 && P.block_bits == 4 &&
-                     P.spree_window == 64 && P.score_per_byte == 135 && P.dict_break == 0 && P.reset_pos == 0 && P.masked_from == kNeverMasked &&
-                     (P.htl == 4 || P.htl == 8) && getenv("BROTLI_MI355X_NO_SPEC") == nullptr;
-  if (lanes) {
-    if (getenv("BROTLI_MI355X_DEBUG_LAUNCH")) fprintf(stderr, "lane launch: %u chains\n", count);
-    for (uint32_t i = 0; i < count; ++i) {
-      const uint32_t k = first_segment + i;
-      uint32_t w, sr, cm;
-      if (P.htl == 8) br_lane_parse<8>(P, T, segments[k], entries[k], exits[k], &w, &sr, &cm);
-      else br_lane_parse<4>(P, T, segments[k], entries[k], exits[k], &w, &sr, &cm);
-    }
-    return;
-  }
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
     if (P.hasher_kind == 9) {
