@@ -27,8 +27,12 @@
  * BROTLI_OPERATION_FLUSH encodes everything received so far (byte-identical to the reference's flush,
  * encode.rs:2940-2975 + 1541-1566) at a cost proportional to window + new input; BROTLI_OPERATION_EMIT_METADATA
  * (encode.rs:2579-2685) flushes pending input the same way and writes the payload (<= 16 MiB) as a metadata block.
- * A stream may be of any length: the hasher reset of the reference at its position wraps (3, 5, 7 ... GiB,
- * encode.rs:1623-1631, 1705-1710) is reproduced.  Streams with a custom
+ * A stream of quality 5..9 (and "9.5") may be of any length: the hasher reset of the reference at its position wraps
+ * (3, 5, 7 ... GiB, encode.rs:1623-1631, 1705-1710) is reproduced; qualities 0 / 1 keep no hasher between fragments and have no
+ * such limit either.  Limits: a stream of quality 2..4 or 10 / 11 must stay below the first wrap (3 GiB) -- their hashers (the
+ * BasicHasher table, the H10 trees) travel through the stream as they are and the reset is not reproduced for them: the call
+ * that would cross the wrap fails (BrotliMi355xLastError says why; the state is unusable afterwards, like after any failed
+ * call), and BrotliEncoderCompress refuses such an input up front, before any work is done.  Streams with a custom
  * dictionary or in the catable / appendable modes stream and flush the same way, piece by piece in bounded memory
  * (tests/test_streaming_dictionary.py).  All input offered to a call is always consumed (*available_in becomes 0).
  *

@@ -225,10 +225,12 @@ void CompressChunk(const EncoderParams& user_params, const uint8_t* input, size_
     FragmentStream fs;
     if (IsFragmentRing(req.params)) FragmentRingCompress(req.params, &fs, req.input, req.input_size, true, false, out);
     else FragmentStreamCompress(req.params, &fs, req.input, req.input_size, true, false, out);
-    // compress_part gives a shard BrotliEncoderMaxCompressedSize(its length) of room and fails the call when the stream does not fit
-    // (threading/mod.rs:337-411): small fragments of these qualities on incompressible input do not
+    // compress_part gives a shard BrotliEncoderMaxCompressedSize(its length) of room; its compress_stream loop returns once that
+    // buffer is full without asking whether the stream is finished (threading/mod.rs:337-411), so the reference hands back a
+    // TRUNCATED shard where the stream does not fit -- small fragments of these qualities on incompressible input do not.
+    // Refused here instead of reproduced.
     if (out->size() > MaxCompressedSize(req.input_size))
-      throw std::runtime_error("brotli_mi355x: the reference encoder fails on this input: a shard of quality 0 / 1 outgrows BrotliEncoderMaxCompressedSize of its length");
+      throw std::runtime_error("brotli_mi355x: refused: a shard of quality 0 / 1 outgrows BrotliEncoderMaxCompressedSize of its length (the reference hands back a truncated shard here: compress_part stops when its fixed buffer is full)");
     return;
   }
   EncodeStream(req, out, nullptr);
@@ -250,7 +252,8 @@ class ShardWorkers {
   // runs job(0) ... job(count - 1), each exactly once, on the calling thread and the helpers; rethrows the first exception
   // light: every job is one wavefront on a table of its own (qualities 2 .. 4, quick_device.h) -- all of them side by side
   void Run(size_t count, const std::function<void(size_t)>& job, bool light = false) {
-    const size_t workers = std::min(count, light && WorkerCount() > 1 ? (size_t)16 : WorkerCount());
+    // (BROTLI_MI355X_SHARD_WORKERS, when set, bounds the light jobs as well: it is the caller's handle on device memory)
+    const size_t workers = std::min(count, light && WorkerCount() > 1 && !WorkerCountSetByUser() ? (size_t)16 : WorkerCount());
     if (workers <= 1) {
       for (size_t i = 0; i < count; ++i) job(i);
       return;
@@ -289,6 +292,10 @@ class ShardWorkers {
     size_t helpers_wanted = 0, helpers_in = 0;  // (under mu_)
     std::exception_ptr error;                   // (under mu_)
   };
+  static bool WorkerCountSetByUser() {
+    static const bool set = getenv("BROTLI_MI355X_SHARD_WORKERS") != nullptr;
+    return set;
+  }
   static size_t WorkerCount() {
     static const size_t n = [] {
       const char* e = getenv("BROTLI_MI355X_SHARD_WORKERS");
@@ -390,7 +397,7 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
       EncoderParams fin = params;
       FinalizeParams(&fin);
       ShardWorkers::Get().Run(num_threads, [&](size_t t) { CompressChunk(params, input, input_size, false, t, num_threads, &chunks[t], nullptr); },
-                              fin.quality < 5);
+                              fin.quality >= 2 && fin.quality < 5);
       // stitched straight into the caller's buffer
       ChunkStitcher stitcher;
       ByteSink sink(encoded, *encoded_size);
@@ -530,12 +537,18 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, BrotliEncoderOper
         // A catable stream at these qualities that has seen input: the reference's process_metadata asks encode_data to flush
         // "pending" input for ever -- its quality 0 / 1 branch never moves last_flush_pos_ (encode.rs:2335-2389, 2621-2629) -- and
         // does not return.  Nothing to reproduce.
-        if (IsFragmentRing(s->params) && s->fragments.saw_input)
-          throw std::runtime_error("a metadata block behind input on a catable stream of quality 0 / 1: the reference encoder does not return from this call");
+        // (It does return while everything received so far goes out as the raw first bytes of the stream -- at most the first
+        // two or three bytes: those move last_flush_pos_.)  The refusal leaves the state as it was: nothing has been done.
+        if (IsFragmentRing(s->params) && !FragmentRingMetadataReturns(s->fragments)) {
+          SetError("BrotliEncoderCompressStream", "a metadata block behind input on a catable stream of quality 0 / 1: the reference encoder does not return from this call");
+          return BROTLI_FALSE;
+        }
         if (s->output_pos != 0) {
           s->output.erase(s->output.begin(), s->output.begin() + (ptrdiff_t)s->output_pos);
           s->output_pos = 0;
         }
+        // encode_data(is_last = false, force_flush = true) on what is pending: the raw first bytes (nothing else is, see above)
+        if (IsFragmentRing(s->params) && !s->fragments.pending.empty()) FragmentRingCompress(s->params, &s->fragments, nullptr, 0, false, true, &s->output);
         FragmentStreamMetadataHeader(s->params, &s->fragments, n_meta, &s->output);
       } catch (const std::exception& e) {
         SetError("BrotliEncoderCompressStream", e.what());
@@ -756,6 +769,14 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
   // encode.rs:1468-1481: the one-shot entry runs quality 10 ("9.5") at quality 9, with an H9 hasher made ahead of time from
   // {q9_5, quality 10} -- the hasher quality 9 selects anyway.  (Quality 10 / 11 through the stream API are Zopfli.)
   if (quality == 10) quality = 9;
+  // Qualities 2 .. 4 and 11 (the BasicHasher table / the H10 trees travel through the stream as they are) do not reproduce the
+  // hasher reset of the reference's 3 GiB position wrap (encode.rs:1623-1631, 1705-1710): a one-shot input that would reach it is
+  // refused here, before any work is done, rather than after gigabytes (include/brotli_mi355x.h, "Limits").
+  if (((quality >= 2 && quality <= 4) || quality == 11) && (uint64_t)input_size > FirstPositionWrap()) {
+    SetError("BrotliEncoderCompress", "qualities 2..4 and 10/11: inputs that cross the reference's position wrap at 3 GiB are not supported (split the input, e.g. BrotliEncoderCompressMulti)");
+    *encoded_size = 0;
+    return BROTLI_FALSE;
+  }
   // (qualities 2 .. 4 walk their blocks one launch at a time with the host resolver replaying the stream so far in between: the
   // pieces of the stream machine keep that replay short -- 16 KiB blocks, quadratic otherwise)
   const size_t stream_above = (quality >= 2 && quality <= 4) ? std::min(OneShotStreamThreshold(), (size_t)64 << 20) : OneShotStreamThreshold();

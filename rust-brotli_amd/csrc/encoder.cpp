@@ -240,6 +240,9 @@ uint64_t LastHasherResetAtOrBelow(uint64_t pos) {
 }
 }  // namespace
 
+// stream position of the reference's first hasher reset (3 GiB; the tests scale it down, WrapShift)
+uint64_t FirstPositionWrap() { return 3ull << WrapShift(); }
+
 uint32_t ChooseSegmentBytes(size_t input_bytes) {
   if (input_bytes <= ((size_t)4 << 20)) return 512;
   if (input_bytes <= ((size_t)16 << 20)) return 1024;

@@ -79,6 +79,8 @@ struct EncodeRequest {
 // Segment size of the speculative parse: short segments give low latency (few, short chains finish quickly), long ones
 // less per-segment overhead (warm-up, resolver work) on big inputs.
 uint32_t ChooseSegmentBytes(size_t input_bytes);
+// stream position of the reference's first hasher reset (encode.rs:1623-1631): 3 GiB
+uint64_t FirstPositionWrap();
 
 void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeStats* stats);
 

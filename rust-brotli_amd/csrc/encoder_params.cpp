@@ -155,9 +155,10 @@ void ChooseHasher(EncoderParams* params) {
   }
 }
 
-// The 512-deep rings of quality 11 + Q9_5 run on kernels of their own (ChainScratchT<.., kDeep>).  Their evidence on the
-// hardware is thin so far -- the reference's 129 715-byte known answer, profiles/r03_q11_q9_5_deep_rings_probe.log; the wider
-// identity set has only run on the emulation build -- hence the switch to turn them off.
+// The 512-deep rings of quality 11 + Q9_5 run on kernels of their own (ChainScratchT<.., kDeep>).  On the hardware: the
+// reference's 129 715-byte known answer and the wide identity set (H5 and H6 at depth 512, lgwin 18 / 20 / 22, streamed pieces,
+// the API sweep), part of the default -m gpu suite since round 4 (profiles/r04_deep_rings_wide_gpu.log).  The switch is a
+// diagnosis aid: with it set such parameters are refused, not taken another way.
 static bool DeepRingsAllowed() {
   static const bool off = getenv("BROTLI_MI355X_NO_DEEP_RINGS") != nullptr;
   return !off;

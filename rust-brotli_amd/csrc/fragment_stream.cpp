@@ -337,6 +337,7 @@ void FragmentRingCompress(const EncoderParams& user_params, FragmentStream* fs, 
       const size_t n = std::min(room, avail);
       fs->pending.insert(fs->pending.end(), input + (size - avail), input + (size - avail) + n);
       fs->saw_input = true;
+      fs->input_seen += n;
       avail -= n;
       continue;
     }
@@ -384,6 +385,7 @@ void FragmentRingCompress(const EncoderParams& user_params, FragmentStream* fs, 
         hb.bytes(fs->pending.data(), n);
         skip = n;
         bytes -= n;
+        fs->flushed_raw += n;
         fs->first_mb = n >= 2 ? 3 : (fs->first_mb == 2 ? 3 : 2);
       }
     }
@@ -395,6 +397,11 @@ void FragmentRingCompress(const EncoderParams& user_params, FragmentStream* fs, 
     }
     if (is_last) processing = false;
   }
+}
+
+bool FragmentRingMetadataReturns(const FragmentStream& fs) {
+  const uint64_t will_go_raw = fs.first_mb != 3 ? std::min<uint64_t>(2, fs.pending.size()) : 0;
+  return fs.input_seen == fs.flushed_raw + will_go_raw;
 }
 
 void FragmentStreamMetadataHeader(const EncoderParams& user_params, FragmentStream* fs, size_t size, std::vector<uint8_t>* out) {

@@ -25,6 +25,8 @@ struct FragmentStream {
   uint32_t first_mb = 0;         // is_first_mb, encode.rs:2261-2333: 0 nothing written, 1 magic-number block, 2 one raw byte, 3 both
   size_t size_hint = 0;          // update_size_hint at the first encode_data (the magic-number block carries it)
   bool saw_input = false;
+  uint64_t input_seen = 0;       // input_pos_: bytes copied in so far
+  uint64_t flushed_raw = 0;      // last_flush_pos_: the quality 0 / 1 branch of encode_data moves it by the raw first bytes only (encode.rs:2283-2389)
 };
 
 // true for the parameter sets that take this path in the reference: quality 0 / 1 and not catable (encode.rs:2929-2937)
@@ -40,6 +42,10 @@ void FragmentRingCompress(const EncoderParams& user_params, FragmentStream* fs, 
 // (the byte-alignment block behind the data, encode.rs:1541-1566), neither = PROCESS.  Whole bytes of output are appended to *out.
 void FragmentStreamCompress(const EncoderParams& user_params, FragmentStream* fs, const uint8_t* input, size_t size, bool finish, bool flush,
                             std::vector<uint8_t>* out);
+// BROTLI_OPERATION_EMIT_METADATA on a catable stream of these qualities: process_metadata (encode.rs:2579-2685) has encode_data flush
+// "pending" input until input_pos_ == last_flush_pos_ -- which the quality 0 / 1 branch moves by the raw first bytes only.  True if
+// the reference returns from that loop: everything received so far is (or, after the forced flush, will be) raw first bytes.
+bool FragmentRingMetadataReturns(const FragmentStream& fs);
 // BROTLI_OPERATION_EMIT_METADATA on such a stream: the header of a metadata block of `size` bytes behind the open byte
 // (write_metadata_header, encode.rs:2545-2575); the caller appends the payload
 void FragmentStreamMetadataHeader(const EncoderParams& user_params, FragmentStream* fs, size_t size, std::vector<uint8_t>* out);

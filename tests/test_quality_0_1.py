@@ -138,8 +138,26 @@ def _refusals(lib):
             e.write(a)
             with pytest.raises(Exception):
                 e.emit_metadata(b"never returns in the reference")
+            # the refusal leaves the stream as it was: it can still be finished
+            assert e.finish() == orc.stream_compress(a, [(Q, q), (W, 22), (167, 1)])[0]
         finally:
             e.close()
+        # ... and the reference DOES return while everything received so far goes out as the raw first bytes of the catable
+        # stream (they are what moves last_flush_pos_, encode.rs:2283-2333): a metadata block behind 0, 1 or 2 bytes of input
+        for upto in (0, 1, 2):
+            params = [(Q, q), (W, 18), (167, 1)]
+            d = a[:50000]
+            e = lib.encoder(params=params)
+            try:
+                pieces = []
+                if upto:
+                    e.write(d[:upto])
+                pieces.append(e.emit_metadata(b"meta" * 5))
+                e.write(d[upto:])
+                pieces.append(e.finish())
+            finally:
+                e.close()
+            assert pieces == orc.stream_with_flushes(d, params, [(upto, b"meta" * 5)]), (q, upto)
 
 
 def test_catable_streams_dictionaries_and_shards_emu():
