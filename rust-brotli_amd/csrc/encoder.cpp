@@ -938,18 +938,36 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     B.out_words = mm.alloc<uint64_t>(out_words);
     dev_h2d(B.mb_out_bit, mb_out_bit.data(), (n_mb + 1) * 8);
     mb_emit(B);
-    for (uint32_t m = 0; m < n_mb; ++m) {
-      if (descs[m].uncompressed) continue;
-      mb_copy_bits(B.out_words, mb_out_bit[m], B.header_words + (size_t)m * B.header_stride, results[m].header_bits);
-    }
-    for (const RawCopy& rc : copies) dev_d2d((uint8_t*)B.out_words + rc.dst_byte, text + rc.src_pos, rc.bytes);
-    if (!bits.pieces.empty()) {
-      // host composed pieces: uploaded as a tiny word-aligned bit string each
-      for (const BitPiece& bp : bits.pieces) {
-        uint64_t w = bp.bits;
-        uint64_t* tmp = mm.alloc<uint64_t>(2);
-        dev_h2d(tmp, &w, 8);
-        mb_copy_bits(B.out_words, bp.pos, tmp, bp.nbits);
+    {
+      // the headers of the compressed meta-blocks, the bytes of the stored ones and what the host composed (stream header, the
+      // headers of stored meta-blocks, tail blocks): one upload and three launches, however many meta-blocks there are -- an
+      // incompressible gigabyte is 700 stored meta-blocks, and a launch + an upload + an allocation per piece was 100 ms of it
+      std::vector<MbBitCopy> headers;
+      for (uint32_t m = 0; m < n_mb; ++m)
+        if (!descs[m].uncompressed) headers.push_back({mb_out_bit[m], (uint64_t)m * B.header_stride, results[m].header_bits});
+      std::vector<MbRawCopy> raws;
+      for (const RawCopy& rc : copies) raws.push_back({rc.dst_byte, rc.src_pos, rc.bytes});
+      std::vector<MbBitPiece> pieces;
+      for (const BitPiece& bp : bits.pieces) pieces.push_back({bp.pos, bp.nbits, 0, bp.bits});
+      const size_t bytes = headers.size() * sizeof(MbBitCopy) + raws.size() * sizeof(MbRawCopy) + pieces.size() * sizeof(MbBitPiece);
+      if (bytes != 0) {
+        std::vector<uint8_t> blob(bytes);
+        uint8_t* at = blob.data();
+        memcpy(at, headers.data(), headers.size() * sizeof(MbBitCopy));
+        at += headers.size() * sizeof(MbBitCopy);
+        memcpy(at, raws.data(), raws.size() * sizeof(MbRawCopy));
+        at += raws.size() * sizeof(MbRawCopy);
+        memcpy(at, pieces.data(), pieces.size() * sizeof(MbBitPiece));
+        uint8_t* blob_dev = mm.alloc<uint8_t>(bytes + 64);
+        dev_h2d(blob_dev, blob.data(), bytes);
+        const MbBitCopy* headers_dev = (const MbBitCopy*)blob_dev;
+        const MbRawCopy* raws_dev = (const MbRawCopy*)(blob_dev + headers.size() * sizeof(MbBitCopy));
+        const MbBitPiece* pieces_dev = (const MbBitPiece*)(blob_dev + headers.size() * sizeof(MbBitCopy) + raws.size() * sizeof(MbRawCopy));
+        // (a grid dimension holds 65 535 items)
+        for (size_t i = 0; i < headers.size(); i += 32768) mb_copy_bits_batch(B.out_words, B.header_words, headers_dev + i, (uint32_t)std::min<size_t>(32768, headers.size() - i));
+        for (size_t i = 0; i < raws.size(); i += 32768) mb_raw_copies((uint8_t*)B.out_words, text, raws_dev + i, (uint32_t)std::min<size_t>(32768, raws.size() - i));
+        mb_place_pieces(B.out_words, pieces_dev, (uint32_t)pieces.size());
+        dev_sync();  // (blob is host memory that goes out of scope)
       }
     }
     stats.ms_phase[7] += clk.lap(prof, "mb7");

@@ -41,6 +41,26 @@ void mb_write_headers(const MbBuffers& B);
 void mb_symbol_bits(const MbBuffers& B, void* scan_scratch);
 void mb_emit(const MbBuffers& B);
 void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits);
+// The tail of the emission in three launches, however many meta-blocks there are (an incompressible gigabyte is 700 stored
+// meta-blocks, each with a handful of host-composed header pieces and one copy of its bytes):
+// out |= bits [0, nbits) of src_words + src_word, placed at dst_bit, for every item (the headers of the compressed meta-blocks)
+struct MbBitCopy {
+  uint64_t dst_bit, src_word, nbits;
+};
+void mb_copy_bits_batch(uint64_t* out, const uint64_t* src_words, const MbBitCopy* items_dev, uint32_t n);
+// out |= the low nbits of bits at bit position pos, for every piece (nbits <= 64): what the host composed
+struct MbBitPiece {
+  uint64_t pos;
+  uint32_t nbits, pad;
+  uint64_t bits;
+};
+void mb_place_pieces(uint64_t* out, const MbBitPiece* pieces_dev, uint32_t n);
+// out_bytes[dst_byte, + bytes) = text[src_pos, + bytes) for every item: the bytes of the stored meta-blocks
+struct MbRawCopy {
+  uint64_t dst_byte;
+  uint32_t src_pos, bytes;
+};
+void mb_raw_copies(uint8_t* out_bytes, const uint8_t* text, const MbRawCopy* items_dev, uint32_t n);
 
 // ---- quality >= 10 (metablock_hq.h; row b10).  Order of a call: census + distance parameters (results: hq_*), symbol
 // streams, FindBlocks iterations (jobs[].num_blocks), ClusterBlocks (the splits), context histograms, context-map

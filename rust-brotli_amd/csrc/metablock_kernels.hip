@@ -330,6 +330,66 @@ void mb_hq_cluster_histograms(const MbBuffers& B, const HqClusterJob* jobs_dev, 
   HIP_CHECK(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void k_copy_bits_batch(unsigned long long* __restrict__ out, const uint64_t* __restrict__ src_words,
+                                                          const MbBitCopy* __restrict__ items) {
+  const MbBitCopy it = items[blockIdx.y];
+  const uint64_t* src = src_words + it.src_word;
+  const uint64_t chunks = (it.nbits + 63) >> 6;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t v = src[c];
+    const uint64_t left = it.nbits - (c << 6);
+    if (left < 64) v &= (1ull << left) - 1ull;
+    if (v == 0) continue;
+    const uint64_t d = it.dst_bit + (c << 6);
+    const uint32_t dh = (uint32_t)(d & 63u);
+    atomicOr(out + (d >> 6), (unsigned long long)(v << dh));
+    if (dh != 0 && (v >> (64u - dh)) != 0) atomicOr(out + (d >> 6) + 1, (unsigned long long)(v >> (64u - dh)));
+  }
+}
+void mb_copy_bits_batch(uint64_t* out, const uint64_t* src_words, const MbBitCopy* items_dev, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_copy_bits_batch, dim3(8, n), dim3(256), 0, BR_STREAM, (unsigned long long*)out, src_words, items_dev);
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void k_place_pieces(unsigned long long* __restrict__ out, const MbBitPiece* __restrict__ pieces, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const MbBitPiece pc = pieces[i];
+  uint64_t v = pc.bits;
+  if (pc.nbits < 64) v &= (1ull << pc.nbits) - 1ull;
+  if (v == 0) return;
+  const uint32_t dh = (uint32_t)(pc.pos & 63u);
+  atomicOr(out + (pc.pos >> 6), (unsigned long long)(v << dh));
+  if (dh != 0 && (v >> (64u - dh)) != 0) atomicOr(out + (pc.pos >> 6) + 1, (unsigned long long)(v >> (64u - dh)));
+}
+void mb_place_pieces(uint64_t* out, const MbBitPiece* pieces_dev, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_place_pieces, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, (unsigned long long*)out, pieces_dev, n);
+  HIP_CHECK(hipGetLastError());
+}
+// (byte-aligned destinations: a stored meta-block starts behind a jump to the byte boundary; 16 bytes per thread where both sides
+// allow it, single bytes at the ragged ends)
+__global__ __launch_bounds__(256) void k_raw_copies(uint8_t* __restrict__ out, const uint8_t* __restrict__ text, const MbRawCopy* __restrict__ items) {
+  const MbRawCopy it = items[blockIdx.y];
+  uint8_t* dst = out + it.dst_byte;
+  const uint8_t* src = text + it.src_pos;
+  // head up to the first 16-byte boundary of the destination
+  uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+  if (head > it.bytes) head = it.bytes;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (uint32_t i = t; i < head; i += nt) dst[i] = src[i];
+  const uint32_t body = (it.bytes - head) / 16u;
+  typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+  typedef uint32_t u32x4_a __attribute__((ext_vector_type(4)));
+  for (uint32_t i = t; i < body; i += nt) *(u32x4_a*)(dst + head + 16u * i) = *(const u32x4_u*)(src + head + 16u * i);
+  for (uint32_t i = head + 16u * body + t; i < it.bytes; i += nt) dst[i] = src[i];
+}
+void mb_raw_copies(uint8_t* out_bytes, const uint8_t* text, const MbRawCopy* items_dev, uint32_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_raw_copies, dim3(64, n), dim3(256), 0, BR_STREAM, out_bytes, text, items_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
 void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t nbits) {
   const uint32_t words = (uint32_t)((nbits + 63) / 64);
   for_each(words, [=] __device__(uint32_t w) { mb_item_copy_bits_word(out, dst_bit, src, nbits, w); });

@@ -150,4 +150,17 @@ void mb_copy_bits(uint64_t* out, uint64_t dst_bit, const uint64_t* src, uint64_t
   for (uint64_t w = 0; w < words; ++w) mb_item_copy_bits_word(out, dst_bit, src, nbits, w);
 }
 
+void mb_copy_bits_batch(uint64_t* out, const uint64_t* src_words, const MbBitCopy* items, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) mb_copy_bits(out, items[i].dst_bit, src_words + items[i].src_word, items[i].nbits);
+}
+void mb_place_pieces(uint64_t* out, const MbBitPiece* pieces, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t w = pieces[i].bits;
+    mb_copy_bits(out, pieces[i].pos, &w, pieces[i].nbits);
+  }
+}
+void mb_raw_copies(uint8_t* out_bytes, const uint8_t* text, const MbRawCopy* items, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) memcpy(out_bytes + items[i].dst_byte, text + items[i].src_pos, items[i].bytes);
+}
+
 }  // namespace brotli_mi355x
