@@ -75,17 +75,48 @@ Pool::Pool() {
   std::lock_guard<std::mutex> lock(g_pools_mu);
   all_pools().push_back(this);
 }
+// What a host thread leaves behind when it ends.  A pool is thread-local, and its destructor runs while the thread is being torn
+// down -- next to the HIP runtime's own thread-local state (hipStreamPerThread), in no defined order: calling into the runtime from
+// there (hipFree, hipHostFree, hipEventDestroy) corrupted the heap now and then (64 Python threads of six calls each:
+// "malloc_consolidate(): unaligned fastbin chunk detected" at exit in two runs of three).  So a dying thread calls nothing: its idle
+// blocks go to this list, from where the next thread that needs one of that size adopts it, and TrimAllPools() hands the rest back
+// to the driver from a live thread.  (Never destroyed, like the list of pools: threads may outlive static destruction.)
+struct Orphans {
+  std::mutex mu;
+  std::multimap<size_t, void*> device_blocks, host_blocks;  // capacity -> block
+};
+Orphans& orphans() {
+  static Orphans* o = new Orphans;
+  return *o;
+}
 Pool::~Pool() {
   {
     std::lock_guard<std::mutex> lock(g_pools_mu);
     auto& v = all_pools();
     v.erase(std::remove(v.begin(), v.end(), this), v.end());
   }
-  for (auto& kv : free_blocks) (void)hipFree(kv.second);  // (errors at process exit are of no consequence)
+  Orphans& o = orphans();
+  std::lock_guard<std::mutex> lock(o.mu);
+  for (auto& kv : free_blocks) o.device_blocks.emplace(kv.first, kv.second);
+}
+static size_t TrimOrphans() {
+  std::vector<void*> drop;
+  size_t bytes = 0;
+  {
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lock(o.mu);
+    for (auto& kv : o.device_blocks) {
+      drop.push_back(kv.second);
+      bytes += kv.first;
+    }
+    o.device_blocks.clear();
+  }
+  for (void* d : drop) (void)hipFree(d);
+  return bytes;
 }
 size_t TrimAllPools() {
+  size_t bytes = TrimOrphans();
   std::lock_guard<std::mutex> lock(g_pools_mu);
-  size_t bytes = 0;
   for (Pool* q : all_pools()) bytes += q->Trim();
   return bytes;
 }
@@ -149,6 +180,19 @@ static void* AllocBlock(size_t bytes) {
       P.pooled_bytes -= it->first;
       P.pooled_seq.erase(p);
       P.free_blocks.erase(it);
+    }
+  }
+  if (!p) {
+    // a block that a finished thread left behind?
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lock(o.mu);
+    auto it = o.device_blocks.lower_bound(cap);
+    if (it != o.device_blocks.end() && it->first <= cap + cap / 4) {
+      p = it->second;
+      const size_t got = it->first;
+      o.device_blocks.erase(it);
+      std::lock_guard<std::mutex> mine(P.mu);
+      P.capacity[p] = got;
     }
   }
   if (!p) {
@@ -221,8 +265,10 @@ namespace {
 struct HostPool {
   std::multimap<size_t, void*> free_blocks;
   std::unordered_map<void*, size_t> capacity;
-  ~HostPool() {
-    for (auto& kv : free_blocks) (void)hipHostFree(kv.second);
+  ~HostPool() {  // (no call into the runtime from a thread that is being torn down: see Orphans)
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lock(o.mu);
+    for (auto& kv : free_blocks) o.host_blocks.emplace(kv.first, kv.second);
   }
 };
 HostPool& host_pool() {
@@ -240,6 +286,17 @@ void* dev_host_alloc(size_t bytes) {
     return p;
   }
   void* p = nullptr;
+  {
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lock(o.mu);
+    auto oit = o.host_blocks.lower_bound(cap);
+    if (oit != o.host_blocks.end() && oit->first <= cap + cap / 4) {
+      p = oit->second;
+      P.capacity[p] = oit->first;
+      o.host_blocks.erase(oit);
+      return p;
+    }
+  }
   HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
   P.capacity[p] = cap;
   return p;
@@ -279,9 +336,25 @@ struct Bounce {
   void init() {
     if (buf[0]) return;
     for (int i = 0; i < 2; ++i) {
-      HIP_CHECK(hipHostMalloc(&buf[i], kBounceBytes, hipHostMallocDefault));
+      {
+        // (the buffers of a thread that has ended are taken over: see Orphans)
+        Orphans& o = orphans();
+        std::lock_guard<std::mutex> lock(o.mu);
+        auto it = o.host_blocks.find(kBounceBytes);
+        if (it != o.host_blocks.end()) {
+          buf[i] = it->second;
+          o.host_blocks.erase(it);
+        }
+      }
+      if (!buf[i]) HIP_CHECK(hipHostMalloc(&buf[i], kBounceBytes, hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     }
+  }
+  ~Bounce() {
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lock(o.mu);
+    for (int i = 0; i < 2; ++i)
+      if (buf[i]) o.host_blocks.emplace(kBounceBytes, buf[i]);
   }
   void wait(int i) {
     if (!busy[i]) return;
@@ -382,10 +455,7 @@ void dev_sync() { wait_stream(); }
 
 namespace {
 struct Mark {
-  hipEvent_t ev = nullptr;
-  ~Mark() {
-    if (ev) (void)hipEventDestroy(ev);
-  }
+  hipEvent_t ev = nullptr;  // (left to the runtime when the thread ends: no call into it from a dying thread, see Orphans)
 };
 Mark& mark() {
   static thread_local Mark m;
