@@ -95,7 +95,6 @@ struct Lz77Buffers {
   uint32_t splice_lists = 1;              // list launches run the chains that restart from / stop at checkpoints (set per launch by the host)
   uint32_t* dict_items = nullptr;  // optional: the two static-dictionary hash items of every position (k_compute_keys)  [total_bytes + 64]
   uint32_t* changed_slot;  // slot of every changed position                [changed_cap]
-  uint32_t* changed_key_bits = nullptr;  // one bit per hash key: some stored flag of the key changed in the last lz77_diff_flags [2048 words]
   uint32_t* row_ctl;    // device-side control words of lz77_rows_update    [4]
   uint32_t* reset_counts;      // Lz77Params::reset_pos != 0: per key, stored positions in front of reset_vis  [65536]
   const uint32_t* count_base;  // optional, per key: positions stored in front of the text (a later piece of a stream)  [65536]

@@ -655,7 +655,6 @@ struct RowArgs {
   uint32_t conditional;
   const unsigned long long* pot;  // Lz77Buffers::pot / pot_state (null: no mask)
   const uint32_t* pot_state;
-  const uint32_t* key_bits;  // Lz77Buffers::changed_key_bits (null: every key may have changed)
 };
 // device-side control words of lz77_rows_update
 enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtlWrapKeyFlip = 3, kCtlWords = 4 };
@@ -1054,8 +1053,6 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.gprev = B.gprev;
   a.pot = B.pot;
   a.pot_state = B.pot_state;
-  static const bool no_key_filter = getenv("BROTLI_MI355X_NO_KEY_FILTER") != nullptr;  // (A/B aid)
-  a.key_bits = (validate && !no_key_filter) ? B.changed_key_bits : nullptr;
   return a;
 }
 
@@ -1198,12 +1195,7 @@ __global__ __launch_bounds__(256) void k_validate_listed_rows(RowArgs a, const u
   SlotsInMemory sl{a.by_key, a.fbits, a.stag, a.smask, a.gprev};
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
     const uint32_t i = pot_list[t];
-    const uint32_t key = a.sorted_keys[i];
-    // a row is a function of the slots of its own key: where no stored flag of the key changed since the rows were last brought
-    // up to date (lz77_diff_flags marks the keys), the row in memory stands.  On incompressible input a round changes the flags
-    // of a few thousand keys and this pass was 4.3 ms of every one of its 15 rounds at 1 GiB.
-    if (a.key_bits != nullptr && ((a.key_bits[key >> 5] >> (key & 31u)) & 1u) == 0) continue;
-    const uint32_t kf = a.key_first[key];
+    const uint32_t kf = a.key_first[a.sorted_keys[i]];
     if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true, a.reset_pos, a.reset_vis)) row_changed(a, a.by_key[i]);
   }
 }
@@ -1602,8 +1594,7 @@ void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int
 // flag arrays in one streaming pass is far cheaper than having every chain read the old flag of each position.)
 __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next, uint32_t n,
                                                      const uint16_t* __restrict__ keys, uint32_t* __restrict__ changed_keys,
-                                                     uint32_t* __restrict__ changed_count, uint32_t cap, uint32_t emit_positions,
-                                                     uint32_t* __restrict__ key_bits) {
+                                                     uint32_t* __restrict__ changed_count, uint32_t cap, uint32_t emit_positions) {
   const uint32_t words = (n + 15) / 16;  // both arrays are padded by 64 bytes
   const uint32_t lane = threadIdx.x & 63u;
   // (the loop bound is wave-uniform: all lanes of a wave take part in the scan below)
@@ -1624,15 +1615,6 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
     }
     const uint32_t mine = (uint32_t)(__popc(d[0]) + __popc(d[1]) + __popc(d[2]) + __popc(d[3]));
     if (__ballot(mine != 0) == 0) continue;
-    if (key_bits != nullptr && mine != 0) {
-      // (every change, also those beyond the capacity of the list)
-      for (uint32_t j = 0; j < 16; ++j)
-        if ((d[j >> 2] >> (8 * (j & 3))) & 1u) {
-          const uint32_t key = keys[wi * 16 + j];
-          // (a round of incompressible input flips hundreds of millions of flags over 2 048 words: look before the atomic)
-          if (((__builtin_nontemporal_load(&key_bits[key >> 5]) >> (key & 31u)) & 1u) == 0) atomicOr(&key_bits[key >> 5], 1u << (key & 31u));
-        }
-    }
     // one atomic per wave: exclusive scan of the per-lane counts, the last lane reserves the range
     uint32_t incl = mine;
     for (uint32_t off = 1; off < 64; off <<= 1) {
@@ -1785,9 +1767,8 @@ void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int ne
   uint32_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   // with candidate rows the list holds the changed POSITIONS (consumed on the device by lz77_rows_update)
-  if (B.changed_key_bits) HIP_CHECK(hipMemsetAsync(B.changed_key_bits, 0, 65536 / 8, BR_STREAM));
   hipLaunchKernelGGL(k_diff_flags, dim3(blocks), dim3(256), 0, BR_STREAM, B.flags[prev], B.flags[next], n, B.keys, B.changed_keys, B.changed_count,
-                     B.rows ? B.changed_cap : kChangedCap, B.rows ? 1u : 0u, B.changed_key_bits);
+                     B.rows ? B.changed_cap : kChangedCap, B.rows ? 1u : 0u);
   HIP_CHECK(hipGetLastError());
 }
 

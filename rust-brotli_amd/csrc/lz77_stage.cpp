@@ -51,7 +51,6 @@ void Lz77Stage::Release() {
     dev_free(B_.rows_changed_hi);
     dev_free(B_.changed_slot);
     dev_free(B_.row_ctl);
-    dev_free(B_.changed_key_bits);
     dev_free(B_.big_tile);
     dev_free(B_.run_end);
     dev_free(L_.num);
@@ -306,7 +305,6 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     B_.changed_keys = (uint32_t*)dev_alloc_uninit((size_t)B_.changed_cap * 4 + 64);
     B_.changed_slot = (uint32_t*)dev_alloc_uninit((size_t)B_.changed_cap * 4 + 64);
     B_.row_ctl = (uint32_t*)dev_alloc(64);
-    B_.changed_key_bits = (uint32_t*)dev_alloc(65536 / 8 + 64);
     B_.big_tile = (uint8_t*)dev_alloc(M / 1024 + 128);
     B_.smask = (unsigned long long*)dev_alloc_uninit((M / 64 + 2) * 8 + 64);
     B_.gprev = (uint32_t*)dev_alloc_uninit((M / 64 + 2) * 4 + 64);
