@@ -110,6 +110,12 @@ struct Lz77Buffers {
   uint32_t* pot_state = nullptr;      // [16], zero at the start of a call: [0] mask there, [1] listed slots, [2] list overflowed
   uint32_t* pot_list = nullptr;       // the slots with the bit, any order  [pot_list_cap]
   uint32_t pot_list_cap = 0;
+  // Where flags flipped in the last launch, coarsely: one bit per (hash key, 1 << cell_shift bytes of text), set by
+  // lz77_diff_flags* for every changed position; the last word is the "too many to tell" mark.  A candidate row holds
+  // stored positions of its key at most max_backward bytes back (1 << cell_shift >= that), so a listed slot whose two
+  // cells are clear kept its row (keys whose ring counter can wrap excepted: lz77_rows_update ignores the cells there).
+  uint32_t* flip_cells = nullptr;  // [65536 * cells_per_key / 32 + 2]
+  uint32_t cell_shift = 0, cells_per_key = 0;
   uint32_t changed_cap; // entries in changed_keys / changed_slot
   // rank-structure chains (qualities 6-9): log of every search (ChainTables::search_log, kSearchLogWords words per
   // position) and the list of searched positions whose candidate list changed in this round (lz77_recheck_searches)
@@ -183,6 +189,7 @@ struct BurstBuffers {
   uint8_t* cand_dirty = nullptr;   // [segments] marks of lz77_rows_update
   uint8_t* entry_dirty = nullptr;  // [segments] the state handed over by the predecessor differs from the entry last used
   uint8_t* touched = nullptr;      // [segments] parsed at least once since the host last cleared it
+  uint8_t* stale = nullptr;        // [segments] parsed by the last launch: flags[which ^ 1] lags behind flags[which] there and nowhere else
   SegEntry* new_entries = nullptr; // [segments] valid where entry_dirty
   uint32_t* list = nullptr;        // [segments] the next launch
   uint32_t* counters = nullptr;    // [0] length of list, [1] number of touched segments (lz77_gather_touched)
@@ -190,6 +197,12 @@ struct BurstBuffers {
 // after lz77_parse_list(list, sched): marks touched[], entry_dirty[] / new_entries[] (see above); the rows_changed_lo / _hi
 // marks of the segments the launch parsed are reset -- call it BEFORE the lz77_rows_update that follows the launch
 void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U);
+// Between the launches of a burst the two flag arrays differ only inside the segments the last launch parsed (U.stale, set by
+// lz77_chain_check): instead of copying all flags before a launch and comparing all of them after it --
+// lz77_flags_catch_up: flags[dst] := flags[src] inside the stale segments, marks cleared (before the launch that writes flags[dst]);
+// lz77_diff_flags_touched: lz77_diff_flags restricted to the stale segments (after lz77_chain_check)
+void lz77_flags_catch_up(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int src, int dst);
+void lz77_diff_flags_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int prev, int next);
 // rows_changed_lo / _hi of every segment := none (after a launch that parsed all of them)
 void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B);
 // the checkpoints of the listed segments are dropped (their parse now stands for another distance cache at the entry than
@@ -247,9 +260,10 @@ void lz77_key_counts(const Lz77Params& P, const Lz77Buffers& B, int which, uint3
 // accumulated device time (HIP events) of the parse kernel launches since the last call
 // work[3] (optional): what those launches did -- positions walked, searches, commands written (all chains, re-parses included)
 void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments, uint64_t* work = nullptr);
-// the same for all input blocks and all 13 sampling phases at once: out[(b * 13 + r) * 256 + v] (see the kernel)
-void lz77_block_sample_histograms(const uint8_t* text, const uint32_t* block_start_dev, const uint32_t* block_end_dev, uint32_t num_blocks,
-                                  uint32_t* out_dev);
+// every-13th-byte histograms of `count` spans {start, bytes} of the text at once (should_compress of all literal-only meta-blocks
+// of a resolver pass): out[r * 256 + v].  ranges and out are HOST arrays; runs beside whatever the calling thread's stream holds
+// and returns when the histograms are there.
+void lz77_sample_histograms(const uint8_t* text_dev, const uint32_t* ranges, uint32_t count, uint32_t* out);
 // every-13th-byte literal histogram for should_compress (encode.rs:1325-1354)
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev);
 // gathers the per-segment command slabs into one array: out[offsets[k] + i] = slab_k[i]

@@ -479,6 +479,11 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     uint64_t L64 = 0;
     for (const MetaBlockPlan& mp : plans) L64 += mp.n_literals;
     const uint32_t L = (uint32_t)L64;
+    // every meta-block stored uncompressed (incompressible input): nothing of the per-symbol machinery below is needed -- no
+    // literal map of a gigabyte of literals, no scans, no symbol bits -- only the layout and the copies of the bytes
+    bool all_raw = n_mb != 0;
+    for (const MetaBlockPlan& mp : plans) all_raw = all_raw && mp.uncompressed;
+    const size_t Ka = all_raw ? 0 : K, La = all_raw ? 0 : L;
 
     DevMem mm;
     MbBuffers B{};
@@ -497,15 +502,15 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     B.header_stride = hq ? kHqHeaderWords : kHeaderWords;
     B.descs = mm.alloc<MbDesc>(n_mb);
     B.results = mm.alloc<MbResult>(n_mb);
-    B.cmd_lit_start = mm.alloc<uint32_t>((size_t)K + 1);
-    B.cmd_pos = mm.alloc<uint32_t>((size_t)K + 1);
-    B.cmd_dist_index = mm.alloc<uint32_t>((size_t)K + 1);
-    B.lit_pos = mm.alloc<uint32_t>((size_t)L + 1);
-    B.lit_cmd = mm.alloc<uint32_t>((size_t)L + 1);
-    B.lit_nbits = mm.alloc<uint32_t>((size_t)L + 1);
-    B.cmd_nbits = mm.alloc<uint32_t>((size_t)K + 1);
-    B.cmd_own_bits = mm.alloc<uint32_t>((size_t)K + 1);
-    void* scan_scratch = mm.alloc<uint8_t>(mb_scan_scratch_bytes(std::max<size_t>(K, L) + 2));
+    B.cmd_lit_start = mm.alloc<uint32_t>(Ka + 1);
+    B.cmd_pos = mm.alloc<uint32_t>(Ka + 1);
+    B.cmd_dist_index = mm.alloc<uint32_t>(Ka + 1);
+    B.lit_pos = mm.alloc<uint32_t>(La + 1);
+    B.lit_cmd = mm.alloc<uint32_t>(La + 1);
+    B.lit_nbits = mm.alloc<uint32_t>(La + 1);
+    B.cmd_nbits = mm.alloc<uint32_t>(Ka + 1);
+    B.cmd_own_bits = mm.alloc<uint32_t>(Ka + 1);
+    void* scan_scratch = mm.alloc<uint8_t>(mb_scan_scratch_bytes(std::max<size_t>(Ka, La) + 2));
 
     std::vector<MbDesc> descs(n_mb);
     for (uint32_t m = 0; m < n_mb; ++m) {
@@ -536,7 +541,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       if (d.simple != kMbGreedy) d.context_mode = 0;
     }
     // prev bytes (encode.rs:2526-2534): bytes preceding the meta-block in the stream, 0 at the very start
-    {
+    if (!all_raw) {
       std::vector<uint32_t> where((size_t)n_mb * 2, 0xffffffffu);
       for (uint32_t m = 0; m < n_mb; ++m) {
         const uint32_t s = descs[m].start;
@@ -562,6 +567,9 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
         lit_base += descs[m].n_lits;
       }
     }
+    std::vector<MbResult> results(n_mb);
+    std::vector<uint32_t> body_off(n_mb + 1);
+    if (!all_raw) {
     dev_h2d(B.descs, descs.data(), n_mb * sizeof(MbDesc));
     uint32_t* boundary_words = mm.alloc<uint32_t>(n_mb + 1);
     mb_command_scans(B, scan_scratch);
@@ -577,7 +585,6 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
       }
       B.n_dists = di[n_mb];
     }
-    std::vector<MbResult> results(n_mb);
     if (hq) {
       // ---- BrotliBuildMetaBlock (metablock.rs:133-307) on the device, metablock_hq.h
       for (uint32_t m = 0; m < n_mb; ++m) {
@@ -878,7 +885,6 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     mb_write_headers(B);
     stats.ms_phase[5] += clk.lap(prof, "mb5");
     mb_symbol_bits(B, scan_scratch);
-    std::vector<uint32_t> body_off(n_mb + 1);
     mb_gather_at_metablock_starts(B, B.cmd_nbits, boundary_words);
     dev_d2h_async(results.data(), B.results, n_mb * sizeof(MbResult));
     dev_d2h_async(body_off.data(), boundary_words, (n_mb + 1) * 4);
@@ -890,6 +896,7 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
                 results[m].num_types[0], results[m].num_blocks[1], results[m].num_types[1], results[m].num_blocks[2], results[m].num_types[2],
                 results[m].header_bits);
     stats.ms_phase[6] += clk.lap(prof, "mb6");
+    }  // !all_raw
 
     // ---- layout of the stream (WriteMetaBlockInternal, encode.rs:1941-2167)
     std::vector<uint64_t> mb_out_bit(n_mb + 1, 0);
@@ -936,8 +943,10 @@ void EncodeStream(const EncodeRequest& req, std::vector<uint8_t>* out, EncodeSta
     const size_t total_bytes = tail_nbits ? all_bytes - 1 : all_bytes;
     const size_t out_words = all_bytes / 8 + 4;
     B.out_words = mm.alloc<uint64_t>(out_words);
-    dev_h2d(B.mb_out_bit, mb_out_bit.data(), (n_mb + 1) * 8);
-    mb_emit(B);
+    if (!all_raw) {
+      dev_h2d(B.mb_out_bit, mb_out_bit.data(), (n_mb + 1) * 8);
+      mb_emit(B);
+    }
     {
       // the headers of the compressed meta-blocks, the bytes of the stored ones and what the host composed (stream header, the
       // headers of stored meta-blocks, tail blocks): one upload and three launches, however many meta-blocks there are -- an

@@ -2430,9 +2430,10 @@ BR_DEV bool br_verify_search(const Lz77Params& P, const ChainTables& t, const Li
 // counters and the books stay what k + 1's entry holds (the host judges those).
 BR_DEV void br_chain_check(const Segment* segments, const SegEntry* entries, const SegExit* exits, uint32_t num_segments, uint32_t k,
                            const uint8_t* sched, uint8_t* touched, uint8_t* entry_dirty, SegEntry* new_entries, uint32_t* rows_changed_lo,
-                           uint32_t* rows_changed_hi) {
+                           uint32_t* rows_changed_hi, uint8_t* stale = nullptr) {
   if (sched[k] != kSchedOwn && sched[k] != kSchedOwnRows && sched[k] != kSchedWalked) return;
   touched[k] = 1;
+  if (stale != nullptr) stale[k] = 1;
   if (rows_changed_lo != nullptr) {  // parsed: what is marked from now on happened after this parse
     rows_changed_lo[k] = 0xffffffffu;
     rows_changed_hi[k] = 0;

@@ -12,6 +12,8 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <string.h>
+#include <mutex>
 #include <vector>
 
 #include "device_api.h"
@@ -655,6 +657,8 @@ struct RowArgs {
   uint32_t conditional;
   const unsigned long long* pot;  // Lz77Buffers::pot / pot_state (null: no mask)
   const uint32_t* pot_state;
+  const uint32_t* flip_cells;     // Lz77Buffers::flip_cells (null: not used in this update)
+  uint32_t cell_shift, cells_per_key, cell_words;
 };
 // device-side control words of lz77_rows_update
 enum RowCtl : uint32_t { kCtlNeedFull = 0, kCtlVirtual = 1, kCtlWalked = 2, kCtlWrapKeyFlip = 3, kCtlWords = 4 };
@@ -1053,6 +1057,11 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.gprev = B.gprev;
   a.pot = B.pot;
   a.pot_state = B.pot_state;
+  // (wrap marks move with the count of ALL stored slots in front of a slot: no cell filter where ring counters can wrap)
+  a.flip_cells = (validate && B.count_base == nullptr && P.reset_pos == 0) ? B.flip_cells : nullptr;
+  a.cell_shift = B.cell_shift;
+  a.cells_per_key = B.cells_per_key;
+  a.cell_words = (uint32_t)(((size_t)65536 * B.cells_per_key) / 32);
   return a;
 }
 
@@ -1195,6 +1204,15 @@ __global__ __launch_bounds__(256) void k_validate_listed_rows(RowArgs a, const u
   SlotsInMemory sl{a.by_key, a.fbits, a.stag, a.smask, a.gprev};
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < count; t += gridDim.x * blockDim.x) {
     const uint32_t i = pot_list[t];
+    if (a.flip_cells != nullptr && a.flip_cells[a.cell_words] == 0) {
+      // no flag of this key flipped within reach of the position: its row is what it was
+      const uint32_t p = a.by_key[i];
+      const uint32_t first = (p > a.max_backward_limit ? p - a.max_backward_limit : 0u) >> a.cell_shift, last = p >> a.cell_shift;
+      const uint32_t cell0 = (uint32_t)a.sorted_keys[i] * a.cells_per_key;
+      bool any = false;
+      for (uint32_t c = cell0 + first; c <= cell0 + last; ++c) any = any || ((a.flip_cells[c >> 5] >> (c & 31u)) & 1u) != 0;
+      if (!any) continue;
+    }
     const uint32_t kf = a.key_first[a.sorted_keys[i]];
     if (br_build_row(sl, a.rows, a.max_backward_limit, i, kf, a.depth, true, a.reset_pos, a.reset_vis)) row_changed(a, a.by_key[i]);
   }
@@ -1351,6 +1369,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   if (has_big_keys) launch_wrap_marks(P, B, true);
   launch_slot_masks(P, B);
   RowArgs a = row_args(P, B, next, true, &geo, dirty_dev);
+  if (has_big_keys) a.flip_cells = nullptr;
   hipLaunchKernelGGL(k_update_rows, dim3(cap < 65536u ? cap : 65536u), dim3(64), 0, BR_STREAM, a, B.changed_slot, B.changed_count, B.keys);
   a.conditional = 1;
   if (B.pot) {
@@ -1592,9 +1611,31 @@ void lz77_parse_custom(const Lz77Params& P, const Lz77Buffers& B, int which, int
 // ------------------------------------------------------------------------------------------ flag diff
 // After a parse launch: which keys had a stored flag change?  (The chains only write flags; comparing the two
 // flag arrays in one streaming pass is far cheaper than having every chain read the old flag of each position.)
+// the flip cells (Lz77Buffers::flip_cells): where, coarsely, the changed positions of a launch lie
+struct FlipCells {
+  uint32_t* bits;  // null: not kept
+  uint32_t shift, per_key, words;  // words: index of the "too many to tell" mark
+};
+__device__ __forceinline__ void mark_flip_cell(const FlipCells& c, uint32_t key, uint32_t pos) {
+  const uint32_t cell = key * c.per_key + (pos >> c.shift);
+  const uint32_t bit = 1u << (cell & 31u);
+  if (!(c.bits[cell >> 5] & bit)) atomicOr(&c.bits[cell >> 5], bit);  // (look first: most changes fall into cells that are set already)
+}
+static FlipCells flip_cells_of(const Lz77Buffers& B) {
+  FlipCells c;
+  c.bits = B.rows ? B.flip_cells : nullptr;
+  c.shift = B.cell_shift;
+  c.per_key = B.cells_per_key;
+  c.words = (uint32_t)(((size_t)65536 * B.cells_per_key) / 32);
+  return c;
+}
+static void clear_flip_cells(const Lz77Buffers& B) {
+  if (B.rows && B.flip_cells) HIP_CHECK(hipMemsetAsync(B.flip_cells, 0, ((size_t)65536 * B.cells_per_key) / 8 + 8, BR_STREAM));
+}
+
 __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next, uint32_t n,
                                                      const uint16_t* __restrict__ keys, uint32_t* __restrict__ changed_keys,
-                                                     uint32_t* __restrict__ changed_count, uint32_t cap, uint32_t emit_positions) {
+                                                     uint32_t* __restrict__ changed_count, uint32_t cap, uint32_t emit_positions, FlipCells cells) {
   const uint32_t words = (n + 15) / 16;  // both arrays are padded by 64 bytes
   const uint32_t lane = threadIdx.x & 63u;
   // (the loop bound is wave-uniform: all lanes of a wave take part in the scan below)
@@ -1622,13 +1663,27 @@ __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ 
       if (lane >= off) incl += up;
     }
     uint32_t base = 0;
-    if (lane == 63) base = atomicAdd(changed_count, incl);
+    // (once the list has overflowed only "more than cap" matters: incompressible input flips most of its flags in round 0, and a
+    // million reservations on one word were 10 of the 12 ms this pass took at 1 GiB)
+    uint32_t sat = 0;
+    if (lane == 63) {
+      if (*(volatile const uint32_t*)changed_count > cap) {
+        base = cap;
+        sat = 1;
+        if (cells.bits) cells.bits[cells.words] = 1;  // (too many changes to tell where: every cell counts as set)
+      } else {
+        base = atomicAdd(changed_count, incl);
+      }
+    }
     base = (uint32_t)__shfl((int)base, 63, 64);
+    sat = (uint32_t)__shfl((int)sat, 63, 64);
     uint32_t idx = base + incl - mine;
-    if (mine == 0 || idx >= cap) continue;
+    const bool mark = cells.bits != nullptr && sat == 0;
+    if (mine == 0 || (idx >= cap && !mark)) continue;
     for (uint32_t j = 0; j < 16; ++j) {
       if ((d[j >> 2] >> (8 * (j & 3))) & 1u) {
         if (idx < cap) changed_keys[idx] = emit_positions ? wi * 16 + j : (uint32_t)keys[wi * 16 + j];
+        if (mark) mark_flip_cell(cells, keys[wi * 16 + j], wi * 16 + j);
         ++idx;
       }
     }
@@ -1678,13 +1733,100 @@ void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_
 __global__ __launch_bounds__(256) void k_chain_check(const Segment* __restrict__ segments, const SegEntry* __restrict__ entries,
                                                       const SegExit* __restrict__ exits, uint32_t num_segments, const uint8_t* __restrict__ sched,
                                                       uint8_t* __restrict__ touched, uint8_t* __restrict__ entry_dirty, SegEntry* __restrict__ new_entries,
-                                                      uint32_t* __restrict__ rows_lo, uint32_t* __restrict__ rows_hi) {
+                                                      uint32_t* __restrict__ rows_lo, uint32_t* __restrict__ rows_hi, uint8_t* __restrict__ stale) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < num_segments) br_chain_check(segments, entries, exits, num_segments, k, sched, touched, entry_dirty, new_entries, rows_lo, rows_hi);
+  if (k < num_segments) br_chain_check(segments, entries, exits, num_segments, k, sched, touched, entry_dirty, new_entries, rows_lo, rows_hi, stale);
 }
 void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
   hipLaunchKernelGGL(k_chain_check, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.segments, B.entries, B.exits, P.num_segments,
-                     U.sched, U.touched, U.entry_dirty, U.new_entries, B.rows_changed_lo, B.rows_changed_hi);
+                     U.sched, U.touched, U.entry_dirty, U.new_entries, B.rows_changed_lo, B.rows_changed_hi, U.stale);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- flag arrays between the launches of a burst (device_api.h): one wavefront per stale segment
+__global__ __launch_bounds__(64) void k_flags_catch_up(const Segment* __restrict__ segments, uint32_t num_segments, uint8_t* __restrict__ stale,
+                                                        const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
+  const uint32_t k = blockIdx.x;
+  if (k >= num_segments || !stale[k]) return;
+  const uint32_t a = segments[k].start, b = segments[k].end;
+  // whole 16-byte words inside [a, b) as words, the ragged ends byte by byte (a word on the boundary belongs to two segments)
+  const uint32_t wa = (a + 15u) / 16u, wb = b / 16u;
+  if (wa < wb) {
+    for (uint32_t w = wa + threadIdx.x; w < wb; w += 64) ((uint4*)dst)[w] = ((const uint4*)src)[w];
+    for (uint32_t q = a + threadIdx.x; q < wa * 16u; q += 64) dst[q] = src[q];
+    for (uint32_t q = wb * 16u + threadIdx.x; q < b; q += 64) dst[q] = src[q];
+  } else {
+    for (uint32_t q = a + threadIdx.x; q < b; q += 64) dst[q] = src[q];
+  }
+  if (threadIdx.x == 0) stale[k] = 0;
+}
+void lz77_flags_catch_up(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int src, int dst) {
+  if (P.num_segments == 0) return;
+  hipLaunchKernelGGL(k_flags_catch_up, dim3(P.num_segments), dim3(64), 0, BR_STREAM, B.segments, P.num_segments, U.stale, B.flags[src], B.flags[dst]);
+  HIP_CHECK(hipGetLastError());
+}
+
+// k_diff_flags over the positions of the stale segments only (same list, same saturating count)
+__global__ __launch_bounds__(64) void k_diff_flags_touched(const Segment* __restrict__ segments, uint32_t num_segments, const uint8_t* __restrict__ stale,
+                                                            const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next,
+                                                            uint32_t* __restrict__ changed_pos, uint32_t* __restrict__ changed_count, uint32_t cap,
+                                                            const uint16_t* __restrict__ keys, FlipCells cells) {
+  const uint32_t k = blockIdx.x;
+  if (k >= num_segments || !stale[k]) return;
+  const uint32_t a = segments[k].start, b = segments[k].end;
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t w0 = a / 16u; w0 * 16u < b; w0 += 64) {
+    const uint32_t wi = w0 + lane;
+    uint32_t d[4] = {0, 0, 0, 0};
+    if (wi * 16u < b) {
+      const uint4 x = ((const uint4*)prev)[wi], y = ((const uint4*)next)[wi];  // (both arrays are padded by 64 bytes)
+      d[0] = (x.x ^ y.x) & 0x05050505u;
+      d[1] = (x.y ^ y.y) & 0x05050505u;
+      d[2] = (x.z ^ y.z) & 0x05050505u;
+      d[3] = (x.w ^ y.w) & 0x05050505u;
+      for (uint32_t j = 0; j < 4; ++j) d[j] = (d[j] | (d[j] >> 2)) & 0x01010101u;
+      if (wi * 16u < a || wi * 16u + 16u > b)
+        for (uint32_t j = 0; j < 16; ++j)
+          if (wi * 16u + j < a || wi * 16u + j >= b) d[j >> 2] &= ~(1u << (8 * (j & 3)));
+    }
+    const uint32_t mine = (uint32_t)(__popc(d[0]) + __popc(d[1]) + __popc(d[2]) + __popc(d[3]));
+    if (__ballot(mine != 0) == 0) continue;
+    uint32_t incl = mine;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    uint32_t base = 0;
+    uint32_t sat = 0;
+    if (lane == 63) {
+      if (*(volatile const uint32_t*)changed_count > cap) {
+        base = cap;
+        sat = 1;
+        if (cells.bits) cells.bits[cells.words] = 1;
+      } else {
+        base = atomicAdd(changed_count, incl);
+      }
+    }
+    base = (uint32_t)__shfl((int)base, 63, 64);
+    sat = (uint32_t)__shfl((int)sat, 63, 64);
+    uint32_t idx = base + incl - mine;
+    const bool mark = cells.bits != nullptr && sat == 0;
+    if (mine == 0 || (idx >= cap && !mark)) continue;
+    for (uint32_t j = 0; j < 16; ++j) {
+      if ((d[j >> 2] >> (8 * (j & 3))) & 1u) {
+        if (idx < cap) changed_pos[idx] = wi * 16u + j;
+        if (mark) mark_flip_cell(cells, keys[wi * 16u + j], wi * 16u + j);
+        ++idx;
+      }
+    }
+  }
+}
+void lz77_diff_flags_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int prev, int next) {
+  HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, BR_STREAM));
+  clear_flip_cells(B);
+  if (P.num_segments == 0) return;
+  hipLaunchKernelGGL(k_diff_flags_touched, dim3(P.num_segments), dim3(64), 0, BR_STREAM, B.segments, P.num_segments, U.stale, B.flags[prev], B.flags[next],
+                     B.changed_keys, B.changed_count, B.changed_cap, B.keys, flip_cells_of(B));
   HIP_CHECK(hipGetLastError());
 }
 void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B) {
@@ -1763,12 +1905,13 @@ void lz77_gather_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstB
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
   const uint32_t n = P.total_bytes;
   HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, BR_STREAM));
+  clear_flip_cells(B);
   if (n == 0) return;
   uint32_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   // with candidate rows the list holds the changed POSITIONS (consumed on the device by lz77_rows_update)
   hipLaunchKernelGGL(k_diff_flags, dim3(blocks), dim3(256), 0, BR_STREAM, B.flags[prev], B.flags[next], n, B.keys, B.changed_keys, B.changed_count,
-                     B.rows ? B.changed_cap : kChangedCap, B.rows ? 1u : 0u);
+                     B.rows ? B.changed_cap : kChangedCap, B.rows ? 1u : 0u, flip_cells_of(B));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1973,26 +2116,94 @@ __global__ __launch_bounds__(256) void k_sample_histogram(const uint8_t* __restr
   if (h[threadIdx.x]) atomicAdd(&histo[threadIdx.x], h[threadIdx.x]);
 }
 
-// Every-13th-byte histograms of all input blocks at once, for each of the 13 possible sampling phases: out[(b * 13 + r) *
-// 256 + v] = number of offsets o in block b with o % 13 == r and byte v.  should_compress (encode.rs:1325-1354) samples a
-// meta-block from its own start, so the phase of a block depends on which meta-block it ends up in; with all phases at
-// hand the host composes the histogram of any meta-block without another trip to the device.
-__global__ __launch_bounds__(256) void k_block_sample_histograms(const uint8_t* __restrict__ text, const uint32_t* __restrict__ block_start,
-                                                                  const uint32_t* __restrict__ block_end, uint32_t* __restrict__ out) {
-  __shared__ uint32_t h[13 * 256];
-  for (uint32_t i = threadIdx.x; i < 13 * 256; i += 256) h[i] = 0;
+// Every-13th-byte histograms (should_compress, encode.rs:1325-1354) of several spans of the text at once: span r =
+// {start, bytes} samples start, start + 13, ...; out[r * 256 + v] = number of samples with byte v.  One workgroup per
+// kSampleChunk samples of a span (blockIdx.y = span); out is zeroed by the caller.
+static constexpr uint32_t kSampleChunk = 8192;
+__global__ __launch_bounds__(256) void k_sample_histograms(const uint8_t* __restrict__ text, const uint32_t* __restrict__ ranges,
+                                                            uint32_t* __restrict__ out) {
+  const uint32_t start = ranges[2 * blockIdx.y], bytes = ranges[2 * blockIdx.y + 1];
+  const uint32_t samples = (bytes + 12) / 13;
+  const uint32_t first = blockIdx.x * kSampleChunk;
+  if (first >= samples) return;
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t bs = block_start[blockIdx.x], be = block_end[blockIdx.x];
-  for (uint32_t o = threadIdx.x; bs + o < be; o += 256) atomicAdd(&h[(o % 13u) * 256u + text[bs + o]], 1u);
+  const uint32_t last = min(first + kSampleChunk, samples);
+  for (uint32_t i = first + threadIdx.x; i < last; i += 256) atomicAdd(&h[text[start + i * 13u]], 1u);
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < 13 * 256; i += 256) out[(size_t)blockIdx.x * 13 * 256 + i] = h[i];
+  if (h[threadIdx.x]) atomicAdd(&out[(size_t)blockIdx.y * 256 + threadIdx.x], h[threadIdx.x]);
 }
 
-void lz77_block_sample_histograms(const uint8_t* text, const uint32_t* block_start_dev, const uint32_t* block_end_dev, uint32_t num_blocks,
-                                  uint32_t* out_dev) {
-  if (num_blocks == 0) return;
-  hipLaunchKernelGGL(k_block_sample_histograms, dim3(num_blocks), dim3(256), 0, BR_STREAM, text, block_start_dev, block_end_dev, out_dev);
+// Runs on a stream of its own and waits for it: the caller is the host resolver in the middle of a pass, while the calling
+// thread's stream is busy for milliseconds with the row update queued behind the parse (the text itself is long in place).
+// Streams and their buffers are kept in a process-wide list (never destroyed: no HIP call from a thread's exit path).
+namespace {
+struct SideLane {
+  hipStream_t stream = nullptr;
+  uint32_t* dev = nullptr;
+  uint32_t* host = nullptr;  // page-locked
+  size_t words = 0;
+  int device = -1;
+};
+std::mutex g_side_mu;
+std::vector<SideLane*> g_side_free;
+SideLane* side_acquire(size_t words) {
+  int device = 0;
+  HIP_CHECK(hipGetDevice(&device));
+  SideLane* lane = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_free.size(); ++i)
+      if (g_side_free[i]->device == device) {
+        lane = g_side_free[i];
+        g_side_free.erase(g_side_free.begin() + i);
+        break;
+      }
+  }
+  if (!lane) {
+    lane = new SideLane;
+    lane->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
+  }
+  if (lane->words < words) {
+    if (lane->dev) HIP_CHECK(hipFree(lane->dev));
+    if (lane->host) HIP_CHECK(hipHostFree(lane->host));
+    lane->words = words + words / 2 + 1024;
+    HIP_CHECK(hipMalloc((void**)&lane->dev, lane->words * 4));
+    HIP_CHECK(hipHostMalloc((void**)&lane->host, lane->words * 4, hipHostMallocDefault));
+  }
+  return lane;
+}
+void side_release(SideLane* lane) {
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  g_side_free.push_back(lane);
+}
+}  // namespace
+
+void lz77_sample_histograms(const uint8_t* text, const uint32_t* ranges, uint32_t count, uint32_t* out) {
+  if (count == 0) return;
+  uint32_t most = 0;
+  for (uint32_t r = 0; r < count; ++r) most = std::max(most, (ranges[2 * r + 1] + 12) / 13);
+  const size_t range_words = (size_t)count * 2, out_words = (size_t)count * 256;
+  SideLane* lane = side_acquire(range_words + out_words);
+  uint32_t* ranges_dev = lane->dev;
+  uint32_t* out_dev = lane->dev + range_words;
+  memcpy(lane->host, ranges, range_words * 4);
+  HIP_CHECK(hipMemcpyAsync(ranges_dev, lane->host, range_words * 4, hipMemcpyHostToDevice, lane->stream));
+  HIP_CHECK(hipMemsetAsync(out_dev, 0, out_words * 4, lane->stream));
+  if (most != 0) {
+    for (uint32_t r0 = 0; r0 < count; r0 += 32768) {  // (grid.y is limited to 65 535)
+      const uint32_t nr = std::min(count - r0, 32768u);
+      hipLaunchKernelGGL(k_sample_histograms, dim3((most + kSampleChunk - 1) / kSampleChunk, nr), dim3(256), 0, lane->stream, text, ranges_dev + 2 * (size_t)r0,
+                         out_dev + (size_t)r0 * 256);
+    }
+  }
   HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(lane->host + range_words, out_dev, out_words * 4, hipMemcpyDeviceToHost, lane->stream));
+  HIP_CHECK(hipStreamSynchronize(lane->stream));
+  memcpy(out, lane->host + range_words, out_words * 4);
+  side_release(lane);
 }
 
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev) {

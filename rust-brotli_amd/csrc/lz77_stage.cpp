@@ -71,6 +71,7 @@ void Lz77Stage::Release() {
     dev_free(B_.pot);
     dev_free(B_.pot_state);
     dev_free(B_.pot_list);
+    dev_free(B_.flip_cells);
     dev_free(Z_.buckets);
     dev_free(Z_.forest);
     dev_free(Z_.nodes);
@@ -313,6 +314,14 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
       B_.pot_state = (uint32_t*)dev_alloc(64);
       B_.pot_list_cap = (uint32_t)(M / 16 + 1024);  // (denser than that: the pass over all rows is the cheaper one)
       B_.pot_list = (uint32_t*)dev_alloc_uninit((size_t)B_.pot_list_cap * 4 + 64);
+      if (getenv("BROTLI_MI355X_NO_FLIP_CELLS") == nullptr) {
+        uint32_t shift = 8;
+        while (shift < 31 && (1u << shift) < P_.max_backward_limit + 1u) ++shift;
+        while (shift < 31 && (M >> shift) + 2 > 1024) ++shift;
+        B_.cell_shift = shift;
+        B_.cells_per_key = (uint32_t)(M >> shift) + 2;
+        B_.flip_cells = (uint32_t*)dev_alloc((size_t)65536 * B_.cells_per_key / 8 + 64);
+      }
     }
     B_.stag = (uint16_t*)dev_alloc_uninit(M * 2 + 64);
     B_.rows = (uint32_t*)dev_alloc_uninit(M * kRowEntries * 4 + 64);
@@ -544,7 +553,9 @@ struct DictTracker {
 // parse loop (br_parse_segment) through a literal spree -- every position, then every 9th, then every 17th
 // (mod.rs:2529-2546) -- is plain arithmetic on (position, apply).  Used by the resolver to carry a corrected phase
 // through a whole stretch of incompressible data in one pass; like every entry guess it is verified by the re-parse.
-static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const SegEntry& e, SegExit* x) {
+// (the loop of br_parse_segment, step by step: the definition.  PredictLiteralRun below takes the strides in closed form --
+// incompressible input asks for every segment, dozens of times -- and BROTLI_MI355X_SELFTEST compares the two.)
+static void PredictLiteralRunStepwise(const Lz77Params& P, const Segment& seg, const SegEntry& e, SegExit* x) {
   const uint32_t pos_end = seg.blk_end, htl = P.htl, window = P.spree_window;
   const uint32_t margin = htl - 1 > 4 ? htl - 1 : 4;
   uint32_t position = e.pos;
@@ -578,40 +589,102 @@ static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const Seg
   x->tail_p1 = position > seg.end ? tail_p1 : 0u;
 }
 
-// Every-13th-byte histogram of the meta-block [start, end) (should_compress, encode.rs:1325-1354), composed on the host
-// from per-block histograms for all 13 sampling phases, which the device computes once per Run() when the first
-// literal-only meta-block shows up (incompressible input has dozens of them, and every pass of the resolver asks).
-void Lz77Stage::SampledHistogram(uint32_t start, uint32_t end, uint32_t* histo) {
-  const uint32_t nblocks = (uint32_t)block_segment_bytes_.size();
-  if (block_histos_.empty()) {
-    std::vector<uint32_t> bs(nblocks), be(nblocks);
-    for (uint32_t b = 0; b < nblocks; ++b) {
-      const Segment& g = segments_[block_first_segment_[b]];
-      bs[b] = g.blk_start;
-      be[b] = g.blk_end;
-    }
-    uint32_t* bounds_dev = (uint32_t*)dev_alloc((size_t)nblocks * 8 + 64);
-    uint32_t* out_dev = (uint32_t*)dev_alloc_uninit((size_t)nblocks * 13 * 256 * 4 + 64);
-    dev_h2d(bounds_dev, bs.data(), (size_t)nblocks * 4);
-    dev_h2d(bounds_dev + nblocks, be.data(), (size_t)nblocks * 4);
-    lz77_block_sample_histograms(B_.text, bounds_dev, bounds_dev + nblocks, nblocks, out_dev);
-    block_histos_.resize((size_t)nblocks * 13 * 256);
-    dev_d2h(block_histos_.data(), out_dev, block_histos_.size() * 4);
-    dev_free(bounds_dev);
-    dev_free(out_dev);
-    block_starts_ = bs;
+static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const SegEntry& e, SegExit* x) {
+  const uint64_t pos_end = seg.blk_end, htl = P.htl, window = P.spree_window;
+  const uint64_t margin = htl - 1 > 4 ? htl - 1 : 4;
+  uint64_t position = e.pos;
+  const uint64_t apply = e.apply;
+  uint32_t tail_kind = e.head_kind;
+  uint64_t tail_base = e.head_base;
+  // the loop runs while position < stop
+  const uint64_t stop = std::min<uint64_t>(pos_end > htl ? pos_end - htl : 0, seg.end);
+  // one position at a time up to `apply`
+  if (position < stop && position < apply) position = std::min(stop, apply);
+  // strides: a step from p looks at p' = p + 1.  p' + 16 >= pos_end - margin ends the block; p' <= apply + 4 * window
+  // jumps 8 on (stride 9), anything later 16 (stride 17).
+  const uint64_t block_tail = pos_end > margin + 16 ? pos_end - margin - 16 : 0;  // p' >= block_tail: the end-of-block step
+  auto stride = [&](uint64_t step, uint64_t p_limit, uint32_t kind) {
+    // steps from positions p = position, position + step, ... while p < stop, p + 1 < block_tail and p + 1 <= p_limit
+    uint64_t bound = stop;                                         // p < bound
+    bound = std::min(bound, block_tail > 0 ? block_tail - 1 : 0);  // p + 1 < block_tail
+    bound = std::min(bound, p_limit);                              // p + 1 <= p_limit  <=>  p < p_limit
+    if (position >= bound) return;
+    const uint64_t n = (bound - position + step - 1) / step;
+    tail_kind = kind;
+    tail_base = position + (n - 1) * step + 1;
+    position += n * step;
+  };
+  if (position < stop) stride(9, apply + 4 * window, kHeadEven4);
+  if (position < stop && position + 1 > apply + 4 * window) stride(17, ~0ull >> 1, kHeadVec4);
+  if (position < stop && position + 1 >= block_tail && position + 1 > apply) {
+    tail_kind = kHeadUnstored;
+    tail_base = position + 1;
+    position = pos_end;
   }
-  memset(histo, 0, 256 * 4);
-  // blocks are contiguous: find the first one by its start
-  uint32_t b = (uint32_t)(std::lower_bound(block_starts_.begin(), block_starts_.end(), start) - block_starts_.begin());
-  for (; b < nblocks && block_starts_[b] < end; ++b) {
-    const uint32_t phase = (13u - (block_starts_[b] - start) % 13u) % 13u;  // offsets o in the block with (block start + o - start) % 13 == 0
-    const uint32_t* h = block_histos_.data() + ((size_t)b * 13 + phase) * 256;
-    for (uint32_t v = 0; v < 256; ++v) histo[v] += h[v];
+  if (seg.flags & kSegLastInBlock) position = pos_end;
+  x->pos = (uint32_t)position;
+  x->apply = (uint32_t)apply;
+  x->insert_len = (uint32_t)position - e.pos;
+  x->tail_kind = position > seg.end ? tail_kind : (uint32_t)kHeadNone;
+  x->tail_base = position > seg.end ? (uint32_t)tail_base : 0u;
+  x->tail_p1 = position > seg.end ? e.head_p1 : 0u;
+  static const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
+  if (selftest) {
+    SegExit y = *x;
+    PredictLiteralRunStepwise(P, seg, e, &y);
+    if (y.pos != x->pos || y.apply != x->apply || y.insert_len != x->insert_len || y.tail_kind != x->tail_kind || y.tail_base != x->tail_base ||
+        y.tail_p1 != x->tail_p1)
+      throw std::runtime_error("selftest: PredictLiteralRun differs from the stepwise loop (segment " + std::to_string(seg.start) + ", entry " +
+                               std::to_string(e.pos) + " / " + std::to_string(e.apply) + ")");
   }
 }
 
+// should_compress (encode.rs:1325-1354) samples every 13th byte of a literal-only meta-block.  Incompressible input has
+// hundreds of such meta-blocks and the resolver meets them in the middle of its pass: the pass notes the meta-blocks it
+// has no answer for yet (wanted_histograms_), goes on with a provisional answer, and Resolve() then asks the device for
+// all of them in one launch and one copy and runs the pass again -- where a meta-block starts and ends hangs on the
+// counts of commands and literals alone, not on the answers, so the second pass meets the same meta-blocks.
+// returns whether every provisional answer of the pass (wanted_guesses_) was the right one
+bool Lz77Stage::FetchShouldCompress() {
+  const uint32_t count = (uint32_t)wanted_histograms_.size();
+  if (count == 0) return true;
+  bool guessed_right = true;
+  std::vector<uint32_t> ranges((size_t)count * 2);
+  for (uint32_t i = 0; i < count; ++i) {
+    ranges[2 * i] = wanted_histograms_[i].first;
+    ranges[2 * i + 1] = wanted_histograms_[i].second;
+  }
+  std::vector<uint32_t> histos((size_t)count * 256);
+  lz77_sample_histograms(B_.text, ranges.data(), count, histos.data());
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t bytes = wanted_histograms_[i].second;
+    const float threshold = (float)bytes * 7.92f / 13.0f;
+    const bool c = !(HostBitsEntropy(histos.data() + (size_t)i * 256, 256) > threshold);
+    should_compress_cache_.emplace(wanted_histograms_[i], c);
+    guessed_right = guessed_right && i < wanted_guesses_.size() && (wanted_guesses_[i] != 0) == c;
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "  should_compress sampled [%u,+%u) -> %d\n", wanted_histograms_[i].first, bytes, (int)c);
+  }
+  wanted_histograms_.clear();
+  return guessed_right;
+}
+
 bool Lz77Stage::Resolve(bool final_pass) {
+  wanted_histograms_.clear();
+  wanted_guesses_.clear();
+  should_compress_guess_ = true;
+  bool consistent = ResolvePass(final_pass);
+  if (!wanted_histograms_.empty()) {
+    if (!FetchShouldCompress()) {  // (a guess was wrong)
+      wanted_guesses_.clear();
+      should_compress_guess_ = true;
+      consistent = ResolvePass(final_pass);
+      if (!wanted_histograms_.empty()) throw std::runtime_error("brotli_mi355x: the resolver asked for a meta-block twice");
+    }
+  }
+  return consistent;
+}
+
+bool Lz77Stage::ResolvePass(bool final_pass) {
   const uint32_t nseg = (uint32_t)segments_.size();
   next_entries_.resize(nseg);  // (every element is written below)
   dbg_mismatch_ = dbg_counts_;
@@ -861,14 +934,15 @@ bool Lz77Stage::Resolve(bool final_pass) {
       auto key = std::make_pair(mb.start, bytes);
       auto it = should_compress_cache.find(key);
       if (it == should_compress_cache.end()) {
-        uint32_t histo[256];
-        SampledHistogram(mb.start, mb.end, histo);
-        const float threshold = (float)bytes * 7.92f / 13.0f;
-        const bool c = !(HostBitsEntropy(histo, 256) > threshold);
-        it = should_compress_cache.emplace(key, c).first;
-        if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "  should_compress sampled [%u,+%u) -> %d\n", key.first, key.second, (int)c);
+        // answered by FetchShouldCompress() after the pass; until then: what the last literal-only meta-block was told (one
+        // incompressible meta-block is followed by another).  The pass is run again only if a guess turns out wrong.
+        wanted_histograms_.push_back(key);
+        compress = should_compress_guess_;
+        wanted_guesses_.push_back(compress ? 1 : 0);
+      } else {
+        compress = it->second;
       }
-      compress = it->second;
+      should_compress_guess_ = compress;
     }
     if (std::find(forced_uncompressed_.begin(), forced_uncompressed_.end(), (uint32_t)metablocks_.size()) !=
         forced_uncompressed_.end())
@@ -932,13 +1006,16 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
     e.dict_matches = dict_dead ? DictTracker::kDeadM : DictTracker::kAliveM;
     wentries[i] = e;
   }
+  timeline().stamp("wu-prepared");
   Segment* wsegs_dev = (Segment*)dev_alloc(count * sizeof(Segment));
   SegEntry* wentries_dev = (SegEntry*)dev_alloc(count * sizeof(SegEntry));
   SegExit* wexits_dev = (SegExit*)dev_alloc(count * sizeof(SegExit));
   dev_h2d(wsegs_dev, wsegs.data(), count * sizeof(Segment));
   dev_h2d(wentries_dev, wentries.data(), count * sizeof(SegEntry));
   lz77_parse_custom(P_, B_, which, rbuf, wsegs_dev, wentries_dev, wexits_dev, count);
+  timeline().stamp("wu-queued");
   dev_d2h(wexits.data(), wexits_dev, count * sizeof(SegExit));
+  timeline().stamp("wu-exits");
   dev_free(wsegs_dev);
   dev_free(wentries_dev);
   dev_free(wexits_dev);
@@ -1079,7 +1156,6 @@ void Lz77Stage::Run() {
   Timer total(true);
   Timer tm(prof);
   should_compress_cache_.clear();
-  block_histos_.clear();
   const uint32_t nseg = (uint32_t)segments_.size();
   if (nseg == 0) {
     metablocks_.clear();
@@ -1454,6 +1530,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   InitFlags();
   tm.stop(&stats_.ms_init);
   const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
+  // (the candidate rows against a rebuild from the flags after EVERY update, not only the first build: minutes per MiB)
+  const bool selftest_rows_every_update = getenv("BROTLI_MI355X_SELFTEST_ROWS") != nullptr;
   if (selftest) SelfTestSort();
   int which = 0, rbuf = 0;
   // (the index build is queued first: the device works on it while the host prepares the entries)
@@ -1554,11 +1632,13 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   // zeros 6 rounds / 736 ms with bursts, 4 rounds / 467 ms without)
   const uint32_t burst_max = (use_rows_ && B_.run_end == nullptr) ? burst_env : 0u;
   BurstBuffers U;
+  bool stale_marks_valid = false;  // U.stale says where the two flag arrays differ (from the first launch of the first burst on)
   if (burst_max != 0) {
     U.sched = (uint8_t*)dev_alloc(nseg + 64);
     U.cand_dirty = dirty_dev;
     U.entry_dirty = (uint8_t*)dev_alloc(nseg + 64);
     U.touched = (uint8_t*)dev_alloc(nseg + 64);
+    U.stale = (uint8_t*)dev_alloc(nseg + 64);
     U.new_entries = (SegEntry*)dev_alloc_uninit((size_t)nseg * sizeof(SegEntry) + 64);
     U.list = (uint32_t*)dev_alloc_uninit((size_t)nseg * 4 + 64);
     U.counters = (uint32_t*)dev_alloc(64);
@@ -1630,15 +1710,23 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         // worth it where most of a re-parse is saved -- launches of a few per cent of the segments, as on text -- and a loss
         // where a fifth of the input is parsed again every round by chains that never fall back into step (pieces of a mix).
         B_.splice_lists = (uint64_t)launch_count * splice_max_share <= nseg ? 1u : 0u;
-        dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+        // flags[which ^ 1] := flags[which]: everything after a full round, afterwards only what the last launch parsed (U.stale)
+        if (stale_marks_valid) {
+          lz77_flags_catch_up(P_, B_, U, which, which ^ 1);
+        } else {
+          dev_d2d(B_.flags[which ^ 1], B_.flags[which], (size_t)P_.total_bytes + 64);
+          dev_memset(U.stale, 0, nseg);
+          stale_marks_valid = true;
+        }
         lz77_parse_list(P_, B_, which, rbuf, launch_list, U.sched, launch_count);
         stats_.segments_parsed += launch_count;
         lz77_chain_check(P_, B_, U);  // (also resets the rows-changed marks of what was parsed: before the marks of this launch's flips)
-        lz77_diff_flags(P_, B_, which, which ^ 1);
+        lz77_diff_flags_touched(P_, B_, U, which, which ^ 1);
         dev_memset(dirty_dev, 0, nseg);
         lz77_rows_update(P_, B_, which, which ^ 1, geo, dirty_dev, has_big_keys_);
         which ^= 1;
         stats_.burst_launches++;
+        if (selftest_rows_every_update) SelfTestRows(which);
         if (it + 1 >= burst_max) break;
         lz77_burst_count(P_, B_, U);
         dev_d2h((void*)counts, U.counters, 4);
@@ -1749,6 +1837,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     tm.stop(&stats_.ms_parse);
     which ^= 1;  // flags[which] now holds the newest flags
+    if (selftest_rows_every_update && use_rows_) SelfTestRows(which);
     // the rank structures are brought up to date on the device while the host chains the exits together
     if (use_rows_) {
       if (n_changed != 0) (n_changed <= B_.changed_cap ? stats_.incremental_ranks : stats_.full_ranks)++;
@@ -1972,6 +2061,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   dev_free(cont_index_dev);
   dev_free(cont_exits_dev);
   dev_free(cont_entries_dev);
+  dev_free(U.stale);
   dev_free(U.sched);
   dev_free(U.entry_dirty);
   dev_free(U.touched);

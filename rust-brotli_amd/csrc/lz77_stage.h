@@ -184,7 +184,8 @@ class Lz77Stage {
   void SelfTestSort();
   void SelfTestRank(int which, int rbuf);
   void SelfTestRows(int which);
-  void SampledHistogram(uint32_t start, uint32_t end, uint32_t* histo);
+  bool FetchShouldCompress();
+  bool ResolvePass(bool final_pass);
   void Release();
 
   EncoderParams params_;
@@ -261,7 +262,9 @@ class Lz77Stage {
   uint32_t dbg_first_[4] = {0, 0, 0, 0};
   uint32_t* dbg_mismatch_ = nullptr;  // set to dbg_counts_ under BROTLI_MI355X_DEBUG
   std::map<std::pair<uint32_t, uint32_t>, bool> should_compress_cache_;
-  std::vector<uint32_t> block_histos_, block_starts_;  // SampledHistogram()
+  std::vector<uint8_t> wanted_guesses_;  // the provisional answers the pass went on with
+  bool should_compress_guess_ = true;
+  std::vector<std::pair<uint32_t, uint32_t>> wanted_histograms_;  // {start, bytes} of the meta-blocks ResolvePass() has no should_compress answer for
   uint32_t first_dirty_ = 0;
   std::vector<uint8_t> predicted_entry_;  // the entry chained for segment k comes out of a predicted literal run
   std::vector<uint8_t> entry_reason_;  // why dirty_entry_[k] is set, see Resolve()

@@ -605,11 +605,12 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments,
   *segments = 0;
 }
 
-void lz77_block_sample_histograms(const uint8_t* text, const uint32_t* block_start, const uint32_t* block_end, uint32_t num_blocks,
-                                  uint32_t* out) {
-  memset(out, 0, (size_t)num_blocks * 13 * 256 * 4);
-  for (uint32_t b = 0; b < num_blocks; ++b)
-    for (uint32_t o = 0; block_start[b] + o < block_end[b]; ++o) out[((size_t)b * 13 + o % 13) * 256 + text[block_start[b] + o]]++;
+void lz77_sample_histograms(const uint8_t* text, const uint32_t* ranges, uint32_t count, uint32_t* out) {
+  memset(out, 0, (size_t)count * 256 * 4);
+  for (uint32_t r = 0; r < count; ++r) {
+    const uint32_t samples = (ranges[2 * r + 1] + 12) / 13;
+    for (uint32_t i = 0; i < samples; ++i) out[(size_t)r * 256 + text[ranges[2 * r] + i * 13u]]++;
+  }
 }
 
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo) {
@@ -649,7 +650,27 @@ void lz77_gather_commands(const Lz77Params& P, const Lz77Buffers& B, uint32_t nu
 // ---- bursts (device_api.h)
 void lz77_chain_check(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
   for (uint32_t k = 0; k < P.num_segments; ++k)
-    br_chain_check(B.segments, B.entries, B.exits, P.num_segments, k, U.sched, U.touched, U.entry_dirty, U.new_entries, B.rows_changed_lo, B.rows_changed_hi);
+    br_chain_check(B.segments, B.entries, B.exits, P.num_segments, k, U.sched, U.touched, U.entry_dirty, U.new_entries, B.rows_changed_lo, B.rows_changed_hi, U.stale);
+}
+void lz77_flags_catch_up(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int src, int dst) {
+  for (uint32_t k = 0; k < P.num_segments; ++k) {
+    if (!U.stale[k]) continue;
+    for (uint32_t q = B.segments[k].start; q < B.segments[k].end; ++q) B.flags[dst][q] = B.flags[src][q];
+    U.stale[k] = 0;
+  }
+}
+void lz77_diff_flags_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int prev, int next) {
+  uint32_t count = 0;
+  for (uint32_t k = 0; k < P.num_segments; ++k) {
+    if (!U.stale[k]) continue;
+    for (uint32_t q = B.segments[k].start; q < B.segments[k].end; ++q) {
+      if ((B.flags[prev][q] ^ B.flags[next][q]) & (kFlagStored | kFlagMasked)) {
+        if (count < B.changed_cap) B.changed_keys[count] = q;
+        count++;
+      }
+    }
+  }
+  *B.changed_count = count;
 }
 void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B) {
   if (B.rows_changed_lo == nullptr) return;

@@ -2,6 +2,7 @@
 # tools/gpu_round.sh <what> [tag] -- what the builder runs on the GPU box through gpurun; everything goes to gpurun_out/<tag>_*.
 #   probe     headline workload: timing, host-side timeline (BROTLI_MI355X_TIMELINE), launch list
 #   trace     ordered rocprofv3 kernel + copy trace of three steps of the headline workload (where the gaps are)
+#   wtrace    ordered kernel trace of one large workload's last call (tools/step_trace.py)
 #   q01       qualities 0 / 1: -m gpu tests of test_quality_0_1.py and tools/q01_probe.py
 #   suite     the whole -m gpu suite
 #   bench     python bench.py with the driver's defaults
@@ -22,6 +23,13 @@ case $WHAT in
     rm -rf $OUT/${TAG}_trace
     timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/${TAG}_trace -o t -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_trace.log 2>&1
     tail -2 $OUT/${TAG}_trace.log | cut -c1-300;;
+  wtrace)  # wtrace <tag> <case>: ordered kernel trace of the last call of one large workload (tools/ab_workload.py)
+    CASE=${3:-c5_xorshift_1GiB_q5}
+    cd /tmp && export TMPDIR=/tmp
+    rm -rf $OUT/${TAG}_wtrace
+    timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_wtrace -o t -- python $ROOT/tools/ab_workload.py $CASE > $OUT/${TAG}_wtrace.log 2>&1
+    python $ROOT/tools/step_trace.py $OUT/${TAG}_wtrace 300 > $OUT/${TAG}_wtrace_${CASE}.txt; rm -rf $OUT/${TAG}_wtrace
+    tail -3 $OUT/${TAG}_wtrace.log | cut -c1-300; tail -30 $OUT/${TAG}_wtrace_${CASE}.txt;;
   q01)
     timeout 900 python -m pytest tests/test_quality_0_1.py -x -q -m gpu > $OUT/${TAG}_q01_tests.log 2>&1; tail -3 $OUT/${TAG}_q01_tests.log
     timeout 600 python tools/q01_probe.py > $OUT/${TAG}_q01_probe.jsonl 2> $OUT/${TAG}_q01_probe.err; cat $OUT/${TAG}_q01_probe.jsonl; tail -3 $OUT/${TAG}_q01_probe.err;;
