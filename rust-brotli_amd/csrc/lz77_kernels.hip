@@ -701,6 +701,18 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
   const uint32_t lo = base >= kRowHalo ? base - kRowHalo : 0u;
   const uint32_t hi = min(base + kRowTile, a.n);
   const uint32_t span = hi - lo;
+  if (a.validate && a.flip_cells != nullptr && a.flip_cells[a.cell_words] == 0 && base < hi) {
+    // a tile of one key (slots are in position order inside a key) whose cells are all clear: every row of it is what it was
+    const uint32_t key = a.sorted_keys[base];
+    if (key == a.sorted_keys[hi - 1] && a.key_last[key] - a.key_first[key] < 65536u) {
+      const uint32_t p0 = a.by_key[base], p1 = a.by_key[hi - 1];
+      const uint32_t first = (p0 > a.max_backward_limit ? p0 - a.max_backward_limit : 0u) >> a.cell_shift, last = p1 >> a.cell_shift;
+      const uint32_t cell0 = key * a.cells_per_key;
+      bool any = false;
+      for (uint32_t c = cell0 + first; c <= cell0 + last; ++c) any = any || ((a.flip_cells[c >> 5] >> (c & 31u)) & 1u) != 0;
+      if (!any) return;
+    }
+  }
   for (uint32_t e = threadIdx.x; e < span; e += 256) {
     const uint32_t i = lo + e;
     s_pos[e] = a.by_key[i];
@@ -745,6 +757,7 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
   // validation passes look only at the slots that can have a candidate at all (Lz77Buffers::pot): the others hold an empty
   // row and keep it whatever the flags do
   const bool use_pot = a.validate && a.pot != nullptr && a.pot_state[0] != 0;
+  const bool use_cells = a.validate && a.flip_cells != nullptr && a.flip_cells[a.cell_words] == 0;
   for (uint32_t r = 0; r < kRowTile / 256; ++r) {
     const uint32_t e = (base - lo) + w * 256 + r * 64 + lane;
     bool valid = lo + e < hi;
@@ -752,6 +765,16 @@ __global__ __launch_bounds__(256) void k_build_rows(RowArgs a) {
       const unsigned long long pw = a.pot[(base + w * 256 + r * 64) >> 6];  // (wave-uniform: the tile starts at a multiple of 64)
       if (pw == 0) continue;
       valid = valid && ((pw >> lane) & 1ull) != 0;
+    }
+    if (use_cells && valid) {
+      // no flag of this key flipped within reach of the position (Lz77Buffers::flip_cells): its row is what it was
+      const uint32_t p = s_pos[e];
+      const uint32_t first = (p > a.max_backward_limit ? p - a.max_backward_limit : 0u) >> a.cell_shift, last = p >> a.cell_shift;
+      const uint32_t key = s_tk[e] >> 16;
+      const uint32_t cell0 = key * a.cells_per_key;
+      bool any = a.key_last[key] - a.key_first[key] >= 65536u;  // (its ring counter can wrap: wrap marks move with every stored slot in front)
+      for (uint32_t c = cell0 + first; c <= cell0 + last; ++c) any = any || ((a.flip_cells[c >> 5] >> (c & 31u)) & 1u) != 0;
+      valid = any;
     }
     bool slow = false;
     if (valid) {
@@ -1057,7 +1080,8 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
   a.gprev = B.gprev;
   a.pot = B.pot;
   a.pot_state = B.pot_state;
-  // (wrap marks move with the count of ALL stored slots in front of a slot: no cell filter where ring counters can wrap)
+  // (wrap marks move with the count of ALL stored slots in front of a slot: no cell filter where ring counters can wrap --
+  // every key when the counters run on from the stream in front or start over inside the text, else the keys with >= 65 536 slots)
   a.flip_cells = (validate && B.count_base == nullptr && P.reset_pos == 0) ? B.flip_cells : nullptr;
   a.cell_shift = B.cell_shift;
   a.cells_per_key = B.cells_per_key;
@@ -1208,8 +1232,9 @@ __global__ __launch_bounds__(256) void k_validate_listed_rows(RowArgs a, const u
       // no flag of this key flipped within reach of the position: its row is what it was
       const uint32_t p = a.by_key[i];
       const uint32_t first = (p > a.max_backward_limit ? p - a.max_backward_limit : 0u) >> a.cell_shift, last = p >> a.cell_shift;
-      const uint32_t cell0 = (uint32_t)a.sorted_keys[i] * a.cells_per_key;
-      bool any = false;
+      const uint32_t key = a.sorted_keys[i];
+      const uint32_t cell0 = key * a.cells_per_key;
+      bool any = a.key_last[key] - a.key_first[key] >= 65536u;  // (its ring counter can wrap: wrap marks move with every stored slot in front)
       for (uint32_t c = cell0 + first; c <= cell0 + last; ++c) any = any || ((a.flip_cells[c >> 5] >> (c & 31u)) & 1u) != 0;
       if (!any) continue;
     }
@@ -1369,7 +1394,6 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   if (has_big_keys) launch_wrap_marks(P, B, true);
   launch_slot_masks(P, B);
   RowArgs a = row_args(P, B, next, true, &geo, dirty_dev);
-  if (has_big_keys) a.flip_cells = nullptr;
   hipLaunchKernelGGL(k_update_rows, dim3(cap < 65536u ? cap : 65536u), dim3(64), 0, BR_STREAM, a, B.changed_slot, B.changed_count, B.keys);
   a.conditional = 1;
   if (B.pot) {

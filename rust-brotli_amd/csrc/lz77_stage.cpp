@@ -2025,7 +2025,8 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     cache_wave.swap(cache_wave_next);
     if (regime_flip) {
       last_death_seg = dict_death_seg_;
-      if (warmup_bytes_ > 0 && dict_death_seg_ + 2 < nseg) {
+      static const bool no_regime_warmup = getenv("BROTLI_MI355X_NO_REGIME_WARMUP") != nullptr;
+      if (warmup_bytes_ > 0 && dict_death_seg_ + 2 < nseg && !no_regime_warmup) {
         Warmup(dict_death_seg_ + 1, true, which, rbuf, &dirty);
         // (the dry run rewrote the entries of the scheduled segments behind that point: none of them is parsed "with the
         // entry it had last time" any more -- a chain that restarted from a checkpoint on that assumption kept the head of a

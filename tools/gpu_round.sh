@@ -27,7 +27,8 @@ case $WHAT in
     CASE=${3:-c5_xorshift_1GiB_q5}
     cd /tmp && export TMPDIR=/tmp
     rm -rf $OUT/${TAG}_wtrace
-    timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_wtrace -o t -- python $ROOT/tools/ab_workload.py $CASE > $OUT/${TAG}_wtrace.log 2>&1
+    if [ "$CASE" = "silesia_256MiB_q5" ]; then RUN="python $ROOT/tools/prof_workload.py $CASE"; else RUN="python $ROOT/tools/ab_workload.py $CASE"; fi
+    timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_wtrace -o t -- $RUN > $OUT/${TAG}_wtrace.log 2>&1
     python $ROOT/tools/step_trace.py $OUT/${TAG}_wtrace 300 > $OUT/${TAG}_wtrace_${CASE}.txt; rm -rf $OUT/${TAG}_wtrace
     tail -3 $OUT/${TAG}_wtrace.log | cut -c1-300; tail -30 $OUT/${TAG}_wtrace_${CASE}.txt;;
   q01)
