@@ -1101,7 +1101,11 @@ static RowArgs row_args(const Lz77Params& P, const Lz77Buffers& B, int which, bo
 // the staged span inside the window (dense keys, i.e. text: nearly every slot, but such input never asks for the mask).
 // The slots with the bit are also LISTED (pot_list; pot_state[1] = their number, pot_state[2] = the list overflowed): the
 // validation pass of sparse input is a pass over that list (k_validate_listed_rows), not over all slots.
-static constexpr uint32_t kPotTile = 1024, kPotHalo = 512, kPotSpan = kPotTile + kPotHalo, kPotTable = 8192;
+#if !defined(BR_POT_TABLE)
+#define BR_POT_TABLE 8192
+#define BR_POT_SHIFT 19
+#endif
+static constexpr uint32_t kPotTile = 1024, kPotHalo = 512, kPotSpan = kPotTile + kPotHalo, kPotTable = BR_POT_TABLE, kPotShift = BR_POT_SHIFT;
 __global__ __launch_bounds__(256) void k_row_potential(const uint32_t* __restrict__ by_key, const uint16_t* __restrict__ sorted_keys,
                                                         const uint16_t* __restrict__ stag, uint32_t n, uint32_t max_backward_limit,
                                                         const uint32_t* __restrict__ ctl, uint32_t* __restrict__ pot_state,
@@ -1130,8 +1134,8 @@ __global__ __launch_bounds__(256) void k_row_potential(const uint32_t* __restric
       // (an entry that repeats the value in front of it is not a first occurrence: runs of one value -- zero fill -- would
       // all hit one table word)
       if (e != 0 && s_val[e - 1] == s_val[e]) continue;
-      atomicMax(&tab[(s_val[e] * 0x9E3779B1u) >> 19], (gen << 16) | (0xffffu - e));
-      atomicMax(&tab2[(s_val[e] * 0x85EBCA6Bu) >> 19], (gen << 16) | (0xffffu - e));
+      atomicMax(&tab[(s_val[e] * 0x9E3779B1u) >> kPotShift], (gen << 16) | (0xffffu - e));
+      atomicMax(&tab2[(s_val[e] * 0x85EBCA6Bu) >> kPotShift], (gen << 16) | (0xffffu - e));
     }
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
@@ -1144,8 +1148,8 @@ __global__ __launch_bounds__(256) void k_row_potential(const uint32_t* __restric
       if (in) {
         val = s_val[e];
         p = s_pos[e];
-        uint32_t f = 0xffffu - (tab[(val * 0x9E3779B1u) >> 19] & 0xffffu);  // (this tile's: e or the head of its run was entered)
-        if (f >= span || s_val[f] != val) f = 0xffffu - (tab2[(val * 0x85EBCA6Bu) >> 19] & 0xffffu);
+        uint32_t f = 0xffffu - (tab[(val * 0x9E3779B1u) >> kPotShift] & 0xffffu);  // (this tile's: e or the head of its run was entered)
+        if (f >= span || s_val[f] != val) f = 0xffffu - (tab2[(val * 0x85EBCA6Bu) >> kPotShift] & 0xffffu);
         if (f >= span) f = e;  // (cannot happen: both words hold an entry of this tile)
         scan = true;
         if (s_val[f] == val) {  // f is the first occurrence of this value in the span
