@@ -36,6 +36,9 @@ void dev_d2d(void* dst, const void* src, size_t bytes);
 void dev_sync();
 void dev_mark();       // records a point in the calling thread's stream ...
 void dev_wait_mark();  // ... and waits until everything queued before the last mark has finished (later work keeps running)
+// the same with a number (0..3): several points of the stream waited for one after the other
+void dev_mark_n(int i);
+void dev_wait_mark_n(int i);
 // page-locked host memory for the buffers that go back and forth every round (copies to and from pageable memory are
 // staged by the runtime and block the caller)
 void* dev_host_alloc(size_t bytes);

@@ -457,11 +457,30 @@ namespace {
 struct Mark {
   hipEvent_t ev = nullptr;  // (left to the runtime when the thread ends: no call into it from a dying thread, see Orphans)
 };
-Mark& mark() {
-  static thread_local Mark m;
-  return m;
+Mark& mark(int i = 4) {
+  static thread_local Mark m[5];
+  return m[i];
+}
+void record_mark(Mark& m) {
+  if (!m.ev) HIP_CHECK(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(m.ev, BR_STREAM));
+}
+void wait_mark(Mark& m) {
+  if (!m.ev) return;
+  if (!polling_waits()) {
+    HIP_CHECK(hipEventSynchronize(m.ev));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipEventQuery(m.ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    __builtin_ia32_pause();
+  }
 }
 }  // namespace
+void dev_mark_n(int i) { record_mark(mark(i & 3)); }
+void dev_wait_mark_n(int i) { wait_mark(mark(i & 3)); }
 void dev_mark() {
   Mark& m = mark();
   if (!m.ev) HIP_CHECK(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));

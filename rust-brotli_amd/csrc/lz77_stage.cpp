@@ -672,24 +672,59 @@ bool Lz77Stage::Resolve(bool final_pass) {
   wanted_histograms_.clear();
   wanted_guesses_.clear();
   should_compress_guess_ = true;
-  bool consistent = ResolvePass(final_pass);
+  static const bool never_incremental = getenv("BROTLI_MI355X_NO_INCREMENTAL_RESOLVE") != nullptr;
+  static const bool check_incremental = getenv("BROTLI_MI355X_SELFTEST") != nullptr || getenv("BROTLI_MI355X_SELFTEST_RESOLVE") != nullptr;
+  const bool incremental = resolve_incremental_ && !never_incremental && !use_live_ && block_records_valid_ && !touch_all_;
+  resolve_blocks_skipped_ = 0;
+  bool consistent = ResolvePass(final_pass, incremental);
   if (!wanted_histograms_.empty()) {
-    if (!FetchShouldCompress()) {  // (a guess was wrong)
+    if (!FetchShouldCompress()) {  // (a guess was wrong: the pass again, every block of it)
       wanted_guesses_.clear();
       should_compress_guess_ = true;
-      consistent = ResolvePass(final_pass);
+      consistent = ResolvePass(final_pass, false);
       if (!wanted_histograms_.empty()) throw std::runtime_error("brotli_mi355x: the resolver asked for a meta-block twice");
     }
   }
+  if (incremental && check_incremental && resolve_blocks_skipped_ != 0) {
+    // selftest: the pass over every block must come out the same
+    const std::vector<MetaBlockPlan> mb = metablocks_;
+    const std::vector<Patch> pa = patches_;
+    const std::vector<TrailingInsert> tr = trailing_;
+    const std::vector<Carry> ca = carries_;
+    const std::vector<SegEntry> ne = next_entries_;
+    const std::vector<uint8_t> de = dirty_entry_, er = entry_reason_, pe = predicted_entry_;
+    const uint32_t fd = first_dirty_, pr = predicted_runs_, dd = dict_death_seg_, df = dict_flips_, rp = resume_pos_;
+    const bool nel = needs_empty_last_;
+    const bool full = ResolvePass(final_pass, false);
+    auto same_bytes = [](const void* a, const void* b, size_t n) { return n == 0 || memcmp(a, b, n) == 0; };
+    const bool same = full == consistent && mb.size() == metablocks_.size() && same_bytes(mb.data(), metablocks_.data(), mb.size() * sizeof(MetaBlockPlan)) &&
+                      pa.size() == patches_.size() && same_bytes(pa.data(), patches_.data(), pa.size() * sizeof(Patch)) && tr.size() == trailing_.size() &&
+                      same_bytes(tr.data(), trailing_.data(), tr.size() * sizeof(TrailingInsert)) && ca.size() == carries_.size() &&
+                      same_bytes(ca.data(), carries_.data(), ca.size() * sizeof(Carry)) && same_bytes(ne.data(), next_entries_.data(), ne.size() * sizeof(SegEntry)) &&
+                      de == dirty_entry_ && er == entry_reason_ && pe == predicted_entry_ && fd == first_dirty_ && pr == predicted_runs_ &&
+                      dd == dict_death_seg_ && df == dict_flips_ && rp == resume_pos_ && nel == needs_empty_last_;
+    if (!same) throw std::runtime_error("selftest: the block-by-block resolver pass differs from the pass over every block");
+  }
+  touch_all_ = false;
+  if (!block_touched_.empty()) std::fill(block_touched_.begin(), block_touched_.end(), (uint8_t)0);
   return consistent;
 }
 
-bool Lz77Stage::ResolvePass(bool final_pass) {
+bool Lz77Stage::ResolvePass(bool final_pass, bool incremental) {
   const uint32_t nseg = (uint32_t)segments_.size();
   next_entries_.resize(nseg);  // (every element is written below)
   dbg_mismatch_ = dbg_counts_;
   memset(dbg_counts_, 0, sizeof(dbg_counts_));
   memset(dbg_first_, 0, sizeof(dbg_first_));
+  const uint32_t nblocks = (uint32_t)block_segment_bytes_.size();
+  if (incremental && (block_records_.size() != (size_t)nblocks + 1 || block_touched_.size() != nblocks || dirty_entry_.size() != nseg)) incremental = false;
+  if (incremental) {
+    // (what the last pass appended, block by block: copied for the blocks that are not looked at again)
+    metablocks_prev_.swap(metablocks_);
+    trailing_prev_.swap(trailing_);
+    carries_prev_.swap(carries_);
+  }
+  std::vector<ResolveBlockRecord> records((size_t)nblocks + 1);
   metablocks_.clear();
   patches_.clear();
   trailing_.clear();
@@ -697,10 +732,13 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
   bool consistent = true;
   predicted_runs_ = 0;
   first_dirty_ = nseg;
-  dirty_entry_.assign(nseg, 0);
-  entry_reason_.assign(nseg, 0);
-  predicted_entry_.assign(nseg, 0);
+  if (!incremental) {
+    dirty_entry_.assign(nseg, 0);
+    entry_reason_.assign(nseg, 0);
+    predicted_entry_.assign(nseg, 0);
+  }
   if (use_live_) live_state_.assign(nseg, LiveBlockState{});
+  uint32_t block_marks = 0, block_first_dirty = nseg;  // of the block being processed
   // reason: bit 1 = the distance cache at the entry differs, bit 0 = anything else
   auto mark = [&](uint32_t k, bool same, uint8_t reason = 1) {
     if (!same) {
@@ -708,6 +746,8 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
       dirty_entry_[k] = 1;
       entry_reason_[k] |= reason;
       if (k < first_dirty_) first_dirty_ = k;
+      block_marks++;
+      if (k < block_first_dirty) block_first_dirty = k;
     }
   };
 
@@ -741,13 +781,148 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
   (void)final_pass;
   std::map<std::pair<uint32_t, uint32_t>, bool>& should_compress_cache = should_compress_cache_;
 
+  auto flow_now = [&]() {
+    ResolveFlow f;
+    memset(&f, 0, sizeof(f));  // (compared as bytes)
+    memcpy(f.cache, cache, sizeof(cache));
+    memcpy(f.saved_cache, saved_cache, sizeof(saved_cache));
+    f.last_insert_len = last_insert_len;
+    f.last_flush_pos = last_flush_pos;
+    f.mb_first_seg = mb_first_seg;
+    f.resume_pos = resume_pos_;
+    f.num_commands = num_commands;
+    f.num_literals = num_literals;
+    f.mb_cmds = mb_cmds;
+    f.dict_state = (uint32_t)dict.state;
+    f.dict_L = dict.L;
+    f.dict_M = dict.M;
+    f.dict_left_alive_at = dict.left_alive_at;
+    f.dict_flips = dict.flips;
+    f.dict_slack = dict.slack;
+    f.last_valid = last_cmd.valid ? 1u : 0u;
+    f.last_seg = last_cmd.seg;
+    f.last_idx = last_cmd.idx;
+    f.last_dist_code = last_cmd.dist_code;
+    f.last_copy_len = last_cmd.copy_len;
+    f.compress_guess = should_compress_guess_ ? 1u : 0u;
+    f.needs_empty_last = needs_empty_last_ ? 1u : 0u;
+    return f;
+  };
+  auto flow_set = [&](const ResolveFlow& f) {
+    memcpy(cache, f.cache, sizeof(cache));
+    memcpy(saved_cache, f.saved_cache, sizeof(saved_cache));
+    last_insert_len = f.last_insert_len;
+    last_flush_pos = f.last_flush_pos;
+    mb_first_seg = f.mb_first_seg;
+    resume_pos_ = f.resume_pos;
+    num_commands = f.num_commands;
+    num_literals = f.num_literals;
+    mb_cmds = f.mb_cmds;
+    dict.state = (DictTracker::State)f.dict_state;
+    dict.L = f.dict_L;
+    dict.M = f.dict_M;
+    dict.left_alive_at = f.dict_left_alive_at;
+    dict.flips = f.dict_flips;
+    dict.slack = f.dict_slack;
+    last_cmd.valid = f.last_valid != 0;
+    last_cmd.seg = f.last_seg;
+    last_cmd.idx = f.last_idx;
+    last_cmd.dist_code = f.last_dist_code;
+    last_cmd.copy_len = f.last_copy_len;
+    should_compress_guess_ = f.compress_guess != 0;
+    needs_empty_last_ = f.needs_empty_last != 0;
+  };
+  uint32_t cur_block = 0xffffffffu, runs_at_entry = 0, dbg_c0[4] = {0, 0, 0, 0}, dbg_f0[4] = {0, 0, 0, 0};
+  // the books of the block just left: what it marked and counted, and the state it is left in (= the next one's entry)
+  auto leave_block = [&]() {
+    ResolveBlockRecord& r = records[cur_block];
+    r.marks = block_marks;
+    r.first_dirty = block_first_dirty;
+    r.predicted_runs = predicted_runs_ - runs_at_entry;
+    for (int i = 0; i < 4; ++i) {
+      r.dbg_counts[i] = dbg_counts_[i] - dbg_c0[i];
+      r.dbg_first[i] = dbg_first_[i] - dbg_f0[i];
+    }
+    ResolveBlockRecord& n = records[cur_block + 1];
+    n.in = flow_now();
+    n.n_metablocks = (uint32_t)metablocks_.size();
+    n.n_patches = (uint32_t)patches_.size();
+    n.n_trailing = (uint32_t)trailing_.size();
+    n.n_carries = (uint32_t)carries_.size();
+  };
+
   uint32_t k = 0;
   while (k < nseg) {
     const uint32_t k0 = k;
     const Segment& g0 = segments_[k0];
     const uint32_t bs = g0.blk_start, be = g0.blk_end;
     uint32_t k1 = k0;
+    cur_block = g0.block_index;
+    {
+      ResolveBlockRecord& r = records[cur_block];
+      r.in = flow_now();
+      r.n_metablocks = (uint32_t)metablocks_.size();
+      r.n_patches = (uint32_t)patches_.size();
+      r.n_trailing = (uint32_t)trailing_.size();
+      r.n_carries = (uint32_t)carries_.size();
+      r.merged_ext = 0;
+      if (incremental && !block_touched_[cur_block]) {
+        const ResolveBlockRecord& o = block_records_[cur_block];
+        const ResolveBlockRecord& on = block_records_[cur_block + 1];
+        // (the number of the meta-block decides whether it is one the encoder forces to be stored: part of the state)
+        if (memcmp(&o.in, &r.in, sizeof(ResolveFlow)) == 0 && o.n_metablocks == r.n_metablocks) {
+          // ---- the block comes out as it did in the last pass
+          if (o.merged_ext != 0) {
+            // (extend_last_command at its start, as below: onto the patch of the same command if there is one)
+            if (!patches_.empty() && patches_.back().segment == last_cmd.seg && patches_.back().index == last_cmd.idx) {
+              patches_.back().ext += o.merged_ext;
+            } else {
+              patches_.push_back({last_cmd.seg, last_cmd.idx, o.merged_ext});
+            }
+          }
+          metablocks_.insert(metablocks_.end(), metablocks_prev_.begin() + o.n_metablocks, metablocks_prev_.begin() + on.n_metablocks);
+          trailing_.insert(trailing_.end(), trailing_prev_.begin() + o.n_trailing, trailing_prev_.begin() + on.n_trailing);
+          carries_.insert(carries_.end(), carries_prev_.begin() + o.n_carries, carries_prev_.begin() + on.n_carries);
+          if (o.marks != 0) {
+            consistent = false;
+            if (o.first_dirty < first_dirty_) first_dirty_ = o.first_dirty;
+          }
+          predicted_runs_ += o.predicted_runs;
+          for (int i = 0; i < 4; ++i) {
+            dbg_counts_[i] += o.dbg_counts[i];
+            dbg_first_[i] += o.dbg_first[i];
+          }
+          r.merged_ext = o.merged_ext;
+          r.marks = o.marks;
+          r.first_dirty = o.first_dirty;
+          r.predicted_runs = o.predicted_runs;
+          memcpy(r.dbg_counts, o.dbg_counts, sizeof(r.dbg_counts));
+          memcpy(r.dbg_first, o.dbg_first, sizeof(r.dbg_first));
+          flow_set(on.in);
+          ResolveBlockRecord& n = records[cur_block + 1];
+          n.in = on.in;
+          n.n_metablocks = (uint32_t)metablocks_.size();
+          n.n_patches = (uint32_t)patches_.size();
+          n.n_trailing = (uint32_t)trailing_.size();
+          n.n_carries = (uint32_t)carries_.size();
+          resolve_blocks_skipped_++;
+          k = block_first_segment_[cur_block + 1];
+          continue;
+        }
+      }
+    }
+    block_marks = 0;
+    block_first_dirty = nseg;
+    runs_at_entry = predicted_runs_;
+    memcpy(dbg_c0, dbg_counts_, sizeof(dbg_c0));
+    memcpy(dbg_f0, dbg_first_, sizeof(dbg_f0));
     while (!(segments_[k1].flags & kSegLastInBlock)) ++k1;
+    if (incremental) {
+      // (a block that is looked at again starts from clean marks)
+      memset(dirty_entry_.data() + k0, 0, k1 - k0 + 1);
+      memset(entry_reason_.data() + k0, 0, k1 - k0 + 1);
+      memset(predicted_entry_.data() + k0, 0, k1 - k0 + 1);
+    }
     // ---- entry of the block
     SegEntry E{};
     E.pos = bs;
@@ -845,6 +1020,7 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
         } else {
           patches_.push_back({last_cmd.seg, last_cmd.idx, X.ext_len});
         }
+        records[cur_block].merged_ext = X.ext_len;  // (a block that is skipped next time repeats this)
         last_cmd.copy_len += X.ext_len;
       }
       num_commands += X.n_cmds;
@@ -908,6 +1084,7 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
     }
     if (!is_last && next_fits && num_literals < max_literals && num_commands < max_commands) {
       // (partial piece: the meta-block that is still open when the input runs out is left to the next piece)
+      leave_block();
       if (batch_end) break;
       k = k1 + 1;
       continue;
@@ -963,7 +1140,11 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
     last_flush_pos = be;
     mb_first_seg = k1 + 1;
     k = k1 + 1;
+    leave_block();
   }
+  block_records_.swap(records);
+  block_records_valid_ = true;
+  if (block_touched_.size() != nblocks) block_touched_.assign(nblocks, 0);
   dict_death_seg_ = dict.left_alive_at;
   dict_flips_ = dict.flips;
   final_dict_lookups_ = dict.L;
@@ -976,19 +1157,34 @@ bool Lz77Stage::ResolvePass(bool final_pass) {
 // state, distance cache) with the state in which the dry run left segment k.  dict_dead selects the static
 // dictionary regime the dry run assumes.
 void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, const std::vector<uint8_t>* only_after_dirty) {
+  WarmupJob job;
+  WarmupBegin(&job, first_seg, (uint32_t)segments_.size(), dict_dead, which, rbuf, only_after_dirty, 3);
+  WarmupEnd(&job);
+}
+
+// The dry runs of segments [first_seg, end_seg) are queued (WarmupBegin) and their results turned into entries (WarmupEnd) in
+// two steps: the host works on one half of the input's dry runs while the device is busy with the other half's (RunRounds).
+void Lz77Stage::WarmupBegin(WarmupJob* job, uint32_t first_seg, uint32_t end_seg, bool dict_dead, int which, int rbuf,
+                            const std::vector<uint8_t>* only_after_dirty, int mark) {
   const uint32_t nseg = (uint32_t)segments_.size();
+  job->count = 0;
+  job->dict_dead = dict_dead;
+  job->whole_input = only_after_dirty == nullptr;
+  job->mark = mark;
   if (first_seg + 1 >= nseg) return;
   // dry-run segment k to get a guess for the entry of k + 1; with only_after_dirty, just where both k and k + 1 are
   // about to be re-parsed (otherwise the resolver already chained the exact entry from a valid parse of k)
-  std::vector<uint32_t> ks;
-  for (uint32_t k = first_seg; k + 1 < nseg; ++k)
+  std::vector<uint32_t>& ks = job->ks;
+  ks.clear();
+  for (uint32_t k = first_seg; k + 1 < nseg && k < end_seg; ++k)
     if (!only_after_dirty || ((*only_after_dirty)[k] && (*only_after_dirty)[k + 1])) ks.push_back(k);
   const uint32_t count = (uint32_t)ks.size();
+  job->count = count;
   if (count == 0) return;
   // (page-locked like everything that moves every call: copies from pageable memory go through the runtime's staging)
-  PinnedArray<Segment> wsegs;
-  PinnedArray<SegEntry> wentries;
-  PinnedArray<SegExit> wexits;
+  PinnedArray<Segment>& wsegs = job->wsegs;
+  PinnedArray<SegEntry>& wentries = job->wentries;
+  PinnedArray<SegExit>& wexits = job->wexits;
   wsegs.resize_discard(count);
   wentries.resize_discard(count);
   wexits.resize_discard(count);
@@ -1014,15 +1210,34 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
   dev_h2d(wentries_dev, wentries.data(), count * sizeof(SegEntry));
   lz77_parse_custom(P_, B_, which, rbuf, wsegs_dev, wentries_dev, wexits_dev, count);
   timeline().stamp("wu-queued");
-  dev_d2h(wexits.data(), wexits_dev, count * sizeof(SegExit));
+  dev_d2h_async(wexits.data(), wexits_dev, count * sizeof(SegExit));
+  dev_mark_n(mark);
+  job->wsegs_dev = wsegs_dev;
+  job->wentries_dev = wentries_dev;
+  job->wexits_dev = wexits_dev;
+}
+
+void Lz77Stage::WarmupEnd(WarmupJob* job) {
+  const uint32_t nseg = (uint32_t)segments_.size();
+  const uint32_t count = job->count;
+  if (count == 0) return;
+  const std::vector<uint32_t>& ks = job->ks;
+  PinnedArray<Segment>& wsegs = job->wsegs;
+  PinnedArray<SegEntry>& wentries = job->wentries;
+  PinnedArray<SegExit>& wexits = job->wexits;
+  const bool dict_dead = job->dict_dead;
+  const bool only_after_dirty = !job->whole_input;
+  dev_wait_mark_n(job->mark);
   timeline().stamp("wu-exits");
-  dev_free(wsegs_dev);
-  dev_free(wentries_dev);
-  dev_free(wexits_dev);
+  dev_free(job->wsegs_dev);
+  dev_free(job->wentries_dev);
+  dev_free(job->wexits_dev);
   if (!dict_dead && !only_after_dirty) {
     // lookups / matches the dry runs saw, scaled to the whole segment: a forecast of where the throttle trips
-    warm_lookups_.assign(nseg, 0.0);
-    warm_matches_.assign(nseg, 0.0);
+    if (warm_lookups_.size() != nseg || ks[0] == 0) {
+      warm_lookups_.assign(nseg, 0.0);
+      warm_matches_.assign(nseg, 0.0);
+    }
     for (uint32_t i = 0; i < count; ++i) {
       const double scale = (double)(segments_[ks[i]].end - segments_[ks[i]].start) / (double)(wsegs[i].end - wsegs[i].start);
       warm_lookups_[ks[i]] = scale * (double)(wexits[i].dict_lookups - wentries[i].dict_lookups);
@@ -1059,7 +1274,8 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
       }
     }
   }
-  if (!only_after_dirty && getenv("BROTLI_MI355X_NO_SPREE_GUESS") == nullptr) {
+  static const bool no_spree_guess = getenv("BROTLI_MI355X_NO_SPREE_GUESS") != nullptr;
+  if (!only_after_dirty && !no_spree_guess) {
     // A dry run that found nothing to copy in the tail of its segment says "incompressible here", but the state it ends in
     // is that of a spree begun at the tail's start; in the real parse the spree began wherever the last copy ended --
     // blocks away in random data -- and where it steps (every 9th, every 17th position, mod.rs:2529-2546) is a matter of
@@ -1090,6 +1306,7 @@ void Lz77Stage::Warmup(uint32_t first_seg, bool dict_dead, int which, int rbuf, 
     }
   }
   stats_.segments_parsed += (uint64_t)count * warmup_bytes_ / segment_bytes_;
+  touch_all_ = true;  // (entries behind every dry run)
 }
 
 // Segments whose entry changed in the distance cache only and whose parse found nothing to copy: instead of parsing
@@ -1123,6 +1340,7 @@ uint32_t Lz77Stage::RecheckCacheOnly(int which, std::vector<uint32_t>* accepted)
     if (!ok[i]) continue;
     const uint32_t k = items[i].segment;
     memcpy(entries_[k].cache, items[i].cache, sizeof(items[i].cache));
+    TouchSegment(k);
     if (accepted) accepted->push_back(k);  // (the device's copy of this entry is stale now)
     dirty_entry_[k] = 0;
     ++cleared;
@@ -1156,6 +1374,9 @@ void Lz77Stage::Run() {
   Timer total(true);
   Timer tm(prof);
   should_compress_cache_.clear();
+  block_records_valid_ = false;  // (Resolve() block by block: nothing of an earlier call, another forced meta-block, another cut)
+  touch_all_ = true;
+  resolve_incremental_ = false;
   const uint32_t nseg = (uint32_t)segments_.size();
   if (nseg == 0) {
     metablocks_.clear();
@@ -1527,6 +1748,11 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   const bool prof = getenv("BROTLI_MI355X_PROFILE") != nullptr;
   Timer tm(prof);
   const uint32_t nseg = (uint32_t)segments_.size();
+  // the resolver passes of this loop look only at the blocks whose segments were handed new entries or exits (TouchSegment)
+  resolve_incremental_ = true;
+  block_records_valid_ = false;
+  touch_all_ = true;
+  block_touched_.assign(block_segment_bytes_.size(), 0);
   InitFlags();
   tm.stop(&stats_.ms_init);
   const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
@@ -1553,35 +1779,41 @@ void Lz77Stage::RunRounds(bool allow_restart) {
   // parse leaves it (greedy parses re-synchronise quickly), so that the first full round already starts
   // almost every chain from its true entry.
   if (const char* w = getenv("BROTLI_MI355X_WARMUP")) warmup_bytes_ = (uint32_t)atoi(w);
-  if (nseg > 1 && warmup_bytes_ > 0) {
-    Warmup(0, false, which, rbuf, nullptr);
-    timeline().stamp("warmed-up");
-    if (P_.use_dictionary && warm_lookups_.size() == nseg) {
-      // forecast of the segment in which the static dictionary gets switched off (matches < lookups >> 7,
-      // mod.rs:1957-1960); chains behind it start with the "off" guess.  A wrong forecast only costs re-parses of
-      // the chains that actually used / could have used a dictionary match (DictTracker::Consume).
-      // Guessing "off" too early is the expensive mistake (a chain that ran without the dictionary cannot tell what
-      // it would have counted, so the exact counters can only advance one redone chain per round), guessing "on" too
-      // long only costs the re-parse of the chains that really used a dictionary match.  Hence a forecast three
-      // standard deviations of the sampled match count on the late side.
-      const double sample = (double)warmup_bytes_ / (double)segment_bytes_;
-      double Lc = 0, Mc = 0;
-      uint32_t death = nseg;
-      for (uint32_t k = 0; k < nseg; ++k) {
-        Lc += warm_lookups_[k];
-        Mc += warm_matches_[k];
-        const double sigma = std::sqrt(std::max(1.0, Mc * sample)) / sample;
-        if (Lc >= 256.0 && Mc + 3.0 * sigma < Lc / 128.0) {
-          death = k;
-          break;
-        }
+  double fc_L = 0, fc_M = 0;  // the forecast's running sums
+  uint32_t fc_death = nseg;
+  bool fc_found = false;
+  // forecast of the segment in which the static dictionary gets switched off (matches < lookups >> 7,
+  // mod.rs:1957-1960); chains behind it start with the "off" guess.  A wrong forecast only costs re-parses of
+  // the chains that actually used / could have used a dictionary match (DictTracker::Consume).
+  // Guessing "off" too early is the expensive mistake (a chain that ran without the dictionary cannot tell what
+  // it would have counted, so the exact counters can only advance one redone chain per round), guessing "on" too
+  // long only costs the re-parse of the chains that really used a dictionary match.  Hence a forecast three
+  // standard deviations of the sampled match count on the late side.
+  auto forecast = [&](uint32_t from, uint32_t upto) {  // segments [from, upto), in order
+    if (!(P_.use_dictionary && warm_lookups_.size() == nseg)) return;
+    const double sample = (double)warmup_bytes_ / (double)segment_bytes_;
+    for (uint32_t k = from; k < upto && !fc_found; ++k) {
+      fc_L += warm_lookups_[k];
+      fc_M += warm_matches_[k];
+      const double sigma = std::sqrt(std::max(1.0, fc_M * sample)) / sample;
+      if (fc_L >= 256.0 && fc_M + 3.0 * sigma < fc_L / 128.0) {
+        fc_death = k;
+        fc_found = true;
       }
-      for (uint32_t k = death + 1; k < nseg; ++k) {
+    }
+    if (upto == nseg || fc_found) {
+      for (uint32_t k = fc_death + 1; k < nseg; ++k) {
         entries_[k].dict_lookups = DictTracker::kDeadL;
         entries_[k].dict_matches = DictTracker::kDeadM;
       }
-      predicted_death_ = death;
+      touch_all_ = true;
+      predicted_death_ = fc_death;
     }
+  };
+  if (nseg > 1 && warmup_bytes_ > 0) {
+    Warmup(0, false, which, rbuf, nullptr);
+    timeline().stamp("warmed-up");
+    forecast(0, nseg);
     tm.stop(&stats_.ms_warmup);
   }
   if (!allow_restart && !saved_block_guess_.empty()) {
@@ -1593,6 +1825,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       if (it == saved_block_guess_.end()) continue;
       memcpy(entries_[k].cache, it->second.cache, sizeof(entries_[k].cache));
       entries_[k].ext_allowed = it->second.ext_allowed;
+      touch_all_ = true;
     }
   }
   // ---- rounds.  Round 0 parses every segment; later rounds re-parse only the segments whose entry state
@@ -1782,6 +2015,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         pending[k] = 0;
         exits_[k] = cont_exits[i];
         entries_[k] = cont_entries[i];
+        TouchSegment(k);
       }
       counts[0] = 1;  // (read the marks of the last lz77_rows_update below)
       counts[1] = 0;
@@ -1789,6 +2023,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     counts[0] = counts[1] = 0;
     if (full_round) {
       dev_d2h_async(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
+      touch_all_ = true;
     } else {
       // the exits of the listed segments, and exit + rewritten entry of the segments that chains continued into (the
       // first kContFirst of them ride along; more are rare and fetched afterwards)
@@ -1818,7 +2053,10 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     const uint32_t n_changed = counts[0], n_cont = counts[1];
     if (!full_round && !burst) {
-      for (uint32_t i = 0; i < count; ++i) exits_[list[i]] = got_exits[i];
+      for (uint32_t i = 0; i < count; ++i) {
+        exits_[list[i]] = got_exits[i];
+        TouchSegment(list[i]);
+      }
       // chains that kept going into unscheduled segments (br_parse_chain) rewrote the entries of those
       if (n_cont > kContFirst) {
         dev_d2h(cont_index, cont_index_dev, (size_t)n_cont * 4);
@@ -1831,6 +2069,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
         pending[k] = 0;
         exits_[k] = cont_exits[i];
         entries_[k] = cont_entries[i];
+        TouchSegment(k);
         cache_wave[k] = 1;
         stats_.segments_parsed++;
       }
@@ -2018,6 +2257,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       pending[k] = 0;
       list[count++] = k;
       entries_[k] = next_entries_[k];
+      TouchSegment(k);
       const bool cache_only = dirty_entry_[k] && entry_reason_[k] == 2;
       cache_wave_next[k] = cache_only;
       front_run = follow_cache_fronts && cache_only && k > 0 && !(segments_[k].flags & kSegFirstInBlock) && cache_wave[k - 1];
@@ -2036,6 +2276,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
       }
     }
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "mismatch pos %u apply %u cache %u apply-only %u | block-first: cache %u ext %u | head %u; dict death seg %u (forecast %u) flips %u\n", dbg_counts_[0], dbg_counts_[1], dbg_counts_[2], dbg_counts_[3], dbg_first_[0], dbg_first_[1], dbg_first_[2], dict_death_seg_, predicted_death_, dict_flips_);
+    if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "  resolver: %u of %u blocks taken over from the last pass\n", resolve_blocks_skipped_, (unsigned)block_segment_bytes_.size());
     if (getenv("BROTLI_MI355X_DEBUG")) fprintf(stderr, "round %u: flag changes %llu, dirty segments %u of %u (entry %u, candidates %u), predicted literal runs %u, cache rechecks passed %u\n", round, (unsigned long long)n_changed, count, nseg, n_dirty_entry, n_dirty_valid, predicted_runs_, rechecked);
     host_schedule_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count();
     stamp("scheduled");
@@ -2053,6 +2294,7 @@ void Lz77Stage::RunRounds(bool allow_restart) {
     }
     full_round = false;
   }
+  resolve_incremental_ = false;
   dev_free(dirty_dev);
   dev_free(list_dev);
   dev_free(geo_tables);

@@ -48,6 +48,8 @@ void dev_d2d(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes
 void dev_sync() {}
 void dev_mark() {}
 void dev_wait_mark() {}
+void dev_mark_n(int) {}
+void dev_wait_mark_n(int) {}
 void dev_make_room(unsigned) {}
 size_t dev_trim_pool() { return 0; }
 void dev_h2d_bulk(void* dst, const void* src, size_t bytes) { dev_h2d(dst, src, bytes); }
