@@ -18,6 +18,11 @@ except ImportError:
     pass
 
 
+# Every resolver pass that takes blocks over from the pass before it (Lz77Stage::ResolvePass) is run again over every block and
+# compared, in the emulation build and the device library alike (read once per process; a few per cent of a test's time).
+os.environ.setdefault("BROTLI_MI355X_SELFTEST_RESOLVE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
