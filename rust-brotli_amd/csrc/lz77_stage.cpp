@@ -628,7 +628,7 @@ static void PredictLiteralRun(const Lz77Params& P, const Segment& seg, const Seg
   x->tail_kind = position > seg.end ? tail_kind : (uint32_t)kHeadNone;
   x->tail_base = position > seg.end ? (uint32_t)tail_base : 0u;
   x->tail_p1 = position > seg.end ? e.head_p1 : 0u;
-  static const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
+  static const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr || getenv("BROTLI_MI355X_SELFTEST_RESOLVE") != nullptr;
   if (selftest) {
     SegExit y = *x;
     PredictLiteralRunStepwise(P, seg, e, &y);
