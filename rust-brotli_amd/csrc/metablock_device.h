@@ -742,25 +742,45 @@ BR_DEV uint64_t br_block_switch_bits(const BlockSplitCode& code, uint32_t typeco
 
 // BuildAndStoreBlockSplitCode, brotli_bit_stream.rs:1536-1591.  Also fills switch_bits/switch_nbits for
 // every block after the first (the command emitted in front of the first symbol of block i).
+// The type code of block i without the running calculator: the last type is that of block i - 1, the one before that of
+// block i - 2 (the calculator starts at 1 / 0) -- every block on its own (k_write_headers).
+BR_DEV uint32_t br_block_type_code_at(const uint8_t* types, uint32_t i) {
+  const uint32_t type = types[i];
+  const uint32_t last = i >= 1 ? types[i - 1] : 1u;
+  const uint32_t second_last = i >= 2 ? types[i - 2] : (i == 1 ? 1u : 0u);
+  return (type == last + 1) ? 1u : (type == second_last ? 0u : type + 2u);
+}
+// histograms_in (type histogram [258] followed by length histogram [26]): counted by the caller, who then also fills
+// switch_bits / switch_nbits of the blocks behind the first one from *code (the wave of k_write_headers, a block per lane;
+// the two walks over all blocks were most of what the one lane composing a header did)
 BR_DEV void br_build_and_store_block_split_code(const uint8_t* types, const uint32_t* lengths, uint32_t num_blocks,
                                                 uint32_t num_types, HuffmanScratch* sc, BlockSplitCode* code,
-                                                uint64_t* switch_bits, uint8_t* switch_nbits, BitSink& out) {
+                                                uint64_t* switch_bits, uint8_t* switch_nbits, BitSink& out,
+                                                const uint32_t* histograms_in = nullptr) {
   uint32_t type_histo[258];
   uint32_t length_histo[26];
-  for (int i = 0; i < 258; ++i) type_histo[i] = 0;
-  for (int i = 0; i < 26; ++i) length_histo[i] = 0;
   BlockTypeCodeCalculator calc;
-  calc.last_type = 1;
-  calc.second_last_type = 0;
-  for (uint32_t i = 0; i < num_blocks; ++i) {
-    const uint32_t type_code = br_next_block_type_code(calc, types[i]);
-    if (i != 0) type_histo[type_code]++;
-    length_histo[br_block_length_prefix_code(lengths[i])]++;
+  if (histograms_in == nullptr) {
+    for (int i = 0; i < 258; ++i) type_histo[i] = 0;
+    for (int i = 0; i < 26; ++i) length_histo[i] = 0;
+    calc.last_type = 1;
+    calc.second_last_type = 0;
+    for (uint32_t i = 0; i < num_blocks; ++i) {
+      const uint32_t type_code = br_next_block_type_code(calc, types[i]);
+      if (i != 0) type_histo[type_code]++;
+      length_histo[br_block_length_prefix_code(lengths[i])]++;
+    }
   }
   br_store_var_len_uint8(num_types - 1, out);
   if (num_types > 1) {
-    br_build_and_store_huffman_tree(type_histo, num_types + 2, num_types + 2, sc, code->type_depths, code->type_bits, out);
-    br_build_and_store_huffman_tree(length_histo, 26, 26, sc, code->length_depths, code->length_bits, out);
+    br_build_and_store_huffman_tree(histograms_in ? histograms_in : type_histo, num_types + 2, num_types + 2, sc, code->type_depths, code->type_bits, out);
+    br_build_and_store_huffman_tree(histograms_in ? histograms_in + 258 : length_histo, 26, 26, sc, code->length_depths, code->length_bits, out);
+    if (histograms_in != nullptr) {
+      uint32_t nb;
+      const uint64_t b = br_block_switch_bits(*code, 0, lengths[0], true, &nb);
+      out.put(nb, b);
+      return;
+    }
     calc.last_type = 1;
     calc.second_last_type = 0;
     for (uint32_t i = 0; i < num_blocks; ++i) {

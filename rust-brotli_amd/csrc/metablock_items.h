@@ -517,7 +517,12 @@ BR_DEV void mb_append_bits(BitSink& out, const uint64_t* words, uint32_t nbits) 
 
 // ---- K6: header of one meta-block (store_meta_block up to the entropy codes, brotli_bit_stream.rs:2074-2191)
 // staging != nullptr: the bits are composed there (zeroed by the caller, e.g. in LDS) instead of in B.header_words
-BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch* sc, uint64_t* staging = nullptr) {
+// what the wave of k_write_headers counts in front of the header's composition and takes over behind it
+struct MbSplitPrepared {
+  uint32_t histograms[3][258 + 26];  // per kind: block type codes, then block length codes
+  BlockSplitCode code[3];
+};
+BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch* sc, uint64_t* staging = nullptr, MbSplitPrepared* prepared = nullptr) {
   const MbDesc d = B.descs[m];
   MbResult& r = B.results[m];
   if (d.uncompressed) {
@@ -531,8 +536,9 @@ BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch*
   out.words = words;
   out.pos = 0;
   br_store_compressed_meta_block_header(d.is_last != 0, d.end - d.start, out);
-  BlockSplitCode code;
+  BlockSplitCode own_code;
   for (uint32_t kind = 0; kind < 3; ++kind) {
+    BlockSplitCode& code = prepared ? prepared->code[kind] : own_code;
     for (int i = 0; i < 258; ++i) {
       code.type_depths[i] = 0;
       code.type_bits[i] = 0;
@@ -543,7 +549,8 @@ BR_DEV void mb_item_write_header(const MbBuffers& B, uint32_t m, HuffmanScratch*
     }
     br_build_and_store_block_split_code(B.block_types[kind] + d.block_base[kind], B.block_lengths[kind] + d.block_base[kind],
                                         r.num_blocks[kind], r.num_types[kind], sc, &code,
-                                        B.switch_bits[kind] + d.block_base[kind], B.switch_nbits[kind] + d.block_base[kind], out);
+                                        B.switch_bits[kind] + d.block_base[kind], B.switch_nbits[kind] + d.block_base[kind], out,
+                                        prepared ? prepared->histograms[kind] : nullptr);
   }
   out.put(2, d.dist_postfix_bits);
   out.put(4, d.num_direct_distance_codes >> d.dist_postfix_bits);

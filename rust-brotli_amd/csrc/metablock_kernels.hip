@@ -200,6 +200,7 @@ __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
   constexpr uint64_t kOtherBits = 160u * 1024u;   // generous bound for everything but the trees (a 16 Ki-entry context map)
   __shared__ uint64_t lw[kLdsWords];
   __shared__ HuffmanScratch sc_lds;  // (the scratch of the small trees -- block-split codes, context map -- as well)
+  __shared__ MbSplitPrepared prep;
   __shared__ uint32_t s_bits;
   const uint32_t m = blockIdx.x;
   if (m >= B.n_mb) return;
@@ -218,12 +219,39 @@ __global__ __launch_bounds__(64) void k_write_headers(MbBuffers B) {
   uint64_t* stage = in_lds ? lw : global_words;
   const uint32_t clear_words = in_lds ? kLdsWords : B.header_stride;
   for (uint32_t i = threadIdx.x; i < clear_words; i += 64) stage[i] = 0;
+  // The block-split codes (BuildAndStoreBlockSplitCode) walk all blocks of a kind twice -- the histograms of the type and length
+  // codes, then the switch command of every block: a block per lane in front of and behind the one lane that composes the header
+  // (a meta-block of a mix has thousands of blocks: 4.8 ms of a 256 MiB Silesia-like call were this kernel).
+  for (uint32_t i = threadIdx.x; i < 3 * (258 + 26); i += 64) (&prep.histograms[0][0])[i] = 0;
+  __syncthreads();
+  for (uint32_t kind = 0; kind < 3; ++kind) {
+    const uint8_t* types = B.block_types[kind] + d.block_base[kind];
+    const uint32_t* lengths = B.block_lengths[kind] + d.block_base[kind];
+    const uint32_t nb = B.results[m].num_blocks[kind];
+    for (uint32_t i = threadIdx.x; i < nb; i += 64) {
+      if (i != 0) atomicAdd(&prep.histograms[kind][br_block_type_code_at(types, i)], 1u);
+      atomicAdd(&prep.histograms[kind][258 + br_block_length_prefix_code(lengths[i])], 1u);
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    mb_item_write_header(B, m, &sc_lds, stage);
+    mb_item_write_header(B, m, &sc_lds, stage, &prep);
     s_bits = B.results[m].header_bits;
   }
   __syncthreads();
+  for (uint32_t kind = 0; kind < 3; ++kind) {
+    if (B.results[m].num_types[kind] <= 1) continue;
+    const uint8_t* types = B.block_types[kind] + d.block_base[kind];
+    const uint32_t* lengths = B.block_lengths[kind] + d.block_base[kind];
+    uint64_t* switch_bits = B.switch_bits[kind] + d.block_base[kind];
+    uint8_t* switch_nbits = B.switch_nbits[kind] + d.block_base[kind];
+    const uint32_t nb = B.results[m].num_blocks[kind];
+    for (uint32_t i = 1 + threadIdx.x; i < nb; i += 64) {
+      uint32_t nbits;
+      switch_bits[i] = br_block_switch_bits(prep.code[kind], br_block_type_code_at(types, i), lengths[i], false, &nbits);
+      switch_nbits[i] = (uint8_t)nbits;
+    }
+  }
   if (in_lds) {
     const uint32_t words = (s_bits + 63) / 64 + 1;
     for (uint32_t i = threadIdx.x; i < words && i < kLdsWords; i += 64) global_words[i] = lw[i];

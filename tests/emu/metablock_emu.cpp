@@ -92,8 +92,40 @@ void mb_build_codes(const MbBuffers& B, const CodeJob* jobs, uint32_t n_jobs) {
   for (uint32_t i = 0; i < n_jobs; ++i) mb_item_build_code(B, jobs[i].kind, jobs[i].row_index, jobs[i].num_distance_symbols, B.huff_scratch, jobs[i].mode);
 }
 
+// the form of k_write_headers: block-split histograms and switch commands a block at a time around the header's composition
+// (BROTLI_EMU_PLAIN_HEADERS=1: the one-lane form, every block walked inside br_build_and_store_block_split_code)
 void mb_write_headers(const MbBuffers& B) {
-  for (uint32_t m = 0; m < B.n_mb; ++m) mb_item_write_header(B, m, B.huff_scratch);
+  static const bool plain = getenv("BROTLI_EMU_PLAIN_HEADERS") != nullptr;
+  for (uint32_t m = 0; m < B.n_mb; ++m) {
+    const MbDesc d = B.descs[m];
+    if (plain || d.uncompressed) {
+      mb_item_write_header(B, m, B.huff_scratch);
+      continue;
+    }
+    static thread_local MbSplitPrepared prep;
+    memset(&prep.histograms[0][0], 0, sizeof(prep.histograms));
+    for (uint32_t kind = 0; kind < 3; ++kind) {
+      const uint8_t* types = B.block_types[kind] + d.block_base[kind];
+      const uint32_t* lengths = B.block_lengths[kind] + d.block_base[kind];
+      const uint32_t nb = B.results[m].num_blocks[kind];
+      for (uint32_t i = 0; i < nb; ++i) {
+        if (i != 0) prep.histograms[kind][br_block_type_code_at(types, i)]++;
+        prep.histograms[kind][258 + br_block_length_prefix_code(lengths[i])]++;
+      }
+    }
+    mb_item_write_header(B, m, B.huff_scratch, nullptr, &prep);
+    for (uint32_t kind = 0; kind < 3; ++kind) {
+      if (B.results[m].num_types[kind] <= 1) continue;
+      const uint8_t* types = B.block_types[kind] + d.block_base[kind];
+      const uint32_t* lengths = B.block_lengths[kind] + d.block_base[kind];
+      const uint32_t nb = B.results[m].num_blocks[kind];
+      for (uint32_t i = 1; i < nb; ++i) {
+        uint32_t nbits;
+        B.switch_bits[kind][d.block_base[kind] + i] = br_block_switch_bits(prep.code[kind], br_block_type_code_at(types, i), lengths[i], false, &nbits);
+        B.switch_nbits[kind][d.block_base[kind] + i] = (uint8_t)nbits;
+      }
+    }
+  }
 }
 
 void mb_symbol_bits(const MbBuffers& B, void*) {
