@@ -16,27 +16,46 @@ def short(name):
     name = name.split("(")[0]
     if name.startswith("void "):
         name = name[5:]
-    if name.startswith("k_parse_segments<"):
-        name = "k_parse_segments"  # the two instantiations (H9 / the others) never run in the same call
-    return name
+    return name  # template instances keep their arguments: k_parse_segments<...,8,false> and <...,8,true> are two rows
+
+
+def family(name):
+    """base name of a template instance (what bench.py's roofline block covers: every launch of every instance)"""
+    return short(name).split("<")[0]
 
 
 def main():
     tag, out = sys.argv[1], sys.argv[2]
     res = {"tag": tag, "kernels": {}, "counters": {}}
+    res["families"] = {}
     for f in glob.glob(os.path.join(out, tag + "_kt", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            res["kernels"][short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
-                                                 "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3), "pct": float(r["Percentage"])}
+            one = {"calls": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
+                   "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3), "pct": float(r["Percentage"])}
+            k = short(r["Name"])
+            if k in res["kernels"]:  # (same short name from two namespaces: add up instead of overwriting)
+                old = res["kernels"][k]
+                one = {"calls": old["calls"] + one["calls"], "total_ms": round(old["total_ms"] + one["total_ms"], 3), "pct": old["pct"] + one["pct"]}
+                one["avg_ms"] = round(one["total_ms"] / one["calls"], 4)
+            res["kernels"][k] = one
+            fam = res["families"].setdefault(family(r["Name"]), {"calls": 0, "total_ms": 0.0, "pct": 0.0, "instances": 0})
+            fam["calls"] += int(r["Calls"])
+            fam["total_ms"] = round(fam["total_ms"] + float(r["TotalDurationNs"]) / 1e6, 3)
+            fam["pct"] = round(fam["pct"] + float(r["Percentage"]), 3)
+            fam["instances"] += 1
+    for fam in res["families"].values():
+        fam["avg_ms"] = round(fam["total_ms"] / max(1, fam["calls"]), 4)
     for d in sorted(glob.glob(os.path.join(out, tag + "_pmc_*"))):
         if not os.path.isdir(d):
             continue
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
             for r in csv.DictReader(open(f)):
-                a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
+                names = {short(r["Kernel_Name"]), family(r["Kernel_Name"])}  # per instance AND per family (all launches)
+                for nm in names:
+                    a = acc[nm][r["Counter_Name"]]
+                    a[0] += float(r["Counter_Value"])
+                    a[1] += 1
             for k, cs in acc.items():
                 for c, (s, n) in cs.items():
                     res["counters"].setdefault(k, {})[c] = {"avg_per_launch": s / n, "launches": n}
@@ -50,6 +69,24 @@ def main():
             # guide applies to wide coalesced reads only, so the raw figure is the lower bound and x2 the upper bound
             "hbm_bytes_per_launch": kib * 1024 + wr * 1024,
         }
+    # FETCH_SIZE + WRITE_SIZE of the WHOLE step: every launch of every kernel of the profiled command (5 steps + 1 warm-up = 6 calls)
+    calls = int(os.environ.get("PROFILE_CALLS", "6"))
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    per_kernel = {}
+    for k, cs in res["counters"].items():
+        if "<" not in k and any(kk.startswith(k + "<") for kk in res["counters"]):
+            continue  # (a family row repeats its template instances)
+        for c in tot:
+            if c in cs:
+                b = cs[c]["avg_per_launch"] * cs[c]["launches"] * 1024.0
+                tot[c] += b
+                per_kernel.setdefault(k, {})[c] = b / calls
+    if tot["FETCH_SIZE"] > 0:
+        res["step_traffic"] = {"what": "FETCH_SIZE + WRITE_SIZE (raw, KiB -> bytes) summed over every launch of every kernel, per call of the library",
+                               "calls": calls, "fetch_bytes_per_step": tot["FETCH_SIZE"] / calls, "write_bytes_per_step": tot["WRITE_SIZE"] / calls,
+                               "bytes_per_step": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / calls,
+                               "top_kernels_bytes_per_step": dict(sorted(((k, round(v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0))) for k, v in per_kernel.items()),
+                                                                         key=lambda kv: -kv[1])[:12])}
     print(json.dumps(res, indent=1))
     # the numbers bench.py quotes as `roofline.traffic` (per launch of the dominant kernel), as a file of their own
     if "FETCH_SIZE" in p:
