@@ -236,11 +236,17 @@ void CompressChunk(const EncoderParams& user_params, const uint8_t* input, size_
   EncodeStream(req, out, nullptr);
 }
 
-// Host threads that keep several chunks of one BrotliEncoderCompressMulti call in flight on the device.  A chunk's
-// LZ77 rounds leave the device idle while the host resolves them, and its late rounds run a handful of wavefronts:
-// two or three chunks side by side fill those gaps.  The helpers live as long as the process (their device memory
-// pools and streams are per thread and are reused from call to call); BROTLI_MI355X_SHARD_WORKERS sets how many
-// chunks run at once (default 8, 1 = one after the other on the calling thread).
+// Host threads that keep several chunks of one BrotliEncoderCompressMulti call in flight -- on every device of the node.
+// A chunk's LZ77 rounds leave its device idle while the host resolves them, and its late rounds run a handful of wavefronts:
+// two or three chunks side by side fill those gaps.  The reference's multi API fans the shards of ONE call over all its workers
+// (src/ffi/multicompress/mod.rs:93, threading/mod.rs:413-453); here the workers are host threads bound to HIP devices: shard t
+// goes to device slot t % (number of slots) -- by default one slot per visible device (hipGetDeviceCount), so a C / Rust / Go
+// caller of BrotliEncoderCompressMulti on an 8-GPU node uses all eight with no collective (host buffers in, D2H per device out;
+// SURVEY 8e).  BROTLI_MI355X_DEVICES: "current" = the calling thread's device only (one process per GPU under a launcher);
+// "0,1,2" = these devices; an entry may repeat ("0,0": two slots on one device -- the multi-device code path on a 1-GPU box).
+// The helpers live as long as the process, each bound to the device of its slot for good (their device memory pools, streams
+// and events are per thread, hence per device, and are reused from call to call); BROTLI_MI355X_SHARD_WORKERS sets how many
+// chunks run at once over all slots (default 8, at least one per slot; 1 with a single slot = one after the other on the calling thread).
 class ShardWorkers {
  public:
   static ShardWorkers& Get() {
@@ -249,48 +255,95 @@ class ShardWorkers {
     static ShardWorkers* w = new ShardWorkers;
     return *w;
   }
+  // the device slots of this process (see above); empty = "current": whatever device the calling thread is on
+  static const std::vector<int>& Slots() {
+    static const std::vector<int> slots = [] {
+      std::vector<int> v;
+      const char* e = getenv("BROTLI_MI355X_DEVICES");
+      const int visible = dev_device_count();
+      if (e && !strcmp(e, "current")) return v;
+      if (e && *e && strcmp(e, "all")) {
+        for (const char* p = e; *p;) {
+          char* end = nullptr;
+          const long d = strtol(p, &end, 10);
+          if (end == p) break;
+          if (d >= 0 && d < visible) v.push_back((int)d);
+          p = *end == ',' ? end + 1 : end;
+        }
+        return v;  // (nothing usable in the list: the calling thread's device)
+      }
+      if (visible > 1)
+        for (int d = 0; d < visible; ++d) v.push_back(d);
+      return v;
+    }();
+    return slots;
+  }
   // runs job(0) ... job(count - 1), each exactly once, on the calling thread and the helpers; rethrows the first exception
   // light: every job is one wavefront on a table of its own (qualities 2 .. 4, quick_device.h) -- all of them side by side
   void Run(size_t count, const std::function<void(size_t)>& job, bool light = false) {
     // (BROTLI_MI355X_SHARD_WORKERS, when set, bounds the light jobs as well: it is the caller's handle on device memory)
-    const size_t workers = std::min(count, light && WorkerCount() > 1 && !WorkerCountSetByUser() ? (size_t)16 : WorkerCount());
-    if (workers <= 1) {
+    const size_t limit = std::min(count, light && WorkerCount() > 1 && !WorkerCountSetByUser() ? (size_t)16 : WorkerCount());
+    const int here = dev_current_device();
+    std::vector<int> slots = Slots();
+    if (slots.empty()) slots.push_back(here);
+    const size_t nslots = std::min(slots.size(), count);
+    if (nslots == 1 && slots[0] == here && limit <= 1) {
       for (size_t i = 0; i < count; ++i) job(i);
       return;
     }
     std::lock_guard<std::mutex> one_call_at_a_time(run_mu_);
     Batch b;
-    b.count = count;
     b.job = &job;
-    b.device = dev_current_device();
+    b.q = std::vector<SlotQueue>(nslots);
+    for (size_t t = 0; t < count; ++t) b.q[t % nslots].jobs.push_back(t);
+    const size_t per_slot = std::max<size_t>(1, (limit + nslots - 1) / nslots);
+    // the calling thread works in the first slot that sits on its own device (its pool and stream belong to that device)
+    size_t my_slot = nslots;
+    for (size_t s = 0; s < nslots && my_slot == nslots; ++s)
+      if (slots[s] == here) my_slot = s;
     {
       std::lock_guard<std::mutex> lock(mu_);
-      while (num_threads_ + 1 < workers) {
-        std::thread([this] { Loop(); }).detach();
-        ++num_threads_;
+      if (threads_of_slot_.size() < slots.size()) threads_of_slot_.resize(slots.size(), 0);
+      for (size_t s = 0; s < nslots; ++s) {
+        const size_t want = std::min(per_slot, b.q[s].jobs.size()) - (s == my_slot ? 1 : 0);
+        while (threads_of_slot_[s] < want) {
+          const int device = slots[s];
+          std::thread([this, s, device] { Loop(s, device); }).detach();
+          ++threads_of_slot_[s];
+        }
+        b.q[s].helpers_wanted = want;
       }
       batch_ = &b;
-      b.helpers_wanted = workers - 1;
       ++generation_;
     }
     cv_.notify_all();
-    Work(&b);
+    if (my_slot < nslots) Work(&b, my_slot);
     {
       std::unique_lock<std::mutex> lock(mu_);
-      done_cv_.wait(lock, [&] { return b.helpers_in == 0 && b.helpers_wanted == 0; });
+      done_cv_.wait(lock, [&] {
+        if (b.helpers_in != 0) return false;
+        for (auto& q : b.q)
+          if (q.helpers_wanted != 0) return false;
+        return true;
+      });
       batch_ = nullptr;
     }
     if (b.error) std::rethrow_exception(b.error);
   }
 
  private:
-  struct Batch {
-    size_t count = 0;
-    const std::function<void(size_t)>* job = nullptr;
-    int device = 0;
+  struct SlotQueue {
+    std::vector<size_t> jobs;      // the shards dealt to this slot, in order
     std::atomic<size_t> next{0};
-    size_t helpers_wanted = 0, helpers_in = 0;  // (under mu_)
-    std::exception_ptr error;                   // (under mu_)
+    size_t helpers_wanted = 0;     // (under mu_)
+    SlotQueue() = default;
+    SlotQueue(const SlotQueue& o) : jobs(o.jobs), next(o.next.load()), helpers_wanted(o.helpers_wanted) {}
+  };
+  struct Batch {
+    const std::function<void(size_t)>* job = nullptr;
+    std::vector<SlotQueue> q;
+    size_t helpers_in = 0;       // (under mu_)
+    std::exception_ptr error;    // (under mu_)
   };
   static bool WorkerCountSetByUser() {
     static const bool set = getenv("BROTLI_MI355X_SHARD_WORKERS") != nullptr;
@@ -304,34 +357,39 @@ class ShardWorkers {
     }();
     return n;
   }
-  void Work(Batch* b) {
+  void Work(Batch* b, size_t slot) {
+    SlotQueue& q = b->q[slot];
     for (;;) {
-      const size_t i = b->next.fetch_add(1);
-      if (i >= b->count) return;
+      const size_t i = q.next.fetch_add(1);
+      if (i >= q.jobs.size()) return;
       try {
-        (*b->job)(i);
+        (*b->job)(q.jobs[i]);
       } catch (...) {
         std::lock_guard<std::mutex> lock(mu_);
         if (!b->error) b->error = std::current_exception();
-        b->next.store(b->count);  // nobody starts another chunk
+        for (auto& other : b->q) other.next.store(other.jobs.size());  // nobody starts another chunk
       }
     }
   }
-  void Loop() {
+  void Loop(size_t slot, int device) {
     uint64_t seen = 0;
+    bool bound = false;
     for (;;) {
       Batch* b = nullptr;
       {
         std::unique_lock<std::mutex> lock(mu_);
-        cv_.wait(lock, [&] { return generation_ != seen && batch_ != nullptr && batch_->helpers_wanted > 0; });
-        seen = generation_;
+        cv_.wait(lock, [&] { return generation_ != seen && batch_ != nullptr && slot < batch_->q.size() && batch_->q[slot].helpers_wanted > 0; });
         b = batch_;
-        b->helpers_wanted--;
+        b->q[slot].helpers_wanted--;
+        seen = generation_;  // (a helper that has taken its place in this batch does not take a second one)
         b->helpers_in++;
       }
       try {
-        dev_use_device(b->device);
-        Work(b);
+        if (!bound) {
+          dev_use_device(device);  // for good: this thread's pool, stream and events live on this device
+          bound = true;
+        }
+        Work(b, slot);
       } catch (...) {
         std::lock_guard<std::mutex> lock(mu_);
         if (!b->error) b->error = std::current_exception();
@@ -345,7 +403,7 @@ class ShardWorkers {
   }
   std::mutex mu_, run_mu_;
   std::condition_variable cv_, done_cv_;
-  size_t num_threads_ = 0;
+  std::vector<size_t> threads_of_slot_;
   Batch* batch_ = nullptr;
   uint64_t generation_ = 0;
 };

@@ -48,6 +48,7 @@ void dev_make_room(unsigned min_free_share);  // trims every thread's pool if le
 size_t dev_trim_pool();  // returns the pooled, currently unused device memory of the calling thread to the driver; bytes freed
 int dev_current_device();        // the calling thread's device (helper threads adopt their caller's)
 void dev_use_device(int device);
+int dev_device_count();          // visible HIP devices
 const char* dev_name();  // "hip:gfx950 ..." or "host-emulation"
 
 // Static read-only tables resident on the device (dictionary, dictionary hash, log tables ...).

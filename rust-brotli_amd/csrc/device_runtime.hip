@@ -38,6 +38,7 @@ struct Pool {
   std::unordered_map<void*, uint64_t> pooled_seq;  // pooled blocks: when they came back (the oldest go first when the pool is over its cap)
   uint64_t seq = 0;
   size_t pooled_bytes = 0;
+  int device = -1;  // the device the owning thread allocates on (a host thread of the library stays on one device)
   // (a 1 GiB piece alone needs ~95 GiB of the 288; with 192 GiB kept by the calling thread, the eight helper threads of a
   // multi-shard call that followed found 7 GB free and trimmed in the middle of the call)
   static constexpr size_t kMaxPooled = (size_t)128 << 30;
@@ -83,7 +84,9 @@ Pool::Pool() {
 // to the driver from a live thread.  (Never destroyed, like the list of pools: threads may outlive static destruction.)
 struct Orphans {
   std::mutex mu;
-  std::multimap<size_t, void*> device_blocks, host_blocks;  // capacity -> block
+  std::map<int, std::multimap<size_t, void*>> device_blocks;  // device -> (capacity -> block): a block is only adopted on its own device
+  std::multimap<size_t, void*> host_blocks;                  // capacity -> block
+  size_t device_bytes = 0;                                    // what device_blocks holds
 };
 Orphans& orphans() {
   static Orphans* o = new Orphans;
@@ -97,21 +100,31 @@ Pool::~Pool() {
   }
   Orphans& o = orphans();
   std::lock_guard<std::mutex> lock(o.mu);
-  for (auto& kv : free_blocks) o.device_blocks.emplace(kv.first, kv.second);
+  for (auto& kv : free_blocks) {
+    o.device_blocks[device].emplace(kv.first, kv.second);
+    o.device_bytes += kv.first;
+  }
 }
+// (called from a live thread: device blocks AND the page-locked host blocks that ended threads left behind go back to the driver;
+// hipFree / hipHostFree wait for the device, so nothing queued by the dead thread can still be using them)
 static size_t TrimOrphans() {
-  std::vector<void*> drop;
+  std::vector<void*> drop, drop_host;
   size_t bytes = 0;
   {
     Orphans& o = orphans();
     std::lock_guard<std::mutex> lock(o.mu);
-    for (auto& kv : o.device_blocks) {
-      drop.push_back(kv.second);
-      bytes += kv.first;
-    }
+    for (auto& dv : o.device_blocks)
+      for (auto& kv : dv.second) {
+        drop.push_back(kv.second);
+        bytes += kv.first;
+      }
     o.device_blocks.clear();
+    o.device_bytes = 0;
+    for (auto& kv : o.host_blocks) drop_host.push_back(kv.second);
+    o.host_blocks.clear();
   }
   for (void* d : drop) (void)hipFree(d);
+  for (void* h : drop_host) (void)hipHostFree(h);
   return bytes;
 }
 size_t TrimAllPools() {
@@ -182,21 +195,44 @@ static void* AllocBlock(size_t bytes) {
       P.free_blocks.erase(it);
     }
   }
+  if (P.device < 0) HIP_CHECK(hipGetDevice(&P.device));
+  bool adopted = false;
   if (!p) {
-    // a block that a finished thread left behind?
+    // a block that a finished thread left behind on this device?
     Orphans& o = orphans();
     std::lock_guard<std::mutex> lock(o.mu);
-    auto it = o.device_blocks.lower_bound(cap);
-    if (it != o.device_blocks.end() && it->first <= cap + cap / 4) {
-      p = it->second;
-      const size_t got = it->first;
-      o.device_blocks.erase(it);
-      std::lock_guard<std::mutex> mine(P.mu);
-      P.capacity[p] = got;
+    auto dv = o.device_blocks.find(P.device);
+    if (dv != o.device_blocks.end()) {
+      auto it = dv->second.lower_bound(cap);
+      if (it != dv->second.end() && it->first <= cap + cap / 4) {
+        p = it->second;
+        const size_t got = it->first;
+        dv->second.erase(it);
+        o.device_bytes -= got;
+        std::lock_guard<std::mutex> mine(P.mu);
+        P.capacity[p] = got;
+        adopted = true;
+      }
     }
+  }
+  if (adopted) {
+    // the block was last used on the DEAD thread's stream, and the rule of the pool -- a block is only reused by work queued behind
+    // its previous use -- does not hold across streams: wait once for the device (adoptions are rare: a thread ended with idle blocks)
+    HIP_CHECK(hipDeviceSynchronize());
   }
   if (!p) {
     DriverCallClock clock(0);
+    // what ended threads left behind does not count against any pool's cap: before asking the driver for more, a live thread hands
+    // back orphaned blocks beyond 32 GiB (nothing of the right size was among them, or it would have been adopted above)
+    {
+      bool trim;
+      {
+        Orphans& o = orphans();
+        std::lock_guard<std::mutex> lock(o.mu);
+        trim = o.device_bytes > ((size_t)32 << 30);
+      }
+      if (trim) TrimOrphans();
+    }
     // Leave the runtime room of its own: kernel scratch, the queues of helper threads, signals.  With every last byte in
     // the pools, a later launch died inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES, "Available Free mem : 0 MB")
     // where nothing can be caught.  Idle pooled blocks go back first -- this thread's, then every thread's.
@@ -539,6 +575,14 @@ int dev_current_device() {
   return d;
 }
 void dev_use_device(int device) { HIP_CHECK(hipSetDevice(device)); }
+int dev_device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
 
 const char* dev_name() {
   static std::string name;

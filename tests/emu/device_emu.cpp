@@ -56,6 +56,7 @@ void dev_h2d_bulk(void* dst, const void* src, size_t bytes) { dev_h2d(dst, src, 
 void dev_d2h_bulk(void* dst, const void* src, size_t bytes) { dev_d2h(dst, src, bytes); }
 int dev_current_device() { return 0; }
 void dev_use_device(int) {}
+int dev_device_count() { return 1; }
 void* dev_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
 void dev_host_free(void* p) { free(p); }
 void dev_pool_counters(double* out, bool) {
