@@ -32,6 +32,7 @@
 #define BR_LANE 0
 #define BR_NLANES 1
 #define BR_SYNC() ((void)0)
+#define BR_WAVE_SYNC() ((void)0)
 #define BR_ATOMIC_INC(ptr) ((*(ptr))++)
 #define BR_UNIFORM(x) (x)
 #define BR_READLANE(x, lane) (x)
@@ -43,6 +44,10 @@
 #define BR_LANE ((int)threadIdx.x)
 #define BR_NLANES 64
 #define BR_SYNC() __syncthreads()
+// Every chain kernel runs ONE wavefront per workgroup (__launch_bounds__(64)): the LDS operations of a wavefront are executed in
+// program order, so between the chain's own LDS writes and reads nothing has to be waited for -- only the compiler must not move
+// them across each other.  (__syncthreads() drains vmcnt as well: the flag stores of the parse loop.)
+#define BR_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define BR_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
 // The control flow of a chain is wave-uniform by construction, but values that come back from vector loads or
 // cross-lane operations live in VGPRs and would make the compiler predicate every branch with exec masks.
@@ -146,6 +151,7 @@ struct ChainScratchT {  // one per wavefront (LDS on the device)
   //  kRows: candidate rows of positions [win_base, win_base + kRowWindow)
   alignas(16) uint32_t win[kRows ? kRowWindow * kRowEntries : kInfoWindow * 2];
   uint16_t dictwin[kRows ? kRowWindow * 2 : 2];  // kRows: the two static-dictionary hash items of every window position
+  uint32_t dictsrc[kRows ? kRowWindow * 2 : 1];  // kRows: where the word of each item starts in the dictionary (offset into dict_data)
   int32_t dc[16];                // distance cache incl. the derived entries (mod.rs:632-651); lanes index it by candidate
   uint32_t cand_prev[2][kMaxCandidates + 2];  // [probe slot][candidate]; the two dictionary probes come last
   uint32_t cand_len[2][kMaxCandidates + 2];
@@ -470,6 +476,20 @@ BR_DEV uint32_t br_match_len_wide(const uint8_t* a, const uint8_t* b, uint32_t l
 // row, c = ndist + 16 / + 17 the two static-dictionary probes.  One memory round trip per probe: the rows and the
 // dictionary hash items of the next kRowWindow positions sit in LDS (refilled with one coalesced load per window).
 static constexpr uint32_t kRowDictLane = 16;  // offset of the dictionary lanes behind the cache lanes
+// Common prefix of the 16 bytes at a and at b, 0..16, without a branch: the position of the lowest differing bit over the four
+// dword differences (v_ffbl gives 0xffffffff for "equal", which survives the OR with the dword's bit offset and loses every minimum).
+// The compiler turned the cascade "first differing qword" of br_match_len_wide into four nested exec-mask regions per probe
+// (round 6: the parse kernel is bound by instruction issue, SALU first), and most candidates differ within a few bytes.
+BR_DEV uint32_t br_common16(const uint8_t* a, const uint8_t* b) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+  const u32x4 a0 = *(const u32x4*)a;
+  const u32x4 b0 = *(const u32x4*)b;
+  auto low = [](uint32_t x, uint32_t bit0) -> uint32_t { return ((uint32_t)__ffs((int)x) - 1u) | bit0; };  // v_ffbl_b32, v_or_b32
+  const uint32_t t0 = low(a0.x ^ b0.x, 0), t1 = low(a0.y ^ b0.y, 32), t2 = low(a0.z ^ b0.z, 64), t3 = low(a0.w ^ b0.w, 96);
+  const uint32_t bits = min(min(min(t0, t1), t2), t3);  // (v_min3_u32, v_min_u32)
+  return min(bits >> 3, 16u);
+}
+
 template <bool kH9>
 BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, true>& s, ProbeMeta& m, uint32_t p0,
                                const int32_t* cache, uint32_t cache_version, uint32_t pos_end) {
@@ -479,7 +499,7 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
   const unsigned long long tp0 = BR_TICK();
 #endif
   if (p0 < m.win_base || p0 + 1 >= m.win_base + kRowWindow) {
-    BR_SYNC();
+    BR_WAVE_SYNC();
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // dictionary hash items of the window positions (SearchInStaticDictionary, mod.rs:1942-1988): lane = 2 * position + probe
     // (first4 holds the items themselves where the per-position array exists: one memory round trip instead of two)
@@ -501,14 +521,20 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
     }
     if (use_dict) {
 #pragma unroll
-      for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j)
-        s.dictwin[j * 64 + BR_LANE] = items_ready ? (uint16_t)(first4[j] >> (16u * (BR_LANE & 1)))
-                                                  : t.dict_hash[(((first4[j] * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
+      for (uint32_t j = 0; j < kRowWindow * 2 / 64; ++j) {
+        const uint32_t item = items_ready ? ((first4[j] >> (16u * (BR_LANE & 1))) & 0xffffu)
+                                          : (uint32_t)t.dict_hash[(((first4[j] * 0x1e35a7bdu) >> (32 - 14)) << 1) + (BR_LANE & 1)];
+        s.dictwin[j * 64 + BR_LANE] = (uint16_t)item;
+        // where the word starts: kBrotliDictionaryOffsetsByLength[len] + len * index (one dependent LDS read per window
+        // instead of one in front of every probe's candidate fetch)
+        const uint32_t wlen = item & 0x1f;
+        s.dictsrc[j * 64 + BR_LANE] = s.dict_off[wlen] + wlen * (item >> 5);
+      }
     }
 #pragma unroll
     for (uint32_t j = 0; j < kRowWindow * (kRowEntries / 4) / 64; ++j) ((u32x4*)s.win)[j * 64 + BR_LANE] = v[j];
     m.win_base = p0;
-    BR_SYNC();
+    BR_WAVE_SYNC();
 #if defined(BR_CHAIN_PROFILE)
     m.t_refill += BR_TICK() - tp0;
     m.n_refill++;
@@ -521,33 +547,39 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
   const uint32_t cur = p0 + w;
   const uint32_t max_length = pos_end - cur;
   const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
-  const uint8_t* cur_data = t.text + cur;
+  const uint32_t rel = cur - m.win_base;
+  const uint32_t ci = c - ndist;  // ring entry number (wraps around for the cache lanes)
   const bool is_cache = c < ndist;
-  const bool is_ring = !is_cache && c < ndist + kRowEntries;
-  const bool is_dict = use_dict && c >= ndist + kRowDictLane && c < ndist + kRowDictLane + 2;
-  uint32_t prev = 0xffffffffu, limit = max_length;
-  const uint8_t* src = nullptr;
-  if (is_cache) {
-    const int64_t b = (int64_t)cache[c];
-    if (b > 0 && b <= (int64_t)max_backward) prev = cur - (uint32_t)b;
-  } else if (is_ring) {
-    prev = s.win[(cur - m.win_base) * kRowEntries + (c - ndist)];  // kRowEnd == "no candidate"
-  } else if (is_dict) {
-    const uint32_t item = s.dictwin[(cur - m.win_base) * 2 + (c - ndist - kRowDictLane)];
-    prev = item;
-    if (item != 0) {
-      const uint32_t wlen = item & 0x1f;
-      if (wlen <= max_length) {
-        src = t.dict_data + s.dict_off[wlen] + wlen * (item >> 5);
-        limit = wlen;
-      }
-    }
-  }
-  if (!is_dict && prev != 0xffffffffu) src = t.text + prev;
+  const bool is_ring = ci < kRowEntries;
+  const bool is_dict = use_dict && (ci - kRowDictLane) < 2u;
+  // Straight-line code: every lane reads all three kinds of source (LDS, in bounds whatever the lane) and selects; the lanes
+  // behind the dictionary lanes and those without a candidate compare the text at `cur` with itself and drop the result.
+  const int32_t cb = cache[c & 15u];
+  const uint32_t ring_e = s.win[rel * kRowEntries + (ci & (kRowEntries - 1u))];
+  const uint32_t di = rel * 2u + (ci & 1u);
+  const uint32_t item = s.dictwin[di];
+  const uint32_t doff = s.dictsrc[di];
+  const uint32_t cache_prev = (cb > 0 && (uint32_t)cb <= max_backward) ? cur - (uint32_t)cb : 0xffffffffu;
+  const uint32_t wlen = item & 0x1fu;
+  const bool dict_word = is_dict && item != 0 && wlen <= max_length;
+  const uint32_t prev = is_cache ? cache_prev : (is_ring ? ring_e : (is_dict ? item : 0xffffffffu));  // kRowEnd == "no candidate"
+  const bool valid = dict_word || (!is_dict && prev != 0xffffffffu);
+  const uint32_t limit = dict_word ? wlen : max_length;
+  const uint8_t* base = dict_word ? t.dict_data : t.text;
+  const uint8_t* src = base + (dict_word ? doff : (valid ? prev : cur));
+  const uint8_t* cur_data = t.text + cur;
 #if defined(BR_CHAIN_PROFILE)
   m.t_setup += BR_TICK() - tp0;
 #endif
-  m.r_len = src ? br_match_len_wide(src, cur_data, limit, is_dict ? nullptr : t.run_end, prev, cur) : 0u;
+  uint32_t n = br_common16(src, cur_data);
+  if (valid && n >= 16u && limit > 16u) {
+    // the minority of candidates that agree in 16 bytes: the next 16, and behind those (rare: runs, long repeats) the 32-byte
+    // strides and the run table of br_match_len_wide
+    const uint32_t n2 = br_common16(src + 16, cur_data + 16);
+    n = 16u + n2;
+    if (n2 >= 16u && limit > 32u) n = br_match_len_wide(src, cur_data, limit, dict_word ? nullptr : t.run_end, prev, cur);
+  }
+  m.r_len = valid ? (n < limit ? n : limit) : 0u;
   m.r_prev = prev;
 }
 #endif
@@ -1042,21 +1074,34 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   bool folded = false;
   if constexpr (kRows) {
     // The candidates of this position are in the registers of its half of the wave (br_probe_pair_rows); entries behind
-    // the end of the row hold kRowEnd and never take part.
+    // the end of the row hold kRowEnd and never take part.  Straight-line scoring (selects, no exec-mask regions).
     const uint32_t c = (uint32_t)BR_LANE & 31u;
     const bool in_range = ((uint32_t)BR_LANE >> 5) == w && c < ndist + kRowEntries;
     const bool is_cache = c < ndist;
     const uint32_t prev = in_range ? m.r_prev : 0xffffffffu;
     const uint32_t unbroken = in_range ? m.r_len : 0u;
     const bool has = prev != 0xffffffffu;
-    const bool special_lane = has && (((prev & P.ring_mask) + unbroken > P.ring_mask) || unbroken == max_length ||
-                                      ((prev & P.ring_mask) < brk && (prev & P.ring_mask) + unbroken > brk));
+    const uint32_t prev_ring = prev & P.ring_mask;
+    const bool special_lane = has && ((prev_ring + unbroken > P.ring_mask) || unbroken == max_length || (prev_ring < brk && prev_ring + unbroken > brk));
     const bool cur_near_wrap = (cur & P.ring_mask) + max_length > P.ring_mask;
     if (!cur_near_wrap && __ballot(special_lane) == 0) {
       folded = true;
       const uint32_t backward = cur - prev;
-      const uint32_t score = is_cache ? br_score_cache<kH9>(P, unbroken, c & 15u) : br_score_ring<kH9>(P, unbroken, has ? backward : 1u);
-      const bool type_ok = is_cache ? (unbroken >= 3 || (unbroken == 2 && c < 2)) : unbroken >= 4;
+      uint32_t score;
+      bool type_ok;
+      if constexpr (kH9) {
+        score = is_cache ? br_score_cache<kH9>(P, unbroken, c & 15u) : br_score_ring<kH9>(P, unbroken, has ? backward : 1u);
+        type_ok = is_cache ? (unbroken >= 3 || (unbroken == 2 && c < 2)) : unbroken >= 4;
+      } else {
+        // BackwardReferenceScoreUsingLastDistance - BackwardReferencePenaltyUsingLastDistance / BackwardReferenceScore
+        // (mod.rs:1871-1889, 1151-1154) as one expression: score_per_byte * len + a per-candidate constant
+        const uint32_t penalty = c == 0 ? 0u : 39u + ((0x1ca10u >> (c & 0xeu)) & 0xeu);
+        const uint32_t lg = br_log2_floor_nonzero(has ? backward : 1u);
+        const uint32_t bias = is_cache ? (30u * 8u * 8u + 15u) - penalty : 30u * 8u * 8u - 30u * lg;
+        score = P.score_per_byte * unbroken + bias;
+        const uint32_t min_len = is_cache ? (c < 2u ? 2u : 3u) : 4u;
+        type_ok = unbroken >= min_len;
+      }
       unsigned long long live = __ballot(has && type_ok);
       uint32_t best_lane = 64;
       while (live != 0) {
@@ -1077,12 +1122,12 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
     } else {
       // rare (a candidate next to a ring-buffer wrap, the block end or the end of a custom dictionary): hand the
       // candidates to the general fold below through LDS
-      BR_SYNC();
+      BR_WAVE_SYNC();
       if (in_range) {
         s.cand_prev[w][c] = m.r_prev;
         s.cand_len[w][c] = m.r_len;
       }
-      BR_SYNC();
+      BR_WAVE_SYNC();
     }
   } else if (ncand <= 64) {
     // Fast path (all candidates in one pass of the wave, nothing near a ring-buffer wrap, the block end or the
@@ -1361,8 +1406,8 @@ BR_DEV SearchResult br_search(const Lz77Params& P, const ChainTables& t, ChainSc
 #endif
   uint32_t w = 1;
   if (!(m.pos != 0xffffffffu && m.version == cache_version && x == m.pos + 1)) {
-    if constexpr (!(kLive && kRows)) BR_SYNC();  // every lane is done reading the previous probe (live chains with register
-                                                 // probes: nothing shared is read, and what was filed is ordered by address)
+    if constexpr (!kRows) BR_SYNC();  // every lane is done reading the previous probe (register probes of the candidate-row and
+                                      // live chains: nothing shared is read; a wavefront's LDS operations run in program order)
     br_probe_pair<kH9, kRows, kLive>(P, t, s, m, x, cache, cache_version, blk_end, live);
     w = 0;
 #if defined(BR_CHAIN_PROFILE)
