@@ -480,15 +480,14 @@ static constexpr uint32_t kRowDictLane = 16;  // offset of the dictionary lanes 
 // dword differences (v_ffbl gives 0xffffffff for "equal", which survives the OR with the dword's bit offset and loses every minimum).
 // The compiler turned the cascade "first differing qword" of br_match_len_wide into four nested exec-mask regions per probe
 // (round 6: the parse kernel is bound by instruction issue, SALU first), and most candidates differ within a few bytes.
-BR_DEV uint32_t br_common16(const uint8_t* a, const uint8_t* b) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
-  const u32x4 a0 = *(const u32x4*)a;
-  const u32x4 b0 = *(const u32x4*)b;
+typedef uint32_t br_u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+BR_DEV uint32_t br_common16v(const br_u32x4 a0, const br_u32x4 b0) {
   auto low = [](uint32_t x, uint32_t bit0) -> uint32_t { return ((uint32_t)__ffs((int)x) - 1u) | bit0; };  // v_ffbl_b32, v_or_b32
   const uint32_t t0 = low(a0.x ^ b0.x, 0), t1 = low(a0.y ^ b0.y, 32), t2 = low(a0.z ^ b0.z, 64), t3 = low(a0.w ^ b0.w, 96);
   const uint32_t bits = min(min(min(t0, t1), t2), t3);  // (v_min3_u32, v_min_u32)
   return min(bits >> 3, 16u);
 }
+BR_DEV uint32_t br_common16(const uint8_t* a, const uint8_t* b) { return br_common16v(*(const br_u32x4*)a, *(const br_u32x4*)b); }
 
 template <bool kH9>
 BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainScratchT<kH9, true>& s, ProbeMeta& m, uint32_t p0,

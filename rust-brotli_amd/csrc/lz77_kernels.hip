@@ -19,6 +19,7 @@
 #include "device_api.h"
 #include "lz77_chain.h"
 #include "lz77_rows.h"
+#include "lz77_groups.h"
 #include "device_scan.h"
 #include "lz77_parse_args.h"
 #include "zopfli_device.h"
@@ -1530,6 +1531,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kDeep ? 4 : 
   }
 }
 
+// Four chains per wavefront (lz77_groups.h): round 0 and the warm-up of the plain quality-5 configuration, where a launch holds
+// every segment of a large input.  The parse state of a chain lives in the vector registers of its 16 lanes: four wavefronts per
+// SIMD is what the register file holds (128 registers each).
+#if !defined(BR_GROUP_WAVES)
+#define BR_GROUP_WAVES 3
+#endif
+template <uint32_t kHtl>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BR_GROUP_WAVES, BR_GROUP_WAVES))) void k_parse_groups(ParseArgs a) {
+  __shared__ uint32_t dict_off[32];
+  if (threadIdx.x < 32) dict_off[threadIdx.x] = threadIdx.x < 25 ? a.T.dict_offsets_by_length[threadIdx.x] : 0u;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t item = blockIdx.x;
+  if (a.per_xcd) item = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+  const uint32_t i = item * 4u + (threadIdx.x >> 4);
+  const bool have = i < a.count;
+  const uint32_t k = a.first_segment + (have ? i : 0u);
+  Lz77Params P = a.P;
+  P.ndist = 4;
+  P.block_bits = 4;
+  P.spree_window = 64;
+  P.score_per_byte = 135;
+  P.dict_break = 0;
+  P.reset_pos = 0;
+  P.masked_from = kNeverMasked;
+  P.htl = kHtl;
+  uint32_t walked, searches, commands;
+  br_group_parse<kHtl>(P, a.T, a.segments[k], a.entries[k], a.exits[k], have, dict_off, &walked, &searches, &commands);
+  if (a.T.work && have && (threadIdx.x & 15u) == 0) {
+    atomicAdd(a.T.work + 0, (unsigned long long)walked);
+    atomicAdd(a.T.work + 1, (unsigned long long)searches);
+    atomicAdd(a.T.work + 2, (unsigned long long)commands);
+  }
+}
+
 static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in, int flags_out, int rbuf, const Segment* segments,
                          SegEntry* entries, SegExit* exits, uint32_t first_segment, const uint32_t* list, uint8_t* sched,
                          uint32_t count) {
@@ -1584,7 +1619,21 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
   a.per_xcd = (xcd_aware && count >= 64) ? (count + 7) / 8 : 0;
   const uint32_t grid = a.per_xcd ? a.per_xcd * 8 : count;
   static const uint32_t lds_pad = getenv("BROTLI_MI355X_LDS_PAD") ? (uint32_t)atoi(getenv("BROTLI_MI355X_LDS_PAD")) : 0u;  // occupancy experiments
-  if (P.hasher_kind == 9) {
+  // four chains per wavefront where a launch holds every segment of a large input (round 0, the warm-up): lz77_groups.h
+  // (measured in round 6, profiles/r06_group_kernel_experiment.json: 1.7 x fewer instructions per search than the wave-per-chain kernel
+  // and byte-identical, but 139 vector registers = three wavefronts per SIMD, which do not hide the candidate-text round trip of a
+  // step: round 0 + warm-up 10.3 ms against 5.2.  Off unless asked for: BROTLI_MI355X_GROUPS_MIN=<chains>.)
+  static const uint32_t groups_min = getenv("BROTLI_MI355X_GROUPS_MIN") ? (uint32_t)atoi(getenv("BROTLI_MI355X_GROUPS_MIN")) : 0xffffffffu;
+  const bool groups = B.rows && list == nullptr && sched == nullptr && count >= groups_min && plain_q5_config(P) && getenv("BROTLI_MI355X_NO_SPEC") == nullptr;
+  if (groups) {
+    const bool own = segments == B.segments;
+    a.T.checkpoints = own ? (Checkpoint*)B.checkpoints : nullptr;
+    const uint32_t waves = (count + 3u) / 4u;
+    a.per_xcd = (xcd_aware && waves >= 64) ? (waves + 7) / 8 : 0;
+    const uint32_t ggrid = a.per_xcd ? a.per_xcd * 8 : waves;
+    if (P.htl == 8) hipLaunchKernelGGL((k_parse_groups<8>), dim3(ggrid), dim3(64), 0, BR_STREAM, a);
+    else hipLaunchKernelGGL((k_parse_groups<4>), dim3(ggrid), dim3(64), 0, BR_STREAM, a);
+  } else if (P.hasher_kind == 9) {
     hipLaunchKernelGGL((k_parse_segments<true, false>), dim3(grid), dim3(64), lds_pad, BR_STREAM, a);
   } else if (B.rows) {
     static const bool spec_off = getenv("BROTLI_MI355X_NO_SPEC") != nullptr;

@@ -15,6 +15,7 @@
 #include "../../rust-brotli_amd/csrc/device_api.h"
 #include "../../rust-brotli_amd/csrc/lz77_chain.h"
 #include "../../rust-brotli_amd/csrc/lz77_rows.h"
+#include "../../rust-brotli_amd/csrc/lz77_groups.h"
 #include "../../rust-brotli_amd/csrc/zopfli_device.h"
 #include "../../rust-brotli_amd/csrc/quick_device.h"
 #include "../../rust-brotli_amd/csrc/fragment_device.h"
@@ -444,6 +445,21 @@ static void run_parse(const Lz77Params& P, const Lz77Buffers& B, int which, int 
   T.splice_off = splice_part_off;
   static const bool splice_off = getenv("BROTLI_MI355X_NO_SPLICE") != nullptr;
   const bool splice = !splice_off && sched != nullptr && own_segments && B.rows != nullptr && B.checkpoints != nullptr && B.splice_lists != 0;
+  // four chains per wavefront (lz77_groups.h), an opt-in experiment on the device (BROTLI_MI355X_GROUPS_MIN=<chains>): here the same
+  // switch runs its state machine with one lane per group and the sequential search (tests/test_emu_parity.py sets it to 0)
+  static const uint32_t groups_min = getenv("BROTLI_MI355X_GROUPS_MIN") ? (uint32_t)atoi(getenv("BROTLI_MI355X_GROUPS_MIN")) : 0xffffffffu;
+  const bool groups = B.rows && list == nullptr && sched == nullptr && count >= groups_min && P.hasher_kind != 9 && P.ndist == 4 && P.block_bits == 4 &&
+                      P.spree_window == 64 && P.score_per_byte == 135 && P.dict_break == 0 && P.reset_pos == 0 && P.masked_from == kNeverMasked &&
+                      (P.htl == 4 || P.htl == 8) && getenv("BROTLI_MI355X_NO_SPEC") == nullptr;
+  if (groups) {
+    for (uint32_t i = 0; i < count; ++i) {
+      const uint32_t k = first_segment + i;
+      uint32_t w, sr, cm;
+      if (P.htl == 8) br_group_parse<8>(P, T, segments[k], entries[k], exits[k], true, nullptr, &w, &sr, &cm);
+      else br_group_parse<4>(P, T, segments[k], entries[k], exits[k], true, nullptr, &w, &sr, &cm);
+    }
+    return;
+  }
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : first_segment + i;
     if (P.hasher_kind == 9) {

@@ -239,3 +239,18 @@ def _quad_straddles_ring_end(L):
 
 def test_quad_that_straddles_the_end_of_the_first_ring_revolution(L):
     _quad_straddles_ring_end(L)
+
+
+def test_group_state_machine_opt_in():
+    """lz77_groups.h (four chains per wavefront, an opt-in experiment on the device): its state machine -- one search per step, the
+    transitions written with selects, the dictionary stage with selects -- on the emulation build, one lane per group, for every launch
+    that qualifies (BROTLI_MI355X_GROUPS_MIN=0; the switch is read once per process, hence the child process)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import emu, synth; from cmp_lz77 import check; L = emu.lib(); "
+            "ok = check('alice', synth.alice(), 5, 22, lib=L) and check('markov3M', synth.markov_text(3 << 20), 5, 22, lib=L) and "
+            "check('markov5M', synth.markov_text(5 << 20), 5, 22, lib=L) and check('silesia1M', synth.silesia_like(1 << 20, min_segment=16 << 10, max_segment=256 << 10), 5, 22, lib=L) "
+            "and check('random300k', synth.random_bytes(300000), 5, 22, lib=L) and check('zeros200k', bytes(200000), 5, 22, lib=L); sys.exit(0 if ok else 1)" % HERE)
+    env = dict(os.environ, BROTLI_MI355X_GROUPS_MIN="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]

@@ -130,3 +130,20 @@ def test_checkpoint_and_burst_switches_leave_the_parse_alone(L):
 def test_quad_that_straddles_the_end_of_the_first_ring_revolution(L):
     from test_emu_parity import _quad_straddles_ring_end
     _quad_straddles_ring_end(L)
+
+
+def test_group_kernel_opt_in():
+    """k_parse_groups (lz77_groups.h: four chains per wavefront, round 0 and the warm-up), an opt-in experiment: with
+    BROTLI_MI355X_GROUPS_MIN=0 every qualifying launch goes through it and the command lists must still equal the oracle's
+    (the switch is read once per process, hence the child process)"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); import torch, gpulib, synth; from cmp_lz77 import check; L = gpulib.lib(); "
+            "ok = check('alice', synth.alice(), 5, 22, lib=L) and check('markov6M', synth.markov_text(6 << 20), 5, 22, lib=L) and "
+            "check('mixed2M', synth.mixed(2 << 20), 5, 22, lib=L) and check('random300k', synth.random_bytes(300000), 5, 22, lib=L) and "
+            "check('zeros300k', bytes(300000), 5, 22, lib=L); sys.exit(0 if ok else 1)" % here)
+    env = dict(os.environ, BROTLI_MI355X_GROUPS_MIN="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
