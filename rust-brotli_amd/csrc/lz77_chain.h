@@ -481,9 +481,15 @@ static constexpr uint32_t kRowDictLane = 16;  // offset of the dictionary lanes 
 // The compiler turned the cascade "first differing qword" of br_match_len_wide into four nested exec-mask regions per probe
 // (round 6: the parse kernel is bound by instruction issue, SALU first), and most candidates differ within a few bytes.
 typedef uint32_t br_u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+// bit number of the lowest set bit, 0xffffffff for 0: v_ffbl_b32 as the hardware defines it (__ffs / __builtin_ctz cost a compare and a
+// select more per word to make the zero case defined)
+BR_DEV uint32_t br_ffbl(uint32_t x) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 BR_DEV uint32_t br_common16v(const br_u32x4 a0, const br_u32x4 b0) {
-  auto low = [](uint32_t x, uint32_t bit0) -> uint32_t { return ((uint32_t)__ffs((int)x) - 1u) | bit0; };  // v_ffbl_b32, v_or_b32
-  const uint32_t t0 = low(a0.x ^ b0.x, 0), t1 = low(a0.y ^ b0.y, 32), t2 = low(a0.z ^ b0.z, 64), t3 = low(a0.w ^ b0.w, 96);
+  const uint32_t t0 = br_ffbl(a0.x ^ b0.x), t1 = br_ffbl(a0.y ^ b0.y) | 32u, t2 = br_ffbl(a0.z ^ b0.z) | 64u, t3 = br_ffbl(a0.w ^ b0.w) | 96u;
   const uint32_t bits = min(min(min(t0, t1), t2), t3);  // (v_min3_u32, v_min_u32)
   return min(bits >> 3, 16u);
 }
@@ -542,7 +548,11 @@ BR_DEV void br_probe_pair_rows(const Lz77Params& P, const ChainTables& t, ChainS
   m.pos = p0;
   m.version = cache_version;
   m.nbucket[0] = m.nbucket[1] = kRowEntries;  // (the generic fold walks the whole row; kRowEnd entries end the walk)
-  const uint32_t w = (uint32_t)BR_LANE >> 5, c = (uint32_t)BR_LANE & 31u;
+  // (the lane number through an empty asm: what hangs on it -- the role masks of the lanes -- is then computed where it is used, one
+  // compare each, instead of being hoisted out of the parse loop into scalar register pairs that spill)
+  uint32_t lane_id = (uint32_t)BR_LANE;
+  asm volatile("" : "+v"(lane_id));
+  const uint32_t w = lane_id >> 5, c = lane_id & 31u;
   const uint32_t cur = p0 + w;
   const uint32_t max_length = pos_end - cur;
   const uint32_t max_backward = cur < P.max_backward_limit ? cur : P.max_backward_limit;
@@ -1074,8 +1084,10 @@ BR_DEV SearchResult br_fold_probe(const Lz77Params& P, const ChainTables& t, Cha
   if constexpr (kRows) {
     // The candidates of this position are in the registers of its half of the wave (br_probe_pair_rows); entries behind
     // the end of the row hold kRowEnd and never take part.  Straight-line scoring (selects, no exec-mask regions).
-    const uint32_t c = (uint32_t)BR_LANE & 31u;
-    const bool in_range = ((uint32_t)BR_LANE >> 5) == w && c < ndist + kRowEntries;
+    uint32_t lane_id = (uint32_t)BR_LANE;
+    asm volatile("" : "+v"(lane_id));  // (see br_probe_pair_rows)
+    const uint32_t c = lane_id & 31u;
+    const bool in_range = (lane_id >> 5) == w && c < ndist + kRowEntries;
     const bool is_cache = c < ndist;
     const uint32_t prev = in_range ? m.r_prev : 0xffffffffu;
     const uint32_t unbroken = in_range ? m.r_len : 0u;
