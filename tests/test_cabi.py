@@ -269,3 +269,58 @@ def test_multi_shards_in_flight_emulation():
 @pytest.mark.gpu
 def test_multi_shards_in_flight_gpu():
     _multi_shards_in_flight(_load("gpu"))
+
+
+def _run_reference_client(path, extra_env=None, args=()):
+    """tests/clients/multiexample = the reference's own c/multiexample.c (with the reference's own headers) linked against the product
+    library: eleven BrotliEncoderCompressWorkPool (or, with NO_WORK_POOL, BrotliEncoderCompressMulti) calls -- quality 10 + Q9_5 with 10
+    threads, 11 + Q9_5 with 11, then qualities 3..11 with as many threads -- each decoded again by the client through libbrotlidec.
+    Returns the eleven compressed sizes it prints."""
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "clients", "multiexample")
+    if not os.path.exists(exe):
+        pytest.skip("tests/clients/multiexample is built where /root/reference is present (__graft_entry__.build)")
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "16")
+    env.update(extra_env or {})
+    p = subprocess.run([exe] + ([path] if path else []) + list(args), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, (p.returncode, p.stderr.decode()[-2000:])
+    sizes = [int(m) for m in re.findall(r"reduced to (\d+)", p.stdout.decode())]
+    assert len(sizes) == 11, p.stdout.decode()
+    return sizes
+
+
+def _oracle_sizes_of_the_reference_client(data, lgwin=None):
+    """what the same eleven calls give on the oracle (c/arg.h: SIZE_HINT = input size first, then the command line, then the override)"""
+    sizes = []
+    for i in range(1, 12):
+        params = [(5, len(data))]
+        if lgwin is not None:
+            params.append((2, lgwin))
+        q = i
+        if i < 3:
+            q = i + 9
+            params.append((150, 1))  # BROTLI_PARAM_Q9_5
+        params.append((1, q))
+        sizes.append(len(orc.compress_multi(data, params, min(max(q, 1), 16))))
+    return sizes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_work_pool", [False, True])
+def test_reference_client_multiexample_gpu(tmp_path, no_work_pool):
+    """the drop-in claim at the link level: the reference's own client, compiled against the reference's own headers, runs on the
+    product library, every stream decodes (the client aborts otherwise), and every size equals the oracle's for the same call"""
+    env = {"NO_WORK_POOL": "1"} if no_work_pool else {}
+    # its built-in text (a few hundred bytes: shards of some forty bytes at eleven threads)
+    example = (b"Mary had a little lamb. Its fleece was white as snow.\n"
+               b"And every where that Mary went, the lamb was sure to go.\n"
+               b"It followed her to school one day which was against the rule.\n"
+               b"It made the children laugh and play to see a lamb at sch00l!\n\n\n\n"
+               b"0 1 1 2 3 5 8 13 21 34 55 89 144 233 377 610 987 1597 2584 4181 6765\n"
+               b"\x11\x99\x2f\xfc\xfe\xef\xff\xd8\xfd\x9c\x43"
+               b"Additional testing characters here\x00")
+    assert _run_reference_client(None, env) == _oracle_sizes_of_the_reference_client(example)
+    # alice29.txt at lgwin 22
+    f = tmp_path / "alice29.txt"
+    f.write_bytes(synth.alice())
+    assert _run_reference_client(str(f), env, ["-w22"]) == _oracle_sizes_of_the_reference_client(synth.alice(), 22)
