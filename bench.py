@@ -347,17 +347,18 @@ def other_workloads(torch, bm, lib, enc, frozen, work_fn, budget):
             sys.stderr.write("[bench extras] " + json.dumps(e) + "\n")
 
     run("c1_alice29", 2, lambda: small_input_workloads(lib))
-    run("q2_4_text", 4, lambda: quality_2_4_workloads(bm, lib))
-    run("stream_nohint", 6, lambda: stream_nohint_workload(bm, lib))
-    for name, est in (("c3_enwik_256MiB_q9", 6), ("c5_xorshift_1GiB_q5", 5)):
+    run("q2_4_text", 8, lambda: quality_2_4_workloads(bm, lib))
+    for name, est in (("c3_enwik_256MiB_q9", 6), ("c5_xorshift_1GiB_q5", 5), ("zero_1GiB_q5", 4)):
         if name in frozen:
             run(name, est, lambda name=name: large_workload(name, torch, bm, lib, enc, frozen, work_fn))
-    run("q0_1_text", 8, lambda: quality_0_1_workloads(lib))
-    run("q10_11_alice29", 8, lambda: quality_10_11_workloads(torch, bm, enc, ("alice29",)))
+    run("q0_1_text", 10, lambda: quality_0_1_workloads(lib))
     run("q9_5_text_8MiB", 5, lambda: quality_9_5_workloads(torch, bm, enc))
-    for name, est in (("c4_silesia_1GiB_multi8_hinted", 10), ("zero_1GiB_q5", 4), ("c4_silesia_128MiB_multi8_h5", 20)):
-        if name in frozen:
-            run(name, est, lambda name=name: large_workload(name, torch, bm, lib, enc, frozen, work_fn))
+    if "c4_silesia_1GiB_multi8_hinted" in frozen:
+        run("c4_silesia_1GiB_multi8_hinted", 10, lambda: large_workload("c4_silesia_1GiB_multi8_hinted", torch, bm, lib, enc, frozen, work_fn))
+    run("stream_nohint", 12, lambda: stream_nohint_workload(bm, lib))
+    run("q10_11_alice29", 8, lambda: quality_10_11_workloads(torch, bm, enc, ("alice29",)))
+    if "c4_silesia_128MiB_multi8_h5" in frozen:
+        run("c4_silesia_128MiB_multi8_h5", 20, lambda: large_workload("c4_silesia_128MiB_multi8_h5", torch, bm, lib, enc, frozen, work_fn))
     run("q10_11_text_1MiB", 40, lambda: quality_10_11_workloads(torch, bm, enc, ("text_1MiB",)))
     return res
 
@@ -396,15 +397,20 @@ def quality_2_4_workloads(bm, lib):
     bound = "see DESIGN.md section 3.10"
     for quality in (2, 3, 4):
         res.append(_host_call_entry(lib, "q%d_text_2MiB" % quality, data, quality, 22, quick, "k_quick_block", bound))
-    try:
-        big = synth.markov_text(64 << 20, 5)
-        res.append(_host_call_entry(lib, "q4_text_64MiB", big, 4, 22, quick, "k_quick_block", bound, reps=1))
-        del big
-    except Exception as e:
-        res.append({"workload": "q4_text_64MiB", "error": repr(e)})
+    q4_rate = res[-1].get("value", 0.0) or 0.0
+    if q4_rate >= 30.0:  # (64 MiB at the 2 MiB rate must fit the budget of the side workloads: below 30 MB/s it does not)
+        try:
+            big = synth.markov_text(64 << 20, 5)
+            res.append(_host_call_entry(lib, "q4_text_64MiB", big, 4, 22, quick, "k_quick_block", bound, reps=1))
+            del big
+        except Exception as e:
+            res.append({"workload": "q4_text_64MiB", "error": repr(e)})
+    else:
+        res.append({"workload": "q4_text_64MiB", "skipped": "one stream of quality 4 runs at %.1f MB/s on 2 MiB: 64 MiB would take %.0f s" % (q4_rate, 67.1 / max(q4_rate, 0.01))})
     try:
         big = synth.markov_text(16 << 20, 77)
         params = {bm.BROTLI_PARAM_QUALITY: 2, bm.BROTLI_PARAM_LGWIN: 22}
+        lib.BrotliCompress(big[:1 << 20], params, 16)  # (warm-up: the helper threads of the library and their device memory pools)
         t0 = time.time()
         out = bytes(lib.BrotliCompress(big, params, 16))
         sec = time.time() - t0
@@ -444,12 +450,13 @@ def quality_0_1_workloads(lib):
 def stream_nohint_workload(bm, lib):
     """the CompressorWriter pattern (src/enc/writer.rs:269-313): BrotliEncoderCompressStream fed 4 KiB writes, NO size hint (size_hint
     = the first write => H5, whose StoreRangeOptBatch files masked ring entries past the 8 MiB ring buffer, mod.rs:1163-1232), quality 5,
-    lgwin 22, 64 MiB of text; the first 16 MiB also through the oracle's writer fed the same way (its rate is the CPU column; the whole
-    stream must decode to the input, and equals the frozen oracle hash when tests/golden/large_hashes.json holds one)"""
+    lgwin 22, 16 MiB of text; the same input through the oracle's writer fed the same way (its rate is the CPU column, its bytes the
+    expected stream)"""
     import orc
     import synth
-    name = "stream_64MiB_q5_nohint"
-    data = synth.markov_text(64 << 20, 5)
+    # (16 MiB: past the 8 MiB ring buffer, where the masked entries begin; 64 MiB at the rate of one live chain would not fit the budget)
+    name = "stream_16MiB_q5_nohint"
+    data = synth.markov_text(16 << 20, 5)
     entry = {"workload": name, "input_bytes": len(data), "quality": QUALITY, "lgwin": LGWIN,
              "residency": "host buffers, BrotliEncoderCompressStream(PROCESS) in 4 KiB writes, then FINISH"}
     try:
@@ -488,17 +495,10 @@ def stream_nohint_workload(bm, lib):
         L.BrotliEncoderDestroyInstance(st)
         sec = time.time() - t0
         out = dst.raw[:n_out]
-        sample = data[:16 << 20]
-        _, col = cpu_oracle_timed(lambda: orc.writer_compress(sample, QUALITY, LGWIN, chunk=step), len(sample),
-                                  "the first 16 MiB of the input through the oracle's CompressorWriter pattern, 4 KiB writes")
+        want, col = cpu_oracle_timed(lambda: orc.writer_compress(data, QUALITY, LGWIN, chunk=step), len(data),
+                                     "the same input through the oracle's CompressorWriter pattern, 4 KiB writes")
         entry.update({"value": round(len(data) / sec / 1e6, 2), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out),
-                      "round_trips": orc.decompress(out, len(data)) == data, "cpu_oracle": col,
-                      "vs_cpu_oracle_sampled": round(len(data) / sec / 1e6 / col["value"], 3)})
-        h = frozen_hashes().get(name)
-        if h:
-            entry["identical_to_cpu_oracle"] = hashlib.sha256(out).hexdigest() == h["stream_sha256"]
-        else:
-            entry["identical_to_cpu_oracle"] = None
+                      "identical_to_cpu_oracle": out == want, "cpu_oracle": col, "vs_cpu_oracle": round(len(data) / sec / 1e6 / col["value"], 3)})
     except Exception as e:
         entry["error"] = repr(e)
     return [entry]
