@@ -107,8 +107,14 @@ void RunFragments(const EncoderParams& p, FragmentStream* fs, const uint8_t* inp
   static const size_t batch_target = getenv("BROTLI_MI355X_FRAGMENT_BATCH") ? (size_t)strtoull(getenv("BROTLI_MI355X_FRAGMENT_BATCH"), nullptr, 10) : ((size_t)256 << 20);
   static const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
   static const bool test_again = getenv("BROTLI_MI355X_TEST_FRAGMENT_AGAIN") != nullptr;  // every fragment off phase 0 takes the one-by-one path
-  // (at most 4096 fragments side by side: slabs and grid dimensions stay bounded when the fragments are tiny)
-  const size_t per_batch = std::min<size_t>(4096, std::max<size_t>(1, batch_target / block_size_limit));
+  // (at most 4096 fragments side by side: slabs and grid dimensions stay bounded when the fragments are tiny -- and at most as many as
+  // 512 MiB of per-fragment scratch hold (hash table + command + literal buffers: about 1.1 MiB per fragment of >= 128 KiB): a 256 MiB
+  // call at lgwin 16 otherwise asked for 4096 of them = 2.5 GiB, times the concurrent callers of the library)
+  const size_t table_bytes = ((size_t)1 << TableBits(p.quality, std::min(size, block_size_limit))) * 4;
+  const size_t scratch_per_fragment = table_bytes + (p.quality == 0 ? 0 : 5 * (std::min<size_t>(std::min(size, block_size_limit), (size_t)1 << 17) + 64));
+  static const size_t scratch_budget = getenv("BROTLI_MI355X_FRAGMENT_SCRATCH") ? (size_t)strtoull(getenv("BROTLI_MI355X_FRAGMENT_SCRATCH"), nullptr, 10) : ((size_t)512 << 20);
+  const size_t by_scratch = std::max<size_t>(1, scratch_budget / std::max<size_t>(1, scratch_per_fragment));
+  const size_t per_batch = std::min<size_t>(std::min<size_t>(4096, by_scratch), std::max<size_t>(1, batch_target / block_size_limit));
   const size_t batch_bytes = per_batch * block_size_limit;
   const size_t in_cap = std::min(size, batch_bytes);
   const size_t max_jobs = in_cap == 0 ? 1 : (in_cap + block_size_limit - 1) / block_size_limit;

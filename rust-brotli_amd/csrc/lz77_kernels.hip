@@ -2256,6 +2256,14 @@ void side_release(SideLane* lane) {
   std::lock_guard<std::mutex> lock(g_side_mu);
   g_side_free.push_back(lane);
 }
+// a lane goes back to the list however the call ends (a HIP_CHECK that throws included)
+struct SideLaneHold {
+  SideLane* lane;
+  explicit SideLaneHold(size_t words) : lane(side_acquire(words)) {}
+  ~SideLaneHold() { side_release(lane); }
+  SideLaneHold(const SideLaneHold&) = delete;
+  SideLaneHold& operator=(const SideLaneHold&) = delete;
+};
 }  // namespace
 
 void lz77_sample_histograms(const uint8_t* text, const uint32_t* ranges, uint32_t count, uint32_t* out) {
@@ -2263,10 +2271,19 @@ void lz77_sample_histograms(const uint8_t* text, const uint32_t* ranges, uint32_
   uint32_t most = 0;
   for (uint32_t r = 0; r < count; ++r) most = std::max(most, (ranges[2 * r + 1] + 12) / 13);
   const size_t range_words = (size_t)count * 2, out_words = (size_t)count * 256;
-  SideLane* lane = side_acquire(range_words + out_words);
+  SideLaneHold hold(range_words + out_words);
+  SideLane* lane = hold.lane;
   uint32_t* ranges_dev = lane->dev;
   uint32_t* out_dev = lane->dev + range_words;
   memcpy(lane->host, ranges, range_words * 4);
+  // the text was uploaded on the calling thread's stream: the side stream waits for what that stream holds NOW (every caller has
+  // synchronised behind the upload long before; the event makes the lane correct without that knowledge)
+  {
+    static thread_local hipEvent_t text_ready = nullptr;
+    if (!text_ready) HIP_CHECK(hipEventCreateWithFlags(&text_ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(text_ready, BR_STREAM));
+    HIP_CHECK(hipStreamWaitEvent(lane->stream, text_ready, 0));
+  }
   HIP_CHECK(hipMemcpyAsync(ranges_dev, lane->host, range_words * 4, hipMemcpyHostToDevice, lane->stream));
   HIP_CHECK(hipMemsetAsync(out_dev, 0, out_words * 4, lane->stream));
   if (most != 0) {
@@ -2280,7 +2297,6 @@ void lz77_sample_histograms(const uint8_t* text, const uint32_t* ranges, uint32_
   HIP_CHECK(hipMemcpyAsync(lane->host + range_words, out_dev, out_words * 4, hipMemcpyDeviceToHost, lane->stream));
   HIP_CHECK(hipStreamSynchronize(lane->stream));
   memcpy(out, lane->host + range_words, out_words * 4);
-  side_release(lane);
 }
 
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev) {

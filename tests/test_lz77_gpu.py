@@ -147,3 +147,16 @@ def test_group_kernel_opt_in():
     env = dict(os.environ, BROTLI_MI355X_GROUPS_MIN="0")
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
+
+
+def test_candidate_rows_equal_a_rebuild_after_every_update():
+    """the flip-cell filters and the listed / incremental row maintenance exist in the HIP build only: with
+    BROTLI_MI355X_SELFTEST_ROWS the rows are compared with a rebuild from the flags after EVERY update (Lz77Stage::SelfTestRows), on
+    random, mixed, Silesia-like and text input, byte identity on top (tools/rows_selftest_gpu.py quick; the switch is read once per
+    process, hence the child process)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rows_selftest_gpu.py"), "quick"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b"ROWS SELFTEST OK" in p.stdout, p.stdout.decode()[-2000:]
