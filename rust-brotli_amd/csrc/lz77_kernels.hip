@@ -2055,8 +2055,12 @@ __global__ __launch_bounds__(64) void k_recheck_searches(RecheckArgs a) {
   if (n > a.cap) n = a.cap;
   for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
     const uint32_t p = a.list[item];
-    const uint32_t blk = (p - a.geo.first_block_start) / a.geo.block_bytes;
-    const uint64_t end64 = (uint64_t)a.geo.first_block_start + (uint64_t)(blk + 1) * a.geo.block_bytes;
+    // (input blocks are cut at prefix_bytes + k * block_bytes -- mark_dirty's geometry; the first one merely STARTS later on a catable
+    // stream, whose first two bytes are stored raw: counting the blocks from first_block_start gave the first two positions of every
+    // block the end of the block in front, i.e. a search of one or two bytes that "found the same as before" -- nothing -- whatever
+    // the candidates had become.  Found by the API sweep in round 6, seed 62 case 213.)
+    const uint32_t blk = (p - a.geo.prefix_bytes) / a.geo.block_bytes;
+    const uint64_t end64 = (uint64_t)a.geo.prefix_bytes + (uint64_t)(blk + 1) * a.geo.block_bytes;
     const uint32_t blk_end = end64 < a.P.total_bytes ? (uint32_t)end64 : a.P.total_bytes;
     const bool same = br_recheck_search<kH9>(a.P, a.T, scratch, p, blk_end);
     if (!same && threadIdx.x == 0) mark_dirty(p, a.geo, a.dirty);

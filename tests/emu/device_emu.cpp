@@ -250,8 +250,8 @@ void lz77_recheck_searches(const Lz77Params& P, const Lz77Buffers& B, int rbuf, 
   const uint32_t n = *B.recheck_count < B.recheck_cap ? *B.recheck_count : B.recheck_cap;
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t p = B.recheck_list[i];
-    const uint32_t blk = (p - geo.first_block_start) / geo.block_bytes;
-    const uint64_t end64 = (uint64_t)geo.first_block_start + (uint64_t)(blk + 1) * geo.block_bytes;
+    const uint32_t blk = (p - geo.prefix_bytes) / geo.block_bytes;  // (blocks are cut at prefix_bytes + k * block_bytes: see k_recheck_searches)
+    const uint64_t end64 = (uint64_t)geo.prefix_bytes + (uint64_t)(blk + 1) * geo.block_bytes;
     const uint32_t blk_end = end64 < P.total_bytes ? (uint32_t)end64 : P.total_bytes;
     const bool same = P.hasher_kind == 9 ? br_recheck_search<true>(P, T, scratch9, p, blk_end)
                       : P.block_bits > 7 ? br_recheck_search<false>(P, T, scratch_deep, p, blk_end)

@@ -254,3 +254,15 @@ def test_group_state_machine_opt_in():
     env = dict(os.environ, BROTLI_MI355X_GROUPS_MIN="0")
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
+
+
+def test_catable_stream_recheck_at_block_starts(L):
+    """Round 6, API sweep seed 62 case 213: on a catable stream (two raw first bytes: the first block starts at 2, the others at
+    multiples of 64 KiB) the single-search re-check of qualities 6-9 counted its blocks from the first block's START, so the first two
+    positions of every block were repeated against the end of the block in front -- a search of one or two bytes that never finds
+    anything -- and a candidate that appeared there in a later round went unnoticed (one command of 22 227: insert 15 / copy 4 where the
+    reference has insert 14 / copy 5).  Segments of 512 bytes, as the library cuts an input of this size."""
+    d = open(os.path.join(GOLDEN, "catable_recheck_at_block_start.bin"), "rb").read()
+    assert check("catable recheck", d, 6, 24, catable=True, seg=512, lib=L)
+    for q in (6, 7, 8, 9):
+        assert check_bytes(L, "catable recheck q%d" % q, d, [(Q, q), (W, 24), (SH, len(d)), (167, 1)], seg=512)

@@ -77,3 +77,11 @@ def test_input_on_which_the_reference_fails(L):
     with pytest.raises(RuntimeError, match="reference encoder fails"):
         emu.encode_stream(L, x[64:], [(Q, 6), (W, 20)], prefix=x[:64])
     assert check_bytes(L, "no boundary", x, [(Q, 6), (W, 20)], verbose=False)
+
+
+def test_catable_stream_recheck_at_block_starts(L):
+    """the GPU twin of test_emu_parity.py::test_catable_stream_recheck_at_block_starts (round 6, API sweep seed 62 case 213): the first
+    two positions of every block of a catable stream were re-checked against the end of the block in front (k_recheck_searches)"""
+    d = open(os.path.join(GOLDEN, "catable_recheck_at_block_start.bin"), "rb").read()
+    for q in (6, 7, 8, 9):
+        assert check_bytes(L, "catable recheck q%d" % q, d, [(1, q), (2, 24), (5, len(d)), (167, 1)], seg=512)
