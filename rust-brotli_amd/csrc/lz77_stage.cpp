@@ -89,6 +89,21 @@ void Lz77Stage::Release() {
     dev_free(Z_.ctl);
     Z_ = ZopfliJob{};
     dev_free(Q_.table);
+    dev_free(S_.ev_slot);
+    dev_free(S_.ev_id);
+    dev_free(S_.ev_of);
+    dev_free(S_.slot_first);
+    dev_free(S_.qrank);
+    dev_free(S_.act);
+    dev_free(S_.val);
+    dev_free(S_.cand[0]);
+    dev_free(S_.cand[1]);
+    dev_free(S_.flags);
+    dev_free(S_.sort_tmp);
+    dev_free(S_.sort_keys_tmp);
+    dev_free(S_.sort_ids_tmp);
+    dev_free(S_.scan_tmp);
+    S_ = QuickSpec{};
     Q_ = QuickJob{};
     dev_free(qsnap_table_);
     qsnap_table_ = nullptr;
@@ -156,18 +171,52 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     // segment per input block; none of the sort / row / rank structures of the speculative path exist.
     use_live_ = use_rows_ = false;
     P_.htl = 8;
-    if (segment_bytes_ != block_bytes_) segment_bytes_ = block_bytes_;
+    // A stream that comes in one piece (no hasher state in front of it, none behind a partial piece) takes the speculative path
+    // (quick_spec.h): the segments of a block side by side on candidates derived from per-position flags, the resolver over
+    // their exits as for qualities 5-9.  Everything else walks the reference's own table block by block (quick_device.h).
+    // BROTLI_MI355X_QUICK_SERIAL=1 keeps every call on the table (test aid).
+    use_qspec_ = !(carry_ && carry_->valid) && !partial_ && getenv("BROTLI_MI355X_QUICK_SERIAL") == nullptr && input_bytes >= 64 &&
+                 (uint64_t)P_.total_bytes * 2 < 0xfffffff0ull;
+    qspec_params_ = params;
+    qspec_text_ = text_dev;
+    qspec_prefix_ = prefix_bytes;
+    qspec_input_ = input_bytes;
+    qspec_raw_head_ = raw_head_bytes;
+    if (!use_qspec_ && segment_bytes_ != block_bytes_) segment_bytes_ = block_bytes_;
     P_.cmd_slab_stride = segment_bytes_ / 2 + 8;
     BuildSegments();
     P_.num_segments = (uint32_t)segments_.size();
-    P_.use_dictionary = 0;  // (the throttle books travel with the table, not with the resolver)
     Q_ = QuickJob{};
     Q_.kind = (uint32_t)params.hasher.type;
     Q_.bucket_bits = Q_.kind == 54 ? 20 : (Q_.kind == 4 ? 17 : 16);
     Q_.sweep = Q_.kind == 2 ? 1 : (Q_.kind == 3 ? 2 : 4);
     Q_.hash_len = Q_.kind == 54 ? 7 : 5;
     Q_.use_dictionary = (params.use_dictionary && (Q_.kind == 2 || Q_.kind == 4)) ? 1 : 0;
+    // serial path: the throttle books travel with the table, not with the resolver; speculative path: the resolver keeps them
+    P_.use_dictionary = use_qspec_ ? Q_.use_dictionary : 0;
     Q_.table = (uint32_t*)dev_alloc_uninit((size_t)quick_table_words(Q_) * 4 + 64);
+    if (use_qspec_) {
+      S_ = QuickSpec{};
+      S_.n = P_.total_bytes;
+      S_.events = Q_.sweep == 1 ? S_.n : 2u * S_.n;
+      S_.slots = quick_slots(Q_);
+      const size_t E = S_.events, N = S_.n;
+      S_.ev_slot = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.ev_id = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.ev_of = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.slot_first = (uint32_t*)dev_alloc_uninit(((size_t)S_.slots + 2) * 4 + 64);
+      S_.qrank = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
+      S_.act = (uint32_t*)dev_alloc_uninit((E + 1) * 4 + 64);
+      S_.val = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.cand[0] = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
+      S_.cand[1] = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
+      S_.flags = (uint8_t*)dev_alloc_uninit(N + 64);
+      S_.sort_tmp_bytes = lz77_qspec_sort_tmp_bytes(S_.events);
+      S_.sort_tmp = dev_alloc_uninit(S_.sort_tmp_bytes);
+      S_.sort_keys_tmp = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.sort_ids_tmp = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.scan_tmp = (uint32_t*)dev_alloc_uninit((E / 1024 + E / (1024 * 1024) + 8192) * 4);
+    }
     cmds_bytes_ = (size_t)total_cmd_slots_ * sizeof(Command) + 64;
     B_.cmds = (Command*)dev_alloc_uninit(cmds_bytes_);
     B_.segments = (Segment*)dev_alloc(segments_.size() * sizeof(Segment) + 64);
@@ -1384,7 +1433,7 @@ void Lz77Stage::Run() {
     return;
   }
   if (use_zopfli_ || use_quick_) {
-    if (use_quick_) RunQuick(); else RunZopfli();
+    if (use_quick_) { if (use_qspec_) RunQuickSpec(); else RunQuick(); } else RunZopfli();
     tm.stop(&stats_.ms_parse);
     Gather();
     tm.stop(&stats_.ms_gather);
@@ -1620,6 +1669,16 @@ void Lz77Stage::ExportQuick(StreamCarry* co, bool partial) {
     qc->table = qsnap_table_;
     qsnap_table_ = nullptr;
   } else {
+    if (use_qspec_) {
+      // the speculative path kept no table: what the reference's would hold behind the text, from the final flags; the books of
+      // the throttle behind the slots (once it has tripped only "matches < lookups >> 7" matters: nothing is looked up any more)
+      lz77_qspec_table(P_, B_, Q_, S_);
+      uint32_t books[16] = {0};
+      books[0] = final_dict_dead_ ? DictTracker::kDeadL : final_dict_lookups_;
+      books[1] = final_dict_dead_ ? DictTracker::kDeadM : final_dict_matches_;
+      dev_h2d(Q_.table + quick_books_at(Q_), books, sizeof(books));
+      dev_sync();
+    }
     qc->table = Q_.table;
     Q_.table = nullptr;
   }
@@ -1665,6 +1724,117 @@ void Lz77Stage::RunQuick() {
       if (mb.end == segments_[from].blk_end) starts_metablock = true;
   }
   if (partial_ && starts_metablock) snapshot();
+  final_flags_ = 0;
+  for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
+}
+
+// Qualities 2 .. 4 on the speculative path (quick_spec.h, quick_api.h).  Round 0 parses every segment from a cold guess (its own
+// start, the default distance cache) on the candidates of "every position filed"; after every launch the resolver chains the exits
+// into entries and the candidates are derived again from the flags the chains wrote; a segment is parsed again when its entry
+// changed or a candidate of a position it searched did.  A candidate of p hangs on the flags in front of p only, so the prefix of
+// segments that are final grows by at least one per round; text settles in a handful of rounds.  An input that does not (more than
+// kMaxRounds launches) is handed to the serial path.
+void Lz77Stage::RunQuickSpec() {
+  const bool debug = getenv("BROTLI_MI355X_DEBUG") != nullptr;
+  auto stamp = [&](const char* what) { timeline().stamp(what); };
+  const uint32_t nseg = (uint32_t)segments_.size();
+  if (P_.reset_pos != 0) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4 across the reference's 32-bit position wrap are not supported");
+  resolve_incremental_ = false;
+  InitEntries();
+  lz77_qspec_index(P_, B_, Q_, S_);
+  lz77_qspec_init_flags(P_, B_, Q_, S_, segments_[0].blk_start);
+  int which = 0;
+  lz77_qspec_candidates(P_, B_, Q_, S_, which, nullptr, nullptr);
+  SegGeometry geo{};
+  geo.prefix_bytes = P_.prefix_bytes;
+  geo.first_block_start = segments_[0].blk_start;
+  geo.block_bytes = block_bytes_;
+  geo.num_blocks = (uint32_t)block_segment_bytes_.size();
+  uint32_t* geo_tables = (uint32_t*)dev_alloc((block_first_segment_.size() + block_segment_bytes_.size()) * 4 + 64);
+  dev_h2d(geo_tables, block_first_segment_.data(), block_first_segment_.size() * 4);
+  dev_h2d(geo_tables + block_first_segment_.size(), block_segment_bytes_.data(), block_segment_bytes_.size() * 4);
+  geo.block_first_segment = geo_tables;
+  geo.block_segment_bytes = geo_tables + block_first_segment_.size();
+  geo.num_segments = nseg;
+  geo.block_size = 1;
+  uint8_t* dirty_dev = (uint8_t*)dev_alloc(nseg + 64);
+  uint32_t* list_dev = (uint32_t*)dev_alloc((size_t)nseg * 4 + 64);
+  SegEntry* up_entries_dev = (SegEntry*)dev_alloc_uninit((size_t)nseg * sizeof(SegEntry) + 64);
+  SegExit* got_exits_dev = (SegExit*)dev_alloc_uninit((size_t)nseg * sizeof(SegExit) + 64);
+  PinnedArray<uint8_t> dirty;
+  dirty.resize_discard(nseg);
+  RoundBuffers& R = round_buffers_;
+  R.up_index.resize_discard(nseg);
+  R.up_entries.resize_discard(nseg);
+  R.got_exits.resize_discard(nseg);
+  stamp("qs-index-queued");
+  // ---- round 0: every segment
+  dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
+  lz77_qspec_parse(P_, B_, Q_, S_, which, nullptr, nseg);
+  stats_.rounds++;
+  stats_.segments_parsed += nseg;
+  dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
+  stamp("qs-round0");
+  static const uint32_t kMaxRounds = getenv("BROTLI_MI355X_QUICK_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_ROUNDS")) : 48u;
+  bool settled = false;
+  for (uint32_t round = 1; round <= kMaxRounds; ++round) {
+    // candidates of the flags as they are now, against the ones every standing parse was validated with (device), beside the
+    // resolver pass over the exits (host)
+    dev_memset(dirty_dev, 0, nseg);
+    lz77_qspec_candidates(P_, B_, Q_, S_, which ^ 1, &geo, dirty_dev);
+    dev_d2h_async(dirty.data(), dirty_dev, nseg);
+    touch_all_ = true;
+    Resolve(false);
+    dev_sync();
+    which ^= 1;
+    uint32_t count = 0, by_entry = 0;
+    for (uint32_t k = 0; k < nseg; ++k) {
+      if (!dirty_entry_[k] && !dirty[k]) continue;
+      by_entry += dirty_entry_[k] ? 1u : 0u;
+      entries_[k] = next_entries_[k];
+      R.up_index[count] = k;
+      R.up_entries[count] = entries_[k];
+      ++count;
+    }
+    if (debug) fprintf(stderr, "quick round %u: %u of %u segments to parse again (%u for their entry)\n", round, count, nseg, by_entry);
+    if (count == 0) {
+      settled = true;
+      break;
+    }
+    stats_.rounds++;
+    stats_.segments_parsed += count;
+    dev_h2d(list_dev, R.up_index.data(), (size_t)count * 4);
+    dev_h2d(up_entries_dev, R.up_entries.data(), (size_t)count * sizeof(SegEntry));
+    lz77_scatter_entries(B_, list_dev, up_entries_dev, count);
+    lz77_qspec_parse(P_, B_, Q_, S_, which, list_dev, count);
+    lz77_qspec_gather_exits(B_, list_dev, count, got_exits_dev);
+    dev_d2h(R.got_exits.data(), got_exits_dev, (size_t)count * sizeof(SegExit));
+    for (uint32_t i = 0; i < count; ++i) exits_[R.up_index[i]] = R.got_exits[i];
+  }
+  stamp("qs-settled");
+  dev_free(geo_tables);
+  dev_free(dirty_dev);
+  dev_free(list_dev);
+  dev_free(up_entries_dev);
+  dev_free(got_exits_dev);
+  if (!settled) {
+    // the serial path from the start: one segment per block on the reference's own table
+    if (debug) fprintf(stderr, "quick: not settled after %u rounds, the serial path takes over\n", kMaxRounds);
+    use_qspec_ = false;
+    P_.use_dictionary = 0;
+    Resegment(block_bytes_);
+    dev_free(B_.entries);
+    dev_free(B_.exits);
+    dev_free(gather_offsets_dev_);
+    dev_free(gather_counts_dev_);
+    B_.entries = (SegEntry*)dev_alloc(segments_.size() * sizeof(SegEntry) + 64);
+    B_.exits = (SegExit*)dev_alloc(segments_.size() * sizeof(SegExit) + 64);
+    gather_offsets_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+    gather_counts_dev_ = (uint32_t*)dev_alloc(segments_.size() * 4 + 64);
+    stats_.coarse_restarts++;
+    RunQuick();
+    return;
+  }
   final_flags_ = 0;
   for (uint32_t k = 0; k < nseg; ++k) stats_.searches += exits_[k].n_searches;
 }

@@ -176,6 +176,7 @@ class Lz77Stage {
   void RunLive();
   void RunZopfli();
   void RunQuick();
+  void RunQuickSpec();
   void InitEntries();
   void InitFlags();
   bool Resolve(bool final_pass);
@@ -215,6 +216,11 @@ class Lz77Stage {
   bool use_quick_ = false;   // qualities 2 .. 4 (quick_device.h)
   QuickJob Q_{};
   uint32_t* qsnap_table_ = nullptr;    // partial pieces: the table in front of the block that starts the open meta-block
+  bool use_qspec_ = false;   // ... on the speculative path (quick_spec.h): whole streams in one piece
+  QuickSpec S_{};
+  EncoderParams qspec_params_{};  // (what Setup was called with, for the fall-back to the serial path)
+  uint8_t* qspec_text_ = nullptr;
+  uint32_t qspec_prefix_ = 0, qspec_input_ = 0, qspec_raw_head_ = 0;
   bool live_verify_ = false;
   std::vector<LiveBlockState> live_state_;  // Resolve(): the meta-block books at the entry of every block (live chains)
   uint32_t input_bytes_ = 0;

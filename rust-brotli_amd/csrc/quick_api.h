@@ -40,5 +40,54 @@ void lz77_quick_prepend(const Lz77Params& P, const Lz77Buffers& B, const QuickJo
 // extend_last_command, CreateBackwardReferences; commands into its slab, exit into B.exits[block].  In stream order.
 void lz77_quick_block(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, uint32_t block);
 
+// ---- the speculative path of these qualities (quick_spec.h, round 6): segments of a block side by side ----------------------
+// What a BasicHasher slot holds when position p is searched is a function of the text and of WHICH positions were filed before p
+// (and, for a quad of StoreRange, under which of two slot offsets): the value of the latest filing into that slot.  Every
+// filing goes by position order (a search files its own position after it has looked, a copy files its range before the next
+// search).  So, given a flag byte per position -- filed / searched / filed by a quad and as which of its four -- the `sweep`
+// candidates of every position are one sort away, like the candidate rows of quality 5: the potential filings ("events": one
+// per position under its own slot offset, for sweep > 1 a second one under the offset a quad that starts in the 8-byte group in
+// front would give it) are sorted by (slot, position) once; per round the active ones are marked from the flags, an
+// exclusive max-scan gives every event the latest active event in front of it, and the candidate of (p, j) is that of p's rank in
+// slot key(p) + j.  Chains (one wavefront per segment, quick_spec.h) parse with these candidates and write flags; the host
+// resolver chains their exits (Lz77Stage::Resolve, as for qualities 5-9); a segment is parsed again when its entry changed or a
+// candidate of a position it searched did.  At the fixed point the parse IS the sequential one.
+// Flag byte of a position (QuickSpec::flags):
+static constexpr uint8_t kQsStored = 1, kQsSearched = 2, kQsQuad = 4;  // bits 3-4: index of the position in its quad
+struct QuickSpec {
+  uint32_t n = 0;           // text positions (P.total_bytes)
+  uint32_t events = 0;      // n (sweep 1) or 2 n
+  uint32_t slots = 0;       // quick_slots(J)
+  uint32_t* ev_slot = nullptr;   // [events] slot of event i, ascending
+  uint32_t* ev_id = nullptr;     // [events] its event id: position (sweep 1) or 2 * position + (1 if the displaced one)
+  uint32_t* ev_of = nullptr;     // [events] inverse: index of event id
+  uint32_t* slot_first = nullptr;  // [slots + 2] first event of every slot
+  uint32_t* qrank = nullptr;     // [n * sweep] index of the first event of slot key(p) + j whose position is >= p
+  uint32_t* act = nullptr;       // [events + 1] per round: index + 1 of the active events, max-scanned (exclusive)
+  uint32_t* val = nullptr;       // [events] per round: what an active event filed
+  uint32_t* cand[2] = {nullptr, nullptr};  // [n * sweep] candidates of every position, double buffered
+  uint8_t* flags = nullptr;      // [n + 64]
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  uint32_t* sort_keys_tmp = nullptr;  // [events] scratch of the sort (keys in, ids in)
+  uint32_t* sort_ids_tmp = nullptr;
+  uint32_t* scan_tmp = nullptr;  // [events / 1024 + 4096]
+};
+size_t lz77_qspec_sort_tmp_bytes(uint32_t events);
+// once per text: events, their order, qrank
+void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S);
+// first guess of the flags: a custom dictionary is filed position by position but for its last 7 bytes, the last three positions of
+// a block in front of a block of >= 7 bytes are filed when that block starts (StitchToPreviousBlock), the last 7 of a block not
+// otherwise; everything else is assumed filed by a search
+void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start);
+// cand[out] from the flags; geo != nullptr: dirty[k] = 1 for the chains that searched a position whose candidates differ from cand[out ^ 1]
+void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int out, const SegGeometry* geo, uint8_t* dirty_dev);
+// the listed segments (list_dev == nullptr: all of them), each from B.entries[k], with cand[which]: flags, commands, B.exits[k]
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int which, const uint32_t* list_dev, uint32_t count);
+// out[i] = B.exits[list[i]] for i < count (list rounds move only what was parsed)
+void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, SegExit* out_dev);
+// the hasher as the reference would leave it behind the text (J.table: slots from the flags; the books are the caller's)
+void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S);
+
 }  // namespace brotli_mi355x
 #endif

@@ -18,6 +18,7 @@
 #include "../../rust-brotli_amd/csrc/lz77_groups.h"
 #include "../../rust-brotli_amd/csrc/zopfli_device.h"
 #include "../../rust-brotli_amd/csrc/quick_device.h"
+#include "../../rust-brotli_amd/csrc/quick_spec.h"
 #include "../../rust-brotli_amd/csrc/fragment_device.h"
 #include "../../tables/brotli_tables.h"
 #include "../../tables/brotli_static_dict_lut.h"
@@ -856,6 +857,71 @@ void lz77_quick_block(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
   T.dict_offsets_by_length = dt.dict_offsets_by_length;
   const Segment seg = B.segments[block];
   br_quick_block(J, P, T, B.text, seg, B.entries[block], B.cmds + seg.cmd_base, B.exits + block);
+}
+
+// ---- qualities 2 .. 4 on the speculative path (quick_spec.h): the same item code, one item after the other
+size_t lz77_qspec_sort_tmp_bytes(uint32_t) { return 64; }
+void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S) {
+  std::vector<uint32_t> slot(S.events), order(S.events);
+  for (uint32_t id = 0; id < S.events; ++id) slot[id] = qs_event_slot(J, B.text, id);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return slot[a] < slot[b]; });
+  for (uint32_t i = 0; i < S.events; ++i) {
+    S.ev_slot[i] = slot[order[i]];
+    S.ev_id[i] = order[i];
+    S.ev_of[order[i]] = i;
+  }
+  uint32_t i = 0;
+  for (uint32_t t = 0; t <= S.slots + 1u; ++t) {
+    while (i < S.events && S.ev_slot[i] < t) ++i;
+    S.slot_first[t] = i;
+  }
+  for (uint32_t p = 0; p < S.n; ++p)
+    for (uint32_t j = 0; j < J.sweep; ++j) {
+      const uint32_t s = qs_hash(J, B.text + p) + j;
+      S.qrank[(size_t)p * J.sweep + j] = qs_rank_in_slot(J, S.ev_id, S.slot_first[s], S.slot_first[s + 1], p);
+    }
+}
+void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start) {
+  for (uint32_t q = 0; q < P.total_bytes; ++q) S.flags[q] = qs_initial_flag(P, q, first_block_start);
+}
+void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int out, const SegGeometry* geo, uint8_t* dirty) {
+  for (uint32_t q = 0; q < S.n; ++q) qs_item_activate(J, P, S, q);
+  S.act[S.events] = 0;
+  uint32_t running = 0;
+  for (uint32_t i = 0; i <= S.events; ++i) {  // exclusive max-scan
+    const uint32_t v = S.act[i];
+    S.act[i] = running;
+    running = std::max(running, v);
+  }
+  for (uint32_t p = 0; p < S.n; ++p)
+    for (uint32_t j = 0; j < J.sweep; ++j) {
+      const size_t item = (size_t)p * J.sweep + j;
+      const uint32_t c = qs_candidate(J, S, qs_hash(J, B.text + p) + j, S.qrank[item]);
+      S.cand[out][item] = c;
+      if (geo != nullptr && c != S.cand[out ^ 1][item]) qs_note_changed(S, p, *geo, dirty);
+    }
+}
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int which, const uint32_t* list, uint32_t count) {
+  const DeviceTables& dt = dev_tables();
+  QsTables T;
+  T.text = B.text;
+  T.cand = S.cand[which];
+  T.flags = S.flags;
+  T.dict.dict_hash = dt.dict_hash;
+  T.dict.dict_data = dt.dict_data;
+  T.dict.dict_offsets_by_length = dt.dict_offsets_by_length;
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t k = list ? list[i] : i;
+    const Segment seg = B.segments[k];
+    br_quick_segment(J, P, T, seg, B.entries[k], B.cmds + seg.cmd_base, B.exits + k);
+  }
+}
+void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list, uint32_t count, SegExit* out) {
+  for (uint32_t i = 0; i < count; ++i) out[i] = B.exits[list[i]];
+}
+void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S) {
+  for (uint32_t s = 0; s < S.slots; ++s) J.table[s] = qs_candidate(J, S, s, S.slot_first[s + 1]);
 }
 
 // ---- qualities 0 and 1 (fragment_device.h): the same item code, called directly, one fragment after the other
