@@ -96,9 +96,13 @@ void Lz77Stage::Release() {
     dev_free(S_.qrank);
     dev_free(S_.act);
     dev_free(S_.val);
-    dev_free(S_.cand[0]);
-    dev_free(S_.cand[1]);
+    dev_free(S_.cand);
     dev_free(S_.flags);
+    dev_free(S_.actraw);
+    dev_free(S_.flags_prev);
+    dev_free(S_.chg_list);
+    dev_free(S_.chg_range);
+    dev_free(S_.chg_count);
     dev_free(S_.sort_tmp);
     dev_free(S_.sort_keys_tmp);
     dev_free(S_.sort_ids_tmp);
@@ -206,11 +210,16 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
       S_.ev_of = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
       S_.slot_first = (uint32_t*)dev_alloc_uninit(((size_t)S_.slots + 2) * 4 + 64);
       S_.qrank = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
-      S_.act = (uint32_t*)dev_alloc_uninit((E + 1) * 4 + 64);
+      S_.actraw = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
+      S_.act = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
       S_.val = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
-      S_.cand[0] = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
-      S_.cand[1] = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
+      S_.cand = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
       S_.flags = (uint8_t*)dev_alloc_uninit(N + 64);
+      S_.flags_prev = (uint8_t*)dev_alloc_uninit(N + 64);
+      S_.chg_cap = (uint32_t)std::max<size_t>(4096, E / 64);
+      S_.chg_list = (uint32_t*)dev_alloc_uninit((size_t)S_.chg_cap * 4 + 64);
+      S_.chg_range = (uint32_t*)dev_alloc_uninit((size_t)S_.chg_cap * 12 + 64);
+      S_.chg_count = (uint32_t*)dev_alloc(64);
       S_.sort_tmp_bytes = lz77_qspec_sort_tmp_bytes(S_.events);
       S_.sort_tmp = dev_alloc_uninit(S_.sort_tmp_bytes);
       S_.sort_keys_tmp = (uint32_t*)dev_alloc_uninit(E * 4 + 64);
@@ -1740,11 +1749,11 @@ void Lz77Stage::RunQuickSpec() {
   const uint32_t nseg = (uint32_t)segments_.size();
   if (P_.reset_pos != 0) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4 across the reference's 32-bit position wrap are not supported");
   resolve_incremental_ = false;
+  const auto t_begin = std::chrono::steady_clock::now();
   InitEntries();
   lz77_qspec_index(P_, B_, Q_, S_);
   lz77_qspec_init_flags(P_, B_, Q_, S_, segments_[0].blk_start);
-  int which = 0;
-  lz77_qspec_candidates(P_, B_, Q_, S_, which, nullptr, nullptr);
+  lz77_qspec_candidates(P_, B_, Q_, S_, nullptr, nullptr);
   SegGeometry geo{};
   geo.prefix_bytes = P_.prefix_bytes;
   geo.first_block_start = segments_[0].blk_start;
@@ -1763,6 +1772,9 @@ void Lz77Stage::RunQuickSpec() {
   SegExit* got_exits_dev = (SegExit*)dev_alloc_uninit((size_t)nseg * sizeof(SegExit) + 64);
   PinnedArray<uint8_t> dirty;
   dirty.resize_discard(nseg);
+  PinnedArray<uint32_t> chg_count;
+  chg_count.resize_discard(16);
+  chg_count[0] = chg_count[1] = 0;
   RoundBuffers& R = round_buffers_;
   R.up_index.resize_discard(nseg);
   R.up_entries.resize_discard(nseg);
@@ -1770,23 +1782,42 @@ void Lz77Stage::RunQuickSpec() {
   stamp("qs-index-queued");
   // ---- round 0: every segment
   dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
-  lz77_qspec_parse(P_, B_, Q_, S_, which, nullptr, nseg);
+  lz77_qspec_parse(P_, B_, Q_, S_, nullptr, nseg);
   stats_.rounds++;
   stats_.segments_parsed += nseg;
   dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
   stamp("qs-round0");
-  static const uint32_t kMaxRounds = getenv("BROTLI_MI355X_QUICK_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_ROUNDS")) : 48u;
+  static const uint32_t kMaxRounds = getenv("BROTLI_MI355X_QUICK_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_ROUNDS")) : 64u;
+  static const bool never_incremental = getenv("BROTLI_MI355X_QUICK_NO_INCREMENTAL") != nullptr;
+  // the candidates follow the flags in proportion to the changes when a launch was short and changed few filings (lz77_qspec_diff /
+  // _repair), else by the pass over everything
   bool settled = false;
+  bool diffed = false;  // the last launch was followed by lz77_qspec_diff: chg_count[0] holds the number of listed events
+  uint32_t incremental_rounds = 0;
   for (uint32_t round = 1; round <= kMaxRounds; ++round) {
-    // candidates of the flags as they are now, against the ones every standing parse was validated with (device), beside the
+    // candidates of the flags as they are now; the chains that searched a position whose candidates changed (device), beside the
     // resolver pass over the exits (host)
     dev_memset(dirty_dev, 0, nseg);
-    lz77_qspec_candidates(P_, B_, Q_, S_, which ^ 1, &geo, dirty_dev);
+    bool repaired = false;
+    if (diffed && chg_count[0] <= S_.chg_cap) {
+      lz77_qspec_repair(P_, B_, Q_, S_, chg_count[0], geo, dirty_dev);
+      dev_d2h_async(chg_count.data(), S_.chg_count, 64);
+      repaired = true;
+    } else {
+      lz77_qspec_candidates(P_, B_, Q_, S_, &geo, dirty_dev);
+    }
     dev_d2h_async(dirty.data(), dirty_dev, nseg);
     touch_all_ = true;
     Resolve(false);
     dev_sync();
-    which ^= 1;
+    if (repaired && chg_count[1] != 0) {
+      // a walk gave up (a long stretch of inactive filings in one slot): the pass over everything, which starts from the flags
+      // (the marks of the repairs that were made stay: those candidates are up to date already and will not be seen to change)
+      lz77_qspec_candidates(P_, B_, Q_, S_, &geo, dirty_dev);
+      dev_d2h(dirty.data(), dirty_dev, nseg);
+      repaired = false;
+    }
+    if (repaired) incremental_rounds++;
     uint32_t count = 0, by_entry = 0;
     for (uint32_t k = 0; k < nseg; ++k) {
       if (!dirty_entry_[k] && !dirty[k]) continue;
@@ -1796,7 +1827,11 @@ void Lz77Stage::RunQuickSpec() {
       R.up_entries[count] = entries_[k];
       ++count;
     }
-    if (debug) fprintf(stderr, "quick round %u: %u of %u segments to parse again (%u for their entry)\n", round, count, nseg, by_entry);
+    if (debug) {
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+      fprintf(stderr, "quick round %u: %u of %u segments to parse again (%u for their entry), %.2f ms into the parse%s\n", round, count, nseg, by_entry, ms,
+              repaired ? " [repaired]" : " [all]");
+    }
     if (count == 0) {
       settled = true;
       break;
@@ -1806,11 +1841,17 @@ void Lz77Stage::RunQuickSpec() {
     dev_h2d(list_dev, R.up_index.data(), (size_t)count * 4);
     dev_h2d(up_entries_dev, R.up_entries.data(), (size_t)count * sizeof(SegEntry));
     lz77_scatter_entries(B_, list_dev, up_entries_dev, count);
-    lz77_qspec_parse(P_, B_, Q_, S_, which, list_dev, count);
+    lz77_qspec_parse(P_, B_, Q_, S_, list_dev, count);
     lz77_qspec_gather_exits(B_, list_dev, count, got_exits_dev);
+    diffed = !never_incremental;
+    if (diffed) {
+      lz77_qspec_diff(P_, B_, Q_, S_, list_dev, count);
+      dev_d2h_async(chg_count.data(), S_.chg_count, 64);
+    }
     dev_d2h(R.got_exits.data(), got_exits_dev, (size_t)count * sizeof(SegExit));
     for (uint32_t i = 0; i < count; ++i) exits_[R.up_index[i]] = R.got_exits[i];
   }
+  stats_.incremental_ranks += incremental_rounds;
   stamp("qs-settled");
   dev_free(geo_tables);
   dev_free(dirty_dev);

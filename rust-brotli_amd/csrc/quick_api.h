@@ -63,9 +63,15 @@ struct QuickSpec {
   uint32_t* ev_of = nullptr;     // [events] inverse: index of event id
   uint32_t* slot_first = nullptr;  // [slots + 2] first event of every slot
   uint32_t* qrank = nullptr;     // [n * sweep] index of the first event of slot key(p) + j whose position is >= p
-  uint32_t* act = nullptr;       // [events + 1] per round: index + 1 of the active events, max-scanned (exclusive)
-  uint32_t* val = nullptr;       // [events] per round: what an active event filed
-  uint32_t* cand[2] = {nullptr, nullptr};  // [n * sweep] candidates of every position, double buffered
+  uint32_t* actraw = nullptr;    // [events] index + 1 of the active events, 0 for the others (from the flags)
+  uint32_t* act = nullptr;       // [events] actraw max-scanned (inclusive): the latest active event at or in front of every event
+  uint32_t* val = nullptr;       // [events] what an active event filed
+  uint8_t* flags_prev = nullptr; // [n + 64] the flags actraw / act / cand stand for
+  uint32_t* chg_list = nullptr;  // [chg_cap] incremental update: the events whose activity or value changed
+  uint32_t* chg_range = nullptr; // [3 * chg_cap] per listed event: its slot and the positions (lo, hi] whose rank in it lies behind a changed scan entry
+  uint32_t* chg_count = nullptr; // [16] [0] changed events (may exceed chg_cap: then the list is useless), [1] a walk gave up
+  uint32_t chg_cap = 0;
+  uint32_t* cand = nullptr;      // [n * sweep] candidates of every position
   uint8_t* flags = nullptr;      // [n + 64]
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -80,10 +86,21 @@ void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
 // a block in front of a block of >= 7 bytes are filed when that block starts (StitchToPreviousBlock), the last 7 of a block not
 // otherwise; everything else is assumed filed by a search
 void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start);
-// cand[out] from the flags; geo != nullptr: dirty[k] = 1 for the chains that searched a position whose candidates differ from cand[out ^ 1]
-void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int out, const SegGeometry* geo, uint8_t* dirty_dev);
-// the listed segments (list_dev == nullptr: all of them), each from B.entries[k], with cand[which]: flags, commands, B.exits[k]
-void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int which, const uint32_t* list_dev, uint32_t count);
+// cand from the flags, every position (flags_prev := flags); geo != nullptr: dirty[k] = 1 for the chains that searched a position one of
+// whose candidates changed in a way that can matter (qs_change_matters)
+void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const SegGeometry* geo, uint8_t* dirty_dev);
+// The same after a launch over a few segments, in two steps, with work in proportion to the changes instead of the text.
+// lz77_qspec_diff: the flags of the listed segments against flags_prev -- the events whose activity or value changed are switched
+// and listed (S.chg_count[0], S.chg_list), flags_prev brought up to date.  lz77_qspec_repair(count): for every listed event the scan
+// entries from it up to the next active event of its slot are rewritten (from actraw alone: repairs that overlap write the same
+// values), then the candidates of the positions whose rank in that slot lies in the rewritten stretch -- found in the 2 sweep - 1
+// slots that hold the own-offset events of positions looking into it -- are derived again and compared.  A walk over more than
+// kQsWalkCap inactive events gives up (S.chg_count[1]): the caller takes the pass over everything then, as when the list overflowed.
+void lz77_qspec_diff(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count);
+void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t changed, const SegGeometry& geo, uint8_t* dirty_dev);
+static constexpr uint32_t kQsWalkCap = 1u << 14;
+// the listed segments (list_dev == nullptr: all of them), each from B.entries[k]: flags, commands, B.exits[k]
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count);
 // out[i] = B.exits[list[i]] for i < count (list rounds move only what was parsed)
 void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, SegExit* out_dev);
 // the hasher as the reference would leave it behind the text (J.table: slots from the flags; the books are the caller's)

@@ -56,31 +56,118 @@ BR_DEV uint32_t qs_rank_in_slot(const QuickJob& J, const uint32_t* ev_id, uint32
   }
   return lo;
 }
-// per round, position q: its two potential filings switched on / off
+// event index of the filing (q, off): the position's own-offset event or (sweep > 1) the displaced one
+BR_DEV uint32_t qs_event_of(const QuickJob& J, const QuickSpec& S, uint32_t q, uint32_t off) {
+  if (J.sweep == 1) return S.ev_of[q];
+  return S.ev_of[2u * q + (off != ((q >> 3) & (J.sweep - 1u)) ? 1u : 0u)];
+}
+// the pass over everything, position q: its potential filings switched on / off
 BR_DEV void qs_item_activate(const QuickJob& J, const Lz77Params& P, const QuickSpec& S, uint32_t q) {
   const uint8_t f = S.flags[q];
+  S.flags_prev[q] = f;
   uint32_t value, off;
   qs_filing(J, P, q, f, &value, &off);
   const bool stored = (f & kQsStored) != 0;
   if (J.sweep == 1) {
     const uint32_t e = S.ev_of[q];
-    S.act[e] = stored ? e + 1u : 0u;
+    S.actraw[e] = stored ? e + 1u : 0u;
     S.val[e] = value;
     return;
   }
   const bool displaced = off != ((q >> 3) & (J.sweep - 1u));
   const uint32_t e0 = S.ev_of[2u * q], e1 = S.ev_of[2u * q + 1u];
-  S.act[e0] = (stored && !displaced) ? e0 + 1u : 0u;
+  S.actraw[e0] = (stored && !displaced) ? e0 + 1u : 0u;
   S.val[e0] = value;
-  S.act[e1] = (stored && displaced) ? e1 + 1u : 0u;
+  S.actraw[e1] = (stored && displaced) ? e1 + 1u : 0u;
   S.val[e1] = value;
 }
-// candidate j of position p (after the max-scan of act): the value of the latest active event in front of p's rank in slot
-// key(p) + j; 0 = the zeroed table (encode.rs:1147), which IS a candidate: text position 0
+// candidate j of position p: the value of the latest active event in front of p's rank in slot key(p) + j (act: inclusive max-scan
+// of actraw, over everything or over the slot alone); none = the zeroed table (encode.rs:1147), which IS a candidate: text position 0
 BR_DEV uint32_t qs_candidate(const QuickJob& J, const QuickSpec& S, uint32_t slot, uint32_t rank) {
-  const uint32_t e = S.act[rank];
-  if (e == 0 || S.ev_slot[e - 1u] != slot) return 0u;
+  if (rank == 0) return 0u;
+  const uint32_t e = S.act[rank - 1u];
+  if (e == 0 || e - 1u < S.slot_first[slot]) return 0u;
   return S.val[e - 1u];
+}
+// incremental update, position q of a segment that was parsed again: if its filing changed the events are switched and handed to `mark`
+template <typename Mark>
+BR_DEV void qs_item_diff(const QuickJob& J, const Lz77Params& P, const QuickSpec& S, uint32_t q, Mark mark) {
+  const uint8_t f = S.flags[q], g = S.flags_prev[q];
+  if (f == g) return;
+  S.flags_prev[q] = f;
+  const uint8_t filing_bits = (uint8_t)(kQsStored | kQsQuad | 0x18u);
+  if (((f ^ g) & filing_bits) == 0) return;
+  uint32_t v_new, off_new, v_old, off_old;
+  qs_filing(J, P, q, f, &v_new, &off_new);
+  qs_filing(J, P, q, g, &v_old, &off_old);
+  const bool s_new = (f & kQsStored) != 0, s_old = (g & kQsStored) != 0;
+  if (!s_new && !s_old) return;
+  const uint32_t e_new = qs_event_of(J, S, q, off_new), e_old = qs_event_of(J, S, q, off_old);
+  if (s_old && s_new && e_old == e_new && v_old == v_new) return;
+  if (s_old) {
+    S.actraw[e_old] = 0u;
+    if (!(s_new && e_new == e_old)) mark(e_old);
+  }
+  if (s_new) {
+    S.actraw[e_new] = e_new + 1u;
+    S.val[e_new] = v_new;
+    mark(e_new);
+  }
+}
+// incremental update, listed event n: the scan entries from it up to the next active event of its slot, from actraw alone; the slot
+// and the positions (lo, hi] whose candidate in that slot reads a rewritten entry go to chg_range.  false: a walk gave up.
+BR_DEV bool qs_item_repair(const QuickJob& J, const QuickSpec& S, uint32_t n) {
+  const uint32_t e = S.chg_list[n];
+  const uint32_t slot = S.ev_slot[e];
+  const uint32_t lo = S.slot_first[slot], hi = S.slot_first[slot + 1];
+  uint32_t v = S.actraw[e];
+  uint32_t steps = 0;
+  if (v == 0) {
+    for (uint32_t i = e; i > lo;) {
+      --i;
+      const uint32_t a = S.actraw[i];
+      if (a != 0) {
+        v = a;
+        break;
+      }
+      if (++steps > kQsWalkCap) return false;
+    }
+  }
+  uint32_t i = e;
+  S.act[i] = v;
+  ++i;
+  while (i < hi && S.actraw[i] == 0) {
+    S.act[i] = v;
+    ++i;
+    if (++steps > kQsWalkCap) return false;
+  }
+  S.chg_range[3u * n] = slot;
+  S.chg_range[3u * n + 1u] = qs_event_position(J, S.ev_id[e]);
+  S.chg_range[3u * n + 2u] = i < hi ? qs_event_position(J, S.ev_id[i]) : 0xffffffffu;
+  return true;
+}
+// incremental update, listed event n and slot `t` of the 2 sweep - 1 around its own: the positions in (lo, hi] whose own-offset event
+// lies in t and that look into the event's slot get that candidate derived again; `changed(p, was, now)` for those that differ
+template <typename Changed>
+BR_DEV void qs_item_recand(const QuickJob& J, const QuickSpec& S, uint32_t n, uint32_t t, Changed changed) {
+  const uint32_t slot = S.chg_range[3u * n], p_lo = S.chg_range[3u * n + 1u], p_hi = S.chg_range[3u * n + 2u];
+  const uint32_t hi = S.slot_first[t + 1];
+  uint32_t i = p_lo == 0xffffffffu ? hi : qs_rank_in_slot(J, S.ev_id, S.slot_first[t], hi, p_lo + 1u);
+  for (; i < hi; ++i) {
+    const uint32_t id = S.ev_id[i];
+    const uint32_t p = qs_event_position(J, id);
+    if (p > p_hi) break;
+    if (J.sweep != 1 && (id & 1u)) continue;
+    const uint32_t key = t - ((p >> 3) & (J.sweep - 1u));
+    const uint32_t j = slot - key;  // (wraps when the key lies behind the slot)
+    if (j >= J.sweep) continue;
+    const size_t item = (size_t)p * J.sweep + j;
+    const uint32_t c = qs_candidate(J, S, slot, S.qrank[item]);
+    const uint32_t was = S.cand[item];
+    if (c == was) continue;
+    S.cand[item] = c;
+    changed(p, was, c);
+  }
 }
 
 // A candidate of position p changed.  The chains that looked at it: the chain of p's segment if p carries the searched flag, and for
@@ -97,6 +184,23 @@ BR_DEV void qs_note_changed(const QuickSpec& S, uint32_t p, const SegGeometry& g
   if (k >= geo.block_first_segment[blk + 1]) k = geo.block_first_segment[blk + 1] - 1;
   if (S.flags[p] & kQsSearched) dirty[k] = 1;
   if (k > first && off - (k - first) * seg_bytes < 8) dirty[k - 1] = 1;
+}
+
+// Can it matter to the search at position p which of two values a slot holds?  A hasher with several slots per key (H3, H4, H54)
+// skips a candidate that fails a test (mod.rs:391-440) and consults the static dictionary only when nothing was found, so a candidate
+// takes part only if it lies inside the window and starts with the four bytes at p (FindMatchLengthWithLimitMin4,
+// static_dict.rs:134-147): a change between two values that both fail that is no change.  The single-slot hasher (H2) RETURNS on a
+// failed distance or quick-reject test without consulting the dictionary (mod.rs:359-390), so there the value shows in the books of
+// the throttle even when it matches nothing -- unless the dictionary is not consulted at all.
+BR_DEV bool qs_candidate_plausible(const Lz77Params& P, const uint8_t* text, uint32_t p, uint32_t v) {
+  const uint32_t backward = p - v;
+  const uint32_t max_backward = p < P.max_backward_limit ? p : P.max_backward_limit;
+  if (backward == 0 || backward > max_backward) return false;
+  return br_load32(text + v) == br_load32(text + p);
+}
+BR_DEV bool qs_change_matters(const QuickJob& J, const Lz77Params& P, const uint8_t* text, uint32_t p, uint32_t old_value, uint32_t new_value) {
+  if (J.sweep == 1 && J.use_dictionary) return true;
+  return qs_candidate_plausible(P, text, p, old_value) || qs_candidate_plausible(P, text, p, new_value);
 }
 
 // First guess of the flag of position q (lz77_qspec_init_flags): a custom dictionary is filed position by position but for its

@@ -81,21 +81,21 @@ void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const Quic
   HIP_CHECK(hipGetLastError());
 }
 
-// ---- candidates (per round) ---------------------------------------------------------------------------------------------------
+// ---- candidates: the pass over everything --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_qs_activate(QuickJob J, Lz77Params P, QuickSpec S) {
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
   if (q < S.n) qs_item_activate(J, P, S, q);
-  if (q == 0) S.act[S.events] = 0u;
 }
 
-// exclusive max-scan of a uint32 array in place (the pattern of device_scan.h with max for +)
+// max-scan of a uint32 array (the pattern of device_scan.h with max for +): dst[i] = max(src[0 .. i]) (inclusive) or max(src[0 .. i - 1])
 static constexpr uint32_t kQsScanTile = 1024;
-__global__ __launch_bounds__(256) void k_qs_maxscan_tiles(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ tile_max) {
+__global__ __launch_bounds__(256) void k_qs_maxscan_tiles(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n, uint32_t* __restrict__ tile_max,
+                                                          bool inclusive) {
   __shared__ uint32_t wave_max[4];
   const uint32_t base = blockIdx.x * kQsScanTile + threadIdx.x * 4;
   uint32_t v[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = (base + j < n) ? data[base + j] : 0u;
+  for (int j = 0; j < 4; ++j) v[j] = (base + j < n) ? src[base + j] : 0u;
   const uint32_t local = max(max(v[0], v[1]), max(v[2], v[3]));
   uint32_t x = local;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -108,12 +108,13 @@ __global__ __launch_bounds__(256) void k_qs_maxscan_tiles(uint32_t* __restrict__
   __syncthreads();
   uint32_t before = 0;
   for (int i = 0; i < w; ++i) before = max(before, wave_max[i]);
-  uint32_t up = __shfl_up(x, 1, 64);
-  uint32_t excl = max(before, lane == 0 ? 0u : up);
+  const uint32_t up = __shfl_up(x, 1, 64);
+  uint32_t run = max(before, lane == 0 ? 0u : up);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (base + j < n) data[base + j] = excl;
-    excl = max(excl, v[j]);
+    const uint32_t incl = max(run, v[j]);
+    if (base + j < n) dst[base + j] = inclusive ? incl : run;
+    run = incl;
   }
   if (threadIdx.x == 255 && tile_max) tile_max[blockIdx.x] = max(before, x);
 }
@@ -124,32 +125,85 @@ __global__ __launch_bounds__(256) void k_qs_maxscan_add(uint32_t* __restrict__ d
   for (int j = 0; j < 4; ++j)
     if (base + j < n) data[base + j] = max(data[base + j], add);
 }
-static void qs_exclusive_maxscan(uint32_t* data, uint32_t n, uint32_t* scratch) {
+static void qs_maxscan(const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t* scratch, bool inclusive) {
   if (n == 0) return;
   const uint32_t tiles = (n + kQsScanTile - 1) / kQsScanTile;
-  hipLaunchKernelGGL(k_qs_maxscan_tiles, dim3(tiles), dim3(256), 0, BR_STREAM, data, n, tiles > 1 ? scratch : (uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_qs_maxscan_tiles, dim3(tiles), dim3(256), 0, BR_STREAM, src, dst, n, tiles > 1 ? scratch : (uint32_t*)nullptr, inclusive);
   if (tiles > 1) {
-    qs_exclusive_maxscan(scratch, tiles, scratch + tiles);
-    hipLaunchKernelGGL(k_qs_maxscan_add, dim3(tiles), dim3(256), 0, BR_STREAM, data, n, scratch);
+    qs_maxscan(scratch, scratch, tiles, scratch + tiles, false);
+    hipLaunchKernelGGL(k_qs_maxscan_add, dim3(tiles), dim3(256), 0, BR_STREAM, dst, n, (const uint32_t*)scratch);
   }
 }
 
-__global__ __launch_bounds__(256) void k_qs_candidates(QuickJob J, QuickSpec S, const uint8_t* __restrict__ text, int out, bool compare, SegGeometry geo,
+__global__ __launch_bounds__(256) void k_qs_candidates(QuickJob J, Lz77Params P, QuickSpec S, const uint8_t* __restrict__ text, bool compare, SegGeometry geo,
                                                        uint8_t* __restrict__ dirty) {
   const uint64_t item = (uint64_t)blockIdx.x * 256u + threadIdx.x;
   if (item >= (uint64_t)S.n * J.sweep) return;
   const uint32_t p = (uint32_t)(item / J.sweep), j = (uint32_t)(item % J.sweep);
   const uint32_t c = qs_candidate(J, S, qs_hash(J, text + p) + j, S.qrank[item]);
-  S.cand[out][item] = c;
-  if (compare && c != S.cand[out ^ 1][item]) qs_note_changed(S, p, geo, dirty);
+  if (compare) {
+    const uint32_t was = S.cand[item];
+    if (c == was) return;
+    if (qs_change_matters(J, P, text, p, was, c)) qs_note_changed(S, p, geo, dirty);
+  }
+  S.cand[item] = c;
 }
 
-void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int out, const SegGeometry* geo, uint8_t* dirty_dev) {
+void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const SegGeometry* geo, uint8_t* dirty_dev) {
   hipLaunchKernelGGL(k_qs_activate, dim3(qs_blocks(S.n)), dim3(256), 0, BR_STREAM, J, P, S);
-  qs_exclusive_maxscan(S.act, S.events + 1u, S.scan_tmp);
+  qs_maxscan(S.actraw, S.act, S.events, S.scan_tmp, true);
   SegGeometry g{};
   if (geo) g = *geo;
-  hipLaunchKernelGGL(k_qs_candidates, dim3(qs_blocks((uint64_t)S.n * J.sweep)), dim3(256), 0, BR_STREAM, J, S, (const uint8_t*)B.text, out, geo != nullptr, g, dirty_dev);
+  hipLaunchKernelGGL(k_qs_candidates, dim3(qs_blocks((uint64_t)S.n * J.sweep)), dim3(256), 0, BR_STREAM, J, P, S, (const uint8_t*)B.text, geo != nullptr, g, dirty_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- candidates: in proportion to the changes ---------------------------------------------------------------------------------------
+// one wavefront per segment that was parsed again: its flags against the ones the candidates stand for
+__global__ __launch_bounds__(64) void k_qs_diff(QuickJob J, Lz77Params P, QuickSpec S, const Segment* __restrict__ segments, const uint32_t* __restrict__ list,
+                                                uint32_t count) {
+  if (blockIdx.x >= count) return;
+  const Segment seg = segments[list[blockIdx.x]];
+  auto mark = [&](uint32_t e) {
+    const uint32_t at = atomicAdd(&S.chg_count[0], 1u);
+    if (at < S.chg_cap) S.chg_list[at] = e;
+  };
+  for (uint32_t q = seg.start + threadIdx.x; q < seg.end; q += 64u) qs_item_diff(J, P, S, q, mark);
+}
+void lz77_qspec_diff(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count) {
+  HIP_CHECK(hipMemsetAsync(S.chg_count, 0, 64, BR_STREAM));
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_qs_diff, dim3(count), dim3(64), 0, BR_STREAM, J, P, S, (const Segment*)B.segments, list_dev, count);
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void k_qs_repair(QuickJob J, QuickSpec S, uint32_t changed) {
+  const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+  if (n >= changed) return;
+  if (!qs_item_repair(J, S, n)) {
+    S.chg_count[1] = 1u;
+    S.chg_range[3u * n + 1u] = 0xffffffffu;  // (nothing to derive again: the caller takes the pass over everything)
+    S.chg_range[3u * n + 2u] = 0u;
+    S.chg_range[3u * n] = S.ev_slot[S.chg_list[n]];
+  }
+}
+__global__ __launch_bounds__(256) void k_qs_recand(QuickJob J, Lz77Params P, QuickSpec S, const uint8_t* __restrict__ text, uint32_t changed, SegGeometry geo,
+                                                   uint8_t* __restrict__ dirty) {
+  const uint32_t around = 2u * J.sweep - 1u;
+  const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+  if (item >= changed * around) return;
+  const uint32_t n = item / around, d = item % around;
+  const uint32_t slot = S.chg_range[3u * n];
+  if (slot + d < J.sweep - 1u) return;
+  const uint32_t t = slot + d - (J.sweep - 1u);
+  if (t >= S.slots) return;
+  qs_item_recand(J, S, n, t, [&](uint32_t p, uint32_t was, uint32_t now) {
+    if (qs_change_matters(J, P, text, p, was, now)) qs_note_changed(S, p, geo, dirty);
+  });
+}
+void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t changed, const SegGeometry& geo, uint8_t* dirty_dev) {
+  if (changed == 0) return;
+  hipLaunchKernelGGL(k_qs_repair, dim3(qs_blocks(changed)), dim3(256), 0, BR_STREAM, J, S, changed);
+  hipLaunchKernelGGL(k_qs_recand, dim3(qs_blocks((uint64_t)changed * (2u * J.sweep - 1u))), dim3(256), 0, BR_STREAM, J, P, S, (const uint8_t*)B.text, changed, geo, dirty_dev);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -161,11 +215,11 @@ __global__ __launch_bounds__(64) void k_qs_parse(QuickJob J, Lz77Params P, QsTab
   const Segment seg = segments[k];
   br_quick_segment(J, P, T, seg, entries[k], cmds + seg.cmd_base, exits + k);
 }
-void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int which, const uint32_t* list_dev, uint32_t count) {
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count) {
   if (count == 0) return;
   QsTables T;
   T.text = B.text;
-  T.cand = S.cand[which];
+  T.cand = S.cand;
   T.flags = S.flags;
   T.dict = qspec_dict_tables();
   hipLaunchKernelGGL(k_qs_parse, dim3(count), dim3(64), 0, BR_STREAM, J, P, T, (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds, B.exits, list_dev, count);

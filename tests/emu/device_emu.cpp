@@ -885,28 +885,61 @@ void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
 void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start) {
   for (uint32_t q = 0; q < P.total_bytes; ++q) S.flags[q] = qs_initial_flag(P, q, first_block_start);
 }
-void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int out, const SegGeometry* geo, uint8_t* dirty) {
+void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const SegGeometry* geo, uint8_t* dirty) {
   for (uint32_t q = 0; q < S.n; ++q) qs_item_activate(J, P, S, q);
-  S.act[S.events] = 0;
   uint32_t running = 0;
-  for (uint32_t i = 0; i <= S.events; ++i) {  // exclusive max-scan
-    const uint32_t v = S.act[i];
+  for (uint32_t i = 0; i < S.events; ++i) {  // inclusive max-scan
+    running = std::max(running, S.actraw[i]);
     S.act[i] = running;
-    running = std::max(running, v);
   }
   for (uint32_t p = 0; p < S.n; ++p)
     for (uint32_t j = 0; j < J.sweep; ++j) {
       const size_t item = (size_t)p * J.sweep + j;
       const uint32_t c = qs_candidate(J, S, qs_hash(J, B.text + p) + j, S.qrank[item]);
-      S.cand[out][item] = c;
-      if (geo != nullptr && c != S.cand[out ^ 1][item]) qs_note_changed(S, p, *geo, dirty);
+      if (geo != nullptr) {
+        const uint32_t was = S.cand[item];
+        if (c == was) continue;
+        if (qs_change_matters(J, P, B.text, p, was, c)) qs_note_changed(S, p, *geo, dirty);
+      }
+      S.cand[item] = c;
     }
 }
-void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, int which, const uint32_t* list, uint32_t count) {
+void lz77_qspec_diff(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list, uint32_t count) {
+  S.chg_count[0] = S.chg_count[1] = 0;
+  auto mark = [&](uint32_t e) {
+    const uint32_t at = S.chg_count[0]++;
+    if (at < S.chg_cap) S.chg_list[at] = e;
+  };
+  for (uint32_t i = 0; i < count; ++i) {
+    const Segment& seg = B.segments[list[i]];
+    for (uint32_t q = seg.start; q < seg.end; ++q) qs_item_diff(J, P, S, q, mark);
+  }
+}
+void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t changed, const SegGeometry& geo, uint8_t* dirty) {
+  for (uint32_t n = 0; n < changed; ++n)
+    if (!qs_item_repair(J, S, n)) {
+      S.chg_count[1] = 1;
+      S.chg_range[3u * n] = S.ev_slot[S.chg_list[n]];
+      S.chg_range[3u * n + 1u] = 0xffffffffu;
+      S.chg_range[3u * n + 2u] = 0u;
+    }
+  const uint32_t around = 2u * J.sweep - 1u;
+  for (uint32_t n = 0; n < changed; ++n)
+    for (uint32_t d = 0; d < around; ++d) {
+      const uint32_t slot = S.chg_range[3u * n];
+      if (slot + d < J.sweep - 1u) continue;
+      const uint32_t t = slot + d - (J.sweep - 1u);
+      if (t >= S.slots) continue;
+      qs_item_recand(J, S, n, t, [&](uint32_t p, uint32_t was, uint32_t now) {
+        if (qs_change_matters(J, P, B.text, p, was, now)) qs_note_changed(S, p, geo, dirty);
+      });
+    }
+}
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list, uint32_t count) {
   const DeviceTables& dt = dev_tables();
   QsTables T;
   T.text = B.text;
-  T.cand = S.cand[which];
+  T.cand = S.cand;
   T.flags = S.flags;
   T.dict.dict_hash = dt.dict_hash;
   T.dict.dict_data = dt.dict_data;
