@@ -175,12 +175,14 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     // segment per input block; none of the sort / row / rank structures of the speculative path exist.
     use_live_ = use_rows_ = false;
     P_.htl = 8;
-    // A stream that comes in one piece (no hasher state in front of it, none behind a partial piece) takes the speculative path
-    // (quick_spec.h): the segments of a block side by side on candidates derived from per-position flags, the resolver over
-    // their exits as for qualities 5-9.  Everything else walks the reference's own table block by block (quick_device.h).
-    // BROTLI_MI355X_QUICK_SERIAL=1 keeps every call on the table (test aid).
-    use_qspec_ = !(carry_ && carry_->valid) && !partial_ && getenv("BROTLI_MI355X_QUICK_SERIAL") == nullptr && input_bytes >= 64 &&
-                 (uint64_t)P_.total_bytes * 2 < 0xfffffff0ull;
+    // The speculative path (quick_spec.h): the segments of a block side by side on candidates derived from per-position flags, the
+    // resolver over their exits as for qualities 5-9.  A later piece of a stream brings the table of the piece in front as what
+    // every slot holds before this text files anything (QuickSpec::base); the table behind the piece -- or, for a partial piece,
+    // in front of the block that opens the meta-block still open -- is derived from the flags (ExportQuick).  The walk over the
+    // reference's own table block by block (quick_device.h) stays as the fall-back for inputs that do not settle, for inputs of
+    // less than 64 bytes, and as a test aid (BROTLI_MI355X_QUICK_SERIAL=1).
+    use_qspec_ = getenv("BROTLI_MI355X_QUICK_SERIAL") == nullptr && input_bytes >= 64 && (uint64_t)P_.total_bytes * 2 < 0xfffffff0ull;
+    qspec_books_in_ = false;
     qspec_params_ = params;
     qspec_text_ = text_dev;
     qspec_prefix_ = prefix_bytes;
@@ -827,6 +829,13 @@ bool Lz77Stage::ResolvePass(bool final_pass, bool incremental) {
     dict.L = carry_->dict_lookups;
     dict.M = carry_->dict_matches;
     if (carry_->dict_dead) dict.state = DictTracker::kDead;
+  }
+  if (use_qspec_ && qspec_books_in_) {
+    // qualities 2 .. 4: the books travel behind the slots of the table (the piece in front may have walked it the serial way, with no
+    // tracker); whether the throttle has tripped is a function of the two counters (mod.rs:1957-1960)
+    dict.L = qspec_lookups_;
+    dict.M = qspec_matches_;
+    dict.state = dict.M < (dict.L >> 7) ? DictTracker::kDead : DictTracker::kAlive;
   }
   struct LastCmd {
     bool valid = false;
@@ -1673,21 +1682,37 @@ QuickCarry::~QuickCarry() { dev_free(table); }
 void Lz77Stage::ExportQuick(StreamCarry* co, bool partial) {
   auto qc = std::make_shared<QuickCarry>();
   qc->text_base = (carry_ && carry_->valid) ? carry_->stream_base : 0;
+  if (use_qspec_) {
+    // The speculative path kept no table: the slots as the reference's hold them behind the text -- or, for a partial piece, in front
+    // of the block at the resume point, before that block's StitchToPreviousBlock files the three positions in front of it (the next
+    // piece does that itself) -- from the final flags.  The books of the throttle behind the slots: the resolver's, as the encoder
+    // has put them into the carry (once the throttle has tripped only "matches < lookups >> 7" matters: nothing is looked up any more).
+    uint32_t* table = (uint32_t*)dev_alloc_uninit((size_t)quick_table_words(Q_) * 4 + 64);
+    const uint32_t first = segments_.empty() ? P_.total_bytes : segments_[0].blk_start;
+    uint32_t upto = 0xffffffffu;
+    if (partial) upto = resume_pos_ >= 3 ? resume_pos_ - 3 : 0;
+    lz77_qspec_table(P_, B_, Q_, S_, upto, table);
+    uint32_t books[16] = {0};
+    if (partial && resume_pos_ <= first) {
+      // (nothing of this piece lies in front of the resume point: the books it came in with)
+      books[0] = qspec_books_in_ ? qspec_lookups_ : 0u;
+      books[1] = qspec_books_in_ ? qspec_matches_ : 0u;
+    } else {
+      books[0] = co->dict_dead ? DictTracker::kDeadL : co->dict_lookups;
+      books[1] = co->dict_dead ? DictTracker::kDeadM : co->dict_matches;
+    }
+    if (!Q_.use_dictionary) books[0] = books[1] = 0;
+    dev_h2d(table + quick_books_at(Q_), books, sizeof(books));
+    dev_sync();
+    qc->table = table;
+    co->quick = std::move(qc);
+    return;
+  }
   if (partial) {
     if (!qsnap_table_) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4: no snapshot of the hash table at the resume point");
     qc->table = qsnap_table_;
     qsnap_table_ = nullptr;
   } else {
-    if (use_qspec_) {
-      // the speculative path kept no table: what the reference's would hold behind the text, from the final flags; the books of
-      // the throttle behind the slots (once it has tripped only "matches < lookups >> 7" matters: nothing is looked up any more)
-      lz77_qspec_table(P_, B_, Q_, S_);
-      uint32_t books[16] = {0};
-      books[0] = final_dict_dead_ ? DictTracker::kDeadL : final_dict_lookups_;
-      books[1] = final_dict_dead_ ? DictTracker::kDeadM : final_dict_matches_;
-      dev_h2d(Q_.table + quick_books_at(Q_), books, sizeof(books));
-      dev_sync();
-    }
     qc->table = Q_.table;
     Q_.table = nullptr;
   }
@@ -1751,8 +1776,29 @@ void Lz77Stage::RunQuickSpec() {
   resolve_incremental_ = false;
   const auto t_begin = std::chrono::steady_clock::now();
   InitEntries();
+  const bool continuing = carry_ && carry_->valid;
+  S_.base = nullptr;
+  qspec_books_in_ = false;
+  if (continuing && carry_->quick) {
+    // a later piece: the table of the piece in front, moved to this piece's text positions, is what the slots hold to begin with; the
+    // books of the throttle sit behind its slots
+    const QuickCarry& qc = *carry_->quick;
+    if (carry_->stream_base < qc.text_base) throw std::runtime_error("brotli_mi355x: qualities 2 .. 4: the carried hash table does not fit this piece");
+    lz77_quick_import(Q_, qc.table, (uint32_t)(carry_->stream_base - qc.text_base));
+    S_.base = Q_.table;
+    uint32_t books[2] = {0, 0};
+    dev_d2h(books, Q_.table + quick_books_at(Q_), sizeof(books));
+    qspec_books_in_ = true;
+    qspec_lookups_ = books[0];
+    qspec_matches_ = books[1];
+    if (P_.use_dictionary) {
+      entries_[0].dict_lookups = books[0];
+      entries_[0].dict_matches = books[1];
+      entries_[0].dict_exact = 1;
+    }
+  }
   lz77_qspec_index(P_, B_, Q_, S_);
-  lz77_qspec_init_flags(P_, B_, Q_, S_, segments_[0].blk_start);
+  lz77_qspec_init_flags(P_, B_, Q_, S_, segments_[0].blk_start, !continuing);
   lz77_qspec_candidates(P_, B_, Q_, S_, nullptr, nullptr);
   SegGeometry geo{};
   geo.prefix_bytes = P_.prefix_bytes;

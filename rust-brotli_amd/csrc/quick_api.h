@@ -73,6 +73,7 @@ struct QuickSpec {
   uint32_t chg_cap = 0;
   uint32_t* cand = nullptr;      // [n * sweep] candidates of every position
   uint8_t* flags = nullptr;      // [n + 64]
+  const uint32_t* base = nullptr;  // [slots] what the table held in front of the text (a later piece of a stream); null: zeroed
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   uint32_t* sort_keys_tmp = nullptr;  // [events] scratch of the sort (keys in, ids in)
@@ -85,7 +86,8 @@ void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
 // first guess of the flags: a custom dictionary is filed position by position but for its last 7 bytes, the last three positions of
 // a block in front of a block of >= 7 bytes are filed when that block starts (StitchToPreviousBlock), the last 7 of a block not
 // otherwise; everything else is assumed filed by a search
-void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start);
+// (prefix_is_dictionary = false: the prefix is the stream so far, whose filings are in S.base)
+void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start, bool prefix_is_dictionary);
 // cand from the flags, every position (flags_prev := flags); geo != nullptr: dirty[k] = 1 for the chains that searched a position one of
 // whose candidates changed in a way that can matter (qs_change_matters)
 void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const SegGeometry* geo, uint8_t* dirty_dev);
@@ -103,8 +105,9 @@ static constexpr uint32_t kQsWalkCap = 1u << 14;
 void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count);
 // out[i] = B.exits[list[i]] for i < count (list rounds move only what was parsed)
 void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, SegExit* out_dev);
-// the hasher as the reference would leave it behind the text (J.table: slots from the flags; the books are the caller's)
-void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S);
+// the slots of the hasher as the reference holds them when it has filed every position in front of `upto` that it files (from the
+// flags the candidates stand for; the books of the throttle are the caller's): out[slots].  out may be S.base.
+void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t upto, uint32_t* out);
 
 }  // namespace brotli_mi355x
 #endif

@@ -84,9 +84,8 @@ BR_DEV void qs_item_activate(const QuickJob& J, const Lz77Params& P, const Quick
 // candidate j of position p: the value of the latest active event in front of p's rank in slot key(p) + j (act: inclusive max-scan
 // of actraw, over everything or over the slot alone); none = the zeroed table (encode.rs:1147), which IS a candidate: text position 0
 BR_DEV uint32_t qs_candidate(const QuickJob& J, const QuickSpec& S, uint32_t slot, uint32_t rank) {
-  if (rank == 0) return 0u;
-  const uint32_t e = S.act[rank - 1u];
-  if (e == 0 || e - 1u < S.slot_first[slot]) return 0u;
+  const uint32_t e = rank == 0 ? 0u : S.act[rank - 1u];
+  if (e == 0 || e - 1u < S.slot_first[slot]) return S.base ? S.base[slot] : 0u;  // (a later piece of a stream: what the table held in front of the text)
   return S.val[e - 1u];
 }
 // incremental update, position q of a segment that was parsed again: if its filing changed the events are switched and handed to `mark`
@@ -207,10 +206,10 @@ BR_DEV bool qs_change_matters(const QuickJob& J, const Lz77Params& P, const uint
 // last 7 bytes (encode.rs:1163-1194, mod.rs:224-229); the last three positions in front of a block of >= 7 bytes are filed when
 // that block starts (StitchToPreviousBlock, mod.rs:210-222), the four in front of them never (store_end, mod.rs:2397-2404; a
 // search needs 8 bytes); everything else is assumed filed.
-BR_DEV uint8_t qs_initial_flag(const Lz77Params& P, uint32_t q, uint32_t first_block_start) {
+BR_DEV uint8_t qs_initial_flag(const Lz77Params& P, uint32_t q, uint32_t first_block_start, bool prefix_is_dictionary) {
   const uint32_t total = P.total_bytes, pre = P.prefix_bytes, bb = P.block_bytes;
   if (q < first_block_start) {
-    bool stored = pre > kQuickHtl - 1u && q < pre - (kQuickHtl - 1u);
+    bool stored = prefix_is_dictionary && pre > kQuickHtl - 1u && q < pre - (kQuickHtl - 1u);
     const uint32_t be = total < pre + bb ? total : pre + bb;
     if (be - first_block_start >= kQuickHtl - 1u && first_block_start >= 3 && q + 3 >= first_block_start) stored = true;
     return stored ? kQsStored : (uint8_t)0;

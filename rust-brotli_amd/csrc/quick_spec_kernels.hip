@@ -71,13 +71,13 @@ void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
 }
 
 // ---- flags --------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_qs_init_flags(Lz77Params P, uint8_t* __restrict__ flags, uint32_t first_block_start) {
+__global__ __launch_bounds__(256) void k_qs_init_flags(Lz77Params P, uint8_t* __restrict__ flags, uint32_t first_block_start, bool prefix_is_dictionary) {
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
   if (q >= P.total_bytes) return;
-  flags[q] = qs_initial_flag(P, q, first_block_start);
+  flags[q] = qs_initial_flag(P, q, first_block_start, prefix_is_dictionary);
 }
-void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start) {
-  hipLaunchKernelGGL(k_qs_init_flags, dim3(qs_blocks(P.total_bytes)), dim3(256), 0, BR_STREAM, P, S.flags, first_block_start);
+void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start, bool prefix_is_dictionary) {
+  hipLaunchKernelGGL(k_qs_init_flags, dim3(qs_blocks(P.total_bytes)), dim3(256), 0, BR_STREAM, P, S.flags, first_block_start, prefix_is_dictionary);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -242,13 +242,14 @@ void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list_dev, uin
 }
 
 // ---- the table behind the text (for the next piece of a stream) ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_qs_table(QuickJob J, QuickSpec S) {
+__global__ __launch_bounds__(256) void k_qs_table(QuickJob J, QuickSpec S, uint32_t upto, uint32_t* __restrict__ out) {
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
   if (s >= S.slots) return;
-  J.table[s] = qs_candidate(J, S, s, S.slot_first[s + 1]);
+  const uint32_t lo = S.slot_first[s], hi = S.slot_first[s + 1];
+  out[s] = qs_candidate(J, S, s, upto == 0xffffffffu ? hi : qs_rank_in_slot(J, S.ev_id, lo, hi, upto));
 }
-void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S) {
-  hipLaunchKernelGGL(k_qs_table, dim3(qs_blocks(S.slots)), dim3(256), 0, BR_STREAM, J, S);
+void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t upto, uint32_t* out) {
+  hipLaunchKernelGGL(k_qs_table, dim3(qs_blocks(S.slots)), dim3(256), 0, BR_STREAM, J, S, upto, out);
   HIP_CHECK(hipGetLastError());
 }
 

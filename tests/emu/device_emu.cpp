@@ -882,8 +882,8 @@ void lz77_qspec_index(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
       S.qrank[(size_t)p * J.sweep + j] = qs_rank_in_slot(J, S.ev_id, S.slot_first[s], S.slot_first[s + 1], p);
     }
 }
-void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start) {
-  for (uint32_t q = 0; q < P.total_bytes; ++q) S.flags[q] = qs_initial_flag(P, q, first_block_start);
+void lz77_qspec_init_flags(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t first_block_start, bool prefix_is_dictionary) {
+  for (uint32_t q = 0; q < P.total_bytes; ++q) S.flags[q] = qs_initial_flag(P, q, first_block_start, prefix_is_dictionary);
 }
 void lz77_qspec_candidates(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const SegGeometry* geo, uint8_t* dirty) {
   for (uint32_t q = 0; q < S.n; ++q) qs_item_activate(J, P, S, q);
@@ -953,8 +953,11 @@ void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
 void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list, uint32_t count, SegExit* out) {
   for (uint32_t i = 0; i < count; ++i) out[i] = B.exits[list[i]];
 }
-void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S) {
-  for (uint32_t s = 0; s < S.slots; ++s) J.table[s] = qs_candidate(J, S, s, S.slot_first[s + 1]);
+void lz77_qspec_table(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t upto, uint32_t* out) {
+  for (uint32_t s = 0; s < S.slots; ++s) {
+    const uint32_t lo = S.slot_first[s], hi = S.slot_first[s + 1];
+    out[s] = qs_candidate(J, S, s, upto == 0xffffffffu ? hi : qs_rank_in_slot(J, S.ev_id, lo, hi, upto));
+  }
 }
 
 // ---- qualities 0 and 1 (fragment_device.h): the same item code, called directly, one fragment after the other
