@@ -393,15 +393,15 @@ def quality_2_4_workloads(bm, lib):
     import synth
     res = []
     data = synth.markov_text(2 << 20)
-    quick = "BasicHasher qualities (DESIGN.md section 3.10)"
-    bound = "see DESIGN.md section 3.10"
+    quick = "BasicHasher qualities on the speculative path: segments side by side on candidates derived from per-position flags (DESIGN.md section 3.10)"
+    bound = "rounds of a fixed-point iteration over 512 B .. 2 KiB segments, one wavefront each (DESIGN.md section 3.10)"
     for quality in (2, 3, 4):
-        res.append(_host_call_entry(lib, "q%d_text_2MiB" % quality, data, quality, 22, quick, "k_quick_block", bound))
+        res.append(_host_call_entry(lib, "q%d_text_2MiB" % quality, data, quality, 22, quick, "k_qs_parse", bound))
     q4_rate = res[-1].get("value", 0.0) or 0.0
     if q4_rate >= 30.0:  # (64 MiB at the 2 MiB rate must fit the budget of the side workloads: below 30 MB/s it does not)
         try:
             big = synth.markov_text(64 << 20, 5)
-            res.append(_host_call_entry(lib, "q4_text_64MiB", big, 4, 22, quick, "k_quick_block", bound, reps=1))
+            res.append(_host_call_entry(lib, "q4_text_64MiB", big, 4, 22, quick, "k_qs_parse", bound, reps=2))
             del big
         except Exception as e:
             res.append({"workload": "q4_text_64MiB", "error": repr(e)})
@@ -420,7 +420,7 @@ def quality_2_4_workloads(bm, lib):
                     "residency": "host buffers in and out (BrotliEncoderCompressMulti)", "value": round(len(big) / sec / 1e6, 3), "unit": "MB/s",
                     "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out), "identical_to_cpu_oracle": out == want, "cpu_oracle": col,
                     "vs_cpu_oracle": round(len(big) / sec / 1e6 / col["value"], 3),
-                    "roofline": stream_roofline("k_quick_block", len(big), len(out), sec, bound + "; 16 shards side by side")})
+                    "roofline": stream_roofline("k_qs_parse", len(big), len(out), sec, bound + "; 16 shards side by side")})
     except Exception as e:
         res.append({"workload": "q2_text_16MiB_multi16", "error": repr(e)})
     return res

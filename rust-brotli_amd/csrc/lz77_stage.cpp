@@ -218,7 +218,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
       S_.cand = (uint32_t*)dev_alloc_uninit(N * Q_.sweep * 4 + 64);
       S_.flags = (uint8_t*)dev_alloc_uninit(N + 64);
       S_.flags_prev = (uint8_t*)dev_alloc_uninit(N + 64);
-      S_.chg_cap = (uint32_t)std::max<size_t>(4096, E / 64);
+      S_.chg_cap = (uint32_t)std::max<size_t>(4096, E / (getenv("BROTLI_MI355X_QUICK_CAP_DIV") ? (size_t)atoi(getenv("BROTLI_MI355X_QUICK_CAP_DIV")) : 16));
       S_.chg_list = (uint32_t*)dev_alloc_uninit((size_t)S_.chg_cap * 4 + 64);
       S_.chg_range = (uint32_t*)dev_alloc_uninit((size_t)S_.chg_cap * 12 + 64);
       S_.chg_count = (uint32_t*)dev_alloc(64);
@@ -1797,9 +1797,17 @@ void Lz77Stage::RunQuickSpec() {
       entries_[0].dict_exact = 1;
     }
   }
+  const bool prof_sync = debug && getenv("BROTLI_MI355X_PROFILE") != nullptr;
+  auto lap = [&](const char* what) {
+    if (!prof_sync) return;
+    dev_sync();
+    fprintf(stderr, "quick %s: %.2f ms into the parse\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   lz77_qspec_index(P_, B_, Q_, S_);
+  lap("index");
   lz77_qspec_init_flags(P_, B_, Q_, S_, segments_[0].blk_start, !continuing);
   lz77_qspec_candidates(P_, B_, Q_, S_, nullptr, nullptr);
+  lap("first candidates");
   SegGeometry geo{};
   geo.prefix_bytes = P_.prefix_bytes;
   geo.first_block_start = segments_[0].blk_start;
@@ -1831,6 +1839,7 @@ void Lz77Stage::RunQuickSpec() {
   lz77_qspec_parse(P_, B_, Q_, S_, nullptr, nseg);
   stats_.rounds++;
   stats_.segments_parsed += nseg;
+  lap("round 0 parsed");
   dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
   stamp("qs-round0");
   static const uint32_t kMaxRounds = getenv("BROTLI_MI355X_QUICK_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_ROUNDS")) : 64u;
