@@ -244,6 +244,9 @@ uint64_t LastHasherResetAtOrBelow(uint64_t pos) {
 uint64_t FirstPositionWrap() { return 3ull << WrapShift(); }
 
 uint32_t ChooseSegmentBytes(size_t input_bytes) {
+  const uint32_t forced = getenv("BROTLI_MI355X_SEGMENT_BYTES") ? (uint32_t)atoi(getenv("BROTLI_MI355X_SEGMENT_BYTES")) : 0u;  // (experiments, tests)
+  if (forced) return forced;
+  if (input_bytes <= ((size_t)512 << 10)) return 256;  // (a small call lasts as long as its chains: 152 KB at quality 5 2.51 -> 2.36 ms)
   if (input_bytes <= ((size_t)4 << 20)) return 512;
   if (input_bytes <= ((size_t)16 << 20)) return 1024;
   if (input_bytes <= ((size_t)128 << 20)) return 2048;

@@ -1842,8 +1842,10 @@ void Lz77Stage::RunQuickSpec() {
   lap("round 0 parsed");
   dev_d2h(exits_.data(), B_.exits, (size_t)nseg * sizeof(SegExit));
   stamp("qs-round0");
-  static const uint32_t kMaxRounds = getenv("BROTLI_MI355X_QUICK_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_ROUNDS")) : 64u;
-  static const bool never_incremental = getenv("BROTLI_MI355X_QUICK_NO_INCREMENTAL") != nullptr;
+  // (read per call: the tests switch them)
+  const uint32_t kMaxRounds = getenv("BROTLI_MI355X_QUICK_ROUNDS") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_ROUNDS")) : 64u;
+  const bool never_incremental = getenv("BROTLI_MI355X_QUICK_NO_INCREMENTAL") != nullptr;
+  const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
   // the candidates follow the flags in proportion to the changes when a launch was short and changed few filings (lz77_qspec_diff /
   // _repair), else by the pass over everything
   bool settled = false;
@@ -1908,6 +1910,18 @@ void Lz77Stage::RunQuickSpec() {
   }
   stats_.incremental_ranks += incremental_rounds;
   stamp("qs-settled");
+  if (settled && selftest) {
+    // the candidates as the repairs of the rounds left them against the pass over everything from the final flags
+    const size_t words = (size_t)S_.n * Q_.sweep;
+    std::vector<uint32_t> kept(words), fresh(words);
+    dev_d2h(kept.data(), S_.cand, words * 4);
+    lz77_qspec_candidates(P_, B_, Q_, S_, nullptr, nullptr);
+    dev_d2h(fresh.data(), S_.cand, words * 4);
+    for (size_t i = 0; i < words; ++i)
+      if (kept[i] != fresh[i])
+        throw std::runtime_error("selftest: candidate " + std::to_string(i % Q_.sweep) + " of position " + std::to_string(i / Q_.sweep) + " is " + std::to_string(kept[i]) +
+                                 " after the repairs of " + std::to_string(incremental_rounds) + " rounds, " + std::to_string(fresh[i]) + " from the final flags");
+  }
   dev_free(geo_tables);
   dev_free(dirty_dev);
   dev_free(list_dev);

@@ -255,6 +255,126 @@ BR_DEV uint64_t br_div_u64(uint64_t a, uint64_t b) {
   return a / b;
 }
 
+#if !defined(BROTLI_HOST_EMU)
+// The two passes of BrotliOptimizeHuffmanCountsForRle behind its early exits (entropy_encode.rs:268-345), by all 64 lanes of a
+// wavefront in lock step (round 6: the 704-symbol command code spent 0.17 ms here, one dependent LDS round trip and a division per
+// symbol).  (1) good_for_rle -- runs of >= 5 zeros / >= 7 equal non-zero counts -- from the start and the end of every symbol's run
+// (two scans across the lanes instead of a walk).  (2) The smoothing walk itself is sequential (stride, sum and limit hang on
+// everything in front), but what it READS lies at or behind its position and is never one of its own writes (those go in front of it):
+// the counts and marks are held 64 to a register across the lanes and fetched with v_readlane at the (uniform) position, so a step
+// is arithmetic only; the writes of a collapsed stride go to LDS, a lane per symbol.
+BR_DEV void br_optimize_counts_tail_coop(uint32_t length, uint32_t* counts, uint8_t* good_for_rle) {
+  const uint32_t lane = threadIdx.x & 63u;
+  length = (uint32_t)__builtin_amdgcn_readfirstlane((int)length);
+  const uint32_t chunks = (length + 63u) / 64u;  // <= 11
+  // ---- (1) run start of every symbol (max-scan forward), run end (min-scan backward), the marks
+  uint32_t rs[11];
+  {
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 11; ++c) {
+      rs[c] = 0;
+      if (c >= chunks) continue;
+      const uint32_t i = c * 64u + lane;
+      const uint32_t v = i < length ? counts[i] : 0u;
+      const uint32_t prev = (i != 0 && i < length) ? counts[i - 1] : ~v;
+      uint32_t x = (i < length && (i == 0 || v != prev)) ? i : 0u;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
+        if ((int)lane >= off) x = x > y ? x : y;
+      }
+      x = x > carry ? x : carry;
+      rs[c] = x;
+      carry = (uint32_t)__shfl((int)x, 63, 64);
+    }
+  }
+  uint32_t gv[11];  // the marks, 64 to a register
+  {
+    uint32_t carry = 0xffffffffu;
+#pragma unroll
+    for (int c = 10; c >= 0; --c) {
+      gv[c] = 0;
+      if ((uint32_t)c >= chunks) continue;
+      const uint32_t i = (uint32_t)c * 64u + lane;
+      const uint32_t v = i < length ? counts[i] : 0u;
+      const bool is_end = i < length && (i + 1 == length || counts[i + 1] != v);
+      uint32_t x = is_end ? i : 0xffffffffu;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_down((int)x, off, 64);
+        if ((int)lane + off < 64) x = x < y ? x : y;
+      }
+      x = x < carry ? x : carry;
+      carry = (uint32_t)__shfl((int)x, 0, 64);
+      const uint32_t len = i < length ? x - rs[c] + 1u : 0u;
+      gv[c] = (i < length && ((v == 0 && len >= 5) || (v != 0 && len >= 7))) ? 1u : 0u;
+    }
+  }
+  // ---- (2) the walk
+  uint32_t cv[11];
+#pragma unroll
+  for (uint32_t c = 0; c < 11; ++c) {
+    const uint32_t i = c * 64u + lane;
+    cv[c] = (c < chunks && i < length) ? counts[i] : 0u;
+  }
+  const uint64_t streak_limit = 1240;
+  uint64_t stride = 0;
+  uint64_t limit = 0;
+  uint64_t sum = 0;
+  uint32_t good_prev = 0;
+  // one chunk of 64 positions: its counts and marks in `cur` / `good`, the counts of the chunk behind it in `nxt` (the walk looks two
+  // positions ahead); the position inside the chunk is uniform, so every fetch is one v_readlane with no branch around it
+  auto walk_chunk = [&](uint32_t base, uint32_t cur, uint32_t nxt, uint32_t good) {
+    if (base == 0) {
+      limit = (uint64_t)((uint32_t)(256u * ((uint32_t)__builtin_amdgcn_readlane((int)cur, 0) + (uint32_t)__builtin_amdgcn_readlane((int)cur, 1) +
+                                            (uint32_t)__builtin_amdgcn_readlane((int)cur, 2))) / 3u + 420u);
+    }
+    for (uint32_t l = 0; l < 64u && base + l <= length; ++l) {
+      const uint32_t i = base + l;
+      const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)l);    // (0 behind the last symbol)
+      const uint32_t gi = (uint32_t)__builtin_amdgcn_readlane((int)good, (int)l);
+      if (i == length || gi != 0 || (i != 0 && good_prev != 0) || (uint64_t)(uint32_t)(256u * ci) - limit + streak_limit >= 2 * streak_limit) {
+        if (stride >= 4 || (stride >= 3 && sum == 0)) {
+          uint64_t count = br_div_u64(sum + stride / 2, stride);
+          if (count == 0) count = 1;
+          if (sum == 0) count = 0;
+          for (uint32_t k = lane; k < (uint32_t)stride; k += 64u) counts[i - k - 1] = (uint32_t)count;
+        }
+        stride = 0;
+        sum = 0;
+        if (i + 2 < length) {
+          const uint32_t c1 = l + 1u < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)((l + 1u) & 63u)) : (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)((l + 1u) & 63u));
+          const uint32_t c2 = l + 2u < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)((l + 2u) & 63u)) : (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)((l + 2u) & 63u));
+          limit = (uint64_t)((uint32_t)(256u * (ci + c1 + c2)) / 3u + 420u);
+        } else if (i < length) {
+          limit = (uint64_t)(uint32_t)(256u * ci);
+        } else {
+          limit = 0;
+        }
+      }
+      stride++;
+      if (i != length) {
+        sum += ci;
+        if (stride >= 4) limit = br_div_u64(256 * sum + stride / 2, stride);
+        if (stride == 4) limit += 120;
+      }
+      good_prev = gi;
+    }
+  };
+#pragma unroll
+  for (uint32_t c = 0; c < 11; ++c) {
+    if (c * 64u > length) break;
+    walk_chunk(c * 64u, cv[c], c + 1 < 11 ? cv[c + 1] : 0u, gv[c]);
+  }
+  if (length == 704u) {  // (the closing step i == length of a full alphabet lies behind the last chunk)
+    walk_chunk(704u, 0u, 0u, 0u);
+  }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+}
+#endif
+
 // coop (device): called by all 64 lanes of a wavefront in lock step on the same buffers; the counting passes are shared out
 BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts, uint8_t* good_for_rle, bool coop = false) {
   uint32_t nonzero_count = 0;
@@ -307,12 +427,11 @@ BR_DEV void br_optimize_huffman_counts_for_rle(uint32_t length, uint32_t* counts
     }
     if (nonzeros < 28) return;
   }
-#if !defined(BROTLI_HOST_EMU)
+#if !defined(BROTLI_HOST_EMU) && !defined(BR_NO_COOP_RLE_TAIL)
   if (coop) {
-    for (uint32_t i = threadIdx.x & 63u; i < 704; i += 64) good_for_rle[i] = 0;
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-  } else
+    br_optimize_counts_tail_coop(length, counts, good_for_rle);
+    return;
+  }
 #endif
   for (uint32_t i = 0; i < 704; ++i) good_for_rle[i] = 0;
   {

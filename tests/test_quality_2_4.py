@@ -148,6 +148,46 @@ def test_past_the_ring_and_shards_gpu():
     _past_the_ring_and_shards(test_cabi._load("gpu"), small=True)
 
 
+def _paths(kind, small):
+    """Round 6: the speculative path (quick_spec.h) beside its fall-backs and test switches, every one against the oracle -- the serial
+    walk on the reference's own table (chosen up front, and taken over when the rounds do not settle: one launch allowed), every
+    round on the pass over everything instead of the repairs, and the selftest that compares the repaired candidates with a
+    rebuild from the final flags; windows inside and past the first ring-buffer lap, a dictionary in front, shards"""
+    import test_cabi
+    lib = test_cabi._load(kind)
+    a = synth.alice()
+    inputs = [("alice", a, 22), ("alice w16", a, 16), ("markov", synth.markov_text(300000 if small else 900000, 3), 22),
+              ("mixed w18", synth.mixed(200000 if small else 600000, 9), 18), ("random", synth.random_bytes(150000), 22),
+              ("zeros + text", bytes(70000) + a[:60000] + bytes(40000), 20), ("short", a[:1000], 22), ("63 bytes", a[:63], 22)]
+    switches = ({"BROTLI_MI355X_QUICK_ROUNDS": "1"}, {"BROTLI_MI355X_QUICK_NO_INCREMENTAL": "1"}, {"BROTLI_MI355X_SELFTEST": "1"},
+                {"BROTLI_MI355X_QUICK_SERIAL": "1"}, {"BROTLI_MI355X_QUICK_CAP_DIV": "100000"}, {"BROTLI_MI355X_SEGMENT_BYTES": "256"})
+    want = {}
+    for env in switches:
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            for name, d, w in inputs:
+                for q in (2, 3, 4):
+                    if (name, q) not in want:
+                        want[(name, q)] = orc.compress(d, q, w)
+                    assert lib.compress(d, q, w) == want[(name, q)], (env, name, q)
+            d = synth.markov_text(400000, 8)
+            got = bytes(lib.BrotliCompress(d, {Q: 3, W: 20}, 4))
+            assert got == orc.compress_multi(d, [(Q, 3), (W, 20)], 4), env
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
+def test_speculative_path_and_its_fallbacks_emu():
+    _paths("emu", small=True)
+
+
+@pytest.mark.gpu
+def test_speculative_path_and_its_fallbacks_gpu():
+    _paths("gpu", small=False)
+
+
 def test_identity_with_the_oracle_emu():
     import emu
     _identity(emu.lib(), small=False)
@@ -170,21 +210,21 @@ def test_streamed_in_pieces_emu():
 @pytest.mark.gpu
 def test_identity_with_the_oracle_gpu():
     import gpulib
-    _identity(gpulib.lib(), small=True)
+    _identity(gpulib.lib(), small=False)  # (round 6: the whole set, as on the emulation build)
 
 
 @pytest.mark.gpu
 def test_one_shot_and_multi_shard_gpu():
     import test_cabi
-    _one_shot_and_multi(test_cabi._load("gpu"), small=True)
+    _one_shot_and_multi(test_cabi._load("gpu"), small=False)
 
 
 @pytest.mark.gpu
 def test_flushes_gpu():
     import test_cabi
-    _flushes(test_cabi._load("gpu"), small=True)
+    _flushes(test_cabi._load("gpu"), small=False)
 
 
 @pytest.mark.gpu
 def test_streamed_in_pieces_gpu():
-    _streamed("gpu", small=True)
+    _streamed("gpu", small=False)
