@@ -328,8 +328,15 @@ BR_DEV bool qs_search_dictionary(const Lz77Params& P, const QuickTables& T, Dict
 
 // BasicHasher::FindLongestMatch, mod.rs:359-473, with the slots read from the candidates of `cur` (q_find_longest_match of
 // quick_device.h on the table; the position is filed by the flag the caller writes)
+#if !BR_SCALAR
+BR_DEV bool qs_find_longest_match_lanes(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
+                                        uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out);
+#endif
 BR_DEV bool qs_find_longest_match(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
                                   uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out) {
+#if !BR_SCALAR && !defined(BR_QS_NO_LANES)
+  if (J.sweep != 1) return qs_find_longest_match_lanes(J, P, T, ds, no_dict, dc0, cur, max_length, max_backward, blk_end, out);
+#endif
   const uint8_t* text = T.text;
   const uint32_t best_len_in = out.len;
   uint8_t compare_char = q_byte(P, text, cur + best_len_in, blk_end);
@@ -392,6 +399,74 @@ BR_DEV bool qs_find_longest_match(const QuickJob& J, const Lz77Params& P, const 
   if (J.use_dictionary && !found) found = qs_search_dictionary(P, T.dict, ds, no_dict, text, cur, max_length, max_backward, out);
   return found;
 }
+
+#if !BR_SCALAR
+// The same search for the hashers with several slots per key, the candidates side by side (device; the emulation runs the loop
+// above): lane 0 takes the last distance, lanes 1 .. sweep the slots -- window test, first four bytes, common prefix, all of their
+// loads in flight together -- and the fold then walks the candidates in the reference's order on the lanes' results.  The
+// quick-reject byte of the loop above (the candidate's byte at the best length so far) follows from the prefix: equal while the best
+// length is shorter than the candidate's prefix, different when it equals it inside the block; only a candidate SHORTER than the best so
+// far (or a prefix that runs to the end of the block) needs its byte looked at.
+BR_DEV bool qs_find_longest_match_lanes(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
+                                        uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out) {
+  const uint8_t* text = T.text;
+  const uint32_t lane = (uint32_t)BR_LANE;
+  const uint32_t best_len_in = out.len;
+  uint32_t prev = 0;
+  bool valid = false;
+  if (lane == 0) {
+    if (dc0 > 0 && (uint32_t)dc0 <= cur) {
+      prev = cur - (uint32_t)dc0;
+      valid = true;
+    }
+  } else if (lane <= J.sweep) {
+    prev = T.cand[(size_t)cur * J.sweep + (lane - 1u)];
+    const uint32_t backward = cur - prev;
+    valid = backward != 0 && backward <= max_backward;
+  }
+  uint32_t raw = 0;
+  if (valid && br_load32(text + prev) == br_load32(text + cur)) raw = br_match_len_wide(text + prev, text + cur, max_length);
+  if (raw < 4) raw = 0;  // FindMatchLengthWithLimitMin4
+  const uint32_t len = raw ? q_fix_len(P, raw, prev) : 0u;
+  uint8_t compare_char = q_byte(P, text, cur + best_len_in, blk_end);
+  uint32_t best_score = out.score, best_len = best_len_in;
+  bool found = false;
+  out.len_x_code = 0;
+  for (uint32_t c = 0; c <= J.sweep; ++c) {
+    const uint32_t raw_c = BR_READLANE(raw, c);
+    if (raw_c == 0) continue;
+    const uint32_t prev_c = BR_READLANE(prev, c), len_c = BR_READLANE(len, c);
+    bool pass;
+    if (best_len < raw_c) pass = true;
+    else if (best_len == raw_c && raw_c < max_length) pass = false;
+    else pass = compare_char == text[prev_c + best_len];
+    if (!pass) continue;
+    if (c == 0) {
+      best_score = q_score_last(P, len_c);
+      best_len = len_c;
+      out.len = len_c;
+      out.distance = (uint32_t)dc0;
+      out.score = best_score;
+      compare_char = q_byte(P, text, cur + best_len, blk_end);
+      found = true;
+    } else {
+      const uint32_t backward = cur - prev_c;
+      const uint32_t score = q_score(P, len_c, backward);
+      if (best_score < score) {
+        best_score = score;
+        best_len = len_c;
+        out.len = len_c;
+        out.distance = backward;
+        out.score = score;
+        compare_char = q_byte(P, text, cur + best_len, blk_end);
+        found = true;
+      }
+    }
+  }
+  if (J.use_dictionary && !found) found = qs_search_dictionary(P, T.dict, ds, no_dict, text, cur, max_length, max_backward, out);
+  return found;
+}
+#endif
 
 // One chain: segment `seg_in` from `entry`; commands into its slab, flags of its own positions, `exit_out`.
 BR_DEV void br_quick_segment(const QuickJob& J, const Lz77Params& P, const QsTables& T, const Segment& seg_in, const SegEntry& entry, Command* slab,
