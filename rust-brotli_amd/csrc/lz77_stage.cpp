@@ -1834,6 +1834,53 @@ void Lz77Stage::RunQuickSpec() {
   R.up_entries.resize_discard(nseg);
   R.got_exits.resize_discard(nseg);
   stamp("qs-index-queued");
+  // ---- warm-up: a dry run over the tail of every segment from a cold state (nothing written but the exit) guesses the state in which
+  // the parse enters the next one -- greedy parses fall into step within a few commands -- so that round 0 already starts almost every
+  // chain where the true parse does, instead of spending a launch over everything on finding that out (RunRounds does the same)
+  const uint32_t warm = getenv("BROTLI_MI355X_QUICK_WARMUP") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_WARMUP")) : std::min(192u, segment_bytes_ / 2u);
+  if (warm != 0 && nseg > 1) {
+    PinnedArray<Segment> wsegs;
+    PinnedArray<SegEntry> wentries;
+    PinnedArray<SegExit> wexits;
+    wsegs.resize_discard(nseg);
+    wentries.resize_discard(nseg);
+    wexits.resize_discard(nseg);
+    for (uint32_t k = 0; k < nseg; ++k) {
+      Segment g = segments_[k];
+      if (g.end - g.start > warm) {
+        g.start = g.end - warm;
+        g.flags &= ~(uint32_t)kSegFirstInBlock;
+      }
+      g.flags |= kSegWarmup;
+      wsegs[k] = g;
+      SegEntry e = entries_[k];
+      e.pos = g.start;
+      e.apply = g.start + P_.spree_window;
+      e.ext_allowed = 0;
+      e.head_kind = kHeadNone;
+      wentries[k] = e;
+    }
+    Segment* wsegs_dev = (Segment*)dev_alloc_uninit((size_t)nseg * sizeof(Segment) + 64);
+    dev_h2d(wsegs_dev, wsegs.data(), (size_t)nseg * sizeof(Segment));
+    dev_h2d(up_entries_dev, wentries.data(), (size_t)nseg * sizeof(SegEntry));
+    lz77_qspec_parse_custom(P_, B_, Q_, S_, wsegs_dev, up_entries_dev, got_exits_dev, nseg);
+    dev_d2h(wexits.data(), got_exits_dev, (size_t)nseg * sizeof(SegExit));
+    dev_free(wsegs_dev);
+    for (uint32_t k = 0; k + 1 < nseg; ++k) {
+      const SegExit& x = wexits[k];
+      SegEntry& n = entries_[k + 1];
+      int32_t out_cache[4];
+      for (uint32_t i = 0; i < 4; ++i) out_cache[i] = i < x.n_pushes ? x.cache[i] : entries_[k].cache[i - x.n_pushes];
+      memcpy(n.cache, out_cache, sizeof(out_cache));
+      if (segments_[k + 1].flags & kSegFirstInBlock) continue;  // (a block is entered at its start)
+      n.pos = x.pos;
+      n.apply = x.apply;
+      n.head_kind = x.tail_kind;
+      n.head_base = x.tail_base;
+      n.head_p1 = x.tail_p1;
+    }
+    stamp("qs-warmed-up");
+  }
   // ---- round 0: every segment
   dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
   lz77_qspec_parse(P_, B_, Q_, S_, nullptr, nseg);

@@ -103,6 +103,10 @@ void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob
 static constexpr uint32_t kQsWalkCap = 1u << 14;
 // the listed segments (list_dev == nullptr: all of them), each from B.entries[k]: flags, commands, B.exits[k]
 void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count);
+// the same chains over `count` segments and entries of the caller's (device arrays), exits to exits_dev: the dry runs of the warm-up
+// (Segment::flags with kSegWarmup: nothing but the exit is written)
+void lz77_qspec_parse_custom(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const Segment* segments_dev, const SegEntry* entries_dev,
+                             SegExit* exits_dev, uint32_t count);
 // out[i] = B.exits[list[i]] for i < count (list rounds move only what was parsed)
 void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, SegExit* out_dev);
 // the slots of the hasher as the reference holds them when it has filed every position in front of `upto` that it files (from the

@@ -56,6 +56,37 @@ BR_DEV uint32_t qs_rank_in_slot(const QuickJob& J, const uint32_t* ev_id, uint32
   }
   return lo;
 }
+// the same, started where p would sit if the slot's positions were spread evenly over the text of n bytes (they nearly are: a
+// handful of neighbouring probes instead of log2 of the slot's length, all in one or two cache lines; index build, 256 M searches at
+// 64 MiB and four slots per key)
+BR_DEV uint32_t qs_rank_in_slot_guess(const QuickJob& J, const uint32_t* ev_id, uint32_t lo, uint32_t hi, uint32_t p, uint32_t n) {
+  if (hi - lo <= 8u) {
+    while (lo < hi && qs_event_position(J, ev_id[lo]) < p) ++lo;
+    return lo;
+  }
+  uint32_t g = lo + (uint32_t)(((uint64_t)(hi - lo) * p) / n);
+  if (g >= hi) g = hi - 1u;
+  uint32_t step = 4u;
+  if (qs_event_position(J, ev_id[g]) < p) {
+    // the answer lies behind g: gallop forward to an event at or behind p
+    uint32_t a = g + 1u;
+    for (;;) {
+      const uint32_t b = a + step < hi ? a + step : hi;
+      if (b == hi || qs_event_position(J, ev_id[b]) >= p) return qs_rank_in_slot(J, ev_id, a, b, p);
+      a = b + 1u;
+      step <<= 1;
+    }
+  }
+  // the answer lies at or in front of g: gallop backward to an event in front of p
+  uint32_t b = g;
+  for (;;) {
+    if (b - lo <= step) return qs_rank_in_slot(J, ev_id, lo, b, p);
+    const uint32_t a = b - step;
+    if (qs_event_position(J, ev_id[a]) < p) return qs_rank_in_slot(J, ev_id, a + 1u, b, p);
+    b = a;
+    step <<= 1;
+  }
+}
 // event index of the filing (q, off): the position's own-offset event or (sweep > 1) the displaced one
 BR_DEV uint32_t qs_event_of(const QuickJob& J, const QuickSpec& S, uint32_t q, uint32_t off) {
   if (J.sweep == 1) return S.ev_of[q];
@@ -491,10 +522,11 @@ BR_DEV void br_quick_segment(const QuickJob& J, const Lz77Params& P, const QsTab
   ds.vmaxdef = -(1 << 30);
   // (once the throttle has tripped under exact counters it stays tripped: no lookups, no virtual books -- "ran blind", mode 4)
   const bool no_dict = J.use_dictionary && BR_UNIFORM(entry.dict_exact) && ds.matches < (ds.lookups >> 7);
+  const bool dry = (seg_flags & kSegWarmup) != 0;  // a dry run over the tail of a segment: only the exit matters, nothing is written
   QsFlagWriter fw;
   fw.flags = T.flags;
-  fw.lo = seg_start;
-  fw.hi = seg_end;
+  fw.lo = dry ? 0u : seg_start;
+  fw.hi = dry ? 0u : seg_end;
   fw.tail_lo = pos_end - 3;
   fw.tail_value = (seg_flags & kSegTailStitched) ? kQsStored : (uint8_t)0;
   uint32_t tail_kind = kHeadNone, tail_base = 0, tail_p1 = 0;
@@ -568,7 +600,7 @@ BR_DEV void br_quick_segment(const QuickJob& J, const Lz77Params& P, const QsTab
         dc[0] = (int32_t)sr.distance;
         n_pushes++;
       }
-      if (BR_LANE == 0 && n_cmds < cmd_cap) slab[n_cmds] = br_raw_command(insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
+      if (BR_LANE == 0 && n_cmds < cmd_cap && !dry) slab[n_cmds] = br_raw_command(insert_length, sr.len, sr.len ^ sr.len_x_code, distance_code);
       if (sr.len < 2) n_bad++;
       ++n_cmds;
       n_lits += insert_length;

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void k_qs_qrank(QuickJob J, QuickSpec S, const
   if (item >= (uint64_t)S.n * J.sweep) return;
   const uint32_t p = (uint32_t)(item / J.sweep), j = (uint32_t)(item % J.sweep);
   const uint32_t slot = qs_hash(J, text + p) + j;
-  S.qrank[item] = qs_rank_in_slot(J, S.ev_id, S.slot_first[slot], S.slot_first[slot + 1], p);
+  // (in the slot of its own offset a position's rank is its own event)
+  if (j == ((p >> 3) & (J.sweep - 1u))) S.qrank[item] = S.ev_of[J.sweep == 1 ? p : 2u * p];
+  else S.qrank[item] = qs_rank_in_slot_guess(J, S.ev_id, S.slot_first[slot], S.slot_first[slot + 1], p, S.n);
 }
 
 size_t lz77_qspec_sort_tmp_bytes(uint32_t events) {
@@ -168,7 +170,20 @@ __global__ __launch_bounds__(64) void k_qs_diff(QuickJob J, Lz77Params P, QuickS
     const uint32_t at = atomicAdd(&S.chg_count[0], 1u);
     if (at < S.chg_cap) S.chg_list[at] = e;
   };
-  for (uint32_t q = seg.start + threadIdx.x; q < seg.end; q += 64u) qs_item_diff(J, P, S, q, mark);
+  // eight flags per lane and load; almost all of them are what they were
+  const uint32_t a0 = (seg.start + 7u) & ~7u, a1 = seg.end & ~7u;
+  if (a0 >= a1) {
+    for (uint32_t q = seg.start + threadIdx.x; q < seg.end; q += 64u) qs_item_diff(J, P, S, q, mark);
+    return;
+  }
+  for (uint32_t q = seg.start + threadIdx.x; q < a0; q += 64u) qs_item_diff(J, P, S, q, mark);
+  for (uint32_t q = a1 + threadIdx.x; q < seg.end; q += 64u) qs_item_diff(J, P, S, q, mark);
+  for (uint32_t q8 = a0 + 8u * threadIdx.x; q8 < a1; q8 += 512u) {
+    const unsigned long long f = *(const unsigned long long*)(S.flags + q8), g = *(const unsigned long long*)(S.flags_prev + q8);
+    if (f == g) continue;
+    for (uint32_t b = 0; b < 8u; ++b)
+      if (((f ^ g) >> (8u * b)) & 0xffull) qs_item_diff(J, P, S, q8 + b, mark);
+  }
 }
 void lz77_qspec_diff(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count) {
   HIP_CHECK(hipMemsetAsync(S.chg_count, 0, 64, BR_STREAM));
@@ -226,6 +241,17 @@ void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
   HIP_CHECK(hipGetLastError());
 }
 
+void lz77_qspec_parse_custom(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const Segment* segments_dev, const SegEntry* entries_dev,
+                             SegExit* exits_dev, uint32_t count) {
+  if (count == 0) return;
+  QsTables T;
+  T.text = B.text;
+  T.cand = S.cand;
+  T.flags = S.flags;
+  T.dict = qspec_dict_tables();
+  hipLaunchKernelGGL(k_qs_parse, dim3(count), dim3(64), 0, BR_STREAM, J, P, T, segments_dev, entries_dev, B.cmds, exits_dev, (const uint32_t*)nullptr, count);
+  HIP_CHECK(hipGetLastError());
+}
 __global__ __launch_bounds__(256) void k_qs_gather_exits(const SegExit* __restrict__ exits, const uint32_t* __restrict__ list, uint32_t count, SegExit* __restrict__ out) {
   // one 4-byte word per thread
   constexpr uint32_t kWords = sizeof(SegExit) / 4;

@@ -950,6 +950,18 @@ void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob&
     br_quick_segment(J, P, T, seg, B.entries[k], B.cmds + seg.cmd_base, B.exits + k);
   }
 }
+void lz77_qspec_parse_custom(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const Segment* segments, const SegEntry* entries,
+                             SegExit* exits, uint32_t count) {
+  const DeviceTables& dt = dev_tables();
+  QsTables T;
+  T.text = B.text;
+  T.cand = S.cand;
+  T.flags = S.flags;
+  T.dict.dict_hash = dt.dict_hash;
+  T.dict.dict_data = dt.dict_data;
+  T.dict.dict_offsets_by_length = dt.dict_offsets_by_length;
+  for (uint32_t k = 0; k < count; ++k) br_quick_segment(J, P, T, segments[k], entries[k], B.cmds + segments[k].cmd_base, exits + k);
+}
 void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list, uint32_t count, SegExit* out) {
   for (uint32_t i = 0; i < count; ++i) out[i] = B.exits[list[i]];
 }
