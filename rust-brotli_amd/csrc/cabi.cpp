@@ -436,7 +436,17 @@ int32_t CompressMultiImpl(size_t num_params, const BrotliEncoderParameter* keys,
     } else {
       EncoderParams params;
       if (!ParamsFromLists(num_params, keys, values, &params)) return 0;
-      dev_make_room(10);  // (the helper threads allocate from pools of their own: room for them while the device is idle)
+      // The helper threads allocate from pools of their own: room for them while the device is idle -- about 100 bytes of scratch per
+      // input byte of every shard in flight.  What the calling thread keeps pooled from earlier one-shot calls
+      // goes back to the driver when it is clearly more than its own share of this call (it works on one shard itself).  Round 6: with
+      // 128 GiB pooled by the calling thread the helpers' hipMalloc calls took 70 ms each and ended in trims of every pool: 5-9 s for
+      // a call of 1.4 s, call after call.
+      {
+        const size_t in_flight = std::min<size_t>(num_threads, 8);
+        const size_t shard_bytes = input_size / num_threads + 1;
+        const size_t per_shard = shard_bytes * 110 + ((size_t)256 << 20);
+        dev_make_room_for(per_shard * in_flight, per_shard);
+      }
       if (params.favor_cpu_efficiency) {
         // threading/mod.rs:456-542: one hasher is filled with the whole input in front of every shard and handed to its
         // encoder instead of priming it from the shard's prefix.  While a shard starts within the window that is the same

@@ -44,6 +44,9 @@ void dev_wait_mark_n(int i);
 void* dev_host_alloc(size_t bytes);
 void dev_host_free(void* p);
 void dev_pool_counters(double* out4, bool reset);  // hipMalloc calls / ms, hipFree calls / ms of the calling thread
+// before work is handed to helper threads that allocate from pools of their own: if less than `bytes` are free and the calling thread
+// keeps more than twice `own_share` pooled (left-overs of earlier, larger calls), its idle blocks go back to the driver
+void dev_make_room_for(size_t bytes, size_t own_share);
 void dev_make_room(unsigned min_free_share);  // trims every thread's pool if less than that percentage of the device memory is free
 size_t dev_trim_pool();  // returns the pooled, currently unused device memory of the calling thread to the driver; bytes freed
 int dev_current_device();        // the calling thread's device (helper threads adopt their caller's)

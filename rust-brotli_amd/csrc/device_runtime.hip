@@ -542,10 +542,33 @@ void dev_wait_mark() {
 // device: the same trim forced by allocations in the middle of the call -- kernels of seconds when the shards are live
 // chains -- stalls every worker (8 H5 shards: 42 s instead of 14 with 7 GB free after the 1 GiB cases).  It is not free
 // either -- handing back ~150 GiB takes seconds -- hence only when memory is really short.
+size_t dev_trim_pool();
 void dev_make_room(unsigned min_free_share) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
-  if (free_b * 100 < total_b * (size_t)min_free_share) TrimAllPools();
+  if (free_b * 100 >= total_b * (size_t)min_free_share) return;
+  // The caller is about to hand its work to helper threads and wait: what sits idle in ITS pool goes first (round 6: a process that had
+  // run 1 GiB one-shot calls -- 128 GiB pooled by the calling thread -- and then multi-shard calls trimmed EVERY pool at the start of
+  // every such call, the helpers' blocks of the call before included: 5 s of hipMalloc per shard, 9 s for a 1.4 s call).
+  dev_trim_pool();
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b * 100 >= total_b * (size_t)min_free_share) return;
+  TrimAllPools();
+}
+
+void dev_make_room_for(size_t bytes, size_t own_share) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
+  // twice the estimate: the shards of a call differ in what they need, and a pool only hands out blocks of about the size asked for
+  if (free_b >= std::min(2 * bytes, total_b - total_b / 8)) return;
+  // (what the helpers keep pooled from the call before is not "free" but is theirs to reuse: only the caller's left-overs are at stake,
+  // and only when they are clearly more than its own share of this call)
+  size_t mine;
+  {
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    mine = P.pooled_bytes;
+  }
+  if (mine > 2 * own_share) dev_trim_pool();
 }
 
 // gives the pooled (currently unused) device memory of the calling thread back to the driver

@@ -53,6 +53,7 @@ void dev_wait_mark() {}
 void dev_mark_n(int) {}
 void dev_wait_mark_n(int) {}
 void dev_make_room(unsigned) {}
+void dev_make_room_for(size_t, size_t) {}
 size_t dev_trim_pool() { return 0; }
 void dev_h2d_bulk(void* dst, const void* src, size_t bytes) { dev_h2d(dst, src, bytes); }
 void dev_d2h_bulk(void* dst, const void* src, size_t bytes) { dev_d2h(dst, src, bytes); }
