@@ -14,9 +14,16 @@
 
 // Every thread of the host program works on its own HIP stream (hipStreamPerThread): independent encoder calls from
 // different threads overlap on the GPU, nothing ever runs on the synchronising null stream.
-#define BR_STREAM hipStreamPerThread
+// BR_STREAM is what every launch, copy, fill and event of the library names as its stream.  Small zero fills (dev_alloc of small
+// blocks, dev_memset(p, 0, n)) are not issued one by one -- a 152 KB call queued about a hundred of them, 5 us of dispatch each --
+// but noted and written by ONE launch in front of the next operation on the stream: naming the stream is what flushes them, so they
+// keep their place in the order of the stream.
+#define BR_STREAM (::brotli_mi355x::dev_stream_flushed())
 
+struct ihipStream_t;
 namespace brotli_mi355x {
+
+ihipStream_t* dev_stream_flushed();  // the calling thread's stream, behind the zero fills noted so far (device_runtime.hip)
 
 // ---- memory ----
 void* dev_alloc(size_t bytes);  // zero-initialised device allocation; throws std::runtime_error

@@ -165,11 +165,80 @@ struct DriverCallClock {
 };
 }  // namespace
 
+// ---- zero fills, noted and written in batches (BR_STREAM, device_api.h)
+namespace {
+constexpr uint32_t kZeroBatch = 32;               // ranges per launch
+constexpr size_t kZeroDeferMax = (size_t)4 << 20; // longer fills go to the runtime's own fill kernel at once
+constexpr size_t kZeroChunk = (size_t)64 << 10;   // bytes per workgroup
+struct ZeroRanges {
+  unsigned long long ptr[kZeroBatch];
+  unsigned long long bytes[kZeroBatch];
+};
+__global__ __launch_bounds__(256) void k_zero_ranges(ZeroRanges z) {
+  const uint32_t r = blockIdx.y;
+  const size_t n = (size_t)z.bytes[r];
+  const size_t lo = (size_t)blockIdx.x * kZeroChunk;
+  if (lo >= n) return;
+  const size_t hi = lo + kZeroChunk < n ? lo + kZeroChunk : n;
+  uint8_t* q = (uint8_t*)z.ptr[r] + lo;
+  uint8_t* e = (uint8_t*)z.ptr[r] + hi;
+  uint8_t* qa = (uint8_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15);
+  if (qa > e) qa = e;
+  uint8_t* ea = (uint8_t*)((uintptr_t)e & ~(uintptr_t)15);
+  if (ea < qa) ea = qa;
+  for (uint8_t* x = q + threadIdx.x; x < qa; x += 256) *x = 0;
+  for (uint4* x = (uint4*)qa + threadIdx.x; x < (uint4*)ea; x += 256) *x = make_uint4(0u, 0u, 0u, 0u);
+  for (uint8_t* x = ea + threadIdx.x; x < e; x += 256) *x = 0;
+}
+struct PendingZero {
+  ZeroRanges z;
+  uint32_t n = 0;
+  size_t longest = 0;
+};
+PendingZero& pending_zero() {
+  static thread_local PendingZero p;
+  return p;
+}
+void flush_zero() {
+  PendingZero& pz = pending_zero();
+  if (pz.n == 0) return;
+  const uint32_t n = pz.n;
+  const size_t longest = pz.longest;
+  pz.n = 0;
+  pz.longest = 0;
+  if (n == 1) {
+    HIP_CHECK(hipMemsetAsync((void*)pz.z.ptr[0], 0, (size_t)pz.z.bytes[0], hipStreamPerThread));
+    return;
+  }
+  hipLaunchKernelGGL(k_zero_ranges, dim3((uint32_t)((longest + kZeroChunk - 1) / kZeroChunk), n), dim3(256), 0, hipStreamPerThread, pz.z);
+  HIP_CHECK(hipGetLastError());
+}
+void note_zero(void* p, size_t bytes) {
+  if (bytes == 0) return;
+  static const bool direct = getenv("BROTLI_MI355X_DIRECT_FILLS") != nullptr;  // (A/B: one runtime fill per request, as before)
+  if (bytes > kZeroDeferMax || direct) {
+    flush_zero();
+    HIP_CHECK(hipMemsetAsync(p, 0, bytes, hipStreamPerThread));
+    return;
+  }
+  PendingZero& pz = pending_zero();
+  if (pz.n == kZeroBatch) flush_zero();
+  pz.z.ptr[pz.n] = (unsigned long long)(uintptr_t)p;
+  pz.z.bytes[pz.n] = bytes;
+  pz.n++;
+  if (bytes > pz.longest) pz.longest = bytes;
+}
+}  // namespace
+ihipStream_t* dev_stream_flushed() {
+  flush_zero();
+  return hipStreamPerThread;
+}
+
 static void* AllocBlock(size_t bytes);
 void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 16;
   void* p = AllocBlock(bytes);
-  HIP_CHECK(hipMemsetAsync(p, 0, bytes, BR_STREAM));
+  note_zero(p, bytes);
   return p;
 }
 // for the big work arrays that are written in full before anything reads them (zero-filling them costs a pass over
@@ -265,6 +334,7 @@ static void* AllocBlock(size_t bytes) {
 }
 void dev_free(void* p) {
   if (!p) return;
+  flush_zero();  // (a noted fill of this block must not outlive it: the pool may hand the block back to the driver)
   Pool& P = pool();
   std::lock_guard<std::mutex> lock(P.mu);
   auto it = P.capacity.find(p);
@@ -349,7 +419,12 @@ void dev_host_free(void* p) {
 }
 static void wait_stream();
 void dev_memset(void* p, int value, size_t bytes) {
-  if (bytes) HIP_CHECK(hipMemsetAsync(p, value, bytes, BR_STREAM));
+  if (bytes == 0) return;
+  if (value == 0) {
+    note_zero(p, bytes);
+    return;
+  }
+  HIP_CHECK(hipMemsetAsync(p, value, bytes, BR_STREAM));
 }
 void dev_h2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, BR_STREAM));

@@ -77,7 +77,7 @@ void lz77_compute_keys(const Lz77Params& P, const Lz77Buffers& B) {
   if (n == 0) return;
   uint32_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  HIP_CHECK(hipMemsetAsync(B.changed_count + 8, 0, 4, BR_STREAM));
+  dev_memset(B.changed_count + 8, 0, 4);
   hipLaunchKernelGGL(k_compute_keys, dim3(blocks), dim3(256), 0, BR_STREAM, B.text, B.keys, n, valid_n, P.hasher_kind, P.bucket_bits,
                      hash_mask, B.changed_count + 8, dev_tables().dict_hash, B.dict_items);
   HIP_CHECK(hipGetLastError());
@@ -104,7 +104,7 @@ void lz77_init_flags(const Lz77Params& P, const Lz77Buffers& B, uint32_t first_b
   // (masked H5 ring entries, Lz77Params::masked_from: texts that have them are parsed by live chains, lz77_live.h; the row
   // and rank kernels below carry kFlagMasked through, which only the live index reads)
   const uint32_t M = P.total_bytes, P0 = P.prefix_bytes, htl = P.htl;
-  HIP_CHECK(hipMemsetAsync(B.flags[0], 0, (size_t)M + 64, BR_STREAM));
+  dev_memset(B.flags[0], 0, (size_t)M + 64);
   if (P0 > htl - 1) HIP_CHECK(hipMemsetAsync(B.flags[0], 1, P0 - (htl - 1), BR_STREAM));  // StoreLookaheadThenStore, mod.rs:224-229
   // the catable raw head (between the prefix and the first searched block) is only stored by the stitch
   if (prefix_flags_host && prefix_flags_bytes) {
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256) void k_rank_apply(const uint32_t* __restrict__
 
 void lz77_key_ranges(const Lz77Params& P, const Lz77Buffers& B) {
   const uint32_t n = P.total_bytes;
-  HIP_CHECK(hipMemsetAsync(B.key_first, 0, 65537 * 4, BR_STREAM));
-  HIP_CHECK(hipMemsetAsync(B.key_last, 0, 65537 * 4, BR_STREAM));
+  dev_memset(B.key_first, 0, 65537 * 4);
+  dev_memset(B.key_last, 0, 65537 * 4);
   if (n == 0) return;
   hipLaunchKernelGGL(k_key_ranges, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.sorted_keys, n, B.key_first, B.key_last);
   HIP_CHECK(hipGetLastError());
@@ -1367,10 +1367,10 @@ void lz77_rows_init(const Lz77Params& P, const Lz77Buffers& B, int which, const 
   uint32_t* tile_sums = (uint32_t*)B.sort_tmp;
   hipLaunchKernelGGL(k_rank_gather, dim3(tiles), dim3(256), 0, BR_STREAM, B.by_key, B.flags[which], n, B.fbits, tile_sums, ig,
                      P.masked_from != kNeverMasked ? 1u : 0u);
-  HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
+  dev_memset(B.row_ctl, 0, kCtlWords * 4);
   if (P.reset_pos) lz77_key_counts(P, B, which, P.reset_vis, B.reset_counts, false);
   if (has_big_keys) {
-    HIP_CHECK(hipMemsetAsync(B.big_tile, 0, tiles + 64, BR_STREAM));
+    dev_memset(B.big_tile, 0, tiles + 64);
     hipLaunchKernelGGL(k_flag_big_tiles, dim3(256), dim3(256), 0, BR_STREAM, B.key_first, B.key_last, B.big_tile,
                        (B.count_base || P.reset_pos) ? 1u : 0u);
     launch_wrap_marks(P, B, false);
@@ -1386,7 +1386,7 @@ void lz77_rows_update(const Lz77Params& P, const Lz77Buffers& B, int prev, int n
   const uint32_t n = P.total_bytes;
   if (n == 0) return;
   const uint32_t cap = B.changed_cap;
-  HIP_CHECK(hipMemsetAsync(B.row_ctl, 0, kCtlWords * 4, BR_STREAM));
+  dev_memset(B.row_ctl, 0, kCtlWords * 4);
   // (B.changed_keys holds POSITIONS here, B.changed_count their number -- see lz77_diff_flags)
   const uint32_t flip_blocks = (cap + 255) / 256;
   hipLaunchKernelGGL(k_apply_flips, dim3(flip_blocks), dim3(256), 0, BR_STREAM, B.changed_keys, B.changed_count, cap, B.keys, B.key_first,
@@ -1591,7 +1591,7 @@ static void launch_parse(const Lz77Params& P, const Lz77Buffers& B, int flags_in
     ParseTiming& ptw = parse_timing();
     if (!ptw.work_dev) {
       HIP_CHECK(hipMalloc((void**)&ptw.work_dev, 4 * sizeof(unsigned long long)));
-      HIP_CHECK(hipMemsetAsync(ptw.work_dev, 0, 4 * sizeof(unsigned long long), BR_STREAM));
+      dev_memset(ptw.work_dev, 0, 4 * sizeof(unsigned long long));
     }
     a.T.work = ptw.work_dev;
   }
@@ -1707,7 +1707,7 @@ static FlipCells flip_cells_of(const Lz77Buffers& B) {
   return c;
 }
 static void clear_flip_cells(const Lz77Buffers& B) {
-  if (B.rows && B.flip_cells) HIP_CHECK(hipMemsetAsync(B.flip_cells, 0, ((size_t)65536 * B.cells_per_key) / 8 + 8, BR_STREAM));
+  if (B.rows && B.flip_cells) dev_memset(B.flip_cells, 0, ((size_t)65536 * B.cells_per_key) / 8 + 8);
 }
 
 __global__ __launch_bounds__(256) void k_diff_flags(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next, uint32_t n,
@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(256) void k_gather_results(const SegExit* __restric
 
 void lz77_gather_results(const Lz77Buffers& B, const uint32_t* list_dev, uint32_t count, const uint8_t* sched_dev, uint32_t num_segments,
                          SegExit* exits_out, uint32_t* cont_count, uint32_t* cont_index, SegExit* cont_exits, SegEntry* cont_entries) {
-  HIP_CHECK(hipMemsetAsync(cont_count, 0, 4, BR_STREAM));
+  dev_memset(cont_count, 0, 4);
   const uint32_t n = count > num_segments ? count : num_segments;
   hipLaunchKernelGGL(k_gather_results, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, B.exits, B.entries, list_dev, count, sched_dev, num_segments,
                      exits_out, cont_count, cont_index, cont_exits, cont_entries);
@@ -1899,7 +1899,7 @@ __global__ __launch_bounds__(64) void k_diff_flags_touched(const Segment* __rest
   }
 }
 void lz77_diff_flags_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, int prev, int next) {
-  HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, BR_STREAM));
+  dev_memset(B.changed_count, 0, 4);
   clear_flip_cells(B);
   if (P.num_segments == 0) return;
   hipLaunchKernelGGL(k_diff_flags_touched, dim3(P.num_segments), dim3(64), 0, BR_STREAM, B.segments, P.num_segments, U.stale, B.flags[prev], B.flags[next],
@@ -1909,7 +1909,7 @@ void lz77_diff_flags_touched(const Lz77Params& P, const Lz77Buffers& B, const Bu
 void lz77_reset_rows_changed(const Lz77Params& P, const Lz77Buffers& B) {
   if (B.rows_changed_lo == nullptr) return;
   HIP_CHECK(hipMemsetAsync(B.rows_changed_lo, 0xff, (size_t)P.num_segments * 4, BR_STREAM));
-  HIP_CHECK(hipMemsetAsync(B.rows_changed_hi, 0, (size_t)P.num_segments * 4, BR_STREAM));
+  dev_memset(B.rows_changed_hi, 0, (size_t)P.num_segments * 4);
 }
 __global__ __launch_bounds__(64) void k_drop_checkpoints(Checkpoint* __restrict__ checkpoints, const Segment* __restrict__ segments,
                                                           const uint32_t* __restrict__ list, uint32_t count) {
@@ -1931,7 +1931,7 @@ __global__ __launch_bounds__(256) void k_burst_count(uint32_t num_segments, cons
   if (m != 0 && (threadIdx.x & 63u) == 0) atomicAdd(&counters[0], (uint32_t)__popcll(m));
 }
 void lz77_burst_count(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
-  HIP_CHECK(hipMemsetAsync(U.counters, 0, 4, BR_STREAM));
+  dev_memset(U.counters, 0, 4);
   hipLaunchKernelGGL(k_burst_count, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, P.num_segments, U.sched, U.cand_dirty, U.entry_dirty,
                      U.counters);
   HIP_CHECK(hipGetLastError());
@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(256) void k_burst_schedule(SegEntry* __restrict__ e
   if (go) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
 }
 void lz77_burst_schedule(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U) {
-  HIP_CHECK(hipMemsetAsync(U.counters, 0, 4, BR_STREAM));
+  dev_memset(U.counters, 0, 4);
   hipLaunchKernelGGL(k_burst_schedule, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.entries, P.num_segments, U.sched, U.cand_dirty,
                      U.entry_dirty, U.new_entries, U.list, U.counters);
   HIP_CHECK(hipGetLastError());
@@ -1973,7 +1973,7 @@ __global__ __launch_bounds__(256) void k_gather_touched(const SegExit* __restric
   entries_out[j] = entries[k];
 }
 void lz77_gather_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstBuffers& U, uint32_t* index_out, SegExit* exits_out, SegEntry* entries_out) {
-  HIP_CHECK(hipMemsetAsync(U.counters + 1, 0, 4, BR_STREAM));
+  dev_memset(U.counters + 1, 0, 4);
   hipLaunchKernelGGL(k_gather_touched, dim3((P.num_segments + 255) / 256), dim3(256), 0, BR_STREAM, B.exits, B.entries, P.num_segments, U.touched,
                      U.counters, index_out, exits_out, entries_out);
   HIP_CHECK(hipGetLastError());
@@ -1981,7 +1981,7 @@ void lz77_gather_touched(const Lz77Params& P, const Lz77Buffers& B, const BurstB
 
 void lz77_diff_flags(const Lz77Params& P, const Lz77Buffers& B, int prev, int next) {
   const uint32_t n = P.total_bytes;
-  HIP_CHECK(hipMemsetAsync(B.changed_count, 0, 4, BR_STREAM));
+  dev_memset(B.changed_count, 0, 4);
   clear_flip_cells(B);
   if (n == 0) return;
   uint32_t blocks = ((n + 15) / 16 + 255) / 256;
@@ -2115,7 +2115,7 @@ void lz77_parse_timing(double* total_ms, uint32_t* launches, uint64_t* segments,
     if (ptw.work_dev) {
       HIP_CHECK(hipMemcpyAsync(h, ptw.work_dev, sizeof(h), hipMemcpyDeviceToHost, BR_STREAM));
       HIP_CHECK(hipStreamSynchronize(BR_STREAM));
-      HIP_CHECK(hipMemsetAsync(ptw.work_dev, 0, sizeof(h), BR_STREAM));
+      dev_memset(ptw.work_dev, 0, sizeof(h));
     }
     if (work)
       for (int i = 0; i < 3; ++i) work[i] = h[i];
@@ -2304,7 +2304,7 @@ void lz77_sample_histograms(const uint8_t* text, const uint32_t* ranges, uint32_
 }
 
 void lz77_sample_histogram(const uint8_t* text, uint32_t start, uint32_t bytes, uint32_t* histo256_dev) {
-  HIP_CHECK(hipMemsetAsync(histo256_dev, 0, 256 * 4, BR_STREAM));
+  dev_memset(histo256_dev, 0, 256 * 4);
   const uint32_t samples = (bytes + 12) / 13;
   uint32_t blocks = (samples + 255) / 256;
   if (blocks > 1024) blocks = 1024;
@@ -2549,11 +2549,11 @@ void lz77_live_verify(const Lz77Params& P, const Lz77Buffers& B, const LiveBuffe
   const uint32_t n = P.total_bytes;
   if (n <= geo.first_block_start) return;
   if (prev >= 0) {
-    HIP_CHECK(hipMemsetAsync(L.changed_key, 0, 65536, BR_STREAM));
+    dev_memset(L.changed_key, 0, 65536);
     hipLaunchKernelGGL(k_live_changed_keys, dim3((n + 255) / 256), dim3(256), 0, BR_STREAM, (const uint8_t*)B.flags[prev], (const uint8_t*)B.flags[next], n,
                        (const uint16_t*)B.keys, L.changed_key);
   }
-  HIP_CHECK(hipMemsetAsync(B.recheck_count, 0, 4, BR_STREAM));
+  dev_memset(B.recheck_count, 0, 4);
   const uint32_t span = n - geo.first_block_start;
   hipLaunchKernelGGL(k_live_list, dim3((span + 255) / 256), dim3(256), 0, BR_STREAM, (const uint8_t*)B.flags[next], n, geo.first_block_start,
                      (const uint16_t*)B.keys, prev >= 0 ? (const uint8_t*)L.changed_key : (const uint8_t*)nullptr, reparsed_dev, geo.prefix_bytes,

@@ -183,6 +183,7 @@ void Lz77Stage::Setup(const EncoderParams& params, uint8_t* text_dev, uint32_t p
     // less than 64 bytes, and as a test aid (BROTLI_MI355X_QUICK_SERIAL=1).
     use_qspec_ = getenv("BROTLI_MI355X_QUICK_SERIAL") == nullptr && input_bytes >= 64 && (uint64_t)P_.total_bytes * 2 < 0xfffffff0ull;
     qspec_books_in_ = false;
+    qspec_coarse_ = false;
     qspec_params_ = params;
     qspec_text_ = text_dev;
     qspec_prefix_ = prefix_bytes;
@@ -1803,7 +1804,16 @@ void Lz77Stage::RunQuickSpec() {
     dev_sync();
     fprintf(stderr, "quick %s: %.2f ms into the parse\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   };
-  lz77_qspec_index(P_, B_, Q_, S_);
+  if (!qspec_coarse_) lz77_qspec_index(P_, B_, Q_, S_);  // (parse-independent: a restart with other segments keeps it)
+  if (qspec_coarse_) {
+    // what the pass with small segments said about the state at every block start
+    for (uint32_t k = 0; k < nseg; ++k) {
+      auto it = saved_block_guess_.find(segments_[k].blk_start);
+      if (it == saved_block_guess_.end() || !(segments_[k].flags & kSegFirstInBlock)) continue;
+      memcpy(entries_[k].cache, it->second.cache, sizeof(entries_[k].cache));
+      entries_[k].ext_allowed = it->second.ext_allowed;
+    }
+  }
   lap("index");
   lz77_qspec_init_flags(P_, B_, Q_, S_, segments_[0].blk_start, !continuing);
   lz77_qspec_candidates(P_, B_, Q_, S_, nullptr, nullptr);
@@ -1895,7 +1905,8 @@ void Lz77Stage::RunQuickSpec() {
   const bool selftest = getenv("BROTLI_MI355X_SELFTEST") != nullptr;
   // the candidates follow the flags in proportion to the changes when a launch was short and changed few filings (lz77_qspec_diff /
   // _repair), else by the pass over everything
-  bool settled = false;
+  bool settled = false, restart_coarse = false, coarse_candidate = false;
+  std::vector<uint32_t> dirty_history;  // segments listed in round 1, 2, ...
   bool diffed = false;  // the last launch was followed by lz77_qspec_diff: chg_count[0] holds the number of listed events
   uint32_t incremental_rounds = 0;
   for (uint32_t round = 1; round <= kMaxRounds; ++round) {
@@ -1933,11 +1944,45 @@ void Lz77Stage::RunQuickSpec() {
     }
     if (debug) {
       double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-      fprintf(stderr, "quick round %u: %u of %u segments to parse again (%u for their entry), %.2f ms into the parse%s\n", round, count, nseg, by_entry, ms,
-              repaired ? " [repaired]" : " [all]");
+      uint32_t by_cache = 0, by_rest = 0, first = nseg;
+      for (uint32_t k = 0; k < nseg; ++k)
+        if (dirty_entry_[k]) {
+          by_cache += (entry_reason_[k] & 2) ? 1u : 0u;
+          by_rest += (entry_reason_[k] & 1) ? 1u : 0u;
+          if (first == nseg) first = k;
+        }
+      if (getenv("BROTLI_MI355X_DEBUG_FIRST") && first < nseg) {
+        for (uint32_t k = first > 0 ? first - 1 : 0; k < std::min(nseg, first + 3); ++k) {
+          const SegEntry& u = entries_[k];
+          const SegEntry& w = next_entries_[k];
+          const SegExit& x = exits_[k];
+          fprintf(stderr, "  seg %u [%u,%u) dirty %d reason %d: used pos %u apply %u cache %d %d %d %d head %u | new pos %u apply %u cache %d %d %d %d head %u | exit pos %u cmds %u pushes %u cache %d %d %d %d ins %u searches %u\n",
+                  k, segments_[k].start, segments_[k].end, (int)dirty_entry_[k], (int)entry_reason_[k], u.pos, u.apply, u.cache[0], u.cache[1], u.cache[2], u.cache[3], u.head_kind,
+                  w.pos, w.apply, w.cache[0], w.cache[1], w.cache[2], w.cache[3], w.head_kind, x.pos, x.n_cmds, x.n_pushes, x.cache[0], x.cache[1], x.cache[2], x.cache[3], x.insert_len, x.n_searches);
+        }
+      }
+      fprintf(stderr, "quick round %u: %u of %u segments to parse again (%u for their entry: %u distance cache, %u position / spree / dictionary, first %u; %u predicted runs), %.2f ms into the parse%s\n",
+              round, count, nseg, by_entry, by_cache, by_rest, first, predicted_runs_, ms, repaired ? " [repaired]" : " [all]");
     }
     if (count == 0) {
       settled = true;
+      break;
+    }
+    // Most chains were entered in another state than the warm-up guessed: the input does not fall into step inside its blocks
+    // (literal sprees file every second or fourth position, and from WHICH one on is a matter of where the spree was entered: in
+    // incompressible stretches the phase of the chain in front never washes out before the block ends, and every change of it
+    // changes the filings, hence the candidates, of everything behind).  It is re-cut into one chain per input block -- nothing is
+    // guessed inside a block then -- and the iteration starts over on the same index (RunRounds does the same for qualities 5-9).
+    // No progress to speak of over eight rounds (the cascade of changed candidates does not die out: structured binary data at four
+    // slots per key can need more rounds than it has segments' worth of positions): the serial walk takes over now rather than after
+    // all kMaxRounds launches.
+    dirty_history.push_back(count);
+    if (round >= 16 && count > std::max<uint32_t>(8u, nseg / 64u) && (uint64_t)count * 10 > (uint64_t)dirty_history[round - 9] * 8) break;
+    // (decided behind the second launch: Silesia-like pieces enter 60 % of their chains in another state than guessed and are down
+    // to 1-2 % of the segments one launch later; the inputs meant here still have 90 % of them to parse again)
+    if (round == 1) coarse_candidate = !qspec_coarse_ && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)by_entry * 3 > nseg && getenv("BROTLI_MI355X_QUICK_NO_COARSE") == nullptr;
+    if (round == 2 && coarse_candidate && (uint64_t)count * 10 > (uint64_t)dirty_history[0] * 6) {
+      restart_coarse = true;
       break;
     }
     stats_.rounds++;
@@ -1974,9 +2019,21 @@ void Lz77Stage::RunQuickSpec() {
   dev_free(list_dev);
   dev_free(up_entries_dev);
   dev_free(got_exits_dev);
+  if (restart_coarse) {
+    saved_block_guess_.clear();
+    for (uint32_t k = 0; k < nseg; ++k)
+      if (segments_[k].flags & kSegFirstInBlock) saved_block_guess_[segments_[k].blk_start] = next_entries_[k];
+    if (debug) fprintf(stderr, "quick: the parse does not fall into step inside the blocks, one chain per block from here\n");
+    coarse_blocks_.assign(block_segment_bytes_.size(), 1);
+    Resegment(segment_bytes_);
+    qspec_coarse_ = true;
+    stats_.coarse_restarts++;
+    RunQuickSpec();
+    return;
+  }
   if (!settled) {
     // the serial path from the start: one segment per block on the reference's own table
-    if (debug) fprintf(stderr, "quick: not settled after %u rounds, the serial path takes over\n", kMaxRounds);
+    if (debug) fprintf(stderr, "quick: not settled after %u rounds, the serial path takes over\n", (unsigned)dirty_history.size());
     use_qspec_ = false;
     P_.use_dictionary = 0;
     Resegment(block_bytes_);

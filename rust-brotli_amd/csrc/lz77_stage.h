@@ -221,6 +221,7 @@ class Lz77Stage {
   EncoderParams qspec_params_{};  // (what Setup was called with, for the fall-back to the serial path)
   uint8_t* qspec_text_ = nullptr;
   uint32_t qspec_prefix_ = 0, qspec_input_ = 0, qspec_raw_head_ = 0;
+  bool qspec_coarse_ = false;    // the input was re-cut into one chain per block (it did not fall into step inside blocks)
   bool qspec_books_in_ = false;  // a later piece: the books of the throttle as the carried table holds them (qspec_lookups_ / _matches_)
   uint32_t qspec_lookups_ = 0, qspec_matches_ = 0;
   bool live_verify_ = false;

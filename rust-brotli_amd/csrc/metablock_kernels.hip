@@ -44,9 +44,9 @@ void mb_command_scans(const MbBuffers& B, void* scan_scratch) {
   const MbBuffers b = B;
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_counts(b, c); });
   // element [K] = 0 so that the exclusive scan leaves the totals there
-  HIP_CHECK(hipMemsetAsync(b.cmd_lit_start + b.n_cmds, 0, 4, BR_STREAM));
-  HIP_CHECK(hipMemsetAsync(b.cmd_pos + b.n_cmds, 0, 4, BR_STREAM));
-  HIP_CHECK(hipMemsetAsync(b.cmd_dist_index + b.n_cmds, 0, 4, BR_STREAM));
+  dev_memset(b.cmd_lit_start + b.n_cmds, 0, 4);
+  dev_memset(b.cmd_pos + b.n_cmds, 0, 4);
+  dev_memset(b.cmd_dist_index + b.n_cmds, 0, 4);
   exclusive_scan_u32(b.cmd_lit_start, b.n_cmds + 1, (uint32_t*)scan_scratch);
   exclusive_scan_u32(b.cmd_pos, b.n_cmds + 1, (uint32_t*)scan_scratch);
   exclusive_scan_u32(b.cmd_dist_index, b.n_cmds + 1, (uint32_t*)scan_scratch);
@@ -115,7 +115,7 @@ void mb_granule_histograms(const MbBuffers& B) {
   if (b.n_granules[kSplitLiteral]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitLiteral]), dim3(256), 0, BR_STREAM, b, (uint32_t)kSplitLiteral);
   if (b.n_granules[kSplitCommand]) hipLaunchKernelGGL(k_granule_histograms, dim3(b.n_granules[kSplitCommand]), dim3(256), 0, BR_STREAM, b, (uint32_t)kSplitCommand);
   if (b.n_granules[kSplitDistance]) {
-    HIP_CHECK(hipMemsetAsync(b.gran_hist[kSplitDistance], 0, (size_t)b.n_granules[kSplitDistance] * kNumDistanceHistoSymbols * 2, BR_STREAM));
+    dev_memset(b.gran_hist[kSplitDistance], 0, (size_t)b.n_granules[kSplitDistance] * kNumDistanceHistoSymbols * 2);
     for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_distance_count(b, c); });
   }
   HIP_CHECK(hipGetLastError());
@@ -267,10 +267,10 @@ void mb_write_headers(const MbBuffers& B) {
 void mb_symbol_bits(const MbBuffers& B, void* scan_scratch) {
   const MbBuffers b = B;
   for_each(b.n_lits, [b] __device__(uint32_t i) { mb_item_literal_nbits(b, i); });
-  HIP_CHECK(hipMemsetAsync(b.lit_nbits + b.n_lits, 0, 4, BR_STREAM));
+  dev_memset(b.lit_nbits + b.n_lits, 0, 4);
   exclusive_scan_u32(b.lit_nbits, b.n_lits + 1, (uint32_t*)scan_scratch);
   for_each(b.n_cmds, [b] __device__(uint32_t c) { mb_item_command_nbits(b, c); });
-  HIP_CHECK(hipMemsetAsync(b.cmd_nbits + b.n_cmds, 0, 4, BR_STREAM));
+  dev_memset(b.cmd_nbits + b.n_cmds, 0, 4);
   exclusive_scan_u32(b.cmd_nbits, b.n_cmds + 1, (uint32_t*)scan_scratch);
   HIP_CHECK(hipGetLastError());
 }

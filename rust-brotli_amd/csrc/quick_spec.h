@@ -179,14 +179,18 @@ BR_DEV bool qs_item_repair(const QuickJob& J, const QuickSpec& S, uint32_t n) {
 // incremental update, listed event n and slot `t` of the 2 sweep - 1 around its own: the positions in (lo, hi] whose own-offset event
 // lies in t and that look into the event's slot get that candidate derived again; `changed(p, was, now)` for those that differ
 template <typename Changed>
-BR_DEV void qs_item_recand(const QuickJob& J, const QuickSpec& S, uint32_t n, uint32_t t, Changed changed) {
+BR_DEV bool qs_item_recand(const QuickJob& J, const QuickSpec& S, uint32_t n, uint32_t t, Changed changed) {
   const uint32_t slot = S.chg_range[3u * n], p_lo = S.chg_range[3u * n + 1u], p_hi = S.chg_range[3u * n + 2u];
   const uint32_t hi = S.slot_first[t + 1];
   uint32_t i = p_lo == 0xffffffffu ? hi : qs_rank_in_slot(J, S.ev_id, S.slot_first[t], hi, p_lo + 1u);
+  uint32_t steps = 0;
   for (; i < hi; ++i) {
     const uint32_t id = S.ev_id[i];
     const uint32_t p = qs_event_position(J, id);
     if (p > p_hi) break;
+    // (a stretch without a filing in one slot can face millions of positions of a neighbouring one -- runs of one byte, whose
+    // positions an extended copy leaves unfiled: the pass over everything is the cheaper one then)
+    if (++steps > kQsWalkCap) return false;
     if (J.sweep != 1 && (id & 1u)) continue;
     const uint32_t key = t - ((p >> 3) & (J.sweep - 1u));
     const uint32_t j = slot - key;  // (wraps when the key lies behind the slot)
@@ -198,6 +202,7 @@ BR_DEV void qs_item_recand(const QuickJob& J, const QuickSpec& S, uint32_t n, ui
     S.cand[item] = c;
     changed(p, was, c);
   }
+  return true;
 }
 
 // A candidate of position p changed.  The chains that looked at it: the chain of p's segment if p carries the searched flag, and for

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void k_qs_diff(QuickJob J, Lz77Params P, QuickS
   }
 }
 void lz77_qspec_diff(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count) {
-  HIP_CHECK(hipMemsetAsync(S.chg_count, 0, 64, BR_STREAM));
+  dev_memset(S.chg_count, 0, 64);
   if (count == 0) return;
   hipLaunchKernelGGL(k_qs_diff, dim3(count), dim3(64), 0, BR_STREAM, J, P, S, (const Segment*)B.segments, list_dev, count);
   HIP_CHECK(hipGetLastError());
@@ -211,9 +211,10 @@ __global__ __launch_bounds__(256) void k_qs_recand(QuickJob J, Lz77Params P, Qui
   if (slot + d < J.sweep - 1u) return;
   const uint32_t t = slot + d - (J.sweep - 1u);
   if (t >= S.slots) return;
-  qs_item_recand(J, S, n, t, [&](uint32_t p, uint32_t was, uint32_t now) {
-    if (qs_change_matters(J, P, text, p, was, now)) qs_note_changed(S, p, geo, dirty);
-  });
+  if (!qs_item_recand(J, S, n, t, [&](uint32_t p, uint32_t was, uint32_t now) {
+        if (qs_change_matters(J, P, text, p, was, now)) qs_note_changed(S, p, geo, dirty);
+      }))
+    S.chg_count[1] = 1u;
 }
 void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t changed, const SegGeometry& geo, uint8_t* dirty_dev) {
   if (changed == 0) return;

@@ -931,9 +931,10 @@ void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob
       if (slot + d < J.sweep - 1u) continue;
       const uint32_t t = slot + d - (J.sweep - 1u);
       if (t >= S.slots) continue;
-      qs_item_recand(J, S, n, t, [&](uint32_t p, uint32_t was, uint32_t now) {
-        if (qs_change_matters(J, P, B.text, p, was, now)) qs_note_changed(S, p, geo, dirty);
-      });
+      if (!qs_item_recand(J, S, n, t, [&](uint32_t p, uint32_t was, uint32_t now) {
+            if (qs_change_matters(J, P, B.text, p, was, now)) qs_note_changed(S, p, geo, dirty);
+          }))
+        S.chg_count[1] = 1;
     }
 }
 void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list, uint32_t count) {
