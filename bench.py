@@ -531,23 +531,35 @@ def small_input_workloads(lib):
                     "roofline": stream_roofline("k_parse_segments", len(data), len(got), sec,
                                                 "launch chain and host round trips: the call is a fixed number of small launches, not bytes")})
         bad = []
+        # sixteen threads of a server that is up: every thread has made two calls before the clock starts (a thread's first call sets
+        # up its stream and its device memory pool: 64 calls from sixteen NEW threads measure sixteen set-ups, round 5: 50 MB/s)
+        ready, go = threading.Barrier(17), threading.Barrier(17)
+        done = threading.Barrier(17)
 
         def work():
+            for _ in range(2):
+                lib.compress(data, QUALITY, LGWIN)
+            ready.wait()
+            go.wait()
             for _ in range(4):
                 if lib.compress(data, QUALITY, LGWIN) != want:
                     bad.append(1)
+            done.wait()
         threads = [threading.Thread(target=work) for _ in range(16)]
-        t0 = time.time()
         for t in threads:
             t.start()
+        ready.wait()
+        t0 = time.time()
+        go.wait()
+        done.wait()
+        sec = time.time() - t0
         for t in threads:
             t.join()
-        sec = time.time() - t0
         res.append({"workload": "c1_alice29_q5_64_calls_16_threads", "input_bytes": 64 * len(data), "quality": QUALITY, "lgwin": LGWIN,
-                    "residency": "host buffers in and out, 16 host threads x 4 calls, each thread on its own stream", "value": round(64 * len(data) / sec / 1e6, 2),
+                    "residency": "host buffers in and out, 16 host threads x 4 calls (after two untimed calls per thread), each thread on its own stream", "value": round(64 * len(data) / sec / 1e6, 2),
                     "unit": "MB/s", "ms_per_step": round(sec * 1e3, 2), "identical_to_cpu_oracle": not bad, "cpu_oracle": col,
                     "vs_cpu_oracle": round(64 * len(data) / sec / 1e6 / col["value"], 3),
-                    "note": "the calls do not overlap to speak of: a small call is bound by the host side of the HIP runtime (launches and copies), which the threads share"})
+                    "note": "a small call is bound by the host side of the HIP runtime (about 150 launches and copies), which the threads share: four calls are in flight at a time (BROTLI_MI355X_SMALL_CALLS_IN_FLIGHT)"})
     except Exception as e:
         res.append({"workload": "c1_alice29_q5", "error": repr(e)})
     return res

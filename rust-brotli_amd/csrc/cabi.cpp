@@ -308,10 +308,12 @@ class ShardWorkers {
         const size_t want = std::min(per_slot, b.q[s].jobs.size()) - (s == my_slot ? 1 : 0);
         while (threads_of_slot_[s] < want) {
           const int device = slots[s];
-          std::thread([this, s, device] { Loop(s, device); }).detach();
+          const size_t ordinal = threads_of_slot_[s];
+          std::thread([this, s, device, ordinal] { Loop(s, device, ordinal); }).detach();
           ++threads_of_slot_[s];
         }
         b.q[s].helpers_wanted = want;
+        b.q[s].helpers_seated = want;
       }
       batch_ = &b;
       ++generation_;
@@ -335,9 +337,10 @@ class ShardWorkers {
   struct SlotQueue {
     std::vector<size_t> jobs;      // the shards dealt to this slot, in order
     std::atomic<size_t> next{0};
-    size_t helpers_wanted = 0;     // (under mu_)
+    size_t helpers_wanted = 0;     // (under mu_) seats not taken yet
+    size_t helpers_seated = 0;     // seats of this batch: the helpers 0 .. helpers_seated - 1 of the slot take them
     SlotQueue() = default;
-    SlotQueue(const SlotQueue& o) : jobs(o.jobs), next(o.next.load()), helpers_wanted(o.helpers_wanted) {}
+    SlotQueue(const SlotQueue& o) : jobs(o.jobs), next(o.next.load()), helpers_wanted(o.helpers_wanted), helpers_seated(o.helpers_seated) {}
   };
   struct Batch {
     const std::function<void(size_t)>* job = nullptr;
@@ -371,14 +374,20 @@ class ShardWorkers {
       }
     }
   }
-  void Loop(size_t slot, int device) {
+  // A call that needs fewer helpers than the slot has (sixteen light shards one call, eight heavy ones the next) is served by the
+  // SAME helpers every time, the lowest-numbered ones: a helper's device memory pool is its own, and with whichever threads woke
+  // first taking the seats every call of bench.py's 1 GiB / 8 shards found two or three cold pools (40-odd hipMalloc calls, 0.7-1.1 s
+  // of a 1.3 s call, call after call).
+  void Loop(size_t slot, int device, size_t ordinal) {
     uint64_t seen = 0;
     bool bound = false;
     for (;;) {
       Batch* b = nullptr;
       {
         std::unique_lock<std::mutex> lock(mu_);
-        cv_.wait(lock, [&] { return generation_ != seen && batch_ != nullptr && slot < batch_->q.size() && batch_->q[slot].helpers_wanted > 0; });
+        cv_.wait(lock, [&] {
+          return generation_ != seen && batch_ != nullptr && slot < batch_->q.size() && ordinal < batch_->q[slot].helpers_seated && batch_->q[slot].helpers_wanted > 0;
+        });
         b = batch_;
         b->q[slot].helpers_wanted--;
         seen = generation_;  // (a helper that has taken its place in this batch does not take a second one)
@@ -406,6 +415,42 @@ class ShardWorkers {
   std::vector<size_t> threads_of_slot_;
   Batch* batch_ = nullptr;
   uint64_t generation_ = 0;
+};
+
+// A small one-shot call is a chain of about 150 launches and copies whatever its size, and the host side of the runtime queues
+// them one thread at a time: measured on alice29 at quality 5 (tools/thread_trace.py, 40 calls per thread) 63 / 108 / 153 MB/s with
+// 1 / 2 / 4 threads -- and 139 / 112 / 92 / 60 MB/s with 8 / 16 / 32 / 64, the threads queueing behind one another inside the runtime.
+// Calls of up to 1 MiB therefore take one of four seats (BROTLI_MI355X_SMALL_CALLS_IN_FLIGHT, 0 = no gate); larger calls are bound
+// by the device and are not gated.
+class SmallCallGate {
+ public:
+  explicit SmallCallGate(size_t input_size) : held_(input_size <= ((size_t)1 << 20) && Seats() != 0) {
+    if (!held_) return;
+    std::unique_lock<std::mutex> lock(Mu());
+    Cv().wait(lock, [] { return InFlight() < Seats(); });
+    ++InFlight();
+  }
+  ~SmallCallGate() {
+    if (!held_) return;
+    {
+      std::lock_guard<std::mutex> lock(Mu());
+      --InFlight();
+    }
+    Cv().notify_one();
+  }
+  SmallCallGate(const SmallCallGate&) = delete;
+  SmallCallGate& operator=(const SmallCallGate&) = delete;
+
+ private:
+  static size_t Seats() {
+    static const size_t n = getenv("BROTLI_MI355X_SMALL_CALLS_IN_FLIGHT") ? (size_t)atol(getenv("BROTLI_MI355X_SMALL_CALLS_IN_FLIGHT")) : 4;
+    return n;
+  }
+  // (never destroyed: calls may still be in flight on other threads when the process ends)
+  static std::mutex& Mu() { static std::mutex* m = new std::mutex; return *m; }
+  static std::condition_variable& Cv() { static std::condition_variable* c = new std::condition_variable; return *c; }
+  static size_t& InFlight() { static size_t n = 0; return n; }
+  const bool held_;
 };
 
 bool ParamsFromLists(size_t num_params, const BrotliEncoderParameter* keys, const uint32_t* values, EncoderParams* p) {
@@ -876,6 +921,7 @@ static BROTLI_BOOL CompressOneShot(int quality, int lgwin, BrotliEncoderMode mod
     req.input_size = input_size;
     req.input_on_device = input_on_device;
     EncodeStats st;
+    SmallCallGate gate(input_size);
     if (IsFragmentStream(req.params)) {
       // qualities 0 and 1: compress_stream(FINISH) takes the fragment path (encode.rs:2929-2937)
       if (input_on_device) throw std::runtime_error("qualities 0 and 1 take their input from host memory");
