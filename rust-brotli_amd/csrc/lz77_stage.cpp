@@ -1836,6 +1836,33 @@ void Lz77Stage::RunQuickSpec() {
   SegExit* got_exits_dev = (SegExit*)dev_alloc_uninit((size_t)nseg * sizeof(SegExit) + 64);
   PinnedArray<uint8_t> dirty;
   dirty.resize_discard(nseg);
+  // One chain per block (the restart below): every chain on a table of its own, read and filed into as the reference does
+  // (QsTables::own), so that what a chain finds inside its own block is exact in the round it is parsed.  A block is parsed again
+  // when its entry changed or a filing changed anywhere in front of it (lz77_qspec_first_change); the candidates are only kept up
+  // for the tables (the scan they are read from) and for the table handed to the next piece of the stream.
+  const uint32_t own_stride = (quick_slots(Q_) + 63u) & ~63u;
+  // (It is the LAST resort in front of the serial walk: a launch of chains on candidates is cheaper -- no tables to derive, nothing but
+  // the chains that have a reason is parsed again -- and most inputs that are re-cut into blocks settle on them; the blocks switch to
+  // tables of their own where that iteration stops making progress, from the first block that is not final.)
+  const uint32_t own_window = getenv("BROTLI_MI355X_QUICK_OWN_WINDOW") ? (uint32_t)atoi(getenv("BROTLI_MI355X_QUICK_OWN_WINDOW")) : 128u;
+  const bool can_own = qspec_coarse_ && getenv("BROTLI_MI355X_QUICK_NO_OWN_TABLES") == nullptr;
+  bool own = can_own && getenv("BROTLI_MI355X_QUICK_OWN_TABLES_FIRST") != nullptr;  // (tests: the tables from round 0 on)
+  const uint32_t own_slots = own ? nseg : std::min(nseg, own_window);
+  uint32_t* own_tables = can_own ? (uint32_t*)dev_alloc_uninit((size_t)own_slots * own_stride * 4 + 64) : nullptr;
+  uint32_t own_from = 0, own_upto = nseg;  // (with the tables from round 0 on, that round parses every block)
+  uint32_t* first_change_dev = (uint32_t*)dev_alloc(64);
+  PinnedArray<uint32_t> first_change;
+  first_change.resize_discard(16);
+  first_change[0] = 0xffffffffu;
+  // segment that holds text position q (segments_ are in text order)
+  auto segment_of = [&](uint32_t q) {
+    uint32_t lo = 0, hi = nseg;
+    while (lo + 1 < hi) {
+      const uint32_t mid = (lo + hi) / 2;
+      if (segments_[mid].start <= q) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
   PinnedArray<uint32_t> chg_count;
   chg_count.resize_discard(16);
   chg_count[0] = chg_count[1] = 0;
@@ -1893,7 +1920,12 @@ void Lz77Stage::RunQuickSpec() {
   }
   // ---- round 0: every segment
   dev_h2d(B_.entries, entries_.data(), (size_t)nseg * sizeof(SegEntry));
-  lz77_qspec_parse(P_, B_, Q_, S_, nullptr, nseg);
+  if (own) lz77_qspec_block_tables(P_, B_, Q_, S_, nullptr, nseg, own_tables, own_stride);
+  lz77_qspec_parse(P_, B_, Q_, S_, nullptr, nseg, own ? own_tables : nullptr, own_stride);
+  if (own) {
+    lz77_qspec_first_change(B_, S_, nullptr, nseg, first_change_dev);
+    dev_d2h_async(first_change.data(), first_change_dev, 4);
+  }
   stats_.rounds++;
   stats_.segments_parsed += nseg;
   lap("round 0 parsed");
@@ -1909,12 +1941,14 @@ void Lz77Stage::RunQuickSpec() {
   std::vector<uint32_t> dirty_history;  // segments listed in round 1, 2, ...
   bool diffed = false;  // the last launch was followed by lz77_qspec_diff: chg_count[0] holds the number of listed events
   uint32_t incremental_rounds = 0;
-  for (uint32_t round = 1; round <= kMaxRounds; ++round) {
+  for (uint32_t round = 1; round <= kMaxRounds + (can_own ? nseg + 8u : 0u); ++round) {
     // candidates of the flags as they are now; the chains that searched a position whose candidates changed (device), beside the
     // resolver pass over the exits (host)
     dev_memset(dirty_dev, 0, nseg);
     bool repaired = false;
-    if (diffed && chg_count[0] <= S_.chg_cap) {
+    if (own) {
+      lz77_qspec_candidates(P_, B_, Q_, S_, nullptr, nullptr);
+    } else if (diffed && chg_count[0] <= S_.chg_cap) {
       lz77_qspec_repair(P_, B_, Q_, S_, chg_count[0], geo, dirty_dev);
       dev_d2h_async(chg_count.data(), S_.chg_count, 64);
       repaired = true;
@@ -1933,6 +1967,21 @@ void Lz77Stage::RunQuickSpec() {
       repaired = false;
     }
     if (repaired) incremental_rounds++;
+    if (own) {
+      // Everything in front of block own_from is final: parsed from its true entry on a table that stood for the final filings of all
+      // that lies in front of it.  The launch before this one parsed [own_from, own_upto): final now are the blocks up to the one in
+      // which a filing changed (the blocks behind it looked into tables that stood for the old one), or up to the first block whose
+      // entry the resolver has just found to be another.  From there the next own_window blocks are parsed again -- each launch moves
+      // the frontier by at least one block, and by as many as entered in their true state.  (dirty[] is zero here: nothing was marked
+      // by candidates.)
+      uint32_t from = first_change[0] != 0xffffffffu ? segment_of(first_change[0]) + 1u : own_upto;
+      for (uint32_t k = own_from; k < from && k < nseg; ++k)
+        if (dirty_entry_[k]) from = k;
+      own_from = from < nseg ? from : nseg;
+      own_upto = own_from + own_window < nseg ? own_from + own_window : nseg;
+      for (uint32_t k = 0; k < nseg; ++k) dirty_entry_[k] = 0;
+      for (uint32_t k = own_from; k < own_upto; ++k) dirty[k] = 1;
+    }
     uint32_t count = 0, by_entry = 0;
     for (uint32_t k = 0; k < nseg; ++k) {
       if (!dirty_entry_[k] && !dirty[k]) continue;
@@ -1977,7 +2026,22 @@ void Lz77Stage::RunQuickSpec() {
     // slots per key can need more rounds than it has segments' worth of positions): the serial walk takes over now rather than after
     // all kMaxRounds launches.
     dirty_history.push_back(count);
-    if (round >= 16 && count > std::max<uint32_t>(8u, nseg / 64u) && (uint64_t)count * 10 > (uint64_t)dirty_history[round - 9] * 8) break;
+    if (!own && (round >= kMaxRounds || (round >= 16 && count > std::max<uint32_t>(8u, nseg / 64u) && (uint64_t)count * 10 > (uint64_t)dirty_history[round - 9] * 8))) {
+      if (!qspec_coarse_ && segment_bytes_ < block_bytes_ && nseg >= 64 && getenv("BROTLI_MI355X_QUICK_NO_COARSE") == nullptr) {
+        restart_coarse = true;
+        break;
+      }
+      if (!can_own) break;
+      // the blocks in front of the first one with a reason to be parsed again are final; from there on tables of their own
+      uint32_t first = 0;
+      while (first < nseg && !dirty_entry_[first] && !dirty[first]) ++first;
+      if (debug) fprintf(stderr, "quick: no progress to speak of, the blocks from %u on go on tables of their own\n", first);
+      own = true;
+      own_from = own_upto = first;
+      first_change[0] = 0xffffffffu;
+      stats_.coarse_restarts++;
+      continue;
+    }
     // (decided behind the second launch: Silesia-like pieces enter 60 % of their chains in another state than guessed and are down
     // to 1-2 % of the segments one launch later; the inputs meant here still have 90 % of them to parse again)
     if (round == 1) coarse_candidate = !qspec_coarse_ && segment_bytes_ < block_bytes_ && nseg >= 64 && (uint64_t)by_entry * 3 > nseg && getenv("BROTLI_MI355X_QUICK_NO_COARSE") == nullptr;
@@ -1990,9 +2054,14 @@ void Lz77Stage::RunQuickSpec() {
     dev_h2d(list_dev, R.up_index.data(), (size_t)count * 4);
     dev_h2d(up_entries_dev, R.up_entries.data(), (size_t)count * sizeof(SegEntry));
     lz77_scatter_entries(B_, list_dev, up_entries_dev, count);
-    lz77_qspec_parse(P_, B_, Q_, S_, list_dev, count);
+    if (own) lz77_qspec_block_tables(P_, B_, Q_, S_, list_dev, count, own_tables, own_stride);
+    lz77_qspec_parse(P_, B_, Q_, S_, list_dev, count, own ? own_tables : nullptr, own_stride);
     lz77_qspec_gather_exits(B_, list_dev, count, got_exits_dev);
-    diffed = !never_incremental;
+    if (own) {
+      lz77_qspec_first_change(B_, S_, list_dev, count, first_change_dev);
+      dev_d2h_async(first_change.data(), first_change_dev, 4);
+    }
+    diffed = !never_incremental && !own;
     if (diffed) {
       lz77_qspec_diff(P_, B_, Q_, S_, list_dev, count);
       dev_d2h_async(chg_count.data(), S_.chg_count, 64);
@@ -2016,6 +2085,8 @@ void Lz77Stage::RunQuickSpec() {
   }
   dev_free(geo_tables);
   dev_free(dirty_dev);
+  dev_free(own_tables);
+  dev_free(first_change_dev);
   dev_free(list_dev);
   dev_free(up_entries_dev);
   dev_free(got_exits_dev);

@@ -102,7 +102,17 @@ void lz77_qspec_diff(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& 
 void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, uint32_t changed, const SegGeometry& geo, uint8_t* dirty_dev);
 static constexpr uint32_t kQsWalkCap = 1u << 14;
 // the listed segments (list_dev == nullptr: all of them), each from B.entries[k]: flags, commands, B.exits[k]
-void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count);
+// own_tables != nullptr: chain i of the launch reads and files into the table own_tables + i * own_stride instead of looking at the
+// candidates (QsTables::own, quick_spec.h; one chain per block)
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count,
+                      uint32_t* own_tables = nullptr, uint32_t own_stride = 0);
+// tables[i * stride + slot], i < count: what the slot holds where segment list[i] (list_dev == nullptr: segment i) starts, under the
+// flags the candidates stand for (lz77_qspec_table with upto = the segment's start, for many segments at once)
+void lz77_qspec_block_tables(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count,
+                             uint32_t* tables, uint32_t stride);
+// *out_dev = the lowest position of the listed segments whose FILING differs between S.flags and S.flags_prev (the flags the
+// candidates and the block tables stand for), 0xffffffff if there is none
+void lz77_qspec_first_change(const Lz77Buffers& B, const QuickSpec& S, const uint32_t* list_dev, uint32_t count, uint32_t* out_dev);
 // the same chains over `count` segments and entries of the caller's (device arrays), exits to exits_dev: the dry runs of the warm-up
 // (Segment::flags with kSegWarmup: nothing but the exit is written)
 void lz77_qspec_parse_custom(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const Segment* segments_dev, const SegEntry* entries_dev,

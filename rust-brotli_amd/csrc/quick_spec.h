@@ -266,7 +266,19 @@ struct QsTables {
   const uint32_t* cand;  // [n * sweep]
   uint8_t* flags;
   QuickTables dict;
+  // One chain per block on a table of its own (lz77_qspec_block_tables: what the slots hold at the block's start under the flags of
+  // everything in front of it): the chain reads the slots and files into them as the reference does, so that what it finds inside its
+  // own block is exact in the round it is parsed -- the candidates of a position stand for the flags of the round BEFORE, the chain's
+  // own block included, and a chain of 16 KiB on them settled a few hundred bytes per launch.  Null: the candidates.
+  uint32_t* own = nullptr;
+  uint32_t own_stride = 0;  // words from one chain's table to the next (the launch sets `own` to the chain's table)
 };
+// the slot `slot` of a chain's own table / the filing of position ix into it (Store, mod.rs:322-327)
+BR_DEV uint32_t qs_own_get(const QsTables& T, uint32_t slot) { return BR_LIVE_LD32(T.own + slot); }
+BR_DEV void qs_own_store(const QuickJob& J, const QsTables& T, uint32_t ix) {
+  const uint32_t slot = q_key(J, T.text + ix) + ((ix >> 3) & (J.sweep - 1u));
+  if (BR_LANE == 0) BR_LIVE_ST32(T.own + slot, ix);
+}
 
 struct QsFlagWriter {
   uint8_t* flags;
@@ -368,8 +380,17 @@ BR_DEV bool qs_search_dictionary(const Lz77Params& P, const QuickTables& T, Dict
 BR_DEV bool qs_find_longest_match_lanes(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
                                         uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out);
 #endif
+BR_DEV bool qs_find_longest_match_slots(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
+                                        uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out);
 BR_DEV bool qs_find_longest_match(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
                                   uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out) {
+  const bool found = qs_find_longest_match_slots(J, P, T, ds, no_dict, dc0, cur, max_length, max_backward, blk_end, out);
+  // (a search files its own position, whatever it found: mod.rs:389, 400, 471 -- behind the look at the slots, one of which is its own)
+  if (T.own) qs_own_store(J, T, cur);
+  return found;
+}
+BR_DEV bool qs_find_longest_match_slots(const QuickJob& J, const Lz77Params& P, const QsTables& T, DictState& ds, bool no_dict, int32_t dc0, uint32_t cur,
+                                        uint32_t max_length, uint32_t max_backward, uint32_t blk_end, QuickResult& out) {
 #if !BR_SCALAR && !defined(BR_QS_NO_LANES)
   if (J.sweep != 1) return qs_find_longest_match_lanes(J, P, T, ds, no_dict, dc0, cur, max_length, max_backward, blk_end, out);
 #endif
@@ -397,8 +418,9 @@ BR_DEV bool qs_find_longest_match(const QuickJob& J, const Lz77Params& P, const 
     }
   }
   const uint32_t* cand = T.cand + (size_t)cur * J.sweep;
+  const uint32_t own_key = T.own ? q_key(J, text + cur) : 0u;
   if (J.sweep == 1) {
-    const uint32_t prev = BR_UNIFORM(cand[0]);
+    const uint32_t prev = BR_UNIFORM(T.own ? qs_own_get(T, own_key) : cand[0]);
     const uint32_t backward = cur - prev;
     if (backward == 0 || backward > max_backward) return false;
     if (compare_char != text[prev + best_len_in]) return false;
@@ -412,7 +434,7 @@ BR_DEV bool qs_find_longest_match(const QuickJob& J, const Lz77Params& P, const 
     }
   } else {
     for (uint32_t j = 0; j < J.sweep; ++j) {
-      const uint32_t prev = BR_UNIFORM(cand[j]);
+      const uint32_t prev = BR_UNIFORM(T.own ? qs_own_get(T, own_key + j) : cand[j]);
       const uint32_t backward = cur - prev;
       if (backward == 0 || backward > max_backward) continue;
       if (compare_char != text[prev + best_len]) continue;
@@ -456,7 +478,7 @@ BR_DEV bool qs_find_longest_match_lanes(const QuickJob& J, const Lz77Params& P, 
       valid = true;
     }
   } else if (lane <= J.sweep) {
-    prev = T.cand[(size_t)cur * J.sweep + (lane - 1u)];
+    prev = T.own ? qs_own_get(T, q_key(J, text + cur) + (lane - 1u)) : T.cand[(size_t)cur * J.sweep + (lane - 1u)];
     const uint32_t backward = cur - prev;
     valid = backward != 0 && backward <= max_backward;
   }
@@ -528,6 +550,8 @@ BR_DEV void br_quick_segment(const QuickJob& J, const Lz77Params& P, const QsTab
   // (once the throttle has tripped under exact counters it stays tripped: no lookups, no virtual books -- "ran blind", mode 4)
   const bool no_dict = J.use_dictionary && BR_UNIFORM(entry.dict_exact) && ds.matches < (ds.lookups >> 7);
   const bool dry = (seg_flags & kSegWarmup) != 0;  // a dry run over the tail of a segment: only the exit matters, nothing is written
+  QuickJob Jo = J;  // (the chain's own table as the table of q_store_range)
+  Jo.table = T.own;
   QsFlagWriter fw;
   fw.flags = T.flags;
   fw.lo = dry ? 0u : seg_start;
@@ -618,6 +642,7 @@ BR_DEV void br_quick_segment(const QuickJob& J, const Lz77Params& P, const QsTab
       fw.one(position, (uint8_t)(kQsStored | kQsSearched));
       if (sr.len > 1) fw.one(position + 1, next_probed ? (uint8_t)(kQsStored | kQsSearched) : fw.unstored(position + 1));
       if (sr.len > 2) fw.copy_range(position + 2u, position + sr.len, store_end);
+      if (T.own) q_store_range(Jo, P, text, position + 2u, position + sr.len < store_end ? position + sr.len : store_end);
       position += sr.len;
     } else {
       fw.one(position, (uint8_t)(kQsStored | kQsSearched));
@@ -635,12 +660,16 @@ BR_DEV void br_quick_segment(const QuickJob& J, const Lz77Params& P, const QsTab
           tail_kind = kHeadVec4;
           tail_base = position;
           for (uint32_t q = position + BR_LANE; q < position + 16u; q += BR_NLANES) fw.put(q, ((q - position) & 3u) == 0 ? kQsStored : (uint8_t)0);
+          if (T.own)
+            for (uint32_t i = 0; i < 4; ++i) qs_own_store(J, T, position + i * 4u);
           insert_length += 16u;
           position += 16u;
         } else {
           tail_kind = kHeadEven4;
           tail_base = position;
           for (uint32_t q = position + BR_LANE; q < position + 8u; q += BR_NLANES) fw.put(q, ((q - position) & 1u) == 0 ? kQsStored : (uint8_t)0);
+          if (T.own)
+            for (uint32_t i = 0; i < 4; ++i) qs_own_store(J, T, position + i * 2u);
           insert_length += 8u;
           position += 8u;
         }

@@ -229,14 +229,18 @@ __global__ __launch_bounds__(64) void k_qs_parse(QuickJob J, Lz77Params P, QsTab
   if (blockIdx.x >= count) return;
   const uint32_t k = list ? list[blockIdx.x] : blockIdx.x;
   const Segment seg = segments[k];
+  if (T.own) T.own += (size_t)blockIdx.x * T.own_stride;
   br_quick_segment(J, P, T, seg, entries[k], cmds + seg.cmd_base, exits + k);
 }
-void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count) {
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count,
+                      uint32_t* own_tables, uint32_t own_stride) {
   if (count == 0) return;
   QsTables T;
   T.text = B.text;
   T.cand = S.cand;
   T.flags = S.flags;
+  T.own = own_tables;
+  T.own_stride = own_stride;
   T.dict = qspec_dict_tables();
   hipLaunchKernelGGL(k_qs_parse, dim3(count), dim3(64), 0, BR_STREAM, J, P, T, (const Segment*)B.segments, (const SegEntry*)B.entries, B.cmds, B.exits, list_dev, count);
   HIP_CHECK(hipGetLastError());
@@ -265,6 +269,42 @@ void lz77_qspec_gather_exits(const Lz77Buffers& B, const uint32_t* list_dev, uin
   if (count == 0) return;
   static_assert(sizeof(SegExit) % 4 == 0, "SegExit is made of 32-bit words");
   hipLaunchKernelGGL(k_qs_gather_exits, dim3(qs_blocks((uint64_t)count * (sizeof(SegExit) / 4))), dim3(256), 0, BR_STREAM, (const SegExit*)B.exits, list_dev, count, out_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- one chain per block on a table of its own: the tables, and where the filings of a launch begin to differ ---------------------------
+__global__ __launch_bounds__(256) void k_qs_block_tables(QuickJob J, QuickSpec S, const Segment* __restrict__ segments, const uint32_t* __restrict__ list, uint32_t first,
+                                                        uint32_t* __restrict__ tables, uint32_t stride) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= S.slots) return;
+  const uint32_t i = first + blockIdx.y;
+  const uint32_t upto = segments[list ? list[i] : i].start;
+  const uint32_t lo = S.slot_first[s], hi = S.slot_first[s + 1];
+  tables[(size_t)i * stride + s] = qs_candidate(J, S, s, qs_rank_in_slot_guess(J, S.ev_id, lo, hi, upto, S.n));
+}
+void lz77_qspec_block_tables(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list_dev, uint32_t count,
+                             uint32_t* tables, uint32_t stride) {
+  for (uint32_t first = 0; first < count; first += 32768u) {  // (grid.y is limited to 65 535)
+    const uint32_t n = count - first < 32768u ? count - first : 32768u;
+    hipLaunchKernelGGL(k_qs_block_tables, dim3(qs_blocks(S.slots), n), dim3(256), 0, BR_STREAM, J, S, (const Segment*)B.segments, list_dev, first, tables, stride);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void k_qs_first_change(QuickSpec S, const Segment* __restrict__ segments, const uint32_t* __restrict__ list, uint32_t count,
+                                                        uint32_t* __restrict__ out) {
+  if (blockIdx.x >= count) return;
+  const Segment seg = segments[list ? list[blockIdx.x] : blockIdx.x];
+  const uint8_t filing_bits = (uint8_t)(kQsStored | kQsQuad | 0x18u);
+  for (uint32_t q = seg.start + threadIdx.x; q < seg.end; q += 256u)
+    if ((S.flags[q] ^ S.flags_prev[q]) & filing_bits) {
+      atomicMin(out, q);
+      return;
+    }
+}
+void lz77_qspec_first_change(const Lz77Buffers& B, const QuickSpec& S, const uint32_t* list_dev, uint32_t count, uint32_t* out_dev) {
+  dev_memset(out_dev, 0xff, 4);
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_qs_first_change, dim3(count), dim3(256), 0, BR_STREAM, S, (const Segment*)B.segments, list_dev, count, out_dev);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -937,20 +937,41 @@ void lz77_qspec_repair(const Lz77Params& P, const Lz77Buffers& B, const QuickJob
         S.chg_count[1] = 1;
     }
 }
-void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list, uint32_t count) {
+void lz77_qspec_parse(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list, uint32_t count, uint32_t* own_tables,
+                      uint32_t own_stride) {
   const DeviceTables& dt = dev_tables();
   QsTables T;
   T.text = B.text;
   T.cand = S.cand;
   T.flags = S.flags;
+  T.own_stride = own_stride;
   T.dict.dict_hash = dt.dict_hash;
   T.dict.dict_data = dt.dict_data;
   T.dict.dict_offsets_by_length = dt.dict_offsets_by_length;
   for (uint32_t i = 0; i < count; ++i) {
     const uint32_t k = list ? list[i] : i;
     const Segment seg = B.segments[k];
+    T.own = own_tables ? own_tables + (size_t)i * own_stride : nullptr;
     br_quick_segment(J, P, T, seg, B.entries[k], B.cmds + seg.cmd_base, B.exits + k);
   }
+}
+void lz77_qspec_block_tables(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const uint32_t* list, uint32_t count, uint32_t* tables,
+                             uint32_t stride) {
+  for (uint32_t i = 0; i < count; ++i) {
+    const uint32_t upto = B.segments[list ? list[i] : i].start;
+    for (uint32_t s = 0; s < S.slots; ++s)
+      tables[(size_t)i * stride + s] = qs_candidate(J, S, s, qs_rank_in_slot_guess(J, S.ev_id, S.slot_first[s], S.slot_first[s + 1], upto, S.n));
+  }
+}
+void lz77_qspec_first_change(const Lz77Buffers& B, const QuickSpec& S, const uint32_t* list, uint32_t count, uint32_t* out) {
+  const uint8_t filing_bits = (uint8_t)(kQsStored | kQsQuad | 0x18u);
+  uint32_t first = 0xffffffffu;
+  for (uint32_t i = 0; i < count; ++i) {
+    const Segment seg = B.segments[list ? list[i] : i];
+    for (uint32_t q = seg.start; q < seg.end && q < first; ++q)
+      if ((S.flags[q] ^ S.flags_prev[q]) & filing_bits) first = q;
+  }
+  *out = first;
 }
 void lz77_qspec_parse_custom(const Lz77Params& P, const Lz77Buffers& B, const QuickJob& J, const QuickSpec& S, const Segment* segments, const SegEntry* entries,
                              SegExit* exits, uint32_t count) {

@@ -179,6 +179,39 @@ def _paths(kind, small):
                 del os.environ[k]
 
 
+def _block_chains(kind, small):
+    """Round 6: inputs whose chains do not fall into step inside their blocks (most segments still to parse again behind the second
+    launch) are re-cut into one chain per block -- on candidates first, on tables of their own (QsTables::own) where that stops making
+    progress; here also from the first launch on, and with a window of three blocks behind the frontier"""
+    import test_cabi
+    lib = test_cabi._load(kind)
+    n = (1 << 20) if small else (4 << 20)
+    inputs = [("stretches", synth.stretches(n, 9)), ("repeated excerpts", synth.repeated_excerpts(n, 35)), ("mixed", synth.mixed(n, 7))]
+    switches = ({}, {"BROTLI_MI355X_QUICK_OWN_TABLES_FIRST": "1"}, {"BROTLI_MI355X_QUICK_OWN_TABLES_FIRST": "1", "BROTLI_MI355X_QUICK_OWN_WINDOW": "3"})
+    want = {}
+    for env in switches:
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            for name, d in inputs:
+                for q in (2, 3, 4):
+                    if (name, q) not in want:
+                        want[(name, q)] = orc.compress(d, q, 22)
+                    assert lib.compress(d, q, 22) == want[(name, q)], (env, name, q)
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
+def test_one_chain_per_block_emu():
+    _block_chains("emu", small=True)
+
+
+@pytest.mark.gpu
+def test_one_chain_per_block_gpu():
+    _block_chains("gpu", small=False)
+
+
 def test_speculative_path_and_its_fallbacks_emu():
     _paths("emu", small=True)
 
