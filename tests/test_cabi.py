@@ -251,19 +251,19 @@ def test_concurrent_calls_from_threads():
     assert results == expected
 
 
-def _multi_shards_in_flight(lib):
+def _multi_shards_in_flight(lib, repeats=4):
     """BrotliEncoderCompressMulti keeps several shards in flight on helper threads (cabi.cpp, ShardWorkers): the stitched
     stream must be the oracle's compress_multi whatever order the shards finish in -- repeated, because a race between
     the helpers would only show now and then"""
     cases = [(synth.mixed(1000003, seed=5), 5, 22, 8), (synth.markov_text(700001, 3), 6, 20, 5), (synth.mixed(300000, seed=9), 9, 20, 8)]
     for data, q, w, shards in cases:
         want = orc.compress_multi(data, [(Q, q), (W, w)], shards)
-        for _ in range(4):
+        for _ in range(repeats):
             assert bytes(lib.BrotliCompress(data, {Q: q, W: w}, shards)) == want
 
 
 def test_multi_shards_in_flight_emulation():
-    _multi_shards_in_flight(_load("emu"))
+    _multi_shards_in_flight(_load("emu"), repeats=2)  # (the CPU suite is sized to minutes; the GPU run repeats four times)
 
 
 @pytest.mark.gpu

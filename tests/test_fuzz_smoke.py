@@ -50,7 +50,7 @@ def test_api_sweep_quality_2_4_emulation():
     quick_device.h), windows from lgwin 10"""
     import emu
     emu.build()
-    assert " 0 failures" in _run("fuzz_api.py", 150, 21, "emu", FUZZ_QUICK="1")
+    assert " 0 failures" in _run("fuzz_api.py", 100, 21, "emu", FUZZ_QUICK="1")
     assert " 0 failures" in _run("fuzz_api.py", 100, 22, "emu", FUZZ_QUICK="1", FUZZ_TINY="1")
 
 

@@ -185,7 +185,7 @@ def _block_chains(kind, small):
     progress; here also from the first launch on, and with a window of three blocks behind the frontier"""
     import test_cabi
     lib = test_cabi._load(kind)
-    n = (1 << 20) if small else (4 << 20)
+    n = (640 << 10) if small else (4 << 20)
     inputs = [("stretches", synth.stretches(n, 9)), ("repeated excerpts", synth.repeated_excerpts(n, 35)), ("mixed", synth.mixed(n, 7))]
     switches = ({}, {"BROTLI_MI355X_QUICK_OWN_TABLES_FIRST": "1"}, {"BROTLI_MI355X_QUICK_OWN_TABLES_FIRST": "1", "BROTLI_MI355X_QUICK_OWN_WINDOW": "3"})
     want = {}
