@@ -223,6 +223,51 @@ def test_library_exports_every_declared_symbol():
     assert lib.BrotliEncoderMaxCompressedSizeMulti(0, 1) == 25  # src/ffi/multicompress/test.rs:258
 
 
+def _small_calls_gate(lib, threads_n, calls):
+    """round 6: one-shot calls of up to 1 MiB take one of four seats (cabi.cpp, SmallCallGate): twelve threads of small calls at
+    qualities 5 / 2 / 0 beside one thread of larger ones (not gated) all finish, every stream the oracle's"""
+    import threading
+    small = [(synth.alice(), 5), (synth.markov_text(90000, 5), 2), (synth.mixed(70000, 4), 0), (synth.alice()[:3000], 9)]
+    big = synth.markov_text((1 << 20) + 4097, 6)
+    want_small = [orc.compress(d, q, 22) for d, q in small]
+    want_big = orc.compress(big, 5, 22)
+    errors = []
+
+    def work(i):
+        try:
+            for c in range(calls):
+                d, q = small[(i + c) % len(small)]
+                if lib.compress(d, q, 22) != want_small[(i + c) % len(small)]:
+                    errors.append(("small", i, c))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def work_big():
+        try:
+            for _ in range(2):
+                if lib.compress(big, 5, 22) != want_big:
+                    errors.append("big")
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(threads_n)] + [threading.Thread(target=work_big)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a thread is still waiting for a seat"
+    assert not errors, errors
+
+
+def test_small_calls_take_seats_emulation():
+    _small_calls_gate(_load("emu"), threads_n=12, calls=3)
+
+
+@pytest.mark.gpu
+def test_small_calls_take_seats_gpu():
+    _small_calls_gate(_load("gpu"), threads_n=12, calls=12)
+
+
 @pytest.mark.gpu
 def test_concurrent_calls_from_threads():
     """independent BrotliEncoderCompress calls from several host threads (one HIP stream per thread) must not disturb
