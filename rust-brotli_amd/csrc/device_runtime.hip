@@ -216,6 +216,8 @@ void flush_zero() {
 void note_zero(void* p, size_t bytes) {
   if (bytes == 0) return;
   static const bool direct = getenv("BROTLI_MI355X_DIRECT_FILLS") != nullptr;  // (A/B: one runtime fill per request, as before)
+  static const bool log_big = getenv("BROTLI_MI355X_DEBUG_FILLS") != nullptr;  // (which zero fills of a call are megabytes)
+  if (log_big && bytes >= ((size_t)1 << 20)) fprintf(stderr, "zero fill of %.1f MiB\n", bytes / 1048576.0);
   if (bytes > kZeroDeferMax || direct) {
     flush_zero();
     HIP_CHECK(hipMemsetAsync(p, 0, bytes, hipStreamPerThread));
