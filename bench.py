@@ -452,58 +452,64 @@ def quality_0_1_workloads(lib):
 def stream_nohint_workload(bm, lib):
     """the CompressorWriter pattern (src/enc/writer.rs:269-313): BrotliEncoderCompressStream fed 4 KiB writes, NO size hint (size_hint
     = the first write => H5, whose StoreRangeOptBatch files masked ring entries past the 8 MiB ring buffer, mod.rs:1163-1232), quality 5,
-    lgwin 22, 16 MiB of text; the same input through the oracle's writer fed the same way (its rate is the CPU column, its bytes the
-    expected stream)"""
+    lgwin 22, text: 7 MiB (inside the first lap of the ring: the speculative path) and 16 MiB (past it: one live chain); the same input
+    through the oracle's writer fed the same way (its rate is the CPU column, its bytes the expected stream)"""
     import orc
     import synth
     # (16 MiB: past the 8 MiB ring buffer, where the masked entries begin; 64 MiB at the rate of one live chain would not fit the budget)
-    name = "stream_16MiB_q5_nohint"
-    data = synth.markov_text(16 << 20, 5)
-    entry = {"workload": name, "input_bytes": len(data), "quality": QUALITY, "lgwin": LGWIN,
-             "residency": "host buffers, BrotliEncoderCompressStream(PROCESS) in 4 KiB writes, then FINISH"}
-    try:
-        L = lib.lib
-        step = 4096
-        src = ctypes.create_string_buffer(data, len(data))
-        cap = len(data) + (len(data) >> 2) + 4096
-        dst = ctypes.create_string_buffer(cap)
-        t0 = time.time()
-        st = L.BrotliEncoderCreateInstance(None, None, None)
-        L.BrotliEncoderSetParameter(st, int(bm.BROTLI_PARAM_QUALITY), QUALITY)
-        L.BrotliEncoderSetParameter(st, int(bm.BROTLI_PARAM_LGWIN), LGWIN)
-        base_in, base_out = ctypes.addressof(src), ctypes.addressof(dst)
-        avail_out = ctypes.c_size_t(cap)
-        next_out = ctypes.c_void_p(base_out)
-        avail_in = ctypes.c_size_t(0)
-        next_in = ctypes.c_void_p(base_in)
-        total = ctypes.c_size_t(0)
-        call = L.BrotliEncoderCompressStream
-        refs = (ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out), ctypes.byref(next_out), ctypes.byref(total))
-        for i in range(0, len(data), step):
-            avail_in.value = min(step, len(data) - i)
-            next_in.value = base_in + i
-            while True:
-                if not call(st, 0, *refs):
-                    raise RuntimeError("BrotliEncoderCompressStream failed: " + lib.last_error())
-                if avail_in.value == 0:
-                    break
-        avail_in.value = 0
-        while True:
-            if not call(st, 2, *refs):
-                raise RuntimeError("BrotliEncoderCompressStream(FINISH) failed: " + lib.last_error())
-            if L.BrotliEncoderIsFinished(st):
-                break
-        n_out = cap - avail_out.value
-        L.BrotliEncoderDestroyInstance(st)
-        sec = time.time() - t0
-        out = dst.raw[:n_out]
-        want, col = cpu_oracle_timed(lambda: orc.writer_compress(data, QUALITY, LGWIN, chunk=step), len(data),
-                                     "the same input through the oracle's CompressorWriter pattern, 4 KiB writes")
-        entry.update({"value": round(len(data) / sec / 1e6, 2), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out),
-                      "identical_to_cpu_oracle": out == want, "cpu_oracle": col, "vs_cpu_oracle": round(len(data) / sec / 1e6 / col["value"], 3)})
-    except Exception as e:
-        entry["error"] = repr(e)
-    return [entry]
+    res = []
+    for name, mib in (("stream_7MiB_q5_nohint", 7), ("stream_16MiB_q5_nohint", 16)):
+        data = synth.markov_text(mib << 20, 5)
+        entry = {"workload": name, "input_bytes": len(data), "quality": QUALITY, "lgwin": LGWIN,
+                 "residency": "host buffers, BrotliEncoderCompressStream(PROCESS) in 4 KiB writes, then FINISH"}
+        try:
+            L = lib.lib
+            step = 4096
+            src = ctypes.create_string_buffer(data, len(data))
+            cap = len(data) + (len(data) >> 2) + 4096
+            dst = ctypes.create_string_buffer(cap)
+            best = None
+            for _ in range(2 if mib < 8 else 1):
+                t0 = time.time()
+                st = L.BrotliEncoderCreateInstance(None, None, None)
+                L.BrotliEncoderSetParameter(st, int(bm.BROTLI_PARAM_QUALITY), QUALITY)
+                L.BrotliEncoderSetParameter(st, int(bm.BROTLI_PARAM_LGWIN), LGWIN)
+                base_in, base_out = ctypes.addressof(src), ctypes.addressof(dst)
+                avail_out = ctypes.c_size_t(cap)
+                next_out = ctypes.c_void_p(base_out)
+                avail_in = ctypes.c_size_t(0)
+                next_in = ctypes.c_void_p(base_in)
+                total = ctypes.c_size_t(0)
+                call = L.BrotliEncoderCompressStream
+                refs = (ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out), ctypes.byref(next_out), ctypes.byref(total))
+                for i in range(0, len(data), step):
+                    avail_in.value = min(step, len(data) - i)
+                    next_in.value = base_in + i
+                    while True:
+                        if not call(st, 0, *refs):
+                            raise RuntimeError("BrotliEncoderCompressStream failed: " + lib.last_error())
+                        if avail_in.value == 0:
+                            break
+                avail_in.value = 0
+                while True:
+                    if not call(st, 2, *refs):
+                        raise RuntimeError("BrotliEncoderCompressStream(FINISH) failed: " + lib.last_error())
+                    if L.BrotliEncoderIsFinished(st):
+                        break
+                n_out = cap - avail_out.value
+                L.BrotliEncoderDestroyInstance(st)
+                sec = time.time() - t0
+                best = sec if best is None else min(best, sec)
+            sec = best
+            out = dst.raw[:n_out]
+            want, col = cpu_oracle_timed(lambda: orc.writer_compress(data, QUALITY, LGWIN, chunk=step), len(data),
+                                         "the same input through the oracle's CompressorWriter pattern, 4 KiB writes")
+            entry.update({"value": round(len(data) / sec / 1e6, 2), "unit": "MB/s", "ms_per_step": round(sec * 1e3, 1), "compressed_bytes": len(out),
+                          "identical_to_cpu_oracle": out == want, "cpu_oracle": col, "vs_cpu_oracle": round(len(data) / sec / 1e6 / col["value"], 3)})
+        except Exception as e:
+            entry["error"] = repr(e)
+        res.append(entry)
+    return res
 
 
 def small_input_workloads(lib):
