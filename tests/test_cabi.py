@@ -223,6 +223,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.BrotliEncoderMaxCompressedSizeMulti(0, 1) == 25  # src/ffi/multicompress/test.rs:258
 
 
+@pytest.mark.gpu
+def test_direct_fills_switch_gpu():
+    """round 6: small zero fills are noted and written by one launch in front of the next operation on the stream
+    (device_runtime.hip); BROTLI_MI355X_DIRECT_FILLS=1 (read once per process) issues every fill by itself as before -- the same
+    streams either way"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import test_cabi, synth, orc\n"
+            "lib = test_cabi._load('gpu')\n"
+            "for d, q, w in ((synth.alice(), 5, 22), (synth.mixed(400000, 3), 9, 20), (synth.markov_text(300000, 2), 2, 22), (synth.alice()[:70000], 0, 18)):\n"
+            "    assert lib.compress(d, q, w) == orc.compress(d, q, w), (q, w)\n"
+            "print('ok')\n") % os.path.dirname(os.path.abspath(__file__))
+    for env_extra in ({"BROTLI_MI355X_DIRECT_FILLS": "1"}, {}):
+        env = dict(os.environ, **env_extra)
+        p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
 def _small_calls_gate(lib, threads_n, calls):
     """round 6: one-shot calls of up to 1 MiB take one of four seats (cabi.cpp, SmallCallGate): twelve threads of small calls at
     qualities 5 / 2 / 0 beside one thread of larger ones (not gated) all finish, every stream the oracle's"""
